@@ -1,0 +1,71 @@
+// Shared device/host helpers for libdis_hip.so (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dis_hip.h"
+
+#define DIS_WAVE 64
+
+#define DIS_CHECK_LAUNCH()                       \
+  do {                                           \
+    hipError_t e__ = hipGetLastError();          \
+    if (e__ != hipSuccess) return (int)e__;      \
+  } while (0)
+
+static inline int dis_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// grid size for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8, never more than needed
+static inline int dis_ew_grid(long work_items, int block) {
+  long g = (work_items + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Block-wide sum of a double; result valid in thread 0.  `sm` needs blockDim.x/64 doubles.
+__device__ __forceinline__ double block_sum_d(double v, double* sm) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) r += sm[i];
+  return r;
+}
+
+__device__ __forceinline__ void atomic_add_d(double* p, double v) { atomicAdd(p, v); }
+
+#define SELU_ALPHA_F 1.6732632423543772848170429916717f
+#define SELU_SCALE_F 1.0507009873554804934193349852946f
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+  if (act == DIS_ACT_SELU) return x > 0.f ? SELU_SCALE_F * x : (SELU_SCALE_F * SELU_ALPHA_F) * (expf(x) - 1.f);
+  if (act == DIS_ACT_RELU) return x > 0.f ? x : 0.f;
+  return x;
+}
+// derivative of the activation expressed through its OUTPUT y
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+  if (act == DIS_ACT_SELU) return y > 0.f ? SELU_SCALE_F : (y + SELU_SCALE_F * SELU_ALPHA_F);
+  if (act == DIS_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+// The reference normalises pixel coordinates to [-1,1] and grid_sample maps them back
+// (networks.py:363-364 -> ATen grid_sampler, align_corners=True).  Reproduce that round trip so that
+// sampling positions carry the same fp32 rounding as the reference's.
+__device__ __forceinline__ float gs_roundtrip(float p, int size) {
+  float g = 2.f * (p / (float)(size - 1) - 0.5f);
+  return (g + 1.f) * ((float)(size - 1) / 2.f);
+}

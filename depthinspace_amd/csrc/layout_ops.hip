@@ -1,0 +1,609 @@
+// Layout changes, bilinear resize, flow-guided feature warps and the multi-frame geometry tensors.
+// Feature maps are nhwc (one 32-channel pixel = one 128-byte line), so every bilinear tap of a warp or
+// a k-NN gather is one fully used cache line; lanes run over channels first => coalesced 16 B/lane.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// planar <-> nhwc
+// ------------------------------------------------------------------------------------------------
+__global__ void pack4_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                             const float* __restrict__ s2, const float* __restrict__ s3, float4* __restrict__ out,
+                             long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float4 v;
+    v.x = s0 ? s0[i] : 0.f;
+    v.y = s1 ? s1[i] : 0.f;
+    v.z = s2 ? s2[i] : 0.f;
+    v.w = s3 ? s3[i] : 0.f;
+    out[i] = v;
+  }
+}
+extern "C" int dis_pack4_nhwc(const float* s0, const float* s1, const float* s2, const float* s3, float* out, int n,
+                              int h, int w, void* stream) {
+  if (!out) return DIS_ERR_NULL;
+  if (n <= 0 || h <= 0 || w <= 0) return DIS_ERR_BAD_SHAPE;
+  long total = (long)n * h * w;
+  hipLaunchKernelGGL(pack4_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, s0, s1, s2, s3,
+                     (float4*)out, total);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// The two-channel image tensor `ir` of the module API is (N,2,H,W): sources 0/1 are its planes, which are
+// H*W apart inside one sample but N*... apart between samples; a strided variant handles that case.
+__global__ void pack4_strided_kernel(const float* __restrict__ s0, long st0, const float* __restrict__ s1, long st1,
+                                     const float* __restrict__ s2, long st2, const float* __restrict__ s3, long st3,
+                                     float4* __restrict__ out, int n, long hw) {
+  const long total = (long)n * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / hw, p = i - b * hw;
+    float4 v;
+    v.x = s0 ? s0[b * st0 + p] : 0.f;
+    v.y = s1 ? s1[b * st1 + p] : 0.f;
+    v.z = s2 ? s2[b * st2 + p] : 0.f;
+    v.w = s3 ? s3[b * st3 + p] : 0.f;
+    out[i] = v;
+  }
+}
+extern "C" int dis_pack4_nhwc_strided(const float* s0, long st0, const float* s1, long st1, const float* s2,
+                                      long st2, const float* s3, long st3, float* out, int n, int h, int w,
+                                      void* stream) {
+  if (!out) return DIS_ERR_NULL;
+  if (n <= 0 || h <= 0 || w <= 0) return DIS_ERR_BAD_SHAPE;
+  long total = (long)n * h * w;
+  hipLaunchKernelGGL(pack4_strided_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, s0,
+                     st0, s1, st1, s2, st2, s3, st3, (float4*)out, n, (long)h * w);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// tiled transpose of a (rows x cols) matrix per batch item: planar (c x hw) <-> nhwc (hw x c)
+__global__ void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const long base = (long)blockIdx.z * rows * cols;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    int r = r0 + j, c = c0 + tx;
+    if (r < rows && c < cols) tile[j][tx] = x[base + (long)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, r = r0 + tx;
+    if (r < rows && c < cols) y[base + (long)c * rows + r] = tile[tx][j];
+  }
+}
+static int launch_transpose(const float* x, float* y, int batch, int rows, int cols, void* stream) {
+  dim3 grid(dis_cdiv(cols, 32), dis_cdiv(rows, 32), batch);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, rows, cols);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_planar_to_nhwc(const float* x, float* y, int n, int c, int h, int w, void* stream) {
+  if (!x || !y) return DIS_ERR_NULL;
+  if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return DIS_ERR_BAD_SHAPE;
+  return launch_transpose(x, y, n, c, h * w, stream);
+}
+extern "C" int dis_nhwc_to_planar(const float* x, float* y, int n, int c, int h, int w, void* stream) {
+  if (!x || !y) return DIS_ERR_NULL;
+  if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return DIS_ERR_BAD_SHAPE;
+  return launch_transpose(x, y, n, h * w, c, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear resize (ATen upsample_bilinear2d semantics)
+// ------------------------------------------------------------------------------------------------
+struct Lerp {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ float resize_scale(int in, int out, int align_corners) {
+  if (align_corners) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  return (float)in / (float)out;
+}
+__device__ __forceinline__ Lerp resize_src(int dst, float scale, int in, int align_corners) {
+  float src;
+  if (align_corners) {
+    src = scale * (float)dst;
+  } else {
+    src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  Lerp L;
+  L.i0 = min((int)src, in - 1);
+  L.i1 = L.i0 + ((L.i0 < in - 1) ? 1 : 0);
+  L.l1 = src - (float)L.i0;
+  L.l0 = 1.f - L.l1;
+  return L;
+}
+
+// nhwc, channels in groups of VEC floats
+template <int VEC>
+__global__ void resize_nhwc_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int hin, int win,
+                                       int hout, int wout, int c, int ac) {
+  const int cg = c / VEC;
+  const long total = (long)n * hout * wout * cg;
+  const float sy = resize_scale(hin, hout, ac), sx = resize_scale(win, wout, ac);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    long p = i / cg;
+    const int ox = (int)(p % wout);
+    p /= wout;
+    const int oy = (int)(p % hout);
+    const int b = (int)(p / hout);
+    const Lerp Ly = resize_src(oy, sy, hin, ac), Lx = resize_src(ox, sx, win, ac);
+    const float* base = x + (long)b * hin * win * c + g * VEC;
+    const float* p00 = base + ((long)Ly.i0 * win + Lx.i0) * c;
+    const float* p01 = base + ((long)Ly.i0 * win + Lx.i1) * c;
+    const float* p10 = base + ((long)Ly.i1 * win + Lx.i0) * c;
+    const float* p11 = base + ((long)Ly.i1 * win + Lx.i1) * c;
+    float* o = y + (((long)b * hout + oy) * wout + ox) * c + g * VEC;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+      o[k] = Ly.l0 * (Lx.l0 * p00[k] + Lx.l1 * p01[k]) + Ly.l1 * (Lx.l0 * p10[k] + Lx.l1 * p11[k]);
+  }
+}
+
+// destination range whose interpolation can touch source index i
+__device__ __forceinline__ void resize_dst_range(int i, float scale, int in, int out, int ac, int* lo, int* hi) {
+  if (scale <= 0.f) {
+    *lo = 0;
+    *hi = out - 1;
+    return;
+  }
+  float a = ((float)i - 1.f), b = ((float)i + 1.f);
+  float dlo, dhi;
+  if (ac) {
+    dlo = a / scale;
+    dhi = b / scale;
+  } else {
+    dlo = (a + 0.5f) / scale - 0.5f;
+    dhi = (b + 0.5f) / scale - 0.5f;
+  }
+  int l = (int)floorf(dlo) - 1, h2 = (int)ceilf(dhi) + 1;
+  if (!ac && i == 0) l = 0;  // src clamped at 0
+  *lo = max(l, 0);
+  *hi = min(h2, out - 1);
+}
+
+// backward as a gather over the destination pixels that read source pixel (iy,ix): deterministic, no atomics
+template <int VEC>
+__global__ void resize_nhwc_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int n, int hin, int win,
+                                       int hout, int wout, int c, int ac) {
+  const int cg = c / VEC;
+  const long total = (long)n * hin * win * cg;
+  const float sy = resize_scale(hin, hout, ac), sx = resize_scale(win, wout, ac);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    long p = i / cg;
+    const int ix = (int)(p % win);
+    p /= win;
+    const int iy = (int)(p % hin);
+    const int b = (int)(p / hin);
+    int ylo, yhi, xlo, xhi;
+    resize_dst_range(iy, sy, hin, hout, ac, &ylo, &yhi);
+    resize_dst_range(ix, sx, win, wout, ac, &xlo, &xhi);
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const Lerp Ly = resize_src(oy, sy, hin, ac);
+      const float wy = (Ly.i0 == iy ? Ly.l0 : 0.f) + (Ly.i1 == iy ? Ly.l1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const Lerp Lx = resize_src(ox, sx, win, ac);
+        const float wx = (Lx.i0 == ix ? Lx.l0 : 0.f) + (Lx.i1 == ix ? Lx.l1 : 0.f);
+        if (wx == 0.f) continue;
+        const float* gp = gy + (((long)b * hout + oy) * wout + ox) * c + g * VEC;
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += wgt * gp[k];
+      }
+    }
+    float* o = gx + (((long)b * hin + iy) * win + ix) * c + g * VEC;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = acc[k];
+  }
+}
+
+extern "C" int dis_resize_bilinear_nhwc_fwd(const float* x, float* y, int n, int hin, int win, int hout, int wout,
+                                            int c, int align_corners, void* stream) {
+  if (!x || !y) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || c <= 0) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (c % 4 == 0) {
+    long total = (long)n * hout * wout * (c / 4);
+    hipLaunchKernelGGL(resize_nhwc_fwd_kernel<4>, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, x, y, n, hin, win,
+                       hout, wout, c, align_corners);
+  } else {
+    long total = (long)n * hout * wout * c;
+    hipLaunchKernelGGL(resize_nhwc_fwd_kernel<1>, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, x, y, n, hin, win,
+                       hout, wout, c, align_corners);
+  }
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_resize_bilinear_nhwc_bwd(const float* gy, float* gx, int n, int hin, int win, int hout, int wout,
+                                            int c, int align_corners, void* stream) {
+  if (!gy || !gx) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || c <= 0) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (c % 4 == 0) {
+    long total = (long)n * hin * win * (c / 4);
+    hipLaunchKernelGGL(resize_nhwc_bwd_kernel<4>, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, gy, gx, n, hin,
+                       win, hout, wout, c, align_corners);
+  } else {
+    long total = (long)n * hin * win * c;
+    hipLaunchKernelGGL(resize_nhwc_bwd_kernel<1>, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, gy, gx, n, hin,
+                       win, hout, wout, c, align_corners);
+  }
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// planar: nc independent planes; optional per-channel scale (resize_flow_like): plane index % c_for_scale
+// selects scale0 (channel 0) / scale1 (channel 1).
+__global__ void resize_planar_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int nc, int hin,
+                                         int win, int hout, int wout, int ac, float scale0, float scale1,
+                                         int c_for_scale) {
+  const long total = (long)nc * hout * wout;
+  const float sy = resize_scale(hin, hout, ac), sx = resize_scale(win, wout, ac);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % wout);
+    long p = i / wout;
+    const int oy = (int)(p % hout);
+    const int pl = (int)(p / hout);
+    const Lerp Ly = resize_src(oy, sy, hin, ac), Lx = resize_src(ox, sx, win, ac);
+    const float* base = x + (long)pl * hin * win;
+    float v = Ly.l0 * (Lx.l0 * base[(long)Ly.i0 * win + Lx.i0] + Lx.l1 * base[(long)Ly.i0 * win + Lx.i1]) +
+              Ly.l1 * (Lx.l0 * base[(long)Ly.i1 * win + Lx.i0] + Lx.l1 * base[(long)Ly.i1 * win + Lx.i1]);
+    if (c_for_scale > 0) v *= ((pl % c_for_scale) == 0) ? scale0 : scale1;
+    y[i] = v;
+  }
+}
+__global__ void resize_planar_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int nc, int hin,
+                                         int win, int hout, int wout, int ac) {
+  const long total = (long)nc * hin * win;
+  const float sy = resize_scale(hin, hout, ac), sx = resize_scale(win, wout, ac);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % win);
+    long p = i / win;
+    const int iy = (int)(p % hin);
+    const int pl = (int)(p / hin);
+    int ylo, yhi, xlo, xhi;
+    resize_dst_range(iy, sy, hin, hout, ac, &ylo, &yhi);
+    resize_dst_range(ix, sx, win, wout, ac, &xlo, &xhi);
+    float acc = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const Lerp Ly = resize_src(oy, sy, hin, ac);
+      const float wy = (Ly.i0 == iy ? Ly.l0 : 0.f) + (Ly.i1 == iy ? Ly.l1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const Lerp Lx = resize_src(ox, sx, win, ac);
+        const float wx = (Lx.i0 == ix ? Lx.l0 : 0.f) + (Lx.i1 == ix ? Lx.l1 : 0.f);
+        acc += wy * wx * gy[((long)pl * hout + oy) * wout + ox];
+      }
+    }
+    gx[i] = acc;
+  }
+}
+extern "C" int dis_resize_bilinear_planar_fwd(const float* x, float* y, int nc, int hin, int win, int hout, int wout,
+                                              int align_corners, float scale0, float scale1, int c_for_scale,
+                                              void* stream) {
+  if (!x || !y) return DIS_ERR_NULL;
+  if (nc <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
+  long total = (long)nc * hout * wout;
+  hipLaunchKernelGGL(resize_planar_fwd_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     nc, hin, win, hout, wout, align_corners, scale0, scale1, c_for_scale);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_resize_bilinear_planar_bwd(const float* gy, float* gx, int nc, int hin, int win, int hout,
+                                              int wout, int align_corners, void* stream) {
+  if (!gy || !gx) return DIS_ERR_NULL;
+  if (nc <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
+  long total = (long)nc * hin * win;
+  hipLaunchKernelGGL(resize_planar_bwd_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gy,
+                     gx, nc, hin, win, hout, wout, align_corners);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear tap set with zeros padding (shared by the warps)
+// ------------------------------------------------------------------------------------------------
+struct Taps {
+  int x0, y0;
+  float w00, w01, w10, w11;
+  bool v00, v01, v10, v11;
+};
+__device__ __forceinline__ Taps make_taps(float px, float py, int h, int w) {
+  Taps t;
+  float ix = gs_roundtrip(px, w), iy = gs_roundtrip(py, h);
+  ix = fminf(fmaxf(ix, -2.f), (float)w + 2.f);
+  iy = fminf(fmaxf(iy, -2.f), (float)h + 2.f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  t.x0 = (int)fx;
+  t.y0 = (int)fy;
+  const float wx = ix - fx, ex = 1.f - wx, wy = iy - fy, ey = 1.f - wy;
+  t.w00 = ey * ex; t.w01 = ey * wx; t.w10 = wy * ex; t.w11 = wy * wx;
+  const bool xa = t.x0 >= 0 && t.x0 < w, xb = t.x0 + 1 >= 0 && t.x0 + 1 < w;
+  const bool ya = t.y0 >= 0 && t.y0 < h, yb = t.y0 + 1 >= 0 && t.y0 + 1 < h;
+  t.v00 = xa && ya; t.v01 = xb && ya; t.v10 = xa && yb; t.v11 = xb && yb;
+  return t;
+}
+
+// frame index held by slot s of target t: slot 0 = t, then the other frames in increasing order
+__device__ __forceinline__ int slot_frame(int t, int s) { return s == 0 ? t : (s - 1 < t ? s - 1 : s); }
+
+// ------------------------------------------------------------------------------------------------
+// gather_warped_feat (reference multi_frame_networks.py:347-360, warp :83-99), all targets at once
+//   feat (tl,bs,h,w,c)  flows (tl*tl,bs,h,w,2)  ->  out (tl,bs,h,w,tl,c)
+// one thread = 4 channels of one (target, sample, pixel, slot)
+// ------------------------------------------------------------------------------------------------
+__global__ void gather_warped_feat_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ flows,
+                                              float* __restrict__ out, int tl, int bs, int h, int w, int c) {
+  const int cg = c >> 2;
+  const long hw = (long)h * w;
+  const long total = (long)tl * bs * hw * tl * cg;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    long r = i / cg;
+    const int s = (int)(r % tl);
+    r /= tl;
+    const long p = r % hw;
+    r /= hw;
+    const int b = (int)(r % bs);
+    const int t = (int)(r / bs);
+    const int j = slot_frame(t, s);
+    const float* src = feat + ((long)j * bs + b) * hw * c + g * 4;
+    float4 v;
+    if (s == 0) {
+      v = *(const float4*)(src + p * c);
+    } else {
+      const int y = (int)(p / w), x = (int)(p - (long)y * w);
+      const float2 f = *(const float2*)(flows + ((((long)t * tl + j) * bs + b) * hw + p) * 2);
+      const Taps tp = make_taps(f.x + (float)x, f.y + (float)y, h, w);
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 a = tp.v00 ? *(const float4*)(src + ((long)tp.y0 * w + tp.x0) * c) : z;
+      const float4 bq = tp.v01 ? *(const float4*)(src + ((long)tp.y0 * w + tp.x0 + 1) * c) : z;
+      const float4 cq = tp.v10 ? *(const float4*)(src + ((long)(tp.y0 + 1) * w + tp.x0) * c) : z;
+      const float4 d = tp.v11 ? *(const float4*)(src + ((long)(tp.y0 + 1) * w + tp.x0 + 1) * c) : z;
+      v.x = a.x * tp.w00 + bq.x * tp.w01 + cq.x * tp.w10 + d.x * tp.w11;
+      v.y = a.y * tp.w00 + bq.y * tp.w01 + cq.y * tp.w10 + d.y * tp.w11;
+      v.z = a.z * tp.w00 + bq.z * tp.w01 + cq.z * tp.w10 + d.z * tp.w11;
+      v.w = a.w * tp.w00 + bq.w * tp.w01 + cq.w * tp.w10 + d.w * tp.w11;
+    }
+    *(float4*)(out + ((((long)t * bs + b) * hw + p) * tl + s) * c + g * 4) = v;
+  }
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, float4 v, float wgt) {
+  atomicAdd(p + 0, v.x * wgt);
+  atomicAdd(p + 1, v.y * wgt);
+  atomicAdd(p + 2, v.z * wgt);
+  atomicAdd(p + 3, v.w * wgt);
+}
+
+__global__ void gather_warped_feat_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ flows,
+                                              float* __restrict__ gfeat, int tl, int bs, int h, int w, int c) {
+  const int cg = c >> 2;
+  const long hw = (long)h * w;
+  const long total = (long)tl * bs * hw * tl * cg;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    long r = i / cg;
+    const int s = (int)(r % tl);
+    r /= tl;
+    const long p = r % hw;
+    r /= hw;
+    const int b = (int)(r % bs);
+    const int t = (int)(r / bs);
+    const int j = slot_frame(t, s);
+    const float4 gv = *(const float4*)(gout + ((((long)t * bs + b) * hw + p) * tl + s) * c + g * 4);
+    float* dst = gfeat + ((long)j * bs + b) * hw * c + g * 4;
+    if (s == 0) {
+      atomic_add4(dst + p * c, gv, 1.f);
+    } else {
+      const int y = (int)(p / w), x = (int)(p - (long)y * w);
+      const float2 f = *(const float2*)(flows + ((((long)t * tl + j) * bs + b) * hw + p) * 2);
+      const Taps tp = make_taps(f.x + (float)x, f.y + (float)y, h, w);
+      if (tp.v00) atomic_add4(dst + ((long)tp.y0 * w + tp.x0) * c, gv, tp.w00);
+      if (tp.v01) atomic_add4(dst + ((long)tp.y0 * w + tp.x0 + 1) * c, gv, tp.w01);
+      if (tp.v10) atomic_add4(dst + ((long)(tp.y0 + 1) * w + tp.x0) * c, gv, tp.w10);
+      if (tp.v11) atomic_add4(dst + ((long)(tp.y0 + 1) * w + tp.x0 + 1) * c, gv, tp.w11);
+    }
+  }
+}
+
+extern "C" int dis_gather_warped_feat_fwd(const float* feat, const float* flows, float* out, int tl, int bs, int h,
+                                          int w, int c, void* stream) {
+  if (!feat || !flows || !out) return DIS_ERR_NULL;
+  if (tl <= 0 || bs <= 0 || h <= 1 || w <= 1 || c <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c % 4 != 0) return DIS_ERR_UNSUPPORTED;
+  long total = (long)tl * bs * h * w * tl * (c / 4);
+  hipLaunchKernelGGL(gather_warped_feat_fwd_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     feat, flows, out, tl, bs, h, w, c);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_gather_warped_feat_bwd(const float* grad_out, const float* flows, float* grad_feat, int tl, int bs,
+                                          int h, int w, int c, void* stream) {
+  if (!grad_out || !flows || !grad_feat) return DIS_ERR_NULL;
+  if (tl <= 0 || bs <= 0 || h <= 1 || w <= 1 || c <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c % 4 != 0) return DIS_ERR_UNSUPPORTED;
+  long total = (long)tl * bs * h * w * tl * (c / 4);
+  hipLaunchKernelGGL(gather_warped_feat_bwd_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     grad_out, flows, grad_feat, tl, bs, h, w, c);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-frame geometry: warped xyz + forward/backward mask per (target, slot)
+// (reference multi_frame_networks.py:172-214, 283-294); out (tl,bs,h,w,tl,4)
+// ------------------------------------------------------------------------------------------------
+struct GeomCam {
+  float Ki[9];
+};
+
+__device__ __forceinline__ void core_ray(const float* Ki, int u, int v, float* r) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    r[c] = (float)((double)u * (double)Ki[c * 3 + 0] + (double)v * (double)Ki[c * 3 + 1] + (double)Ki[c * 3 + 2]);
+}
+
+// camera-t coordinates of core pixel (x,y) of frame j:  ((d*ray - t_j) R_j) R_t^T + t_t
+__device__ __forceinline__ void xyz_in_view(const GeomCam& cam, int us, int vs, int x, int y, float d,
+                                            const float* Rj, const float* tj, const float* Rt, const float* tt,
+                                            float* o) {
+  float ray[3], a[3], wv[3];
+  core_ray(cam.Ki, us * x, vs * y, ray);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a[c] = d * ray[c] - tj[c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) wv[c] = a[0] * Rj[0 * 3 + c] + a[1] * Rj[1 * 3 + c] + a[2] * Rj[2 * 3 + c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] = (wv[0] * Rt[c * 3 + 0] + wv[1] * Rt[c * 3 + 1] + wv[2] * Rt[c * 3 + 2]) + tt[c];
+}
+
+__global__ void mf_geometry_kernel(const float* __restrict__ depth, const float* __restrict__ R,
+                                   const float* __restrict__ tv, const float* __restrict__ flows, GeomCam cam,
+                                   int us, int vs, float4* __restrict__ out, int tl, int bs, int h, int w) {
+  const long hw = (long)h * w;
+  const long total = (long)tl * bs * hw * tl;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int s = (int)(i % tl);
+    long r = i / tl;
+    const long p = r % hw;
+    r /= hw;
+    const int b = (int)(r % bs);
+    const int t = (int)(r / bs);
+    const int j = slot_frame(t, s);
+    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const float* Rt = R + ((long)t * bs + b) * 9;
+    const float* tt = tv + ((long)t * bs + b) * 3;
+    const float* Rj = R + ((long)j * bs + b) * 9;
+    const float* tj = tv + ((long)j * bs + b) * 3;
+    const float* dj = depth + ((long)j * bs + b) * hw;
+    float4 o;
+    if (s == 0) {
+      float q[3];
+      xyz_in_view(cam, us, vs, x, y, dj[p], Rj, tj, Rt, tt, q);
+      o = make_float4(q[0], q[1], q[2], 1.f);
+    } else {
+      const float2 f0 = *(const float2*)(flows + ((((long)t * tl + j) * bs + b) * hw + p) * 2);
+      const Taps tp = make_taps(f0.x + (float)x, f0.y + (float)y, h, w);
+      const float* fl1 = flows + (((long)j * tl + t) * bs + b) * hw * 2;
+      float acc[3] = {0.f, 0.f, 0.f};
+      float f10x = 0.f, f10y = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool valid = (k == 0) ? tp.v00 : (k == 1) ? tp.v01 : (k == 2) ? tp.v10 : tp.v11;
+        const float wgt = (k == 0) ? tp.w00 : (k == 1) ? tp.w01 : (k == 2) ? tp.w10 : tp.w11;
+        if (valid) {
+          const int tx = tp.x0 + (k & 1), ty = tp.y0 + (k >> 1);
+          float q[3];
+          xyz_in_view(cam, us, vs, tx, ty, dj[(long)ty * w + tx], Rj, tj, Rt, tt, q);
+          acc[0] += q[0] * wgt;
+          acc[1] += q[1] * wgt;
+          acc[2] += q[2] * wgt;
+          const float2 g = *(const float2*)(fl1 + ((long)ty * w + tx) * 2);
+          f10x += g.x * wgt;
+          f10y += g.y * wgt;
+        }
+      }
+      const float sx = f0.x + f10x, sy = f0.y + f10y;
+      const float lhs = sx * sx + sy * sy;
+      const float rhs = 0.5f + 0.01f * ((f0.x * f0.x + f0.y * f0.y) + (f10x * f10x + f10y * f10y));
+      o = make_float4(acc[0], acc[1], acc[2], lhs < rhs ? 1.f : 0.f);
+    }
+    out[i] = o;
+  }
+}
+
+extern "C" int dis_mf_geometry(const float* depth_core, const float* R, const float* t, const float* flows,
+                               const float* Kinv_host, int u_step, int v_step, float* out, int tl, int bs, int h,
+                               int w, void* stream) {
+  if (!depth_core || !R || !t || !flows || !Kinv_host || !out) return DIS_ERR_NULL;
+  if (tl <= 0 || bs <= 0 || h <= 1 || w <= 1) return DIS_ERR_BAD_SHAPE;
+  GeomCam cam;
+  for (int i = 0; i < 9; ++i) cam.Ki[i] = Kinv_host[i];
+  long total = (long)tl * bs * h * w * tl;
+  hipLaunchKernelGGL(mf_geometry_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, depth_core,
+                     R, t, flows, cam, u_step, v_step, (float4*)out, tl, bs, h, w);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// bilinear (align_corners) resize of the (tl*bs, h, w, tl*4) geometry tensor; masks re-binarised (> 0.5)
+__global__ void mf_geometry_resize_kernel(const float4* __restrict__ x, float4* __restrict__ y, int n, int hin,
+                                          int win, int hout, int wout, int slots) {
+  const long total = (long)n * hout * wout * slots;
+  const float sy = resize_scale(hin, hout, 1), sx = resize_scale(win, wout, 1);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int s = (int)(i % slots);
+    long p = i / slots;
+    const int ox = (int)(p % wout);
+    p /= wout;
+    const int oy = (int)(p % hout);
+    const int b = (int)(p / hout);
+    const Lerp Ly = resize_src(oy, sy, hin, 1), Lx = resize_src(ox, sx, win, 1);
+    const float4* base = x + (long)b * hin * win * slots + s;
+    const float4 a = base[((long)Ly.i0 * win + Lx.i0) * slots], bq = base[((long)Ly.i0 * win + Lx.i1) * slots];
+    const float4 c = base[((long)Ly.i1 * win + Lx.i0) * slots], d = base[((long)Ly.i1 * win + Lx.i1) * slots];
+    float4 o;
+    o.x = Ly.l0 * (Lx.l0 * a.x + Lx.l1 * bq.x) + Ly.l1 * (Lx.l0 * c.x + Lx.l1 * d.x);
+    o.y = Ly.l0 * (Lx.l0 * a.y + Lx.l1 * bq.y) + Ly.l1 * (Lx.l0 * c.y + Lx.l1 * d.y);
+    o.z = Ly.l0 * (Lx.l0 * a.z + Lx.l1 * bq.z) + Ly.l1 * (Lx.l0 * c.z + Lx.l1 * d.z);
+    const float m = Ly.l0 * (Lx.l0 * a.w + Lx.l1 * bq.w) + Ly.l1 * (Lx.l0 * c.w + Lx.l1 * d.w);
+    o.w = m > 0.5f ? 1.f : 0.f;
+    y[i] = o;
+  }
+}
+extern "C" int dis_mf_geometry_resize(const float* geom, float* out, int tl, int bs, int hin, int win, int hout,
+                                      int wout, void* stream) {
+  if (!geom || !out) return DIS_ERR_NULL;
+  if (tl <= 0 || bs <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
+  long total = (long)tl * bs * hout * wout * tl;
+  hipLaunchKernelGGL(mf_geometry_resize_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)geom, (float4*)out, tl * bs, hin, win, hout, wout, tl);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// slot weighting of the gathered features: out = (wf * mask) / mean_slots(mask)
+// (reference multi_frame_networks.py:410).  Linear in wf, so the same call is its own backward.
+// ------------------------------------------------------------------------------------------------
+__global__ void mask_weight_slots_kernel(const float* __restrict__ wf, const float4* __restrict__ geom,
+                                         float* __restrict__ out, long pixels, int tl, int c) {
+  const int cg = c >> 2;
+  const long total = pixels * tl * cg;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / cg;
+    const int s = (int)(r % tl);
+    const long p = r / tl;
+    float msum = 0.f;
+    for (int k = 0; k < tl; ++k) msum += geom[p * tl + k].w;
+    const float mean = msum / (float)tl;
+    const float m = geom[p * tl + s].w;
+    float4 v = *(const float4*)(wf + i * 4);
+    v.x = (v.x * m) / mean;
+    v.y = (v.y * m) / mean;
+    v.z = (v.z * m) / mean;
+    v.w = (v.w * m) / mean;
+    *(float4*)(out + i * 4) = v;
+  }
+}
+extern "C" int dis_mask_weight_slots(const float* wf, const float* geom, float* out, long pixels, int tl, int c,
+                                     void* stream) {
+  if (!wf || !geom || !out) return DIS_ERR_NULL;
+  if (pixels <= 0 || tl <= 0 || c <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c % 4 != 0) return DIS_ERR_UNSUPPORTED;
+  long total = pixels * tl * (c / 4);
+  hipLaunchKernelGGL(mask_weight_slots_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, wf,
+                     (const float4*)geom, out, pixels, tl, c);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}

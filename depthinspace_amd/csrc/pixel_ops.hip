@@ -1,0 +1,777 @@
+// Per-pixel operators of the DIS training step: LCN, photometric census window, pattern projection,
+// scalar reductions, Sobel smoothness, disparity->depth, flow-consistency (geometric) loss.
+// All are HBM-bandwidth-bound stencil/gather kernels: coalesced row-major access, LDS halo tiles for the
+// windowed ones, wavefront-shuffle + fp64-atomic reductions for the scalar losses.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// LCN  (reference model/networks.py:663-689)
+// ------------------------------------------------------------------------------------------------
+#define LCN_TX 32
+#define LCN_TY 8
+#define LCN_MAXR 7
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  // ReflectionPad2d (no edge repeat); valid for |overshoot| < n
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+__global__ __launch_bounds__(LCN_TX* LCN_TY) void lcn_fwd_kernel(const float* __restrict__ x,
+                                                                    float* __restrict__ out_lcn,
+                                                                    float* __restrict__ out_std, int h, int w,
+                                                                    int radius, float eps) {
+  __shared__ float tile[(LCN_TY + 2 * LCN_MAXR) * (LCN_TX + 2 * LCN_MAXR)];
+  const int n = blockIdx.z;
+  const int x0 = blockIdx.x * LCN_TX, y0 = blockIdx.y * LCN_TY;
+  const int tw = LCN_TX + 2 * radius, th = LCN_TY + 2 * radius;
+  const float* img = x + (long)n * h * w;
+  for (int i = threadIdx.x; i < tw * th; i += blockDim.x) {
+    int ty = i / tw, tx = i - ty * tw;
+    int gy = reflect_idx(y0 + ty - radius, h), gx = reflect_idx(x0 + tx - radius, w);
+    gy = min(max(gy, 0), h - 1);
+    gx = min(max(gx, 0), w - 1);
+    tile[i] = img[(long)gy * w + gx];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x % LCN_TX, ly = threadIdx.x / LCN_TX;
+  const int px = x0 + lx, py = y0 + ly;
+  if (px >= w || py >= h) return;
+  // fp64 box sums: the reference's fp32 conv result is reproduced to within its own rounding error
+  double s = 0.0, s2 = 0.0;
+  const int k = 2 * radius + 1;
+  for (int dy = 0; dy < k; ++dy) {
+    const float* row = tile + (ly + dy) * tw + lx;
+    for (int dx = 0; dx < k; ++dx) {
+      float v = row[dx];
+      s += (double)v;
+      s2 += (double)v * (double)v;
+    }
+  }
+  const float kk = (float)(k * k);
+  float box = (float)s, box2 = (float)s2;
+  float avg = box / kk;
+  float var = box2 / kk - avg * avg + 1e-6f;
+  var = var < 0.f ? 0.f : var;
+  float sd = sqrtf(var) + eps;
+  float c = tile[(ly + radius) * tw + lx + radius];
+  long o = (long)n * h * w + (long)py * w + px;
+  out_lcn[o] = (c - avg) / sd;
+  out_std[o] = sd;
+}
+
+extern "C" int dis_lcn_fwd(const float* x, float* out_lcn, float* out_std, int n, int h, int w, int radius,
+                           float eps, void* stream) {
+  if (!x || !out_lcn || !out_std) return DIS_ERR_NULL;
+  if (n <= 0 || h <= 0 || w <= 0) return DIS_ERR_BAD_SHAPE;
+  if (radius < 0 || radius > LCN_MAXR || radius >= h || radius >= w) return DIS_ERR_UNSUPPORTED;
+  dim3 grid(dis_cdiv(w, LCN_TX), dis_cdiv(h, LCN_TY), n);
+  hipLaunchKernelGGL(lcn_fwd_kernel, grid, dim3(LCN_TX * LCN_TY), 0, (hipStream_t)stream, x, out_lcn, out_std, h,
+                     w, radius, eps);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// photometric window loss (reference model/ext_functions.py:115-183)
+// ------------------------------------------------------------------------------------------------
+#define PH_TX 32
+#define PH_TY 8
+#define PH_MAXP 7
+
+__device__ __forceinline__ float census_h(float d, float eps) { return 0.5f * (1.f + d / sqrtf(d * d + eps)); }
+// d/dd of census_h
+__device__ __forceinline__ float census_dh(float d, float eps) {
+  float q = d * d + eps;
+  return 0.5f * eps / (q * sqrtf(q));
+}
+
+template <int TYPE>
+__global__ __launch_bounds__(PH_TX* PH_TY) void photometric_fwd_kernel(const float* __restrict__ es,
+                                                                         const float* __restrict__ ta,
+                                                                         float* __restrict__ out, int c, int h,
+                                                                         int w, int block, float eps) {
+  __shared__ float te[(PH_TY + 2 * PH_MAXP) * (PH_TX + 2 * PH_MAXP)];
+  __shared__ float tt[(PH_TY + 2 * PH_MAXP) * (PH_TX + 2 * PH_MAXP)];
+  const int p = block / 2;
+  const int n = blockIdx.z;
+  const int x0 = blockIdx.x * PH_TX, y0 = blockIdx.y * PH_TY;
+  const int tw = PH_TX + 2 * p, th = PH_TY + 2 * p;
+  const int lx = threadIdx.x % PH_TX, ly = threadIdx.x / PH_TX;
+  const int px = x0 + lx, py = y0 + ly;
+  float acc = 0.f;
+  for (int ch = 0; ch < c; ++ch) {
+    const float* ie = es + ((long)n * c + ch) * h * w;
+    const float* it = ta + ((long)n * c + ch) * h * w;
+    __syncthreads();
+    for (int i = threadIdx.x; i < tw * th; i += blockDim.x) {
+      int ty = i / tw, tx = i - ty * tw;
+      int gy = min(max(y0 + ty - p, 0), h - 1), gx = min(max(x0 + tx - p, 0), w - 1);  // replicate pad
+      te[i] = ie[(long)gy * w + gx];
+      tt[i] = it[(long)gy * w + gx];
+    }
+    __syncthreads();
+    const float ec = te[(ly + p) * tw + lx + p], tc = tt[(ly + p) * tw + lx + p];
+    for (int dy = 0; dy < block; ++dy) {
+      for (int dx = 0; dx < block; ++dx) {
+        float e = te[(ly + dy) * tw + lx + dx], t = tt[(ly + dy) * tw + lx + dx];
+        float r;
+        if (TYPE == 0) {
+          r = (e - t) * (e - t);
+        } else if (TYPE == 1) {
+          r = fabsf(e - t);
+        } else {
+          float diff = census_h(e - ec, eps) - census_h(t - tc, eps);
+          r = (TYPE == 2) ? diff * diff : fabsf(diff);
+        }
+        acc += r;
+      }
+    }
+  }
+  if (px < w && py < h) out[(long)n * h * w + (long)py * w + px] = acc / (float)(block * block);
+}
+
+// number of window offsets d in [-p,p] with clamp(pc + d, 0, size-1) == kc
+__device__ __forceinline__ int clamp_mult(int pc, int kc, int p, int size) {
+  if (kc > 0 && kc < size - 1) return (abs(kc - pc) <= p) ? 1 : 0;
+  int m = 0;
+  if (kc == 0) {
+    int hi = -pc;  // d <= -pc
+    if (hi >= -p) m += min(hi, p) - (-p) + 1;
+  }
+  if (kc == size - 1) {
+    int lo = size - 1 - pc;  // d >= lo
+    if (lo <= p) m += p - max(lo, -p) + 1;
+  }
+  if (size == 1) m = 2 * p + 1;
+  return m;
+}
+
+// Gather formulation of the backward pass (no atomics): pixel k collects
+//   (a) its role as a NEIGHBOUR of every window centre p around it (with replicate-pad multiplicity), and
+//   (b) its role as the CENTRE of its own window (census types only).
+template <int TYPE>
+__global__ __launch_bounds__(PH_TX* PH_TY) void photometric_bwd_kernel(const float* __restrict__ es,
+                                                                         const float* __restrict__ ta,
+                                                                         const float* __restrict__ gout,
+                                                                         float* __restrict__ ges, int c, int h,
+                                                                         int w, int block, float eps) {
+  __shared__ float te[(PH_TY + 2 * PH_MAXP) * (PH_TX + 2 * PH_MAXP)];
+  __shared__ float tt[(PH_TY + 2 * PH_MAXP) * (PH_TX + 2 * PH_MAXP)];
+  __shared__ float tg[(PH_TY + 2 * PH_MAXP) * (PH_TX + 2 * PH_MAXP)];
+  const int p = block / 2;
+  const int n = blockIdx.z;
+  const int x0 = blockIdx.x * PH_TX, y0 = blockIdx.y * PH_TY;
+  const int tw = PH_TX + 2 * p, th = PH_TY + 2 * p;
+  const int lx = threadIdx.x % PH_TX, ly = threadIdx.x / PH_TX;
+  const int px = x0 + lx, py = y0 + ly;
+  const float inv = 1.f / (float)(block * block);
+  const float* ig = gout + (long)n * h * w;
+  for (int ch = 0; ch < c; ++ch) {
+    const float* ie = es + ((long)n * c + ch) * h * w;
+    const float* it = ta + ((long)n * c + ch) * h * w;
+    __syncthreads();
+    for (int i = threadIdx.x; i < tw * th; i += blockDim.x) {
+      int ty = i / tw, tx = i - ty * tw;
+      int ry = y0 + ty - p, rx = x0 + tx - p;
+      int gy = min(max(ry, 0), h - 1), gx = min(max(rx, 0), w - 1);
+      te[i] = ie[(long)gy * w + gx];
+      tt[i] = it[(long)gy * w + gx];
+      // window centres outside the image do not exist: zero gradient there
+      tg[i] = (ry >= 0 && ry < h && rx >= 0 && rx < w) ? ig[(long)gy * w + gx] * inv : 0.f;
+    }
+    __syncthreads();
+    if (px < w && py < h) {
+      const float ek = te[(ly + p) * tw + lx + p], tk = tt[(ly + p) * tw + lx + p];
+      const float gk = tg[(ly + p) * tw + lx + p];
+      float acc = 0.f;
+      const bool interior = (px > 0 && px < w - 1 && py > 0 && py < h - 1);
+      for (int dy = 0; dy < block; ++dy) {
+        for (int dx = 0; dx < block; ++dx) {
+          const int li = (ly + dy) * tw + lx + dx;
+          const float e = te[li], t = tt[li], g = tg[li];
+          // (a) window centre at p = k + (dy-p, dx-p); te/tt hold the clamped image but tg is 0 outside
+          float mult = 1.f;
+          if (!interior) {
+            int cy = py + dy - p, cx = px + dx - p;
+            mult = (float)(clamp_mult(cy, py, p, h) * clamp_mult(cx, px, p, w));
+          }
+          if (TYPE == 0) {
+            acc += mult * g * 2.f * (ek - tk);
+          } else if (TYPE == 1) {
+            float d = ek - tk;
+            acc += mult * g * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+          } else {
+            // as neighbour of centre p: des = e_k - e_p, dta = t_k - t_p
+            float des = ek - e, dta = tk - t;
+            float diff = census_h(des, eps) - census_h(dta, eps);
+            float s = (TYPE == 2) ? 2.f * diff : (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+            acc += mult * g * s * census_dh(des, eps);
+            // (b) as centre of its own window with neighbour q = clamp(k + off): des = e_q - e_k
+            float des2 = e - ek, dta2 = t - tk;
+            float diff2 = census_h(des2, eps) - census_h(dta2, eps);
+            float s2 = (TYPE == 2) ? 2.f * diff2 : (diff2 > 0.f ? 1.f : (diff2 < 0.f ? -1.f : 0.f));
+            acc -= gk * s2 * census_dh(des2, eps);
+          }
+        }
+      }
+      ges[((long)n * c + ch) * h * w + (long)py * w + px] = acc;
+    }
+  }
+}
+
+extern "C" int dis_photometric_fwd(const float* es, const float* ta, float* out, int n, int c, int h, int w,
+                                   int block, int type, float eps, void* stream) {
+  if (!es || !ta || !out) return DIS_ERR_NULL;
+  if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return DIS_ERR_BAD_SHAPE;
+  if (block < 1 || (block & 1) == 0 || block / 2 > PH_MAXP || type < 0 || type > 3) return DIS_ERR_UNSUPPORTED;
+  dim3 grid(dis_cdiv(w, PH_TX), dis_cdiv(h, PH_TY), n), blk(PH_TX * PH_TY);
+  hipStream_t s = (hipStream_t)stream;
+  switch (type) {
+    case 0: hipLaunchKernelGGL(photometric_fwd_kernel<0>, grid, blk, 0, s, es, ta, out, c, h, w, block, eps); break;
+    case 1: hipLaunchKernelGGL(photometric_fwd_kernel<1>, grid, blk, 0, s, es, ta, out, c, h, w, block, eps); break;
+    case 2: hipLaunchKernelGGL(photometric_fwd_kernel<2>, grid, blk, 0, s, es, ta, out, c, h, w, block, eps); break;
+    default: hipLaunchKernelGGL(photometric_fwd_kernel<3>, grid, blk, 0, s, es, ta, out, c, h, w, block, eps); break;
+  }
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+extern "C" int dis_photometric_bwd(const float* es, const float* ta, const float* grad_out, float* grad_es, int n,
+                                   int c, int h, int w, int block, int type, float eps, void* stream) {
+  if (!es || !ta || !grad_out || !grad_es) return DIS_ERR_NULL;
+  if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return DIS_ERR_BAD_SHAPE;
+  if (block < 1 || (block & 1) == 0 || block / 2 > PH_MAXP || type < 0 || type > 3) return DIS_ERR_UNSUPPORTED;
+  dim3 grid(dis_cdiv(w, PH_TX), dis_cdiv(h, PH_TY), n), blk(PH_TX * PH_TY);
+  hipStream_t s = (hipStream_t)stream;
+  switch (type) {
+    case 0: hipLaunchKernelGGL(photometric_bwd_kernel<0>, grid, blk, 0, s, es, ta, grad_out, grad_es, c, h, w, block, eps); break;
+    case 1: hipLaunchKernelGGL(photometric_bwd_kernel<1>, grid, blk, 0, s, es, ta, grad_out, grad_es, c, h, w, block, eps); break;
+    case 2: hipLaunchKernelGGL(photometric_bwd_kernel<2>, grid, blk, 0, s, es, ta, grad_out, grad_es, c, h, w, block, eps); break;
+    default: hipLaunchKernelGGL(photometric_bwd_kernel<3>, grid, blk, 0, s, es, ta, grad_out, grad_es, c, h, w, block, eps); break;
+  }
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pattern projection (reference model/networks.py:358-367), 'border' padding, align_corners=True
+// ------------------------------------------------------------------------------------------------
+__global__ void pattern_warp_kernel(const float* __restrict__ pattern, const float* __restrict__ disp,
+                                    const float* __restrict__ gproj, float* __restrict__ out, int n, int h, int w,
+                                    int backward) {
+  const long total = (long)n * h * w;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    const int y = (int)((i / w) % h);
+    float ix = gs_roundtrip((float)x - disp[i], w);
+    float iy = gs_roundtrip((float)y, h);
+    // border: clip coordinates; gradient is zero where clipped
+    float gmul = 1.f;
+    if (ix <= 0.f) { ix = 0.f; gmul = 0.f; }   // ATen clip_coordinates_set_grad: grad 0 at/below 0 ...
+    if (ix >= (float)(w - 1)) { ix = (float)(w - 1); gmul = 0.f; }
+    iy = fminf(fmaxf(iy, 0.f), (float)(h - 1));
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx = ix - fx, ex = 1.f - wx, wy = iy - fy, ey = 1.f - wy;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx1 = x1 <= w - 1, vy1 = y1 <= h - 1;
+    const float nw = pattern[(long)y0 * w + x0];
+    const float ne = vx1 ? pattern[(long)y0 * w + x1] : 0.f;
+    const float sw = vy1 ? pattern[(long)y1 * w + x0] : 0.f;
+    const float se = (vx1 && vy1) ? pattern[(long)y1 * w + x1] : 0.f;
+    if (!backward) {
+      out[i] = nw * (ey * ex) + ne * (ey * wx) + sw * (wy * ex) + se * (wy * wx);
+    } else {
+      // d out / d ix, then ix = (x - disp) up to the (linear) normalisation round trip => d ix / d disp = -1
+      float gix = (ne - nw) * ey + (se - sw) * wy;
+      out[i] = -gproj[i] * gix * gmul;
+    }
+  }
+}
+
+extern "C" int dis_pattern_warp_fwd(const float* pattern, const float* disp, float* proj, int n, int h, int w,
+                                    void* stream) {
+  if (!pattern || !disp || !proj) return DIS_ERR_NULL;
+  if (n <= 0 || h <= 1 || w <= 1) return DIS_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(pattern_warp_kernel, dim3(dis_ew_grid((long)n * h * w, 256)), dim3(256), 0,
+                     (hipStream_t)stream, pattern, disp, (const float*)nullptr, proj, n, h, w, 0);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_pattern_warp_bwd(const float* pattern, const float* disp, const float* grad_proj,
+                                    float* grad_disp, int n, int h, int w, void* stream) {
+  if (!pattern || !disp || !grad_proj || !grad_disp) return DIS_ERR_NULL;
+  if (n <= 0 || h <= 1 || w <= 1) return DIS_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(pattern_warp_kernel, dim3(dis_ew_grid((long)n * h * w, 256)), dim3(256), 0,
+                     (hipStream_t)stream, pattern, disp, grad_proj, grad_disp, n, h, w, 1);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar reductions
+// ------------------------------------------------------------------------------------------------
+__global__ void weighted_sum_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                    double* __restrict__ acc, long count) {
+  __shared__ double sm[8];
+  double s0 = 0.0, s1 = 0.0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    float wi = w ? w[i] : 1.f;
+    s0 += (double)(wi * x[i]);
+    s1 += (double)wi;
+  }
+  double r0 = block_sum_d(s0, sm);
+  double r1 = block_sum_d(s1, sm);
+  if (threadIdx.x == 0) {
+    atomic_add_d(acc, r0);
+    atomic_add_d(acc + 1, r1);
+  }
+}
+__global__ void ratio_finalize_kernel(const double* __restrict__ acc, float* __restrict__ out, double eps_den) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)((float)acc[0] / ((float)acc[1] + (float)eps_den));
+}
+__global__ void weighted_mean_bwd_kernel(const float* __restrict__ w, const double* __restrict__ acc,
+                                         const float* __restrict__ gscale, float* __restrict__ gx, long count) {
+  const float g = gscale[0] / (float)acc[1];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+    gx[i] = g * (w ? w[i] : 1.f);
+}
+
+extern "C" int dis_weighted_mean_fwd(const float* x, const float* w, double* acc, float* out, long count,
+                                     void* stream) {
+  if (!x || !acc || !out) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(dis_ew_grid(count, 256)), dim3(256), 0, s, x, w, acc, count);
+  hipLaunchKernelGGL(ratio_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)acc, out, 0.0);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_weighted_mean_bwd(const float* w, const double* acc, const float* gscale, float* grad_x,
+                                     long count, void* stream) {
+  if (!acc || !gscale || !grad_x) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(weighted_mean_bwd_kernel, dim3(dis_ew_grid(count, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     acc, gscale, grad_x, count);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+__global__ void l1_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ acc,
+                              long count) {
+  __shared__ double sm[8];
+  double s0 = 0.0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+    s0 += (double)fabsf(a[i] - b[i]);
+  double r0 = block_sum_d(s0, sm);
+  if (threadIdx.x == 0) atomic_add_d(acc, r0);
+}
+__global__ void mean_finalize_kernel(const double* __restrict__ acc, float* __restrict__ out, double count) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(acc[0] / count);
+}
+__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                              const float* __restrict__ gscale, float* __restrict__ ga, long count) {
+  const float g = gscale[0] / (float)count;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    float d = a[i] - b[i];
+    ga[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+  }
+}
+extern "C" int dis_l1_mean_fwd(const float* a, const float* b, double* acc, float* out, long count, void* stream) {
+  if (!a || !b || !acc || !out) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(l1_sum_kernel, dim3(dis_ew_grid(count, 256)), dim3(256), 0, s, a, b, acc, count);
+  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)acc, out, (double)count);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_l1_mean_bwd(const float* a, const float* b, const float* gscale, float* grad_a, long count,
+                               void* stream) {
+  if (!a || !b || !gscale || !grad_a) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(dis_ew_grid(count, 256)), dim3(256), 0, (hipStream_t)stream, a, b, gscale,
+                     grad_a, count);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sobel-5 smoothness (reference model/networks.py:411-431, 693-731)
+// ------------------------------------------------------------------------------------------------
+__constant__ float c_sobel5[25] = {-5.f / 240.f, -4.f / 240.f,  0.f, 4.f / 240.f,  5.f / 240.f,
+                                   -8.f / 240.f, -10.f / 240.f, 0.f, 10.f / 240.f, 8.f / 240.f,
+                                   -10.f / 240.f, -20.f / 240.f, 0.f, 20.f / 240.f, 10.f / 240.f,
+                                   -8.f / 240.f, -10.f / 240.f, 0.f, 10.f / 240.f, 8.f / 240.f,
+                                   -5.f / 240.f, -4.f / 240.f,  0.f, 4.f / 240.f,  5.f / 240.f};
+#define SM_TX 32
+#define SM_TY 8
+
+// mode 0: accumulate sum |g * exp(-|255 ga|)| into acc.  mode 1: write s_x, s_y = sign(g) * e * gscale/count
+__global__ __launch_bounds__(SM_TX* SM_TY) void smooth_kernel(const float* __restrict__ disp,
+                                                                const float* __restrict__ amb,
+                                                                double* __restrict__ acc,
+                                                                const float* __restrict__ gscale,
+                                                                float* __restrict__ splanes, int n_total, int h,
+                                                                int w, int mode) {
+  __shared__ float td[(SM_TY + 4) * (SM_TX + 4)];
+  __shared__ float tam[(SM_TY + 4) * (SM_TX + 4)];
+  __shared__ double sm[8];
+  const int n = blockIdx.z;
+  const int x0 = blockIdx.x * SM_TX, y0 = blockIdx.y * SM_TY;
+  const int tw = SM_TX + 4, th = SM_TY + 4;
+  const float* idp = disp + (long)n * h * w;
+  const float* iam = amb + (long)n * h * w;
+  for (int i = threadIdx.x; i < tw * th; i += blockDim.x) {
+    int ty = i / tw, tx = i - ty * tw;
+    int gy = min(max(y0 + ty - 2, 0), h - 1), gx = min(max(x0 + tx - 2, 0), w - 1);
+    td[i] = idp[(long)gy * w + gx];
+    tam[i] = iam[(long)gy * w + gx];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x % SM_TX, ly = threadIdx.x / SM_TX;
+  const int px = x0 + lx, py = y0 + ly;
+  double local = 0.0;
+  if (px < w && py < h) {
+    float gx = 0.f, gy = 0.f, ax = 0.f, ay = 0.f;
+    for (int dy = 0; dy < 5; ++dy)
+      for (int dx = 0; dx < 5; ++dx) {
+        float kx = c_sobel5[dy * 5 + dx], ky = c_sobel5[dx * 5 + dy];
+        float d = td[(ly + dy) * tw + lx + dx], a = tam[(ly + dy) * tw + lx + dx];
+        gx += kx * d;
+        gy += ky * d;
+        ax += kx * a;
+        ay += ky * a;
+      }
+    float e_x = expf(-fabsf(255.f * ax)), e_y = expf(-fabsf(255.f * ay));
+    if (mode == 0) {
+      local = (double)fabsf(gx * e_x) + (double)fabsf(gy * e_y);
+    } else {
+      const float g = gscale[0] / (float)((long)n_total * 2 * h * w);
+      float vx = gx * e_x, vy = gy * e_y;
+      long o = (long)n * 2 * h * w + (long)py * w + px;
+      splanes[o] = (vx > 0.f ? g : (vx < 0.f ? -g : 0.f)) * e_x;
+      splanes[o + (long)h * w] = (vy > 0.f ? g : (vy < 0.f ? -g : 0.f)) * e_y;
+    }
+  }
+  if (mode == 0) {
+    double r = block_sum_d(local, sm);
+    if (threadIdx.x == 0) atomic_add_d(acc, r);
+  }
+}
+
+// grad_disp[k] = sum over window centres p and offsets off with clamp(p+off)==k of coef[off]*s[p]
+__global__ void smooth_bwd_gather_kernel(const float* __restrict__ splanes, float* __restrict__ gdisp, int n, int h,
+                                         int w) {
+  const long total = (long)n * h * w;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int kx = (int)(i % w), ky = (int)((i / w) % h);
+    const int b = (int)(i / ((long)h * w));
+    const float* sx = splanes + (long)b * 2 * h * w;
+    const float* sy = sx + (long)h * w;
+    float acc = 0.f;
+    for (int py = max(ky - 2, 0); py <= min(ky + 2, h - 1); ++py) {
+      // offsets oy in [-2,2] with clamp(py+oy)==ky
+      int oy_lo = ky - py, oy_hi = ky - py;
+      if (ky == 0) oy_lo = -2;
+      if (ky == h - 1) oy_hi = 2;
+      for (int px = max(kx - 2, 0); px <= min(kx + 2, w - 1); ++px) {
+        int ox_lo = kx - px, ox_hi = kx - px;
+        if (kx == 0) ox_lo = -2;
+        if (kx == w - 1) ox_hi = 2;
+        float cx = 0.f, cy = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+          for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            cx += c_sobel5[(oy + 2) * 5 + ox + 2];
+            cy += c_sobel5[(ox + 2) * 5 + oy + 2];
+          }
+        acc += cx * sx[(long)py * w + px] + cy * sy[(long)py * w + px];
+      }
+    }
+    gdisp[i] = acc;
+  }
+}
+
+extern "C" int dis_smooth_loss_fwd(const float* disp, const float* amb, double* acc, float* out, int n, int h,
+                                   int w, void* stream) {
+  if (!disp || !amb || !acc || !out) return DIS_ERR_NULL;
+  if (n <= 0 || h < 3 || w < 3) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(dis_cdiv(w, SM_TX), dis_cdiv(h, SM_TY), n);
+  hipLaunchKernelGGL(smooth_kernel, grid, dim3(SM_TX * SM_TY), 0, s, disp, amb, acc, (const float*)nullptr,
+                     (float*)nullptr, n, h, w, 0);
+  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)acc, out,
+                     (double)((long)n * 2 * h * w));
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_smooth_loss_bwd(const float* disp, const float* amb, const float* gscale, float* grad_disp,
+                                   float* workspace, int n, int h, int w, void* stream) {
+  if (!disp || !amb || !gscale || !grad_disp || !workspace) return DIS_ERR_NULL;
+  if (n <= 0 || h < 3 || w < 3) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(dis_cdiv(w, SM_TX), dis_cdiv(h, SM_TY), n);
+  hipLaunchKernelGGL(smooth_kernel, grid, dim3(SM_TX * SM_TY), 0, s, disp, amb, (double*)nullptr, gscale, workspace,
+                     n, h, w, 1);
+  hipLaunchKernelGGL(smooth_bwd_gather_kernel, dim3(dis_ew_grid((long)n * h * w, 256)), dim3(256), 0, s,
+                     (const float*)workspace, grad_disp, n, h, w);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// disparity -> depth (reference model/networks.py:311-319)
+// ------------------------------------------------------------------------------------------------
+__global__ void d2d_kernel(const float* __restrict__ disp, const float* __restrict__ gdepth,
+                           float* __restrict__ out, float bf, long count, int backward) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    float d = disp[i];
+    float r = (d > 0.f ? d : 0.f) + 1e-12f;
+    if (!backward) {
+      out[i] = bf / r;
+    } else {
+      out[i] = d > 0.f ? -gdepth[i] * bf / (r * r) : 0.f;
+    }
+  }
+}
+extern "C" int dis_disp_to_depth_fwd(const float* disp, float* depth, float bf, long count, void* stream) {
+  if (!disp || !depth) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(d2d_kernel, dim3(dis_ew_grid(count, 256)), dim3(256), 0, (hipStream_t)stream, disp,
+                     (const float*)nullptr, depth, bf, count, 0);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* grad_disp, float bf,
+                                     long count, void* stream) {
+  if (!disp || !grad_depth || !grad_disp) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(d2d_kernel, dim3(dis_ew_grid(count, 256)), dim3(256), 0, (hipStream_t)stream, disp, grad_depth,
+                     grad_disp, bf, count, 1);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// flow-consistency (geometric) loss, one direction (reference model/networks.py:564-601, 619-655)
+// ------------------------------------------------------------------------------------------------
+struct GeoCam {
+  float K[9];
+  float Ki[9];
+};
+
+// ray = [u,v,1] . Ki^T evaluated in fp64 and rounded to fp32, as numpy does for int64 @ float32
+__device__ __forceinline__ void pixel_ray(const float* Ki, int u, int v, float* r) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    r[c] = (float)((double)u * (double)Ki[c * 3 + 0] + (double)v * (double)Ki[c * 3 + 1] + (double)Ki[c * 3 + 2]);
+}
+// row vector times 3x3 (row-major M): out_c = sum_k a_k M[k][c]
+__device__ __forceinline__ void vec_mat(const float* a, const float* M, float* o) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] = a[0] * M[0 * 3 + c] + a[1] * M[1 * 3 + c] + a[2] * M[2 * 3 + c];
+}
+// row vector times M^T: out_c = sum_k a_k M[c][k]
+__device__ __forceinline__ void vec_matT(const float* a, const float* M, float* o) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] = a[0] * M[c * 3 + 0] + a[1] * M[c * 3 + 1] + a[2] * M[c * 3 + 2];
+}
+
+struct Bilin {
+  int x0, y0;
+  float nw, ne, sw, se;   // weights
+  bool v00, v01, v10, v11;  // tap validity (zeros padding)
+};
+__device__ __forceinline__ Bilin bilin_zeros(float px, float py, int h, int w) {
+  Bilin b;
+  float ix = gs_roundtrip(px, w), iy = gs_roundtrip(py, h);
+  float fx = floorf(ix), fy = floorf(iy);
+  // keep the int conversion defined for far-out coordinates
+  fx = fminf(fmaxf(fx, -2.f), (float)w + 1.f);
+  fy = fminf(fmaxf(fy, -2.f), (float)h + 1.f);
+  ix = fminf(fmaxf(ix, -2.f), (float)w + 2.f);
+  iy = fminf(fmaxf(iy, -2.f), (float)h + 2.f);
+  b.x0 = (int)fx;
+  b.y0 = (int)fy;
+  float wx = ix - fx, ex = 1.f - wx, wy = iy - fy, ey = 1.f - wy;
+  b.nw = ey * ex; b.ne = ey * wx; b.sw = wy * ex; b.se = wy * wx;
+  bool xa = b.x0 >= 0 && b.x0 < w, xb = b.x0 + 1 >= 0 && b.x0 + 1 < w;
+  bool ya = b.y0 >= 0 && b.y0 < h, yb = b.y0 + 1 >= 0 && b.y0 + 1 < h;
+  b.v00 = xa && ya; b.v01 = xb && ya; b.v10 = xa && yb; b.v11 = xb && yb;
+  return b;
+}
+__device__ __forceinline__ float bilin_fetch(const float* img, const Bilin& b, int w) {
+  float a = b.v00 ? img[(long)b.y0 * w + b.x0] : 0.f;
+  float c = b.v01 ? img[(long)b.y0 * w + b.x0 + 1] : 0.f;
+  float d = b.v10 ? img[(long)(b.y0 + 1) * w + b.x0] : 0.f;
+  float e = b.v11 ? img[(long)(b.y0 + 1) * w + b.x0 + 1] : 0.f;
+  return a * b.nw + c * b.ne + d * b.sw + e * b.se;
+}
+
+// z (and optionally uv) of pixel (u,v) of camera A with depth d, reprojected into camera B
+__device__ __forceinline__ void reproject(const GeoCam& cam, int u, int v, float d, const float* RA,
+                                          const float* tA, const float* RB, const float* tB, float* uvw) {
+  float ray[3], xyz[3], xw[3], xc[3];
+  pixel_ray(cam.Ki, u, v, ray);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) xyz[c] = d * ray[c] - tA[c];
+  vec_mat(xyz, RA, xw);
+  vec_matT(xw, RB, xc);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) xc[c] += tB[c];
+  vec_matT(xc, cam.K, uvw);  // uvw = xc . K^T
+}
+
+__global__ void geo_loss_fwd_kernel(const float* __restrict__ depth0, const float* __restrict__ depth1,
+                                    const float* __restrict__ flow0, const float* __restrict__ flow1,
+                                    const float* __restrict__ amb0, const float* __restrict__ amb1,
+                                    const float* __restrict__ pdepth1, const float* __restrict__ R0,
+                                    const float* __restrict__ t0, const float* __restrict__ R1,
+                                    const float* __restrict__ t1, GeoCam cam, float clampv,
+                                    float* __restrict__ mask_out, double* __restrict__ acc, int bs, int h, int w) {
+  __shared__ double sm[8];
+  const long hw = (long)h * w, total = (long)bs * hw;
+  double s_diff = 0.0, s_mask = 0.0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / hw);
+    const long p = i - (long)b * hw;
+    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const float *rA = R0 + b * 9, *tA = t0 + b * 3, *rB = R1 + b * 9, *tB = t1 + b * 3;
+    float uvw[3];
+    reproject(cam, x, y, depth0[i], rA, tA, rB, tB, uvw);
+    const float d1 = uvw[2];
+    const float f0x = flow0[(long)b * 2 * hw + p], f0y = flow0[(long)b * 2 * hw + hw + p];
+    Bilin bl = bilin_zeros(f0x + (float)x, f0y + (float)y, h, w);
+    const float depth10 = bilin_fetch(depth1 + (long)b * hw, bl, w);
+    float diff = fabsf(d1 - depth10);
+    if (clampv > 0.f) diff = fminf(fmaxf(diff, 0.f), clampv);
+    // masks (no gradient)
+    const float f10x = bilin_fetch(flow1 + (long)b * 2 * hw, bl, w);
+    const float f10y = bilin_fetch(flow1 + (long)b * 2 * hw + hw, bl, w);
+    const float sx = f0x + f10x, sy = f0y + f10y;
+    const float lhs = sx * sx + sy * sy;
+    const float rhs = 0.5f + 0.02f * ((f0x * f0x + f0y * f0y) + (f10x * f10x + f10y * f10y));
+    float m = lhs < rhs ? 1.f : 0.f;
+    const float amb10 = bilin_fetch(amb1 + (long)b * hw, bl, w);
+    m *= (fabsf(amb0[i] - amb10) < 0.01f) ? 1.f : 0.f;
+    if (pdepth1) {
+      // uv0 = projection of frame-1 primary depth into frame 0, sampled at the flow target (4 taps)
+      float wu = 0.f, wv = 0.f;
+      const float* pd = pdepth1 + (long)b * hw;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int tx = bl.x0 + (k & 1), ty = bl.y0 + (k >> 1);
+        const bool valid = (k == 0) ? bl.v00 : (k == 1) ? bl.v01 : (k == 2) ? bl.v10 : bl.v11;
+        const float wgt = (k == 0) ? bl.nw : (k == 1) ? bl.ne : (k == 2) ? bl.sw : bl.se;
+        if (valid) {
+          float q[3];
+          reproject(cam, tx, ty, pd[(long)ty * w + tx], rB, tB, rA, tA, q);
+          float den = (q[2] > 0.f ? q[2] : 0.f) + 1e-12f;
+          wu += (q[0] / den) * wgt;
+          wv += (q[1] / den) * wgt;
+        }
+      }
+      const float du = wu - (float)x, dv = wv - (float)y;
+      m *= (du * du + dv * dv < 1.f) ? 1.f : 0.f;
+    }
+    mask_out[i] = m;
+    s_diff += (double)(diff * m);
+    s_mask += (double)m;
+  }
+  double r0 = block_sum_d(s_diff, sm);
+  double r1 = block_sum_d(s_mask, sm);
+  if (threadIdx.x == 0) {
+    atomic_add_d(acc, r0);
+    atomic_add_d(acc + 1, r1);
+  }
+}
+
+__global__ void geo_loss_bwd_kernel(const float* __restrict__ depth0, const float* __restrict__ depth1,
+                                    const float* __restrict__ flow0, const float* __restrict__ R0,
+                                    const float* __restrict__ t0, const float* __restrict__ R1,
+                                    const float* __restrict__ t1, GeoCam cam, float clampv,
+                                    const float* __restrict__ mask, const double* __restrict__ acc,
+                                    const float* __restrict__ gscale, float* __restrict__ gdepth0,
+                                    float* __restrict__ gdepth1, int bs, int h, int w) {
+  const long hw = (long)h * w, total = (long)bs * hw;
+  const float gs = gscale[0] / ((float)acc[1] + 1e-8f);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float m = mask[i];
+    if (m == 0.f) continue;
+    const int b = (int)(i / hw);
+    const long p = i - (long)b * hw;
+    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const float *rA = R0 + b * 9, *tA = t0 + b * 3, *rB = R1 + b * 9, *tB = t1 + b * 3;
+    float uvw[3];
+    reproject(cam, x, y, depth0[i], rA, tA, rB, tB, uvw);
+    const float d1 = uvw[2];
+    const float f0x = flow0[(long)b * 2 * hw + p], f0y = flow0[(long)b * 2 * hw + hw + p];
+    Bilin bl = bilin_zeros(f0x + (float)x, f0y + (float)y, h, w);
+    const float depth10 = bilin_fetch(depth1 + (long)b * hw, bl, w);
+    const float raw = d1 - depth10;
+    float a = fabsf(raw);
+    if (clampv > 0.f && a > clampv) continue;  // clamp passes gradient only inside [0, clamp]
+    const float sgn = raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f);
+    const float g = gs * m * sgn;
+    // d d1 / d depth0 = ((ray R0) R1^T K^T)_z
+    float ray[3], a1[3], a2[3], a3[3];
+    pixel_ray(cam.Ki, x, y, ray);
+    vec_mat(ray, rA, a1);
+    vec_matT(a1, rB, a2);
+    vec_matT(a2, cam.K, a3);
+    gdepth0[i] += g * a3[2];
+    float* g1 = gdepth1 + (long)b * hw;
+    if (bl.v00) atomicAdd(g1 + (long)bl.y0 * w + bl.x0, -g * bl.nw);
+    if (bl.v01) atomicAdd(g1 + (long)bl.y0 * w + bl.x0 + 1, -g * bl.ne);
+    if (bl.v10) atomicAdd(g1 + (long)(bl.y0 + 1) * w + bl.x0, -g * bl.sw);
+    if (bl.v11) atomicAdd(g1 + (long)(bl.y0 + 1) * w + bl.x0 + 1, -g * bl.se);
+  }
+}
+
+static void fill_cam(GeoCam& cam, const float* K, const float* Ki) {
+  for (int i = 0; i < 9; ++i) {
+    cam.K[i] = K[i];
+    cam.Ki[i] = Ki[i];
+  }
+}
+
+extern "C" int dis_geo_loss_fwd(const float* depth0, const float* depth1, const float* flow0, const float* flow1,
+                                const float* amb0, const float* amb1, const float* primary_depth1,
+                                const float* R0, const float* t0, const float* R1, const float* t1,
+                                const float* K_host, const float* Kinv_host, float clampv, float* mask_out,
+                                double* acc, float* out, int bs, int h, int w, void* stream) {
+  if (!depth0 || !depth1 || !flow0 || !flow1 || !amb0 || !amb1 || !R0 || !t0 || !R1 || !t1 || !K_host ||
+      !Kinv_host || !mask_out || !acc || !out)
+    return DIS_ERR_NULL;
+  if (bs <= 0 || h <= 1 || w <= 1) return DIS_ERR_BAD_SHAPE;
+  GeoCam cam;
+  fill_cam(cam, K_host, Kinv_host);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(geo_loss_fwd_kernel, dim3(dis_ew_grid((long)bs * h * w, 256)), dim3(256), 0, s, depth0, depth1,
+                     flow0, flow1, amb0, amb1, primary_depth1, R0, t0, R1, t1, cam, clampv, mask_out, acc, bs, h, w);
+  hipLaunchKernelGGL(ratio_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)acc, out, 1e-8);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+extern "C" int dis_geo_loss_bwd(const float* depth0, const float* depth1, const float* flow0, const float* R0,
+                                const float* t0, const float* R1, const float* t1, const float* K_host,
+                                const float* Kinv_host, float clampv, const float* mask, const double* acc,
+                                const float* gscale, float* grad_depth0, float* grad_depth1, int bs, int h, int w,
+                                void* stream) {
+  if (!depth0 || !depth1 || !flow0 || !R0 || !t0 || !R1 || !t1 || !K_host || !Kinv_host || !mask || !acc ||
+      !gscale || !grad_depth0 || !grad_depth1)
+    return DIS_ERR_NULL;
+  if (bs <= 0 || h <= 1 || w <= 1) return DIS_ERR_BAD_SHAPE;
+  GeoCam cam;
+  fill_cam(cam, K_host, Kinv_host);
+  hipLaunchKernelGGL(geo_loss_bwd_kernel, dim3(dis_ew_grid((long)bs * h * w, 256)), dim3(256), 0,
+                     (hipStream_t)stream, depth0, depth1, flow0, R0, t0, R1, t1, cam, clampv, mask, acc, gscale,
+                     grad_depth0, grad_depth1, bs, h, w);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+extern "C" int dis_abi_version(void) { return 1; }

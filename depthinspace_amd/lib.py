@@ -1,0 +1,131 @@
+"""ctypes binding of libdis_hip.so (the C ABI declared in include/dis_hip.h).
+
+The HIP library is the product; there is NO fallback.  If the shared object is missing or a symbol
+is absent, importing/using this module raises.  PyTorch is used only as the owner of device memory
+and of the current HIP stream.
+"""
+import ctypes
+import os
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdis_hip.so')
+
+# signature strings: p = pointer (device or host), i = int, l = long, f = float; the return type is int
+# unless listed in _RET_LONG.  Keep in sync with include/dis_hip.h (tests/test_abi.py checks the symbol set).
+SIGS = {
+    'dis_abi_version': '',
+    'dis_lcn_fwd': 'pppiiiifp',
+    'dis_photometric_fwd': 'pppiiiiiifp',
+    'dis_photometric_bwd': 'ppppiiiiiifp',
+    'dis_pattern_warp_fwd': 'pppiiip',
+    'dis_pattern_warp_bwd': 'ppppiiip',
+    'dis_weighted_mean_fwd': 'pppplp',
+    'dis_weighted_mean_bwd': 'pppplp',
+    'dis_l1_mean_fwd': 'pppplp',
+    'dis_l1_mean_bwd': 'pppplp',
+    'dis_smooth_loss_fwd': 'ppppiiip',
+    'dis_smooth_loss_bwd': 'pppppiiip',
+    'dis_disp_to_depth_fwd': 'ppflp',
+    'dis_disp_to_depth_bwd': 'pppflp',
+    'dis_geo_loss_fwd': 'ppppppppppppp' + 'f' + 'ppp' + 'iiip',
+    'dis_geo_loss_bwd': 'ppppppppp' + 'f' + 'ppppp' + 'iiip',
+    'dis_pack4_nhwc': 'pppppiiip',
+    'dis_planar_to_nhwc': 'ppiiiip',
+    'dis_nhwc_to_planar': 'ppiiiip',
+    'dis_resize_bilinear_nhwc_fwd': 'ppiiiiiiip',
+    'dis_resize_bilinear_nhwc_bwd': 'ppiiiiiiip',
+    'dis_resize_bilinear_planar_fwd': 'ppiiiiiiffip',
+    'dis_resize_bilinear_planar_bwd': 'ppiiiiiip',
+    'dis_gather_warped_feat_fwd': 'pppiiiiip',
+    'dis_gather_warped_feat_bwd': 'pppiiiiip',
+    'dis_mf_geometry': 'pppppiipiiiip',
+    'dis_mf_geometry_resize': 'ppiiiiiip',
+    'dis_conv2d_pack_weights': 'ppiiiip',
+    'dis_conv2d_fwd': 'pppppiiiiiiiiip',
+    'dis_conv2d_wgrad_workspace': 'iii',
+    'dis_conv2d_wgrad': 'pppppiiiiiiiip',
+    'dis_conv2d_dgrad_strided': 'pppiiiiiiiip',
+    'dis_disp_head_fwd': 'ppppiiiiffp',
+    'dis_disp_head_bwd': 'ppppppppp' + 'iiiifp',
+    'dis_act_bwd': 'pppilp',
+    'dis_gn_stats': 'ppilp',
+    'dis_gn_apply': 'ppppppiliifp',
+    'dis_gn_apply_bwd': 'ppppp' + 'pppp' + 'pp' + 'iliifp',
+    'dis_add_act_fwd': 'pppilp',
+    'dis_mask_weight_slots': 'ppplilp'.replace('lil', 'lii'),
+    'dis_conv3d_knn_fwd': 'ppppppppp' + 'iiiiip',
+    'dis_conv3d_knn_bwd': 'ppppppp' + 'pppppp' + 'iiiiip',
+    'dis_adam_step': 'pppplffffifp',
+}
+_RET_LONG = {'dis_conv2d_wgrad_workspace'}
+
+_CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
+_lib = None
+
+
+def load():
+    """Load libdis_hip.so and bind every entry point; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(or `make -C depthinspace_amd/csrc`). There is no non-HIP fallback.')
+    _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+_bound = {}
+
+
+def fn(name):
+    """Bound entry point (argtypes set); AttributeError if the library does not export it."""
+    f = _bound.get(name)
+    if f is None:
+        f = getattr(load(), name)  # missing symbol => loud failure, by design
+        f.argtypes = [_CT[c] for c in SIGS[name]]
+        f.restype = ctypes.c_long if name in _RET_LONG else ctypes.c_int
+        _bound[name] = f
+    return f
+
+
+def check_all_symbols():
+    """Bind every entry point declared in SIGS (== include/dis_hip.h); raises on the first missing one."""
+    for name in SIGS:
+        fn(name)
+    return len(SIGS)
+
+
+class DisHipError(RuntimeError):
+    pass
+
+
+_ERR = {-1: 'bad shape', -2: 'unsupported configuration', -3: 'null pointer'}
+
+
+def call(name, *args):
+    """Call a C-ABI entry point; tensors are passed as device pointers, None as NULL.
+    Appends the current HIP stream.  Raises DisHipError on a non-zero status (like the reference's
+    C++ exceptions surfacing as RuntimeError, model/ext_functions.py:123-126)."""
+    f = fn(name)
+    conv = []
+    for a in args:
+        if a is None:
+            conv.append(None)
+        elif isinstance(a, torch.Tensor):
+            conv.append(a.data_ptr())
+        elif isinstance(a, ctypes.Array):
+            conv.append(ctypes.cast(a, ctypes.c_void_p))
+        else:
+            conv.append(a)
+    conv.append(torch.cuda.current_stream().cuda_stream)
+    rc = f(*conv)
+    if rc != 0:
+        raise DisHipError(f'{name} failed: {_ERR.get(rc, "hipError_t " + str(rc))}')
+
+
+def host_floats(vals):
+    vals = [float(v) for v in vals]
+    return (ctypes.c_float * len(vals))(*vals)

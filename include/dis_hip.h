@@ -1,0 +1,244 @@
+/*
+ * libdis_hip.so -- C ABI of the MI355X (gfx950) DIS-SF / DIS-MF training-step kernels.
+ *
+ * This is the drop-in boundary.  The reference's only native seam is the
+ * pybind module pair `ext_cpu` / `ext_cuda` of connecting_the_dots' torchext, bound at
+ *   /root/reference/model/ext_functions.py:32-39   (import by bare name from CTD_DIR/torchext)
+ *   /root/reference/model/ext_functions.py:124,126 (photometric_loss_forward)
+ *   /root/reference/model/ext_functions.py:137,139 (photometric_loss_backward)
+ * `dis_photometric_fwd/bwd` replace exactly those two entry points.  Every other function below
+ * replaces a group of ATen/cuDNN operator calls inside model/networks.py and
+ * model/multi_frame_networks.py (cited per function); the reference has no native code for them.
+ *
+ * Conventions
+ *  - plain C symbols, raw DEVICE pointers, sizes as int, no torch types.
+ *  - the caller owns every buffer (inputs, outputs, workspaces); the library never allocates,
+ *    frees or synchronises, and keeps no state.  All calls are asynchronous on `stream`
+ *    (a hipStream_t passed as void*), graph-capturable and re-entrant.
+ *  - return value: 0 on success, DIS_ERR_* (<0) on a rejected argument, or the positive hipError_t
+ *    of a failed launch.  Nothing throws across the boundary.
+ *  - "planar" tensors are (N,C,H,W) contiguous fp32 (the reference layout, used for the 1-3 channel
+ *    images/disparities/flows of the module API).  "nhwc" tensors are (N,H,W,C) contiguous fp32 and
+ *    are used for every feature map inside the networks (one pixel of 32 channels = one 128-B line).
+ *  - reductions to a scalar accumulate in fp64 in a caller-provided, ZEROED `double` workspace.
+ */
+#ifndef DIS_HIP_H
+#define DIS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIS_OK 0
+#define DIS_ERR_BAD_SHAPE (-1)
+#define DIS_ERR_UNSUPPORTED (-2)
+#define DIS_ERR_NULL (-3)
+
+#define DIS_ACT_NONE 0
+#define DIS_ACT_SELU 1
+#define DIS_ACT_RELU 2
+
+/* ABI version of this header; bumped on any signature change. */
+int dis_abi_version(void);
+
+/* ---------------------------------------------------------------- per-pixel operators ------- */
+
+/* Local contrast normalisation, reference model/networks.py:663-689 (LCN.tforward).
+ * x, out_lcn, out_std: (n,1,h,w).  reflect pad `radius`, (2r+1)^2 box sums. */
+int dis_lcn_fwd(const float* x, float* out_lcn, float* out_std, int n, int h, int w, int radius, float eps,
+                void* stream);
+
+/* Photometric window loss, replaces ext_{cpu,cuda}.photometric_loss_forward
+ * (reference model/ext_functions.py:124,126; arithmetic per :156-183).
+ * es, ta: (n,c,h,w); out: (n,1,h,w).  type: 0 mse, 1 sad, 2 census_mse, 3 census_sad. block odd <= 15. */
+int dis_photometric_fwd(const float* es, const float* ta, float* out, int n, int c, int h, int w, int block,
+                        int type, float eps, void* stream);
+/* replaces photometric_loss_backward (reference model/ext_functions.py:137,139): gradient wrt `es` only. */
+int dis_photometric_bwd(const float* es, const float* ta, const float* grad_out, float* grad_es, int n, int c,
+                        int h, int w, int block, int type, float eps, void* stream);
+
+/* Pattern projection of RectifiedPatternSimilarityLoss, reference model/networks.py:358-367:
+ * proj[n,y,x] = bilinear(pattern, x - disp[n,y,x], y), align_corners=True, padding 'border'.
+ * pattern: (1,1,h,w) shared by all n.  disp, proj: (n,1,h,w). */
+int dis_pattern_warp_fwd(const float* pattern, const float* disp, float* proj, int n, int h, int w, void* stream);
+/* grad_disp = -grad_proj * d(sample)/dx   (the only path by which the photometric loss reaches the net). */
+int dis_pattern_warp_bwd(const float* pattern, const float* disp, const float* grad_proj, float* grad_disp, int n,
+                         int h, int w, void* stream);
+
+/* val = sum(w*x)/sum(w) (reference model/networks.py:374), or mean(|x-y|) style reductions.
+ * acc: 2 zeroed doubles {sum(w*x), sum(w)}; out: 1 float.  w may be NULL (=> plain mean over count). */
+int dis_weighted_mean_fwd(const float* x, const float* w, double* acc, float* out, long count, void* stream);
+/* grad_x = gscale[0] * w / sum(w)  (acc as left by the forward). */
+int dis_weighted_mean_bwd(const float* w, const double* acc, const float* gscale, float* grad_x, long count,
+                          void* stream);
+
+/* mean(|a-b|)  (warm-up / pseudo-GT L1, reference model/multi_frame_worker.py:164, single_frame_worker.py:154) */
+int dis_l1_mean_fwd(const float* a, const float* b, double* acc, float* out, long count, void* stream);
+/* grad_a = gscale[0] * sign(a-b) / count */
+int dis_l1_mean_bwd(const float* a, const float* b, const float* gscale, float* grad_a, long count, void* stream);
+
+/* DisparitySmoothLoss, reference model/networks.py:411-431 with SobelFilter(ksize=5) :693-731.
+ * disp, amb: (n,1,h,w).  acc: 1 zeroed double; out: 1 float = mean over (n,2,h,w). */
+int dis_smooth_loss_fwd(const float* disp, const float* amb, double* acc, float* out, int n, int h, int w,
+                        void* stream);
+/* grad_disp is OVERWRITTEN (the scatter through the 5x5 taps is done as a gather, no atomics).
+ * workspace: 2*n*h*w floats. */
+int dis_smooth_loss_bwd(const float* disp, const float* amb, const float* gscale, float* grad_disp,
+                        float* workspace, int n, int h, int w, void* stream);
+
+/* DispToDepth, reference model/networks.py:311-319: depth = bf / (relu(disp) + 1e-12) */
+int dis_disp_to_depth_fwd(const float* disp, float* depth, float bf, long count, void* stream);
+int dis_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* grad_disp, float bf, long count,
+                          void* stream);
+
+/* One direction of the flow-consistency (geometric) loss:
+ *   multi-frame  reference model/networks.py:564-601  (primary_depth1 != NULL: adds the rf mask)
+ *   single-frame reference model/networks.py:619-655  (clamp > 0: diff clamped to [0,clamp])
+ * depth0, depth1, amb0, amb1, primary_depth1: (bs,1,h,w); flow0, flow1: (bs,2,h,w) pixel units;
+ * R0,R1: (bs,3,3); t0,t1: (bs,3) device pointers; K: 9 floats, Kinv: 9 floats (host values, by pointer to host).
+ * mask_out: (bs,1,h,w) {0,1} loss mask (saved for backward); acc: 2 zeroed doubles {sum(diff*mask), sum(mask)};
+ * out: 1 float = acc0/(acc1+1e-8). */
+int dis_geo_loss_fwd(const float* depth0, const float* depth1, const float* flow0, const float* flow1,
+                     const float* amb0, const float* amb1, const float* primary_depth1, const float* R0,
+                     const float* t0, const float* R1, const float* t1, const float* K_host,
+                     const float* Kinv_host, float clamp, float* mask_out, double* acc, float* out, int bs, int h,
+                     int w, void* stream);
+/* grad_depth0 (bs,1,h,w) is WRITTEN (+=); grad_depth1 (bs,1,h,w) is scatter-added (atomics).  Both must be
+ * valid accumulators (zeroed or holding earlier contributions). */
+int dis_geo_loss_bwd(const float* depth0, const float* depth1, const float* flow0, const float* R0,
+                     const float* t0, const float* R1, const float* t1, const float* K_host,
+                     const float* Kinv_host, float clamp, const float* mask, const double* acc,
+                     const float* gscale, float* grad_depth0, float* grad_depth1, int bs, int h, int w,
+                     void* stream);
+
+/* ---------------------------------------------------------------- layout / resize / warp ---- */
+
+/* Pack up to 4 planar single-channel sources (n,1,h,w) into nhwc C=4 (NULL source => zeros).
+ * Used for the FuseNet stem input cat(ir(2), amb, d) (reference multi_frame_networks.py:217,273). */
+int dis_pack4_nhwc(const float* s0, const float* s1, const float* s2, const float* s3, float* out, int n, int h,
+                   int w, void* stream);
+/* planar (n,c,h,w) <-> nhwc (n,h,w,c) */
+int dis_planar_to_nhwc(const float* x, float* y, int n, int c, int h, int w, void* stream);
+int dis_nhwc_to_planar(const float* x, float* y, int n, int c, int h, int w, void* stream);
+
+/* Bilinear resize (F.interpolate mode='bilinear'), reference multi_frame_networks.py:47,63,246,420,422
+ * (align_corners=1) and networks.py:273-293 (align_corners=0).  nhwc, any c.
+ * scale_x/scale_y multiply channel 0 / channel 1 of the result when c==2 && flow_scale!=0
+ * (resize_flow_like, reference multi_frame_networks.py:64-65). */
+int dis_resize_bilinear_nhwc_fwd(const float* x, float* y, int n, int hin, int win, int hout, int wout, int c,
+                                 int align_corners, void* stream);
+int dis_resize_bilinear_nhwc_bwd(const float* gy, float* gx /*zeroed*/, int n, int hin, int win, int hout, int wout,
+                                 int c, int align_corners, void* stream);
+int dis_resize_bilinear_planar_fwd(const float* x, float* y, int nc, int hin, int win, int hout, int wout,
+                                   int align_corners, float scale0, float scale1, int c_for_scale, void* stream);
+
+/* gather_warped_feat for all targets, reference multi_frame_networks.py:347-360 + warp :83-99.
+ * feat: (tl,bs,h,w,c) nhwc; flows: (tl*tl, bs, h, w, 2) nhwc, entry [i*tl+j] = flow_ij (diagonal unused).
+ * out: (tl, bs, h, w, tl, c): slot 0 = own frame, slots 1.. = other frames in increasing index, warped. */
+int dis_gather_warped_feat_fwd(const float* feat, const float* flows, float* out, int tl, int bs, int h, int w,
+                               int c, void* stream);
+/* grad_feat (zeroed by caller) += scatter of grad_out (atomics for warped slots). */
+int dis_gather_warped_feat_bwd(const float* grad_out, const float* flows, float* grad_feat, int tl, int bs, int h,
+                               int w, int c, void* stream);
+
+/* unproject + change_view_angle + gather_warped_xyz + forward/backward flow mask for every target,
+ * reference multi_frame_networks.py:172-214,283-294.  No gradient.
+ * depth_core: (tl,bs,h,w); R (tl,bs,3,3), t (tl,bs,3) device; Kinv_host 9 floats;
+ * ray uses the pixel coordinates (u_step*x, v_step*y) (even full-res pixels for the core grid).
+ * out: (tl, bs, h, w, tl, 4) = xyz + mask per slot. */
+int dis_mf_geometry(const float* depth_core, const float* R, const float* t, const float* flows,
+                    const float* Kinv_host, int u_step, int v_step, float* out, int tl, int bs, int h, int w,
+                    void* stream);
+/* quarter-resolution version: bilinear (align_corners) resize of `geom` and mask re-binarised with >0.5
+ * (reference multi_frame_networks.py:393-394). */
+int dis_mf_geometry_resize(const float* geom, float* out, int tl, int bs, int hin, int win, int hout, int wout,
+                           void* stream);
+
+/* ---------------------------------------------------------------- dense layers -------------- */
+
+/* Repack OIHW weights (cout,cin,k,k) into the conv kernel's layout; mode 0 = forward,
+ * mode 1 = dgrad (spatially flipped, cin<->cout swapped).  packed has cout*cin*k*k floats. */
+int dis_conv2d_pack_weights(const float* w_oihw, float* packed, int cout, int cin, int k, int mode, void* stream);
+
+/* Implicit-GEMM convolution on MFMA (fp32 in / fp32 accumulate), nhwc.
+ * Replaces ZeroPad2d + Conv2d (+SELU/ReLU) of reference multi_frame_networks.py:159-164,330-345,514-542
+ * and Conv2d of networks.py:222-234.
+ * x: (n,hin,win,cin); y: (n,hout,wout,cout), hout = (hin + 2*pad - k)/stride + 1.
+ * bias may be NULL.  act: DIS_ACT_*.  stats (optional, may be NULL): (n,2) zeroed doubles receiving
+ * sum / sum of squares of y per sample (GroupNorm(1 group) statistics of the conv output). */
+int dis_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, double* stats, int n,
+                   int hin, int win, int cin, int cout, int k, int stride, int pad, int act, void* stream);
+/* weight/bias gradient.  gy: (n,hout,wout,cout) gradient wrt the PRE-activation output.
+ * workspace: dis_conv2d_wgrad_workspace() floats.  grad_w: (cout,cin,k,k) OIHW, grad_b: (cout) or NULL; both are
+ * OVERWRITTEN. */
+long dis_conv2d_wgrad_workspace(int cin, int cout, int k);
+int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
+                     int hin, int win, int cin, int cout, int k, int stride, int pad, void* stream);
+/* input gradient for stride-2 convolutions (transposed convolution); stride-1 dgrad is dis_conv2d_fwd with
+ * mode-1 packed weights.  w_oihw is the unpacked weight.  gx: (n,hin,win,cin) overwritten. */
+int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, float* gx, int n, int hin, int win, int cin,
+                             int cout, int k, int stride, int pad, void* stream);
+
+/* Head: Conv2d(cin,1,3,pad 1) + alpha*sigmoid(x - offset) (reference networks.py:121-125,140-149;
+ * multi_frame_networks.py:157,265).  x nhwc (n,h,w,cin); w (1,cin,3,3); y planar (n,1,h,w). */
+int dis_disp_head_fwd(const float* x, const float* w, const float* b, float* y, int n, int h, int wd, int cin,
+                      float alpha, float offset, void* stream);
+/* gy (n,1,h,w) gradient wrt y; y is the forward output.  gx (n,h,w,cin) overwritten; grad_w/grad_b overwritten.
+ * workspace: n*h*wd floats (pre-sigmoid gradient). */
+int dis_disp_head_bwd(const float* x, const float* w, const float* y, const float* gy, float* gx, float* grad_w,
+                      float* grad_b, float* workspace, double* acc /* (cin*9+1) zeroed doubles */, int n, int h,
+                      int wd, int cin, float alpha, void* stream);
+
+/* dy *= act'(y) given the activation OUTPUT y (SELU and ReLU are invertible enough for that). In place ok. */
+int dis_act_bwd(const float* gy, const float* y, float* gpre, int act, long count, void* stream);
+
+/* GroupNorm(num_groups=1) statistics: stats (n,2) zeroed doubles <- sum, sumsq over (h,w,c) per sample. */
+int dis_gn_stats(const float* x, double* stats, int n, long per_sample, void* stream);
+/* y = act( gamma_c*(x-mean)*rstd + beta_c (+ residual) );  nhwc, eps 1e-5 (torch default).
+ * Covers GroupNorm of reference multi_frame_networks.py:336,344,451,522,526 and the residual tail :539-540. */
+int dis_gn_apply(const float* x, const double* stats, const float* gamma, const float* beta, const float* residual,
+                 float* y, int n, long hw, int c, int act, float eps, void* stream);
+/* Backward of dis_gn_apply.  gy: grad wrt y; y: forward output (needed when act != none); x: forward input.
+ * red: (n,2) zeroed doubles workspace; gparam_acc: (2*c) zeroed doubles.
+ * gx overwritten; gres (optional) receives the residual-branch gradient (= gradient after act');
+ * grad_gamma/grad_beta (c floats) overwritten. */
+int dis_gn_apply_bwd(const float* gy, const float* y, const float* x, const double* stats, const float* gamma,
+                     float* gx, float* gres, float* grad_gamma, float* grad_beta, double* red, double* gparam_acc,
+                     int n, long hw, int c, int act, float eps, void* stream);
+
+/* y = act(a + b) elementwise and its backward (residual SELU of Block2D3D, reference :428). */
+int dis_add_act_fwd(const float* a, const float* b, float* y, int act, long count, void* stream);
+
+/* Scale the tl slots of a gathered feature tensor by mask/mean(mask) (reference multi_frame_networks.py:410):
+ * wf (tl,bs,h,w,tl,c); geom (tl,bs,h,w,tl,4) (mask in .w); out same shape as wf.  Backward is the same call on
+ * the gradient. */
+int dis_mask_weight_slots(const float* wf, const float* geom, float* out, long pixels, int tl, int c, void* stream);
+
+/* ---------------------------------------------------------------- Conv3D (k-NN continuous conv) */
+
+/* reference multi_frame_networks.py:469-512 for ALL target frames at once.
+ * geom: (tl,bs,h,w,tl,4) xyz+mask per slot; wf: (tl,bs,h,w,tl,c) gathered features (c == 32).
+ * dense1_w (16,3), dense1_b (16), dense2_w (32,16), dense2_b (32), w (32,32).
+ * idx_out: (tl,bs,ho,wo,9) uint8 candidate ids (ky*3+kx)*tl+slot, ascending (saved for backward).
+ * y: (tl,bs,ho,wo,32) = SELU(agg @ w)  (GroupNorm follows as dis_gn_*). */
+int dis_conv3d_knn_fwd(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
+                       const float* dense2_w, const float* dense2_b, const float* w, unsigned char* idx_out,
+                       float* y, int tl, int bs, int h, int wd, int stride, void* stream);
+/* gy: gradient wrt y (post-SELU).  grad_wf (zeroed) scatter-added.  gparams: 16*3+16+32*16+32+32*32 floats
+ * overwritten in that order (dense1_w, dense1_b, dense2_w, dense2_b, w).  acc: same count of zeroed doubles. */
+int dis_conv3d_knn_bwd(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
+                       const float* dense2_w, const float* dense2_b, const float* w, const unsigned char* idx,
+                       const float* y, const float* gy, float* grad_wf, float* gparams, double* acc, int tl, int bs,
+                       int h, int wd, int stride, void* stream);
+
+/* ---------------------------------------------------------------- optimiser ----------------- */
+
+/* torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) on a flat fp32 buffer (reference train_val.py:55-56).
+ * step_count is the 1-based step index; grads are multiplied by grad_scale first (1/world_size for DP). */
+int dis_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, float lr,
+                  float beta1, float beta2, float eps, int step_count, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

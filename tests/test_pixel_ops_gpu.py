@@ -1,0 +1,165 @@
+"""HIP per-pixel operators (through the C ABI) vs the CPU oracle and the reference goldens."""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dis_oracle as O
+
+
+def dev(x):
+    return torch.as_tensor(x).cuda()
+
+
+def close(a, b, atol, rtol=0.0, what=''):
+    a = a.detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f'{what}: max err {float(err.max()):.3e} (tol {atol:.1e}+{rtol:.1e}*|ref|)'
+
+
+@pytest.fixture(scope='module')
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, 'ops.npz'))
+
+
+def test_lcn_golden(G):
+    from depthinspace_amd import ops
+    l, s = ops.lcn(dev(G['lcn_x']))
+    close(s, G['lcn_std'], 2e-5, what='lcn std')
+    close(l, G['lcn_out'], 2e-4, what='lcn out')
+
+
+def test_lcn_full_size():
+    from depthinspace_amd import ops, synth
+    st = synth.make_settings()
+    b = synth.make_batch(st, 1, 4, seed=5, with_flow=False)
+    x = torch.from_numpy(b['im0'][0])
+    l, s = ops.lcn(x.cuda())
+    ol, os_ = O.lcn(x)
+    close(s, os_, 2e-5, what='std')
+    close(l, ol, 3e-4, what='lcn')
+
+
+@pytest.mark.parametrize('name', ['mse', 'sad', 'census_mse', 'census_sad'])
+@pytest.mark.parametrize('blk,eps', [(9, 0.5), (5, 0.1)])
+def test_photometric_golden(G, name, blk, eps):
+    from depthinspace_amd import ops
+    es = dev(G['ph_es']).requires_grad_(True)
+    out = ops.photometric(es, dev(G['ph_ta']), blk, O.PHOTO_TYPES[name], eps)
+    out.backward(dev(G['ph_go']))
+    close(out, G[f'ph_{name}_{blk}_out'], 1e-5, 1e-5, what='fwd')
+    close(es.grad, G[f'ph_{name}_{blk}_grad'], 2e-6, 2e-5, what='bwd')
+
+
+def test_photometric_ragged_sizes():
+    from depthinspace_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for (n, c, h, w) in [(1, 1, 9, 9), (2, 2, 33, 41), (1, 1, 8, 70)]:
+        es = torch.randn(n, c, h, w, generator=g)
+        ta = torch.randn(n, c, h, w, generator=g)
+        go = torch.rand(n, 1, h, w, generator=g)
+        e1 = es.clone().requires_grad_(True)
+        y = O.photometric(e1, ta, 9, 'census_sad', 0.5)
+        y.backward(go)
+        e2 = es.cuda().requires_grad_(True)
+        y2 = ops.photometric(e2, ta.cuda(), 9, 3, 0.5)
+        y2.backward(go.cuda())
+        close(y2, y, 1e-5, 1e-5, what=f'fwd {n,c,h,w}')
+        close(e2.grad, e1.grad, 2e-6, 2e-5, what=f'bwd {n,c,h,w}')
+
+
+def test_photometric_rejects_bad_args():
+    from depthinspace_amd import ops, lib
+    x = torch.zeros(1, 1, 8, 8).cuda()
+    with pytest.raises(lib.DisHipError):
+        ops.photometric(x, x, 8, 3, 0.5)   # even block
+    with pytest.raises(lib.DisHipError):
+        ops.photometric(x, x, 9, 7, 0.5)   # unknown type
+    with pytest.raises(RuntimeError):
+        ops.photometric(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8), 9, 3, 0.5)  # CPU tensors: no fallback
+
+
+def test_pattern_loss_golden(G):
+    from depthinspace_amd import ops
+    pat = torch.from_numpy(G['pl_pat'])
+    pat1 = torch.cat([pat] * 3, 1).mean(dim=1, keepdim=True).contiguous()
+    disp = dev(G['pl_disp']).requires_grad_(True)
+    proj = ops.pattern_warp(pat1.cuda(), disp)
+    diff = ops.photometric(proj, dev(G['pl_im']), 9, 3, 0.5)
+    val = ops.weighted_mean(diff, dev(G['pl_std']))
+    val.backward()
+    close(proj, G['pl_proj'], 2e-6, 1e-5, what='proj')
+    close(val, float(G['pl_val']), 1e-6, 1e-5, what='val')
+    close(disp.grad, G['pl_grad'], 1e-8, 2e-4, what='grad')
+
+
+def test_smooth_golden(G):
+    from depthinspace_amd import ops
+    disp = dev(G['sm_disp']).requires_grad_(True)
+    val = ops.smooth_loss(disp, dev(G['sm_amb']))
+    val.backward()
+    close(val, float(G['sm_val']), 1e-7, 1e-5, what='val')
+    close(disp.grad, G['sm_grad'], 1e-9, 1e-4, what='grad')
+
+
+def test_d2d_golden(G):
+    from depthinspace_amd import ops
+    d = dev(G['d2d_in']).requires_grad_(True)
+    y = ops.disp_to_depth(d, 0.025 * 435.2)
+    close(y, G['d2d_out'], 0, 1e-6, what='d2d')
+    d1 = torch.from_numpy(G['d2d_in']).requires_grad_(True)
+    y1 = O.disp_to_depth(d1, 435.2, 0.025)
+    go = torch.rand(y1.shape) * 1e-3
+    y1.backward(go)
+    y.backward(go.cuda())
+    close(d.grad, d1.grad, 1e-12, 1e-5, what='d2d grad')
+
+
+def test_l1_mean():
+    from depthinspace_amd import ops
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(3, 1, 17, 19, generator=g)
+    b = torch.randn(3, 1, 17, 19, generator=g)
+    a1 = a.clone().requires_grad_(True)
+    v1 = (a1 - b).abs().mean()
+    v1.backward()
+    a2 = a.cuda().requires_grad_(True)
+    v2 = ops.l1_mean(a2, b.cuda())
+    (v2 * 0.1).backward()
+    close(v2, v1, 1e-7, 1e-6)
+    close(a2.grad, a1.grad * 0.1, 1e-10, 1e-6)
+
+
+@pytest.mark.parametrize('mode', ['mf', 'sf'])
+def test_geo_loss_golden(G, mode):
+    from depthinspace_amd import ops, synth, lib
+    st = synth.make_settings(48, 56)
+    b = synth.make_random_batch(st, 2, 4, seed=int(G['ge_seed']))
+    tb = {k: torch.from_numpy(v).transpose(0, 1).contiguous() if v.ndim > 2 else torch.from_numpy(v) for k, v in b.items()}
+    K = lib.host_floats(st.K.reshape(-1))
+    Ki = lib.host_floats(np.linalg.inv(st.K).reshape(-1))
+    bf = float(st.K[0, 0]) * st.baseline
+    disp = dev(G['ge_disp']).requires_grad_(True)
+    depth = ops.disp_to_depth(disp, bf)
+    pdepth = ops.disp_to_depth(tb['primary_disp'].cuda(), bf)
+    i, j = 0, 2
+    c = lambda t: t.contiguous().cuda()
+    f0, f1 = c(tb['flow_02'][0]), c(tb['flow_20'][0])
+    a0, a1 = c(tb['ambient0'][i]), c(tb['ambient0'][j])
+    R, t = tb['R'].cuda(), tb['t'].cuda()
+    if mode == 'mf':
+        l0, _ = ops.geo_loss_dir(depth[i], depth[j], f0, f1, a0, a1, pdepth[j], R[i], t[i], R[j], t[j], K, Ki, -1.0)
+        l1, _ = ops.geo_loss_dir(depth[j], depth[i], f1, f0, a1, a0, pdepth[i], R[j], t[j], R[i], t[i], K, Ki, -1.0)
+    else:
+        l0, _ = ops.geo_loss_dir(depth[i], depth[j], f0, f1, a0, a1, None, R[i], t[i], R[j], t[j], K, Ki, 0.1)
+        l1, _ = ops.geo_loss_dir(depth[j], depth[i], f1, f0, a1, a0, None, R[j], t[j], R[i], t[i], K, Ki, 0.1)
+    val = l0 + l1
+    val.backward()
+    close(val, float(G[f'ge_{mode}_val']), 1e-7, 2e-5, what='val')
+    ref = torch.from_numpy(G[f'ge_{mode}_grad'])
+    scale = float(ref.abs().max())
+    close(disp.grad, ref, 2e-5 * scale, 1e-4, what='grad')
