@@ -1,0 +1,36 @@
+// Fused Adam over a flat fp32 parameter buffer (torch.optim.Adam defaults, reference train_val.py:55-56).
+#include "common.h"
+
+__global__ void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                            float4* __restrict__ v, long count4, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, float gscale) {
+  const float step = lr / bc1;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count4; i += (long)gridDim.x * blockDim.x) {
+    float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+    float* P = (float*)&pp; float* G = (float*)&gg; float* M = (float*)&mm; float* V = (float*)&vv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = G[k] * gscale;
+      M[k] = M[k] * b1 + gr * (1.f - b1);
+      V[k] = V[k] * b2 + (gr * gr) * (1.f - b2);
+      const float denom = sqrtf(V[k]) / bc2_sqrt + eps;
+      P[k] = P[k] - step * (M[k] / denom);
+    }
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+
+extern "C" int dis_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count,
+                             float lr, float beta1, float beta2, float eps, int step_count, float grad_scale,
+                             void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq) return DIS_ERR_NULL;
+  if (count <= 0 || step_count <= 0) return DIS_ERR_BAD_SHAPE;
+  if (count % 4 != 0) return DIS_ERR_UNSUPPORTED;   // the flat buffer is padded by the caller
+  const double bc1 = 1.0 - pow((double)beta1, (double)step_count);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step_count);
+  hipLaunchKernelGGL(adam_kernel, dim3(dis_ew_grid(count / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (float4*)param, (const float4*)grad, (float4*)exp_avg, (float4*)exp_avg_sq, count / 4, lr,
+                     beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}

@@ -1,0 +1,759 @@
+// Implicit-GEMM 2-D convolution on the CDNA4 matrix cores, fp32 in / fp32 accumulate
+// (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, 64 FLOP/clk/SIMD).
+//
+// Layout: activations nhwc.  GEMM view per output tile:  D[pixel][cout] += A[pixel][k] * B[k][cout],
+// k = (tap, cin).  One MFMA consumes 4 k's, one per 16-lane group g; group g owns the channel range
+// [g*KG, (g+1)*KG) of the current 32/16/4-channel chunk, so every lane reads CONTIGUOUS channels of its
+// pixel from LDS (ds_read_b128).  A workgroup (4 waves) owns a TROWS x 16 pixel tile; wave w owns rows
+// [w*MT, (w+1)*MT); each wave keeps MT x (COUT/16) accumulator tiles.
+//
+//   * all weights of the layer stay resident in LDS in exactly the order the B fragments are read
+//     (packed once per step by dis_conv2d_pack_weights); workgroups are persistent over tiles;
+//   * the input halo tile of the NEXT (tile, chunk) is fetched into registers while the MFMAs of the
+//     current one run (issue-early / write-late staging);
+//   * tiles are dealt to workgroups in contiguous ranges per XCD (blockIdx % 8) so halos are re-read
+//     from that XCD's L2;
+//   * epilogue fuses bias, SELU/ReLU and the GroupNorm(1 group) sum / sum-of-squares of the output.
+//
+// The same kernel computes stride-1 input gradients (flipped/transposed weights) and, with a 2x2 tap
+// set and interleaved output addressing, the four phases of the stride-2 transposed convolution.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float* x;
+  const float* w;     // packed
+  const float* bias;  // may be null
+  float* y;
+  double* stats;  // may be null: (n,2)
+  int n, hin, win;
+  int hv, wv;          // virtual output grid the tiles run over
+  int pad_y, pad_x;
+  int hf, wf;          // full output tensor dims
+  int osy, ooy, osx, oox;  // output pixel = (vy*osy+ooy, vx*osx+oox)
+  int act;
+};
+
+template <int CIN, int COUT, int KH, int KW, int S>
+struct ConvCfg {
+  static constexpr int CINB = (CIN % 32 == 0) ? 32 : ((CIN % 16 == 0) ? 16 : 4);
+  static_assert(CIN % CINB == 0, "cin must be a multiple of the chunk");
+  static_assert(COUT % 16 == 0, "cout must be a multiple of 16");
+  static constexpr int NCHUNK = CIN / CINB;
+  static constexpr int KG = CINB / 4;                 // channels per MFMA k-group
+  static constexpr int E = (KG >= 4) ? 4 : KG;        // floats per fragment read
+  static constexpr int NQ = KG / E;                   // fragment reads per tap
+  static constexpr int NT = COUT / 16;
+  static constexpr int MT = (S == 1) ? 2 : 1;
+  static constexpr int TROWS = 4 * MT;
+  static constexpr int TCOLS = 16;
+  static constexpr int IN_ROWS = (TROWS - 1) * S + KH;
+  static constexpr int IN_COLS = (TCOLS - 1) * S + KW;
+  static constexpr int CS = (CINB >= 16) ? CINB + 4 : CINB;  // padded pixel stride in LDS (floats)
+  static constexpr int W_FLOATS = KH * KW * CIN * COUT;
+  static constexpr int IN_FLOATS = IN_ROWS * IN_COLS * CS;
+  static constexpr int RED_FLOATS = 16;  // 8 doubles for the stats reduction
+  static constexpr int LDS_BYTES = (W_FLOATS + IN_FLOATS + RED_FLOATS) * 4;
+  static constexpr int NV = CINB / 4;  // float4 per pixel per chunk
+  static constexpr int NITEMS = IN_ROWS * IN_COLS * NV;
+  static constexpr int NLOAD = (NITEMS + 255) / 256;
+};
+
+// packed-weight offset of (tap, channel c, cout)
+__host__ __device__ inline long packed_w_offset(int tap, int c, int co, int cin, int cout) {
+  const int cinb = (cin % 32 == 0) ? 32 : ((cin % 16 == 0) ? 16 : 4);
+  const int nchunk = cin / cinb, kg = cinb / 4, e = kg >= 4 ? 4 : kg, nq = kg / e;
+  const int chunk = c / cinb, cl = c % cinb;
+  const int g = cl / kg, r = cl % kg, q = r / e, ee = r % e;
+  return ((((long)(tap * nchunk + chunk) * 4 + g) * nq + q) * cout + co) * e + ee;
+}
+
+template <int CIN, int COUT, int KH, int KW, int S>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+  using C = ConvCfg<CIN, COUT, KH, KW, S>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;
+  float* xl = smem + C::W_FLOATS;
+  double* red = (double*)(smem + C::W_FLOATS + C::IN_FLOATS);
+
+  for (int i = threadIdx.x; i < C::W_FLOATS / 4; i += 256) ((float4*)wl)[i] = ((const float4*)a.w)[i];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int tiles_x = (a.wv + C::TCOLS - 1) / C::TCOLS, tiles_y = (a.hv + C::TROWS - 1) / C::TROWS;
+  const int ntiles = a.n * tiles_y * tiles_x;
+
+  // XCD-aware persistent schedule: workgroups with equal blockIdx%8 share an XCD (speed only)
+  const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
+  const int xcd = blockIdx.x % nxcd, rank = blockIdx.x / nxcd, per = gridDim.x / nxcd;
+  const int t_lo = (int)((long)ntiles * xcd / nxcd), t_hi = (int)((long)ntiles * (xcd + 1) / nxcd);
+
+  float4 pre[C::NLOAD];
+  auto prefetch = [&](int tile, int chunk) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int iy0 = ty * C::TROWS * S - a.pad_y, ix0 = tx * C::TCOLS * S - a.pad_x;
+    const float* xb = a.x + (long)n * a.hin * a.win * CIN + chunk * C::CINB;
+#pragma unroll
+    for (int it = 0; it < C::NLOAD; ++it) {
+      const int idx = threadIdx.x + it * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < C::NITEMS) {
+        const int vv = idx % C::NV, pix = idx / C::NV;
+        const int c = pix % C::IN_COLS, r = pix / C::IN_COLS;
+        const int iy = iy0 + r, ix = ix0 + c;
+        if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
+          v = *(const float4*)(xb + ((long)iy * a.win + ix) * CIN + vv * 4);
+      }
+      pre[it] = v;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < C::NLOAD; ++it) {
+      const int idx = threadIdx.x + it * 256;
+      if (idx < C::NITEMS) {
+        const int vv = idx % C::NV, pix = idx / C::NV;
+        *(float4*)(xl + pix * C::CS + vv * 4) = pre[it];
+      }
+    }
+  };
+
+  int tile = t_lo + rank;
+  if (tile < t_hi) prefetch(tile, 0);
+  f32x4 acc[C::MT][C::NT];
+
+  while (tile < t_hi) {
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
+      __syncthreads();  // everyone finished reading the previous LDS tile (and the weights are in)
+      stage();
+      __syncthreads();
+      // issue the next halo tile's loads now; they land while the MFMAs below run
+      if (chunk + 1 < C::NCHUNK) prefetch(tile, chunk + 1);
+      else if (tile + per < t_hi) prefetch(tile + per, 0);
+
+#pragma unroll
+      for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+          const int tap = ky * KW + kx;
+#pragma unroll
+          for (int q = 0; q < C::NQ; ++q) {
+            float av[C::MT][4], bv[C::NT][4];
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) {
+              const int row = wave * C::MT + mt;
+              const float* p = xl + (((row * S + ky) * C::IN_COLS) + (li * S + kx)) * C::CS + lg * C::KG + q * C::E;
+              if (C::E == 4) {
+                const f32x4 t = *(const f32x4*)p;
+                av[mt][0] = t[0]; av[mt][1] = t[1]; av[mt][2] = t[2]; av[mt][3] = t[3];
+              } else {
+#pragma unroll
+                for (int e = 0; e < C::E; ++e) av[mt][e] = p[e];
+              }
+            }
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt) {
+              const float* p = wl + ((((long)(tap * C::NCHUNK + chunk) * 4 + lg) * C::NQ + q) * COUT + nt * 16 + li) * C::E;
+              if (C::E == 4) {
+                const f32x4 t = *(const f32x4*)p;
+                bv[nt][0] = t[0]; bv[nt][1] = t[1]; bv[nt][2] = t[2]; bv[nt][3] = t[3];
+              } else {
+#pragma unroll
+                for (int e = 0; e < C::E; ++e) bv[nt][e] = p[e];
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < C::E; ++e)
+#pragma unroll
+              for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < C::NT; ++nt)
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], bv[nt][e], acc[mt][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    // epilogue: bias + activation + store (+ GroupNorm statistics)
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt) {
+      const int vy = ty * C::TROWS + wave * C::MT + mt;
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) {
+        const int co = nt * 16 + li;
+        const float bval = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int vx = tx * C::TCOLS + lg * 4 + r;
+          if (vy < a.hv && vx < a.wv) {
+            float v = act_apply(acc[mt][nt][r] + bval, a.act);
+            a.y[(((long)n * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * COUT + co] = v;
+            s1 += (double)v;
+            s2 += (double)v * (double)v;
+          }
+        }
+      }
+    }
+    if (a.stats) {
+      const double r1 = block_sum_d(s1, red);
+      const double r2 = block_sum_d(s2, red);
+      if (threadIdx.x == 0) {
+        atomic_add_d(a.stats + 2 * n, r1);
+        atomic_add_d(a.stats + 2 * n + 1, r2);
+      }
+    }
+    tile += per;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+//   mode 0: forward          w'(tap=(ky,kx), c=ci, co)            = w[co][ci][ky][kx]
+//   mode 1: stride-1 dgrad   w'(tap=(ky,kx), c=co_orig, co'=ci)   = w[co_orig][ci][K-1-ky][K-1-kx]
+//   mode 2: stride-2 k4 dgrad phase (py,px), 2x2 taps (dy,dx):    = w[co_orig][ci][3-py-2dy][3-px-2dx]
+// `cin_real` <= cin_pad: extra input channels of the padded layout get zero weights (mode 0 only).
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int cout, int cin_real,
+                                    int cin_pad, int k, int mode, int py, int px) {
+  const int kk = (mode == 2) ? 2 : k;
+  const int ncin = (mode == 0) ? cin_pad : cout;   // channels of the packed conv's input
+  const int ncout = (mode == 0) ? cout : cin_real;  // and output
+  const long total = (long)kk * kk * ncin * ncout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % ncout);
+    long r = i / ncout;
+    const int c = (int)(r % ncin);
+    const int tap = (int)(r / ncin);
+    const int ky = tap / kk, kx = tap % kk;
+    float v;
+    if (mode == 0) {
+      v = (c < cin_real) ? w[(((long)co * cin_real + c) * k + ky) * k + kx] : 0.f;
+    } else if (mode == 1) {
+      v = w[(((long)c * cin_real + co) * k + (k - 1 - ky)) * k + (k - 1 - kx)];
+    } else {
+      v = w[(((long)c * cin_real + co) * k + (3 - py - 2 * ky)) * k + (3 - px - 2 * kx)];
+    }
+    packed[packed_w_offset(tap, c, co, ncin, ncout)] = v;
+  }
+}
+
+extern "C" int dis_conv2d_pack_weights(const float* w_oihw, float* packed, int cout, int cin_real, int cin_pad,
+                                       int k, int mode, void* stream) {
+  if (!w_oihw || !packed) return DIS_ERR_NULL;
+  if (cout <= 0 || cin_real <= 0 || cin_pad < cin_real || k <= 0) return DIS_ERR_BAD_SHAPE;
+  if (mode < 0 || mode > 1) return DIS_ERR_UNSUPPORTED;
+  if (mode == 1 && cin_pad != cin_real) return DIS_ERR_UNSUPPORTED;
+  long total = (long)k * k * cin_pad * cout;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     packed, cout, cin_real, cin_pad, k, mode, 0, 0);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch plumbing
+// ------------------------------------------------------------------------------------------------
+static int g_num_cu = 0;
+static int num_cus() {
+  if (g_num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_num_cu = prop.multiProcessorCount;
+    if (g_num_cu <= 0) g_num_cu = 256;
+  }
+  return g_num_cu;
+}
+
+template <int CIN, int COUT, int KH, int KW, int S>
+static int launch_conv(const ConvArgs& a, hipStream_t s) {
+  using C = ConvCfg<CIN, COUT, KH, KW, S>;
+  static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+  static bool attr_set = false;
+  auto kern = conv_fwd_kernel<CIN, COUT, KH, KW, S>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int tiles_x = (a.wv + C::TCOLS - 1) / C::TCOLS, tiles_y = (a.hv + C::TROWS - 1) / C::TROWS;
+  const long ntiles = (long)a.n * tiles_y * tiles_x;
+  int per_cu = (160 * 1024) / C::LDS_BYTES;
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  long grid = (long)num_cus() * per_cu;
+  if (grid > ntiles) grid = ntiles;
+  if (grid >= 8) grid -= grid % 8;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, s, a);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+#define CONV_CASE(CI, CO, KH_, KW_, S_)                                      \
+  if (cin == CI && cout == CO && kh == KH_ && kw == KW_ && stride == S_) \
+    return launch_conv<CI, CO, KH_, KW_, S_>(a, s);
+
+static int dispatch_conv(const ConvArgs& a, int cin, int cout, int kh, int kw, int stride, hipStream_t s) {
+  CONV_CASE(4, 16, 4, 4, 2)
+  CONV_CASE(4, 16, 3, 3, 1)
+  CONV_CASE(16, 16, 3, 3, 1)
+  CONV_CASE(16, 32, 3, 3, 1)
+  CONV_CASE(32, 16, 3, 3, 1)
+  CONV_CASE(32, 32, 3, 3, 1)
+  CONV_CASE(48, 32, 3, 3, 1)
+  CONV_CASE(32, 48, 3, 3, 1)
+  CONV_CASE(96, 32, 3, 3, 1)
+  CONV_CASE(32, 96, 3, 3, 1)
+  CONV_CASE(128, 32, 1, 1, 1)
+  CONV_CASE(32, 128, 1, 1, 1)
+  CONV_CASE(32, 32, 4, 4, 2)
+  CONV_CASE(32, 32, 2, 2, 1)
+  return DIS_ERR_UNSUPPORTED;
+}
+
+extern "C" int dis_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, double* stats,
+                              int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act,
+                              void* stream) {
+  if (!x || !w_packed || !y) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || k <= 0 || stride <= 0 || pad < 0)
+    return DIS_ERR_BAD_SHAPE;
+  const int hout = (hin + 2 * pad - k) / stride + 1, wout = (win + 2 * pad - k) / stride + 1;
+  if (hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
+  ConvArgs a;
+  a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.stats = stats;
+  a.n = n; a.hin = hin; a.win = win; a.hv = hout; a.wv = wout; a.pad_y = pad; a.pad_x = pad;
+  a.hf = hout; a.wf = wout; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0; a.act = act;
+  return dispatch_conv(a, cin, cout, k, k, stride, (hipStream_t)stream);
+}
+
+// Input gradient of a k4/stride-2/pad-1 convolution: four 2x2 stride-1 phase convolutions of gy on the
+// matrix cores, each writing one parity class of gx.  workspace: 4 * (4*cin*cout) floats.
+extern "C" int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, float* gx, float* workspace, int n,
+                                        int hin, int win, int cin, int cout, int k, int stride, int pad,
+                                        void* stream) {
+  if (!gy || !w_oihw || !gx || !workspace) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0) return DIS_ERR_BAD_SHAPE;
+  if (k != 4 || stride != 2 || pad != 1 || (hin & 1) || (win & 1)) return DIS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int hout = hin / 2, wout = win / 2;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      float* packed = workspace + (long)(py * 2 + px) * 4 * cin * cout;
+      long total = 4L * cin * cout;
+      hipLaunchKernelGGL(pack_weights_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, w_oihw, packed, cout,
+                         cin, cin, k, 2, py, px);
+      ConvArgs a;
+      a.x = gy; a.w = packed; a.bias = nullptr; a.y = gx; a.stats = nullptr;
+      a.n = n; a.hin = hout; a.win = wout; a.hv = hout; a.wv = wout;
+      a.pad_y = (py == 0) ? 1 : 0; a.pad_x = (px == 0) ? 1 : 0;
+      a.hf = hin; a.wf = win; a.osy = 2; a.ooy = py; a.osx = 2; a.oox = px; a.act = DIS_ACT_NONE;
+      int rc = dispatch_conv(a, cout, cin, 2, 2, 1, s);
+      if (rc != DIS_OK) return rc;
+    }
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient:  dW[(tap,ci)][co] = sum_pixels X[pixel+tap][ci] * G[pixel][co]
+// GEMM view: M = (tap,ci) rows, N = cout, K = pixels.  Each wave owns a disjoint pixel subset of the
+// tile and keeps the whole (M x N) accumulator of one cin-chunk (and one ky row when split) in registers
+// across ALL its tiles; partial results of every wave are written once and summed by a second kernel
+// (deterministic, no float atomics).
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int KH, int KW, int S>
+struct WgCfg {
+  static constexpr int CINB = (CIN % 32 == 0) ? 32 : ((CIN % 16 == 0) ? 16 : 4);
+  static constexpr int NCHUNK = CIN / CINB;
+  static constexpr bool KYSPLIT = (KH * KW * CINB * COUT) > 160 * 64;  // accumulator registers > 160
+  static constexpr int KHB = KYSPLIT ? 1 : KH;     // tap rows handled per block
+  static constexpr int NSPLIT = KYSPLIT ? KH : 1;
+  static constexpr int MROWS = KHB * KW * CINB;
+  static constexpr int MB = (MROWS + 15) / 16;
+  static constexpr int NB = COUT / 16;
+  static constexpr int TROWS = (S == 1) ? 8 : 4;
+  static constexpr int RPW = TROWS / 4;            // tile rows per wave
+  static constexpr int STEPS = RPW * 4;            // MFMA k-steps per wave per tile (16 px per row / 4)
+  static constexpr int IN_ROWS = (TROWS - 1) * S + KHB;
+  static constexpr int IN_COLS = 15 * S + KW;
+  static constexpr int CS = (CINB >= 16) ? CINB + 4 : CINB;
+  static constexpr int GS = COUT + 4;
+  static constexpr int IN_FLOATS = IN_ROWS * IN_COLS * CS;
+  static constexpr int G_FLOATS = TROWS * 16 * GS;
+  static constexpr int LDS_BYTES = (IN_FLOATS + G_FLOATS) * 4;
+  static constexpr int NV = CINB / 4;
+  static constexpr int PART = MB * 16 * COUT;      // floats per partial slab
+};
+
+struct WgArgs {
+  const float* x;
+  const float* gy;
+  float* part;  // [worker][wave][chunk][split][PART]
+  int n, hin, win, hout, wout, pad;
+};
+
+template <int CIN, int COUT, int KH, int KW, int S>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
+  using C = WgCfg<CIN, COUT, KH, KW, S>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xl = smem;
+  float* gl = smem + C::IN_FLOATS;
+  const int chunk = blockIdx.y, split = blockIdx.z;
+  const int ky0 = C::KYSPLIT ? split : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + C::TROWS - 1) / C::TROWS;
+  const int ntiles = a.n * tiles_y * tiles_x;
+
+  // per-lane A-row constants: m = mb*16 + li  ->  (tap, ci)
+  int aoff[C::MB];
+  bool aval[C::MB];
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb) {
+    const int m = mb * 16 + li;
+    aval[mb] = m < C::MROWS;
+    const int mm = aval[mb] ? m : 0;
+    const int tap = mm / C::CINB, ci = mm % C::CINB;
+    const int ky = tap / KW, kx = tap % KW;
+    aoff[mb] = (ky * C::IN_COLS + kx) * C::CS + ci;
+  }
+  f32x4 acc[C::MB][C::NB];
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int iy0 = ty * C::TROWS * S - a.pad + ky0, ix0 = tx * 16 * S - a.pad;
+    __syncthreads();
+    const float* xb = a.x + (long)n * a.hin * a.win * CIN + chunk * C::CINB;
+    for (int idx = threadIdx.x; idx < C::IN_ROWS * C::IN_COLS * C::NV; idx += 256) {
+      const int vv = idx % C::NV, pix = idx / C::NV;
+      const int c = pix % C::IN_COLS, r = pix / C::IN_COLS;
+      const int iy = iy0 + r, ix = ix0 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = *(const float4*)(xb + ((long)iy * a.win + ix) * CIN + vv * 4);
+      *(float4*)(xl + pix * C::CS + vv * 4) = v;
+    }
+    const float* gb = a.gy + (long)n * a.hout * a.wout * COUT;
+    for (int idx = threadIdx.x; idx < C::TROWS * 16 * (COUT / 4); idx += 256) {
+      const int vv = idx % (COUT / 4), pix = idx / (COUT / 4);
+      const int c = pix % 16, r = pix / 16;
+      const int oy = ty * C::TROWS + r, ox = tx * 16 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oy < a.hout && ox < a.wout) v = *(const float4*)(gb + ((long)oy * a.wout + ox) * COUT + vv * 4);
+      *(float4*)(gl + pix * C::GS + vv * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < C::STEPS; ++st) {
+      const int pk = wave * (C::RPW * 16) + st * 4 + lg;  // pixel inside the tile owned by this k-slot
+      const int pr = pk >> 4, pc = pk & 15;
+      const float* xp = xl + ((pr * S) * C::IN_COLS + pc * S) * C::CS;
+      const float* gp = gl + pk * C::GS + li;
+      float bv[C::NB];
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb) bv[nb] = gp[nb * 16];
+#pragma unroll
+      for (int mb = 0; mb < C::MB; ++mb) {
+        float av = xp[aoff[mb]];
+        if (!aval[mb]) av = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nb], acc[mb][nb], 0, 0, 0);
+      }
+    }
+  }
+  // partial slab of this wave: [m][co]
+  float* out = a.part + ((((long)blockIdx.x * 4 + wave) * C::NCHUNK + chunk) * C::NSPLIT + split) * C::PART;
+#pragma unroll
+  for (int mb = 0; mb < C::MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(mb * 16 + lg * 4 + r) * COUT + nb * 16 + li] = acc[mb][nb][r];
+}
+
+// sum the partial slabs and scatter into OIHW
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int nslabs, int cinb,
+                                    int nchunk, int nsplit, int khb, int kw, int kh, int cout, int cin_real,
+                                    int partsz) {
+  const int mrows = khb * kw * cinb;
+  const long total = (long)nchunk * nsplit * mrows * cout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % cout);
+    long r = i / cout;
+    const int m = (int)(r % mrows);
+    r /= mrows;
+    const int split = (int)(r % nsplit);
+    const int chunk = (int)(r / nsplit);
+    const long stride = (long)nchunk * nsplit * partsz;
+    const float* p = part + ((long)chunk * nsplit + split) * partsz + (long)m * cout + co;
+    float s = 0.f;
+    for (int k = 0; k < nslabs; ++k) s += p[k * stride];
+    const int tap = m / cinb, ci = chunk * cinb + m % cinb;
+    const int ky = (nsplit > 1 ? split : 0) + tap / kw, kx = tap % kw;
+    if (ci < cin_real) gw[(((long)co * cin_real + ci) * kh + ky) * kw + kx] = s;
+  }
+}
+
+// bias gradient: per-channel sum of gy over all pixels (fp64 block partials + atomics, then cast)
+__global__ void bias_grad_kernel(const float* __restrict__ gy, double* __restrict__ acc, long pixels, int cout) {
+  // thread t handles channel t % cout; blockDim.x is a multiple of cout
+  const int co = threadIdx.x % cout;
+  const int lanes_per = blockDim.x / cout;
+  const int sub = threadIdx.x / cout;
+  double s = 0.0;
+  for (long p = (long)blockIdx.x * lanes_per + sub; p < pixels; p += (long)gridDim.x * lanes_per)
+    s += (double)gy[p * cout + co];
+  __shared__ double sm[256];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (sub == 0) {
+    double t = 0.0;
+    for (int k = 0; k < lanes_per; ++k) t += sm[k * cout + co];
+    atomic_add_d(acc + co, t);
+  }
+}
+__global__ void cast_d2f_kernel(const double* __restrict__ a, float* __restrict__ o, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = (float)a[i];
+}
+
+#define WG_WORKERS 256
+
+template <int CIN, int COUT, int KH, int KW, int S>
+static long wgrad_ws(void) {
+  using C = WgCfg<CIN, COUT, KH, KW, S>;
+  return (long)WG_WORKERS * 4 * C::NCHUNK * C::NSPLIT * C::PART;
+}
+
+template <int CIN, int COUT, int KH, int KW, int S>
+static int launch_wgrad(const WgArgs& a, float* gw, int cin_real, hipStream_t s) {
+  using C = WgCfg<CIN, COUT, KH, KW, S>;
+  static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+  static bool attr_set = false;
+  auto kern = conv_wgrad_kernel<CIN, COUT, KH, KW, S>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + C::TROWS - 1) / C::TROWS;
+  const long ntiles = (long)a.n * tiles_y * tiles_x;
+  int workers = WG_WORKERS;
+  if (workers > ntiles) workers = (int)ntiles;
+  hipLaunchKernelGGL(kern, dim3(workers, C::NCHUNK, C::NSPLIT), dim3(256), C::LDS_BYTES, s, a);
+  const long total = (long)C::NCHUNK * C::NSPLIT * C::MROWS * COUT;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)a.part, gw,
+                     workers * 4, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, KW, KH, COUT, cin_real, C::PART);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+#define WG_CASE(CI, CO, K_, S_) \
+  if (cin == CI && cout == CO && k == K_ && stride == S_) return launch_wgrad<CI, CO, K_, K_, S_>(a, gw, cin_real, s);
+#define WS_CASE(CI, CO, K_, S_) \
+  if (cin == CI && cout == CO && k == K_ && stride == S_) return wgrad_ws<CI, CO, K_, K_, S_>();
+
+static int dispatch_wgrad(const WgArgs& a, float* gw, int cin_real, int cin, int cout, int k, int stride,
+                          hipStream_t s) {
+  WG_CASE(4, 16, 4, 2)
+  WG_CASE(4, 16, 3, 1)
+  WG_CASE(16, 16, 3, 1)
+  WG_CASE(16, 32, 3, 1)
+  WG_CASE(32, 16, 3, 1)
+  WG_CASE(32, 32, 3, 1)
+  WG_CASE(48, 32, 3, 1)
+  WG_CASE(96, 32, 3, 1)
+  WG_CASE(128, 32, 1, 1)
+  WG_CASE(32, 32, 4, 2)
+  return DIS_ERR_UNSUPPORTED;
+}
+
+extern "C" long dis_conv2d_wgrad_workspace(int cin, int cout, int k, int stride) {
+  WS_CASE(4, 16, 4, 2)
+  WS_CASE(4, 16, 3, 1)
+  WS_CASE(16, 16, 3, 1)
+  WS_CASE(16, 32, 3, 1)
+  WS_CASE(32, 16, 3, 1)
+  WS_CASE(32, 32, 3, 1)
+  WS_CASE(48, 32, 3, 1)
+  WS_CASE(96, 32, 3, 1)
+  WS_CASE(128, 32, 1, 1)
+  WS_CASE(32, 32, 4, 2)
+  return -1;
+}
+
+extern "C" int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace,
+                                double* bias_acc, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k,
+                                int stride, int pad, void* stream) {
+  if (!x || !gy || !grad_w || !workspace) return DIS_ERR_NULL;
+  if (grad_b && !bias_acc) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0 || cin_pad <= 0 || cin_real <= 0 || cin_real > cin_pad || cout <= 0)
+    return DIS_ERR_BAD_SHAPE;
+  const int hout = (hin + 2 * pad - k) / stride + 1, wout = (win + 2 * pad - k) / stride + 1;
+  if (hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  WgArgs a;
+  a.x = x; a.gy = gy; a.part = workspace; a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
+  int rc = dispatch_wgrad(a, grad_w, cin_real, cin_pad, cout, k, stride, s);
+  if (rc != DIS_OK) return rc;
+  if (grad_b) {
+    if (256 % cout != 0) return DIS_ERR_UNSUPPORTED;
+    const long pixels = (long)n * hout * wout;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(dis_ew_grid(pixels * cout, 256 * 8)), dim3(256), 0, s, gy, bias_acc,
+                       pixels, cout);
+    hipLaunchKernelGGL(cast_d2f_kernel, dim3(1), dim3(64), 0, s, (const double*)bias_acc, grad_b, cout);
+    DIS_CHECK_LAUNCH();
+  }
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// disparity head: Conv2d(cin,1,3,pad 1) + alpha*sigmoid(x-offset)  (bandwidth-bound, VALU)
+// ------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                const float* __restrict__ b, float* __restrict__ y, int n, int h, int wd,
+                                float alpha, float offset) {
+  __shared__ float ws[9 * CIN];
+  for (int i = threadIdx.x; i < 9 * CIN; i += blockDim.x) {
+    const int tap = i / CIN, ci = i % CIN;
+    ws[i] = w[ci * 9 + tap];  // (1,cin,3,3) -> [tap][ci]
+  }
+  __syncthreads();
+  const long total = (long)n * h * wd;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % wd), py = (int)((i / wd) % h);
+    const long nb = i / ((long)h * wd);
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = py + ky - 1;
+      if (iy < 0 || iy >= h) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = px + kx - 1;
+        if (ix < 0 || ix >= wd) continue;
+        const float4* p = (const float4*)(x + ((nb * h + iy) * wd + ix) * CIN);
+        const float* wt = ws + (ky * 3 + kx) * CIN;
+#pragma unroll
+        for (int v = 0; v < CIN / 4; ++v) {
+          const float4 q = p[v];
+          acc += q.x * wt[v * 4] + q.y * wt[v * 4 + 1] + q.z * wt[v * 4 + 2] + q.w * wt[v * 4 + 3];
+        }
+      }
+    }
+    const float z = acc + b[0] - offset;
+    y[i] = alpha / (1.f + expf(-z));
+  }
+}
+
+// pre-sigmoid gradient plane
+__global__ void head_gpre_kernel(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gp,
+                                 float alpha, long count) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float s = y[i] / alpha;
+    gp[i] = gy[i] * alpha * s * (1.f - s);
+  }
+}
+
+// gx (gather over the 9 taps) and the weight/bias reductions (per-thread fp32 partials -> fp64 atomics)
+template <int CIN>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ gp, float* __restrict__ gx,
+                                                         double* __restrict__ acc, int n, int h, int wd) {
+  __shared__ float ws[9 * CIN];
+  __shared__ double red[4];
+  for (int i = threadIdx.x; i < 9 * CIN; i += blockDim.x) {
+    const int tap = i / CIN, ci = i % CIN;
+    ws[i] = w[ci * 9 + tap];
+  }
+  __syncthreads();
+  float gw[9][CIN];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) gw[t][c] = 0.f;
+  float gb = 0.f;
+  const long total = (long)n * h * wd;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % wd), py = (int)((i / wd) % h);
+    const long nb = i / ((long)h * wd);
+    const float g = gp[i];
+    gb += g;
+    float gxa[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) gxa[c] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        // weight gradient: gw[tap][ci] += gpre[p] * x[p + tap - 1][ci]
+        const int iy = py + ky - 1, ix = px + kx - 1;
+        if (iy >= 0 && iy < h && ix >= 0 && ix < wd) {
+          const float* p = x + ((nb * h + iy) * wd + ix) * CIN;
+#pragma unroll
+          for (int c = 0; c < CIN; ++c) gw[ky * 3 + kx][c] += g * p[c];
+        }
+        // input gradient: gx[p][ci] += gpre[p - tap + 1] * w[tap][ci]
+        const int oy = py - ky + 1, ox = px - kx + 1;
+        if (oy >= 0 && oy < h && ox >= 0 && ox < wd) {
+          const float go = gp[(nb * h + oy) * wd + ox];
+          const float* wt = ws + (ky * 3 + kx) * CIN;
+#pragma unroll
+          for (int c = 0; c < CIN; ++c) gxa[c] += go * wt[c];
+        }
+      }
+    }
+    float4* o = (float4*)(gx + i * CIN);
+#pragma unroll
+    for (int v = 0; v < CIN / 4; ++v) o[v] = make_float4(gxa[v * 4], gxa[v * 4 + 1], gxa[v * 4 + 2], gxa[v * 4 + 3]);
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      const double r = block_sum_d((double)gw[t][c], red);
+      if (threadIdx.x == 0) atomic_add_d(acc + c * 9 + t, r);
+    }
+  const double rb = block_sum_d((double)gb, red);
+  if (threadIdx.x == 0) atomic_add_d(acc + 9 * CIN, rb);
+}
+
+extern "C" int dis_disp_head_fwd(const float* x, const float* w, const float* b, float* y, int n, int h, int wd,
+                                 int cin, float alpha, float offset, void* stream) {
+  if (!x || !w || !b || !y) return DIS_ERR_NULL;
+  if (n <= 0 || h <= 0 || wd <= 0) return DIS_ERR_BAD_SHAPE;
+  if (cin != 16) return DIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(head_fwd_kernel<16>, dim3(dis_ew_grid((long)n * h * wd, 256)), dim3(256), 0, (hipStream_t)stream,
+                     x, w, b, y, n, h, wd, alpha, offset);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_disp_head_bwd(const float* x, const float* w, const float* y, const float* gy, float* gx,
+                                 float* grad_w, float* grad_b, float* workspace, double* acc, int n, int h, int wd,
+                                 int cin, float alpha, void* stream) {
+  if (!x || !w || !y || !gy || !gx || !grad_w || !grad_b || !workspace || !acc) return DIS_ERR_NULL;
+  if (n <= 0 || h <= 0 || wd <= 0) return DIS_ERR_BAD_SHAPE;
+  if (cin != 16) return DIS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)n * h * wd;
+  hipLaunchKernelGGL(head_gpre_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, y, gy, workspace, alpha, total);
+  int grid = dis_ew_grid(total, 256);
+  if (grid > 512) grid = 512;
+  hipLaunchKernelGGL(head_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, w, (const float*)workspace, gx, acc, n, h, wd);
+  hipLaunchKernelGGL(cast_d2f_kernel, dim3(1), dim3(256), 0, s, (const double*)acc, grad_w, 9 * cin);
+  hipLaunchKernelGGL(cast_d2f_kernel, dim3(1), dim3(64), 0, s, (const double*)(acc + 9 * cin), grad_b, 1);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}

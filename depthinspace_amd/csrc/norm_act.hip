@@ -1,0 +1,258 @@
+// GroupNorm(num_groups=1) and activation kernels, nhwc.  Bandwidth-bound elementwise / reduction work:
+// float4 per lane, per-sample statistics in fp64 (sum / sum of squares accumulated with fp64 atomics).
+#include "common.h"
+
+__global__ void act_bwd_kernel(const float4* __restrict__ gy, const float4* __restrict__ y, float4* __restrict__ gp,
+                               int act, long count4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count4; i += (long)gridDim.x * blockDim.x) {
+    const float4 g = gy[i], v = y[i];
+    gp[i] = make_float4(g.x * act_grad_from_out(v.x, act), g.y * act_grad_from_out(v.y, act),
+                        g.z * act_grad_from_out(v.z, act), g.w * act_grad_from_out(v.w, act));
+  }
+}
+extern "C" int dis_act_bwd(const float* gy, const float* y, float* gpre, int act, long count, void* stream) {
+  if (!gy || !y || !gpre) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  if (count % 4 != 0) return DIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(dis_ew_grid(count / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)gy, (const float4*)y, (float4*)gpre, act, count / 4);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+__global__ void add_act_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ y,
+                               int act, long count4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count4; i += (long)gridDim.x * blockDim.x) {
+    const float4 p = a[i], q = b[i];
+    y[i] = make_float4(act_apply(p.x + q.x, act), act_apply(p.y + q.y, act), act_apply(p.z + q.z, act),
+                       act_apply(p.w + q.w, act));
+  }
+}
+extern "C" int dis_add_act_fwd(const float* a, const float* b, float* y, int act, long count, void* stream) {
+  if (!a || !b || !y) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  if (count % 4 != 0) return DIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(add_act_kernel, dim3(dis_ew_grid(count / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)a, (const float4*)b, (float4*)y, act, count / 4);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistics
+// ------------------------------------------------------------------------------------------------
+__global__ void gn_stats_kernel(const float4* __restrict__ x, double* __restrict__ stats, long per4) {
+  __shared__ double sm[8];
+  const int n = blockIdx.y;
+  const float4* p = x + (long)n * per4;
+  double s1 = 0.0, s2 = 0.0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = p[i];
+    s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  const double r1 = block_sum_d(s1, sm), r2 = block_sum_d(s2, sm);
+  if (threadIdx.x == 0) {
+    atomic_add_d(stats + 2 * n, r1);
+    atomic_add_d(stats + 2 * n + 1, r2);
+  }
+}
+extern "C" int dis_gn_stats(const float* x, double* stats, int n, long per_sample, void* stream) {
+  if (!x || !stats) return DIS_ERR_NULL;
+  if (n <= 0 || per_sample <= 0) return DIS_ERR_BAD_SHAPE;
+  if (per_sample % 4 != 0) return DIS_ERR_UNSUPPORTED;
+  int gx = dis_ew_grid(per_sample / 4, 256);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, (const float4*)x, stats,
+                     per_sample / 4);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+#define GN_MAXC 128
+
+__device__ __forceinline__ void gn_moments(const double* stats, int n, double m, float eps, float* mean, float* rstd) {
+  const double mu = stats[2 * n] / m;
+  double var = stats[2 * n + 1] / m - mu * mu;
+  if (var < 0.0) var = 0.0;
+  *mean = (float)mu;
+  *rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = act(x*scale_c + shift_c (+ residual)),  scale_c = rstd*gamma_c, shift_c = beta_c - scale_c*mean
+__global__ void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ res, float* __restrict__ y, long hw, int c, int act,
+                                float eps) {
+  __shared__ float sc[GN_MAXC], sh[GN_MAXC];
+  const int n = blockIdx.y;
+  if (threadIdx.x < c) {
+    float mean, rstd;
+    gn_moments(stats, n, (double)hw * c, eps, &mean, &rstd);
+    const float s = rstd * gamma[threadIdx.x];
+    sc[threadIdx.x] = s;
+    sh[threadIdx.x] = beta[threadIdx.x] - s * mean;
+  }
+  __syncthreads();
+  const int cg = c >> 2;
+  const long per4 = hw * cg;
+  const float4* xp = (const float4*)(x + (long)n * hw * c);
+  const float4* rp = res ? (const float4*)(res + (long)n * hw * c) : nullptr;
+  float4* yp = (float4*)(y + (long)n * hw * c);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per4; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg) * 4;
+    const float4 v = xp[i];
+    float4 o = make_float4(v.x * sc[g] + sh[g], v.y * sc[g + 1] + sh[g + 1], v.z * sc[g + 2] + sh[g + 2],
+                           v.w * sc[g + 3] + sh[g + 3]);
+    if (rp) {
+      const float4 r = rp[i];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    yp[i] = make_float4(act_apply(o.x, act), act_apply(o.y, act), act_apply(o.z, act), act_apply(o.w, act));
+  }
+}
+extern "C" int dis_gn_apply(const float* x, const double* stats, const float* gamma, const float* beta,
+                            const float* residual, float* y, int n, long hw, int c, int act, float eps,
+                            void* stream) {
+  if (!x || !stats || !gamma || !beta || !y) return DIS_ERR_NULL;
+  if (n <= 0 || hw <= 0 || c <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c % 4 != 0 || c > GN_MAXC) return DIS_ERR_UNSUPPORTED;
+  int gx = dis_ew_grid(hw * (c / 4), 256);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, residual,
+                     y, hw, c, act, eps);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// backward pass 1: per-sample s1 = sum g*gamma, s2 = sum g*gamma*xhat ; per-channel dgamma, dbeta
+__global__ void gn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                     const float* __restrict__ x, const double* __restrict__ stats,
+                                     const float* __restrict__ gamma, double* __restrict__ red,
+                                     double* __restrict__ gparam, long hw, int c, int act, float eps) {
+  __shared__ float gam[GN_MAXC];
+  __shared__ double sm[8];
+  __shared__ float pg[256 * 4], pb[256 * 4];
+  const int n = blockIdx.y;
+  float mean, rstd;
+  gn_moments(stats, n, (double)hw * c, eps, &mean, &rstd);
+  if (threadIdx.x < c) gam[threadIdx.x] = gamma[threadIdx.x];
+  __syncthreads();
+  const int cg = c >> 2;
+  const long per4 = hw * cg;
+  const float4* gp = (const float4*)(gy + (long)n * hw * c);
+  const float4* yp = (const float4*)(y + (long)n * hw * c);
+  const float4* xp = (const float4*)(x + (long)n * hw * c);
+  // blockDim.x (256) is a multiple of cg, and the grid stride is a multiple of cg: each thread keeps one
+  // channel group for its whole loop
+  const int g = (int)(threadIdx.x % cg) * 4;
+  float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+  double s1 = 0.0, s2 = 0.0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per4; i += (long)gridDim.x * blockDim.x) {
+    float4 gv = gp[i];
+    if (act != DIS_ACT_NONE) {
+      const float4 yv = yp[i];
+      gv.x *= act_grad_from_out(yv.x, act); gv.y *= act_grad_from_out(yv.y, act);
+      gv.z *= act_grad_from_out(yv.z, act); gv.w *= act_grad_from_out(yv.w, act);
+    }
+    const float4 xv = xp[i];
+    const float xh[4] = {(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
+    const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      dg[k] += ga[k] * xh[k];
+      db[k] += ga[k];
+      const float t = ga[k] * gam[g + k];
+      s1 += (double)t;
+      s2 += (double)(t * xh[k]);
+    }
+  }
+  const double r1 = block_sum_d(s1, sm), r2 = block_sum_d(s2, sm);
+  if (threadIdx.x == 0) {
+    atomic_add_d(red + 2 * n, r1);
+    atomic_add_d(red + 2 * n + 1, r2);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    pg[threadIdx.x * 4 + k] = dg[k];
+    pb[threadIdx.x * 4 + k] = db[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < c) {
+    const int grp = threadIdx.x >> 2, k = threadIdx.x & 3;
+    double a = 0.0, b = 0.0;
+    for (int t = grp; t < 256; t += cg) {
+      a += (double)pg[t * 4 + k];
+      b += (double)pb[t * 4 + k];
+    }
+    atomic_add_d(gparam + threadIdx.x, a);
+    atomic_add_d(gparam + c + threadIdx.x, b);
+  }
+}
+
+// backward pass 2: gx = rstd*(g*gamma - s1/M - xhat*s2/M); gres = g
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                    const float* __restrict__ x, const double* __restrict__ stats,
+                                    const float* __restrict__ gamma, const double* __restrict__ red,
+                                    float* __restrict__ gx, float* __restrict__ gres, long hw, int c, int act,
+                                    float eps) {
+  __shared__ float gam[GN_MAXC];
+  const int n = blockIdx.y;
+  float mean, rstd;
+  const double m = (double)hw * c;
+  gn_moments(stats, n, m, eps, &mean, &rstd);
+  const float a1 = (float)(red[2 * n] / m), a2 = (float)(red[2 * n + 1] / m);
+  if (threadIdx.x < c) gam[threadIdx.x] = gamma[threadIdx.x];
+  __syncthreads();
+  const int cg = c >> 2;
+  const long per4 = hw * cg;
+  const float4* gp = (const float4*)(gy + (long)n * hw * c);
+  const float4* yp = (const float4*)(y + (long)n * hw * c);
+  const float4* xp = (const float4*)(x + (long)n * hw * c);
+  float4* op = (float4*)(gx + (long)n * hw * c);
+  float4* rp = gres ? (float4*)(gres + (long)n * hw * c) : nullptr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per4; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg) * 4;
+    float4 gv = gp[i];
+    if (act != DIS_ACT_NONE) {
+      const float4 yv = yp[i];
+      gv.x *= act_grad_from_out(yv.x, act); gv.y *= act_grad_from_out(yv.y, act);
+      gv.z *= act_grad_from_out(yv.z, act); gv.w *= act_grad_from_out(yv.w, act);
+    }
+    if (rp) rp[i] = gv;
+    const float4 xv = xp[i];
+    float4 o;
+    o.x = rstd * (gv.x * gam[g] - a1 - ((xv.x - mean) * rstd) * a2);
+    o.y = rstd * (gv.y * gam[g + 1] - a1 - ((xv.y - mean) * rstd) * a2);
+    o.z = rstd * (gv.z * gam[g + 2] - a1 - ((xv.z - mean) * rstd) * a2);
+    o.w = rstd * (gv.w * gam[g + 3] - a1 - ((xv.w - mean) * rstd) * a2);
+    op[i] = o;
+  }
+}
+__global__ void gn_param_cast_kernel(const double* __restrict__ acc, float* __restrict__ gg, float* __restrict__ gb,
+                                     int c) {
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    gg[i] = (float)acc[i];
+    gb[i] = (float)acc[c + i];
+  }
+}
+
+extern "C" int dis_gn_apply_bwd(const float* gy, const float* y, const float* x, const double* stats,
+                                const float* gamma, float* gx, float* gres, float* grad_gamma, float* grad_beta,
+                                double* red, double* gparam_acc, int n, long hw, int c, int act, float eps,
+                                void* stream) {
+  if (!gy || !x || !stats || !gamma || !gx || !grad_gamma || !grad_beta || !red || !gparam_acc) return DIS_ERR_NULL;
+  if (act != DIS_ACT_NONE && !y) return DIS_ERR_NULL;
+  if (n <= 0 || hw <= 0 || c <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c % 4 != 0 || c > GN_MAXC || 256 % (c / 4) != 0) return DIS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  int gxg = dis_ew_grid(hw * (c / 4), 256);
+  if (gxg > 256) gxg = 256;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(gxg, n), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma, red,
+                     gparam_acc, hw, c, act, eps);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gxg * 2, n), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma,
+                     (const double*)red, gx, gres, hw, c, act, eps);
+  hipLaunchKernelGGL(gn_param_cast_kernel, dim3(1), dim3(128), 0, s, (const double*)gparam_acc, grad_gamma, grad_beta, c);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}

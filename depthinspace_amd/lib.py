@@ -31,6 +31,7 @@ SIGS = {
     'dis_geo_loss_fwd': 'ppppppppppppp' + 'f' + 'ppp' + 'iiip',
     'dis_geo_loss_bwd': 'ppppppppp' + 'f' + 'ppppp' + 'iiip',
     'dis_pack4_nhwc': 'pppppiiip',
+    'dis_pack4_nhwc_strided': 'plplplplpiiip',
     'dis_planar_to_nhwc': 'ppiiiip',
     'dis_nhwc_to_planar': 'ppiiiip',
     'dis_resize_bilinear_nhwc_fwd': 'ppiiiiiiip',
@@ -41,11 +42,11 @@ SIGS = {
     'dis_gather_warped_feat_bwd': 'pppiiiiip',
     'dis_mf_geometry': 'pppppiipiiiip',
     'dis_mf_geometry_resize': 'ppiiiiiip',
-    'dis_conv2d_pack_weights': 'ppiiiip',
+    'dis_conv2d_pack_weights': 'ppiiiiip',
     'dis_conv2d_fwd': 'pppppiiiiiiiiip',
-    'dis_conv2d_wgrad_workspace': 'iii',
-    'dis_conv2d_wgrad': 'pppppiiiiiiiip',
-    'dis_conv2d_dgrad_strided': 'pppiiiiiiiip',
+    'dis_conv2d_wgrad_workspace': 'iiii',
+    'dis_conv2d_wgrad': 'ppppppiiiiiiiiip',
+    'dis_conv2d_dgrad_strided': 'ppppiiiiiiiip',
     'dis_disp_head_fwd': 'ppppiiiiffp',
     'dis_disp_head_bwd': 'ppppppppp' + 'iiiifp',
     'dis_act_bwd': 'pppilp',
@@ -53,7 +54,7 @@ SIGS = {
     'dis_gn_apply': 'ppppppiliifp',
     'dis_gn_apply_bwd': 'ppppp' + 'pppp' + 'pp' + 'iliifp',
     'dis_add_act_fwd': 'pppilp',
-    'dis_mask_weight_slots': 'ppplilp'.replace('lil', 'lii'),
+    'dis_mask_weight_slots': 'pppliip',
     'dis_conv3d_knn_fwd': 'ppppppppp' + 'iiiiip',
     'dis_conv3d_knn_bwd': 'ppppppp' + 'pppppp' + 'iiiiip',
     'dis_adam_step': 'pppplffffifp',

@@ -246,3 +246,349 @@ class _GeoLossDir(torch.autograd.Function):
 def geo_loss_dir(depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1, K, Kinv, clamp=-1.0):
     """K, Kinv: lib.host_floats(9).  Returns (loss, mask)."""
     return _GeoLossDir.apply(depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1, K, Kinv, clamp)
+
+
+# --------------------------------------------------------------------------------------------------
+# layout helpers (no gradient: they only touch network inputs)
+# --------------------------------------------------------------------------------------------------
+def pack4_nhwc(srcs, n, h, w):
+    """srcs: list of up to 4 (tensor, sample_stride_in_floats) or None -> (n,h,w,4) nhwc."""
+    dev = next(s[0] for s in srcs if s is not None).device
+    out = torch.empty((n, h, w, 4), dtype=torch.float32, device=dev)
+    args = []
+    for i in range(4):
+        s = srcs[i] if i < len(srcs) else None
+        if s is None:
+            args += [None, 0]
+        else:
+            args += [s[0], int(s[1])]
+    lib.call('dis_pack4_nhwc_strided', *args, out, n, h, w)
+    return out
+
+
+def planar_to_nhwc(x):
+    x = _c(x)
+    _chk(x)
+    n, c, h, w = x.shape
+    y = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    lib.call('dis_planar_to_nhwc', x, y, n, c, h, w)
+    return y
+
+
+def nhwc_to_planar(x):
+    x = _c(x)
+    _chk(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    lib.call('dis_nhwc_to_planar', x, y, n, c, h, w)
+    return y
+
+
+class _ResizePlanar(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size, align_corners, scale0, scale1, c_for_scale):
+        x = _c(x)
+        _chk(x)
+        lead = x.shape[:-2]
+        hin, win = x.shape[-2:]
+        nc = 1
+        for d in lead:
+            nc *= d
+        y = torch.empty((*lead, size[0], size[1]), dtype=torch.float32, device=x.device)
+        lib.call('dis_resize_bilinear_planar_fwd', x, y, nc, hin, win, size[0], size[1], int(align_corners),
+                 float(scale0), float(scale1), int(c_for_scale))
+        ctx.cfg = (nc, hin, win, size[0], size[1], int(align_corners), x.shape, int(c_for_scale))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        nc, hin, win, ho, wo, ac, shape, cfs = ctx.cfg
+        if cfs != 0:
+            raise RuntimeError('resize with flow scaling has no backward (flows are data)')
+        gx = torch.empty(shape, dtype=torch.float32, device=g.device)
+        lib.call('dis_resize_bilinear_planar_bwd', _c(g), gx, nc, hin, win, ho, wo, ac)
+        return gx, None, None, None, None, None
+
+
+def resize_planar(x, size, align_corners=True, flow_scale=None):
+    """bilinear resize over the last two dims of a planar tensor.  flow_scale=(sx,sy) multiplies channel 0/1
+    of a (...,2,H,W) flow tensor (reference resize_flow_like)."""
+    if flow_scale is None:
+        return _ResizePlanar.apply(x, tuple(size), align_corners, 1.0, 1.0, 0)
+    assert x.shape[-3] == 2
+    return _ResizePlanar.apply(x, tuple(size), align_corners, flow_scale[0], flow_scale[1], 2)
+
+
+class _ResizeNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size, align_corners):
+        x = _c(x)
+        _chk(x)
+        n, hin, win, c = x.shape
+        y = torch.empty((n, size[0], size[1], c), dtype=torch.float32, device=x.device)
+        lib.call('dis_resize_bilinear_nhwc_fwd', x, y, n, hin, win, size[0], size[1], c, int(align_corners))
+        ctx.cfg = (n, hin, win, size[0], size[1], c, int(align_corners))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, hin, win, ho, wo, c, ac = ctx.cfg
+        gx = torch.empty((n, hin, win, c), dtype=torch.float32, device=g.device)
+        lib.call('dis_resize_bilinear_nhwc_bwd', _c(g), gx, n, hin, win, ho, wo, c, ac)
+        return gx, None, None
+
+
+def resize_nhwc(x, size, align_corners=True):
+    return _ResizeNHWC.apply(x, tuple(size), align_corners)
+
+
+# --------------------------------------------------------------------------------------------------
+# convolution (MFMA implicit GEMM)
+# --------------------------------------------------------------------------------------------------
+def _pack_w(weight, cin_pad, mode):
+    cout, cin, k, _ = weight.shape
+    packed = torch.empty(k * k * cin_pad * cout, dtype=torch.float32, device=weight.device)
+    lib.call('dis_conv2d_pack_weights', weight, packed, cout, cin, cin_pad, k, mode)
+    return packed
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, need_dgrad):
+        x, weight = _c(x), _c(weight)
+        _chk(x, weight, bias)
+        n, hin, win, cin_pad = x.shape
+        cout, cin, k, _ = weight.shape
+        ho = (hin + 2 * pad - k) // stride + 1
+        wo = (win + 2 * pad - k) // stride + 1
+        y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+        stats = _zeros_d(2 * n, x.device) if want_stats else None
+        lib.call('dis_conv2d_fwd', x, _pack_w(weight, cin_pad, 0), bias, y, stats, n, hin, win, cin_pad, cout, k,
+                 stride, pad, act)
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        ctx.cfg = (stride, pad, act, bias is not None, need_dgrad)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, gy, _gstats):
+        x, weight, y = ctx.saved_tensors
+        stride, pad, act, has_bias, need_dgrad = ctx.cfg
+        n, hin, win, cin_pad = x.shape
+        cout, cin, k, _ = weight.shape
+        gy = _c(gy)
+        if act != ACT_NONE:
+            gpre = torch.empty_like(gy)
+            lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
+        else:
+            gpre = gy
+        gx = None
+        if need_dgrad and ctx.needs_input_grad[0]:
+            assert cin_pad == cin
+            gx = torch.empty_like(x)
+            if stride == 1:
+                lib.call('dis_conv2d_fwd', gpre, _pack_w(weight, cin, 1), None, gx, None, n, gpre.shape[1],
+                         gpre.shape[2], cout, cin, k, 1, k - 1 - pad, ACT_NONE)
+            else:
+                ws = torch.empty(16 * cin * cout, dtype=torch.float32, device=x.device)
+                lib.call('dis_conv2d_dgrad_strided', gpre, weight, gx, ws, n, hin, win, cin, cout, k, stride, pad)
+        gw = torch.empty_like(weight)
+        gb = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+        wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin_pad, cout, k, stride)
+        if wsz < 0:
+            raise lib.DisHipError(f'conv2d wgrad: unsupported shape cin={cin_pad} cout={cout} k={k} s={stride}')
+        ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
+        bacc = _zeros_d(cout, x.device) if has_bias else None
+        lib.call('dis_conv2d_wgrad', x, gpre, gw, gb, ws, bacc, n, hin, win, cin_pad, cin, cout, k, stride, pad)
+        return gx, gw, gb, None, None, None, None, None
+
+
+def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, need_dgrad=True):
+    """x nhwc (n,h,w,cin_pad>=cin); weight OIHW.  Returns (y, stats|None)."""
+    return _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad)
+
+
+class _DispHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, alpha, offset):
+        x, weight, bias = _c(x), _c(weight), _c(bias)
+        _chk(x, weight, bias)
+        n, h, w, cin = x.shape
+        y = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
+        lib.call('dis_disp_head_fwd', x, weight, bias, y, n, h, w, cin, float(alpha), float(offset))
+        ctx.save_for_backward(x, weight, y)
+        ctx.alpha = float(alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        n, h, w, cin = x.shape
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(weight)
+        gb = torch.empty(1, dtype=torch.float32, device=x.device)
+        ws = torch.empty(n * h * w, dtype=torch.float32, device=x.device)
+        acc = _zeros_d(9 * cin + 1, x.device)
+        lib.call('dis_disp_head_bwd', x, weight, y, _c(gy), gx, gw, gb, ws, acc, n, h, w, cin, ctx.alpha)
+        return gx, gw, gb, None, None
+
+
+def disp_head(x, weight, bias, alpha, offset=3.0):
+    return _DispHead.apply(x, weight, bias, alpha, offset)
+
+
+# --------------------------------------------------------------------------------------------------
+# GroupNorm(1 group) (+ residual + activation)
+# --------------------------------------------------------------------------------------------------
+class _GroupNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stats, gamma, beta, residual, act, eps):
+        x = _c(x)
+        residual = _c(residual) if residual is not None else None
+        _chk(x, gamma, beta, residual)
+        n = x.shape[0]
+        c = x.shape[-1]
+        hw = x.numel() // (n * c)
+        if stats is None:
+            stats = _zeros_d(2 * n, x.device)
+            lib.call('dis_gn_stats', x, stats, n, hw * c)
+        y = torch.empty_like(x)
+        lib.call('dis_gn_apply', x, stats, gamma, beta, residual, y, n, hw, c, act, float(eps))
+        ctx.save_for_backward(x, stats, gamma, y if act != ACT_NONE else None)
+        ctx.cfg = (n, hw, c, act, float(eps), residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, gamma, y = ctx.saved_tensors
+        n, hw, c, act, eps, has_res = ctx.cfg
+        gy = _c(gy)
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if has_res else None
+        gg = torch.empty(c, dtype=torch.float32, device=x.device)
+        gb = torch.empty(c, dtype=torch.float32, device=x.device)
+        red = _zeros_d(2 * n, x.device)
+        pacc = _zeros_d(2 * c, x.device)
+        lib.call('dis_gn_apply_bwd', gy, y, x, stats, gamma, gx, gres, gg, gb, red, pacc, n, hw, c, act, eps)
+        return gx, None, gg, gb, gres, None, None
+
+
+def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5):
+    """GroupNorm(1 group) over all but the first dim of an nhwc tensor; y = act(gn(x) (+ residual))."""
+    return _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps)
+
+
+# --------------------------------------------------------------------------------------------------
+# multi-frame: gathered/warped features, geometry, slot weighting, Conv3D
+# --------------------------------------------------------------------------------------------------
+class _GatherWarpedFeat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, flows):
+        feat, flows = _c(feat), _c(flows)
+        _chk(feat, flows)
+        tl, bs, h, w, c = feat.shape
+        assert flows.shape == (tl * tl, bs, h, w, 2), flows.shape
+        out = torch.empty((tl, bs, h, w, tl, c), dtype=torch.float32, device=feat.device)
+        lib.call('dis_gather_warped_feat_fwd', feat, flows, out, tl, bs, h, w, c)
+        ctx.save_for_backward(flows)
+        ctx.shape = feat.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (flows,) = ctx.saved_tensors
+        tl, bs, h, w, c = ctx.shape
+        gf = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        lib.call('dis_gather_warped_feat_bwd', _c(g), flows, gf, tl, bs, h, w, c)
+        return gf, None
+
+
+def gather_warped_feat(feat, flows):
+    return _GatherWarpedFeat.apply(feat, flows)
+
+
+def mf_geometry(depth_core, R, t, flows_core, Kinv, u_step, v_step):
+    depth_core, R, t, flows_core = _c(depth_core), _c(R), _c(t), _c(flows_core)
+    _chk(depth_core, R, t, flows_core)
+    tl, bs, h, w = depth_core.shape
+    out = torch.empty((tl, bs, h, w, tl, 4), dtype=torch.float32, device=depth_core.device)
+    lib.call('dis_mf_geometry', depth_core, R, t, flows_core, Kinv, int(u_step), int(v_step), out, tl, bs, h, w)
+    return out
+
+
+def mf_geometry_resize(geom, size):
+    tl, bs, hin, win, _, _ = geom.shape
+    out = torch.empty((tl, bs, size[0], size[1], tl, 4), dtype=torch.float32, device=geom.device)
+    lib.call('dis_mf_geometry_resize', geom, out, tl, bs, hin, win, size[0], size[1])
+    return out
+
+
+class _MaskWeightSlots(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, wf, geom):
+        wf, geom = _c(wf), _c(geom)
+        tl, bs, h, w, s, c = wf.shape
+        out = torch.empty_like(wf)
+        lib.call('dis_mask_weight_slots', wf, geom, out, tl * bs * h * w, s, c)
+        ctx.save_for_backward(geom)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (geom,) = ctx.saved_tensors
+        g = _c(g)
+        tl, bs, h, w, s, c = g.shape
+        out = torch.empty_like(g)
+        lib.call('dis_mask_weight_slots', g, geom, out, tl * bs * h * w, s, c)
+        return out, None
+
+
+def mask_weight_slots(wf, geom):
+    return _MaskWeightSlots.apply(wf, geom)
+
+
+class _Conv3dKnn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, geom, wf, d1w, d1b, d2w, d2b, w, stride):
+        geom, wf = _c(geom), _c(wf)
+        d1w, d1b, d2w, d2b, w = [_c(p) for p in (d1w, d1b, d2w, d2b, w)]
+        _chk(geom, wf, d1w, d1b, d2w, d2b, w)
+        tl, bs, h, wd, s, c = wf.shape
+        assert c == 32 and s == tl
+        ho = (h + 2 - 3) // stride + 1
+        wo = (wd + 2 - 3) // stride + 1
+        idx = torch.empty((tl, bs, ho, wo, 9), dtype=torch.uint8, device=wf.device)
+        y = torch.empty((tl, bs, ho, wo, c), dtype=torch.float32, device=wf.device)
+        lib.call('dis_conv3d_knn_fwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, tl, bs, h, wd, stride)
+        ctx.save_for_backward(geom, wf, d1w, d1b, d2w, d2b, w, idx, y)
+        ctx.stride = stride
+        ctx.mark_non_differentiable(idx)
+        return y, idx
+
+    @staticmethod
+    def backward(ctx, gy, _gidx):
+        geom, wf, d1w, d1b, d2w, d2b, w, idx, y = ctx.saved_tensors
+        tl, bs, h, wd, s, c = wf.shape
+        gwf = torch.zeros_like(wf)
+        gp = torch.empty(1632, dtype=torch.float32, device=wf.device)
+        acc = _zeros_d(1632, wf.device)
+        lib.call('dis_conv3d_knn_bwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, _c(gy), gwf, gp, acc, tl, bs, h, wd,
+                 ctx.stride)
+        return (None, gwf, gp[0:48].view(16, 3), gp[48:64], gp[64:576].view(32, 16), gp[576:608],
+                gp[608:1632].view(32, 32), None)
+
+
+def conv3d_knn(geom, wf, d1w, d1b, d2w, d2b, w, stride):
+    """returns (y (tl,bs,ho,wo,32) = SELU(agg @ w), idx uint8 (tl,bs,ho,wo,9))"""
+    return _Conv3dKnn.apply(geom, wf, d1w, d1b, d2w, d2b, w, stride)
+
+
+# --------------------------------------------------------------------------------------------------
+# optimiser
+# --------------------------------------------------------------------------------------------------
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _chk(param, grad, exp_avg, exp_avg_sq)
+    lib.call('dis_adam_step', param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(beta1), float(beta2),
+             float(eps), int(step), float(grad_scale))

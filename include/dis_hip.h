@@ -117,6 +117,9 @@ int dis_geo_loss_bwd(const float* depth0, const float* depth1, const float* flow
  * Used for the FuseNet stem input cat(ir(2), amb, d) (reference multi_frame_networks.py:217,273). */
 int dis_pack4_nhwc(const float* s0, const float* s1, const float* s2, const float* s3, float* out, int n, int h,
                    int w, void* stream);
+/* same with a per-source sample stride (floats), e.g. the two planes of an (n,2,h,w) tensor: stride 2*h*w */
+int dis_pack4_nhwc_strided(const float* s0, long st0, const float* s1, long st1, const float* s2, long st2,
+                           const float* s3, long st3, float* out, int n, int h, int w, void* stream);
 /* planar (n,c,h,w) <-> nhwc (n,h,w,c) */
 int dis_planar_to_nhwc(const float* x, float* y, int n, int c, int h, int w, void* stream);
 int dis_nhwc_to_planar(const float* x, float* y, int n, int c, int h, int w, void* stream);
@@ -131,6 +134,8 @@ int dis_resize_bilinear_nhwc_bwd(const float* gy, float* gx /*zeroed*/, int n, i
                                  int c, int align_corners, void* stream);
 int dis_resize_bilinear_planar_fwd(const float* x, float* y, int nc, int hin, int win, int hout, int wout,
                                    int align_corners, float scale0, float scale1, int c_for_scale, void* stream);
+int dis_resize_bilinear_planar_bwd(const float* gy, float* gx, int nc, int hin, int win, int hout, int wout,
+                                   int align_corners, void* stream);
 
 /* gather_warped_feat for all targets, reference multi_frame_networks.py:347-360 + warp :83-99.
  * feat: (tl,bs,h,w,c) nhwc; flows: (tl*tl, bs, h, w, 2) nhwc, entry [i*tl+j] = flow_ij (diagonal unused).
@@ -156,28 +161,36 @@ int dis_mf_geometry_resize(const float* geom, float* out, int tl, int bs, int hi
 
 /* ---------------------------------------------------------------- dense layers -------------- */
 
-/* Repack OIHW weights (cout,cin,k,k) into the conv kernel's layout; mode 0 = forward,
- * mode 1 = dgrad (spatially flipped, cin<->cout swapped).  packed has cout*cin*k*k floats. */
-int dis_conv2d_pack_weights(const float* w_oihw, float* packed, int cout, int cin, int k, int mode, void* stream);
+/* Repack OIHW weights (cout,cin_real,k,k) into the LDS fragment order of dis_conv2d_fwd.
+ * mode 0 = forward: the packed conv has cin_pad >= cin_real input channels (extra ones get zero weights,
+ *          e.g. the 1-channel ambient conv runs as a 4-channel conv on a zero-padded nhwc4 input).
+ * mode 1 = stride-1 input gradient: spatially flipped, cin<->cout swapped (cin_pad must equal cin_real).
+ * packed has k*k*cin_pad*cout floats. */
+int dis_conv2d_pack_weights(const float* w_oihw, float* packed, int cout, int cin_real, int cin_pad, int k,
+                            int mode, void* stream);
 
-/* Implicit-GEMM convolution on MFMA (fp32 in / fp32 accumulate), nhwc.
+/* Implicit-GEMM convolution on the matrix cores (v_mfma_f32_16x16x4_f32: fp32 in, fp32 accumulate), nhwc.
  * Replaces ZeroPad2d + Conv2d (+SELU/ReLU) of reference multi_frame_networks.py:159-164,330-345,514-542
  * and Conv2d of networks.py:222-234.
  * x: (n,hin,win,cin); y: (n,hout,wout,cout), hout = (hin + 2*pad - k)/stride + 1.
  * bias may be NULL.  act: DIS_ACT_*.  stats (optional, may be NULL): (n,2) zeroed doubles receiving
- * sum / sum of squares of y per sample (GroupNorm(1 group) statistics of the conv output). */
+ * sum / sum of squares of y per sample (GroupNorm(1 group) statistics of the conv output).
+ * The stride-1 input gradient is the same call on gy with mode-1 packed weights (cin/cout swapped). */
 int dis_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, double* stats, int n,
                    int hin, int win, int cin, int cout, int k, int stride, int pad, int act, void* stream);
-/* weight/bias gradient.  gy: (n,hout,wout,cout) gradient wrt the PRE-activation output.
- * workspace: dis_conv2d_wgrad_workspace() floats.  grad_w: (cout,cin,k,k) OIHW, grad_b: (cout) or NULL; both are
- * OVERWRITTEN. */
-long dis_conv2d_wgrad_workspace(int cin, int cout, int k);
-int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
-                     int hin, int win, int cin, int cout, int k, int stride, int pad, void* stream);
-/* input gradient for stride-2 convolutions (transposed convolution); stride-1 dgrad is dis_conv2d_fwd with
- * mode-1 packed weights.  w_oihw is the unpacked weight.  gx: (n,hin,win,cin) overwritten. */
-int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, float* gx, int n, int hin, int win, int cin,
-                             int cout, int k, int stride, int pad, void* stream);
+/* Weight/bias gradient.  gy: (n,hout,wout,cout) gradient wrt the PRE-activation output; x has cin_pad channels.
+ * workspace: dis_conv2d_wgrad_workspace(cin_pad,cout,k,stride) floats (-1 if the shape is unsupported).
+ * grad_w: (cout,cin_real,k,k) OIHW, grad_b: (cout) or NULL, both OVERWRITTEN; bias_acc: cout zeroed doubles
+ * (needed when grad_b != NULL). */
+long dis_conv2d_wgrad_workspace(int cin_pad, int cout, int k, int stride);
+int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace,
+                     double* bias_acc, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k,
+                     int stride, int pad, void* stream);
+/* Input gradient of a k=4, stride=2, pad=1 convolution (transposed convolution) as four 2x2 phase convolutions on
+ * the matrix cores.  w_oihw is the unpacked weight (cout,cin,4,4).  workspace: 16*cin*cout floats.
+ * gx: (n,hin,win,cin) overwritten. */
+int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, float* gx, float* workspace, int n, int hin,
+                             int win, int cin, int cout, int k, int stride, int pad, void* stream);
 
 /* Head: Conv2d(cin,1,3,pad 1) + alpha*sigmoid(x - offset) (reference networks.py:121-125,140-149;
  * multi_frame_networks.py:157,265).  x nhwc (n,h,w,cin); w (1,cin,3,3); y planar (n,1,h,w). */
