@@ -314,23 +314,33 @@ static int c3_dims(C3Dims* d, int tl, int bs, int h, int w, int stride) {
   return DIS_OK;
 }
 
+extern "C" int dis_conv3d_knn_select(const float* geom, unsigned char* idx_out, int tl, int bs, int h, int wd,
+                                     int stride, void* stream) {
+  if (!geom || !idx_out) return DIS_ERR_NULL;
+  C3Dims d;
+  int rc = c3_dims(&d, tl, bs, h, wd, stride);
+  if (rc != DIS_OK) return rc;
+  const long total = (long)tl * bs * d.ho * d.wo;
+  hipLaunchKernelGGL(conv3d_select_kernel, dim3(dis_ew_grid(total, 128)), dim3(128), 0, (hipStream_t)stream,
+                     (const float4*)geom, idx_out, d);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 extern "C" int dis_conv3d_knn_fwd(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
                                   const float* dense2_w, const float* dense2_b, const float* w,
-                                  unsigned char* idx_out, float* y, int tl, int bs, int h, int wd, int stride,
+                                  const unsigned char* idx, float* y, int tl, int bs, int h, int wd, int stride,
                                   void* stream) {
-  if (!geom || !wf || !dense1_w || !dense1_b || !dense2_w || !dense2_b || !w || !idx_out || !y) return DIS_ERR_NULL;
+  if (!geom || !wf || !dense1_w || !dense1_b || !dense2_w || !dense2_b || !w || !idx || !y) return DIS_ERR_NULL;
   C3Dims d;
   int rc = c3_dims(&d, tl, bs, h, wd, stride);
   if (rc != DIS_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)tl * bs * d.ho * d.wo;
-  hipLaunchKernelGGL(conv3d_select_kernel, dim3(dis_ew_grid(total, 128)), dim3(128), 0, s, (const float4*)geom,
-                     idx_out, d);
   C3Params P{dense1_w, dense1_b, dense2_w, dense2_b, w};
   int grid = dis_cdiv(total, 8);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(conv3d_aggregate_kernel, dim3(grid), dim3(256), 0, s, (const float4*)geom, wf, P,
-                     (const unsigned char*)idx_out, y, d);
+  hipLaunchKernelGGL(conv3d_aggregate_kernel, dim3(grid), dim3(256), 0, s, (const float4*)geom, wf, P, idx, y, d);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

@@ -55,6 +55,7 @@ SIGS = {
     'dis_gn_apply_bwd': 'ppppp' + 'pppp' + 'pp' + 'iliifp',
     'dis_add_act_fwd': 'pppilp',
     'dis_mask_weight_slots': 'pppliip',
+    'dis_conv3d_knn_select': 'ppiiiiip',
     'dis_conv3d_knn_fwd': 'ppppppppp' + 'iiiiip',
     'dis_conv3d_knn_bwd': 'ppppppp' + 'pppppp' + 'iiiiip',
     'dis_adam_step': 'pppplffffifp',

@@ -549,9 +549,21 @@ def mask_weight_slots(wf, geom):
     return _MaskWeightSlots.apply(wf, geom)
 
 
+def conv3d_select(geom, stride):
+    """top-9 neighbour ids per output pixel (tl,bs,ho,wo,9) uint8; depends on the geometry only."""
+    geom = _c(geom)
+    _chk(geom)
+    tl, bs, h, wd, s, _ = geom.shape
+    ho = (h + 2 - 3) // stride + 1
+    wo = (wd + 2 - 3) // stride + 1
+    idx = torch.empty((tl, bs, ho, wo, 9), dtype=torch.uint8, device=geom.device)
+    lib.call('dis_conv3d_knn_select', geom, idx, tl, bs, h, wd, stride)
+    return idx
+
+
 class _Conv3dKnn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, geom, wf, d1w, d1b, d2w, d2b, w, stride):
+    def forward(ctx, geom, wf, d1w, d1b, d2w, d2b, w, idx, stride):
         geom, wf = _c(geom), _c(wf)
         d1w, d1b, d2w, d2b, w = [_c(p) for p in (d1w, d1b, d2w, d2b, w)]
         _chk(geom, wf, d1w, d1b, d2w, d2b, w)
@@ -559,16 +571,15 @@ class _Conv3dKnn(torch.autograd.Function):
         assert c == 32 and s == tl
         ho = (h + 2 - 3) // stride + 1
         wo = (wd + 2 - 3) // stride + 1
-        idx = torch.empty((tl, bs, ho, wo, 9), dtype=torch.uint8, device=wf.device)
+        assert idx.dtype == torch.uint8 and tuple(idx.shape) == (tl, bs, ho, wo, 9) and idx.is_contiguous()
         y = torch.empty((tl, bs, ho, wo, c), dtype=torch.float32, device=wf.device)
         lib.call('dis_conv3d_knn_fwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, tl, bs, h, wd, stride)
         ctx.save_for_backward(geom, wf, d1w, d1b, d2w, d2b, w, idx, y)
         ctx.stride = stride
-        ctx.mark_non_differentiable(idx)
-        return y, idx
+        return y
 
     @staticmethod
-    def backward(ctx, gy, _gidx):
+    def backward(ctx, gy):
         geom, wf, d1w, d1b, d2w, d2b, w, idx, y = ctx.saved_tensors
         tl, bs, h, wd, s, c = wf.shape
         gwf = torch.zeros_like(wf)
@@ -577,12 +588,12 @@ class _Conv3dKnn(torch.autograd.Function):
         lib.call('dis_conv3d_knn_bwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, _c(gy), gwf, gp, acc, tl, bs, h, wd,
                  ctx.stride)
         return (None, gwf, gp[0:48].view(16, 3), gp[48:64], gp[64:576].view(32, 16), gp[576:608],
-                gp[608:1632].view(32, 32), None)
+                gp[608:1632].view(32, 32), None, None)
 
 
-def conv3d_knn(geom, wf, d1w, d1b, d2w, d2b, w, stride):
-    """returns (y (tl,bs,ho,wo,32) = SELU(agg @ w), idx uint8 (tl,bs,ho,wo,9))"""
-    return _Conv3dKnn.apply(geom, wf, d1w, d1b, d2w, d2b, w, stride)
+def conv3d_knn(geom, wf, d1w, d1b, d2w, d2b, w, idx, stride):
+    """y (tl,bs,ho,wo,32) = SELU(agg @ w) for the neighbour sets `idx` (from conv3d_select)."""
+    return _Conv3dKnn.apply(geom, wf, d1w, d1b, d2w, d2b, w, idx, stride)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -229,13 +229,21 @@ int dis_mask_weight_slots(const float* wf, const float* geom, float* out, long p
 
 /* ---------------------------------------------------------------- Conv3D (k-NN continuous conv) */
 
-/* reference multi_frame_networks.py:469-512 for ALL target frames at once.
+/* reference multi_frame_networks.py:469-512 for ALL target frames at once, in two stages.
  * geom: (tl,bs,h,w,tl,4) xyz+mask per slot; wf: (tl,bs,h,w,tl,c) gathered features (c == 32).
- * dense1_w (16,3), dense1_b (16), dense2_w (32,16), dense2_b (32), w (32,32).
- * idx_out: (tl,bs,ho,wo,9) uint8 candidate ids (ky*3+kx)*tl+slot, ascending (saved for backward).
+ *
+ * stage 1, neighbour selection (reference :489-498): per output pixel the 9 candidates with the smallest masked
+ * planar distance among the 3x3 x tl window (candidate id = (ky*3+kx)*tl+slot, zero-padded border).
+ * idx_out: (tl,bs,ho,wo,9) uint8.  Ties / masked fills resolve to the lowest candidate id (the reference leaves
+ * them to torch.topk(sorted=False), i.e. implementation-defined).  The selection depends on the geometry
+ * only, so one call serves every Conv3D layer that shares `geom`. */
+int dis_conv3d_knn_select(const float* geom, unsigned char* idx_out, int tl, int bs, int h, int wd, int stride,
+                          void* stream);
+/* stage 2 (reference :499-508): gather, MLP 3->16->32 on the local coordinates, weighted feature sum, 32x32 mix,
+ * SELU.  dense1_w (16,3), dense1_b (16), dense2_w (32,16), dense2_b (32), w (32,32).
  * y: (tl,bs,ho,wo,32) = SELU(agg @ w)  (GroupNorm follows as dis_gn_*). */
 int dis_conv3d_knn_fwd(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
-                       const float* dense2_w, const float* dense2_b, const float* w, unsigned char* idx_out,
+                       const float* dense2_w, const float* dense2_b, const float* w, const unsigned char* idx,
                        float* y, int tl, int bs, int h, int wd, int stride, void* stream);
 /* gy: gradient wrt y (post-SELU).  grad_wf (zeroed) scatter-added.  gparams: 16*3+16+32*16+32+32*32 floats
  * overwritten in that order (dense1_w, dense1_b, dense2_w, dense2_b, w).  acc: same count of zeroed doubles. */

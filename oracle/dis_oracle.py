@@ -363,7 +363,14 @@ def _resblock(p, name, x):
     return F.selu(o + x)
 
 
-def conv3d_knn(p, name, xyz, feat, mask, stride, tl=4, neighbors=9, return_index=False):
+# test hook: when set to a list, every conv3d_knn call appends {'name','idx','key'} (neighbour ids and keys)
+CONV3D_TAP = None
+# test hook: when set to a dict {layer-geometry 'core'|'quarter': LongTensor (tl,bs,ho,wo,9)}, conv3d_knn uses
+# these neighbour sets instead of its own top-k (used to propagate one selection through perturbed inputs)
+CONV3D_FORCE = None
+
+
+def conv3d_knn(p, name, xyz, feat, mask, stride, tl=4, neighbors=9, return_index=False, target=None):
     """Conv3D.tforward.  reference model/multi_frame_networks.py:469-512.
     xyz (tl,bs,3,h,w), feat (tl,bs,C,h,w), mask (tl,bs,1,h,w) -> (bs,C,h',w')."""
     def candidates(x):
@@ -390,6 +397,11 @@ def conv3d_knn(p, name, xyz, feat, mask, stride, tl=4, neighbors=9, return_index
     dist = (plane_local ** 2).sum(dim=-1, keepdim=True)
     key = M * dist + (1 - M) * (dist.max() + 1)
     _, idx = torch.topk(key, neighbors, dim=1, largest=False, sorted=False)
+    if CONV3D_FORCE is not None and target is not None:
+        idx = CONV3D_FORCE['core' if stride == 2 else 'quarter'][target].reshape(-1, neighbors, 1).long()
+    if CONV3D_TAP is not None:
+        CONV3D_TAP.append({'name': name, 'target': target, 'idx': idx.view(*bhw, neighbors).clone(),
+                           'key': key.view(*bhw, 9 * tl).clone()})
     nb_xyz = torch.gather(local, 1, idx.expand(-1, -1, 3))
     nb_feat = torch.gather(Fe, 1, idx.expand(-1, -1, Fe.shape[-1]))
     h1 = F.selu(F.linear(nb_xyz, p[name + '.dense1.0.weight'], p[name + '.dense1.0.bias']))
@@ -441,14 +453,15 @@ def mf_block(p, B, feat, wxyz, wmask, flow_core, tl):
     bs = feat.shape[1]
     # 3-D branch, stride 2 (core -> quarter)
     wfeat = torch.stack([_gather_warped_feat(feat, flow_core, ti, tl) for ti in range(tl)], 0)  # (tl,4,bs,C,h,w)
-    o3d1 = torch.stack([conv3d_knn(p, B + 'conv3d_1', wxyz[ti], wfeat[ti], wmask[ti], 2, tl) for ti in range(tl)], 0)
+    o3d1 = torch.stack([conv3d_knn(p, B + 'conv3d_1', wxyz[ti], wfeat[ti], wmask[ti], 2, tl, target=ti)
+                        for ti in range(tl)], 0)
     # 3-D branch, stride 1 at quarter resolution
     q = o3d1.shape[-2:]
     flow_q = resize_flow(flow_core, q)
     wxyz_q = resize_ac(wxyz, q)
     wmask_q = (resize_ac(wmask, q) > 0.5).float()
     o3d2 = torch.stack([conv3d_knn(p, B + 'conv3d_2', wxyz_q[ti], _gather_warped_feat(o3d1, flow_q, ti, tl),
-                                   wmask_q[ti], 1, tl) for ti in range(tl)], 0)
+                                   wmask_q[ti], 1, tl, target=ti) for ti in range(tl)], 0)
     # 2-D branch
     x = (wfeat * wmask / wmask.mean(dim=1, keepdim=True)).transpose(1, 2)
     x = x.reshape(tl * bs, -1, *x.shape[4:])
