@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: DIS-MF training step (FuseNet fwd + losses + bwd + Adam), bs=4 per GPU,
+512x432 default-pattern synthetic data, fp32, on N MI355X of one node (one process per GPU, RCCL).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task description): BASELINE.json's metric
+(training frames/s, frame = one 512x432 image of a 4-frame track), plus
+  roofline     : the dominant kernel (MFMA fp32 32->32 3x3 implicit-GEMM conv) against the fp32 matrix peak,
+                 duration measured live with HIP events around every launch of that kernel in one step;
+  cpu_baseline : the CPU oracle (pure PyTorch restatement of the reference step) timed on the host cores on a
+                 bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+H, W, TL = 512, 432, 4
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0           # same guide, HBM3E spec peak
+
+
+def make_args(bs):
+    return argparse.Namespace(use_pseudo_gt=False, lcn_radius=5, track_length=TL, data_type='synthetic',
+                              architecture='multi_frame', epochs=1, warmup_epochs=150, train_batch_size=bs,
+                              max_disp=128)
+
+
+def make_device_batch(settings, bs, seed, dev):
+    from depthinspace_amd import synth
+    b = synth.make_batch(settings, bs, TL, seed=seed)
+    out = {}
+    stacked = np.zeros((bs, TL * TL, 2, H, W), np.float32)
+    for k, v in b.items():
+        if k.startswith('flow_'):
+            i, j = int(k[5]), int(k[6])
+            stacked[:, i * TL + j] = v[:, 0]
+        else:
+            out[k] = torch.from_numpy(v).to(dev)
+    out['_flow_stacked'] = torch.from_numpy(stacked).to(dev)
+    return out
+
+
+def conv_flops(n, ho, wo, cin, cout, k):
+    return 2.0 * n * ho * wo * cin * cout * k * k
+
+
+def cpu_baseline():
+    """Oracle step on the host cores: 1 step, bs=1 (4 frames), full resolution."""
+    from depthinspace_amd import synth
+    from oracle import dis_oracle as O
+    settings = synth.make_settings(H, W)
+    batch = synth.make_batch(settings, 1, TL, seed=1234)
+    params = O.init_params(O.mf_param_shapes(), seed=0)
+    ctx = O.StepContext(settings)
+    st = {'step': 0, 'm': {}, 'v': {}}
+    t0 = time.time()
+    O.train_step(ctx, 'multi_frame', params, {k: torch.from_numpy(v) for k, v in batch.items()}, adam_state=st, epoch=2)
+    dt = time.time() - t0
+    return {'value': TL / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 training step of the CPU oracle, DIS-MF bs=1 (4 frames) 512x432 fp32, {dt:.1f} s, '
+                      f'torch threads={torch.get_num_threads()} of os.cpu_count()={os.cpu_count()}'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--bs', type=int, default=4)
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of one hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--epoch', type=int, default=2, help='training epoch the step models (epoch<2 adds the L1 warm-up term)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from depthinspace_amd import synth, lib
+    from depthinspace_amd.model import multi_frame_networks, multi_frame_worker
+    from depthinspace_amd.trainer import FlatAdam
+    lib.check_all_symbols()
+
+    settings = synth.make_settings(H, W)
+    torch.manual_seed(0)  # identical initial weights on every rank
+    net = multi_frame_networks.FuseNet(imsize=(H, W), K=settings.K, baseline=settings.baseline, track_length=TL,
+                                       max_disp=128).to(dev)
+    worker = multi_frame_worker.Worker(make_args(args.bs), settings=settings, train_device=str(dev))
+    worker.build_losses(device=dev)
+    worker.current_epoch = args.epoch
+    opt = FlatAdam(net.parameters(), lr=1e-4, world_size=world)
+    batch = make_device_batch(settings, args.bs, 1234 + rank, dev)  # weak scaling: own tracks per rank
+
+    loss_buf = torch.zeros(16, device=dev)
+
+    def fwd_bwd():
+        worker.copy_data(batch, device=dev, requires_grad=False, train=True)
+        opt.zero_grad()
+        flow = worker.read_optical_flow(train=True)
+        out = worker.net_forward(net, flow)
+        errs = worker.loss_forward(out, True, flow)
+        total = sum(errs)
+        total.backward()
+        loss_buf[:len(errs)].copy_(torch.stack([e.detach() for e in errs]))
+        return len(errs)
+
+    def step_eager():
+        n = fwd_bwd()
+        opt.step()
+        return n
+
+    use_graph = not args.no_graph
+    nterms = 0
+    # ---- warm-up (eager; also sizes the caching allocator and initialises kernel attributes)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(1, min(args.warmup, 2)) if use_graph else args.warmup):
+            nterms = step_eager()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+    g_fb = g_opt = None
+    if use_graph:
+        try:
+            g_fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fb):
+                nterms = fwd_bwd()
+                if world == 1:
+                    opt.step(all_reduce=False)
+            if world > 1:
+                g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_opt):
+                    opt.step(all_reduce=False)
+        except Exception as e:  # pragma: no cover
+            if rank == 0:
+                print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
+            g_fb = g_opt = None
+            use_graph = False
+            torch.cuda.synchronize()
+
+    def step():
+        if g_fb is None:
+            step_eager()
+        else:
+            g_fb.replay()
+            if world > 1:
+                opt.all_reduce_grads()
+                g_opt.replay()
+
+    for _ in range(max(0, args.warmup - 2) if use_graph else 0):
+        step()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    losses = [float(v) for v in loss_buf[:nterms].cpu()]
+
+    # ---- roofline leg: HIP events around every launch of the dominant kernel during one eager step
+    roof = None
+    if rank == 0:
+        lib.profile_start()
+        step_eager()
+        rec = lib.profile_stop()
+        per = {}
+        for name, ia, ms in rec:
+            per.setdefault(name, [0, 0.0])
+            per[name][0] += 1
+            per[name][1] += ms
+        # dis_conv2d_fwd int args: (n, hin, win, cin, cout, k, stride, pad, act); same kernel template for the
+        # forward 32->32 3x3 convs and their input gradients
+        sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_conv2d_fwd' and ia[3:7] == (32, 32, 3, 1)]
+        fl = sum(conv_flops(ia[0], ia[1], ia[2], 32, 32, 3) for ia, _ in sel)
+        tm = sum(ms for _, ms in sel) * 1e-3
+        if sel:
+            ach = fl / tm / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel<32,32,3,3,1> (fp32 MFMA 16x16x4)',
+                    'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'launches_per_step': len(sel),
+                    'avg_launch_ms': tm * 1e3 / len(sel), 'flop_per_launch_avg': fl / len(sel),
+                    'share_of_step_kernel_time': tm / (sum(ms for _, _, ms in rec) * 1e-3)}
+        top = sorted(per.items(), key=lambda kv: -kv[1][1])[:12]
+        kernel_ms = {k: {'calls': v[0], 'ms': round(v[1], 3)} for k, v in top}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        frames = world * args.bs * TL * args.steps
+        res = {
+            'metric': 'DIS-MF train frames/sec bs=4 default-pattern', 'value': frames / dt, 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'DIS-MF (FuseNet) training step, bs={args.bs} per GPU x 4 frames, 512x432, '
+                                   f'default-pattern synthetic, fwd+losses+bwd+Adam, epoch>={args.epoch}',
+                       'global_batch': world * args.bs, 'parallelism': f'dp{world}', 'hip_graph': bool(use_graph)},
+            'roofline': roof, 'cpu_baseline': cpu, 'loss_terms': losses, 'kernel_ms_one_eager_step': kernel_ms,
+        }
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

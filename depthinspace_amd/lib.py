@@ -107,6 +107,23 @@ class DisHipError(RuntimeError):
 _ERR = {-1: 'bad shape', -2: 'unsupported configuration', -3: 'null pointer'}
 
 
+# optional per-call HIP-event timing (bench.py roofline leg): list of (name, int-args, start_event, end_event)
+_profile = None
+
+
+def profile_start():
+    global _profile
+    _profile = []
+
+
+def profile_stop():
+    """-> list of (name, int_args_tuple, milliseconds); synchronises the device."""
+    global _profile
+    rec, _profile = _profile, None
+    torch.cuda.synchronize()
+    return [(n, a, e0.elapsed_time(e1)) for (n, a, e0, e1) in rec]
+
+
 def call(name, *args):
     """Call a C-ABI entry point; tensors are passed as device pointers, None as NULL.
     Appends the current HIP stream.  Raises DisHipError on a non-zero status (like the reference's
@@ -123,7 +140,15 @@ def call(name, *args):
         else:
             conv.append(a)
     conv.append(torch.cuda.current_stream().cuda_stream)
-    rc = f(*conv)
+    if _profile is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = f(*conv)
+        e1.record()
+        _profile.append((name, tuple(a for a in args if isinstance(a, int)), e0, e1))
+    else:
+        rc = f(*conv)
     if rc != 0:
         raise DisHipError(f'{name} failed: {_ERR.get(rc, "hipError_t " + str(rc))}')
 

@@ -173,6 +173,15 @@ class Worker(object):
             if len(val.shape) > 2:
                 val = val.transpose(0, 1)
             self.data[key] = val.to(device).contiguous()
+        if '_flow_stacked' in self.data:
+            # all ordered-pair flows delivered as one (bs, tl*tl, 2, H, W) tensor (entry i*tl+j): after the
+            # transpose it is exactly the stacked layout the network consumes; flow_ij become views of it
+            fs = self.data['_flow_stacked']
+            tl = int(round(fs.shape[0] ** 0.5))
+            for i in range(tl):
+                for j in range(tl):
+                    if i != j:
+                        self.data[f'flow_{i}{j}'] = fs[i * tl + j].unsqueeze(0)
         im = self.data['im0']
         tl, bs = im.shape[0], im.shape[1]
         im_lcn, im_std = self.lcn_in(im.view(-1, *im.shape[2:]))

@@ -239,8 +239,9 @@ def test_conv3d_golden(golden_dir, stride):
     geom = geom1.unsqueeze(0).expand(tl, -1, -1, -1, -1, -1).contiguous().cuda()
     wf1 = feat.permute(1, 3, 4, 0, 2)
     wf = wf1.unsqueeze(0).expand(tl, -1, -1, -1, -1, -1).contiguous().cuda().requires_grad_(True)
-    y, idx = ops.conv3d_knn(geom, wf, pd['dense1.0.weight'], pd['dense1.0.bias'], pd['dense2.0.weight'],
-                            pd['dense2.0.bias'], pd['w'], stride)
+    idx = ops.conv3d_select(geom, stride)
+    y = ops.conv3d_knn(geom, wf, pd['dense1.0.weight'], pd['dense1.0.bias'], pd['dense2.0.weight'],
+                       pd['dense2.0.bias'], pd['w'], idx, stride)
     ho, wo = y.shape[2:4]
     yn = ops.group_norm(y.view(tl * bs, ho, wo, C), pd['bn.weight'], pd['bn.bias'])
     out = yn.view(tl, bs, ho, wo, C)
