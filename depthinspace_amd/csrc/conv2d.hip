@@ -396,7 +396,8 @@ struct WgCfg {
 struct WgArgs {
   const float* x;
   const float* gy;
-  float* part;  // [worker][wave][chunk][split][PART]
+  float* part;   // [worker][chunk][split][PART]
+  float* bpart;  // [worker][COUT] bias partial sums (written by chunk 0 / split 0 workgroups), may be null
   int n, hin, win, hout, wout, pad;
 };
 
@@ -431,6 +432,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int nb = 0; nb < C::NB; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  float bsum[C::NB];
+#pragma unroll
+  for (int nb = 0; nb < C::NB; ++nb) bsum[nb] = 0.f;
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * C::TROWS * S - a.pad + ky0, ix0 = tx * 16 * S - a.pad;
@@ -462,7 +467,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
       const float* gp = gl + pk * C::GS + li;
       float bv[C::NB];
 #pragma unroll
-      for (int nb = 0; nb < C::NB; ++nb) bv[nb] = gp[nb * 16];
+      for (int nb = 0; nb < C::NB; ++nb) {
+        bv[nb] = gp[nb * 16];
+        bsum[nb] += bv[nb];
+      }
 #pragma unroll
       for (int mb = 0; mb < C::MB; ++mb) {
         float av = xp[aoff[mb]];
@@ -473,22 +481,65 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
       }
     }
   }
-  // partial slab of this wave: [m][co]
-  float* out = a.part + ((((long)blockIdx.x * 4 + wave) * C::NCHUNK + chunk) * C::NSPLIT + split) * C::PART;
+  // cross-wave reduction through LDS (the tile buffers are free now), then ONE slab per workgroup: [m][co]
+  float* red = smem;  // needs 4 * NB * 256 floats
+  float* out = a.part + (((long)blockIdx.x * C::NCHUNK + chunk) * C::NSPLIT + split) * C::PART;
 #pragma unroll
-  for (int mb = 0; mb < C::MB; ++mb)
+  for (int mb = 0; mb < C::MB; ++mb) {
+    __syncthreads();
 #pragma unroll
     for (int nb = 0; nb < C::NB; ++nb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[(mb * 16 + lg * 4 + r) * COUT + nb * 16 + li] = acc[mb][nb][r];
+      for (int r = 0; r < 4; ++r) red[((wave * C::NB + nb) * 4 + r) * 64 + lane] = acc[mb][nb][r];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < C::NB; ++k) {
+      const int v = threadIdx.x + k * 256;
+      const int nb = v >> 8, r = (v & 255) >> 6, ln = v & 63;
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sum += red[((w * C::NB + nb) * 4 + r) * 64 + ln];
+      out[(mb * 16 + (ln >> 4) * 4 + r) * COUT + nb * 16 + (ln & 15)] = sum;
+    }
+  }
+  if (a.bpart && chunk == 0 && split == 0) {
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb) {
+      float v = bsum[nb];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lg == 0) red[(wave * C::NB + nb) * 16 + li] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < COUT) {
+      const int nb = threadIdx.x >> 4, l2 = threadIdx.x & 15;
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sum += red[(w * C::NB + nb) * 16 + l2];
+      a.bpart[(long)blockIdx.x * COUT + threadIdx.x] = sum;
+    }
+  }
 }
 
-// sum the partial slabs and scatter into OIHW
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int nslabs, int cinb,
-                                    int nchunk, int nsplit, int khb, int kw, int kh, int cout, int cin_real,
-                                    int partsz) {
+// level 1: every thread sums a contiguous range of slabs for one element -> tmp[split16][elements]
+#define WG_RSPLIT 16
+__global__ void wgrad_reduce1_kernel(const float* __restrict__ part, float* __restrict__ tmp, int nslabs,
+                                     long elems) {
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e >= elems) return;
+  const int sp = blockIdx.y;
+  const int lo = (int)((long)nslabs * sp / WG_RSPLIT), hi = (int)((long)nslabs * (sp + 1) / WG_RSPLIT);
+  float s = 0.f;
+  for (int k = lo; k < hi; ++k) s += part[(long)k * elems + e];
+  tmp[(long)sp * elems + e] = s;
+}
+// level 2: sum the 16 partial sums and scatter into OIHW
+__global__ void wgrad_reduce2_kernel(const float* __restrict__ tmp, float* __restrict__ gw, int cinb, int nchunk,
+                                     int nsplit, int khb, int kw, int kh, int cout, int cin_real, int partsz) {
   const int mrows = khb * kw * cinb;
   const long total = (long)nchunk * nsplit * mrows * cout;
+  const long elems = (long)nchunk * nsplit * partsz;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int co = (int)(i % cout);
     long r = i / cout;
@@ -496,50 +547,40 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
     r /= mrows;
     const int split = (int)(r % nsplit);
     const int chunk = (int)(r / nsplit);
-    const long stride = (long)nchunk * nsplit * partsz;
-    const float* p = part + ((long)chunk * nsplit + split) * partsz + (long)m * cout + co;
+    const float* p = tmp + ((long)chunk * nsplit + split) * partsz + (long)m * cout + co;
     float s = 0.f;
-    for (int k = 0; k < nslabs; ++k) s += p[k * stride];
+#pragma unroll
+    for (int k = 0; k < WG_RSPLIT; ++k) s += p[k * elems];
     const int tap = m / cinb, ci = chunk * cinb + m % cinb;
     const int ky = (nsplit > 1 ? split : 0) + tap / kw, kx = tap % kw;
     if (ci < cin_real) gw[(((long)co * cin_real + ci) * kh + ky) * kw + kx] = s;
   }
 }
-
-// bias gradient: per-channel sum of gy over all pixels (fp64 block partials + atomics, then cast)
-__global__ void bias_grad_kernel(const float* __restrict__ gy, double* __restrict__ acc, long pixels, int cout) {
-  // thread t handles channel t % cout; blockDim.x is a multiple of cout
-  const int co = threadIdx.x % cout;
-  const int lanes_per = blockDim.x / cout;
-  const int sub = threadIdx.x / cout;
-  double s = 0.0;
-  for (long p = (long)blockIdx.x * lanes_per + sub; p < pixels; p += (long)gridDim.x * lanes_per)
-    s += (double)gy[p * cout + co];
-  __shared__ double sm[256];
-  sm[threadIdx.x] = s;
-  __syncthreads();
-  if (sub == 0) {
-    double t = 0.0;
-    for (int k = 0; k < lanes_per; ++k) t += sm[k * cout + co];
-    atomic_add_d(acc + co, t);
-  }
+__global__ void bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ gb, int workers, int cout) {
+  const int co = threadIdx.x;
+  if (co >= cout) return;
+  float s = 0.f;
+  for (int k = 0; k < workers; ++k) s += bpart[(long)k * cout + co];
+  gb[co] = s;
 }
 __global__ void cast_d2f_kernel(const double* __restrict__ a, float* __restrict__ o, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = (float)a[i];
 }
 
-#define WG_WORKERS 256
+#define WG_WORKERS 512
 
 template <int CIN, int COUT, int KH, int KW, int S>
 static long wgrad_ws(void) {
   using C = WgCfg<CIN, COUT, KH, KW, S>;
-  return (long)WG_WORKERS * 4 * C::NCHUNK * C::NSPLIT * C::PART;
+  const long elems = (long)C::NCHUNK * C::NSPLIT * C::PART;
+  return (long)WG_WORKERS * elems + (long)WG_RSPLIT * elems + (long)WG_WORKERS * COUT;
 }
 
 template <int CIN, int COUT, int KH, int KW, int S>
-static int launch_wgrad(const WgArgs& a, float* gw, int cin_real, hipStream_t s) {
+static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_t s) {
   using C = WgCfg<CIN, COUT, KH, KW, S>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+  static_assert(C::IN_FLOATS + C::G_FLOATS >= 4 * C::NB * 256, "reduction scratch does not fit the tile buffers");
   static bool attr_set = false;
   auto kern = conv_wgrad_kernel<CIN, COUT, KH, KW, S>;
   if (!attr_set) {
@@ -549,23 +590,30 @@ static int launch_wgrad(const WgArgs& a, float* gw, int cin_real, hipStream_t s)
   }
   const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + C::TROWS - 1) / C::TROWS;
   const long ntiles = (long)a.n * tiles_y * tiles_x;
-  int workers = WG_WORKERS;
-  if (workers > ntiles) workers = (int)ntiles;
-  hipLaunchKernelGGL(kern, dim3(workers, C::NCHUNK, C::NSPLIT), dim3(256), C::LDS_BYTES, s, a);
+  long workers = 2L * num_cus();
+  if (workers > WG_WORKERS) workers = WG_WORKERS;
+  if (workers > ntiles) workers = ntiles;
+  const long elems = (long)C::NCHUNK * C::NSPLIT * C::PART;
+  float* tmp = a.part + (long)WG_WORKERS * elems;
+  a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
+  hipLaunchKernelGGL(kern, dim3((unsigned)workers, C::NCHUNK, C::NSPLIT), dim3(256), C::LDS_BYTES, s, a);
+  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(dis_cdiv(elems, 256), WG_RSPLIT), dim3(256), 0, s,
+                     (const float*)a.part, tmp, (int)workers, elems);
   const long total = (long)C::NCHUNK * C::NSPLIT * C::MROWS * COUT;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)a.part, gw,
-                     workers * 4, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, KW, KH, COUT, cin_real, C::PART);
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)tmp, gw,
+                     C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, KW, KH, COUT, cin_real, C::PART);
+  if (gb) hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(64), 0, s, (const float*)a.bpart, gb, (int)workers, COUT);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
 
 #define WG_CASE(CI, CO, K_, S_) \
-  if (cin == CI && cout == CO && k == K_ && stride == S_) return launch_wgrad<CI, CO, K_, K_, S_>(a, gw, cin_real, s);
+  if (cin == CI && cout == CO && k == K_ && stride == S_) return launch_wgrad<CI, CO, K_, K_, S_>(a, gw, gb, cin_real, s);
 #define WS_CASE(CI, CO, K_, S_) \
   if (cin == CI && cout == CO && k == K_ && stride == S_) return wgrad_ws<CI, CO, K_, K_, S_>();
 
-static int dispatch_wgrad(const WgArgs& a, float* gw, int cin_real, int cin, int cout, int k, int stride,
-                          hipStream_t s) {
+static int dispatch_wgrad(const WgArgs& a, float* gw, float* gb, int cin_real, int cin, int cout, int k,
+                          int stride, hipStream_t s) {
   WG_CASE(4, 16, 4, 2)
   WG_CASE(4, 16, 3, 1)
   WG_CASE(16, 16, 3, 1)
@@ -594,28 +642,17 @@ extern "C" long dis_conv2d_wgrad_workspace(int cin, int cout, int k, int stride)
 }
 
 extern "C" int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace,
-                                double* bias_acc, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k,
-                                int stride, int pad, void* stream) {
+                                int n, int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride,
+                                int pad, void* stream) {
   if (!x || !gy || !grad_w || !workspace) return DIS_ERR_NULL;
-  if (grad_b && !bias_acc) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0 || cin_pad <= 0 || cin_real <= 0 || cin_real > cin_pad || cout <= 0)
     return DIS_ERR_BAD_SHAPE;
   const int hout = (hin + 2 * pad - k) / stride + 1, wout = (win + 2 * pad - k) / stride + 1;
   if (hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
-  hipStream_t s = (hipStream_t)stream;
   WgArgs a;
-  a.x = x; a.gy = gy; a.part = workspace; a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
-  int rc = dispatch_wgrad(a, grad_w, cin_real, cin_pad, cout, k, stride, s);
-  if (rc != DIS_OK) return rc;
-  if (grad_b) {
-    if (256 % cout != 0) return DIS_ERR_UNSUPPORTED;
-    const long pixels = (long)n * hout * wout;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(dis_ew_grid(pixels * cout, 256 * 8)), dim3(256), 0, s, gy, bias_acc,
-                       pixels, cout);
-    hipLaunchKernelGGL(cast_d2f_kernel, dim3(1), dim3(64), 0, s, (const double*)bias_acc, grad_b, cout);
-    DIS_CHECK_LAUNCH();
-  }
-  return DIS_OK;
+  a.x = x; a.gy = gy; a.part = workspace; a.bpart = nullptr;
+  a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
+  return dispatch_wgrad(a, grad_w, grad_b, cin_real, cin_pad, cout, k, stride, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

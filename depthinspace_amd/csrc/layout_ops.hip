@@ -378,41 +378,45 @@ __global__ void gather_warped_feat_fwd_kernel(const float* __restrict__ feat, co
   }
 }
 
-__device__ __forceinline__ void atomic_add4(float* p, float4 v, float wgt) {
-  atomicAdd(p + 0, v.x * wgt);
-  atomicAdd(p + 1, v.y * wgt);
-  atomicAdd(p + 2, v.z * wgt);
-  atomicAdd(p + 3, v.w * wgt);
+// Backward.  Phase 1 (plain stores, also replaces a memset): grad_feat[t] = grad_out[t, slot 0].
+// Phase 2 (float atomics): the warped slots scatter through their 4 bilinear taps.  One LANE = one channel,
+// so a wave-instruction's 64 atomics are two contiguous 128-byte rows: the shape the memory-side atomic unit
+// runs at full rate (MI355X_MICROARCH.md, "Global float atomics").
+__global__ void gather_warped_feat_bwd_own_kernel(const float* __restrict__ gout, float* __restrict__ gfeat,
+                                                  long pixels, int tl, int c) {
+  const int cg = c >> 2;
+  const long total = pixels * cg;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    const long p = i / cg;
+    *(float4*)(gfeat + p * c + g * 4) = *(const float4*)(gout + (p * tl) * c + g * 4);
+  }
 }
 
 __global__ void gather_warped_feat_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ flows,
                                               float* __restrict__ gfeat, int tl, int bs, int h, int w, int c) {
-  const int cg = c >> 2;
   const long hw = (long)h * w;
-  const long total = (long)tl * bs * hw * tl * cg;
+  const int ns = tl - 1;  // warped slots
+  const long total = (long)tl * bs * hw * ns * c;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int g = (int)(i % cg);
-    long r = i / cg;
-    const int s = (int)(r % tl);
-    r /= tl;
+    const int ch = (int)(i % c);
+    long r = i / c;
+    const int s = (int)(r % ns) + 1;
+    r /= ns;
     const long p = r % hw;
     r /= hw;
     const int b = (int)(r % bs);
     const int t = (int)(r / bs);
     const int j = slot_frame(t, s);
-    const float4 gv = *(const float4*)(gout + ((((long)t * bs + b) * hw + p) * tl + s) * c + g * 4);
-    float* dst = gfeat + ((long)j * bs + b) * hw * c + g * 4;
-    if (s == 0) {
-      atomic_add4(dst + p * c, gv, 1.f);
-    } else {
-      const int y = (int)(p / w), x = (int)(p - (long)y * w);
-      const float2 f = *(const float2*)(flows + ((((long)t * tl + j) * bs + b) * hw + p) * 2);
-      const Taps tp = make_taps(f.x + (float)x, f.y + (float)y, h, w);
-      if (tp.v00) atomic_add4(dst + ((long)tp.y0 * w + tp.x0) * c, gv, tp.w00);
-      if (tp.v01) atomic_add4(dst + ((long)tp.y0 * w + tp.x0 + 1) * c, gv, tp.w01);
-      if (tp.v10) atomic_add4(dst + ((long)(tp.y0 + 1) * w + tp.x0) * c, gv, tp.w10);
-      if (tp.v11) atomic_add4(dst + ((long)(tp.y0 + 1) * w + tp.x0 + 1) * c, gv, tp.w11);
-    }
+    const float gv = gout[((((long)t * bs + b) * hw + p) * tl + s) * c + ch];
+    float* dst = gfeat + ((long)j * bs + b) * hw * c + ch;
+    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const float2 f = *(const float2*)(flows + ((((long)t * tl + j) * bs + b) * hw + p) * 2);
+    const Taps tp = make_taps(f.x + (float)x, f.y + (float)y, h, w);
+    if (tp.v00) atomicAdd(dst + ((long)tp.y0 * w + tp.x0) * c, gv * tp.w00);
+    if (tp.v01) atomicAdd(dst + ((long)tp.y0 * w + tp.x0 + 1) * c, gv * tp.w01);
+    if (tp.v10) atomicAdd(dst + ((long)(tp.y0 + 1) * w + tp.x0) * c, gv * tp.w10);
+    if (tp.v11) atomicAdd(dst + ((long)(tp.y0 + 1) * w + tp.x0 + 1) * c, gv * tp.w11);
   }
 }
 
@@ -432,9 +436,14 @@ extern "C" int dis_gather_warped_feat_bwd(const float* grad_out, const float* fl
   if (!grad_out || !flows || !grad_feat) return DIS_ERR_NULL;
   if (tl <= 0 || bs <= 0 || h <= 1 || w <= 1 || c <= 0) return DIS_ERR_BAD_SHAPE;
   if (c % 4 != 0) return DIS_ERR_UNSUPPORTED;
-  long total = (long)tl * bs * h * w * tl * (c / 4);
-  hipLaunchKernelGGL(gather_warped_feat_bwd_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     grad_out, flows, grad_feat, tl, bs, h, w, c);
+  const long pixels = (long)tl * bs * h * w;
+  hipLaunchKernelGGL(gather_warped_feat_bwd_own_kernel, dim3(dis_ew_grid(pixels * (c / 4), 256)), dim3(256), 0,
+                     (hipStream_t)stream, grad_out, grad_feat, pixels, tl, c);
+  const long total = pixels * (tl - 1) * c;
+  int grid = dis_cdiv(total, 256);
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(gather_warped_feat_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_out, flows,
+                     grad_feat, tl, bs, h, w, c);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

@@ -45,7 +45,7 @@ SIGS = {
     'dis_conv2d_pack_weights': 'ppiiiiip',
     'dis_conv2d_fwd': 'pppppiiiiiiiiip',
     'dis_conv2d_wgrad_workspace': 'iiii',
-    'dis_conv2d_wgrad': 'ppppppiiiiiiiiip',
+    'dis_conv2d_wgrad': 'pppppiiiiiiiiip',
     'dis_conv2d_dgrad_strided': 'ppppiiiiiiiip',
     'dis_disp_head_fwd': 'ppppiiiiffp',
     'dis_disp_head_bwd': 'ppppppppp' + 'iiiifp',

@@ -400,8 +400,7 @@ class _Conv2d(torch.autograd.Function):
         if wsz < 0:
             raise lib.DisHipError(f'conv2d wgrad: unsupported shape cin={cin_pad} cout={cout} k={k} s={stride}')
         ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
-        bacc = _zeros_d(cout, x.device) if has_bias else None
-        lib.call('dis_conv2d_wgrad', x, gpre, gw, gb, ws, bacc, n, hin, win, cin_pad, cin, cout, k, stride, pad)
+        lib.call('dis_conv2d_wgrad', x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
         return gx, gw, gb, None, None, None, None, None
 
 
@@ -500,7 +499,7 @@ class _GatherWarpedFeat(torch.autograd.Function):
     def backward(ctx, g):
         (flows,) = ctx.saved_tensors
         tl, bs, h, w, c = ctx.shape
-        gf = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        gf = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
         lib.call('dis_gather_warped_feat_bwd', _c(g), flows, gf, tl, bs, h, w, c)
         return gf, None
 

@@ -142,7 +142,7 @@ int dis_resize_bilinear_planar_bwd(const float* gy, float* gx, int nc, int hin, 
  * out: (tl, bs, h, w, tl, c): slot 0 = own frame, slots 1.. = other frames in increasing index, warped. */
 int dis_gather_warped_feat_fwd(const float* feat, const float* flows, float* out, int tl, int bs, int h, int w,
                                int c, void* stream);
-/* grad_feat (zeroed by caller) += scatter of grad_out (atomics for warped slots). */
+/* grad_feat is OVERWRITTEN: own-frame slot by plain stores, then the warped slots scatter-add (float atomics). */
 int dis_gather_warped_feat_bwd(const float* grad_out, const float* flows, float* grad_feat, int tl, int bs, int h,
                                int w, int c, void* stream);
 
@@ -180,12 +180,12 @@ int dis_conv2d_fwd(const float* x, const float* w_packed, const float* bias, flo
                    int hin, int win, int cin, int cout, int k, int stride, int pad, int act, void* stream);
 /* Weight/bias gradient.  gy: (n,hout,wout,cout) gradient wrt the PRE-activation output; x has cin_pad channels.
  * workspace: dis_conv2d_wgrad_workspace(cin_pad,cout,k,stride) floats (-1 if the shape is unsupported).
- * grad_w: (cout,cin_real,k,k) OIHW, grad_b: (cout) or NULL, both OVERWRITTEN; bias_acc: cout zeroed doubles
- * (needed when grad_b != NULL). */
+ * grad_w: (cout,cin_real,k,k) OIHW, grad_b: (cout) or NULL, both OVERWRITTEN.  Deterministic (partial slabs
+ * per workgroup summed in a fixed order, no float atomics). */
 long dis_conv2d_wgrad_workspace(int cin_pad, int cout, int k, int stride);
-int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace,
-                     double* bias_acc, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k,
-                     int stride, int pad, void* stream);
+int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
+                     int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,
+                     void* stream);
 /* Input gradient of a k=4, stride=2, pad=1 convolution (transposed convolution) as four 2x2 phase convolutions on
  * the matrix cores.  w_oihw is the unpacked weight (cout,cin,4,4).  workspace: 16*cin*cout floats.
  * gx: (n,hin,win,cin) overwritten. */
