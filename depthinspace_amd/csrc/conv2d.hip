@@ -556,12 +556,23 @@ __global__ void wgrad_reduce2_kernel(const float* __restrict__ tmp, float* __res
     if (ci < cin_real) gw[(((long)co * cin_real + ci) * kh + ky) * kw + kx] = s;
   }
 }
-__global__ void bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ gb, int workers, int cout) {
-  const int co = threadIdx.x;
-  if (co >= cout) return;
+// 1024 threads: thread t sums workers {t/cout, t/cout + 1024/cout, ...} of channel t%cout (coalesced rows of bpart),
+// then the 1024/cout partial sums of a channel are added in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ gb,
+                                                           int workers, int cout) {
+  __shared__ float red[1024];
+  const int lanes = 1024 / cout;  // cout divides 1024 (16, 32, 64, ...)
+  const int co = threadIdx.x % cout, sub = threadIdx.x / cout;
   float s = 0.f;
-  for (int k = 0; k < workers; ++k) s += bpart[(long)k * cout + co];
-  gb[co] = s;
+  if (sub < lanes)
+    for (int k = sub; k < workers; k += lanes) s += bpart[(long)k * cout + co];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < cout) {
+    float t = 0.f;
+    for (int k = 0; k < lanes; ++k) t += red[k * cout + threadIdx.x];
+    gb[threadIdx.x] = t;
+  }
 }
 __global__ void cast_d2f_kernel(const double* __restrict__ a, float* __restrict__ o, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = (float)a[i];
@@ -602,7 +613,7 @@ static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_
   const long total = (long)C::NCHUNK * C::NSPLIT * C::MROWS * COUT;
   hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)tmp, gw,
                      C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, KW, KH, COUT, cin_real, C::PART);
-  if (gb) hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(64), 0, s, (const float*)a.bpart, gb, (int)workers, COUT);
+  if (gb) hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)a.bpart, gb, (int)workers, COUT);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

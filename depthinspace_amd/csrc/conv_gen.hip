@@ -1,0 +1,584 @@
+// General implicit-GEMM convolution family on the CDNA4 matrix cores (fp32 in / fp32 accumulate,
+// v_mfma_f32_16x16x4_f32) for the DIS-SF encoder-decoder (DispNetS, reference model/networks.py:170-295):
+// channel counts 2..1024, kernels 7/5/3, stride 1/2, ConvTranspose2d(k3,s2,p1,op1) with crop_like, and all
+// their input / weight / bias gradients.
+//
+// Unlike conv2d.hip (whole layer's weights resident in LDS, specialised per FuseNet shape) the weights here
+// do not fit LDS (up to 1024x512x9 floats), so both operands are streamed:
+//
+//   forward-like kernel  D[pixel][co] += A[pixel][(tap,ci)] * B[(tap,ci)][co]
+//     tile 128 pixels x BN couts per workgroup (4 waves x 32 pixels), k-step = 16 channels of one tap,
+//     A gathered from nhwc global memory by per-thread (tap-shifted) addresses, B read from a pre-packed
+//     fragment-ordered weight image; both double-buffered in LDS with register prefetch (one barrier per
+//     k-step).  Lane group g of a wave owns channels [4g,4g+4) of the chunk so every fragment is one
+//     ds_read_b128 feeding 4 MFMAs.
+//     A "tap" is an arbitrary (dy,dx) input offset, the output grid may be strided/offset, so the same kernel
+//     runs: conv forward (stride 1/2), stride-1 and stride-2 (4 parity phases) input gradients, the transposed
+//     convolution forward (4 parity phases) and its input gradient (a stride-2 conv of gy).
+//
+//   weight-gradient kernel  dW[tap][xc][gc] = sum_pixels X[pixel+tap][xc] * G[pixel][gc]
+//     tile (one tap) x TX x-channels x TG g-channels per workgroup, k = 32 pixels per step, split-K over
+//     pixel ranges into partial slabs that a second kernel sums in a fixed order (deterministic).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CG_MAXTAPS 49
+#define CG_BM 128
+#define CG_CK 16
+#define CG_AS 20  // LDS pixel stride of the A tile (floats): 16 channels + 4 pad
+
+struct GenArgs {
+  const float* x;
+  const float* w;  // packed [tap][chunk][nblk][4][BN][4]
+  const float* bias;
+  float* y;
+  int n, hin, win, ldx, xoff, cin;  // channels [xoff, xoff+cin) of a pixel of ldx floats; cin % 4 == 0
+  int nchunk;                       // ceil(cin / 16)
+  int hv, wv, S;                    // virtual output grid and the input step per virtual pixel
+  int hf, wf, ldy, yoff, cout;      // output tensor (n,hf,wf,ldy): channels [yoff, yoff+cout) are written
+  int osy, ooy, osx, oox;           // output pixel = (vy*osy+ooy, vx*osx+oox)
+  int act, ntaps, nblk;
+  short tdy[CG_MAXTAPS], tdx[CG_MAXTAPS];
+};
+
+template <int BN>
+__global__ __launch_bounds__(256) void convg_fwd_kernel(GenArgs a) {
+  constexpr int NT = BN / 16;
+  constexpr int A_FL = CG_BM * CG_AS, B_FL = 16 * BN;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_FL + B_FL)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int M = a.n * a.hv * a.wv;
+  const int nb = blockIdx.x % a.nblk, m0 = (blockIdx.x / a.nblk) * CG_BM;
+
+  // loader role: thread owns quarter pq of pixels p0 and p0+64 of the tile
+  const int pq = tid & 3, p0 = tid >> 2;
+  long pbase[2];
+  int piy[2], pix[2];
+  bool pval[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + p0 + j * 64;
+    pval[j] = m < M;
+    const int mm = pval[j] ? m : 0;
+    const int vx = mm % a.wv, t = mm / a.wv, vy = t % a.hv, nn = t / a.hv;
+    pbase[j] = (long)nn * a.hin * a.win;
+    piy[j] = vy * a.S;
+    pix[j] = vx * a.S;
+  }
+  float4 ra[2], rb = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto prefetch = [&](int tap, int chunk) {
+    const int dy = a.tdy[tap], dx = a.tdx[tap];
+    const int c = chunk * CG_CK + pq * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int iy = piy[j] + dy, ix = pix[j] + dx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pval[j] && c < a.cin && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
+        v = *(const float4*)(a.x + (pbase[j] + (long)iy * a.win + ix) * a.ldx + a.xoff + c);
+      ra[j] = v;
+    }
+    if (tid < BN * 4) rb = ((const float4*)a.w)[((long)(tap * a.nchunk + chunk) * a.nblk + nb) * (BN * 4) + tid];
+  };
+  auto stage = [&](int buf) {
+    float* A = smem + buf * (A_FL + B_FL);
+    float* B = A + A_FL;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *(float4*)(A + (p0 + j * 64) * CG_AS + pq * 4) = ra[j];
+    if (tid < BN * 4) ((float4*)B)[tid] = rb;
+  };
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.ntaps * a.nchunk;
+  prefetch(0, 0);
+  stage(0);
+  __syncthreads();
+  int tap = 0, chunk = 0;
+  for (int ks = 0; ks < nk; ++ks) {
+    int ntap = tap, nch = chunk + 1;
+    if (nch == a.nchunk) {
+      nch = 0;
+      ++ntap;
+    }
+    const bool more = ks + 1 < nk;
+    if (more) prefetch(ntap, nch);
+    const float* A = smem + (ks & 1) * (A_FL + B_FL);
+    const float* B = A + A_FL;
+    f32x4 av[2], bv[NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) av[mt] = *(const f32x4*)(A + (wave * 32 + mt * 16 + li) * CG_AS + lg * 4);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const f32x4*)(B + (lg * BN + nt * 16 + li) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], bv[nt][e], acc[mt][nt], 0, 0, 0);
+    if (more) stage((ks + 1) & 1);
+    __syncthreads();
+    tap = ntap;
+    chunk = nch;
+  }
+
+  // epilogue: bias + activation, masked store of the real output channels
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * 32 + mt * 16 + lg * 4 + r;
+      if (m >= M) continue;
+      const int vx = m % a.wv, t = m / a.wv, vy = t % a.hv, nn = t / a.hv;
+      float* yp = a.y + (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = nb * BN + nt * 16 + li;
+        if (co < a.cout) {
+          const float bval = a.bias ? a.bias[co] : 0.f;
+          yp[co] = act_apply(acc[mt][nt][r] + bval, a.act);
+        }
+      }
+    }
+  }
+}
+
+// packed[tap][chunk][nb][lg][col][e] = W(tap, ci = chunk*16 + lg*4 + e, co = nb*BN + col)
+//   W = w[ci*s_ci + co*s_co + tsrc[tap]] for ci < ci_real && co < co_real, else 0
+struct PackArgs {
+  const float* w;
+  float* packed;
+  int ntaps, nchunk, nblk, bn, ci_real, co_real;
+  long s_ci, s_co;
+  short tsrc[CG_MAXTAPS];
+};
+__global__ void convg_pack_kernel(PackArgs a) {
+  const long total = (long)a.ntaps * a.nchunk * a.nblk * 16 * a.bn;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 3);
+    long r = i >> 2;
+    const int col = (int)(r % a.bn);
+    r /= a.bn;
+    const int lg = (int)(r & 3);
+    r >>= 2;
+    const int nb = (int)(r % a.nblk);
+    r /= a.nblk;
+    const int chunk = (int)(r % a.nchunk);
+    const int tap = (int)(r / a.nchunk);
+    const int ci = chunk * CG_CK + lg * 4 + e, co = nb * a.bn + col;
+    float v = 0.f;
+    if (ci < a.ci_real && co < a.co_real) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
+    a.packed[i] = v;
+  }
+}
+
+static int cg_bn(int cout) { return cout > 32 ? 64 : (cout > 16 ? 32 : 16); }
+
+// one launch of the forward-like kernel (packs its weights first)
+static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int co_real, long s_ci, long s_co,
+                  const short* tsrc, hipStream_t s) {
+  if (a.ntaps <= 0) return DIS_OK;  // empty phase
+  if ((long)a.n * a.hv * a.wv <= 0) return DIS_OK;
+  const int bn = cg_bn(a.cout);
+  a.nblk = (a.cout + bn - 1) / bn;
+  a.nchunk = (a.cin + CG_CK - 1) / CG_CK;
+  PackArgs p;
+  p.w = w_raw; p.packed = wpack; p.ntaps = a.ntaps; p.nchunk = a.nchunk; p.nblk = a.nblk; p.bn = bn;
+  p.ci_real = ci_real; p.co_real = co_real; p.s_ci = s_ci; p.s_co = s_co;
+  for (int t = 0; t < a.ntaps; ++t) p.tsrc[t] = tsrc[t];
+  const long ptotal = (long)a.ntaps * a.nchunk * a.nblk * 16 * bn;
+  hipLaunchKernelGGL(convg_pack_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
+  a.w = wpack;
+  const long M = (long)a.n * a.hv * a.wv;
+  const long grid = ((M + CG_BM - 1) / CG_BM) * a.nblk;
+  if (grid > 2147483647L) return DIS_ERR_BAD_SHAPE;
+  if (bn == 64) hipLaunchKernelGGL(convg_fwd_kernel<64>, dim3((unsigned)grid), dim3(256), 0, s, a);
+  else if (bn == 32) hipLaunchKernelGGL(convg_fwd_kernel<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(convg_fwd_kernel<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+extern "C" long dis_convg_pack_workspace(int cin, int cout, int k) {
+  if (cin <= 0 || cout <= 0 || k <= 0 || k * k > CG_MAXTAPS) return -1;
+  const int bn = cg_bn(cout);
+  const long nblk = (cout + bn - 1) / bn, nchunk = (cin + CG_CK - 1) / CG_CK;
+  return (long)k * k * nchunk * nblk * 16 * bn;
+}
+
+static int floordiv2(int v) { return (v >= 0) ? v / 2 : -((-v + 1) / 2); }
+
+extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const float* w, const float* bias,
+                             float* y, int ldy, int yoff, float* wpack, int n, int hin, int win, int cin,
+                             int cin_w, int hout, int wout, int cout, int cout_w, int k, int stride, int pad,
+                             int act, void* stream) {
+  if (!x || !w || !y || !wpack) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || cin <= 0 || cout <= 0 || cin_w <= 0 ||
+      cout_w <= 0 || k <= 0 || pad < 0)
+    return DIS_ERR_BAD_SHAPE;
+  if (k * k > CG_MAXTAPS || (stride != 1 && stride != 2) || mode < 0 || mode > 3) return DIS_ERR_UNSUPPORTED;
+  if ((cin & 3) || (xoff & 3) || (ldx & 3) || xoff + cin > ldx || yoff + cout > ldy || cin_w > cin || cout_w > cout)
+    return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  GenArgs a;
+  a.x = x; a.w = nullptr; a.bias = bias; a.y = y;
+  a.n = n; a.hin = hin; a.win = win; a.ldx = ldx; a.xoff = xoff; a.cin = cin;
+  a.hf = hout; a.wf = wout; a.ldy = ldy; a.yoff = yoff; a.cout = cout; a.act = act;
+  short tsrc[CG_MAXTAPS];
+  const long kk = (long)k * k;
+  if (mode == DIS_CONVG_CONV || mode == DIS_CONVG_TCONV_DGRAD) {
+    // direct form: out[vy][vx] = sum_taps in[vy*S + ky - pad][vx*S + kx - pad] * W
+    if (mode == DIS_CONVG_CONV) {
+      if (hout != (hin + 2 * pad - k) / stride + 1 || wout != (win + 2 * pad - k) / stride + 1) return DIS_ERR_BAD_SHAPE;
+    } else if (stride != 2) {
+      return DIS_ERR_UNSUPPORTED;
+    }
+    a.hv = hout; a.wv = wout; a.S = stride; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
+    a.ntaps = k * k;
+    for (int ky = 0; ky < k; ++ky)
+      for (int kx = 0; kx < k; ++kx) {
+        a.tdy[ky * k + kx] = (short)(ky - pad);
+        a.tdx[ky * k + kx] = (short)(kx - pad);
+        tsrc[ky * k + kx] = (short)(ky * k + kx);
+      }
+    // conv: w[co][ci][ky][kx] (co rows of cin_w);  tconv dgrad: w[ci_t = out][co_t = in][ky][kx]
+    const long s_ci = kk, s_co = (long)cin_w * kk;
+    return cg_run(a, w, wpack, cin_w, cout_w, s_ci, s_co, tsrc, s);
+  }
+  // transposed form: out[oy][ox] = sum_{ky,kx : parity} in[(oy + pad - ky)/S][(ox + pad - kx)/S] * W
+  //   conv dgrad:  w[ci_in(= conv cout)][co_out(= conv cin)]  stored as w[conv_co][conv_ci][ky][kx]
+  //   tconv fwd :  w[ci][co][ky][kx]
+  // both: in-channel stride = cout_w*k*k, out-channel stride = k*k
+  const long s_ci = (long)cout_w * kk, s_co = kk;
+  if (stride == 1) {
+    a.hv = hout; a.wv = wout; a.S = 1; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
+    a.ntaps = k * k;
+    for (int ky = 0; ky < k; ++ky)
+      for (int kx = 0; kx < k; ++kx) {
+        a.tdy[ky * k + kx] = (short)(pad - ky);
+        a.tdx[ky * k + kx] = (short)(pad - kx);
+        tsrc[ky * k + kx] = (short)(ky * k + kx);
+      }
+    return cg_run(a, w, wpack, cin_w, cout_w, s_ci, s_co, tsrc, s);
+  }
+  const long pstride = dis_convg_pack_workspace(cin, cout, k);  // every phase packs into its own slice
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      GenArgs b = a;
+      b.hv = (hout - py + 1) / 2; b.wv = (wout - px + 1) / 2; b.S = 1;
+      b.osy = 2; b.ooy = py; b.osx = 2; b.oox = px;
+      int nt = 0;
+      for (int ky = 0; ky < k; ++ky) {
+        if ((py + pad - ky) & 1) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          if ((px + pad - kx) & 1) continue;
+          b.tdy[nt] = (short)floordiv2(py + pad - ky);
+          b.tdx[nt] = (short)floordiv2(px + pad - kx);
+          tsrc[nt] = (short)(ky * k + kx);
+          ++nt;
+        }
+      }
+      b.ntaps = nt;
+      if (b.hv <= 0 || b.wv <= 0) continue;
+      if (nt == 0) {
+        // no tap reaches this parity class (cannot happen for k >= 2): outputs would be bias only
+        return DIS_ERR_UNSUPPORTED;
+      }
+      int rc = cg_run(b, w, wpack + (long)(py * 2 + px) * pstride, cin_w, cout_w, s_ci, s_co, tsrc, s);
+      if (rc != DIS_OK) return rc;
+    }
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+struct WgGenArgs {
+  const float* X;
+  const float* G;
+  float* part;  // [ksplit][tap][cXp][cGp]
+  int n, hX, wX, ldX, xoff, cX;
+  int hG, wG, ldG, goff, cG;
+  int S, pad, k;
+  int nxb, ngb;
+  int mper;  // G pixels per split (multiple of 32)
+  int cXp, cGp;
+};
+
+template <int MTW, int NTW>
+__global__ __launch_bounds__(256) void convg_wgrad_kernel(WgGenArgs a) {
+  constexpr int TX = 32 * MTW, TG = 32 * NTW, XS = TX + 16, GS = TG + 16;
+  constexpr int X_FL = 32 * XS, G_FL = 32 * GS;
+  constexpr int NLX = TX / 32, NLG = TG / 32;  // float4 loads per thread per step
+  __shared__ __attribute__((aligned(16))) float smem[2 * (X_FL + G_FL)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int ntaps = a.k * a.k;
+  const int tap = blockIdx.x % ntaps;
+  const int rest = blockIdx.x / ntaps;
+  const int xb = rest % a.nxb, gb = rest / a.nxb;
+  const int ky = tap / a.k, kx = tap % a.k;
+  const int M = a.n * a.hG * a.wG;
+  const int m_lo = blockIdx.y * a.mper;
+  const int m_hi = min(M, m_lo + a.mper);
+
+  float4 rx[NLX], rg[NLG];
+  auto prefetch = [&](int mbase) {
+#pragma unroll
+    for (int j = 0; j < NLX; ++j) {
+      const int item = tid + j * 256;
+      const int px = item / (TX / 4), q = item % (TX / 4);
+      const int m = mbase + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c = xb * TX + q * 4;
+      if (m < m_hi && c < a.cX) {
+        const int gx = m % a.wG, t = m / a.wG, gy = t % a.hG, nn = t / a.hG;
+        const int iy = gy * a.S - a.pad + ky, ix = gx * a.S - a.pad + kx;
+        if (iy >= 0 && iy < a.hX && ix >= 0 && ix < a.wX)
+          v = *(const float4*)(a.X + (((long)nn * a.hX + iy) * a.wX + ix) * a.ldX + a.xoff + c);
+      }
+      rx[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NLG; ++j) {
+      const int item = tid + j * 256;
+      const int px = item / (TG / 4), q = item % (TG / 4);
+      const int m = mbase + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c = gb * TG + q * 4;
+      if (m < m_hi && c < a.cG) v = *(const float4*)(a.G + (long)m * a.ldG + a.goff + c);
+      rg[j] = v;
+    }
+  };
+  auto stage = [&](int buf) {
+    float* Xt = smem + buf * (X_FL + G_FL);
+    float* Gt = Xt + X_FL;
+#pragma unroll
+    for (int j = 0; j < NLX; ++j) {
+      const int item = tid + j * 256;
+      const int px = item / (TX / 4), q = item % (TX / 4);
+      *(float4*)(Xt + px * XS + q * 4) = rx[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NLG; ++j) {
+      const int item = tid + j * 256;
+      const int px = item / (TG / 4), q = item % (TG / 4);
+      *(float4*)(Gt + px * GS + q * 4) = rg[j];
+    }
+  };
+
+  f32x4 acc[MTW][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int wx = wave & 1, wg = wave >> 1;
+
+  if (m_lo < m_hi) {
+    prefetch(m_lo);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int mb = m_lo; mb < m_hi; mb += 32) {
+      const bool more = mb + 32 < m_hi;
+      if (more) prefetch(mb + 32);
+      const float* Xt = smem + buf * (X_FL + G_FL);
+      const float* Gt = Xt + X_FL;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        float av[MTW], bv[NTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) av[mt] = Xt[(kk * 4 + lg) * XS + wx * 16 * MTW + mt * 16 + li];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) bv[nt] = Gt[(kk * 4 + lg) * GS + wg * 16 * NTW + nt * 16 + li];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+      }
+      if (more) stage(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  float* out = a.part + ((long)blockIdx.y * ntaps + tap) * a.cXp * a.cGp;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int xc = xb * TX + wx * 16 * MTW + mt * 16 + lg * 4 + r;
+        const int gc = gb * TG + wg * 16 * NTW + nt * 16 + li;
+        out[(long)xc * a.cGp + gc] = acc[mt][nt][r];
+      }
+}
+
+// grad_w[(g*cXw + x)*k*k + tap] = sum_split part[split][tap][x][g]
+__global__ void convg_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int nsplit, int ntaps,
+                                          int cXp, int cGp, int cXw, int cGw) {
+  const long total = (long)ntaps * cXw * cGw;
+  const long slab = (long)ntaps * cXp * cGp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cGw);
+    long r = i / cGw;
+    const int x = (int)(r % cXw);
+    const int tap = (int)(r / cXw);
+    const float* p = part + ((long)tap * cXp + x) * cGp + g;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += p[k * slab];
+    gw[((long)g * cXw + x) * ntaps + tap] = s;
+  }
+}
+
+static void wg_tiles(int cX, int cG, int* mtw, int* ntw) {
+  *mtw = cX > 32 ? 2 : 1;
+  *ntw = cG > 32 ? 2 : 1;
+}
+static void wg_plan(int n, int hG, int wG, int cX, int cG, int k, int* nxb, int* ngb, int* nsplit, int* mper) {
+  int mtw, ntw;
+  wg_tiles(cX, cG, &mtw, &ntw);
+  const int TX = 32 * mtw, TG = 32 * ntw;
+  *nxb = (cX + TX - 1) / TX;
+  *ngb = (cG + TG - 1) / TG;
+  const long base = (long)k * k * (*nxb) * (*ngb);
+  const long M = (long)n * hG * wG;
+  long sp = (2048 + base - 1) / base;
+  const long maxsp = (M + 255) / 256;  // at least 256 pixels (8 k-steps) per split
+  if (sp > maxsp) sp = maxsp;
+  if (sp < 1) sp = 1;
+  long mp = (M + sp - 1) / sp;
+  mp = (mp + 31) / 32 * 32;
+  sp = (M + mp - 1) / mp;
+  *nsplit = (int)sp;
+  *mper = (int)mp;
+}
+
+extern "C" long dis_convg_wgrad_workspace(int n, int hG, int wG, int cX, int cG, int k) {
+  if (n <= 0 || hG <= 0 || wG <= 0 || cX <= 0 || cG <= 0 || k <= 0 || k * k > CG_MAXTAPS) return -1;
+  int nxb, ngb, nsplit, mper, mtw, ntw;
+  wg_plan(n, hG, wG, cX, cG, k, &nxb, &ngb, &nsplit, &mper);
+  wg_tiles(cX, cG, &mtw, &ntw);
+  return (long)nsplit * k * k * (nxb * 32 * mtw) * (ngb * 32 * ntw);
+}
+
+extern "C" int dis_convg_wgrad(const float* X, int ldX, int xoff, int hX, int wX, int cX, int cX_w, const float* G,
+                               int ldG, int goff, int hG, int wG, int cG, int cG_w, float* grad_w, float* workspace,
+                               int n, int k, int stride, int pad, void* stream) {
+  if (!X || !G || !grad_w || !workspace) return DIS_ERR_NULL;
+  if (n <= 0 || hX <= 0 || wX <= 0 || hG <= 0 || wG <= 0 || cX <= 0 || cG <= 0 || cX_w <= 0 || cG_w <= 0 ||
+      cX_w > cX || cG_w > cG || k <= 0 || pad < 0)
+    return DIS_ERR_BAD_SHAPE;
+  if ((cX & 3) || (cG & 3) || (xoff & 3) || (goff & 3) || (ldX & 3) || (ldG & 3) || xoff + cX > ldX || goff + cG > ldG)
+    return DIS_ERR_BAD_SHAPE;
+  if (k * k > CG_MAXTAPS || (stride != 1 && stride != 2)) return DIS_ERR_UNSUPPORTED;
+  if ((long)n * hG * wG > 2147483647L - 64) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  WgGenArgs a;
+  a.X = X; a.G = G; a.part = workspace;
+  a.n = n; a.hX = hX; a.wX = wX; a.ldX = ldX; a.xoff = xoff; a.cX = cX;
+  a.hG = hG; a.wG = wG; a.ldG = ldG; a.goff = goff; a.cG = cG;
+  a.S = stride; a.pad = pad; a.k = k;
+  int nsplit, mtw, ntw;
+  wg_plan(n, hG, wG, cX, cG, k, &a.nxb, &a.ngb, &nsplit, &a.mper);
+  wg_tiles(cX, cG, &mtw, &ntw);
+  a.cXp = a.nxb * 32 * mtw;
+  a.cGp = a.ngb * 32 * ntw;
+  const dim3 grid((unsigned)(k * k * a.nxb * a.ngb), (unsigned)nsplit);
+  if (mtw == 2 && ntw == 2) hipLaunchKernelGGL((convg_wgrad_kernel<2, 2>), grid, dim3(256), 0, s, a);
+  else if (mtw == 2) hipLaunchKernelGGL((convg_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, a);
+  else if (ntw == 2) hipLaunchKernelGGL((convg_wgrad_kernel<1, 2>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((convg_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, a);
+  const long total = (long)k * k * cX_w * cG_w;
+  hipLaunchKernelGGL(convg_wgrad_reduce_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s,
+                     (const float*)workspace, grad_w, nsplit, k * k, a.cXp, a.cGp, cX_w, cG_w);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums (bias gradients): out[c] = sum_pixels G[pixel][goff + c], deterministic two-level sum
+// ------------------------------------------------------------------------------------------------
+#define CS_BLOCKS 256
+__global__ __launch_bounds__(256) void colsum1_kernel(const float* __restrict__ G, int ldG, int goff, long npix, int c,
+                                                       float* __restrict__ part) {
+  __shared__ float red[256];
+  const long lo = npix * blockIdx.x / gridDim.x, hi = npix * (blockIdx.x + 1) / gridDim.x;
+  for (int c0 = 0; c0 < c; c0 += 256) {
+    const int cw = min(256, c - c0);          // channels handled in this pass
+    const int rows = 256 / cw > 0 ? 256 / cw : 1;
+    const int ch = threadIdx.x % cw, row = threadIdx.x / cw;
+    float s = 0.f;
+    if (row < rows)
+      for (long p = lo + row; p < hi; p += rows) s += G[p * ldG + goff + c0 + ch];
+    __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < cw) {
+      float t = 0.f;
+      for (int k = 0; k < rows; ++k) t += red[k * cw + threadIdx.x];
+      part[(long)blockIdx.x * c + c0 + threadIdx.x] = t;
+    }
+  }
+}
+__global__ void colsum2_kernel(const float* __restrict__ part, int nblocks, int c, float* __restrict__ out) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float s = 0.f;
+  for (int k = 0; k < nblocks; ++k) s += part[(long)k * c + ch];
+  out[ch] = s;
+}
+
+extern "C" long dis_colsum_workspace(int c) { return c > 0 ? (long)CS_BLOCKS * c : -1; }
+
+extern "C" int dis_colsum(const float* G, int ldG, int goff, long npix, int c, float* out, float* workspace,
+                          void* stream) {
+  if (!G || !out || !workspace) return DIS_ERR_NULL;
+  if (npix <= 0 || c <= 0 || goff < 0 || goff + c > ldG) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  int nb = CS_BLOCKS;
+  if (nb > npix) nb = (int)npix;
+  hipLaunchKernelGGL(colsum1_kernel, dim3(nb), dim3(256), 0, s, G, ldG, goff, npix, c, workspace);
+  hipLaunchKernelGGL(colsum2_kernel, dim3(dis_cdiv(c, 256)), dim3(256), 0, s, (const float*)workspace, nb, c, out);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SigmoidAffine of the disparity heads (reference model/networks.py:140-149): y = alpha*sigmoid(x - offset)
+// ------------------------------------------------------------------------------------------------
+__global__ void sigmoid_affine_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float alpha, float offset,
+                                          long count) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+    y[i] = alpha / (1.f + expf(-(x[i] - offset)));
+}
+// gpre4 (count,4): channel 0 = gy * alpha * s * (1 - s), channels 1..3 = 0 (padded layout for the conv kernels)
+__global__ void sigmoid_affine_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy,
+                                          float4* __restrict__ gpre4, float alpha, long count) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float sg = y[i] / alpha;
+    gpre4[i] = make_float4(gy[i] * alpha * sg * (1.f - sg), 0.f, 0.f, 0.f);
+  }
+}
+extern "C" int dis_sigmoid_affine_fwd(const float* x, float* y, float alpha, float offset, long count, void* stream) {
+  if (!x || !y) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(sigmoid_affine_fwd_kernel, dim3(dis_ew_grid(count, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     alpha, offset, count);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_sigmoid_affine_bwd(const float* y, const float* gy, float* gpre4, float alpha, long count,
+                                      void* stream) {
+  if (!y || !gy || !gpre4) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(sigmoid_affine_bwd_kernel, dim3(dis_ew_grid(count, 256)), dim3(256), 0, (hipStream_t)stream, y,
+                     gy, (float4*)gpre4, alpha, count);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}

@@ -58,9 +58,18 @@ SIGS = {
     'dis_conv3d_knn_select': 'ppiiiiip',
     'dis_conv3d_knn_fwd': 'ppppppppp' + 'iiiiip',
     'dis_conv3d_knn_bwd': 'ppppppp' + 'pppppp' + 'iiiiip',
+    'dis_convg_pack_workspace': 'iii',
+    'dis_convg_run': 'ipiipppiip' + 'iiiiiiiiiiiii' + 'p',
+    'dis_convg_wgrad_workspace': 'iiiiii',
+    'dis_convg_wgrad': 'piiiiiipiiiiiipp' + 'iiiip',
+    'dis_colsum_workspace': 'i',
+    'dis_colsum': 'piilippp',
+    'dis_sigmoid_affine_fwd': 'ppfflp',
+    'dis_sigmoid_affine_bwd': 'pppflp',
     'dis_adam_step': 'pppplffffifp',
 }
-_RET_LONG = {'dis_conv2d_wgrad_workspace'}
+_RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
+             'dis_colsum_workspace'}
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
 _lib = None

@@ -85,7 +85,122 @@ class OutputLayerFactory(object):
         self.params = params
 
     def __call__(self, channels_in, imsize=None):
-        return Slots({0: ConvParams(channels_in, 1, 3)})
+        m = Slots({0: ConvParams(channels_in, 1, 3)})
+        # SigmoidAffine constants (reference :140-149); gamma is 1 and beta 0 on the hot path
+        m.alpha = float(self.params.get('alpha', 1.0))
+        m.offset = float(self.params.get('offset', 0.0))
+        return m
+
+
+class DispNetS(TimedModule):
+    """DIS-SF network.  reference model/networks.py:170-295: seven [conv s2 + conv s1, ReLU] encoder stages
+    (k 7,5,3,3,3,3,3), seven ConvTranspose2d(k3,s2,p1,op1)+ReLU decoder stages with crop_like and skip concatenation
+    followed by a 3x3 iconv, four disparity heads whose outputs are bilinearly x2-upsampled (align_corners=False)
+    into the next level and finally resized to full resolution.  Same state_dict keys (`conv1.0.weight`,
+    `upconv7.0.weight`, `iconv3.0.weight`, `predict_disp4.0.weight`, ...).  Feature maps are nhwc; every conv runs
+    on the streaming MFMA kernels of csrc/conv_gen.hip."""
+
+    def __init__(self, channels_in, imsizes, output_facs, coordconv=False, weight_init=False, channel_multiplier=1):
+        super().__init__(mod_name='DispNetS')
+        cp = [channel_multiplier * c for c in (32, 64, 128, 256, 512, 512, 512)]
+        up = [channel_multiplier * c for c in (512, 512, 256, 128, 64, 32, 16)]
+        self.channels_in = channels_in
+        ks = [7, 5, 3, 3, 3, 3, 3]
+        cin = channels_in
+        for i in range(7):
+            setattr(self, f'conv{i + 1}', Slots({0: ConvParams(cin, cp[i], ks[i]), 2: ConvParams(cp[i], cp[i], ks[i])}))
+            cin = cp[i]
+        ups_in = [cp[6]] + up[:6]
+        for j, lvl in enumerate(range(7, 0, -1)):
+            setattr(self, f'upconv{lvl}', Slots({0: ConvParams(ups_in[j], up[j], 3, transposed=True)}))
+        icin = {7: up[0] + cp[5], 6: up[1] + cp[4], 5: up[2] + cp[3], 4: up[3] + cp[2], 3: 1 + up[4] + cp[1],
+                2: 1 + up[5] + cp[0], 1: 1 + up[6]}
+        for j, lvl in enumerate(range(7, 0, -1)):
+            setattr(self, f'iconv{lvl}', Slots({0: ConvParams(icin[lvl], up[j], 3)}))
+        facs = output_facs if isinstance(output_facs, list) else [output_facs] * 4
+        self.predict_disp4 = facs[3](up[3], imsizes[3])
+        self.predict_disp3 = facs[2](up[4], imsizes[2])
+        self.predict_disp2 = facs[1](up[5], imsizes[1])
+        self.predict_disp1 = facs[0](up[6], imsizes[0])
+
+    @staticmethod
+    def _conv(x, p, stride=1, need_dgrad=True):
+        k = p.weight.shape[2]
+        return ops.convg(x, p.weight, p.bias, stride, (k - 1) // 2, ops.ACT_RELU, need_dgrad)
+
+    @staticmethod
+    def _down(x, slots, need_dgrad=True):
+        """downsample_conv (:222-228)"""
+        return DispNetS._conv(DispNetS._conv(x, slots[0], 2, need_dgrad), slots[2], 1)
+
+    @staticmethod
+    def _up(x, slots, like):
+        """upconv (:236-240) + crop_like (:242-244)"""
+        return ops.convg_transposed(x, slots[0].weight, slots[0].bias, (like.shape[1], like.shape[2]), 1, ops.ACT_RELU)
+
+    @staticmethod
+    def _head(x, m):
+        return ops.disp_head_g(x, m[0].weight, m[0].bias, m.alpha, m.offset)
+
+    @staticmethod
+    def _up2_like(d, like):
+        """x2 bilinear (align_corners=False) of a planar (n,1,h,w) disparity, cropped like `like` (nhwc), returned
+        as an nhwc 1-channel tensor."""
+        n, _, h, w = d.shape
+        u = ops.resize_planar(d, (2 * h, 2 * w), False)
+        u = u[:, :, :like.shape[1], :like.shape[2]]
+        return u.reshape(n, like.shape[1], like.shape[2], 1)
+
+    @staticmethod
+    def _cat(parts):
+        """channel concatenation, zero-padded to a multiple of 4 channels (memory op only)"""
+        c = sum(p.shape[3] for p in parts)
+        if c % 4:
+            z = torch.zeros(parts[0].shape[:3] + (4 - c % 4,), dtype=parts[0].dtype, device=parts[0].device)
+            parts = list(parts) + [z]
+        return torch.cat(parts, dim=3)
+
+    def tforward(self, x):
+        """x planar (N,channels_in,H,W) -> 4 planar (N,1,H,W) disparities"""
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        assert C == self.channels_in and C <= 4
+        HW = H * W
+        flat = x.view(-1)
+        x4 = ops.pack4_nhwc([(flat[c * HW:], C * HW) for c in range(C)], N, H, W)
+        e1 = self._down(x4, self.conv1, need_dgrad=False)
+        e2 = self._down(e1, self.conv2)
+        e3 = self._down(e2, self.conv3)
+        e4 = self._down(e3, self.conv4)
+        e5 = self._down(e4, self.conv5)
+        e6 = self._down(e5, self.conv6)
+        e7 = self._down(e6, self.conv7)
+        i7 = self._conv(self._cat((self._up(e7, self.upconv7, e6), e6)), self.iconv7[0])
+        i6 = self._conv(self._cat((self._up(i7, self.upconv6, e5), e5)), self.iconv6[0])
+        i5 = self._conv(self._cat((self._up(i6, self.upconv5, e4), e4)), self.iconv5[0])
+        i4 = self._conv(self._cat((self._up(i5, self.upconv4, e3), e3)), self.iconv4[0])
+        d4 = self._head(i4, self.predict_disp4)
+        i3 = self._conv(self._cat((self._up(i4, self.upconv3, e2), e2, self._up2_like(d4, e2))), self.iconv3[0])
+        d3 = self._head(i3, self.predict_disp3)
+        i2 = self._conv(self._cat((self._up(i3, self.upconv2, e1), e1, self._up2_like(d3, e1))), self.iconv2[0])
+        d2 = self._head(i2, self.predict_disp2)
+        i1 = self._conv(self._cat((self._up(i2, self.upconv1, x4), self._up2_like(d2, x4))), self.iconv1[0])
+        d1 = self._head(i1, self.predict_disp1)
+        rs = lambda d: ops.resize_planar(d, (H, W), False)
+        return (d1, rs(d2), rs(d3), rs(d4))
+
+
+class DispDecoder(TimedModule):
+    """reference model/networks.py:297-309"""
+
+    def __init__(self, *args, max_disp=128, **kwargs):
+        super().__init__(mod_name='DispDecoder')
+        output_facs_disp = [OutputLayerFactory(type='disp', params={'alpha': max_disp / (2 ** s), 'beta': 0, 'gamma': 1,
+                                                                    'offset': 3}) for s in range(4)]
+        self.disp_decoder = DispNetS(*args, output_facs=output_facs_disp, **kwargs)
+
+    def tforward(self, x):
+        return self.disp_decoder(x)
 
 
 class DispToDepth(TimedModule):

@@ -439,6 +439,143 @@ def disp_head(x, weight, bias, alpha, offset=3.0):
 
 
 # --------------------------------------------------------------------------------------------------
+# general convolution family (DIS-SF / DispNetS): streaming implicit GEMM, csrc/conv_gen.hip
+# --------------------------------------------------------------------------------------------------
+CONVG_CONV, CONVG_CONV_DGRAD, CONVG_TCONV, CONVG_TCONV_DGRAD = 0, 1, 2, 3
+
+
+def _convg_run(mode, x, w, bias, y, n, hin, win, cin, cin_w, hout, wout, cout, cout_w, k, stride, pad, act):
+    per = lib.fn('dis_convg_pack_workspace')(cin, cout, k)
+    if per < 0:
+        raise lib.DisHipError(f'convg: unsupported shape cin={cin} cout={cout} k={k}')
+    phases = 4 if (mode in (CONVG_CONV_DGRAD, CONVG_TCONV) and stride == 2) else 1
+    wp = torch.empty(per * phases, dtype=torch.float32, device=x.device)
+    lib.call('dis_convg_run', mode, x, x.shape[-1], 0, w, bias, y, y.shape[-1], 0, wp, n, hin, win, cin, cin_w, hout,
+             wout, cout, cout_w, k, stride, pad, act)
+
+
+def _convg_wgrad(X, hX, wX, cX, cX_w, G, hG, wG, cG, cG_w, gw, n, k, stride, pad):
+    wsz = lib.fn('dis_convg_wgrad_workspace')(n, hG, wG, cX, cG, k)
+    if wsz < 0:
+        raise lib.DisHipError('convg wgrad: unsupported shape')
+    ws = torch.empty(wsz, dtype=torch.float32, device=X.device)
+    lib.call('dis_convg_wgrad', X, X.shape[-1], 0, hX, wX, cX, cX_w, G, G.shape[-1], 0, hG, wG, cG, cG_w, gw, ws, n, k,
+             stride, pad)
+
+
+def _colsum(G, c_real):
+    """sum over all pixels of the first c_real channels of an nhwc tensor"""
+    ld = G.shape[-1]
+    npix = G.numel() // ld
+    out = torch.empty(c_real, dtype=torch.float32, device=G.device)
+    ws = torch.empty(lib.fn('dis_colsum_workspace')(c_real), dtype=torch.float32, device=G.device)
+    lib.call('dis_colsum', G, ld, 0, npix, c_real, out, ws)
+    return out
+
+
+class _ConvG(torch.autograd.Function):
+    """Conv2d / ConvTranspose2d(k,s2,p,op=1, cropped to out_hw) + bias + activation on nhwc tensors.
+    x (n,h,w,cin_mem): cin_mem % 4 == 0 and >= the weight's input channels (extra channels must be zero-weight
+    padding lanes; their gradient is returned as zeros)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act, transposed, out_hw, need_dgrad):
+        x, weight = _c(x), _c(weight)
+        _chk(x, weight, bias)
+        n, hin, win, cin_mem = x.shape
+        if transposed:
+            cin_w, cout, k, _ = weight.shape
+            hout, wout = out_hw
+            if stride != 2 or hout > 2 * hin or wout > 2 * win:
+                raise RuntimeError('transposed conv: stride 2 and out_hw <= 2x input expected')
+        else:
+            cout, cin_w, k, _ = weight.shape
+            hout, wout = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
+        if cin_mem % 4 or cin_w > cin_mem or cout % 4:
+            raise RuntimeError(f'convg: bad channel counts cin_mem={cin_mem} cin_w={cin_w} cout={cout}')
+        y = torch.empty((n, hout, wout, cout), dtype=torch.float32, device=x.device)
+        _convg_run(CONVG_TCONV if transposed else CONVG_CONV, x, weight, bias, y, n, hin, win, cin_mem, cin_w, hout,
+                   wout, cout, cout, k, stride, pad, act)
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        ctx.cfg = (stride, pad, act, transposed, bias is not None, need_dgrad)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        stride, pad, act, transposed, has_bias, need_dgrad = ctx.cfg
+        n, hin, win, cin_mem = x.shape
+        gy = _c(gy)
+        _, hout, wout, cout = gy.shape
+        k = weight.shape[2]
+        cin_w = weight.shape[0] if transposed else weight.shape[1]
+        if act != ACT_NONE:
+            gpre = torch.empty_like(gy)
+            lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
+        else:
+            gpre = gy
+        gx = None
+        if need_dgrad and ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _convg_run(CONVG_TCONV_DGRAD if transposed else CONVG_CONV_DGRAD, gpre, weight, None, gx, n, hout, wout,
+                       cout, cout, hin, win, cin_mem, cin_w, k, stride, pad, ACT_NONE)
+        gw = torch.empty_like(weight)
+        if transposed:
+            _convg_wgrad(gpre, hout, wout, cout, cout, x, hin, win, cin_mem, cin_w, gw, n, k, stride, pad)
+        else:
+            _convg_wgrad(x, hin, win, cin_mem, cin_w, gpre, hout, wout, cout, cout, gw, n, k, stride, pad)
+        gb = _colsum(gpre, cout) if has_bias else None
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+def convg(x, weight, bias, stride=1, pad=0, act=ACT_NONE, need_dgrad=True):
+    """Conv2d on an nhwc tensor through the streaming MFMA kernel (any channel count that is a multiple of 4)."""
+    return _ConvG.apply(x, weight, bias, stride, pad, act, False, None, need_dgrad)
+
+
+def convg_transposed(x, weight, bias, out_hw, pad=1, act=ACT_NONE):
+    """ConvTranspose2d(k=3, stride=2, padding=pad, output_padding=1) cropped to out_hw (crop_like)."""
+    return _ConvG.apply(x, weight, bias, 2, pad, act, True, tuple(out_hw), True)
+
+
+class _HeadG(torch.autograd.Function):
+    """Conv2d(cin,1,3,pad 1) + alpha*sigmoid(. - offset) for any cin % 4 == 0: x nhwc -> y planar (n,1,h,w)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, alpha, offset):
+        x, weight, bias = _c(x), _c(weight), _c(bias)
+        _chk(x, weight, bias)
+        n, h, w, cin = x.shape
+        k = weight.shape[2]
+        y = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
+        _convg_run(CONVG_CONV, x, weight, bias, y.view(n, h, w, 1), n, h, w, cin, weight.shape[1], h, w, 1, 1, k, 1,
+                   k // 2, ACT_NONE)
+        lib.call('dis_sigmoid_affine_fwd', y, y, float(alpha), float(offset), y.numel())
+        ctx.save_for_backward(x, weight, y)
+        ctx.alpha = float(alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        n, h, w, cin = x.shape
+        k = weight.shape[2]
+        cin_w = weight.shape[1]
+        gpre4 = torch.empty((n, h, w, 4), dtype=torch.float32, device=x.device)
+        lib.call('dis_sigmoid_affine_bwd', y, _c(gy), gpre4, ctx.alpha, n * h * w)
+        gx = torch.empty_like(x)
+        _convg_run(CONVG_CONV_DGRAD, gpre4, weight, None, gx, n, h, w, 4, 1, h, w, cin, cin_w, k, 1, k // 2, ACT_NONE)
+        gw = torch.empty_like(weight)
+        _convg_wgrad(x, h, w, cin, cin_w, gpre4, h, w, 4, 1, gw, n, k, 1, k // 2)
+        gb = _colsum(gpre4, 1)
+        return gx, gw, gb, None, None
+
+
+def disp_head_g(x, weight, bias, alpha, offset=3.0):
+    return _HeadG.apply(x, weight, bias, alpha, offset)
+
+
+# --------------------------------------------------------------------------------------------------
 # GroupNorm(1 group) (+ residual + activation)
 # --------------------------------------------------------------------------------------------------
 class _GroupNorm(torch.autograd.Function):

@@ -252,6 +252,52 @@ int dis_conv3d_knn_bwd(const float* geom, const float* wf, const float* dense1_w
                        const float* y, const float* gy, float* grad_wf, float* gparams, double* acc, int tl, int bs,
                        int h, int wd, int stride, void* stream);
 
+/* ---------------------------------------------------------------- general convolution family (DIS-SF) */
+
+/* Streaming implicit-GEMM convolution on the matrix cores for the DispNetS encoder-decoder (reference
+ * model/networks.py:170-295: Conv2d k7/k5/k3 stride 1/2 with ReLU :222-234, ConvTranspose2d(k3,s2,p1,op1) :236-240
+ * with crop_like :242-244), channel counts 2..1024.  All tensors nhwc; a tensor argument is (pointer, ld, off):
+ * a pixel occupies `ld` floats and the channels [off, off+c) are used, so channel slices of a concatenated buffer
+ * can be read / written in place.  `cin`/`cout` are the channel counts processed (cin % 4 == 0); `cin_w`/`cout_w`
+ * (<= cin/cout) are the channels the weight tensor really has: the rest are zero-padded lanes (read as zero weights,
+ * written as zeros).
+ *   DIS_CONVG_CONV        y = act(conv(x, w[cout_w][cin_w][k][k]) + bias), hout = (hin+2*pad-k)/stride+1
+ *   DIS_CONVG_CONV_DGRAD  x := gradient wrt the conv's pre-activation output (n,hin,win,cin = conv cout);
+ *                         y := gradient wrt the conv's input (n,hout,wout,cout = conv cin); w is the conv's weight
+ *                         [cin_w][cout_w][k][k]; stride 2 runs as 4 output-parity phases
+ *   DIS_CONVG_TCONV       y = act(conv_transpose(x, w[cin_w][cout_w][k][k], stride 2) + bias) cropped to (hout,wout)
+ *   DIS_CONVG_TCONV_DGRAD x := gradient wrt the (cropped) transposed-conv output; y := gradient wrt its input;
+ *                         w is the transposed conv's weight [cout_w][cin_w][k][k]
+ * wpack: workspace of dis_convg_pack_workspace(cin,cout,k) floats (x4 for the two phase-decomposed cases:
+ * CONV_DGRAD and TCONV with stride 2). */
+#define DIS_CONVG_CONV 0
+#define DIS_CONVG_CONV_DGRAD 1
+#define DIS_CONVG_TCONV 2
+#define DIS_CONVG_TCONV_DGRAD 3
+long dis_convg_pack_workspace(int cin, int cout, int k);
+int dis_convg_run(int mode, const float* x, int ldx, int xoff, const float* w, const float* bias, float* y, int ldy,
+                  int yoff, float* wpack, int n, int hin, int win, int cin, int cin_w, int hout, int wout, int cout,
+                  int cout_w, int k, int stride, int pad, int act, void* stream);
+
+/* Weight gradient of the family: grad_w[g][x][ky][kx] = sum_{n,gy,gx} X[n][gy*stride-pad+ky][gx*stride-pad+kx][x] *
+ * G[n][gy][gx][g]  (g < cG_w, x < cX_w; OVERWRITTEN; deterministic split-K slabs).
+ *   conv:            X = layer input,              G = gradient wrt the pre-activation output  -> (cout,cin,k,k)
+ *   transposed conv: X = gradient wrt its output,  G = layer input                             -> (cin,cout,k,k)
+ * workspace: dis_convg_wgrad_workspace(n,hG,wG,cX,cG,k) floats. */
+long dis_convg_wgrad_workspace(int n, int hG, int wG, int cX, int cG, int k);
+int dis_convg_wgrad(const float* X, int ldX, int xoff, int hX, int wX, int cX, int cX_w, const float* G, int ldG,
+                    int goff, int hG, int wG, int cG, int cG_w, float* grad_w, float* workspace, int n, int k,
+                    int stride, int pad, void* stream);
+
+/* out[c] = sum over npix pixels of G[pixel*ldG + goff + c]  (bias gradients).  workspace: dis_colsum_workspace(c). */
+long dis_colsum_workspace(int c);
+int dis_colsum(const float* G, int ldG, int goff, long npix, int c, float* out, float* workspace, void* stream);
+
+/* SigmoidAffine of the DIS-SF disparity heads, reference model/networks.py:140-149: y = alpha*sigmoid(x - offset).
+ * The backward writes the pre-sigmoid gradient as a zero-padded 4-channel nhwc tensor (count,4) for dis_convg_*. */
+int dis_sigmoid_affine_fwd(const float* x, float* y, float alpha, float offset, long count, void* stream);
+int dis_sigmoid_affine_bwd(const float* y, const float* gy, float* gpre4, float alpha, long count, void* stream);
+
 /* ---------------------------------------------------------------- optimiser ----------------- */
 
 /* torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) on a flat fp32 buffer (reference train_val.py:55-56).

@@ -1,0 +1,226 @@
+"""DIS-SF on the HIP path: the streaming MFMA convolution family (csrc/conv_gen.hip) through the C ABI vs plain
+PyTorch fp32 CPU references, the DispNetS forward/backward vs the CPU oracle (incl. the crop_like path), and the
+whole DIS-SF / DIS-FTSF training step vs the reference goldens (tests/golden/sf_*.npz, produced by
+oracle/make_golden.py from the imported reference)."""
+import os
+import argparse
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dis_oracle as O
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+# cin (weight), cin_mem (padded buffer), cout, k, stride, h, w: the DispNetS layer shapes at small spatial sizes
+CONVG_SHAPES = [
+    (2, 4, 32, 7, 2, 40, 36),      # conv1.0 (2-channel input in a 4-channel buffer)
+    (32, 32, 32, 7, 1, 20, 18),    # conv1.2
+    (32, 32, 64, 5, 2, 21, 19),    # conv2.0, odd sizes
+    (64, 64, 64, 5, 1, 11, 10),    # conv2.2
+    (64, 64, 128, 3, 2, 14, 7),    # conv3.0
+    (256, 256, 512, 3, 2, 8, 7),   # conv5.0
+    (512, 512, 512, 3, 1, 4, 4),   # conv7.2
+    (1024, 1024, 512, 3, 1, 8, 7),  # iconv7
+    (129, 132, 64, 3, 1, 16, 14),  # iconv3: concat with one disparity channel, zero-padded to 132
+    (17, 20, 16, 3, 1, 32, 27),    # iconv1
+]
+
+
+@pytest.mark.parametrize('cin,cin_mem,cout,k,stride,h,w', CONVG_SHAPES)
+def test_convg_conv_fwd_bwd(cin, cin_mem, cout, k, stride, h, w):
+    from depthinspace_amd import ops
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    n, pad = 2, (k - 1) // 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.relu(F.conv2d(xr, wr, br, stride=stride, padding=pad))
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+
+    xp = torch.zeros(n, h, w, cin_mem)
+    xp[..., :cin] = nhwc(x)
+    xd = xp.cuda().requires_grad_(True)
+    wd, bd = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yd = ops.convg(xd, wd, bd, stride, pad, ops.ACT_RELU)
+    assert tuple(yd.shape) == (n, y.shape[2], y.shape[3], cout)
+    assert relerr(nchw(yd), y) < 2e-5
+    yd.backward(nhwc(go).cuda())
+    assert relerr(nchw(xd.grad[..., :cin]), xr.grad) < 5e-5
+    if cin_mem > cin:
+        assert float(xd.grad[..., cin:].abs().max()) == 0.0
+    assert relerr(wd.grad, wr.grad) < 5e-5
+    assert relerr(bd.grad, br.grad) < 5e-5
+
+
+# cin, cout, hin, win, hout, wout (crop_like target)
+TCONV_SHAPES = [
+    (512, 512, 4, 4, 8, 7),     # upconv7 at 512x432: 8x8 cropped to 8x7
+    (512, 256, 16, 14, 32, 27),  # upconv5: 32x28 cropped to 32x27
+    (64, 32, 12, 9, 24, 18),    # upconv2, no crop
+    (32, 16, 10, 11, 19, 21),   # upconv1 with a crop in both directions
+]
+
+
+@pytest.mark.parametrize('cin,cout,hin,win,hout,wout', TCONV_SHAPES)
+def test_convg_transposed_fwd_bwd(cin, cout, hin, win, hout, wout):
+    from depthinspace_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + hin)
+    n = 2
+    x = torch.randn(n, cin, hin, win, generator=g)
+    wt = torch.randn(cin, cout, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.relu(F.conv_transpose2d(xr, wr, br, stride=2, padding=1, output_padding=1))[:, :, :hout, :wout]
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+
+    xd = nhwc(x).cuda().requires_grad_(True)
+    wd, bd = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yd = ops.convg_transposed(xd, wd, bd, (hout, wout), 1, ops.ACT_RELU)
+    assert relerr(nchw(yd), y) < 2e-5
+    yd.backward(nhwc(go).cuda())
+    assert relerr(nchw(xd.grad), xr.grad) < 5e-5
+    assert relerr(wd.grad, wr.grad) < 5e-5
+    assert relerr(bd.grad, br.grad) < 5e-5
+
+
+@pytest.mark.parametrize('cin,alpha', [(128, 16.0), (64, 32.0), (32, 64.0), (16, 128.0)])
+def test_convg_head_fwd_bwd(cin, alpha):
+    from depthinspace_amd import ops
+    g = torch.Generator().manual_seed(cin)
+    n, h, w = 2, 13, 17
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(1, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(1, generator=g) * 0.1 + 3.0
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = alpha * torch.sigmoid(F.conv2d(xr, wr, br, padding=1) - 3)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+    xd = nhwc(x).cuda().requires_grad_(True)
+    wd, bd = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yd = ops.disp_head_g(xd, wd, bd, alpha, 3.0)
+    assert tuple(yd.shape) == (n, 1, h, w)
+    assert relerr(yd, y) < 2e-5
+    yd.backward(go.cuda())
+    assert relerr(nchw(xd.grad), xr.grad) < 5e-5
+    assert relerr(wd.grad, wr.grad) < 5e-5
+    assert relerr(bd.grad, br.grad) < 5e-5
+
+
+def test_convg_rejects_bad_arguments():
+    from depthinspace_amd import ops, lib
+    x = torch.zeros(1, 8, 8, 6, device='cuda')  # 6 channels: not a multiple of 4
+    w = torch.zeros(16, 6, 3, 3, device='cuda')
+    with pytest.raises(RuntimeError):
+        ops.convg(x, w, None, 1, 1)
+    with pytest.raises(RuntimeError):
+        ops.convg(torch.zeros(1, 8, 8, 8), torch.zeros(16, 8, 3, 3), None, 1, 1)  # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize('H,W', [(64, 64), (64, 56)])
+def test_dispnets_matches_oracle(H, W):
+    """DispDecoder forward + parameter gradients vs the CPU oracle; 64x56 exercises crop_like
+    (widths 56,28,14,7,4,2,1,1: upconv4 8->7 and upconv7 2->1 are cropped)."""
+    from depthinspace_amd.model import networks
+    params = O.init_params(O.sf_param_shapes(), seed=5)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 2, H, W, generator=g)
+    outs = O.sf_forward(params, x)
+    gos = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * go).sum() for o, go in zip(outs, gos)).backward()
+
+    imsizes = [(H, W)]
+    for _ in range(3):
+        imsizes.append((imsizes[-1][0] // 2, imsizes[-1][1] // 2))
+    net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=imsizes)
+    net.load_state_dict({k: v.detach() for k, v in params.items()})
+    net = net.cuda()
+    outs_d = net(x.cuda())
+    assert len(outs_d) == 4
+    for o, od in zip(outs, outs_d):
+        assert tuple(od.shape) == tuple(o.shape)
+        l1 = float((od.detach().cpu() - o.detach()).abs().mean())
+        assert l1 < 1e-4, l1
+    sum((od * go.cuda()).sum() for od, go in zip(outs_d, gos)).backward()
+    worst = 0.0
+    for k, p in net.named_parameters():
+        e = relerr(p.grad, params[k].grad)
+        worst = max(worst, e)
+        assert e < 2e-3, (k, e)
+    print('DispNetS', H, W, 'worst grad rel err', worst)
+
+
+def make_args(bs, use_pseudo_gt):
+    return argparse.Namespace(use_pseudo_gt=use_pseudo_gt, lcn_radius=5, track_length=4, data_type='synthetic',
+                              architecture='single_frame', epochs=1, warmup_epochs=150, train_batch_size=bs,
+                              max_disp=128)
+
+
+@pytest.mark.parametrize('name', ['sf_64_bs1', 'sf_128_bs1_pgt'])
+def test_sf_step_matches_reference(golden_dir, name):
+    from depthinspace_amd import synth
+    from depthinspace_amd.model import networks, single_frame_worker
+    from depthinspace_amd.trainer import FlatAdam
+    G = np.load(os.path.join(golden_dir, name + '.npz'))
+    H, W, bs, pgt = int(G['H']), int(G['W']), int(G['bs']), bool(int(G['use_pseudo_gt']))
+    settings = synth.make_settings(H, W)
+    batch = synth.make_batch(settings, bs, 4, seed=int(G['bseed']), with_pseudo_gt=pgt)
+    params = O.init_params(O.sf_param_shapes(), seed=int(G['pseed']))
+    w = single_frame_worker.Worker(make_args(bs, pgt), settings=settings)
+    w.build_losses()
+    w.current_epoch = int(G['epoch'])
+    net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=w.imsizes)
+    net.load_state_dict({k: v.detach() for k, v in params.items()})
+    net = net.cuda()
+    opt = FlatAdam(net.parameters(), lr=1e-4)
+    errs, outs = w.train_step(net, opt, {k: torch.from_numpy(v) for k, v in batch.items()})
+    torch.cuda.synchronize()
+    # (ii) the four full-resolution disparities: L1 vs reference < 1e-4 (north-star tolerance)
+    assert len(outs) == 4
+    for i, o in enumerate(outs):
+        ref = torch.from_numpy(G[f'out{i}'])
+        l1 = float((o.detach().cpu() - ref).abs().mean())
+        assert l1 < 1e-4, (i, l1)
+    # (iii) ordered loss terms
+    vals = np.array([float(e.detach()) for e in errs])
+    assert len(vals) == len(G['vals'])
+    np.testing.assert_allclose(vals, G['vals'], rtol=2e-4, atol=2e-6)
+    # (iv) gradients of every parameter
+    keys = list(G['grad_keys'])
+    named = dict(net.named_parameters())
+    worst = 0.0
+    for i, k in enumerate(keys):
+        g = named[k].grad
+        scale = float(G['grad_absmax'][i]) + 1e-20
+        l2_ref = float(G['grad_l2'][i])
+        l2 = float(g.double().norm())
+        assert abs(l2 - l2_ref) <= 2e-3 * l2_ref + 1e-12, (k, l2, l2_ref)
+        if 'grad:' + k in G.files:
+            err = float((g.cpu() - torch.from_numpy(G['grad:' + k])).abs().max()) / scale
+            worst = max(worst, err)
+            assert err < 5e-3, (k, err)
+    # (v) parameters after one Adam step, where stored
+    for k in keys:
+        if 'new:' + k in G.files:
+            new_ref = torch.from_numpy(G['new:' + k])
+            assert float((named[k].detach().cpu() - new_ref).abs().max()) <= 2.1e-4, k
+    print(name, 'worst grad rel err', worst)
