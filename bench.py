@@ -30,9 +30,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak 
 PEAK_HBM_GBS = 8000.0           # same guide, HBM3E spec peak
 
 
-def make_args(bs):
+def make_args(bs, arch='multi_frame'):
     return argparse.Namespace(use_pseudo_gt=False, lcn_radius=5, track_length=TL, data_type='synthetic',
-                              architecture='multi_frame', epochs=1, warmup_epochs=150, train_batch_size=bs,
+                              architecture=arch, epochs=1, warmup_epochs=150, train_batch_size=bs,
                               max_disp=128)
 
 
@@ -55,20 +55,21 @@ def conv_flops(n, ho, wo, cin, cout, k):
     return 2.0 * n * ho * wo * cin * cout * k * k
 
 
-def cpu_baseline():
+def cpu_baseline(arch='multi_frame'):
     """Oracle step on the host cores: 1 step, bs=1 (4 frames), full resolution."""
     from depthinspace_amd import synth
     from oracle import dis_oracle as O
     settings = synth.make_settings(H, W)
     batch = synth.make_batch(settings, 1, TL, seed=1234)
-    params = O.init_params(O.mf_param_shapes(), seed=0)
+    params = O.init_params(O.mf_param_shapes() if arch == 'multi_frame' else O.sf_param_shapes(), seed=0)
     ctx = O.StepContext(settings)
     st = {'step': 0, 'm': {}, 'v': {}}
     t0 = time.time()
-    O.train_step(ctx, 'multi_frame', params, {k: torch.from_numpy(v) for k, v in batch.items()}, adam_state=st, epoch=2)
+    O.train_step(ctx, arch, params, {k: torch.from_numpy(v) for k, v in batch.items()}, adam_state=st, epoch=2)
     dt = time.time() - t0
+    tag = 'DIS-MF' if arch == 'multi_frame' else 'DIS-SF'
     return {'value': TL / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 training step of the CPU oracle, DIS-MF bs=1 (4 frames) 512x432 fp32, {dt:.1f} s, '
+            'sample': f'1 training step of the CPU oracle, {tag} bs=1 (4 frames) 512x432 fp32, {dt:.1f} s, '
                       f'torch threads={torch.get_num_threads()} of os.cpu_count()={os.cpu_count()}'}
 
 
@@ -77,11 +78,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--bs', type=int, default=4)
+    ap.add_argument('--bs', type=int, default=None, help='tracks per GPU (default 4 for multi_frame, 8 for single_frame)')
+    ap.add_argument('--arch', default='multi_frame', choices=['multi_frame', 'single_frame'],
+                    help='multi_frame = BASELINE.json metric (config 3/4); single_frame = DIS-SF (config 2, run in fp32)')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of one hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--epoch', type=int, default=2, help='training epoch the step models (epoch<2 adds the L1 warm-up term)')
     args = ap.parse_args()
+    if args.bs is None:
+        args.bs = 4 if args.arch == 'multi_frame' else 8
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -96,15 +101,21 @@ def main():
         torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from depthinspace_amd import synth, lib
-    from depthinspace_amd.model import multi_frame_networks, multi_frame_worker
+    from depthinspace_amd.model import multi_frame_networks, multi_frame_worker, single_frame_worker, networks
     from depthinspace_amd.trainer import FlatAdam
     lib.check_all_symbols()
 
     settings = synth.make_settings(H, W)
     torch.manual_seed(0)  # identical initial weights on every rank
-    net = multi_frame_networks.FuseNet(imsize=(H, W), K=settings.K, baseline=settings.baseline, track_length=TL,
-                                       max_disp=128).to(dev)
-    worker = multi_frame_worker.Worker(make_args(args.bs), settings=settings, train_device=str(dev))
+    mf = args.arch == 'multi_frame'
+    if mf:
+        net = multi_frame_networks.FuseNet(imsize=(H, W), K=settings.K, baseline=settings.baseline, track_length=TL,
+                                           max_disp=128).to(dev)
+        worker = multi_frame_worker.Worker(make_args(args.bs), settings=settings, train_device=str(dev))
+    else:
+        worker = single_frame_worker.Worker(make_args(args.bs, 'single_frame'), settings=settings,
+                                            train_device=str(dev))
+        net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=worker.imsizes).to(dev)
     worker.build_losses(device=dev)
     worker.current_epoch = args.epoch
     opt = FlatAdam(net.parameters(), lr=1e-4, world_size=world)
@@ -199,14 +210,28 @@ def main():
             per.setdefault(name, [0, 0.0])
             per[name][0] += 1
             per[name][1] += ms
-        # dis_conv2d_fwd int args: (n, hin, win, cin, cout, k, stride, pad, act); same kernel template for the
-        # forward 32->32 3x3 convs and their input gradients
-        sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_conv2d_fwd' and ia[3:7] == (32, 32, 3, 1)]
-        fl = sum(conv_flops(ia[0], ia[1], ia[2], 32, 32, 3) for ia, _ in sel)
+        if mf:
+            # dis_conv2d_fwd int args: (n, hin, win, cin, cout, k, stride, pad, act); same kernel template for the
+            # forward 32->32 3x3 convs and their input gradients
+            sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_conv2d_fwd' and ia[3:7] == (32, 32, 3, 1)]
+            fl = sum(conv_flops(ia[0], ia[1], ia[2], 32, 32, 3) for ia, _ in sel)
+            kname = 'conv_fwd_kernel<32,32,3,3,1> (fp32 MFMA 16x16x4)'
+        else:
+            # dis_convg_run int args: (mode, ldx, xoff, ldy, yoff, n, hin, win, cin, cin_w, hout, wout, cout, cout_w,
+            # k, stride, pad, act): every launch of the streaming kernel family convg_fwd_kernel<BN>; algorithmic
+            # flops use the real channel counts and the spatial size of the strided side
+            sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_convg_run']
+
+            def gflops(ia):
+                mode, n, hin, win, cw, hout, wout, cow, k = ia[0], ia[5], ia[6], ia[7], ia[9], ia[10], ia[11], ia[13], ia[14]
+                hw = hout * wout if mode in (0, 3) else hin * win
+                return 2.0 * n * hw * cw * cow * k * k
+            fl = sum(gflops(ia) for ia, _ in sel)
+            kname = 'convg_fwd_kernel<BN> (fp32 MFMA 16x16x4, all conv / dgrad / transposed-conv launches)'
         tm = sum(ms for _, ms in sel) * 1e-3
         if sel:
             ach = fl / tm / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel<32,32,3,3,1> (fp32 MFMA 16x16x4)',
+            roof = {'bound': 'mfma', 'kernel': kname,
                     'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'launches_per_step': len(sel),
                     'avg_launch_ms': tm * 1e3 / len(sel), 'flop_per_launch_avg': fl / len(sel),
@@ -215,15 +240,18 @@ def main():
         kernel_ms = {k: {'calls': v[0], 'ms': round(v[1], 3)} for k, v in top}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(args.arch)
 
     if rank == 0:
         frames = world * args.bs * TL * args.steps
         res = {
-            'metric': 'DIS-MF train frames/sec bs=4 default-pattern', 'value': frames / dt, 'unit': 'frames/s',
+            'metric': ('DIS-MF train frames/sec bs=4 default-pattern' if mf else
+                       f'DIS-SF train frames/sec bs={args.bs} default-pattern (fp32)'),
+            'value': frames / dt, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'DIS-MF (FuseNet) training step, bs={args.bs} per GPU x 4 frames, 512x432, '
+            'config': {'workload': (f'DIS-MF (FuseNet)' if mf else 'DIS-SF (DispNetS)') +
+                                   f' training step, bs={args.bs} per GPU x 4 frames, 512x432, '
                                    f'default-pattern synthetic, fwd+losses+bwd+Adam, epoch>={args.epoch}',
                        'global_batch': world * args.bs, 'parallelism': f'dp{world}', 'hip_graph': bool(use_graph)},
             'roofline': roof, 'cpu_baseline': cpu, 'loss_terms': losses, 'kernel_ms_one_eager_step': kernel_ms,

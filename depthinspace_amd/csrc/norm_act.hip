@@ -125,8 +125,12 @@ extern "C" int dis_gn_apply(const float* x, const double* stats, const float* ga
   return DIS_OK;
 }
 
-// backward pass 1: per-sample s1 = sum g*gamma, s2 = sum g*gamma*xhat ; per-channel dgamma, dbeta
-__global__ void gn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+// backward pass 1: per-sample s1 = sum g*gamma, s2 = sum g*gamma*xhat ; per-channel dgamma, dbeta.
+// Every block writes its partial sums to its own workspace slot (no atomics: 4096 blocks x 66 fp64 atomics on 96
+// addresses used to cost more than the memory pass itself); the second pass and a small reducer add them up in a
+// fixed order (deterministic).
+#define GN_BWD_BLOCKS 64
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                      const float* __restrict__ x, const double* __restrict__ stats,
                                      const float* __restrict__ gamma, double* __restrict__ red,
                                      double* __restrict__ gparam, long hw, int c, int act, float eps) {
@@ -148,29 +152,48 @@ __global__ void gn_bwd_reduce_kernel(const float* __restrict__ gy, const float* 
   const int g = (int)(threadIdx.x % cg) * 4;
   float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
   double s1 = 0.0, s2 = 0.0;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per4; i += (long)gridDim.x * blockDim.x) {
-    float4 gv = gp[i];
+  const long stride = (long)gridDim.x * blockDim.x;
+  auto body = [&](float4 gv, const float4 yv, const float4 xv) {
     if (act != DIS_ACT_NONE) {
-      const float4 yv = yp[i];
       gv.x *= act_grad_from_out(yv.x, act); gv.y *= act_grad_from_out(yv.y, act);
       gv.z *= act_grad_from_out(yv.z, act); gv.w *= act_grad_from_out(yv.w, act);
     }
-    const float4 xv = xp[i];
     const float xh[4] = {(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
     const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       dg[k] += ga[k] * xh[k];
       db[k] += ga[k];
       const float t = ga[k] * gam[g + k];
-      s1 += (double)t;
-      s2 += (double)(t * xh[k]);
+      t1 += t;
+      t2 += t * xh[k];
     }
+    s1 += (double)t1;
+    s2 += (double)t2;
+  };
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  // 4 independent loads per tensor in flight
+  for (; i + 3 * stride < per4; i += 4 * stride) {
+    float4 gv[4], yv[4], xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      gv[u] = gp[i + u * stride];
+      xv[u] = xp[i + u * stride];
+      yv[u] = (act != DIS_ACT_NONE) ? yp[i + u * stride] : gv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(gv[u], yv[u], xv[u]);
+  }
+  for (; i < per4; i += stride) {
+    const float4 gv = gp[i];
+    body(gv, (act != DIS_ACT_NONE) ? yp[i] : gv, xp[i]);
   }
   const double r1 = block_sum_d(s1, sm), r2 = block_sum_d(s2, sm);
+  const long slot = (long)n * gridDim.x + blockIdx.x;
   if (threadIdx.x == 0) {
-    atomic_add_d(red + 2 * n, r1);
-    atomic_add_d(red + 2 * n + 1, r2);
+    red[2 * slot] = r1;
+    red[2 * slot + 1] = r2;
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -185,8 +208,8 @@ __global__ void gn_bwd_reduce_kernel(const float* __restrict__ gy, const float* 
       a += (double)pg[t * 4 + k];
       b += (double)pb[t * 4 + k];
     }
-    atomic_add_d(gparam + threadIdx.x, a);
-    atomic_add_d(gparam + c + threadIdx.x, b);
+    gparam[slot * 2 * c + threadIdx.x] = a;
+    gparam[slot * 2 * c + c + threadIdx.x] = b;
   }
 }
 
@@ -195,15 +218,29 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
                                     const float* __restrict__ x, const double* __restrict__ stats,
                                     const float* __restrict__ gamma, const double* __restrict__ red,
                                     float* __restrict__ gx, float* __restrict__ gres, long hw, int c, int act,
-                                    float eps) {
+                                    float eps, int nred) {
   __shared__ float gam[GN_MAXC];
   const int n = blockIdx.y;
   float mean, rstd;
   const double m = (double)hw * c;
   gn_moments(stats, n, m, eps, &mean, &rstd);
-  const float a1 = (float)(red[2 * n] / m), a2 = (float)(red[2 * n + 1] / m);
+  __shared__ double tot[2];
+  if (threadIdx.x < 64) {  // wave 0 adds the per-block partials of pass 1 (same order in every block)
+    double t1 = 0.0, t2 = 0.0;
+    for (int b = threadIdx.x; b < nred; b += 64) {
+      t1 += red[2 * ((long)n * nred + b)];
+      t2 += red[2 * ((long)n * nred + b) + 1];
+    }
+    t1 = wave_sum_d(t1);
+    t2 = wave_sum_d(t2);
+    if (threadIdx.x == 0) {
+      tot[0] = t1;
+      tot[1] = t2;
+    }
+  }
   if (threadIdx.x < c) gam[threadIdx.x] = gamma[threadIdx.x];
   __syncthreads();
+  const float a1 = (float)(tot[0] / m), a2 = (float)(tot[1] / m);
   const int cg = c >> 2;
   const long per4 = hw * cg;
   const float4* gp = (const float4*)(gy + (long)n * hw * c);
@@ -229,13 +266,20 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
     op[i] = o;
   }
 }
-__global__ void gn_param_cast_kernel(const double* __restrict__ acc, float* __restrict__ gg, float* __restrict__ gb,
-                                     int c) {
-  for (int i = threadIdx.x; i < c; i += blockDim.x) {
-    gg[i] = (float)acc[i];
-    gb[i] = (float)acc[c + i];
+// dgamma / dbeta: one wave per (channel, kind); sums the `slots` block partials in a fixed order
+__global__ void gn_param_reduce_kernel(const double* __restrict__ part, float* __restrict__ gg, float* __restrict__ gb,
+                                       int c, int slots) {
+  const int j = blockIdx.x;  // 0..2c-1
+  double s = 0.0;
+  for (int k = threadIdx.x; k < slots; k += 64) s += part[(long)k * 2 * c + j];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) {
+    if (j < c) gg[j] = (float)s;
+    else gb[j - c] = (float)s;
   }
 }
+
+extern "C" long dis_gn_bwd_workspace(int n, int c) { return (n > 0 && c > 0) ? (long)n * GN_BWD_BLOCKS * (2 + 2 * c) : -1; }
 
 extern "C" int dis_gn_apply_bwd(const float* gy, const float* y, const float* x, const double* stats,
                                 const float* gamma, float* gx, float* gres, float* grad_gamma, float* grad_beta,
@@ -248,11 +292,13 @@ extern "C" int dis_gn_apply_bwd(const float* gy, const float* y, const float* x,
   hipStream_t s = (hipStream_t)stream;
   int gxg = dis_ew_grid(hw * (c / 4), 256);
   if (gxg > 256) gxg = 256;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(gxg, n), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma, red,
+  const int nred = GN_BWD_BLOCKS;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nred, n), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma, red,
                      gparam_acc, hw, c, act, eps);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gxg * 2, n), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma,
-                     (const double*)red, gx, gres, hw, c, act, eps);
-  hipLaunchKernelGGL(gn_param_cast_kernel, dim3(1), dim3(128), 0, s, (const double*)gparam_acc, grad_gamma, grad_beta, c);
+                     (const double*)red, gx, gres, hw, c, act, eps, nred);
+  hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(2 * c), dim3(64), 0, s, (const double*)gparam_acc, grad_gamma,
+                     grad_beta, c, n * nred);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

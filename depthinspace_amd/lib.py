@@ -52,6 +52,7 @@ SIGS = {
     'dis_act_bwd': 'pppilp',
     'dis_gn_stats': 'ppilp',
     'dis_gn_apply': 'ppppppiliifp',
+    'dis_gn_bwd_workspace': 'ii',
     'dis_gn_apply_bwd': 'ppppp' + 'pppp' + 'pp' + 'iliifp',
     'dis_add_act_fwd': 'pppilp',
     'dis_mask_weight_slots': 'pppliip',
@@ -69,7 +70,7 @@ SIGS = {
     'dis_adam_step': 'pppplffffifp',
 }
 _RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
-             'dis_colsum_workspace'}
+             'dis_colsum_workspace', 'dis_gn_bwd_workspace'}
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
 _lib = None

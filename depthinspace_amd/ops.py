@@ -605,8 +605,10 @@ class _GroupNorm(torch.autograd.Function):
         gres = torch.empty_like(x) if has_res else None
         gg = torch.empty(c, dtype=torch.float32, device=x.device)
         gb = torch.empty(c, dtype=torch.float32, device=x.device)
-        red = _zeros_d(2 * n, x.device)
-        pacc = _zeros_d(2 * c, x.device)
+        wtot = lib.fn('dis_gn_bwd_workspace')(n, c)
+        ws = torch.empty(wtot, dtype=torch.float64, device=x.device)
+        nred2 = wtot // (2 + 2 * c) * 2
+        red, pacc = ws[:nred2], ws[nred2:]
         lib.call('dis_gn_apply_bwd', gy, y, x, stats, gamma, gx, gres, gg, gb, red, pacc, n, hw, c, act, eps)
         return gx, None, gg, gb, gres, None, None
 

@@ -212,9 +212,12 @@ int dis_gn_stats(const float* x, double* stats, int n, long per_sample, void* st
 int dis_gn_apply(const float* x, const double* stats, const float* gamma, const float* beta, const float* residual,
                  float* y, int n, long hw, int c, int act, float eps, void* stream);
 /* Backward of dis_gn_apply.  gy: grad wrt y; y: forward output (needed when act != none); x: forward input.
- * red: (n,2) zeroed doubles workspace; gparam_acc: (2*c) zeroed doubles.
+ * red / gparam_acc: workspaces for per-block partial sums (no zeroing needed, no atomics; summed in a fixed order):
+ * with W = dis_gn_bwd_workspace(n,c) doubles in total, red = W*2/(2+2c) doubles and gparam_acc = W*2c/(2+2c) doubles
+ * (i.e. n*64*2 and n*64*2c).
  * gx overwritten; gres (optional) receives the residual-branch gradient (= gradient after act');
  * grad_gamma/grad_beta (c floats) overwritten. */
+long dis_gn_bwd_workspace(int n, int c);
 int dis_gn_apply_bwd(const float* gy, const float* y, const float* x, const double* stats, const float* gamma,
                      float* gx, float* gres, float* grad_gamma, float* grad_beta, double* red, double* gparam_acc,
                      int n, long hw, int c, int act, float eps, void* stream);
