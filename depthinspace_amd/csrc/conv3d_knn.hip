@@ -4,10 +4,16 @@
 // Data layout is built for this gather: geom (tl,bs,h,w,tl,4) keeps xyz+mask of the 4 slots of a pixel
 // in one 64-B line, wf (tl,bs,h,w,tl,32) keeps each slot's 32 features in one 128-B line.
 //   kernel 1 (select):    one lane per output pixel: 36 keys, masked top-9 (lowest candidate id wins ties)
-//   kernel 2 (aggregate): one half-wave (32 lanes = 32 channels) per output pixel: MLP 3->16->32 on the
-//                         local coordinates, feature gather (one line per neighbour), 32x32 mix, SELU.
-//   backward:             same mapping; per-lane register accumulators for the weight gradients, one
-//                         coalesced 128-B float-atomic row per neighbour for the feature gradient.
+//   kernel 2 (forward):   one wave per group of 16 output pixels.  Every per-pixel matrix product (dense2 16->32 per
+//                         neighbour, the 32x32 mix) runs on the matrix cores (v_mfma_f32_16x16x4_f32) in a
+//                         "pixel on the lane" layout: lane (li,lg) owns pixel li and channels {16*mt + 4*lg + r},
+//                         which is both the MFMA B-operand layout for products that contract over channels and
+//                         the MFMA result layout, so the chain h1 -> h2 -> agg -> y needs no data movement.
+//   backward:             same mapping for the recomputed forward and the per-pixel products (d agg, d h1); the
+//                         weight gradients contract over PIXELS, so their operands are transposed once through
+//                         a small per-wave LDS tile and accumulated in MFMA accumulators across all groups of a
+//                         wave; feature gradients leave as 128-B float-atomic rows.  Parameter gradients are
+//                         reduced through per-block slabs (deterministic, no atomics).
 #include "common.h"
 #include <float.h>
 
@@ -81,87 +87,15 @@ struct C3Params {
   const float* w;   // (32,32)
 };
 
-// per-half-wave LDS scratch
-struct __attribute__((aligned(16))) C3Scratch {
-  float h1[C3_NB][C3_H1];
-  float v32a[C3_C];
-  float v32b[C3_C];
-};
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float selu_f(float x) {
-  return x > 0.f ? SELU_SCALE_F * x : (SELU_SCALE_F * SELU_ALPHA_F) * (expf(x) - 1.f);
-}
+#define C3_GP 16   // output pixels per wave group
+#define C3_WS 36   // LDS row stride of w   (32 + 4: conflict-free b128 row reads and b32 column reads)
+#define C3_W2S 20  // LDS row stride of w2  (16 + 4)
+#define C3_XS 36   // LDS row stride of the 16x32 transposition tile
+#define C3_HS 20   // LDS row stride of the 16x16 transposition tile
 
-__device__ __forceinline__ void c3_neighbor(const C3Dims& d, int oy, int ox, int id, int* iy, int* ix, int* slot,
-                                            bool* inb) {
-  const int tap = id / C3_TL;
-  *slot = id % C3_TL;
-  *iy = oy * d.stride - 1 + tap / 3;
-  *ix = ox * d.stride - 1 + tap % 3;
-  *inb = *iy >= 0 && *iy < d.h && *ix >= 0 && *ix < d.w;
-}
-
-__global__ __launch_bounds__(256) void conv3d_aggregate_kernel(const float4* __restrict__ geom,
-                                                                 const float* __restrict__ wf, C3Params P,
-                                                                 const unsigned char* __restrict__ idx,
-                                                                 float* __restrict__ y, C3Dims d) {
-  __shared__ C3Scratch scr[8];
-  const int hw_id = threadIdx.x >> 5;      // half-wave inside the block
-  const int c = threadIdx.x & 31;          // channel
-  const int k16 = c & 15;
-  C3Scratch& S = scr[hw_id];
-  float w2r[C3_H1], wcol[C3_C];
-#pragma unroll
-  for (int k = 0; k < C3_H1; ++k) w2r[k] = P.w2[c * C3_H1 + k];
-#pragma unroll
-  for (int k = 0; k < C3_C; ++k) wcol[k] = P.w[k * C3_C + c];
-  const float b2c = P.b2[c];
-  const float w1x = P.w1[k16 * 3], w1y = P.w1[k16 * 3 + 1], w1z = P.w1[k16 * 3 + 2], b1k = P.b1[k16];
-
-  const long total = (long)d.tl * d.bs * d.ho * d.wo;
-  const long nhalf = (long)gridDim.x * 8;
-  for (long i = (long)blockIdx.x * 8 + hw_id; i < total; i += nhalf) {
-    const int ox = (int)(i % d.wo);
-    const int oy = (int)((i / d.wo) % d.ho);
-    const long tb = i / ((long)d.wo * d.ho);
-    const float4* g = geom + tb * d.h * d.w * C3_TL;
-    const float* f = wf + tb * d.h * d.w * C3_TL * C3_C;
-    const float4 ctr = g[((long)(oy * d.stride) * d.w + ox * d.stride) * C3_TL];
-    float agg = 0.f;
-#pragma unroll
-    for (int n = 0; n < C3_NB; ++n) {
-      const int id = idx[i * C3_NB + n];
-      int iy, ix, slot;
-      bool inb;
-      c3_neighbor(d, oy, ox, id, &iy, &ix, &slot, &inb);
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      float fv = 0.f;
-      if (inb) {
-        q = g[((long)iy * d.w + ix) * C3_TL + slot];
-        fv = f[(((long)iy * d.w + ix) * C3_TL + slot) * C3_C + c];
-      }
-      const float lx = q.x - ctr.x, ly = q.y - ctr.y, lz = q.z - ctr.z;
-      const float h1 = selu_f(((lx * w1x + ly * w1y) + lz * w1z) + b1k);
-      if (c < C3_H1) S.h1[n][c] = h1;
-      __builtin_amdgcn_wave_barrier();
-      float a = 0.f;
-#pragma unroll
-      for (int k = 0; k < C3_H1; ++k) a += S.h1[n][k] * w2r[k];
-      const float h2 = selu_f(a + b2c);
-      agg += h2 * fv;
-    }
-    S.v32a[c] = agg;
-    __builtin_amdgcn_wave_barrier();
-    float o = 0.f;
-#pragma unroll
-    for (int k = 0; k < C3_C; ++k) o += S.v32a[k] * wcol[k];
-    y[i * C3_C + c] = selu_f(o);
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// parameter-gradient accumulator layout (doubles / floats): dense1_w 48, dense1_b 16, dense2_w 512,
-// dense2_b 32, w 1024
+// parameter-gradient layout (floats): dense1_w 48, dense1_b 16, dense2_w 512, dense2_b 32, w 1024
 #define C3_OFF_W1 0
 #define C3_OFF_B1 48
 #define C3_OFF_W2 64
@@ -169,140 +103,375 @@ __global__ __launch_bounds__(256) void conv3d_aggregate_kernel(const float4* __r
 #define C3_OFF_W 608
 #define C3_NPARAM 1632
 
-__global__ __launch_bounds__(256) void conv3d_bwd_kernel(const float4* __restrict__ geom,
-                                                           const float* __restrict__ wf, C3Params P,
-                                                           const unsigned char* __restrict__ idx,
-                                                           const float* __restrict__ y, const float* __restrict__ gy,
-                                                           float* __restrict__ gwf, double* __restrict__ acc,
-                                                           C3Dims d) {
-  __shared__ C3Scratch scr[8];
-  __shared__ float redbuf[8][C3_C];
-  const int hw_id = threadIdx.x >> 5;
-  const int c = threadIdx.x & 31;
-  const int k16 = c & 15;
-  C3Scratch& S = scr[hw_id];
-  float w2r[C3_H1], wrow[C3_C], wcol[C3_C], w2c[C3_C];
-#pragma unroll
-  for (int k = 0; k < C3_H1; ++k) w2r[k] = P.w2[c * C3_H1 + k];
-#pragma unroll
-  for (int k = 0; k < C3_C; ++k) {
-    wrow[k] = P.w[c * C3_C + k];
-    wcol[k] = P.w[k * C3_C + c];
-    w2c[k] = P.w2[k * C3_H1 + k16];  // column k16 of dense2 (used by lanes < 16)
-  }
-  const float b2c = P.b2[c];
-  const float w1x = P.w1[k16 * 3], w1y = P.w1[k16 * 3 + 1], w1z = P.w1[k16 * 3 + 2], b1k = P.b1[k16];
+struct __attribute__((aligned(16))) C3Lds {
+  float w[C3_C * C3_WS];
+  float w2[C3_C * C3_W2S];
+  float X[4][C3_GP * C3_XS];
+  float H[4][C3_GP * C3_HS];
+  long F[4][C3_GP];
+};
 
-  float dwrow[C3_C], dw2r[C3_H1];
+__device__ __forceinline__ float selu_f(float x) {
+  return x > 0.f ? SELU_SCALE_F * x : (SELU_SCALE_F * SELU_ALPHA_F) * (expf(x) - 1.f);
+}
+
+__device__ __forceinline__ void c3_load_weights(C3Lds& L, const C3Params& P) {
+  for (int i = threadIdx.x; i < C3_C * C3_C; i += blockDim.x) L.w[(i >> 5) * C3_WS + (i & 31)] = P.w[i];
+  for (int i = threadIdx.x; i < C3_C * C3_H1; i += blockDim.x) L.w2[(i >> 4) * C3_W2S + (i & 15)] = P.w2[i];
+}
+
+// Neighbour n of output pixel i (owned by this lane): local coordinates and the element offset of its
+// 32-feature line (or -1 for a zero-padded border candidate / an invalid lane).
+struct C3Nb {
+  float lx, ly, lz;
+  long foff;
+};
+__device__ __forceinline__ C3Nb c3_neighbor(const float4* __restrict__ geom, const unsigned char* __restrict__ idx,
+                                            const C3Dims& d, long i, int n, bool pv, int oy, int ox, long tb,
+                                            const float4& ctr) {
+  C3Nb r;
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  r.foff = -1;
+  if (pv) {
+    const int id = idx[i * C3_NB + n];
+    const int tap = id / C3_TL, slot = id % C3_TL;
+    const int iy = oy * d.stride - 1 + tap / 3, ix = ox * d.stride - 1 + tap % 3;
+    if (iy >= 0 && iy < d.h && ix >= 0 && ix < d.w) {
+      const long e = (tb * d.h * d.w + (long)iy * d.w + ix) * C3_TL + slot;
+      q = geom[e];
+      r.foff = e * C3_C;
+    }
+  }
+  r.lx = q.x - ctr.x;
+  r.ly = q.y - ctr.y;
+  r.lz = q.z - ctr.z;
+  return r;
+}
+
+struct C3Lane {
+  int li, lg;
+  float w1x[4], w1y[4], w1z[4], b1[4];  // dense1 rows k16 = 4*lg + e
+  float b2[2][4];                        // dense2 bias of channels 16*mt + 4*lg + r
+};
+__device__ __forceinline__ void c3_lane_init(C3Lane& Q, const C3Params& P) {
+  const int lane = threadIdx.x & 63;
+  Q.li = lane & 15;
+  Q.lg = lane >> 4;
 #pragma unroll
-  for (int k = 0; k < C3_C; ++k) dwrow[k] = 0.f;
+  for (int e = 0; e < 4; ++e) {
+    const int k = Q.lg * 4 + e;
+    Q.w1x[e] = P.w1[k * 3];
+    Q.w1y[e] = P.w1[k * 3 + 1];
+    Q.w1z[e] = P.w1[k * 3 + 2];
+    Q.b1[e] = P.b1[k];
+  }
 #pragma unroll
-  for (int k = 0; k < C3_H1; ++k) dw2r[k] = 0.f;
-  float db2 = 0.f, db1 = 0.f, dw1x = 0.f, dw1y = 0.f, dw1z = 0.f;
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Q.b2[mt][r] = P.b2[mt * 16 + Q.lg * 4 + r];
+}
+
+// h1 (lane: pixel li, k16 = 4*lg + e) and h2 (lane: pixel li, channels 16*mt + 4*lg + r) of one neighbour
+__device__ __forceinline__ void c3_mlp(const C3Lds& L, const C3Lane& Q, const C3Nb& nb, float h1[4], f32x4 h2[2]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) h1[e] = selu_f(((nb.lx * Q.w1x[e] + nb.ly * Q.w1y[e]) + nb.lz * Q.w1z[e]) + Q.b1[e]);
+  f32x4 pre[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  f32x4 wa[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) wa[mt] = *(const f32x4*)(L.w2 + (mt * 16 + Q.li) * C3_W2S + Q.lg * 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) pre[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][e], h1[e], pre[mt], 0, 0, 0);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h2[mt][r] = selu_f(pre[mt][r] + Q.b2[mt][r]);
+}
+
+__global__ __launch_bounds__(256) void conv3d_fwd_kernel(const float4* __restrict__ geom, const float* __restrict__ wf,
+                                                          C3Params P, const unsigned char* __restrict__ idx,
+                                                          float* __restrict__ y, C3Dims d) {
+  __shared__ C3Lds L;
+  c3_load_weights(L, P);
+  C3Lane Q;
+  c3_lane_init(Q, P);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  const long total = (long)d.tl * d.bs * d.ho * d.wo;
+  const long ngroups = (total + C3_GP - 1) / C3_GP;
+  for (long grp = (long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long)gridDim.x * 4) {
+    const long i = grp * C3_GP + Q.li;
+    const bool pv = i < total;
+    const long ic = pv ? i : total - 1;
+    const int ox = (int)(ic % d.wo), oy = (int)((ic / d.wo) % d.ho);
+    const long tb = ic / ((long)d.wo * d.ho);
+    const float4 ctr = geom[(tb * d.h * d.w + (long)(oy * d.stride) * d.w + ox * d.stride) * C3_TL];
+    f32x4 agg[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 3
+    for (int n = 0; n < C3_NB; ++n) {
+      const C3Nb nb = c3_neighbor(geom, idx, d, ic, n, pv, oy, ox, tb, ctr);
+      f32x4 fv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+      if (nb.foff >= 0) {
+        fv[0] = *(const f32x4*)(wf + nb.foff + Q.lg * 4);
+        fv[1] = *(const f32x4*)(wf + nb.foff + 16 + Q.lg * 4);
+      }
+      float h1[4];
+      f32x4 h2[2];
+      c3_mlp(L, Q, nb, h1, h2);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) agg[mt] += h2[mt] * fv[mt];
+    }
+    // y[px][c'] = selu(sum_c agg[px][c] * w[c][c'])
+    f32x4 out[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* wr = L.w + (ms * 16 + Q.lg * 4 + r) * C3_WS + Q.li;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          out[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[mt * 16], agg[ms][r], out[mt], 0, 0, 0);
+      }
+    if (pv) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = selu_f(out[mt][r]);
+        *(f32x4*)(y + i * C3_C + mt * 16 + Q.lg * 4) = o;
+      }
+    }
+  }
+}
+
+// sum over the 16 lanes that share lg (xor-shuffles stay inside a 16-lane group)
+__device__ __forceinline__ float c3_sum16(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void conv3d_bwd_kernel(const float4* __restrict__ geom,
+                                                              const float* __restrict__ wf, C3Params P,
+                                                              const unsigned char* __restrict__ idx,
+                                                              const float* __restrict__ y, const float* __restrict__ gy,
+                                                              float* __restrict__ gwf, float* __restrict__ part,
+                                                              C3Dims d) {
+  __shared__ C3Lds L;
+  __shared__ float red[4][C3_NPARAM];
+  c3_load_weights(L, P);
+  C3Lane Q;
+  c3_lane_init(Q, P);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* X = L.X[wave];
+  float* H = L.H[wave];
+  long* F = L.F[wave];
+
+  f32x4 accW[2][2], accW2[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    accW2[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) accW[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float db2[2][4], dw1x[4], dw1y[4], dw1z[4], db1[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    db2[0][e] = db2[1][e] = 0.f;
+    dw1x[e] = dw1y[e] = dw1z[e] = db1[e] = 0.f;
+  }
 
   const long total = (long)d.tl * d.bs * d.ho * d.wo;
-  const long nhalf = (long)gridDim.x * 8;
-  for (long i = (long)blockIdx.x * 8 + hw_id; i < total; i += nhalf) {
-    const int ox = (int)(i % d.wo);
-    const int oy = (int)((i / d.wo) % d.ho);
-    const long tb = i / ((long)d.wo * d.ho);
-    const float4* g = geom + tb * d.h * d.w * C3_TL;
-    const float* f = wf + tb * d.h * d.w * C3_TL * C3_C;
-    float* gf = gwf + tb * d.h * d.w * C3_TL * C3_C;
-    const float4 ctr = g[((long)(oy * d.stride) * d.w + ox * d.stride) * C3_TL];
-    // ---- recompute the forward
-    float h2v[C3_NB], fvv[C3_NB], lxv[C3_NB], lyv[C3_NB], lzv[C3_NB];
-    long foff[C3_NB];
-    float agg = 0.f;
-#pragma unroll
+  const long ngroups = (total + C3_GP - 1) / C3_GP;
+  for (long grp = (long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long)gridDim.x * 4) {
+    const long i = grp * C3_GP + Q.li;
+    const bool pv = i < total;
+    const long ic = pv ? i : total - 1;
+    const int ox = (int)(ic % d.wo), oy = (int)((ic / d.wo) % d.ho);
+    const long tb = ic / ((long)d.wo * d.ho);
+    const float4 ctr = geom[(tb * d.h * d.w + (long)(oy * d.stride) * d.w + ox * d.stride) * C3_TL];
+    // ---- recompute the forward aggregate (h1/h2 are recomputed again per neighbour below: cheaper than holding
+    //      72 registers of h2 across the group, which spilled and halved the occupancy)
+    f32x4 agg[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 3
     for (int n = 0; n < C3_NB; ++n) {
-      const int id = idx[i * C3_NB + n];
-      int iy, ix, slot;
-      bool inb;
-      c3_neighbor(d, oy, ox, id, &iy, &ix, &slot, &inb);
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      float fv = 0.f;
-      foff[n] = -1;
-      if (inb) {
-        q = g[((long)iy * d.w + ix) * C3_TL + slot];
-        foff[n] = (((long)iy * d.w + ix) * C3_TL + slot) * C3_C + c;
-        fv = f[foff[n]];
+      const C3Nb nb = c3_neighbor(geom, idx, d, ic, n, pv, oy, ox, tb, ctr);
+      f32x4 fv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+      if (nb.foff >= 0) {
+        fv[0] = *(const f32x4*)(wf + nb.foff + Q.lg * 4);
+        fv[1] = *(const f32x4*)(wf + nb.foff + 16 + Q.lg * 4);
       }
-      lxv[n] = q.x - ctr.x; lyv[n] = q.y - ctr.y; lzv[n] = q.z - ctr.z;
-      const float h1 = selu_f(((lxv[n] * w1x + lyv[n] * w1y) + lzv[n] * w1z) + b1k);
-      if (c < C3_H1) S.h1[n][c] = h1;
-      __builtin_amdgcn_wave_barrier();
-      float a = 0.f;
+      float h1[4];
+      f32x4 h2[2];
+      c3_mlp(L, Q, nb, h1, h2);
 #pragma unroll
-      for (int k = 0; k < C3_H1; ++k) a += S.h1[n][k] * w2r[k];
-      h2v[n] = selu_f(a + b2c);
-      fvv[n] = fv;
-      agg += h2v[n] * fv;
+      for (int mt = 0; mt < 2; ++mt) agg[mt] += h2[mt] * fv[mt];
     }
-    // ---- output mix backward
-    const float yv = y[i * C3_C + c];
-    const float gpre = gy[i * C3_C + c] * act_grad_from_out(yv, DIS_ACT_SELU);
-    S.v32a[c] = gpre;
-    __builtin_amdgcn_wave_barrier();
-    float dagg = 0.f;
+    // ---- output mix backward: gpre = gy * selu'(y);  dagg[c] = sum_c' gpre[c'] w[c][c']
+    f32x4 gpre[2];
 #pragma unroll
-    for (int k = 0; k < C3_C; ++k) {
-      const float gk = S.v32a[k];
-      dagg += gk * wrow[k];     // d agg[c] = sum_c' gpre[c'] w[c][c']
-      dwrow[k] += agg * gk;     // d w[c][c'] += agg[c] gpre[c']
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f}, yv = (f32x4){1.f, 1.f, 1.f, 1.f};
+      if (pv) {
+        g = *(const f32x4*)(gy + i * C3_C + mt * 16 + Q.lg * 4);
+        yv = *(const f32x4*)(y + i * C3_C + mt * 16 + Q.lg * 4);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gpre[mt][r] = g[r] * act_grad_from_out(yv[r], DIS_ACT_SELU);
     }
+    f32x4 dagg[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      f32x4 wa[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) wa[mt] = *(const f32x4*)(L.w + (mt * 16 + Q.li) * C3_WS + ms * 16 + Q.lg * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          dagg[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][r], gpre[ms][r], dagg[mt], 0, 0, 0);
+    }
+    // ---- dW[c][c'] += sum_px agg[px][c] gpre[px][c']: both operands transposed to "pixel on the k slot"
+    f32x4 aggD[2], gpreD[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) *(f32x4*)(X + Q.li * C3_XS + mt * 16 + Q.lg * 4) = agg[mt];
     __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) aggD[nt][r] = X[(Q.lg * 4 + r) * C3_XS + nt * 16 + Q.li];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) *(f32x4*)(X + Q.li * C3_XS + mt * 16 + Q.lg * 4) = gpre[mt];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gpreD[nt][r] = X[(Q.lg * 4 + r) * C3_XS + nt * 16 + Q.li];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          accW[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aggD[mt][r], gpreD[nt][r], accW[mt][nt], 0, 0, 0);
+
     // ---- neighbours
-#pragma unroll
+#pragma unroll 1
     for (int n = 0; n < C3_NB; ++n) {
-      if (foff[n] >= 0) atomicAdd(gf + foff[n], dagg * h2v[n]);
-      const float dpre2 = (dagg * fvv[n]) * act_grad_from_out(h2v[n], DIS_ACT_SELU);
-      db2 += dpre2;
+      const C3Nb nb = c3_neighbor(geom, idx, d, ic, n, pv, oy, ox, tb, ctr);
+      f32x4 fv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+      if (nb.foff >= 0) {
+        fv[0] = *(const f32x4*)(wf + nb.foff + Q.lg * 4);
+        fv[1] = *(const f32x4*)(wf + nb.foff + 16 + Q.lg * 4);
+      }
+      float h1[4];
+      f32x4 h2[2];
+      c3_mlp(L, Q, nb, h1, h2);
+      f32x4 dpre2[2], dfeat[2];
 #pragma unroll
-      for (int k = 0; k < C3_H1; ++k) dw2r[k] += dpre2 * S.h1[n][k];
-      S.v32b[c] = dpre2;
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float h2v = h2[mt][r];
+          dfeat[mt][r] = dagg[mt][r] * h2v;
+          dpre2[mt][r] = (dagg[mt][r] * fv[mt][r]) * act_grad_from_out(h2v, DIS_ACT_SELU);
+          db2[mt][r] += dpre2[mt][r];
+        }
+      // d h1[k16] = sum_c w2[c][k16] dpre2[c]
+      f32x4 dh1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dh1 = __builtin_amdgcn_mfma_f32_16x16x4f32(L.w2[(ms * 16 + Q.lg * 4 + r) * C3_W2S + Q.li], dpre2[ms][r], dh1, 0,
+                                                     0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dpre1 = dh1[e] * act_grad_from_out(h1[e], DIS_ACT_SELU);
+        db1[e] += dpre1;
+        dw1x[e] += dpre1 * nb.lx;
+        dw1y[e] += dpre1 * nb.ly;
+        dw1z[e] += dpre1 * nb.lz;
+      }
+      // d w2[c][k16] += sum_px dpre2[px][c] h1[px][k16]
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) *(f32x4*)(X + Q.li * C3_XS + mt * 16 + Q.lg * 4) = dpre2[mt];
+      *(f32x4*)(H + Q.li * C3_HS + Q.lg * 4) = (f32x4){h1[0], h1[1], h1[2], h1[3]};
       __builtin_amdgcn_wave_barrier();
-      // d h1[k] = sum_c w2[c][k] dpre2[c]   (lanes k < 16; the upper 16 lanes mirror them)
-      float dh1 = 0.f;
+      f32x4 dpre2D[2];
+      float h1D[4];
 #pragma unroll
-      for (int k = 0; k < C3_C; ++k) dh1 += S.v32b[k] * w2c[k];
-      const float h1 = S.h1[n][k16];
-      const float dpre1 = dh1 * act_grad_from_out(h1, DIS_ACT_SELU);
-      if (c < C3_H1) {
-        db1 += dpre1;
-        dw1x += dpre1 * lxv[n];
-        dw1y += dpre1 * lyv[n];
-        dw1z += dpre1 * lzv[n];
+      for (int r = 0; r < 4; ++r) {
+        h1D[r] = H[(Q.lg * 4 + r) * C3_HS + Q.li];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) dpre2D[nt][r] = X[(Q.lg * 4 + r) * C3_XS + nt * 16 + Q.li];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          accW2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpre2D[mt][r], h1D[r], accW2[mt], 0, 0, 0);
+      // feature gradient: 128-B rows (2 pixels per wave instruction) of float atomics
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) *(f32x4*)(X + Q.li * C3_XS + mt * 16 + Q.lg * 4) = dfeat[mt];
+      if (Q.lg == 0) F[Q.li] = nb.foff;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < C3_GP / 2; ++j) {
+        const int px = 2 * j + (lane >> 5), c = lane & 31;
+        const long fo = F[px];
+        if (fo >= 0) atomicAdd(gwf + fo + c, X[px * C3_XS + c]);
       }
       __builtin_amdgcn_wave_barrier();
     }
   }
-  // ---- reduce the per-lane parameter gradients over the 8 half-waves, then fp64 atomics
-  auto reduce_store = [&](float v, int off, bool active) {
-    __syncthreads();
-    redbuf[hw_id][c] = active ? v : 0.f;
-    __syncthreads();
-    if (hw_id == 0 && active) {
-      double t = 0.0;
+
+  // ---- parameter gradients: per-wave results -> LDS -> one slab per block
+  float* rw = red[wave];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += (double)redbuf[k][c];
-      atomic_add_d(acc + off, t);
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = mt * 16 + Q.lg * 4 + r;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) rw[C3_OFF_W + c * C3_C + nt * 16 + Q.li] = accW[mt][nt][r];
+      rw[C3_OFF_W2 + c * C3_H1 + Q.li] = accW2[mt][r];
+      const float s = c3_sum16(db2[mt][r]);
+      if (Q.li == 0) rw[C3_OFF_B2 + c] = s;
     }
-  };
 #pragma unroll
-  for (int k = 0; k < C3_C; ++k) reduce_store(dwrow[k], C3_OFF_W + c * C3_C + k, true);
-#pragma unroll
-  for (int k = 0; k < C3_H1; ++k) reduce_store(dw2r[k], C3_OFF_W2 + c * C3_H1 + k, true);
-  reduce_store(db2, C3_OFF_B2 + c, true);
-  reduce_store(db1, C3_OFF_B1 + k16, c < C3_H1);
-  reduce_store(dw1x, C3_OFF_W1 + k16 * 3 + 0, c < C3_H1);
-  reduce_store(dw1y, C3_OFF_W1 + k16 * 3 + 1, c < C3_H1);
-  reduce_store(dw1z, C3_OFF_W1 + k16 * 3 + 2, c < C3_H1);
+  for (int e = 0; e < 4; ++e) {
+    const int k = Q.lg * 4 + e;
+    const float sb = c3_sum16(db1[e]), sx = c3_sum16(dw1x[e]), sy = c3_sum16(dw1y[e]), sz = c3_sum16(dw1z[e]);
+    if (Q.li == 0) {
+      rw[C3_OFF_B1 + k] = sb;
+      rw[C3_OFF_W1 + k * 3] = sx;
+      rw[C3_OFF_W1 + k * 3 + 1] = sy;
+      rw[C3_OFF_W1 + k * 3 + 2] = sz;
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < C3_NPARAM; t += blockDim.x)
+    part[(long)blockIdx.x * C3_NPARAM + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
-__global__ void c3_cast_kernel(const double* __restrict__ a, float* __restrict__ o, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = (float)a[i];
+// gparams[t] = sum over blocks (fixed order)
+__global__ void c3_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ o, int nblocks) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= C3_NPARAM) return;
+  float s = 0.f;
+  for (int k = 0; k < nblocks; ++k) s += part[(long)k * C3_NPARAM + t];
+  o[t] = s;
 }
+
+#define C3_BWD_BLOCKS 512
 
 static int c3_dims(C3Dims* d, int tl, int bs, int h, int w, int stride) {
   if (tl != C3_TL) return DIS_ERR_UNSUPPORTED;
@@ -338,20 +507,22 @@ extern "C" int dis_conv3d_knn_fwd(const float* geom, const float* wf, const floa
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)tl * bs * d.ho * d.wo;
   C3Params P{dense1_w, dense1_b, dense2_w, dense2_b, w};
-  int grid = dis_cdiv(total, 8);
-  if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(conv3d_aggregate_kernel, dim3(grid), dim3(256), 0, s, (const float4*)geom, wf, P, idx, y, d);
+  int grid = dis_cdiv(dis_cdiv(total, C3_GP), 4);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(conv3d_fwd_kernel, dim3(grid), dim3(256), 0, s, (const float4*)geom, wf, P, idx, y, d);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
 
+extern "C" long dis_conv3d_knn_bwd_workspace(void) { return (long)C3_BWD_BLOCKS * C3_NPARAM; }
+
 extern "C" int dis_conv3d_knn_bwd(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
                                   const float* dense2_w, const float* dense2_b, const float* w,
                                   const unsigned char* idx, const float* y, const float* gy, float* grad_wf,
-                                  float* gparams, double* acc, int tl, int bs, int h, int wd, int stride,
+                                  float* gparams, float* workspace, int tl, int bs, int h, int wd, int stride,
                                   void* stream) {
   if (!geom || !wf || !dense1_w || !dense1_b || !dense2_w || !dense2_b || !w || !idx || !y || !gy || !grad_wf ||
-      !gparams || !acc)
+      !gparams || !workspace)
     return DIS_ERR_NULL;
   C3Dims d;
   int rc = c3_dims(&d, tl, bs, h, wd, stride);
@@ -359,11 +530,12 @@ extern "C" int dis_conv3d_knn_bwd(const float* geom, const float* wf, const floa
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)tl * bs * d.ho * d.wo;
   C3Params P{dense1_w, dense1_b, dense2_w, dense2_b, w};
-  int grid = dis_cdiv(total, 8);
-  if (grid > 1024) grid = 1024;
+  int grid = dis_cdiv(dis_cdiv(total, C3_GP), 4);
+  if (grid > C3_BWD_BLOCKS) grid = C3_BWD_BLOCKS;
   hipLaunchKernelGGL(conv3d_bwd_kernel, dim3(grid), dim3(256), 0, s, (const float4*)geom, wf, P, idx, y, gy, grad_wf,
-                     acc, d);
-  hipLaunchKernelGGL(c3_cast_kernel, dim3(7), dim3(256), 0, s, (const double*)acc, gparams, C3_NPARAM);
+                     workspace, d);
+  hipLaunchKernelGGL(c3_param_reduce_kernel, dim3(dis_cdiv(C3_NPARAM, 256)), dim3(256), 0, s, (const float*)workspace,
+                     gparams, grid);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

@@ -58,6 +58,7 @@ SIGS = {
     'dis_mask_weight_slots': 'pppliip',
     'dis_conv3d_knn_select': 'ppiiiiip',
     'dis_conv3d_knn_fwd': 'ppppppppp' + 'iiiiip',
+    'dis_conv3d_knn_bwd_workspace': '',
     'dis_conv3d_knn_bwd': 'ppppppp' + 'pppppp' + 'iiiiip',
     'dis_convg_pack_workspace': 'iii',
     'dis_convg_run': 'ipiipppiip' + 'iiiiiiiiiiiii' + 'p',
@@ -70,7 +71,7 @@ SIGS = {
     'dis_adam_step': 'pppplffffifp',
 }
 _RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
-             'dis_colsum_workspace', 'dis_gn_bwd_workspace'}
+             'dis_colsum_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace'}
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
 _lib = None

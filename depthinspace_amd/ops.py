@@ -722,7 +722,7 @@ class _Conv3dKnn(torch.autograd.Function):
         tl, bs, h, wd, s, c = wf.shape
         gwf = torch.zeros_like(wf)
         gp = torch.empty(1632, dtype=torch.float32, device=wf.device)
-        acc = _zeros_d(1632, wf.device)
+        acc = torch.empty(lib.fn('dis_conv3d_knn_bwd_workspace')(), dtype=torch.float32, device=wf.device)
         lib.call('dis_conv3d_knn_bwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, _c(gy), gwf, gp, acc, tl, bs, h, wd,
                  ctx.stride)
         return (None, gwf, gp[0:48].view(16, 3), gp[48:64], gp[64:576].view(32, 16), gp[576:608],
