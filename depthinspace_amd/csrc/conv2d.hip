@@ -89,23 +89,26 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const int xcd = blockIdx.x % nxcd, rank = blockIdx.x / nxcd, per = gridDim.x / nxcd;
   const int t_lo = (int)((long)ntiles * xcd / nxcd), t_hi = (int)((long)ntiles * (xcd + 1) / nxcd);
 
+  // Loads are unconditional (out-of-image taps read a clamped, valid address) and are zeroed only when they are
+  // written to LDS: a load under a branch made hipcc wait for it (s_waitcnt vmcnt(0)) right at the issue point,
+  // which exposed the whole memory latency before the MFMAs of every tile.
   float4 pre[C::NLOAD];
+  unsigned okmask = 0;
   auto prefetch = [&](int tile, int chunk) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * C::TROWS * S - a.pad_y, ix0 = tx * C::TCOLS * S - a.pad_x;
     const float* xb = a.x + (long)n * a.hin * a.win * CIN + chunk * C::CINB;
+    okmask = 0;
 #pragma unroll
     for (int it = 0; it < C::NLOAD; ++it) {
-      const int idx = threadIdx.x + it * 256;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < C::NITEMS) {
-        const int vv = idx % C::NV, pix = idx / C::NV;
-        const int c = pix % C::IN_COLS, r = pix / C::IN_COLS;
-        const int iy = iy0 + r, ix = ix0 + c;
-        if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
-          v = *(const float4*)(xb + ((long)iy * a.win + ix) * CIN + vv * 4);
-      }
-      pre[it] = v;
+      const int idx = min(threadIdx.x + it * 256, C::NITEMS - 1);
+      const int vv = idx % C::NV, pix = idx / C::NV;
+      const int c = pix % C::IN_COLS, r = pix / C::IN_COLS;
+      const int iy = iy0 + r, ix = ix0 + c;
+      const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+      const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
+      pre[it] = *(const float4*)(xb + ((long)cy * a.win + cx) * CIN + vv * 4);
+      okmask |= (ok ? 1u : 0u) << it;
     }
   };
   auto stage = [&]() {
@@ -114,7 +117,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       const int idx = threadIdx.x + it * 256;
       if (idx < C::NITEMS) {
         const int vv = idx % C::NV, pix = idx / C::NV;
-        *(float4*)(xl + pix * C::CS + vv * 4) = pre[it];
+        const bool ok = (okmask >> it) & 1u;
+        *(float4*)(xl + pix * C::CS + vv * 4) = ok ? pre[it] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
@@ -122,6 +126,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   int tile = t_lo + rank;
   if (tile < t_hi) prefetch(tile, 0);
   f32x4 acc[C::MT][C::NT];
+  double s1 = 0.0, s2 = 0.0;
+  int stat_n = -1;
 
   while (tile < t_hi) {
 #pragma unroll
@@ -137,52 +143,69 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       if (chunk + 1 < C::NCHUNK) prefetch(tile, chunk + 1);
       else if (tile + per < t_hi) prefetch(tile + per, 0);
 
+      // software-pipelined fragment reads: the LDS reads of step s+1 are issued before the MFMAs of step s
+      constexpr int NS = KH * KW * C::NQ;
+      float av[2][C::MT][4], bv[2][C::NT][4];
+      auto load_frag = [&](int s, float (&fa)[C::MT][4], float (&fb)[C::NT][4]) {
+        const int q = s % C::NQ, tap = s / C::NQ, ky = tap / KW, kx = tap % KW;
 #pragma unroll
-      for (int ky = 0; ky < KH; ++ky) {
+        for (int mt = 0; mt < C::MT; ++mt) {
+          const int row = wave * C::MT + mt;
+          const float* p = xl + (((row * S + ky) * C::IN_COLS) + (li * S + kx)) * C::CS + lg * C::KG + q * C::E;
+          if (C::E == 4) {
+            const f32x4 t = *(const f32x4*)p;
+            fa[mt][0] = t[0]; fa[mt][1] = t[1]; fa[mt][2] = t[2]; fa[mt][3] = t[3];
+          } else {
 #pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-          const int tap = ky * KW + kx;
-#pragma unroll
-          for (int q = 0; q < C::NQ; ++q) {
-            float av[C::MT][4], bv[C::NT][4];
-#pragma unroll
-            for (int mt = 0; mt < C::MT; ++mt) {
-              const int row = wave * C::MT + mt;
-              const float* p = xl + (((row * S + ky) * C::IN_COLS) + (li * S + kx)) * C::CS + lg * C::KG + q * C::E;
-              if (C::E == 4) {
-                const f32x4 t = *(const f32x4*)p;
-                av[mt][0] = t[0]; av[mt][1] = t[1]; av[mt][2] = t[2]; av[mt][3] = t[3];
-              } else {
-#pragma unroll
-                for (int e = 0; e < C::E; ++e) av[mt][e] = p[e];
-              }
-            }
-#pragma unroll
-            for (int nt = 0; nt < C::NT; ++nt) {
-              const float* p = wl + ((((long)(tap * C::NCHUNK + chunk) * 4 + lg) * C::NQ + q) * COUT + nt * 16 + li) * C::E;
-              if (C::E == 4) {
-                const f32x4 t = *(const f32x4*)p;
-                bv[nt][0] = t[0]; bv[nt][1] = t[1]; bv[nt][2] = t[2]; bv[nt][3] = t[3];
-              } else {
-#pragma unroll
-                for (int e = 0; e < C::E; ++e) bv[nt][e] = p[e];
-              }
-            }
-#pragma unroll
-            for (int e = 0; e < C::E; ++e)
-#pragma unroll
-              for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < C::NT; ++nt)
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], bv[nt][e], acc[mt][nt], 0, 0, 0);
+            for (int e = 0; e < C::E; ++e) fa[mt][e] = p[e];
           }
         }
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) {
+          const float* p = wl + ((((long)(tap * C::NCHUNK + chunk) * 4 + lg) * C::NQ + q) * COUT + nt * 16 + li) * C::E;
+          if (C::E == 4) {
+            const f32x4 t = *(const f32x4*)p;
+            fb[nt][0] = t[0]; fb[nt][1] = t[1]; fb[nt][2] = t[2]; fb[nt][3] = t[3];
+          } else {
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) fb[nt][e] = p[e];
+          }
+        }
+      };
+      load_frag(0, av[0], bv[0]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) load_frag(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < C::E; ++e)
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][mt][e], bv[s & 1][nt][e], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 
-    // epilogue: bias + activation + store (+ GroupNorm statistics)
+    // epilogue: bias + activation + store (+ GroupNorm statistics).  The statistics are summed in fp32 per lane and
+    // tile (16 values), then carried in fp64 registers across the consecutive tiles of one sample; the block
+    // reduction + 2 fp64 atomics happen only when the sample changes (or at the end), not per tile.
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-    double s1 = 0.0, s2 = 0.0;
+    if (a.stats && n != stat_n) {
+      if (stat_n >= 0) {
+        const double r1 = block_sum_d(s1, red);
+        const double r2 = block_sum_d(s2, red);
+        if (threadIdx.x == 0) {
+          atomic_add_d(a.stats + 2 * stat_n, r1);
+          atomic_add_d(a.stats + 2 * stat_n + 1, r2);
+        }
+      }
+      stat_n = n;
+      s1 = 0.0;
+      s2 = 0.0;
+    }
+    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt) {
       const int vy = ty * C::TROWS + wave * C::MT + mt;
@@ -196,21 +219,23 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
           if (vy < a.hv && vx < a.wv) {
             float v = act_apply(acc[mt][nt][r] + bval, a.act);
             a.y[(((long)n * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * COUT + co] = v;
-            s1 += (double)v;
-            s2 += (double)v * (double)v;
+            t1 += v;
+            t2 += v * v;
           }
         }
       }
     }
-    if (a.stats) {
-      const double r1 = block_sum_d(s1, red);
-      const double r2 = block_sum_d(s2, red);
-      if (threadIdx.x == 0) {
-        atomic_add_d(a.stats + 2 * n, r1);
-        atomic_add_d(a.stats + 2 * n + 1, r2);
-      }
-    }
+    s1 += (double)t1;
+    s2 += (double)t2;
     tile += per;
+  }
+  if (a.stats && stat_n >= 0) {
+    const double r1 = block_sum_d(s1, red);
+    const double r2 = block_sum_d(s2, red);
+    if (threadIdx.x == 0) {
+      atomic_add_d(a.stats + 2 * stat_n, r1);
+      atomic_add_d(a.stats + 2 * stat_n + 1, r2);
+    }
   }
 }
 
@@ -384,8 +409,10 @@ struct WgCfg {
   static constexpr int STEPS = RPW * 4;            // MFMA k-steps per wave per tile (16 px per row / 4)
   static constexpr int IN_ROWS = (TROWS - 1) * S + KHB;
   static constexpr int IN_COLS = 15 * S + KW;
-  static constexpr int CS = (CINB >= 16) ? CINB + 4 : CINB;
-  static constexpr int GS = COUT + 4;
+  // pixel strides == 16 (mod 32) floats: the ds_read_b32 fragment reads of lanes l and l+16 (neighbouring pixels)
+  // then hit disjoint banks
+  static constexpr int CS = (CINB >= 16) ? CINB + 16 : CINB;
+  static constexpr int GS = (COUT % 32 == 0) ? COUT + 16 : COUT;
   static constexpr int IN_FLOATS = IN_ROWS * IN_COLS * CS;
   static constexpr int G_FLOATS = TROWS * 16 * GS;
   static constexpr int LDS_BYTES = (IN_FLOATS + G_FLOATS) * 4;
@@ -436,29 +463,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
   for (int nb = 0; nb < C::NB; ++nb) bsum[nb] = 0.f;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // issue-early / write-late staging: the x halo tile and the gy tile of the NEXT tile are fetched into registers
+  // while the MFMAs of the current one run
+  constexpr int NIX = C::IN_ROWS * C::IN_COLS * C::NV, NLX = (NIX + 255) / 256;
+  constexpr int NIG = C::TROWS * 16 * (COUT / 4), NLG = (NIG + 255) / 256;
+  float4 prex[NLX], preg[NLG];
+  // (loads stay under their bounds branches here: the unconditional/clamped form that helps conv_fwd_kernel made
+  //  hipcc park the prefetched values in AGPRs right behind each load in this register-bound kernel: 114 -> 77 TFLOP/s)
+  auto prefetch = [&](int tile) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * C::TROWS * S - a.pad + ky0, ix0 = tx * 16 * S - a.pad;
-    __syncthreads();
     const float* xb = a.x + (long)n * a.hin * a.win * CIN + chunk * C::CINB;
-    for (int idx = threadIdx.x; idx < C::IN_ROWS * C::IN_COLS * C::NV; idx += 256) {
-      const int vv = idx % C::NV, pix = idx / C::NV;
-      const int c = pix % C::IN_COLS, r = pix / C::IN_COLS;
-      const int iy = iy0 + r, ix = ix0 + c;
+#pragma unroll
+    for (int it = 0; it < NLX; ++it) {
+      const int idx = threadIdx.x + it * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = *(const float4*)(xb + ((long)iy * a.win + ix) * CIN + vv * 4);
-      *(float4*)(xl + pix * C::CS + vv * 4) = v;
+      if (idx < NIX) {
+        const int vv = idx % C::NV, pix = idx / C::NV;
+        const int c = pix % C::IN_COLS, r = pix / C::IN_COLS;
+        const int iy = iy0 + r, ix = ix0 + c;
+        if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = *(const float4*)(xb + ((long)iy * a.win + ix) * CIN + vv * 4);
+      }
+      prex[it] = v;
     }
     const float* gb = a.gy + (long)n * a.hout * a.wout * COUT;
-    for (int idx = threadIdx.x; idx < C::TROWS * 16 * (COUT / 4); idx += 256) {
-      const int vv = idx % (COUT / 4), pix = idx / (COUT / 4);
-      const int c = pix % 16, r = pix / 16;
-      const int oy = ty * C::TROWS + r, ox = tx * 16 + c;
+#pragma unroll
+    for (int it = 0; it < NLG; ++it) {
+      const int idx = threadIdx.x + it * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (oy < a.hout && ox < a.wout) v = *(const float4*)(gb + ((long)oy * a.wout + ox) * COUT + vv * 4);
-      *(float4*)(gl + pix * C::GS + vv * 4) = v;
+      if (idx < NIG) {
+        const int vv = idx % (COUT / 4), pix = idx / (COUT / 4);
+        const int c = pix % 16, r = pix / 16;
+        const int oy = ty * C::TROWS + r, ox = tx * 16 + c;
+        if (oy < a.hout && ox < a.wout) v = *(const float4*)(gb + ((long)oy * a.wout + ox) * COUT + vv * 4);
+      }
+      preg[it] = v;
     }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < NLX; ++it) {
+      const int idx = threadIdx.x + it * 256;
+      if (idx < NIX) *(float4*)(xl + (idx / C::NV) * C::CS + (idx % C::NV) * 4) = prex[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NLG; ++it) {
+      const int idx = threadIdx.x + it * 256;
+      if (idx < NIG) *(float4*)(gl + (idx / (COUT / 4)) * C::GS + (idx % (COUT / 4)) * 4) = preg[it];
+    }
+  };
+
+  if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
+    stage();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
 #pragma unroll
     for (int st = 0; st < C::STEPS; ++st) {
       const int pk = wave * (C::RPW * 16) + st * 4 + lg;  // pixel inside the tile owned by this k-slot
