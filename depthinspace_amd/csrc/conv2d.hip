@@ -18,6 +18,8 @@
 // The same kernel computes stride-1 input gradients (flipped/transposed weights) and, with a 2x2 tap
 // set and interleaved output addressing, the four phases of the stride-2 transposed convolution.
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -89,36 +91,50 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   const int xcd = blockIdx.x % nxcd, rank = blockIdx.x / nxcd, per = gridDim.x / nxcd;
   const int t_lo = (int)((long)ntiles * xcd / nxcd), t_hi = (int)((long)ntiles * (xcd + 1) / nxcd);
 
-  // Loads are unconditional (out-of-image taps read a clamped, valid address) and are zeroed only when they are
-  // written to LDS: a load under a branch made hipcc wait for it (s_waitcnt vmcnt(0)) right at the issue point,
-  // which exposed the whole memory latency before the MFMAs of every tile.
+  // Halo prefetch.  Loads are unconditional (out-of-image taps read a clamped, valid address) and are zeroed only
+  // when they are written to LDS: a load under a branch made hipcc wait for it (s_waitcnt vmcnt(0)) right at the
+  // issue point.  Everything that does not depend on the tile (item -> row/col/channel-group, element offset
+  // inside the halo window) is computed once per thread; interior tiles skip the per-item clamps.
   float4 pre[C::NLOAD];
   unsigned okmask = 0;
+  int it_r[C::NLOAD], it_c[C::NLOAD], it_off[C::NLOAD], it_lds[C::NLOAD];
+#pragma unroll
+  for (int it = 0; it < C::NLOAD; ++it) {
+    const int idx = min((int)threadIdx.x + it * 256, C::NITEMS - 1);
+    const int vv = idx % C::NV, pix = idx / C::NV;
+    it_c[it] = pix % C::IN_COLS;
+    it_r[it] = pix / C::IN_COLS;
+    it_off[it] = (it_r[it] * a.win + it_c[it]) * CIN + vv * 4;
+    it_lds[it] = pix * C::CS + vv * 4;
+  }
   auto prefetch = [&](int tile, int chunk) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * C::TROWS * S - a.pad_y, ix0 = tx * C::TCOLS * S - a.pad_x;
     const float* xb = a.x + (long)n * a.hin * a.win * CIN + chunk * C::CINB;
-    okmask = 0;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + C::IN_ROWS <= a.hin && ix0 + C::IN_COLS <= a.win;
+    if (interior) {
+      const float* xo = xb + ((long)iy0 * a.win + ix0) * CIN;
+      okmask = 0xffffffffu;
 #pragma unroll
-    for (int it = 0; it < C::NLOAD; ++it) {
-      const int idx = min(threadIdx.x + it * 256, C::NITEMS - 1);
-      const int vv = idx % C::NV, pix = idx / C::NV;
-      const int c = pix % C::IN_COLS, r = pix / C::IN_COLS;
-      const int iy = iy0 + r, ix = ix0 + c;
-      const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-      const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
-      pre[it] = *(const float4*)(xb + ((long)cy * a.win + cx) * CIN + vv * 4);
-      okmask |= (ok ? 1u : 0u) << it;
+      for (int it = 0; it < C::NLOAD; ++it) pre[it] = *(const float4*)(xo + it_off[it]);
+    } else {
+      okmask = 0;
+#pragma unroll
+      for (int it = 0; it < C::NLOAD; ++it) {
+        const int iy = iy0 + it_r[it], ix = ix0 + it_c[it];
+        const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+        const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
+        pre[it] = *(const float4*)(xb + ((long)cy * a.win + cx) * CIN + it_lds[it] % C::CS);
+        okmask |= (ok ? 1u : 0u) << it;
+      }
     }
   };
   auto stage = [&]() {
 #pragma unroll
     for (int it = 0; it < C::NLOAD; ++it) {
-      const int idx = threadIdx.x + it * 256;
-      if (idx < C::NITEMS) {
-        const int vv = idx % C::NV, pix = idx / C::NV;
+      if ((int)threadIdx.x + it * 256 < C::NITEMS) {
         const bool ok = (okmask >> it) & 1u;
-        *(float4*)(xl + pix * C::CS + vv * 4) = ok ? pre[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)(xl + it_lds[it]) = ok ? pre[it] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
@@ -128,6 +144,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   f32x4 acc[C::MT][C::NT];
   double s1 = 0.0, s2 = 0.0;
   int stat_n = -1;
+  float bias_v[C::NT];
+#pragma unroll
+  for (int nt = 0; nt < C::NT; ++nt) bias_v[nt] = a.bias ? a.bias[nt * 16 + li] : 0.f;
+  const long ypix = (long)a.osx * COUT;  // floats between horizontally adjacent outputs of this launch
 
   while (tile < t_hi) {
 #pragma unroll
@@ -191,6 +211,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     // epilogue: bias + activation + store (+ GroupNorm statistics).  The statistics are summed in fp32 per lane and
     // tile (16 values), then carried in fp64 registers across the consecutive tiles of one sample; the block
     // reduction + 2 fp64 atomics happen only when the sample changes (or at the end), not per tile.
+    // The activation is dispatched once per tile (not per element) and interior tiles store without bounds checks.
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     if (a.stats && n != stat_n) {
       if (stat_n >= 0) {
@@ -206,25 +227,43 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       s2 = 0.0;
     }
     float t1 = 0.f, t2 = 0.f;
+    const int vy0 = ty * C::TROWS + wave * C::MT, vx0 = tx * C::TCOLS + lg * 4;
+    float* ybase = a.y + (((long)n * a.hf + ((long)vy0 * a.osy + a.ooy)) * a.wf + ((long)vx0 * a.osx + a.oox)) * COUT + li;
+    const long yrow = (long)a.osy * a.wf * COUT;
+    const bool full = (ty + 1) * C::TROWS <= a.hv && (tx + 1) * C::TCOLS <= a.wv;
+    auto emit = [&](auto actc) {
+      constexpr int ACT = decltype(actc)::value;
+      if (full) {
 #pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt) {
-      const int vy = ty * C::TROWS + wave * C::MT + mt;
+        for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < C::NT; ++nt) {
-        const int co = nt * 16 + li;
-        const float bval = a.bias ? a.bias[co] : 0.f;
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int vx = tx * C::TCOLS + lg * 4 + r;
-          if (vy < a.hv && vx < a.wv) {
-            float v = act_apply(acc[mt][nt][r] + bval, a.act);
-            a.y[(((long)n * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * COUT + co] = v;
-            t1 += v;
-            t2 += v * v;
-          }
-        }
+            for (int nt = 0; nt < C::NT; ++nt) {
+              const float v = act_apply(acc[mt][nt][r] + bias_v[nt], ACT);
+              ybase[mt * yrow + r * ypix + nt * 16] = v;
+              t1 += v;
+              t2 += v * v;
+            }
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (vy0 + mt < a.hv && vx0 + r < a.wv) {
+#pragma unroll
+              for (int nt = 0; nt < C::NT; ++nt) {
+                const float v = act_apply(acc[mt][nt][r] + bias_v[nt], ACT);
+                ybase[mt * yrow + r * ypix + nt * 16] = v;
+                t1 += v;
+                t2 += v * v;
+              }
+            }
       }
-    }
+    };
+    if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{});
+    else if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{});
+    else emit(std::integral_constant<int, DIS_ACT_NONE>{});
     s1 += (double)t1;
     s2 += (double)t2;
     tile += per;
