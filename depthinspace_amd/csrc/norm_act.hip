@@ -218,7 +218,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
                                     const float* __restrict__ x, const double* __restrict__ stats,
                                     const float* __restrict__ gamma, const double* __restrict__ red,
                                     float* __restrict__ gx, float* __restrict__ gres, long hw, int c, int act,
-                                    float eps, int nred) {
+                                    float eps, int nred, int in_act) {
   __shared__ float gam[GN_MAXC];
   const int n = blockIdx.y;
   float mean, rstd;
@@ -263,6 +263,10 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
     o.y = rstd * (gv.y * gam[g + 1] - a1 - ((xv.y - mean) * rstd) * a2);
     o.z = rstd * (gv.z * gam[g + 2] - a1 - ((xv.z - mean) * rstd) * a2);
     o.w = rstd * (gv.w * gam[g + 3] - a1 - ((xv.w - mean) * rstd) * a2);
+    if (in_act != DIS_ACT_NONE) {  // x is the activation OUTPUT of the producing conv: emit its pre-activation gradient
+      o.x *= act_grad_from_out(xv.x, in_act); o.y *= act_grad_from_out(xv.y, in_act);
+      o.z *= act_grad_from_out(xv.z, in_act); o.w *= act_grad_from_out(xv.w, in_act);
+    }
     op[i] = o;
   }
 }
@@ -284,7 +288,7 @@ extern "C" long dis_gn_bwd_workspace(int n, int c) { return (n > 0 && c > 0) ? (
 extern "C" int dis_gn_apply_bwd(const float* gy, const float* y, const float* x, const double* stats,
                                 const float* gamma, float* gx, float* gres, float* grad_gamma, float* grad_beta,
                                 double* red, double* gparam_acc, int n, long hw, int c, int act, float eps,
-                                void* stream) {
+                                int in_act, void* stream) {
   if (!gy || !x || !stats || !gamma || !gx || !grad_gamma || !grad_beta || !red || !gparam_acc) return DIS_ERR_NULL;
   if (act != DIS_ACT_NONE && !y) return DIS_ERR_NULL;
   if (n <= 0 || hw <= 0 || c <= 0) return DIS_ERR_BAD_SHAPE;
@@ -296,7 +300,7 @@ extern "C" int dis_gn_apply_bwd(const float* gy, const float* y, const float* x,
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nred, n), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma, red,
                      gparam_acc, hw, c, act, eps);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gxg * 2, n), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma,
-                     (const double*)red, gx, gres, hw, c, act, eps, nred);
+                     (const double*)red, gx, gres, hw, c, act, eps, nred, in_act);
   hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(2 * c), dim3(64), 0, s, (const double*)gparam_acc, grad_gamma,
                      grad_beta, c, n * nred);
   DIS_CHECK_LAUNCH();

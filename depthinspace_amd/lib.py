@@ -53,7 +53,7 @@ SIGS = {
     'dis_gn_stats': 'ppilp',
     'dis_gn_apply': 'ppppppiliifp',
     'dis_gn_bwd_workspace': 'ii',
-    'dis_gn_apply_bwd': 'ppppp' + 'pppp' + 'pp' + 'iliifp',
+    'dis_gn_apply_bwd': 'ppppp' + 'pppp' + 'pp' + 'iliifip',
     'dis_add_act_fwd': 'pppilp',
     'dis_mask_weight_slots': 'pppliip',
     'dis_conv3d_knn_select': 'ppiiiiip',

@@ -89,8 +89,8 @@ class ResNetBlock(torch.nn.Module):
         self.bn2 = NormParams(planes)
 
     def forward(self, x):
-        o, st = ops.conv2d(x, self.conv1.weight, self.conv1.bias, 1, 1, SELU, want_stats=True)
-        o = ops.group_norm(o, self.bn1.weight, self.bn1.bias, stats=st)
+        o, st = ops.conv2d(x, self.conv1.weight, self.conv1.bias, 1, 1, SELU, want_stats=True, gy_is_pre=True)
+        o = ops.group_norm(o, self.bn1.weight, self.bn1.bias, stats=st, in_act=SELU)
         o, st = ops.conv2d(o, self.conv2.weight, self.conv2.bias, 1, 1, NONE, want_stats=True)
         return ops.group_norm(o, self.bn2.weight, self.bn2.bias, stats=st, residual=x, act=SELU)
 
@@ -138,8 +138,8 @@ class Block2D3D(TimedModule):
 
     @staticmethod
     def _conv_gn(x, slots, gn_idx, stride, pad, act):
-        o, st = ops.conv2d(x, slots[1].weight, slots[1].bias, stride, pad, act, want_stats=True)
-        return ops.group_norm(o, slots[gn_idx].weight, slots[gn_idx].bias, stats=st)
+        o, st = ops.conv2d(x, slots[1].weight, slots[1].bias, stride, pad, act, want_stats=True, gy_is_pre=True)
+        return ops.group_norm(o, slots[gn_idx].weight, slots[gn_idx].bias, stats=st, in_act=act)
 
     def tforward(self, feat, geom, geom_q, flows, flows_q, idx=None, idx_q=None):
         """feat (tl,bs,h,w,C) nhwc.  geom/geom_q: core / quarter geometry; flows/flows_q: (tl*tl,bs,.,.,2);

@@ -32,6 +32,41 @@ def _zeros_d(n, dev):
 
 
 # --------------------------------------------------------------------------------------------------
+# gradient sinks: weight-gradient kernels write straight into the flat gradient buffer of trainer.FlatAdam
+# --------------------------------------------------------------------------------------------------
+# data_ptr of a parameter -> [view of the flat gradient buffer, written-this-step flag].  The kernels OVERWRITE their
+# output, so the first backward use of a parameter in a step may write the view directly and return None to autograd
+# (saves one temporary + one `grad += g` launch per parameter, ~236 per DIS-MF step); any further use in the same step
+# falls back to returning the gradient for autograd to accumulate.  FlatAdam.zero_grad() re-arms the flags.
+_GRAD_SINK = {}
+
+
+def register_grad_sinks(params):
+    _GRAD_SINK.clear()
+    for p in params:
+        if p.grad is not None:
+            _GRAD_SINK[p.data_ptr()] = [p.grad, False]
+
+
+def reset_grad_sinks():
+    for e in _GRAD_SINK.values():
+        e[1] = False
+
+
+def _sink(param):
+    """-> (tensor to write the gradient into, value to return to autograd)"""
+    e = _GRAD_SINK.get(param.data_ptr())
+    # the tensor must really be the registered parameter: its .grad IS the flat view (guards against a stale entry
+    # whose address was reused by an unrelated tensor)
+    if (e is not None and not e[1] and e[0].shape == param.shape and param.grad is not None
+            and param.grad.data_ptr() == e[0].data_ptr()):
+        e[1] = True
+        return e[0], None
+    g = torch.empty_like(param)
+    return g, g
+
+
+# --------------------------------------------------------------------------------------------------
 # LCN
 # --------------------------------------------------------------------------------------------------
 def lcn(x, radius=5, eps=0.05):
@@ -354,7 +389,7 @@ def _pack_w(weight, cin_pad, mode):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, need_dgrad):
+    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre=False):
         x, weight = _c(x), _c(weight)
         _chk(x, weight, bias)
         n, hin, win, cin_pad = x.shape
@@ -365,8 +400,11 @@ class _Conv2d(torch.autograd.Function):
         stats = _zeros_d(2 * n, x.device) if want_stats else None
         lib.call('dis_conv2d_fwd', x, _pack_w(weight, cin_pad, 0), bias, y, stats, n, hin, win, cin_pad, cout, k,
                  stride, pad, act)
+        if gy_is_pre:
+            act = ACT_NONE  # the consumer (group_norm(in_act=...)) hands back the pre-activation gradient
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         ctx.cfg = (stride, pad, act, bias is not None, need_dgrad)
+        ctx.bias_ref = bias  # only its address/shape are used (gradient sink lookup)
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -394,19 +432,21 @@ class _Conv2d(torch.autograd.Function):
             else:
                 ws = torch.empty(16 * cin * cout, dtype=torch.float32, device=x.device)
                 lib.call('dis_conv2d_dgrad_strided', gpre, weight, gx, ws, n, hin, win, cin, cout, k, stride, pad)
-        gw = torch.empty_like(weight)
-        gb = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+        gw, gw_ret = _sink(weight)
+        gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
         wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin_pad, cout, k, stride)
         if wsz < 0:
             raise lib.DisHipError(f'conv2d wgrad: unsupported shape cin={cin_pad} cout={cout} k={k} s={stride}')
         ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
         lib.call('dis_conv2d_wgrad', x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw_ret, gb_ret, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, need_dgrad=True):
-    """x nhwc (n,h,w,cin_pad>=cin); weight OIHW.  Returns (y, stats|None)."""
-    return _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad)
+def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, need_dgrad=True, gy_is_pre=False):
+    """x nhwc (n,h,w,cin_pad>=cin); weight OIHW.  Returns (y, stats|None).
+    gy_is_pre: the only consumer of y is group_norm(..., in_act=act), whose backward already multiplies by act'(y);
+    the incoming gradient is then taken as the pre-activation gradient."""
+    return _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre)
 
 
 class _DispHead(torch.autograd.Function):
@@ -519,13 +559,13 @@ class _ConvG(torch.autograd.Function):
             gx = torch.empty_like(x)
             _convg_run(CONVG_TCONV_DGRAD if transposed else CONVG_CONV_DGRAD, gpre, weight, None, gx, n, hout, wout,
                        cout, cout, hin, win, cin_mem, cin_w, k, stride, pad, ACT_NONE)
-        gw = torch.empty_like(weight)
+        gw, gw_ret = _sink(weight)
         if transposed:
             _convg_wgrad(gpre, hout, wout, cout, cout, x, hin, win, cin_mem, cin_w, gw, n, k, stride, pad)
         else:
             _convg_wgrad(x, hin, win, cin_mem, cin_w, gpre, hout, wout, cout, cout, gw, n, k, stride, pad)
         gb = _colsum(gpre, cout) if has_bias else None
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw_ret, gb, None, None, None, None, None, None
 
 
 def convg(x, weight, bias, stride=1, pad=0, act=ACT_NONE, need_dgrad=True):
@@ -580,7 +620,7 @@ def disp_head_g(x, weight, bias, alpha, offset=3.0):
 # --------------------------------------------------------------------------------------------------
 class _GroupNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, stats, gamma, beta, residual, act, eps):
+    def forward(ctx, x, stats, gamma, beta, residual, act, eps, in_act=ACT_NONE):
         x = _c(x)
         residual = _c(residual) if residual is not None else None
         _chk(x, gamma, beta, residual)
@@ -593,29 +633,32 @@ class _GroupNorm(torch.autograd.Function):
         y = torch.empty_like(x)
         lib.call('dis_gn_apply', x, stats, gamma, beta, residual, y, n, hw, c, act, float(eps))
         ctx.save_for_backward(x, stats, gamma, y if act != ACT_NONE else None)
-        ctx.cfg = (n, hw, c, act, float(eps), residual is not None)
+        ctx.cfg = (n, hw, c, act, float(eps), residual is not None, in_act)
+        ctx.beta_ref = beta
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, stats, gamma, y = ctx.saved_tensors
-        n, hw, c, act, eps, has_res = ctx.cfg
+        n, hw, c, act, eps, has_res, in_act = ctx.cfg
         gy = _c(gy)
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if has_res else None
-        gg = torch.empty(c, dtype=torch.float32, device=x.device)
-        gb = torch.empty(c, dtype=torch.float32, device=x.device)
+        gg, gg_ret = _sink(gamma)
+        gb, gb_ret = _sink(ctx.beta_ref)
         wtot = lib.fn('dis_gn_bwd_workspace')(n, c)
         ws = torch.empty(wtot, dtype=torch.float64, device=x.device)
         nred2 = wtot // (2 + 2 * c) * 2
         red, pacc = ws[:nred2], ws[nred2:]
-        lib.call('dis_gn_apply_bwd', gy, y, x, stats, gamma, gx, gres, gg, gb, red, pacc, n, hw, c, act, eps)
-        return gx, None, gg, gb, gres, None, None
+        lib.call('dis_gn_apply_bwd', gy, y, x, stats, gamma, gx, gres, gg, gb, red, pacc, n, hw, c, act, eps, in_act)
+        return gx, None, gg_ret, gb_ret, gres, None, None, None
 
 
-def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5):
-    """GroupNorm(1 group) over all but the first dim of an nhwc tensor; y = act(gn(x) (+ residual))."""
-    return _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps)
+def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5, in_act=ACT_NONE):
+    """GroupNorm(1 group) over all but the first dim of an nhwc tensor; y = act(gn(x) (+ residual)).
+    in_act: x is the output of that activation (conv2d(..., act, gy_is_pre=True)); the backward then returns the
+    gradient wrt the producer's pre-activation output."""
+    return _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act)
 
 
 # --------------------------------------------------------------------------------------------------

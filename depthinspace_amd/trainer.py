@@ -38,9 +38,12 @@ class FlatAdam(object):
         self.step_count = 0
         self.world_size = world_size
         self.process_group = process_group
+        if dev.type == 'cuda':
+            ops.register_grad_sinks(self.params)
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
+        ops.reset_grad_sinks()
 
     def all_reduce_grads(self):
         if self.world_size > 1:

@@ -216,11 +216,14 @@ int dis_gn_apply(const float* x, const double* stats, const float* gamma, const 
  * with W = dis_gn_bwd_workspace(n,c) doubles in total, red = W*2/(2+2c) doubles and gparam_acc = W*2c/(2+2c) doubles
  * (i.e. n*64*2 and n*64*2c).
  * gx overwritten; gres (optional) receives the residual-branch gradient (= gradient after act');
- * grad_gamma/grad_beta (c floats) overwritten. */
+ * grad_gamma/grad_beta (c floats) overwritten.
+ * in_act != DIS_ACT_NONE: x is the activation OUTPUT of the producing layer (conv -> SELU -> GroupNorm, reference
+ * multi_frame_networks.py:338-345,533-535) and gx is additionally multiplied by act'(x), i.e. it is the gradient wrt
+ * that layer's PRE-activation output (saves the separate dis_act_bwd pass). */
 long dis_gn_bwd_workspace(int n, int c);
 int dis_gn_apply_bwd(const float* gy, const float* y, const float* x, const double* stats, const float* gamma,
                      float* gx, float* gres, float* grad_gamma, float* grad_beta, double* red, double* gparam_acc,
-                     int n, long hw, int c, int act, float eps, void* stream);
+                     int n, long hw, int c, int act, float eps, int in_act, void* stream);
 
 /* y = act(a + b) elementwise and its backward (residual SELU of Block2D3D, reference :428). */
 int dis_add_act_fwd(const float* a, const float* b, float* y, int act, long count, void* stream);
