@@ -449,6 +449,188 @@ extern "C" int dis_gather_warped_feat_bwd(const float* grad_out, const float* fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// Scatter index of gather_warped_feat, built once per step and shared by every backward call at that resolution
+// (the flows are data: all four Block2D3D gather the same pattern).  CSR by DESTINATION pixel d = (frame j, b, q):
+// entries (source row of grad_out, bilinear weight).  With it the backward is a gather of whole 128-byte rows with
+// plain loads/stores (HBM/L2 rate) instead of 12 float-atomic rows per pixel (memory-side atomic rate, ~1.3 TB/s),
+// and, the lists being sorted by source row, it is bitwise reproducible.
+//   csr (int32 words): [0, nd]          offsets (nd+1)
+//                      [nd+1, 2nd+1)    cursor  (scratch of the build)
+//                      [2nd+1, ...)     entries: 2 words each (source row, weight bits), nd*... <= pixels*(tl-1)*4
+// ------------------------------------------------------------------------------------------------
+#define CSR_SCAN_ELEMS 2048
+__global__ void csr_count_fill_kernel(const float* __restrict__ flows, int* __restrict__ cursor,
+                                      int* __restrict__ entries, int tl, int bs, int h, int w, int fill) {
+  const long hw = (long)h * w;
+  const int ns = tl - 1;
+  const long total = (long)tl * bs * hw * ns;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int s = (int)(i % ns) + 1;
+    long r = i / ns;
+    const long p = r % hw;
+    r /= hw;
+    const int b = (int)(r % bs);
+    const int t = (int)(r / bs);
+    const int j = slot_frame(t, s);
+    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const float2 f = *(const float2*)(flows + ((((long)t * tl + j) * bs + b) * hw + p) * 2);
+    const Taps tp = make_taps(f.x + (float)x, f.y + (float)y, h, w);
+    const int row = (int)(((((long)t * bs + b) * hw + p) * tl) + s);
+    const long dbase = ((long)j * bs + b) * hw;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool valid = (k == 0) ? tp.v00 : (k == 1) ? tp.v01 : (k == 2) ? tp.v10 : tp.v11;
+      if (!valid) continue;
+      const float wgt = (k == 0) ? tp.w00 : (k == 1) ? tp.w01 : (k == 2) ? tp.w10 : tp.w11;
+      const long d = dbase + (long)(tp.y0 + (k >> 1)) * w + tp.x0 + (k & 1);
+      const int pos = atomicAdd(cursor + d, 1);
+      if (fill) {
+        entries[2 * (long)pos] = row;
+        entries[2 * (long)pos + 1] = __float_as_int(wgt);
+      }
+    }
+  }
+}
+// exclusive scan of cnt[0..n) in three passes (block sums, scan of the sums by one block, block rescans)
+__global__ __launch_bounds__(256) void csr_scan1_kernel(const int* __restrict__ cnt, int* __restrict__ bsum, long n) {
+  __shared__ int sm[4];
+  const long base = (long)blockIdx.x * CSR_SCAN_ELEMS;
+  int s = 0;
+  for (int k = 0; k < CSR_SCAN_ELEMS / 256; ++k) {
+    const long i = base + k * 256 + threadIdx.x;
+    if (i < n) s += cnt[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bsum[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ void csr_scan2_kernel(int* __restrict__ bsum, int nblk) {  // one thread: nblk <= a few thousand
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k < nblk; ++k) {
+      const int v = bsum[k];
+      bsum[k] = run;
+      run += v;
+    }
+    bsum[nblk] = run;
+  }
+}
+// offsets[i] = exclusive prefix; cursor[i] = offsets[i] (start position for the fill pass); offsets[n] = total
+__global__ __launch_bounds__(256) void csr_scan3_kernel(int* __restrict__ cursor, int* __restrict__ offsets,
+                                                         const int* __restrict__ bsum, long n, int nblk) {
+  __shared__ int sm[256];
+  const long base = (long)blockIdx.x * CSR_SCAN_ELEMS + (long)threadIdx.x * (CSR_SCAN_ELEMS / 256);
+  int v[CSR_SCAN_ELEMS / 256], s = 0;
+#pragma unroll
+  for (int k = 0; k < CSR_SCAN_ELEMS / 256; ++k) {
+    v[k] = (base + k < n) ? cursor[base + k] : 0;
+    s += v[k];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  int pre = bsum[blockIdx.x];
+  for (int k = 0; k < (int)threadIdx.x; ++k) pre += sm[k];
+#pragma unroll
+  for (int k = 0; k < CSR_SCAN_ELEMS / 256; ++k) {
+    if (base + k < n) {
+      offsets[base + k] = pre;
+      cursor[base + k] = pre;
+    }
+    pre += v[k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = bsum[nblk];
+}
+// sort every destination's (short) list by source row: fixed summation order in the gather
+__global__ void csr_sort_kernel(const int* __restrict__ offsets, int* __restrict__ entries, long nd) {
+  for (long d = blockIdx.x * (long)blockDim.x + threadIdx.x; d < nd; d += (long)gridDim.x * blockDim.x) {
+    const int lo = offsets[d], hi = offsets[d + 1];
+    for (int a = lo + 1; a < hi; ++a) {
+      const int kr = entries[2 * (long)a], kw = entries[2 * (long)a + 1];
+      int bpos = a - 1;
+      while (bpos >= lo && entries[2 * (long)bpos] > kr) {
+        entries[2 * (long)bpos + 2] = entries[2 * (long)bpos];
+        entries[2 * (long)bpos + 3] = entries[2 * (long)bpos + 1];
+        --bpos;
+      }
+      entries[2 * (long)bpos + 2] = kr;
+      entries[2 * (long)bpos + 3] = kw;
+    }
+  }
+}
+// grad_feat[d] = grad_out[d, slot 0] + sum_e w_e * grad_out[row_e];  one thread = 4 channels of one destination
+__global__ void gather_warped_feat_bwd_csr_kernel(const float* __restrict__ gout, const int* __restrict__ offsets,
+                                                  const int* __restrict__ entries, float* __restrict__ gfeat,
+                                                  long nd, int tl, int c) {
+  const int cg = c >> 2;
+  const long total = nd * cg;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    const long d = i / cg;
+    float4 acc = *(const float4*)(gout + (d * tl) * c + g * 4);
+    const int lo = offsets[d], hi = offsets[d + 1];
+    for (int e = lo; e < hi; ++e) {
+      const int row = entries[2 * (long)e];
+      const float wgt = __int_as_float(entries[2 * (long)e + 1]);
+      const float4 v = *(const float4*)(gout + (long)row * c + g * 4);
+      acc.x += v.x * wgt; acc.y += v.y * wgt; acc.z += v.z * wgt; acc.w += v.w * wgt;
+    }
+    *(float4*)(gfeat + d * c + g * 4) = acc;
+  }
+}
+
+static long csr_words(int tl, int bs, int h, int w) {
+  const long nd = (long)tl * bs * h * w;
+  return (nd + 1) + nd + 2 * nd * (tl - 1) * 4;
+}
+extern "C" long dis_gather_csr_workspace(int tl, int bs, int h, int w) {
+  if (tl <= 1 || bs <= 0 || h <= 1 || w <= 1) return -1;
+  const long nd = (long)tl * bs * h * w;
+  const long nblk = (nd + CSR_SCAN_ELEMS - 1) / CSR_SCAN_ELEMS;
+  return csr_words(tl, bs, h, w) + nblk + 1;
+}
+extern "C" int dis_gather_csr_build(const float* flows, int* csr, int tl, int bs, int h, int w, void* stream) {
+  if (!flows || !csr) return DIS_ERR_NULL;
+  if (tl <= 1 || bs <= 0 || h <= 1 || w <= 1) return DIS_ERR_BAD_SHAPE;
+  const long nd = (long)tl * bs * h * w;
+  if (nd * tl >= 2147483647L || nd * (tl - 1) * 4 >= 1073741823L) return DIS_ERR_UNSUPPORTED;  // int32 rows / positions
+  hipStream_t s = (hipStream_t)stream;
+  int* offsets = csr;
+  int* cursor = csr + nd + 1;
+  int* entries = csr + 2 * nd + 1;
+  int* bsum = csr + csr_words(tl, bs, h, w);
+  const int nblk = (int)((nd + CSR_SCAN_ELEMS - 1) / CSR_SCAN_ELEMS);
+  hipError_t e = hipMemsetAsync(cursor, 0, nd * sizeof(int), s);
+  if (e != hipSuccess) return (int)e;
+  const long items = nd * (tl - 1);
+  int grid = dis_cdiv(items, 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(csr_count_fill_kernel, dim3(grid), dim3(256), 0, s, flows, cursor, entries, tl, bs, h, w, 0);
+  hipLaunchKernelGGL(csr_scan1_kernel, dim3(nblk), dim3(256), 0, s, (const int*)cursor, bsum, nd);
+  hipLaunchKernelGGL(csr_scan2_kernel, dim3(1), dim3(64), 0, s, bsum, nblk);
+  hipLaunchKernelGGL(csr_scan3_kernel, dim3(nblk), dim3(256), 0, s, cursor, offsets, (const int*)bsum, nd, nblk);
+  hipLaunchKernelGGL(csr_count_fill_kernel, dim3(grid), dim3(256), 0, s, flows, cursor, entries, tl, bs, h, w, 1);
+  hipLaunchKernelGGL(csr_sort_kernel, dim3(dis_ew_grid(nd, 256)), dim3(256), 0, s, (const int*)offsets, entries, nd);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* csr, float* grad_feat, int tl, int bs,
+                                              int h, int w, int c, void* stream) {
+  if (!grad_out || !csr || !grad_feat) return DIS_ERR_NULL;
+  if (tl <= 1 || bs <= 0 || h <= 1 || w <= 1 || c <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c % 4 != 0) return DIS_ERR_UNSUPPORTED;
+  const long nd = (long)tl * bs * h * w;
+  const long total = nd * (c / 4);
+  int grid = dis_cdiv(total, 256);
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(gather_warped_feat_bwd_csr_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_out, csr,
+                     csr + 2 * nd + 1, grad_feat, nd, tl, c);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // multi-frame geometry: warped xyz + forward/backward mask per (target, slot)
 // (reference multi_frame_networks.py:172-214, 283-294); out (tl,bs,h,w,tl,4)
 // ------------------------------------------------------------------------------------------------

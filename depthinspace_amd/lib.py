@@ -40,6 +40,9 @@ SIGS = {
     'dis_resize_bilinear_planar_bwd': 'ppiiiiiip',
     'dis_gather_warped_feat_fwd': 'pppiiiiip',
     'dis_gather_warped_feat_bwd': 'pppiiiiip',
+    'dis_gather_csr_workspace': 'iiii',
+    'dis_gather_csr_build': 'ppiiiip',
+    'dis_gather_warped_feat_bwd_csr': 'pppiiiiip',
     'dis_mf_geometry': 'pppppiipiiiip',
     'dis_mf_geometry_resize': 'ppiiiiiip',
     'dis_conv2d_pack_weights': 'ppiiiiip',
@@ -71,7 +74,7 @@ SIGS = {
     'dis_adam_step': 'pppplffffifp',
 }
 _RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
-             'dis_colsum_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace'}
+             'dis_colsum_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_gather_csr_workspace'}
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
 _lib = None

@@ -141,15 +141,15 @@ class Block2D3D(TimedModule):
         o, st = ops.conv2d(x, slots[1].weight, slots[1].bias, stride, pad, act, want_stats=True, gy_is_pre=True)
         return ops.group_norm(o, slots[gn_idx].weight, slots[gn_idx].bias, stats=st, in_act=act)
 
-    def tforward(self, feat, geom, geom_q, flows, flows_q, idx=None, idx_q=None):
+    def tforward(self, feat, geom, geom_q, flows, flows_q, idx=None, idx_q=None, csr=None, csr_q=None):
         """feat (tl,bs,h,w,C) nhwc.  geom/geom_q: core / quarter geometry; flows/flows_q: (tl*tl,bs,.,.,2);
         idx/idx_q: neighbour sets of the two Conv3D layers (shared by all blocks: they depend on geometry only)."""
         tl, bs, h, w, C = feat.shape
         N = tl * bs
         # 3-D branch (fwd_3d_1 / fwd_3d_2, reference :376-404)
-        wf = ops.gather_warped_feat(feat, flows)
+        wf = ops.gather_warped_feat(feat, flows, csr)
         o3d1 = self.conv3d_1(geom, wf, idx)
-        wfq = ops.gather_warped_feat(o3d1, flows_q)
+        wfq = ops.gather_warped_feat(o3d1, flows_q, csr_q)
         o3d2 = self.conv3d_2(geom_q, wfq, idx_q)
         hq, wq = o3d2.shape[2:4]
         # 2-D branch (fwd_2d, reference :406-430)
@@ -262,10 +262,13 @@ class FuseNet(TimedModule):
             ov = self.knn_index_override
             idx = ov[0] if ov is not None else ops.conv3d_select(geom, 2)
             idx_q = ov[1] if ov is not None else ops.conv3d_select(geom_q, 1)
+            # scatter index of the feature warps (data only): built once, shared by the 4 blocks' backward passes
+            csr = ops.gather_csr(flows) if torch.is_grad_enabled() or feat.requires_grad else None
+            csr_q = ops.gather_csr(flows_q) if csr is not None else None
         self.last_knn_index = (idx, idx_q)
 
         for block in self.blocks:
-            feat = block(feat, geom, geom_q, flows, flows_q, idx, idx_q)
+            feat = block(feat, geom, geom_q, flows, flows_q, idx, idx_q, csr, csr_q)
 
         amb4 = ops.pack4_nhwc([(amb, HW)], N, H, W)
         disp = self.post_process(feat.view(N, h, w, self.channels), amb4)

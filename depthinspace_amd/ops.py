@@ -666,28 +666,46 @@ def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5
 # --------------------------------------------------------------------------------------------------
 class _GatherWarpedFeat(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, flows):
+    def forward(ctx, feat, flows, csr):
         feat, flows = _c(feat), _c(flows)
         _chk(feat, flows)
         tl, bs, h, w, c = feat.shape
         assert flows.shape == (tl * tl, bs, h, w, 2), flows.shape
         out = torch.empty((tl, bs, h, w, tl, c), dtype=torch.float32, device=feat.device)
         lib.call('dis_gather_warped_feat_fwd', feat, flows, out, tl, bs, h, w, c)
-        ctx.save_for_backward(flows)
+        ctx.save_for_backward(flows, csr)
         ctx.shape = feat.shape
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (flows,) = ctx.saved_tensors
+        flows, csr = ctx.saved_tensors
         tl, bs, h, w, c = ctx.shape
         gf = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
-        lib.call('dis_gather_warped_feat_bwd', _c(g), flows, gf, tl, bs, h, w, c)
-        return gf, None
+        if csr is not None:
+            lib.call('dis_gather_warped_feat_bwd_csr', _c(g), csr, gf, tl, bs, h, w, c)
+        else:
+            lib.call('dis_gather_warped_feat_bwd', _c(g), flows, gf, tl, bs, h, w, c)
+        return gf, None, None
 
 
-def gather_warped_feat(feat, flows):
-    return _GatherWarpedFeat.apply(feat, flows)
+def gather_csr(flows):
+    """Scatter index of gather_warped_feat for `flows` (tl*tl,bs,h,w,2): build once per step and pass to every
+    gather_warped_feat call that uses these flows; the backward then runs without atomics (deterministic)."""
+    flows = _c(flows)
+    _chk(flows)
+    t2, bs, h, w, _ = flows.shape
+    tl = int(round(t2 ** 0.5))
+    n = lib.fn('dis_gather_csr_workspace')(tl, bs, h, w)
+    if n < 0:
+        raise lib.DisHipError('gather_csr: unsupported shape')
+    csr = torch.empty(n, dtype=torch.int32, device=flows.device)
+    lib.call('dis_gather_csr_build', flows, csr, tl, bs, h, w)
+    return csr
+
+
+def gather_warped_feat(feat, flows, csr=None):
+    return _GatherWarpedFeat.apply(feat, flows, csr)
 
 
 def mf_geometry(depth_core, R, t, flows_core, Kinv, u_step, v_step):

@@ -146,6 +146,15 @@ int dis_gather_warped_feat_fwd(const float* feat, const float* flows, float* out
 int dis_gather_warped_feat_bwd(const float* grad_out, const float* flows, float* grad_feat, int tl, int bs, int h,
                                int w, int c, void* stream);
 
+/* Deterministic, atomic-free form of the same backward.  dis_gather_csr_build turns `flows` into a CSR index by
+ * destination pixel (lists sorted by source row) once per step and resolution: csr = dis_gather_csr_workspace(...)
+ * int32 words; every dis_gather_warped_feat_bwd_csr call with the same flows then gathers whole rows of grad_out with
+ * plain loads (grad_feat OVERWRITTEN, bitwise reproducible). */
+long dis_gather_csr_workspace(int tl, int bs, int h, int w);
+int dis_gather_csr_build(const float* flows, int* csr, int tl, int bs, int h, int w, void* stream);
+int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* csr, float* grad_feat, int tl, int bs, int h,
+                                   int w, int c, void* stream);
+
 /* unproject + change_view_angle + gather_warped_xyz + forward/backward flow mask for every target,
  * reference multi_frame_networks.py:172-214,283-294.  No gradient.
  * depth_core: (tl,bs,h,w); R (tl,bs,3,3), t (tl,bs,3) device; Kinv_host 9 floats;

@@ -188,6 +188,16 @@ def test_gather_warped_feat():
     out.backward(go.permute(0, 2, 4, 5, 1, 3).contiguous().cuda())
     assert relerr(out.permute(0, 4, 1, 5, 2, 3), ref) < 2e-6
     assert relerr(fd.grad.permute(0, 1, 4, 2, 3), fr.grad) < 1e-5
+    # CSR (atomic-free) backward: same gradient, bitwise reproducible from call to call
+    god = go.permute(0, 2, 4, 5, 1, 3).contiguous().cuda()
+    grads = []
+    for _ in range(2):
+        csr = ops.gather_csr(fl)
+        f2 = feat.permute(0, 1, 3, 4, 2).contiguous().cuda().requires_grad_(True)
+        ops.gather_warped_feat(f2, fl, csr).backward(god)
+        grads.append(f2.grad.clone())
+    assert relerr(grads[0].permute(0, 1, 4, 2, 3), fr.grad) < 1e-5
+    assert torch.equal(grads[0], grads[1])
 
 
 def test_mf_geometry_and_mask_weight():
