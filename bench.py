@@ -231,9 +231,19 @@ def main():
         tm = sum(ms for _, ms in sel) * 1e-3
         if sel:
             ach = fl / tm / 1e12
+            traffic, tsrc = None, None
+            tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
+            if mf and os.path.exists(tpath):
+                # HBM bytes per launch from the PMC passes (separate rocprofv3 runs, see profiles/README.md)
+                tj = json.load(open(tpath))
+                traffic, tsrc = tj['hbm_bytes_per_launch'], tj['source']
             roof = {'bound': 'mfma', 'kernel': kname,
                     'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'launches_per_step': len(sel),
+                    'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
+                    'traffic_source': tsrc,
+                    'algorithmic_bytes_per_launch_avg': (sum(2.0 * ia[0] * ia[1] * ia[2] * 32 * 4 for ia, _ in sel) / len(sel)
+                                                         if mf else None),
+                    'launches_per_step': len(sel),
                     'avg_launch_ms': tm * 1e3 / len(sel), 'flop_per_launch_avg': fl / len(sel),
                     'share_of_step_kernel_time': tm / (sum(ms for _, _, ms in rec) * 1e-3)}
         top = sorted(per.items(), key=lambda kv: -kv[1][1])[:12]

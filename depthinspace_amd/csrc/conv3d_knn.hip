@@ -462,13 +462,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_bwd_kernel(const float4* __rest
     part[(long)blockIdx.x * C3_NPARAM + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
-// gparams[t] = sum over blocks (fixed order)
-__global__ void c3_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ o, int nblocks) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// gparams[t] = sum over blocks: one wave per parameter, lanes stride over the block slabs, fixed-order wave reduction
+__global__ __launch_bounds__(256) void c3_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ o,
+                                                               int nblocks) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (t >= C3_NPARAM) return;
   float s = 0.f;
-  for (int k = 0; k < nblocks; ++k) s += part[(long)k * C3_NPARAM + t];
-  o[t] = s;
+  for (int k = lane; k < nblocks; k += 64) s += part[(long)k * C3_NPARAM + t];
+  s = wave_sum(s);
+  if (lane == 0) o[t] = s;
 }
 
 #define C3_BWD_BLOCKS 512
@@ -534,7 +536,7 @@ extern "C" int dis_conv3d_knn_bwd(const float* geom, const float* wf, const floa
   if (grid > C3_BWD_BLOCKS) grid = C3_BWD_BLOCKS;
   hipLaunchKernelGGL(conv3d_bwd_kernel, dim3(grid), dim3(256), 0, s, (const float4*)geom, wf, P, idx, y, gy, grad_wf,
                      workspace, d);
-  hipLaunchKernelGGL(c3_param_reduce_kernel, dim3(dis_cdiv(C3_NPARAM, 256)), dim3(256), 0, s, (const float*)workspace,
+  hipLaunchKernelGGL(c3_param_reduce_kernel, dim3(dis_cdiv(C3_NPARAM, 4)), dim3(256), 0, s, (const float*)workspace,
                      gparams, grid);
   DIS_CHECK_LAUNCH();
   return DIS_OK;

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Turn one profiling round (gpurun_out/<tag>/, written by scripts/prof_round.sh on the GPU box) into the tracked
+summaries under profiles/:
+
+  <tag>_bench.json / <tag>_bench_sf.json   the bench lines (DIS-MF headline, DIS-SF)
+  <tag>_bench_under_rocprof.json           the bench line printed under the profiler
+  <tag>_kernel_stats.csv                   rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3`
+  <tag>_pmc_sq.csv                         per-kernel averages of the SQ counters (one eager step)
+  <tag>_pmc_mem.csv                        per-kernel FETCH_SIZE / WRITE_SIZE / L2 hit counters (separate passes)
+  <tag>_kernels.md                         ranking: time per step, measured HBM bytes and GB/s, MFMA/wait fractions
+  roofline_traffic.json                    HBM bytes per launch of the dominant kernel (read by bench.py)
+
+    python scripts/make_profile_summary.py r1v5
+"""
+import csv
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DOMINANT = 'void conv_fwd_kernel<32, 32, 3, 3, 1>(ConvArgs)'
+
+
+def main(tag):
+    src = os.path.join(ROOT, 'gpurun_out', tag)
+    dst = os.path.join(ROOT, 'profiles')
+    for a, b in (('bench.json', f'{tag}_bench.json'), ('bench_sf.json', f'{tag}_bench_sf.json'),
+                 ('bench_prof.json', f'{tag}_bench_under_rocprof.json'),
+                 ('trace/run_kernel_stats.csv', f'{tag}_kernel_stats.csv')):
+        if os.path.exists(os.path.join(src, a)):
+            shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+    summ = os.path.join(ROOT, 'scripts', 'pmc_summary.py')
+    with open(os.path.join(dst, f'{tag}_pmc_sq.csv'), 'w') as f:
+        subprocess.check_call([sys.executable, summ, os.path.join(src, 'sq', 'sq_counter_collection.csv')], stdout=f)
+    with open(os.path.join(dst, f'{tag}_pmc_mem.csv'), 'w') as f:
+        subprocess.check_call([sys.executable, summ, os.path.join(src, 'fetch', 'fetch_counter_collection.csv'),
+                               os.path.join(src, 'write', 'write_counter_collection.csv')], stdout=f)
+    stats = list(csv.DictReader(open(os.path.join(dst, f'{tag}_kernel_stats.csv'))))
+    prof = json.loads(open(os.path.join(dst, f'{tag}_bench_under_rocprof.json')).read().strip().splitlines()[-1])
+    # the profiled command runs steps + warmup + 1 eager roofline step (+1 capture) of kernels
+    nsteps = prof['steps'] + prof['warmup'] + 1
+    sq = {r['Kernel']: r for r in csv.DictReader(open(os.path.join(dst, f'{tag}_pmc_sq.csv')))}
+    mem = {r['Kernel']: r for r in csv.DictReader(open(os.path.join(dst, f'{tag}_pmc_mem.csv')))}
+    lines = ['| kernel | launches/step | ms/step | avg us | HBM read MB (2xFETCH_SIZE) | HBM write MB | GB/s | L2 hit | '
+             'wait_any | wait_inst | active |', '|---|---|---|---|---|---|---|---|---|---|---|']
+    tot = sum(float(r['TotalDurationNs']) for r in stats)
+    for r in stats[:40]:
+        k = r['Name']
+        us = float(r['AverageNs']) / 1e3
+        m, q = mem.get(k), sq.get(k)
+        if m:
+            rd, wr = float(m['FETCH_SIZE']) * 2 / 1024, float(m['WRITE_SIZE']) / 1024
+            hit = float(m['TCC_HIT_sum']) / max(float(m['TCC_HIT_sum']) + float(m['TCC_MISS_sum']), 1)
+            gbs = (rd + wr) / float(m['AvgUs']) * 1e3
+            mtxt = f'{rd:.1f} | {wr:.1f} | {gbs:.0f} | {hit:.2f}'
+        else:
+            mtxt = ' | | | '
+        if q:
+            wc = max(float(q['SQ_WAVE_CYCLES']), 1)
+            qtxt = f"{float(q['SQ_WAIT_ANY'])/wc:.2f} | {float(q['SQ_WAIT_INST_ANY'])/wc:.2f} | {float(q['SQ_ACTIVE_INST_ANY'])/wc:.2f}"
+        else:
+            qtxt = ' | | '
+        lines.append(f"| `{k[:90]}` | {int(r['Calls'])/nsteps:.1f} | {float(r['TotalDurationNs'])/1e6/nsteps:.3f} | {us:.1f} | "
+                     f"{mtxt} | {qtxt} |")
+    with open(os.path.join(dst, f'{tag}_kernels.md'), 'w') as f:
+        f.write(f'# {tag}: kernel ranking of the DIS-MF bs=4 step (sum of kernel time {tot/1e6/nsteps:.1f} ms/step over '
+                f'{nsteps} profiled steps)\n\n'
+                'HBM columns: PMC passes of one eager step (`scripts/prof_round.sh`), FETCH_SIZE doubled as '
+                'MI355X_MICROARCH.md prescribes for gfx950; wait/active columns are fractions of SQ_WAVE_CYCLES.\n\n')
+        f.write('\n'.join(lines) + '\n')
+    m = mem.get(DOMINANT)
+    if m:
+        rd, wr = float(m['FETCH_SIZE']) * 2 * 1024, float(m['WRITE_SIZE']) * 1024
+        json.dump({'kernel': DOMINANT, 'hbm_bytes_per_launch': rd + wr, 'read_bytes': rd, 'write_bytes': wr,
+                   'launches_averaged': int(m['Calls']),
+                   'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over one eager step; '
+                             'FETCH_SIZE (KB) doubled (gfx950 counts 64 B per 128-B request), WRITE_SIZE (KB) as read',
+                   'source': f'profiles/{tag}_pmc_mem.csv'}, open(os.path.join(dst, 'roofline_traffic.json'), 'w'), indent=1)
+    print('wrote profiles/', tag)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
