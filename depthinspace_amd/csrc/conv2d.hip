@@ -35,6 +35,7 @@ struct ConvArgs {
   int hf, wf;          // full output tensor dims
   int osy, ooy, osx, oox;  // output pixel = (vy*osy+ooy, vx*osx+oox)
   int act;
+  int accum;  // epilogue adds the previous contents of y (before the activation): y = act(y_old + conv + bias)
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -231,8 +232,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     float* ybase = a.y + (((long)n * a.hf + ((long)vy0 * a.osy + a.ooy)) * a.wf + ((long)vx0 * a.osx + a.oox)) * COUT + li;
     const long yrow = (long)a.osy * a.wf * COUT;
     const bool full = (ty + 1) * C::TROWS <= a.hv && (tx + 1) * C::TCOLS <= a.wv;
-    auto emit = [&](auto actc) {
+    auto emit = [&](auto actc, auto accc) {
       constexpr int ACT = decltype(actc)::value;
+      constexpr bool ACC = decltype(accc)::value != 0;
       if (full) {
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt)
@@ -240,8 +242,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int nt = 0; nt < C::NT; ++nt) {
-              const float v = act_apply(acc[mt][nt][r] + bias_v[nt], ACT);
-              ybase[mt * yrow + r * ypix + nt * 16] = v;
+              float* yp = ybase + mt * yrow + r * ypix + nt * 16;
+              float pre_v = acc[mt][nt][r] + bias_v[nt];
+              if (ACC) pre_v += *yp;
+              const float v = act_apply(pre_v, ACT);
+              *yp = v;
               t1 += v;
               t2 += v * v;
             }
@@ -253,17 +258,28 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             if (vy0 + mt < a.hv && vx0 + r < a.wv) {
 #pragma unroll
               for (int nt = 0; nt < C::NT; ++nt) {
-                const float v = act_apply(acc[mt][nt][r] + bias_v[nt], ACT);
-                ybase[mt * yrow + r * ypix + nt * 16] = v;
+                float* yp = ybase + mt * yrow + r * ypix + nt * 16;
+                float pre_v = acc[mt][nt][r] + bias_v[nt];
+                if (ACC) pre_v += *yp;
+                const float v = act_apply(pre_v, ACT);
+                *yp = v;
                 t1 += v;
                 t2 += v * v;
               }
             }
       }
     };
-    if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{});
-    else if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{});
-    else emit(std::integral_constant<int, DIS_ACT_NONE>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (a.accum) {
+      if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{}, I1{});
+      else if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{}, I1{});
+      else emit(std::integral_constant<int, DIS_ACT_NONE>{}, I1{});
+    } else {
+      if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{}, I0{});
+      else if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{}, I0{});
+      else emit(std::integral_constant<int, DIS_ACT_NONE>{}, I0{});
+    }
     s1 += (double)t1;
     s2 += (double)t2;
     tile += per;
@@ -395,7 +411,10 @@ extern "C" int dis_conv2d_fwd(const float* x, const float* w_packed, const float
   ConvArgs a;
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.stats = stats;
   a.n = n; a.hin = hin; a.win = win; a.hv = hout; a.wv = wout; a.pad_y = pad; a.pad_x = pad;
-  a.hf = hout; a.wf = wout; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0; a.act = act;
+  a.hf = hout; a.wf = wout; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
+  a.act = act & 0xff;
+  a.accum = (act & DIS_CONV_ACCUM) ? 1 : 0;
+  if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
   return dispatch_conv(a, cin, cout, k, k, stride, (hipStream_t)stream);
 }
 
@@ -403,7 +422,7 @@ extern "C" int dis_conv2d_fwd(const float* x, const float* w_packed, const float
 // matrix cores, each writing one parity class of gx.  workspace: 4 * (4*cin*cout) floats.
 extern "C" int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, float* gx, float* workspace, int n,
                                         int hin, int win, int cin, int cout, int k, int stride, int pad,
-                                        void* stream) {
+                                        int accumulate, void* stream) {
   if (!gy || !w_oihw || !gx || !workspace) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0) return DIS_ERR_BAD_SHAPE;
   if (k != 4 || stride != 2 || pad != 1 || (hin & 1) || (win & 1)) return DIS_ERR_UNSUPPORTED;
@@ -420,6 +439,7 @@ extern "C" int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, fl
       a.n = n; a.hin = hout; a.win = wout; a.hv = hout; a.wv = wout;
       a.pad_y = (py == 0) ? 1 : 0; a.pad_x = (px == 0) ? 1 : 0;
       a.hf = hin; a.wf = win; a.osy = 2; a.ooy = py; a.osx = 2; a.oox = px; a.act = DIS_ACT_NONE;
+      a.accum = accumulate ? 1 : 0;
       int rc = dispatch_conv(a, cout, cin, 2, 2, 1, s);
       if (rc != DIS_OK) return rc;
     }

@@ -561,14 +561,18 @@ __global__ void csr_sort_kernel(const int* __restrict__ offsets, int* __restrict
 }
 // grad_feat[d] = grad_out[d, slot 0] + sum_e w_e * grad_out[row_e];  one thread = 4 channels of one destination
 __global__ void gather_warped_feat_bwd_csr_kernel(const float* __restrict__ gout, const int* __restrict__ offsets,
-                                                  const int* __restrict__ entries, float* __restrict__ gfeat,
-                                                  long nd, int tl, int c) {
+                                                  const int* __restrict__ entries, const float* __restrict__ init,
+                                                  float* __restrict__ gfeat, long nd, int tl, int c) {
   const int cg = c >> 2;
   const long total = nd * cg;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int g = (int)(i % cg);
     const long d = i / cg;
     float4 acc = *(const float4*)(gout + (d * tl) * c + g * 4);
+    if (init) {
+      const float4 q = *(const float4*)(init + d * c + g * 4);
+      acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+    }
     const int lo = offsets[d], hi = offsets[d + 1];
     for (int e = lo; e < hi; ++e) {
       const int row = entries[2 * (long)e];
@@ -615,8 +619,8 @@ extern "C" int dis_gather_csr_build(const float* flows, int* csr, int tl, int bs
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
-extern "C" int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* csr, float* grad_feat, int tl, int bs,
-                                              int h, int w, int c, void* stream) {
+extern "C" int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* csr, const float* init,
+                                              float* grad_feat, int tl, int bs, int h, int w, int c, void* stream) {
   if (!grad_out || !csr || !grad_feat) return DIS_ERR_NULL;
   if (tl <= 1 || bs <= 0 || h <= 1 || w <= 1 || c <= 0) return DIS_ERR_BAD_SHAPE;
   if (c % 4 != 0) return DIS_ERR_UNSUPPORTED;
@@ -625,7 +629,7 @@ extern "C" int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* 
   int grid = dis_cdiv(total, 256);
   if (grid > 16384) grid = 16384;
   hipLaunchKernelGGL(gather_warped_feat_bwd_csr_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_out, csr,
-                     csr + 2 * nd + 1, grad_feat, nd, tl, c);
+                     csr + 2 * nd + 1, init, grad_feat, nd, tl, c);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
@@ -768,7 +772,7 @@ extern "C" int dis_mf_geometry_resize(const float* geom, float* out, int tl, int
 // (reference multi_frame_networks.py:410).  Linear in wf, so the same call is its own backward.
 // ------------------------------------------------------------------------------------------------
 __global__ void mask_weight_slots_kernel(const float* __restrict__ wf, const float4* __restrict__ geom,
-                                         float* __restrict__ out, long pixels, int tl, int c) {
+                                         float* __restrict__ out, long pixels, int tl, int c, int accumulate) {
   const int cg = c >> 2;
   const long total = pixels * tl * cg;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -784,17 +788,21 @@ __global__ void mask_weight_slots_kernel(const float* __restrict__ wf, const flo
     v.y = (v.y * m) / mean;
     v.z = (v.z * m) / mean;
     v.w = (v.w * m) / mean;
+    if (accumulate) {
+      const float4 o = *(const float4*)(out + i * 4);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
     *(float4*)(out + i * 4) = v;
   }
 }
 extern "C" int dis_mask_weight_slots(const float* wf, const float* geom, float* out, long pixels, int tl, int c,
-                                     void* stream) {
+                                     int accumulate, void* stream) {
   if (!wf || !geom || !out) return DIS_ERR_NULL;
   if (pixels <= 0 || tl <= 0 || c <= 0) return DIS_ERR_BAD_SHAPE;
   if (c % 4 != 0) return DIS_ERR_UNSUPPORTED;
   long total = pixels * tl * (c / 4);
   hipLaunchKernelGGL(mask_weight_slots_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, wf,
-                     (const float4*)geom, out, pixels, tl, c);
+                     (const float4*)geom, out, pixels, tl, c, accumulate);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

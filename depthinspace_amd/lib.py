@@ -42,14 +42,14 @@ SIGS = {
     'dis_gather_warped_feat_bwd': 'pppiiiiip',
     'dis_gather_csr_workspace': 'iiii',
     'dis_gather_csr_build': 'ppiiiip',
-    'dis_gather_warped_feat_bwd_csr': 'pppiiiiip',
+    'dis_gather_warped_feat_bwd_csr': 'ppppiiiiip',
     'dis_mf_geometry': 'pppppiipiiiip',
     'dis_mf_geometry_resize': 'ppiiiiiip',
     'dis_conv2d_pack_weights': 'ppiiiiip',
     'dis_conv2d_fwd': 'pppppiiiiiiiiip',
     'dis_conv2d_wgrad_workspace': 'iiii',
     'dis_conv2d_wgrad': 'pppppiiiiiiiiip',
-    'dis_conv2d_dgrad_strided': 'ppppiiiiiiiip',
+    'dis_conv2d_dgrad_strided': 'ppppiiiiiiiiip',
     'dis_disp_head_fwd': 'ppppiiiiffp',
     'dis_disp_head_bwd': 'ppppppppp' + 'iiiifp',
     'dis_act_bwd': 'pppilp',
@@ -58,7 +58,7 @@ SIGS = {
     'dis_gn_bwd_workspace': 'ii',
     'dis_gn_apply_bwd': 'ppppp' + 'pppp' + 'pp' + 'iliifip',
     'dis_add_act_fwd': 'pppilp',
-    'dis_mask_weight_slots': 'pppliip',
+    'dis_mask_weight_slots': 'pppliiip',
     'dis_conv3d_knn_select': 'ppiiiiip',
     'dis_conv3d_knn_fwd': 'ppppppppp' + 'iiiiip',
     'dis_conv3d_knn_bwd_workspace': '',

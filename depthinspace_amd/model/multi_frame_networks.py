@@ -89,10 +89,11 @@ class ResNetBlock(torch.nn.Module):
         self.bn2 = NormParams(planes)
 
     def forward(self, x):
-        o, st = ops.conv2d(x, self.conv1.weight, self.conv1.bias, 1, 1, SELU, want_stats=True, gy_is_pre=True)
+        j = ops.GradJoin() if x.requires_grad else None  # x feeds conv1 and the residual: one shared gradient buffer
+        o, st = ops.conv2d(x, self.conv1.weight, self.conv1.bias, 1, 1, SELU, want_stats=True, gy_is_pre=True, join=j)
         o = ops.group_norm(o, self.bn1.weight, self.bn1.bias, stats=st, in_act=SELU)
         o, st = ops.conv2d(o, self.conv2.weight, self.conv2.bias, 1, 1, NONE, want_stats=True)
-        return ops.group_norm(o, self.bn2.weight, self.bn2.bias, stats=st, residual=x, act=SELU)
+        return ops.group_norm(o, self.bn2.weight, self.bn2.bias, stats=st, residual=x, act=SELU, join=j)
 
 
 class Conv3D(TimedModule):
@@ -109,11 +110,11 @@ class Conv3D(TimedModule):
         torch.nn.init.xavier_uniform_(self.w, gain=0.1)
         self.bn = NormParams(channels_out)
 
-    def tforward(self, geom, wf, idx=None):
+    def tforward(self, geom, wf, idx=None, join=None):
         if idx is None:
             idx = ops.conv3d_select(geom, self.stride)
         y = ops.conv3d_knn(geom, wf, self.dense1[0].weight, self.dense1[0].bias, self.dense2[0].weight,
-                           self.dense2[0].bias, self.w, idx, self.stride)
+                           self.dense2[0].bias, self.w, idx, self.stride, join)
         tl, bs, ho, wo, c = y.shape
         o = ops.group_norm(y.view(tl * bs, ho, wo, c), self.bn.weight, self.bn.bias)
         return o.view(tl, bs, ho, wo, c)
@@ -137,8 +138,9 @@ class Block2D3D(TimedModule):
         self.conv3d_2 = Conv3D(channels_in=C, channels_out=C, tl=tl, stride=1)
 
     @staticmethod
-    def _conv_gn(x, slots, gn_idx, stride, pad, act):
-        o, st = ops.conv2d(x, slots[1].weight, slots[1].bias, stride, pad, act, want_stats=True, gy_is_pre=True)
+    def _conv_gn(x, slots, gn_idx, stride, pad, act, join=None):
+        o, st = ops.conv2d(x, slots[1].weight, slots[1].bias, stride, pad, act, want_stats=True, gy_is_pre=True,
+                           join=join)
         return ops.group_norm(o, slots[gn_idx].weight, slots[gn_idx].bias, stats=st, in_act=act)
 
     def tforward(self, feat, geom, geom_q, flows, flows_q, idx=None, idx_q=None, csr=None, csr_q=None):
@@ -146,25 +148,29 @@ class Block2D3D(TimedModule):
         idx/idx_q: neighbour sets of the two Conv3D layers (shared by all blocks: they depend on geometry only)."""
         tl, bs, h, w, C = feat.shape
         N = tl * bs
+        # tensors with two consumers on the tape share one gradient buffer each (ops.GradJoin): feat (gather + residual),
+        # wf (Conv3D + the 2-D branch) and mf (the two 2-D branches)
+        grad = torch.is_grad_enabled() and feat.requires_grad
+        j_feat, j_wf, j_mf = (ops.GradJoin(), ops.GradJoin(), ops.GradJoin()) if grad else (None, None, None)
         # 3-D branch (fwd_3d_1 / fwd_3d_2, reference :376-404)
-        wf = ops.gather_warped_feat(feat, flows, csr)
-        o3d1 = self.conv3d_1(geom, wf, idx)
+        wf = ops.gather_warped_feat(feat, flows, csr, j_feat)
+        o3d1 = self.conv3d_1(geom, wf, idx, j_wf)
         wfq = ops.gather_warped_feat(o3d1, flows_q, csr_q)
         o3d2 = self.conv3d_2(geom_q, wfq, idx_q)
         hq, wq = o3d2.shape[2:4]
         # 2-D branch (fwd_2d, reference :406-430)
-        x = ops.mask_weight_slots(wf, geom).view(N, h, w, tl * C)
+        x = ops.mask_weight_slots(wf, geom, j_wf).view(N, h, w, tl * C)
         mf = self._conv_gn(x, self.conv_mf, 2, 1, 0, NONE)
-        a = self._conv_gn(mf, self.conv1_1, 3, 1, 1, SELU)
+        a = self._conv_gn(mf, self.conv1_1, 3, 1, 1, SELU, j_mf)
         a = self._conv_gn(a, self.conv1_2, 3, 1, 1, SELU)
-        b = self._conv_gn(mf, self.conv2_1, 3, 2, 1, SELU)
+        b = self._conv_gn(mf, self.conv2_1, 3, 2, 1, SELU, j_mf)
         b = self._conv_gn(b, self.conv2_2, 3, 1, 1, SELU)
         b = ops.resize_nhwc(b, (2 * b.shape[1], 2 * b.shape[2]), True)
         c = ops.resize_nhwc(o3d2.view(N, hq, wq, C), (2 * hq, 2 * wq), True)
-        fuse_in = torch.cat((a, b, c), dim=3)  # memory op only
-        f, st = ops.conv2d(fuse_in, self.conv_fuse[1].weight, self.conv_fuse[1].bias, 1, 1, NONE, want_stats=True)
+        # conv over cat(a, b, c) as three accumulating 32->32 launches: the 96-channel tensor never exists
+        f, st = ops.conv2d_multi((a, b, c), self.conv_fuse[1].weight, self.conv_fuse[1].bias, 1, NONE, want_stats=True)
         out = ops.group_norm(f, self.conv_fuse[2].weight, self.conv_fuse[2].bias, stats=st,
-                             residual=feat.view(N, h, w, C), act=SELU)
+                             residual=feat.view(N, h, w, C), act=SELU, join=j_feat)
         return out.view(tl, bs, h, w, C)
 
 
@@ -230,7 +236,7 @@ class FuseNet(TimedModule):
         a = ops.conv2d(amb4, self.amb_conv[1].weight, self.amb_conv[1].bias, 1, 1, SELU, need_dgrad=False)[0]
         a = self.amb_res2(self.amb_res1(a))
         up = ops.resize_nhwc(feat, (H, W), True)
-        x = ops.conv2d(torch.cat([up, a], dim=3), self.ref_conv[1].weight, self.ref_conv[1].bias, 1, 1, SELU)[0]
+        x = ops.conv2d_multi((up, a), self.ref_conv[1].weight, self.ref_conv[1].bias, 1, SELU)[0]
         x = self.ref_res3(self.ref_res2(self.ref_res1(x)))
         x = ops.conv2d(x, self.final_conv[1].weight, self.final_conv[1].bias, 1, 1, SELU)[0]
         return ops.disp_head(x, self.predict_disp[0].weight, self.predict_disp[0].bias, float(self.max_disp), 3.0)

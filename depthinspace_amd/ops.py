@@ -8,6 +8,7 @@ import torch
 from . import lib
 
 ACT_NONE, ACT_SELU, ACT_RELU = 0, 1, 2
+CONV_ACCUM = 0x100
 PHOTO_TYPES = {'mse': 0, 'sad': 1, 'census_mse': 2, 'census_sad': 3}
 
 
@@ -39,6 +40,26 @@ def _zeros_d(n, dev):
 # (saves one temporary + one `grad += g` launch per parameter, ~236 per DIS-MF step); any further use in the same step
 # falls back to returning the gradient for autograd to accumulate.  FlatAdam.zero_grad() re-arms the flags.
 _GRAD_SINK = {}
+
+
+class GradJoin(object):
+    """Shared gradient buffer of a tensor that has exactly TWO consumers on the tape (a residual branch, the two heads of
+    a fork).  The consumer whose backward runs first stores its input gradient here and returns None to autograd; the
+    one that runs second accumulates into the stored buffer inside its own kernel (conv epilogue / atomic scatter /
+    row gather) and returns the buffer.  This replaces autograd's separate `g1 + g2` pass over the activation.
+    Create one per forward call; tensors may be views of different shape over the same contiguous memory."""
+
+    def __init__(self):
+        self.buf = None
+
+    def first(self, g):
+        """called by the first producer: keep g, return what autograd should see (nothing)"""
+        self.buf = g
+        return None
+
+    def take(self, shape):
+        b, self.buf = self.buf, None
+        return b.view(shape)
 
 
 def register_grad_sinks(params):
@@ -389,7 +410,7 @@ def _pack_w(weight, cin_pad, mode):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre=False):
+    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre=False, join=None):
         x, weight = _c(x), _c(weight)
         _chk(x, weight, bias)
         n, hin, win, cin_pad = x.shape
@@ -405,6 +426,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         ctx.cfg = (stride, pad, act, bias is not None, need_dgrad)
         ctx.bias_ref = bias  # only its address/shape are used (gradient sink lookup)
+        ctx.join = join
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -425,13 +447,18 @@ class _Conv2d(torch.autograd.Function):
         gx = None
         if need_dgrad and ctx.needs_input_grad[0]:
             assert cin_pad == cin
-            gx = torch.empty_like(x)
+            join = ctx.join
+            second = join is not None and join.buf is not None
+            gx = join.take(x.shape) if second else torch.empty_like(x)
             if stride == 1:
                 lib.call('dis_conv2d_fwd', gpre, _pack_w(weight, cin, 1), None, gx, None, n, gpre.shape[1],
-                         gpre.shape[2], cout, cin, k, 1, k - 1 - pad, ACT_NONE)
+                         gpre.shape[2], cout, cin, k, 1, k - 1 - pad, ACT_NONE | (CONV_ACCUM if second else 0))
             else:
                 ws = torch.empty(16 * cin * cout, dtype=torch.float32, device=x.device)
-                lib.call('dis_conv2d_dgrad_strided', gpre, weight, gx, ws, n, hin, win, cin, cout, k, stride, pad)
+                lib.call('dis_conv2d_dgrad_strided', gpre, weight, gx, ws, n, hin, win, cin, cout, k, stride, pad,
+                         1 if second else 0)
+            if join is not None and not second:
+                gx = join.first(gx)
         gw, gw_ret = _sink(weight)
         gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
         wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin_pad, cout, k, stride)
@@ -439,14 +466,94 @@ class _Conv2d(torch.autograd.Function):
             raise lib.DisHipError(f'conv2d wgrad: unsupported shape cin={cin_pad} cout={cout} k={k} s={stride}')
         ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
         lib.call('dis_conv2d_wgrad', x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
-        return gx, gw_ret, gb_ret, None, None, None, None, None, None
+        return gx, gw_ret, gb_ret, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, need_dgrad=True, gy_is_pre=False):
+def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, need_dgrad=True, gy_is_pre=False,
+           join=None):
     """x nhwc (n,h,w,cin_pad>=cin); weight OIHW.  Returns (y, stats|None).
     gy_is_pre: the only consumer of y is group_norm(..., in_act=act), whose backward already multiplies by act'(y);
-    the incoming gradient is then taken as the pre-activation gradient."""
-    return _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre)
+    the incoming gradient is then taken as the pre-activation gradient.
+    join: GradJoin shared with the other consumer of x (see GradJoin)."""
+    return _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre, join)
+
+
+class _Conv2dMulti(torch.autograd.Function):
+    """Conv2d (stride 1) over the channel concatenation of several nhwc tensors WITHOUT materialising the
+    concatenation: one launch per source with the matching slice of the weight, the later launches accumulate into
+    y (DIS_CONV_ACCUM); bias enters with the first launch, the activation and the GroupNorm statistics with the last.
+    The backward produces one input gradient per source directly (no split copies)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, pad, act, want_stats, gy_is_pre, *xs):
+        xs = [_c(x) for x in xs]
+        weight = _c(weight)
+        _chk(weight, bias, *xs)
+        cout, cin, k, _ = weight.shape
+        n, h, w, _ = xs[0].shape
+        cs = [x.shape[3] for x in xs]
+        assert sum(cs) == cin and all(tuple(x.shape[:3]) == (n, h, w) for x in xs)
+        ho, wo = h + 2 * pad - k + 1, w + 2 * pad - k + 1
+        y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=weight.device)
+        stats = _zeros_d(2 * n, weight.device) if want_stats else None
+        off = 0
+        for i, x in enumerate(xs):
+            last = i == len(xs) - 1
+            wi = weight[:, off:off + cs[i]].contiguous()
+            a = (act if last else ACT_NONE) | (CONV_ACCUM if i > 0 else 0)
+            lib.call('dis_conv2d_fwd', x, _pack_w(wi, cs[i], 0), bias if i == 0 else None, y, stats if last else None, n, h,
+                     w, cs[i], cout, k, 1, pad, a)
+            off += cs[i]
+        if gy_is_pre:
+            act = ACT_NONE
+        ctx.save_for_backward(weight, y if act != ACT_NONE else None, *xs)
+        ctx.cfg = (pad, act, bias is not None, cs)
+        ctx.bias_ref = bias
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, gy, _gstats):
+        weight, y = ctx.saved_tensors[:2]
+        xs = ctx.saved_tensors[2:]
+        pad, act, has_bias, cs = ctx.cfg
+        cout, cin, k, _ = weight.shape
+        n, h, w, _ = xs[0].shape
+        gy = _c(gy)
+        if act != ACT_NONE:
+            gpre = torch.empty_like(gy)
+            lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
+        else:
+            gpre = gy
+        gw, gw_ret = _sink(weight)
+        gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
+        gxs = []
+        off = 0
+        for i, x in enumerate(xs):
+            wi = weight[:, off:off + cs[i]].contiguous()
+            gx = None
+            if ctx.needs_input_grad[6 + i]:
+                gx = torch.empty_like(x)
+                lib.call('dis_conv2d_fwd', gpre, _pack_w(wi, cs[i], 1), None, gx, None, n, gpre.shape[1], gpre.shape[2],
+                         cout, cs[i], k, 1, k - 1 - pad, ACT_NONE)
+            gxs.append(gx)
+            gwi = torch.empty_like(wi)
+            wsz = lib.fn('dis_conv2d_wgrad_workspace')(cs[i], cout, k, 1)
+            if wsz < 0:
+                raise lib.DisHipError(f'conv2d_multi wgrad: unsupported shape cin={cs[i]} cout={cout} k={k}')
+            ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
+            lib.call('dis_conv2d_wgrad', x, gpre, gwi, gb if (i == 0 and has_bias) else None, ws, n, h, w, cs[i], cs[i],
+                     cout, k, 1, pad)
+            gw[:, off:off + cs[i]].copy_(gwi)  # small strided memory move into the (flat) weight-gradient slice
+            off += cs[i]
+        return (gw_ret, gb_ret, None, None, None, None) + tuple(gxs)
+
+
+def conv2d_multi(xs, weight, bias, pad=0, act=ACT_NONE, want_stats=False, gy_is_pre=False):
+    """conv2d(cat(xs, channel dim), weight) without the cat.  Returns (y, stats|None)."""
+    return _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, *xs)
 
 
 class _DispHead(torch.autograd.Function):
@@ -620,7 +727,7 @@ def disp_head_g(x, weight, bias, alpha, offset=3.0):
 # --------------------------------------------------------------------------------------------------
 class _GroupNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, stats, gamma, beta, residual, act, eps, in_act=ACT_NONE):
+    def forward(ctx, x, stats, gamma, beta, residual, act, eps, in_act=ACT_NONE, join=None):
         x = _c(x)
         residual = _c(residual) if residual is not None else None
         _chk(x, gamma, beta, residual)
@@ -635,6 +742,7 @@ class _GroupNorm(torch.autograd.Function):
         ctx.save_for_backward(x, stats, gamma, y if act != ACT_NONE else None)
         ctx.cfg = (n, hw, c, act, float(eps), residual is not None, in_act)
         ctx.beta_ref = beta
+        ctx.join = join
         return y
 
     @staticmethod
@@ -651,14 +759,19 @@ class _GroupNorm(torch.autograd.Function):
         nred2 = wtot // (2 + 2 * c) * 2
         red, pacc = ws[:nred2], ws[nred2:]
         lib.call('dis_gn_apply_bwd', gy, y, x, stats, gamma, gx, gres, gg, gb, red, pacc, n, hw, c, act, eps, in_act)
-        return gx, None, gg_ret, gb_ret, gres, None, None, None
+        if gres is not None and ctx.join is not None:
+            if ctx.join.buf is None:
+                gres = ctx.join.first(gres)
+            else:  # the other consumer ran first (not the case in the networks here): plain accumulation
+                gres = ctx.join.take(gres.shape).add_(gres)
+        return gx, None, gg_ret, gb_ret, gres, None, None, None, None
 
 
-def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5, in_act=ACT_NONE):
+def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5, in_act=ACT_NONE, join=None):
     """GroupNorm(1 group) over all but the first dim of an nhwc tensor; y = act(gn(x) (+ residual)).
     in_act: x is the output of that activation (conv2d(..., act, gy_is_pre=True)); the backward then returns the
     gradient wrt the producer's pre-activation output."""
-    return _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act)
+    return _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act, join)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -666,7 +779,7 @@ def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5
 # --------------------------------------------------------------------------------------------------
 class _GatherWarpedFeat(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, flows, csr):
+    def forward(ctx, feat, flows, csr, join):
         feat, flows = _c(feat), _c(flows)
         _chk(feat, flows)
         tl, bs, h, w, c = feat.shape
@@ -675,18 +788,27 @@ class _GatherWarpedFeat(torch.autograd.Function):
         lib.call('dis_gather_warped_feat_fwd', feat, flows, out, tl, bs, h, w, c)
         ctx.save_for_backward(flows, csr)
         ctx.shape = feat.shape
+        ctx.join = join
         return out
 
     @staticmethod
     def backward(ctx, g):
         flows, csr = ctx.saved_tensors
         tl, bs, h, w, c = ctx.shape
-        gf = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        join = ctx.join
+        second = join is not None and join.buf is not None
         if csr is not None:
-            lib.call('dis_gather_warped_feat_bwd_csr', _c(g), csr, gf, tl, bs, h, w, c)
+            init = join.take(ctx.shape) if second else None
+            gf = init if second else torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+            lib.call('dis_gather_warped_feat_bwd_csr', _c(g), csr, init, gf, tl, bs, h, w, c)
         else:
+            gf = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
             lib.call('dis_gather_warped_feat_bwd', _c(g), flows, gf, tl, bs, h, w, c)
-        return gf, None, None
+            if second:
+                gf.add_(join.take(ctx.shape))
+        if join is not None and not second:
+            gf = join.first(gf)
+        return gf, None, None, None
 
 
 def gather_csr(flows):
@@ -704,8 +826,8 @@ def gather_csr(flows):
     return csr
 
 
-def gather_warped_feat(feat, flows, csr=None):
-    return _GatherWarpedFeat.apply(feat, flows, csr)
+def gather_warped_feat(feat, flows, csr=None, join=None):
+    return _GatherWarpedFeat.apply(feat, flows, csr, join)
 
 
 def mf_geometry(depth_core, R, t, flows_core, Kinv, u_step, v_step):
@@ -726,12 +848,13 @@ def mf_geometry_resize(geom, size):
 
 class _MaskWeightSlots(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, wf, geom):
+    def forward(ctx, wf, geom, join):
         wf, geom = _c(wf), _c(geom)
         tl, bs, h, w, s, c = wf.shape
         out = torch.empty_like(wf)
-        lib.call('dis_mask_weight_slots', wf, geom, out, tl * bs * h * w, s, c)
+        lib.call('dis_mask_weight_slots', wf, geom, out, tl * bs * h * w, s, c, 0)
         ctx.save_for_backward(geom)
+        ctx.join = join
         return out
 
     @staticmethod
@@ -739,13 +862,17 @@ class _MaskWeightSlots(torch.autograd.Function):
         (geom,) = ctx.saved_tensors
         g = _c(g)
         tl, bs, h, w, s, c = g.shape
-        out = torch.empty_like(g)
-        lib.call('dis_mask_weight_slots', g, geom, out, tl * bs * h * w, s, c)
-        return out, None
+        join = ctx.join
+        second = join is not None and join.buf is not None
+        out = join.take(g.shape) if second else torch.empty_like(g)
+        lib.call('dis_mask_weight_slots', g, geom, out, tl * bs * h * w, s, c, 1 if second else 0)
+        if join is not None and not second:
+            out = join.first(out)
+        return out, None, None
 
 
-def mask_weight_slots(wf, geom):
-    return _MaskWeightSlots.apply(wf, geom)
+def mask_weight_slots(wf, geom, join=None):
+    return _MaskWeightSlots.apply(wf, geom, join)
 
 
 def conv3d_select(geom, stride):
@@ -762,7 +889,7 @@ def conv3d_select(geom, stride):
 
 class _Conv3dKnn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, geom, wf, d1w, d1b, d2w, d2b, w, idx, stride):
+    def forward(ctx, geom, wf, d1w, d1b, d2w, d2b, w, idx, stride, join=None):
         geom, wf = _c(geom), _c(wf)
         d1w, d1b, d2w, d2b, w = [_c(p) for p in (d1w, d1b, d2w, d2b, w)]
         _chk(geom, wf, d1w, d1b, d2w, d2b, w)
@@ -775,24 +902,29 @@ class _Conv3dKnn(torch.autograd.Function):
         lib.call('dis_conv3d_knn_fwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, tl, bs, h, wd, stride)
         ctx.save_for_backward(geom, wf, d1w, d1b, d2w, d2b, w, idx, y)
         ctx.stride = stride
+        ctx.join = join
         return y
 
     @staticmethod
     def backward(ctx, gy):
         geom, wf, d1w, d1b, d2w, d2b, w, idx, y = ctx.saved_tensors
         tl, bs, h, wd, s, c = wf.shape
-        gwf = torch.zeros_like(wf)
+        join = ctx.join
+        second = join is not None and join.buf is not None
+        gwf = join.take(wf.shape) if second else torch.zeros_like(wf)  # the scatter accumulates (float atomics)
         gp = torch.empty(1632, dtype=torch.float32, device=wf.device)
         acc = torch.empty(lib.fn('dis_conv3d_knn_bwd_workspace')(), dtype=torch.float32, device=wf.device)
         lib.call('dis_conv3d_knn_bwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, _c(gy), gwf, gp, acc, tl, bs, h, wd,
                  ctx.stride)
+        if join is not None and not second:
+            gwf = join.first(gwf)
         return (None, gwf, gp[0:48].view(16, 3), gp[48:64], gp[64:576].view(32, 16), gp[576:608],
-                gp[608:1632].view(32, 32), None, None)
+                gp[608:1632].view(32, 32), None, None, None)
 
 
-def conv3d_knn(geom, wf, d1w, d1b, d2w, d2b, w, idx, stride):
+def conv3d_knn(geom, wf, d1w, d1b, d2w, d2b, w, idx, stride, join=None):
     """y (tl,bs,ho,wo,32) = SELU(agg @ w) for the neighbour sets `idx` (from conv3d_select)."""
-    return _Conv3dKnn.apply(geom, wf, d1w, d1b, d2w, d2b, w, idx, stride)
+    return _Conv3dKnn.apply(geom, wf, d1w, d1b, d2w, d2b, w, idx, stride, join)
 
 
 # --------------------------------------------------------------------------------------------------

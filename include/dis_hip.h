@@ -37,6 +37,9 @@ extern "C" {
 #define DIS_ACT_NONE 0
 #define DIS_ACT_SELU 1
 #define DIS_ACT_RELU 2
+/* OR-ed into the `act` argument of dis_conv2d_fwd: y = act(y_previous + conv(x) + bias) (sum of convolutions over
+ * several input tensors = a convolution over their channel concatenation; accumulation of input gradients). */
+#define DIS_CONV_ACCUM 0x100
 
 /* ABI version of this header; bumped on any signature change. */
 int dis_abi_version(void);
@@ -149,11 +152,12 @@ int dis_gather_warped_feat_bwd(const float* grad_out, const float* flows, float*
 /* Deterministic, atomic-free form of the same backward.  dis_gather_csr_build turns `flows` into a CSR index by
  * destination pixel (lists sorted by source row) once per step and resolution: csr = dis_gather_csr_workspace(...)
  * int32 words; every dis_gather_warped_feat_bwd_csr call with the same flows then gathers whole rows of grad_out with
- * plain loads (grad_feat OVERWRITTEN, bitwise reproducible). */
+ * plain loads (grad_feat OVERWRITTEN, bitwise reproducible).  `init` (optional, may alias grad_feat) is a second
+ * gradient of `feat` (e.g. its residual branch) that is added in the same pass. */
 long dis_gather_csr_workspace(int tl, int bs, int h, int w);
 int dis_gather_csr_build(const float* flows, int* csr, int tl, int bs, int h, int w, void* stream);
-int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* csr, float* grad_feat, int tl, int bs, int h,
-                                   int w, int c, void* stream);
+int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* csr, const float* init, float* grad_feat, int tl,
+                                   int bs, int h, int w, int c, void* stream);
 
 /* unproject + change_view_angle + gather_warped_xyz + forward/backward flow mask for every target,
  * reference multi_frame_networks.py:172-214,283-294.  No gradient.
@@ -197,9 +201,9 @@ int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad
                      void* stream);
 /* Input gradient of a k=4, stride=2, pad=1 convolution (transposed convolution) as four 2x2 phase convolutions on
  * the matrix cores.  w_oihw is the unpacked weight (cout,cin,4,4).  workspace: 16*cin*cout floats.
- * gx: (n,hin,win,cin) overwritten. */
+ * gx: (n,hin,win,cin) overwritten, or added to when `accumulate` != 0. */
 int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, float* gx, float* workspace, int n, int hin,
-                             int win, int cin, int cout, int k, int stride, int pad, void* stream);
+                             int win, int cin, int cout, int k, int stride, int pad, int accumulate, void* stream);
 
 /* Head: Conv2d(cin,1,3,pad 1) + alpha*sigmoid(x - offset) (reference networks.py:121-125,140-149;
  * multi_frame_networks.py:157,265).  x nhwc (n,h,w,cin); w (1,cin,3,3); y planar (n,1,h,w). */
@@ -239,8 +243,9 @@ int dis_add_act_fwd(const float* a, const float* b, float* y, int act, long coun
 
 /* Scale the tl slots of a gathered feature tensor by mask/mean(mask) (reference multi_frame_networks.py:410):
  * wf (tl,bs,h,w,tl,c); geom (tl,bs,h,w,tl,4) (mask in .w); out same shape as wf.  Backward is the same call on
- * the gradient. */
-int dis_mask_weight_slots(const float* wf, const float* geom, float* out, long pixels, int tl, int c, void* stream);
+ * the gradient; accumulate != 0 adds the result to `out` instead of overwriting it. */
+int dis_mask_weight_slots(const float* wf, const float* geom, float* out, long pixels, int tl, int c, int accumulate,
+                          void* stream);
 
 /* ---------------------------------------------------------------- Conv3D (k-NN continuous conv) */
 
