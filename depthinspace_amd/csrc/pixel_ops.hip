@@ -203,16 +203,14 @@ __global__ __launch_bounds__(PH_TX* PH_TY) void photometric_bwd_kernel(const flo
             float d = ek - tk;
             acc += mult * g * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
           } else {
-            // as neighbour of centre p: des = e_k - e_p, dta = t_k - t_p
+            // (a) as neighbour of centre p: des = e_k - e_p, dta = t_k - t_p
+            // (b) as centre of its own window with neighbour q = clamp(k + off): des' = e_q - e_k = -des, dta' = -dta.
+            //     h(-d) = 1 - h(d) and h' is even, so diff' = -diff and term (b) = +g_k * s * h'(des): both roles share
+            //     one evaluation of the two soft signs (half the sqrt/div work of evaluating them separately).
             float des = ek - e, dta = tk - t;
             float diff = census_h(des, eps) - census_h(dta, eps);
             float s = (TYPE == 2) ? 2.f * diff : (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
-            acc += mult * g * s * census_dh(des, eps);
-            // (b) as centre of its own window with neighbour q = clamp(k + off): des = e_q - e_k
-            float des2 = e - ek, dta2 = t - tk;
-            float diff2 = census_h(des2, eps) - census_h(dta2, eps);
-            float s2 = (TYPE == 2) ? 2.f * diff2 : (diff2 > 0.f ? 1.f : (diff2 < 0.f ? -1.f : 0.f));
-            acc -= gk * s2 * census_dh(des2, eps);
+            acc += (mult * g + gk) * (s * census_dh(des, eps));
           }
         }
       }
