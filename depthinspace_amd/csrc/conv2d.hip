@@ -48,7 +48,7 @@ struct ConvCfg {
   static constexpr int E = (KG >= 4) ? 4 : KG;        // floats per fragment read
   static constexpr int NQ = KG / E;                   // fragment reads per tap
   static constexpr int NT = COUT / 16;
-  static constexpr int MT = (S == 1) ? 2 : 1;
+  static constexpr int MT = 1;  // one 16-pixel row per wave: 4x16 tiles keep the halo tile small enough for 3+ workgroups per CU
   static constexpr int TROWS = 4 * MT;
   static constexpr int TCOLS = 16;
   static constexpr int IN_ROWS = (TROWS - 1) * S + KH;

@@ -20,6 +20,7 @@
 //     tile (one tap) x TX x-channels x TG g-channels per workgroup, k = 32 pixels per step, split-K over
 //     pixel ranges into partial slabs that a second kernel sums in a fixed order (deterministic).
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -66,25 +67,30 @@ __global__ __launch_bounds__(256) void convg_fwd_kernel(GenArgs a) {
     piy[j] = vy * a.S;
     pix[j] = vx * a.S;
   }
+  // Loads are unconditional (clamped to a valid address) and zeroed when written to LDS: a load under a branch makes
+  // hipcc wait for it right at the issue point (see conv2d.hip).
   float4 ra[2], rb = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool rok[2] = {false, false};
+  const int wtid = (tid < BN * 4) ? tid : 0;
   auto prefetch = [&](int tap, int chunk) {
     const int dy = a.tdy[tap], dx = a.tdx[tap];
     const int c = chunk * CG_CK + pq * 4;
+    const int cc = min(c, a.cin - 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int iy = piy[j] + dy, ix = pix[j] + dx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pval[j] && c < a.cin && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
-        v = *(const float4*)(a.x + (pbase[j] + (long)iy * a.win + ix) * a.ldx + a.xoff + c);
-      ra[j] = v;
+      rok[j] = pval[j] && c < a.cin && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+      const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
+      ra[j] = *(const float4*)(a.x + (pbase[j] + (long)cy * a.win + cx) * a.ldx + a.xoff + cc);
     }
-    if (tid < BN * 4) rb = ((const float4*)a.w)[((long)(tap * a.nchunk + chunk) * a.nblk + nb) * (BN * 4) + tid];
+    rb = ((const float4*)a.w)[((long)(tap * a.nchunk + chunk) * a.nblk + nb) * (BN * 4) + wtid];
   };
   auto stage = [&](int buf) {
     float* A = smem + buf * (A_FL + B_FL);
     float* B = A + A_FL;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) *(float4*)(A + (p0 + j * 64) * CG_AS + pq * 4) = ra[j];
+    for (int j = 0; j < 2; ++j)
+      *(float4*)(A + (p0 + j * 64) * CG_AS + pq * 4) = rok[j] ? ra[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < BN * 4) ((float4*)B)[tid] = rb;
   };
 
@@ -127,25 +133,35 @@ __global__ __launch_bounds__(256) void convg_fwd_kernel(GenArgs a) {
     chunk = nch;
   }
 
-  // epilogue: bias + activation, masked store of the real output channels
+  // epilogue: bias + activation (dispatched once, not per element), masked store of the real output channels
+  float bias_v[NT];
+  bool cok[NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = nb * BN + nt * 16 + li;
+    cok[nt] = co < a.cout;
+    bias_v[nt] = (a.bias && cok[nt]) ? a.bias[co] : 0.f;
+  }
+  auto emit = [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wave * 32 + mt * 16 + lg * 4 + r;
-      if (m >= M) continue;
-      const int vx = m % a.wv, t = m / a.wv, vy = t % a.hv, nn = t / a.hv;
-      float* yp = a.y + (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff;
+    for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int co = nb * BN + nt * 16 + li;
-        if (co < a.cout) {
-          const float bval = a.bias ? a.bias[co] : 0.f;
-          yp[co] = act_apply(acc[mt][nt][r] + bval, a.act);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wave * 32 + mt * 16 + lg * 4 + r;
+        if (m >= M) continue;
+        const int vx = m % a.wv, t = m / a.wv, vy = t % a.hv, nn = t / a.hv;
+        float* yp = a.y + (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff +
+                    nb * BN + li;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if (cok[nt]) yp[nt * 16] = act_apply(acc[mt][nt][r] + bias_v[nt], ACT);
       }
     }
-  }
+  };
+  if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{});
+  else if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{});
+  else emit(std::integral_constant<int, DIS_ACT_NONE>{});
 }
 
 // packed[tap][chunk][nb][lg][col][e] = W(tap, ci = chunk*16 + lg*4 + e, co = nb*BN + col)
