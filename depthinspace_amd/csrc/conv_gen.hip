@@ -520,7 +520,7 @@ extern "C" int dis_convg_wgrad(const float* X, int ldX, int xoff, int hX, int wX
 // ------------------------------------------------------------------------------------------------
 // column sums (bias gradients): out[c] = sum_pixels G[pixel][goff + c], deterministic two-level sum
 // ------------------------------------------------------------------------------------------------
-#define CS_BLOCKS 256
+#define CS_BLOCKS 2048
 __global__ __launch_bounds__(256) void colsum1_kernel(const float* __restrict__ G, int ldG, int goff, long npix, int c,
                                                        float* __restrict__ part) {
   __shared__ float red[256];
@@ -529,11 +529,20 @@ __global__ __launch_bounds__(256) void colsum1_kernel(const float* __restrict__ 
     const int cw = min(256, c - c0);          // channels handled in this pass
     const int rows = 256 / cw > 0 ? 256 / cw : 1;
     const int ch = threadIdx.x % cw, row = threadIdx.x / cw;
-    float s = 0.f;
-    if (row < rows)
-      for (long p = lo + row; p < hi; p += rows) s += G[p * ldG + goff + c0 + ch];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // 4 independent loads in flight
+    if (row < rows) {
+      const float* gp = G + goff + c0 + ch;
+      long p = lo + row;
+      for (; p + 3L * rows < hi; p += 4L * rows) {
+        s0 += gp[p * ldG];
+        s1 += gp[(p + rows) * ldG];
+        s2 += gp[(p + 2L * rows) * ldG];
+        s3 += gp[(p + 3L * rows) * ldG];
+      }
+      for (; p < hi; p += rows) s0 += gp[p * ldG];
+    }
     __syncthreads();
-    red[threadIdx.x] = s;
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (threadIdx.x < cw) {
       float t = 0.f;
@@ -542,12 +551,15 @@ __global__ __launch_bounds__(256) void colsum1_kernel(const float* __restrict__ 
     }
   }
 }
-__global__ void colsum2_kernel(const float* __restrict__ part, int nblocks, int c, float* __restrict__ out) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per channel: lanes stride over the block partials, fixed-order wave reduction
+__global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ part, int nblocks, int c,
+                                                       float* __restrict__ out) {
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (ch >= c) return;
   float s = 0.f;
-  for (int k = 0; k < nblocks; ++k) s += part[(long)k * c + ch];
-  out[ch] = s;
+  for (int k = lane; k < nblocks; k += 64) s += part[(long)k * c + ch];
+  s = wave_sum(s);
+  if (lane == 0) out[ch] = s;
 }
 
 extern "C" long dis_colsum_workspace(int c) { return c > 0 ? (long)CS_BLOCKS * c : -1; }
@@ -557,10 +569,10 @@ extern "C" int dis_colsum(const float* G, int ldG, int goff, long npix, int c, f
   if (!G || !out || !workspace) return DIS_ERR_NULL;
   if (npix <= 0 || c <= 0 || goff < 0 || goff + c > ldG) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  int nb = CS_BLOCKS;
-  if (nb > npix) nb = (int)npix;
+  long want = npix / 64;  // >= 64 pixels per block
+  int nb = (int)(want < 1 ? 1 : (want > CS_BLOCKS ? CS_BLOCKS : want));
   hipLaunchKernelGGL(colsum1_kernel, dim3(nb), dim3(256), 0, s, G, ldG, goff, npix, c, workspace);
-  hipLaunchKernelGGL(colsum2_kernel, dim3(dis_cdiv(c, 256)), dim3(256), 0, s, (const float*)workspace, nb, c, out);
+  hipLaunchKernelGGL(colsum2_kernel, dim3(dis_cdiv(c, 4)), dim3(256), 0, s, (const float*)workspace, nb, c, out);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
