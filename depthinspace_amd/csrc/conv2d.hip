@@ -447,6 +447,291 @@ extern "C" int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32 convolution on the bf16 matrix cores ("bf16x3"): every fp32 operand is split into three bf16 terms
+// x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 significant bits in all), and a
+// product a*b is accumulated as the six terms a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 in the fp32 accumulator of
+// v_mfma_f32_16x16x32_bf16 (each bf16 x bf16 product is exact in fp32; the dropped terms are <= 2^-24 relative, the
+// size of one fp32 rounding).  Six bf16 MFMAs of K=32 replace eight fp32 MFMAs of K=4 at 1/16 of their cost each.
+// Specialised for the dominant FuseNet shape: 32 -> 32 channels, 3x3, stride 1 (also its input gradient).
+//   workgroup = 8 waves = 16x16 output pixels, wave = 2 rows x all 32 couts; weights (3 planes) resident in LDS,
+//   the halo tile is split into its 3 bf16 planes when it is written to LDS.
+// ------------------------------------------------------------------------------------------------
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned f2bf_bits(float x) {
+  unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf_bits2f(unsigned h) { return __uint_as_float(h << 16); }
+// x -> 3 bf16 planes (bits)
+__device__ __forceinline__ void split3(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
+  h1 = f2bf_bits(x);
+  const float r1 = x - bf_bits2f(h1);
+  h2 = f2bf_bits(r1);
+  const float r2 = r1 - bf_bits2f(h2);
+  h3 = f2bf_bits(r2);
+}
+
+#define BX_PS 104  // LDS pixel stride in 16-bit units: 3 planes x 32 channels + 8 pad (208 B: conflict-free b128 rows)
+#define BX_TR 16
+#define BX_TC 16
+#define BX_IR 18
+#define BX_IC 18
+#define BX_W_U16 (9 * 3 * 4 * 32 * 8)
+#define BX_X_U16 (BX_IR * BX_IC * BX_PS)
+#define BX_LDS_BYTES (BX_W_U16 * 2 + BX_X_U16 * 2 + 64)
+#define BX_NITEMS (BX_IR * BX_IC * 8)
+#define BX_NLOAD ((BX_NITEMS + 511) / 512)
+
+// packed[tap][plane][lg][co][j] (16-bit) = plane of W(tap, ci = 8*lg + j, co);  modes as pack_weights_kernel (0 fwd, 1 dgrad)
+__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int mode) {
+  const int total = 9 * 32 * 32;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i % 32, c = (i / 32) % 32, tap = i / 1024;
+    const int ky = tap / 3, kx = tap % 3;
+    const float v = (mode == 0) ? w[((co * 32 + c) * 3 + ky) * 3 + kx] : w[((c * 32 + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
+    unsigned h1, h2, h3;
+    split3(v, h1, h2, h3);
+    const int lg = c >> 3, j = c & 7;
+    const int base = ((tap * 3 * 4 + lg) * 32 + co) * 8 + j;
+    packed[base] = (unsigned short)h1;
+    packed[base + 4 * 32 * 8] = (unsigned short)h2;
+    packed[base + 2 * 4 * 32 * 8] = (unsigned short)h3;
+  }
+}
+
+__global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  unsigned short* wl = smem16;
+  unsigned short* xl = smem16 + BX_W_U16;
+  double* red = (double*)(smem16 + BX_W_U16 + BX_X_U16);
+  for (int i = threadIdx.x; i < BX_W_U16 / 8; i += 512) ((uint4*)wl)[i] = ((const uint4*)a.w)[i];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int tiles_x = (a.wv + BX_TC - 1) / BX_TC, tiles_y = (a.hv + BX_TR - 1) / BX_TR;
+  const int ntiles = a.n * tiles_y * tiles_x;
+  const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
+  const int xcd = blockIdx.x % nxcd, rank = blockIdx.x / nxcd, per = gridDim.x / nxcd;
+  const int t_lo = (int)((long)ntiles * xcd / nxcd), t_hi = (int)((long)ntiles * (xcd + 1) / nxcd);
+
+  float4 pre[BX_NLOAD];
+  unsigned okmask = 0;
+  int it_r[BX_NLOAD], it_c[BX_NLOAD], it_off[BX_NLOAD], it_lds[BX_NLOAD], it_vv[BX_NLOAD];
+#pragma unroll
+  for (int it = 0; it < BX_NLOAD; ++it) {
+    const int idx = min((int)threadIdx.x + it * 512, BX_NITEMS - 1);
+    const int vv = idx & 7, pix = idx >> 3;
+    it_c[it] = pix % BX_IC;
+    it_r[it] = pix / BX_IC;
+    it_vv[it] = vv;
+    it_off[it] = (it_r[it] * a.win + it_c[it]) * 32 + vv * 4;
+    it_lds[it] = pix * BX_PS + vv * 4;
+  }
+  auto prefetch = [&](int tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int iy0 = ty * BX_TR - a.pad_y, ix0 = tx * BX_TC - a.pad_x;
+    const float* xb = a.x + (long)n * a.hin * a.win * 32;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + BX_IR <= a.hin && ix0 + BX_IC <= a.win;
+    if (interior) {
+      const float* xo = xb + ((long)iy0 * a.win + ix0) * 32;
+      okmask = 0xffffffffu;
+#pragma unroll
+      for (int it = 0; it < BX_NLOAD; ++it) pre[it] = *(const float4*)(xo + it_off[it]);
+    } else {
+      okmask = 0;
+#pragma unroll
+      for (int it = 0; it < BX_NLOAD; ++it) {
+        const int iy = iy0 + it_r[it], ix = ix0 + it_c[it];
+        const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+        const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
+        pre[it] = *(const float4*)(xb + ((long)cy * a.win + cx) * 32 + it_vv[it] * 4);
+        okmask |= (ok ? 1u : 0u) << it;
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < BX_NLOAD; ++it) {
+      if ((int)threadIdx.x + it * 512 < BX_NITEMS) {
+        const bool ok = (okmask >> it) & 1u;
+        const float4 v = ok ? pre[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned a1, a2, a3, b1, b2, b3, c1, c2, c3, d1, d2, d3;
+        split3(v.x, a1, a2, a3);
+        split3(v.y, b1, b2, b3);
+        split3(v.z, c1, c2, c3);
+        split3(v.w, d1, d2, d3);
+        unsigned short* p = xl + it_lds[it];
+        *(uint2*)(p) = make_uint2(a1 | (b1 << 16), c1 | (d1 << 16));
+        *(uint2*)(p + 32) = make_uint2(a2 | (b2 << 16), c2 | (d2 << 16));
+        *(uint2*)(p + 64) = make_uint2(a3 | (b3 << 16), c3 | (d3 << 16));
+      }
+    }
+  };
+
+  int tile = t_lo + rank;
+  if (tile < t_hi) prefetch(tile);
+  f32x4 acc[2][2];
+  double s1 = 0.0, s2 = 0.0;
+  int stat_n = -1;
+  float bias_v[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) bias_v[nt] = a.bias ? a.bias[nt * 16 + li] : 0.f;
+  const long ypix = (long)a.osx * 32;
+
+  while (tile < t_hi) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (tile + per < t_hi) prefetch(tile + per);
+
+    s16x8 fa[2][3][2], fb[2][3][2];  // [buffer][plane][mt|nt]
+    auto load_frag = [&](int tap, s16x8 (&A)[3][2], s16x8 (&B)[3][2]) {
+      const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          A[p][mt] = *(const s16x8*)(xl + ((wave * 2 + mt + ky) * BX_IC + li + kx) * BX_PS + p * 32 + lg * 8);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) B[p][nt] = *(const s16x8*)(wl + (((tap * 3 + p) * 4 + lg) * 32 + nt * 16 + li) * 8);
+      }
+    };
+    load_frag(0, fa[0], fb[0]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) load_frag(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int b = tap & 1;
+      // smallest terms first
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+      constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[b][PA[q]][mt]),
+                                                                 __builtin_bit_cast(bf16x8, fb[b][PB[q]][nt]),
+                                                                 acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // epilogue (as conv_fwd_kernel)
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    if (a.stats && n != stat_n) {
+      if (stat_n >= 0) {
+        const double r1 = block_sum_d(s1, red);
+        const double r2 = block_sum_d(s2, red);
+        if (threadIdx.x == 0) {
+          atomic_add_d(a.stats + 2 * stat_n, r1);
+          atomic_add_d(a.stats + 2 * stat_n + 1, r2);
+        }
+      }
+      stat_n = n;
+      s1 = 0.0;
+      s2 = 0.0;
+    }
+    float t1 = 0.f, t2 = 0.f;
+    const int vy0 = ty * BX_TR + wave * 2, vx0 = tx * BX_TC + lg * 4;
+    float* ybase = a.y + (((long)n * a.hf + ((long)vy0 * a.osy + a.ooy)) * a.wf + ((long)vx0 * a.osx + a.oox)) * 32 + li;
+    const long yrow = (long)a.osy * a.wf * 32;
+    const bool full = (ty + 1) * BX_TR <= a.hv && (tx + 1) * BX_TC <= a.wv;
+    auto emit = [&](auto actc, auto accc) {
+      constexpr int ACT = decltype(actc)::value;
+      constexpr bool ACC = decltype(accc)::value != 0;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (full || (vy0 + mt < a.hv && vx0 + r < a.wv)) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              float* yp = ybase + mt * yrow + r * ypix + nt * 16;
+              float pre_v = acc[mt][nt][r] + bias_v[nt];
+              if (ACC) pre_v += *yp;
+              const float v = act_apply(pre_v, ACT);
+              *yp = v;
+              t1 += v;
+              t2 += v * v;
+            }
+          }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (a.accum) {
+      if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{}, I1{});
+      else if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{}, I1{});
+      else emit(std::integral_constant<int, DIS_ACT_NONE>{}, I1{});
+    } else {
+      if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{}, I0{});
+      else if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{}, I0{});
+      else emit(std::integral_constant<int, DIS_ACT_NONE>{}, I0{});
+    }
+    s1 += (double)t1;
+    s2 += (double)t2;
+    tile += per;
+  }
+  if (a.stats && stat_n >= 0) {
+    const double r1 = block_sum_d(s1, red);
+    const double r2 = block_sum_d(s2, red);
+    if (threadIdx.x == 0) {
+      atomic_add_d(a.stats + 2 * stat_n, r1);
+      atomic_add_d(a.stats + 2 * stat_n + 1, r2);
+    }
+  }
+}
+
+extern "C" int dis_conv2d_pack_weights_bf16x3(const float* w_oihw, void* packed, int cout, int cin, int k, int mode,
+                                              void* stream) {
+  if (!w_oihw || !packed) return DIS_ERR_NULL;
+  if (cout != 32 || cin != 32 || k != 3 || mode < 0 || mode > 1) return DIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(36), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     (unsigned short*)packed, mode);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+extern "C" int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y, double* stats,
+                                     int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act,
+                                     void* stream) {
+  if (!x || !w_packed || !y) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0 || pad < 0) return DIS_ERR_BAD_SHAPE;
+  if (cin != 32 || cout != 32 || k != 3 || stride != 1) return DIS_ERR_UNSUPPORTED;
+  const int hout = hin + 2 * pad - 2, wout = win + 2 * pad - 2;
+  if (hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
+  ConvArgs a;
+  a.x = x; a.w = (const float*)w_packed; a.bias = bias; a.y = y; a.stats = stats;
+  a.n = n; a.hin = hin; a.win = win; a.hv = hout; a.wv = wout; a.pad_y = pad; a.pad_x = pad;
+  a.hf = hout; a.wf = wout; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
+  a.act = act & 0xff;
+  a.accum = (act & DIS_CONV_ACCUM) ? 1 : 0;
+  if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       BX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int tiles_x = (wout + BX_TC - 1) / BX_TC, tiles_y = (hout + BX_TR - 1) / BX_TR;
+  const long ntiles = (long)n * tiles_y * tiles_x;
+  long grid = num_cus();
+  if (grid > ntiles) grid = ntiles;
+  if (grid >= 8) grid -= grid % 8;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(conv_bf16x3_kernel, dim3((unsigned)grid), dim3(512), BX_LDS_BYTES, (hipStream_t)stream, a);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient:  dW[(tap,ci)][co] = sum_pixels X[pixel+tap][ci] * G[pixel][co]
 // GEMM view: M = (tap,ci) rows, N = cout, K = pixels.  Each wave owns a disjoint pixel subset of the
 // tile and keeps the whole (M x N) accumulator of one cin-chunk (and one ky row when split) in registers

@@ -47,6 +47,8 @@ SIGS = {
     'dis_mf_geometry_resize': 'ppiiiiiip',
     'dis_conv2d_pack_weights': 'ppiiiiip',
     'dis_conv2d_fwd': 'pppppiiiiiiiiip',
+    'dis_conv2d_pack_weights_bf16x3': 'ppiiiip',
+    'dis_conv2d_fwd_bf16x3': 'pppppiiiiiiiiip',
     'dis_conv2d_wgrad_workspace': 'iiii',
     'dis_conv2d_wgrad': 'pppppiiiiiiiiip',
     'dis_conv2d_dgrad_strided': 'ppppiiiiiiiiip',

@@ -28,7 +28,30 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Zeroed fp64 accumulators (GroupNorm statistics, loss sums) come from one arena per device that is cleared ONCE per
+# step (begin_step, called by FlatAdam.zero_grad) instead of one tiny fill kernel per accumulator (~100 per step).
+# A slice is handed out at most once between two clears; without begin_step (tests, inference) the arena simply runs
+# out and plain torch.zeros takes over.
+_ARENA = {}
+_ARENA_DOUBLES = 1 << 16
+
+
+def begin_step(dev):
+    dev = torch.device(dev)
+    a = _ARENA.get(dev)
+    if a is None:
+        a = _ARENA[dev] = [torch.zeros(_ARENA_DOUBLES, dtype=torch.float64, device=dev), 0]
+    else:
+        a[0].zero_()
+    a[1] = 0
+
+
 def _zeros_d(n, dev):
+    a = _ARENA.get(dev)
+    if a is not None and a[1] + n <= _ARENA_DOUBLES:
+        v = a[0][a[1]:a[1] + n]
+        a[1] += (n + 1) // 2 * 2
+        return v
     return torch.zeros(n, dtype=torch.float64, device=dev)
 
 
@@ -408,6 +431,22 @@ def _pack_w(weight, cin_pad, mode):
     return packed
 
 
+import os as _os
+BF16X3 = _os.environ.get('DIS_CONV_BF16X3', '1') != '0'
+
+
+def _conv_fwd_any(x, weight, cin_pad, mode, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act):
+    """dis_conv2d_fwd, or its bf16x3 form (fp32 accuracy on the bf16 matrix cores) for the 32->32 3x3 stride-1 shape.
+    `weight` is the unpacked OIHW tensor, `mode` the packing mode (0 forward, 1 stride-1 input gradient)."""
+    if BF16X3 and cin == 32 and cout == 32 and k == 3 and stride == 1 and tuple(weight.shape) == (32, 32, 3, 3):
+        packed = torch.empty(9 * 3 * 4 * 32 * 8, dtype=torch.int16, device=weight.device)
+        lib.call('dis_conv2d_pack_weights_bf16x3', weight, packed, 32, 32, 3, mode)
+        lib.call('dis_conv2d_fwd_bf16x3', x, packed, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act)
+    else:
+        lib.call('dis_conv2d_fwd', x, _pack_w(weight, cin_pad, mode), bias, y, stats, n, hin, win, cin, cout, k, stride,
+                 pad, act)
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre=False, join=None):
@@ -419,8 +458,7 @@ class _Conv2d(torch.autograd.Function):
         wo = (win + 2 * pad - k) // stride + 1
         y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
         stats = _zeros_d(2 * n, x.device) if want_stats else None
-        lib.call('dis_conv2d_fwd', x, _pack_w(weight, cin_pad, 0), bias, y, stats, n, hin, win, cin_pad, cout, k,
-                 stride, pad, act)
+        _conv_fwd_any(x, weight, cin_pad, 0, bias, y, stats, n, hin, win, cin_pad, cout, k, stride, pad, act)
         if gy_is_pre:
             act = ACT_NONE  # the consumer (group_norm(in_act=...)) hands back the pre-activation gradient
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
@@ -451,8 +489,8 @@ class _Conv2d(torch.autograd.Function):
             second = join is not None and join.buf is not None
             gx = join.take(x.shape) if second else torch.empty_like(x)
             if stride == 1:
-                lib.call('dis_conv2d_fwd', gpre, _pack_w(weight, cin, 1), None, gx, None, n, gpre.shape[1],
-                         gpre.shape[2], cout, cin, k, 1, k - 1 - pad, ACT_NONE | (CONV_ACCUM if second else 0))
+                _conv_fwd_any(gpre, weight, cin, 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cin, k, 1,
+                              k - 1 - pad, ACT_NONE | (CONV_ACCUM if second else 0))
             else:
                 ws = torch.empty(16 * cin * cout, dtype=torch.float32, device=x.device)
                 lib.call('dis_conv2d_dgrad_strided', gpre, weight, gx, ws, n, hin, win, cin, cout, k, stride, pad,
@@ -501,8 +539,8 @@ class _Conv2dMulti(torch.autograd.Function):
             last = i == len(xs) - 1
             wi = weight[:, off:off + cs[i]].contiguous()
             a = (act if last else ACT_NONE) | (CONV_ACCUM if i > 0 else 0)
-            lib.call('dis_conv2d_fwd', x, _pack_w(wi, cs[i], 0), bias if i == 0 else None, y, stats if last else None, n, h,
-                     w, cs[i], cout, k, 1, pad, a)
+            _conv_fwd_any(x, wi, cs[i], 0, bias if i == 0 else None, y, stats if last else None, n, h, w, cs[i], cout, k, 1,
+                          pad, a)
             off += cs[i]
         if gy_is_pre:
             act = ACT_NONE
@@ -536,8 +574,8 @@ class _Conv2dMulti(torch.autograd.Function):
             gx = None
             if ctx.needs_input_grad[6 + i]:
                 gx = torch.empty_like(x)
-                lib.call('dis_conv2d_fwd', gpre, _pack_w(wi, cs[i], 1), None, gx, None, n, gpre.shape[1], gpre.shape[2],
-                         cout, cs[i], k, 1, k - 1 - pad, ACT_NONE)
+                _conv_fwd_any(gpre, wi, cs[i], 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cs[i], k, 1,
+                              k - 1 - pad, ACT_NONE)
             gxs.append(gx)
             gwi = torch.empty_like(wi)
             wsz = lib.fn('dis_conv2d_wgrad_workspace')(cs[i], cout, k, 1)

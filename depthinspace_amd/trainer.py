@@ -44,6 +44,8 @@ class FlatAdam(object):
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
         ops.reset_grad_sinks()
+        if self.flat_g.is_cuda:
+            ops.begin_step(self.flat_g.device)
 
     def all_reduce_grads(self):
         if self.world_size > 1:

@@ -191,6 +191,14 @@ int dis_conv2d_pack_weights(const float* w_oihw, float* packed, int cout, int ci
  * The stride-1 input gradient is the same call on gy with mode-1 packed weights (cin/cout swapped). */
 int dis_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, double* stats, int n,
                    int hin, int win, int cin, int cout, int k, int stride, int pad, int act, void* stream);
+/* The same convolution for the dominant FuseNet shape (cin = cout = 32, k = 3, stride 1; also its input gradient with
+ * mode-1 weights) computed on the bf16 matrix cores at fp32 accuracy: every operand is split into three bf16 terms
+ * (24 significant bits) and each product is accumulated as six bf16 x bf16 terms in the fp32 MFMA accumulator; the
+ * dropped terms are <= 2^-24 relative, one fp32 rounding.  `packed` holds 9*3*4*32*8 16-bit words. */
+int dis_conv2d_pack_weights_bf16x3(const float* w_oihw, void* packed, int cout, int cin, int k, int mode, void* stream);
+int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y, double* stats, int n, int hin,
+                          int win, int cin, int cout, int k, int stride, int pad, int act, void* stream);
+
 /* Weight/bias gradient.  gy: (n,hout,wout,cout) gradient wrt the PRE-activation output; x has cin_pad channels.
  * workspace: dis_conv2d_wgrad_workspace(cin_pad,cout,k,stride) floats (-1 if the shape is unsupported).
  * grad_w: (cout,cin_real,k,k) OIHW, grad_b: (cout) or NULL, both OVERWRITTEN.  Deterministic (partial slabs

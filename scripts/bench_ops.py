@@ -35,6 +35,18 @@ def conv_case(name, n, h, w, cin, cout, k, stride, pad, act, stats):
     fl = 2.0 * n * ho * wo * cin * cout * k * k
     t = timeit(lambda: lib.call('dis_conv2d_fwd', x, wp, b, y, st, n, h, w, cin, cout, k, stride, pad, act))
     print(f'{name:34s} fwd   {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TFLOP/s')
+    if (cin, cout, k, stride) == (32, 32, 3, 1):
+        pk = torch.empty(9 * 3 * 4 * 32 * 8, dtype=torch.int16, device=dev)
+        lib.call('dis_conv2d_pack_weights_bf16x3', wt, pk, 32, 32, 3, 0)
+        y2 = torch.empty_like(y)
+        st2 = torch.zeros(2 * n, dtype=torch.float64, device=dev) if stats else None
+        t = timeit(lambda: lib.call('dis_conv2d_fwd_bf16x3', x, pk, b, y2, st2, n, h, w, cin, cout, k, stride, pad, act))
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), b.double(), padding=pad)
+        ref = torch.nn.functional.selu(ref) if act == 1 else ref
+        ref = ref.permute(0, 2, 3, 1)
+        e32 = float((y.double() - ref).abs().max() / ref.abs().max())
+        ex3 = float((y2.double() - ref).abs().max() / ref.abs().max())
+        print(f'{name:34s} fwd3  {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TFLOP/s-equivalent   max rel err vs fp64: fp32-MFMA {e32:.2e}  bf16x3 {ex3:.2e}')
     gy = torch.randn_like(y)
     gw = torch.empty_like(wt); gb = torch.empty(cout, device=dev)
     wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin, cout, k, stride)
