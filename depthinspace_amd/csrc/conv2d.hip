@@ -473,6 +473,21 @@ __device__ __forceinline__ void split3(float x, unsigned& h1, unsigned& h2, unsi
   h3 = f2bf_bits(r2);
 }
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two fp32 values -> three packed bf16 pairs (v_cvt_pk_bf16_f32: round to nearest even)
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+  const f32x2 v = {x, y};
+  const bf16x2 h1 = __builtin_convertvector(v, bf16x2);
+  const f32x2 r1 = v - __builtin_convertvector(h1, f32x2);
+  const bf16x2 h2 = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(h2, f32x2);
+  const bf16x2 h3 = __builtin_convertvector(r2, bf16x2);
+  p1 = __builtin_bit_cast(unsigned, h1);
+  p2 = __builtin_bit_cast(unsigned, h2);
+  p3 = __builtin_bit_cast(unsigned, h3);
+}
+
 #define BX_PS 104  // LDS pixel stride in 16-bit units: 3 planes x 32 channels + 8 pad (208 B: conflict-free b128 rows)
 #define BX_TR 16
 #define BX_TC 16
@@ -557,15 +572,13 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
       if ((int)threadIdx.x + it * 512 < BX_NITEMS) {
         const bool ok = (okmask >> it) & 1u;
         const float4 v = ok ? pre[it] : make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned a1, a2, a3, b1, b2, b3, c1, c2, c3, d1, d2, d3;
-        split3(v.x, a1, a2, a3);
-        split3(v.y, b1, b2, b3);
-        split3(v.z, c1, c2, c3);
-        split3(v.w, d1, d2, d3);
+        unsigned a1, a2, a3, b1, b2, b3;
+        split3_pair(v.x, v.y, a1, a2, a3);
+        split3_pair(v.z, v.w, b1, b2, b3);
         unsigned short* p = xl + it_lds[it];
-        *(uint2*)(p) = make_uint2(a1 | (b1 << 16), c1 | (d1 << 16));
-        *(uint2*)(p + 32) = make_uint2(a2 | (b2 << 16), c2 | (d2 << 16));
-        *(uint2*)(p + 64) = make_uint2(a3 | (b3 << 16), c3 | (d3 << 16));
+        *(uint2*)(p) = make_uint2(a1, b1);
+        *(uint2*)(p + 32) = make_uint2(a2, b2);
+        *(uint2*)(p + 64) = make_uint2(a3, b3);
       }
     }
   };
@@ -1022,6 +1035,207 @@ static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_
   return DIS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16x3 weight gradient of the 32 -> 32 3x3 stride-1 convolution (same operand split as conv_bf16x3_kernel).
+// GEMM view dW[(tap,ci)][co] = sum_pixels X[pixel+tap][ci] * G[pixel][co]: the contraction runs over PIXELS, so both
+// MFMA operands need, per lane, 8 consecutive pixels of one channel.  The LDS images stay [pixel][plane][channel]
+// (written exactly like the forward kernel's halo tile) and the operands are fetched with the hardware transposing
+// read ds_read_b64_tr_b16 (4 pixel rows x 16 channels per 16-lane group, delivered channel-major).
+// Workgroup = 4 waves, tile = 8x16 output pixels (4 k-steps of 32 pixels); the 36 accumulator tiles (18 (tap,ci/16)
+// row blocks x 2 cout blocks) are split over the waves, 9 each, and stay in registers across all tiles; no cross-wave
+// reduction.  Partial slabs / bias partials use the layout of conv_wgrad_kernel, so its reducers finish the job.
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define WX_IR 10
+#define WX_IC 18
+#define WX_X_U16 (WX_IR * WX_IC * BX_PS)
+#define WX_G_U16 (128 * BX_PS)
+#define WX_LDS_BYTES ((WX_X_U16 + WX_G_U16) * 2 + 1024 * 4)
+#define WX_NIX (WX_IR * WX_IC * 8)
+#define WX_NLX ((WX_NIX + 255) / 256)
+#define WX_NLG 4  // 128 pixels x 8 float4 / 256 threads
+
+__device__ __forceinline__ s16x8 tr_read8(const unsigned short* p0, const unsigned short* p1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  unsigned short* xl = smem16;
+  unsigned short* gl = smem16 + WX_X_U16;
+  float* bred = (float*)(smem16 + WX_X_U16 + WX_G_U16);  // 1024 floats: bias partial reduction
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lg = lane >> 4, l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3;  // tr-read role: row tq, column chunk tp
+  const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + 7) / 8;
+  const int ntiles = a.n * tiles_y * tiles_x;
+
+  // my 9 accumulator tiles: t = 9*wave + j -> (mb = t >> 1, nb = t & 1); mb = tap*2 + half.  The per-wave tile set is
+  // a compile-time constant inside run<W>() below (static register indexing of the accumulators).
+  f32x4 acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);  // channels 4*(tid&7).. of the gy pixels this thread stages
+
+  float4 prex[WX_NLX], preg[WX_NLG];
+  unsigned okx = 0, okg = 0;
+  int ix_r[WX_NLX], ix_c[WX_NLX], ix_lds[WX_NLX], ix_vv[WX_NLX];
+#pragma unroll
+  for (int it = 0; it < WX_NLX; ++it) {
+    const int idx = min((int)threadIdx.x + it * 256, WX_NIX - 1);
+    const int vv = idx & 7, pix = idx >> 3;
+    ix_c[it] = pix % WX_IC;
+    ix_r[it] = pix / WX_IC;
+    ix_vv[it] = vv;
+    ix_lds[it] = pix * BX_PS + vv * 4;
+  }
+  auto prefetch = [&](int tile) __attribute__((always_inline)) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int iy0 = ty * 8 - a.pad, ix0 = tx * 16 - a.pad;
+    const float* xb = a.x + (long)n * a.hin * a.win * 32;
+    okx = 0;
+    okg = 0;
+#pragma unroll
+    for (int it = 0; it < WX_NLX; ++it) {
+      const int iy = iy0 + ix_r[it], ix = ix0 + ix_c[it];
+      const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+      const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
+      prex[it] = *(const float4*)(xb + ((long)cy * a.win + cx) * 32 + ix_vv[it] * 4);
+      okx |= (ok ? 1u : 0u) << it;
+    }
+    const float* gb = a.gy + (long)n * a.hout * a.wout * 32;
+#pragma unroll
+    for (int it = 0; it < WX_NLG; ++it) {
+      const int idx = threadIdx.x + it * 256;
+      const int vv = idx & 7, pix = idx >> 3;
+      const int oy = ty * 8 + (pix >> 4), ox = tx * 16 + (pix & 15);
+      const bool ok = oy < a.hout && ox < a.wout;
+      const int cy = min(oy, a.hout - 1), cx = min(ox, a.wout - 1);
+      preg[it] = *(const float4*)(gb + ((long)cy * a.wout + cx) * 32 + vv * 4);
+      okg |= (ok ? 1u : 0u) << it;
+    }
+  };
+  auto put3 = [&](unsigned short* p, const float4& v) __attribute__((always_inline)) {
+    unsigned a1, a2, a3, b1, b2, b3;
+    split3_pair(v.x, v.y, a1, a2, a3);
+    split3_pair(v.z, v.w, b1, b2, b3);
+    *(uint2*)(p) = make_uint2(a1, b1);
+    *(uint2*)(p + 32) = make_uint2(a2, b2);
+    *(uint2*)(p + 64) = make_uint2(a3, b3);
+  };
+  auto stage = [&]() __attribute__((always_inline)) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < WX_NLX; ++it)
+      if ((int)threadIdx.x + it * 256 < WX_NIX) put3(xl + ix_lds[it], ((okx >> it) & 1u) ? prex[it] : z);
+#pragma unroll
+    for (int it = 0; it < WX_NLG; ++it) {
+      const int idx = threadIdx.x + it * 256;
+      const float4 v = ((okg >> it) & 1u) ? preg[it] : z;
+      bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+      put3(gl + (idx >> 3) * BX_PS + (idx & 7) * 4, v);
+    }
+  };
+
+  if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+  auto run = [&](auto wc) __attribute__((always_inline)) {
+    constexpr int W = decltype(wc)::value, T0 = 9 * W;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      __syncthreads();
+      stage();
+      __syncthreads();
+      if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+#pragma unroll 1
+      for (int ks = 0; ks < 4; ++ks) {
+        // this lane group's 8 pixels of the k-step: tile row pr, columns pc0 .. pc0+7; tr-read rows tq (+4)
+        const int pr = 2 * ks + (lg >> 1), pc0 = 8 * (lg & 1);
+        s16x8 fb[3][2];  // gy operands: 3 planes x both cout blocks
+        const unsigned short* gq = gl + (pr * 16 + pc0 + tq) * BX_PS + tp * 4;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) fb[p][nb] = tr_read8(gq + p * 32 + nb * 16, gq + 4 * BX_PS + p * 32 + nb * 16);
+        s16x8 fa[3];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          constexpr int dummy = 0;
+          const int t = T0 + j, mb = t >> 1, nb = t & 1;  // compile-time after unrolling
+          if (j == 0 || nb == 0) {
+            const int tap = mb >> 1, half = mb & 1, ky = tap / 3, kx = tap - 3 * ky;
+            const unsigned short* xq = xl + ((pr + ky) * WX_IC + pc0 + tq + kx) * BX_PS + half * 16 + tp * 4;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[p] = tr_read8(xq + p * 32, xq + 4 * BX_PS + p * 32);
+          }
+          constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+          constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[PA[q]]),
+                                                             __builtin_bit_cast(bf16x8, fb[PB[q]][nb]), acc[j], 0, 0, 0);
+          (void)dummy;
+        }
+      }
+    }
+    // partial slab of this workgroup: [m = mb*16 + row][co]
+    float* out = a.part + (long)blockIdx.x * (18 * 16 * 32);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int t = T0 + j, mb = t >> 1, nb = t & 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(mb * 16 + lg * 4 + r) * 32 + nb * 16 + l16] = acc[j][r];
+    }
+  };
+  switch (wave) {  // wave-uniform; every branch executes the same barriers
+    case 0: run(std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}); break;
+    default: run(std::integral_constant<int, 3>{}); break;
+  }
+  if (a.bpart) {
+    __syncthreads();
+    const int vv = threadIdx.x & 7, row = threadIdx.x >> 3;  // 32 rows of partial sums per channel group
+    bred[(row * 8 + vv) * 4 + 0] = bsum.x;
+    bred[(row * 8 + vv) * 4 + 1] = bsum.y;
+    bred[(row * 8 + vv) * 4 + 2] = bsum.z;
+    bred[(row * 8 + vv) * 4 + 3] = bsum.w;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float sum = 0.f;
+      for (int r = 0; r < 32; ++r) sum += bred[r * 32 + threadIdx.x];
+      a.bpart[(long)blockIdx.x * 32 + threadIdx.x] = sum;
+    }
+  }
+}
+
+static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, hipStream_t s) {
+  using C = WgCfg<32, 32, 3, 3, 1>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       WX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + 7) / 8;
+  const long ntiles = (long)a.n * tiles_y * tiles_x;
+  long workers = 2L * num_cus();
+  if (workers > WG_WORKERS) workers = WG_WORKERS;
+  if (workers > ntiles) workers = ntiles;
+  const long elems = C::PART;
+  float* tmp = a.part + (long)WG_WORKERS * elems;
+  a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
+  hipLaunchKernelGGL(conv_wgrad_bf16x3_kernel, dim3((unsigned)workers), dim3(256), WX_LDS_BYTES, s, a);
+  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(dis_cdiv(elems, 256), WG_RSPLIT), dim3(256), 0, s,
+                     (const float*)a.part, tmp, (int)workers, elems);
+  const long total = (long)C::MROWS * 32;
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)tmp, gw,
+                     C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, 32, 32, C::PART);
+  if (gb) hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)a.bpart, gb, (int)workers, 32);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 #define WG_CASE(CI, CO, K_, S_) \
   if (cin == CI && cout == CO && k == K_ && stride == S_) return launch_wgrad<CI, CO, K_, K_, S_>(a, gw, gb, cin_real, s);
 #define WS_CASE(CI, CO, K_, S_) \
@@ -1054,6 +1268,21 @@ extern "C" long dis_conv2d_wgrad_workspace(int cin, int cout, int k, int stride)
   WS_CASE(128, 32, 1, 1)
   WS_CASE(32, 32, 4, 2)
   return -1;
+}
+
+// same contract as dis_conv2d_wgrad (and the same workspace size) for cin = cout = 32, k = 3, stride 1
+extern "C" int dis_conv2d_wgrad_bf16x3(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace,
+                                       int n, int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride,
+                                       int pad, void* stream) {
+  if (!x || !gy || !grad_w || !workspace) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0) return DIS_ERR_BAD_SHAPE;
+  if (cin_pad != 32 || cin_real != 32 || cout != 32 || k != 3 || stride != 1) return DIS_ERR_UNSUPPORTED;
+  const int hout = hin + 2 * pad - 2, wout = win + 2 * pad - 2;
+  if (hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
+  WgArgs a;
+  a.x = x; a.gy = gy; a.part = workspace; a.bpart = nullptr;
+  a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
+  return launch_wgrad_bf16x3(a, grad_w, grad_b, (hipStream_t)stream);
 }
 
 extern "C" int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace,

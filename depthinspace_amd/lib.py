@@ -51,6 +51,7 @@ SIGS = {
     'dis_conv2d_fwd_bf16x3': 'pppppiiiiiiiiip',
     'dis_conv2d_wgrad_workspace': 'iiii',
     'dis_conv2d_wgrad': 'pppppiiiiiiiiip',
+    'dis_conv2d_wgrad_bf16x3': 'pppppiiiiiiiiip',
     'dis_conv2d_dgrad_strided': 'ppppiiiiiiiiip',
     'dis_disp_head_fwd': 'ppppiiiiffp',
     'dis_disp_head_bwd': 'ppppppppp' + 'iiiifp',

@@ -435,6 +435,14 @@ import os as _os
 BF16X3 = _os.environ.get('DIS_CONV_BF16X3', '1') != '0'
 
 
+def _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad):
+    """dis_conv2d_wgrad, or its bf16x3 form for the 32->32 3x3 stride-1 shape."""
+    name = 'dis_conv2d_wgrad'
+    if BF16X3 and cin_pad == 32 and cin == 32 and cout == 32 and k == 3 and stride == 1:
+        name = 'dis_conv2d_wgrad_bf16x3'
+    lib.call(name, x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
+
+
 def _conv_fwd_any(x, weight, cin_pad, mode, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act):
     """dis_conv2d_fwd, or its bf16x3 form (fp32 accuracy on the bf16 matrix cores) for the 32->32 3x3 stride-1 shape.
     `weight` is the unpacked OIHW tensor, `mode` the packing mode (0 forward, 1 stride-1 input gradient)."""
@@ -503,7 +511,7 @@ class _Conv2d(torch.autograd.Function):
         if wsz < 0:
             raise lib.DisHipError(f'conv2d wgrad: unsupported shape cin={cin_pad} cout={cout} k={k} s={stride}')
         ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
-        lib.call('dis_conv2d_wgrad', x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
+        _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
         return gx, gw_ret, gb_ret, None, None, None, None, None, None, None
 
 
@@ -582,8 +590,7 @@ class _Conv2dMulti(torch.autograd.Function):
             if wsz < 0:
                 raise lib.DisHipError(f'conv2d_multi wgrad: unsupported shape cin={cs[i]} cout={cout} k={k}')
             ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
-            lib.call('dis_conv2d_wgrad', x, gpre, gwi, gb if (i == 0 and has_bias) else None, ws, n, h, w, cs[i], cs[i],
-                     cout, k, 1, pad)
+            _conv_wgrad_any(x, gpre, gwi, gb if (i == 0 and has_bias) else None, ws, n, h, w, cs[i], cs[i], cout, k, 1, pad)
             gw[:, off:off + cs[i]].copy_(gwi)  # small strided memory move into the (flat) weight-gradient slice
             off += cs[i]
         return (gw_ret, gb_ret, None, None, None, None) + tuple(gxs)

@@ -204,6 +204,11 @@ int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bia
  * grad_w: (cout,cin_real,k,k) OIHW, grad_b: (cout) or NULL, both OVERWRITTEN.  Deterministic (partial slabs
  * per workgroup summed in a fixed order, no float atomics). */
 long dis_conv2d_wgrad_workspace(int cin_pad, int cout, int k, int stride);
+/* bf16x3 form (fp32 accuracy on the bf16 matrix cores, transposing LDS reads) for cin = cout = 32, k = 3, stride 1;
+ * same arguments, workspace and determinism as dis_conv2d_wgrad. */
+int dis_conv2d_wgrad_bf16x3(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
+                            int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,
+                            void* stream);
 int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
                      int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,
                      void* stream);

@@ -53,6 +53,17 @@ def conv_case(name, n, h, w, cin, cout, k, stride, pad, act, stats):
     ws = torch.empty(wsz, device=dev)
     t = timeit(lambda: lib.call('dis_conv2d_wgrad', x, gy, gw, gb, ws, n, h, w, cin, cin, cout, k, stride, pad))
     print(f'{name:34s} wgrad {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TFLOP/s')
+    if (cin, cout, k, stride) == (32, 32, 3, 1):
+        gw2 = torch.empty_like(wt); gb2 = torch.empty(cout, device=dev)
+        t = timeit(lambda: lib.call('dis_conv2d_wgrad_bf16x3', x, gy, gw2, gb2, ws, n, h, w, cin, cin, cout, k, stride, pad))
+        xr = x.permute(0, 3, 1, 2).double().requires_grad_(False)
+        wr = wt.double().clone().requires_grad_(True)
+        br = b.double().clone().requires_grad_(True)
+        torch.nn.functional.conv2d(xr, wr, br, padding=pad).backward(gy.permute(0, 3, 1, 2).double())
+        e32 = float((gw.double() - wr.grad).abs().max() / wr.grad.abs().max())
+        ex3 = float((gw2.double() - wr.grad).abs().max() / wr.grad.abs().max())
+        eb = float((gb2.double() - br.grad).abs().max() / br.grad.abs().max())
+        print(f'{name:34s} wgrd3 {t*1e3:8.1f} us  {fl/t/1e9:7.1f} TFLOP/s-equivalent   max rel err vs fp64: fp32-MFMA {e32:.2e}  bf16x3 {ex3:.2e}  bias {eb:.2e}')
 
 
 def main():
