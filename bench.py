@@ -27,6 +27,7 @@ import torch
 
 H, W, TL = 512, 432, 4
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0           # same guide, HBM3E spec peak
 
 
@@ -210,12 +211,19 @@ def main():
             per.setdefault(name, [0, 0.0])
             per[name][0] += 1
             per[name][1] += ms
+        peak, peak_note = PEAK_FP32_MFMA_TFLOPS, 'fp32 MFMA dense peak'
         if mf:
-            # dis_conv2d_fwd int args: (n, hin, win, cin, cout, k, stride, pad, act); same kernel template for the
+            # dis_conv2d_fwd[_bf16x3] int args: (n, hin, win, cin, cout, k, stride, pad, act); same kernel for the
             # forward 32->32 3x3 convs and their input gradients
-            sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_conv2d_fwd' and ia[3:7] == (32, 32, 3, 1)]
+            sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_conv2d_fwd_bf16x3' and ia[3:7] == (32, 32, 3, 1)]
+            kname = ('conv_bf16x3_kernel (fp32 conv as 6 bf16 products per MAC on v_mfma_f32_16x16x32_bf16, fp32 '
+                     'accumulate; TFLOP/s are fp32-equivalent algorithmic flops)')
+            peak, peak_note = PEAK_BF16_MFMA_TFLOPS / 6.0, 'bf16 MFMA dense peak (2500 TFLOP/s) / 6 products per fp32 MAC'
+            if not sel:  # DIS_CONV_BF16X3=0: the fp32-MFMA kernel
+                sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_conv2d_fwd' and ia[3:7] == (32, 32, 3, 1)]
+                kname = 'conv_fwd_kernel<32,32,3,3,1> (fp32 MFMA 16x16x4)'
+                peak, peak_note = PEAK_FP32_MFMA_TFLOPS, 'fp32 MFMA dense peak'
             fl = sum(conv_flops(ia[0], ia[1], ia[2], 32, 32, 3) for ia, _ in sel)
-            kname = 'conv_fwd_kernel<32,32,3,3,1> (fp32 MFMA 16x16x4)'
         else:
             # dis_convg_run int args: (mode, ldx, xoff, ldy, yoff, n, hin, win, cin, cin_w, hout, wout, cout, cout_w,
             # k, stride, pad, act): every launch of the streaming kernel family convg_fwd_kernel<BN>; algorithmic
@@ -238,8 +246,9 @@ def main():
                 tj = json.load(open(tpath))
                 traffic, tsrc = tj['hbm_bytes_per_launch'], tj['source']
             roof = {'bound': 'mfma', 'kernel': kname,
-                    'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch',
+                    'achieved': ach, 'peak': peak, 'peak_note': peak_note, 'unit': 'TFLOP/s',
+                    'frac': ach / peak, 'achieved_over_fp32_mfma_peak': ach / PEAK_FP32_MFMA_TFLOPS,
+                    'traffic': traffic, 'traffic_unit': 'bytes/launch',
                     'traffic_source': tsrc,
                     'algorithmic_bytes_per_launch_avg': (sum(2.0 * ia[0] * ia[1] * ia[2] * 32 * 4 for ia, _ in sel) / len(sel)
                                                          if mf else None),

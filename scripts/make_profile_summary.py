@@ -20,7 +20,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = 'void conv_fwd_kernel<32, 32, 3, 3, 1>(ConvArgs)'
+DOMINANT = 'conv_bf16x3_kernel(ConvArgs)'
 
 
 def main(tag):
