@@ -50,8 +50,13 @@ __device__ __forceinline__ void atomic_add_d(double* p, double v) { atomicAdd(p,
 #define SELU_ALPHA_F 1.6732632423543772848170429916717f
 #define SELU_SCALE_F 1.0507009873554804934193349852946f
 
+// exp for the SELU negative branch: v_exp_f32 on x*log2(e) (argument <= 0, result in (0,1]; a few ulp, the same order as
+// one fp32 rounding of the result) instead of the ~10-instruction library expf: the conv / Conv3D epilogues are
+// VALU-issue-bound.
+__device__ __forceinline__ float selu_exp(float x) { return __expf(x); }
+
 __device__ __forceinline__ float act_apply(float x, int act) {
-  if (act == DIS_ACT_SELU) return x > 0.f ? SELU_SCALE_F * x : (SELU_SCALE_F * SELU_ALPHA_F) * (expf(x) - 1.f);
+  if (act == DIS_ACT_SELU) return x > 0.f ? SELU_SCALE_F * x : (SELU_SCALE_F * SELU_ALPHA_F) * (selu_exp(x) - 1.f);
   if (act == DIS_ACT_RELU) return x > 0.f ? x : 0.f;
   return x;
 }

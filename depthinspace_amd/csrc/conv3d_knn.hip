@@ -112,7 +112,7 @@ struct __attribute__((aligned(16))) C3Lds {
 };
 
 __device__ __forceinline__ float selu_f(float x) {
-  return x > 0.f ? SELU_SCALE_F * x : (SELU_SCALE_F * SELU_ALPHA_F) * (expf(x) - 1.f);
+  return x > 0.f ? SELU_SCALE_F * x : (SELU_SCALE_F * SELU_ALPHA_F) * (selu_exp(x) - 1.f);
 }
 
 __device__ __forceinline__ void c3_load_weights(C3Lds& L, const C3Params& P) {
