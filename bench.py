@@ -101,7 +101,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    from depthinspace_amd import synth, lib
+    from depthinspace_amd import synth, lib, ops
     from depthinspace_amd.model import multi_frame_networks, multi_frame_worker, single_frame_worker, networks
     from depthinspace_amd.trainer import FlatAdam
     lib.check_all_symbols()
@@ -272,7 +272,12 @@ def main():
             'config': {'workload': (f'DIS-MF (FuseNet)' if mf else 'DIS-SF (DispNetS)') +
                                    f' training step, bs={args.bs} per GPU x 4 frames, 512x432, '
                                    f'default-pattern synthetic, fwd+losses+bwd+Adam, epoch>={args.epoch}',
-                       'global_batch': world * args.bs, 'parallelism': f'dp{world}', 'hip_graph': bool(use_graph)},
+                       'global_batch': world * args.bs, 'parallelism': f'dp{world}', 'hip_graph': bool(use_graph),
+                       'conv_arithmetic': ('fp32 results everywhere; the 32->32 3x3 convs (fwd, dgrad, wgrad) run as '
+                                           'bf16x3 (3-way bf16 operand split, 6 products, fp32 accumulate: error vs fp64 '
+                                           '<= the exact-fp32 MFMA kernel, tests/test_net_ops_gpu.py), all other convs on '
+                                           'v_mfma_f32_16x16x4_f32' if (mf and ops.BF16X3) else
+                                           'v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains)')},
             'roofline': roof, 'cpu_baseline': cpu, 'loss_terms': losses, 'kernel_ms_one_eager_step': kernel_ms,
         }
         print(json.dumps(res))
