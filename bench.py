@@ -84,6 +84,9 @@ def main():
                     help='multi_frame = BASELINE.json metric (config 3/4); single_frame = DIS-SF (config 2, run in fp32)')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of one hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='torch.distributed backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the '
+                         'multi-rank code path on a box with fewer GPUs than ranks)')
     ap.add_argument('--epoch', type=int, default=2, help='training epoch the step models (epoch<2 adds the L1 warm-up term)')
     args = ap.parse_args()
     if args.bs is None:
@@ -95,11 +98,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == 'nccl':
+        raise SystemExit(f'rank {rank}: local rank {local_rank} but only {ndev} GPU(s) visible')
+    dev_idx = local_rank % max(ndev, 1)  # ranks share a device only in the gloo plumbing test
+    torch.cuda.set_device(dev_idx)
+    dev = torch.device('cuda', dev_idx)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
 
     from depthinspace_amd import synth, lib, ops
     from depthinspace_amd.model import multi_frame_networks, multi_frame_worker, single_frame_worker, networks
@@ -204,7 +214,8 @@ def main():
     roof = None
     if rank == 0:
         lib.profile_start()
-        step_eager()
+        fwd_bwd()                    # rank-local: no collective here (only rank 0 runs this leg)
+        opt.step(all_reduce=False)
         rec = lib.profile_stop()
         per = {}
         for name, ia, ms in rec:
@@ -273,6 +284,7 @@ def main():
                                    f' training step, bs={args.bs} per GPU x 4 frames, 512x432, '
                                    f'default-pattern synthetic, fwd+losses+bwd+Adam, epoch>={args.epoch}',
                        'global_batch': world * args.bs, 'parallelism': f'dp{world}', 'hip_graph': bool(use_graph),
+                       'backend': (args.backend if world > 1 else None),
                        'conv_arithmetic': ('fp32 results everywhere; the 32->32 3x3 convs (fwd, dgrad, wgrad) run as '
                                            'bf16x3 (3-way bf16 operand split, 6 products, fp32 accumulate: error vs fp64 '
                                            '<= the exact-fp32 MFMA kernel, tests/test_net_ops_gpu.py), all other convs on '
