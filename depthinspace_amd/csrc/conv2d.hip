@@ -36,6 +36,8 @@ struct ConvArgs {
   int osy, ooy, osx, oox;  // output pixel = (vy*osy+ooy, vx*osx+oox)
   int act;
   int accum;  // epilogue adds the previous contents of y (before the activation): y = act(y_old + conv + bias)
+  const float* xscale;  // optional (n,hin,win,NCHUNK): input pixel x chunk multiplier applied when the halo is staged
+  const float* yscale;  // optional (n,hf,wf,COUT/32): output pixel x 32-channel-group multiplier (before bias/accum)
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   // issue point.  Everything that does not depend on the tile (item -> row/col/channel-group, element offset
   // inside the halo window) is computed once per thread; interior tiles skip the per-item clamps.
   float4 pre[C::NLOAD];
+  float psc[C::NLOAD];
   unsigned okmask = 0;
   int it_r[C::NLOAD], it_c[C::NLOAD], it_off[C::NLOAD], it_lds[C::NLOAD];
 #pragma unroll
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     it_r[it] = pix / C::IN_COLS;
     it_off[it] = (it_r[it] * a.win + it_c[it]) * CIN + vv * 4;
     it_lds[it] = pix * C::CS + vv * 4;
+    psc[it] = 1.f;
   }
   auto prefetch = [&](int tile, int chunk) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
@@ -129,13 +133,22 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         okmask |= (ok ? 1u : 0u) << it;
       }
     }
+    if (a.xscale) {  // per (input pixel, chunk) multiplier, e.g. the slot weights of the multi-frame 1x1 conv
+#pragma unroll
+      for (int it = 0; it < C::NLOAD; ++it) {
+        const int cy = min(max(iy0 + it_r[it], 0), a.hin - 1), cx = min(max(ix0 + it_c[it], 0), a.win - 1);
+        psc[it] = a.xscale[(((long)n * a.hin + cy) * a.win + cx) * C::NCHUNK + chunk];
+      }
+    }
   };
   auto stage = [&]() {
 #pragma unroll
     for (int it = 0; it < C::NLOAD; ++it) {
       if ((int)threadIdx.x + it * 256 < C::NITEMS) {
         const bool ok = (okmask >> it) & 1u;
-        *(float4*)(xl + it_lds[it]) = ok ? pre[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float sc = psc[it];
+        *(float4*)(xl + it_lds[it]) =
+            ok ? make_float4(pre[it].x * sc, pre[it].y * sc, pre[it].z * sc, pre[it].w * sc) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
@@ -232,6 +245,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     float* ybase = a.y + (((long)n * a.hf + ((long)vy0 * a.osy + a.ooy)) * a.wf + ((long)vx0 * a.osx + a.oox)) * COUT + li;
     const long yrow = (long)a.osy * a.wf * COUT;
     const bool full = (ty + 1) * C::TROWS <= a.hv && (tx + 1) * C::TCOLS <= a.wv;
+    if (a.yscale) {  // per (output pixel, 32-channel group) multiplier (input gradient of a scaled-input 1x1 conv)
+      constexpr int NG = (C::NT + 1) / 2;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int oy = min(vy0 + mt, a.hv - 1) * a.osy + a.ooy, ox = min(vx0 + r, a.wv - 1) * a.osx + a.oox;
+          const float* sp = a.yscale + (((long)n * a.hf + oy) * a.wf + ox) * NG;
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt][r] *= sp[nt >> 1];
+        }
+    }
     auto emit = [&](auto actc, auto accc) {
       constexpr int ACT = decltype(actc)::value;
       constexpr bool ACC = decltype(accc)::value != 0;
@@ -414,6 +439,29 @@ extern "C" int dis_conv2d_fwd(const float* x, const float* w_packed, const float
   a.hf = hout; a.wf = wout; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
   a.act = act & 0xff;
   a.accum = (act & DIS_CONV_ACCUM) ? 1 : 0;
+  a.xscale = nullptr;
+  a.yscale = nullptr;
+  if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
+  return dispatch_conv(a, cin, cout, k, k, stride, (hipStream_t)stream);
+}
+
+extern "C" int dis_conv2d_fwd_scaled(const float* x, const float* xscale, const float* w_packed, const float* bias,
+                                     float* y, const float* yscale, double* stats, int n, int hin, int win, int cin,
+                                     int cout, int k, int stride, int pad, int act, void* stream) {
+  if (!x || !w_packed || !y) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || k <= 0 || stride <= 0 || pad < 0)
+    return DIS_ERR_BAD_SHAPE;
+  if (yscale && (cout % 32)) return DIS_ERR_UNSUPPORTED;
+  const int hout = (hin + 2 * pad - k) / stride + 1, wout = (win + 2 * pad - k) / stride + 1;
+  if (hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
+  ConvArgs a;
+  a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.stats = stats;
+  a.n = n; a.hin = hin; a.win = win; a.hv = hout; a.wv = wout; a.pad_y = pad; a.pad_x = pad;
+  a.hf = hout; a.wf = wout; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
+  a.act = act & 0xff;
+  a.accum = (act & DIS_CONV_ACCUM) ? 1 : 0;
+  a.xscale = xscale;
+  a.yscale = yscale;
   if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
   return dispatch_conv(a, cin, cout, k, k, stride, (hipStream_t)stream);
 }
@@ -440,6 +488,8 @@ extern "C" int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, fl
       a.pad_y = (py == 0) ? 1 : 0; a.pad_x = (px == 0) ? 1 : 0;
       a.hf = hin; a.wf = win; a.osy = 2; a.ooy = py; a.osx = 2; a.oox = px; a.act = DIS_ACT_NONE;
       a.accum = accumulate ? 1 : 0;
+      a.xscale = nullptr;
+      a.yscale = nullptr;
       int rc = dispatch_conv(a, cout, cin, 2, 2, 1, s);
       if (rc != DIS_OK) return rc;
     }
@@ -725,6 +775,8 @@ extern "C" int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const
   a.hf = hout; a.wf = wout; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
   a.act = act & 0xff;
   a.accum = (act & DIS_CONV_ACCUM) ? 1 : 0;
+  a.xscale = nullptr;
+  a.yscale = nullptr;
   if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
@@ -783,6 +835,7 @@ struct WgArgs {
   float* part;   // [worker][chunk][split][PART]
   float* bpart;  // [worker][COUT] bias partial sums (written by chunk 0 / split 0 workgroups), may be null
   int n, hin, win, hout, wout, pad;
+  const float* xscale;  // optional (n,hin,win,NCHUNK) multiplier of x (see ConvArgs::xscale)
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -839,7 +892,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
         const int vv = idx % C::NV, pix = idx / C::NV;
         const int c = pix % C::IN_COLS, r = pix / C::IN_COLS;
         const int iy = iy0 + r, ix = ix0 + c;
-        if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) v = *(const float4*)(xb + ((long)iy * a.win + ix) * CIN + vv * 4);
+        if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) {
+          v = *(const float4*)(xb + ((long)iy * a.win + ix) * CIN + vv * 4);
+          if (a.xscale) {
+            const float sc = a.xscale[(((long)n * a.hin + iy) * a.win + ix) * C::NCHUNK + chunk];
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+          }
+        }
       }
       prex[it] = v;
     }
@@ -1282,6 +1341,7 @@ extern "C" int dis_conv2d_wgrad_bf16x3(const float* x, const float* gy, float* g
   WgArgs a;
   a.x = x; a.gy = gy; a.part = workspace; a.bpart = nullptr;
   a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
+  a.xscale = nullptr;
   return launch_wgrad_bf16x3(a, grad_w, grad_b, (hipStream_t)stream);
 }
 
@@ -1296,6 +1356,22 @@ extern "C" int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, 
   WgArgs a;
   a.x = x; a.gy = gy; a.part = workspace; a.bpart = nullptr;
   a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
+  a.xscale = nullptr;
+  return dispatch_wgrad(a, grad_w, grad_b, cin_real, cin_pad, cout, k, stride, (hipStream_t)stream);
+}
+
+extern "C" int dis_conv2d_wgrad_scaled(const float* x, const float* xscale, const float* gy, float* grad_w, float* grad_b,
+                                       float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout,
+                                       int k, int stride, int pad, void* stream) {
+  if (!x || !gy || !grad_w || !workspace) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0 || cin_pad <= 0 || cin_real <= 0 || cin_real > cin_pad || cout <= 0)
+    return DIS_ERR_BAD_SHAPE;
+  const int hout = (hin + 2 * pad - k) / stride + 1, wout = (win + 2 * pad - k) / stride + 1;
+  if (hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
+  WgArgs a;
+  a.x = x; a.gy = gy; a.part = workspace; a.bpart = nullptr;
+  a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
+  a.xscale = xscale;
   return dispatch_wgrad(a, grad_w, grad_b, cin_real, cin_pad, cout, k, stride, (hipStream_t)stream);
 }
 

@@ -795,6 +795,25 @@ __global__ void mask_weight_slots_kernel(const float* __restrict__ wf, const flo
     *(float4*)(out + i * 4) = v;
   }
 }
+// wgt[p][s] = mask[p][s] / mean_s(mask[p][.])  (the multiplier of mask_weight_slots as a small tensor of its own, so the
+// multi-frame 1x1 convolution can apply it while staging its input instead of reading a pre-scaled copy)
+__global__ void slot_weights_kernel(const float4* __restrict__ geom, float* __restrict__ wgt, long pixels, int tl) {
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < pixels; p += (long)gridDim.x * blockDim.x) {
+    float msum = 0.f;
+    for (int k = 0; k < tl; ++k) msum += geom[p * tl + k].w;
+    const float mean = msum / (float)tl;
+    for (int k = 0; k < tl; ++k) wgt[p * tl + k] = geom[p * tl + k].w / mean;
+  }
+}
+extern "C" int dis_slot_weights(const float* geom, float* wgt, long pixels, int tl, void* stream) {
+  if (!geom || !wgt) return DIS_ERR_NULL;
+  if (pixels <= 0 || tl <= 0) return DIS_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(slot_weights_kernel, dim3(dis_ew_grid(pixels, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)geom, wgt, pixels, tl);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 extern "C" int dis_mask_weight_slots(const float* wf, const float* geom, float* out, long pixels, int tl, int c,
                                      int accumulate, void* stream) {
   if (!wf || !geom || !out) return DIS_ERR_NULL;

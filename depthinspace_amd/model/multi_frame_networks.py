@@ -143,7 +143,7 @@ class Block2D3D(TimedModule):
                            join=join)
         return ops.group_norm(o, slots[gn_idx].weight, slots[gn_idx].bias, stats=st, in_act=act)
 
-    def tforward(self, feat, geom, geom_q, flows, flows_q, idx=None, idx_q=None, csr=None, csr_q=None):
+    def tforward(self, feat, geom, geom_q, flows, flows_q, idx=None, idx_q=None, csr=None, csr_q=None, wgt=None):
         """feat (tl,bs,h,w,C) nhwc.  geom/geom_q: core / quarter geometry; flows/flows_q: (tl*tl,bs,.,.,2);
         idx/idx_q: neighbour sets of the two Conv3D layers (shared by all blocks: they depend on geometry only)."""
         tl, bs, h, w, C = feat.shape
@@ -159,8 +159,12 @@ class Block2D3D(TimedModule):
         o3d2 = self.conv3d_2(geom_q, wfq, idx_q)
         hq, wq = o3d2.shape[2:4]
         # 2-D branch (fwd_2d, reference :406-430)
-        x = ops.mask_weight_slots(wf, geom, j_wf).view(N, h, w, tl * C)
-        mf = self._conv_gn(x, self.conv_mf, 2, 1, 0, NONE)
+        # conv_mf over the mask-weighted slots: the weights mask/mean(mask) (:410) are applied inside the 1x1 conv kernels
+        if wgt is None:
+            wgt = ops.slot_weights(geom)
+        o, st = ops.conv2d_scaled_in(wf.view(N, h, w, tl * C), wgt, self.conv_mf[1].weight, self.conv_mf[1].bias, 1, 0,
+                                     want_stats=True, join=j_wf)
+        mf = ops.group_norm(o, self.conv_mf[2].weight, self.conv_mf[2].bias, stats=st)
         a = self._conv_gn(mf, self.conv1_1, 3, 1, 1, SELU, j_mf)
         a = self._conv_gn(a, self.conv1_2, 3, 1, 1, SELU)
         b = self._conv_gn(mf, self.conv2_1, 3, 2, 1, SELU, j_mf)
@@ -271,10 +275,11 @@ class FuseNet(TimedModule):
             # scatter index of the feature warps (data only): built once, shared by the 4 blocks' backward passes
             csr = ops.gather_csr(flows) if torch.is_grad_enabled() or feat.requires_grad else None
             csr_q = ops.gather_csr(flows_q) if csr is not None else None
+            wgt = ops.slot_weights(geom)
         self.last_knn_index = (idx, idx_q)
 
         for block in self.blocks:
-            feat = block(feat, geom, geom_q, flows, flows_q, idx, idx_q, csr, csr_q)
+            feat = block(feat, geom, geom_q, flows, flows_q, idx, idx_q, csr, csr_q, wgt)
 
         amb4 = ops.pack4_nhwc([(amb, HW)], N, H, W)
         disp = self.post_process(feat.view(N, h, w, self.channels), amb4)

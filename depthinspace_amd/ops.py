@@ -601,6 +601,70 @@ def conv2d_multi(xs, weight, bias, pad=0, act=ACT_NONE, want_stats=False, gy_is_
     return _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, *xs)
 
 
+class _Conv2dScaledIn(torch.autograd.Function):
+    """y = conv2d(x * xscale[..., chunk]) with the multiplier applied inside the kernels: forward while the input is
+    staged, input gradient in the epilogue (optionally accumulating into a GradJoin buffer), weight gradient while x
+    is staged.  x (n,h,w,cin), xscale (n,h,w,cin/32)."""
+
+    @staticmethod
+    def forward(ctx, x, xscale, weight, bias, stride, pad, act, want_stats, join):
+        x, xscale, weight = _c(x), _c(xscale), _c(weight)
+        _chk(x, xscale, weight, bias)
+        n, hin, win, cin = x.shape
+        cout, _, k, _ = weight.shape
+        assert cin % 32 == 0 and tuple(xscale.shape) == (n, hin, win, cin // 32) and act == ACT_NONE
+        ho, wo = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
+        y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+        stats = _zeros_d(2 * n, x.device) if want_stats else None
+        lib.call('dis_conv2d_fwd_scaled', x, xscale, _pack_w(weight, cin, 0), bias, y, None, stats, n, hin, win, cin, cout,
+                 k, stride, pad, act)
+        ctx.save_for_backward(x, xscale, weight)
+        ctx.cfg = (stride, pad, bias is not None)
+        ctx.bias_ref = bias
+        ctx.join = join
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, gy, _gstats):
+        x, xscale, weight = ctx.saved_tensors
+        stride, pad, has_bias = ctx.cfg
+        n, hin, win, cin = x.shape
+        cout, _, k, _ = weight.shape
+        gy = _c(gy)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            assert stride == 1
+            join = ctx.join
+            second = join is not None and join.buf is not None
+            gx = join.take(x.shape) if second else torch.empty_like(x)
+            lib.call('dis_conv2d_fwd_scaled', gy, None, _pack_w(weight, cin, 1), None, gx, xscale, None, n, gy.shape[1],
+                     gy.shape[2], cout, cin, k, 1, k - 1 - pad, ACT_NONE | (CONV_ACCUM if second else 0))
+            if join is not None and not second:
+                gx = join.first(gx)
+        gw, gw_ret = _sink(weight)
+        gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
+        wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin, cout, k, stride)
+        ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
+        lib.call('dis_conv2d_wgrad_scaled', x, xscale, gy, gw, gb, ws, n, hin, win, cin, cin, cout, k, stride, pad)
+        return gx, None, gw_ret, gb_ret, None, None, None, None, None
+
+
+def conv2d_scaled_in(x, xscale, weight, bias, stride=1, pad=0, want_stats=False, join=None):
+    return _Conv2dScaledIn.apply(x, xscale, weight, bias, stride, pad, ACT_NONE, want_stats, join)
+
+
+def slot_weights(geom):
+    """(tl,bs,h,w,tl,4) geometry -> (tl*bs,h,w,tl) multipliers mask/mean(mask) (reference multi_frame_networks.py:410)"""
+    geom = _c(geom)
+    tl, bs, h, w, s, _ = geom.shape
+    out = torch.empty((tl * bs, h, w, s), dtype=torch.float32, device=geom.device)
+    lib.call('dis_slot_weights', geom, out, tl * bs * h * w, s)
+    return out
+
+
 class _DispHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, alpha, offset):

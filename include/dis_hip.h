@@ -199,11 +199,28 @@ int dis_conv2d_pack_weights_bf16x3(const float* w_oihw, void* packed, int cout, 
 int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y, double* stats, int n, int hin,
                           int win, int cin, int cout, int k, int stride, int pad, int act, void* stream);
 
+/* dis_conv2d_fwd with per-pixel multipliers fused into the kernel (both optional, may be NULL):
+ *   xscale (n,hin,win,NCHUNK): x[pixel][chunk c] is multiplied by xscale[pixel][c] while it is staged (NCHUNK = cin/32
+ *          for cin % 32 == 0): conv(x * s) without materialising x * s;
+ *   yscale (n,hout,wout,cout/32): the result (before bias / accumulation) of 32-channel group g is multiplied by
+ *          yscale[pixel][g]: the input gradient of such a conv.
+ * Used for the multi-frame 1x1 conv over the mask-weighted slots (reference multi_frame_networks.py:410-413) with
+ * xscale = yscale = dis_slot_weights(geom). */
+int dis_conv2d_fwd_scaled(const float* x, const float* xscale, const float* w_packed, const float* bias, float* y,
+                          const float* yscale, double* stats, int n, int hin, int win, int cin, int cout, int k,
+                          int stride, int pad, int act, void* stream);
+/* wgt (pixels,tl) = mask / mean(mask) from geom (pixels,tl,4) */
+int dis_slot_weights(const float* geom, float* wgt, long pixels, int tl, void* stream);
+
 /* Weight/bias gradient.  gy: (n,hout,wout,cout) gradient wrt the PRE-activation output; x has cin_pad channels.
  * workspace: dis_conv2d_wgrad_workspace(cin_pad,cout,k,stride) floats (-1 if the shape is unsupported).
  * grad_w: (cout,cin_real,k,k) OIHW, grad_b: (cout) or NULL, both OVERWRITTEN.  Deterministic (partial slabs
  * per workgroup summed in a fixed order, no float atomics). */
 long dis_conv2d_wgrad_workspace(int cin_pad, int cout, int k, int stride);
+/* dis_conv2d_wgrad of conv(x * xscale) (see dis_conv2d_fwd_scaled); xscale may be NULL */
+int dis_conv2d_wgrad_scaled(const float* x, const float* xscale, const float* gy, float* grad_w, float* grad_b,
+                            float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k,
+                            int stride, int pad, void* stream);
 /* bf16x3 form (fp32 accuracy on the bf16 matrix cores, transposing LDS reads) for cin = cout = 32, k = 3, stride 1;
  * same arguments, workspace and determinism as dis_conv2d_wgrad. */
 int dis_conv2d_wgrad_bf16x3(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
