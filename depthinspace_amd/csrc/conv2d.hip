@@ -1011,8 +1011,11 @@ __global__ void wgrad_reduce1_kernel(const float* __restrict__ part, float* __re
   tmp[(long)sp * elems + e] = s;
 }
 // level 2: sum the 16 partial sums and scatter into OIHW
-__global__ void wgrad_reduce2_kernel(const float* __restrict__ tmp, float* __restrict__ gw, int cinb, int nchunk,
-                                     int nsplit, int khb, int kw, int kh, int cout, int cin_real, int partsz) {
+__global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ tmp, float* __restrict__ gw,
+                                                             int cinb, int nchunk, int nsplit, int khb, int kw, int kh,
+                                                             int cout, int cin_real, int partsz,
+                                                             const float* __restrict__ bpart, float* __restrict__ gb,
+                                                             int workers) {
   const int mrows = khb * kw * cinb;
   const long total = (long)nchunk * nsplit * mrows * cout;
   const long elems = (long)nchunk * nsplit * partsz;
@@ -1030,6 +1033,23 @@ __global__ void wgrad_reduce2_kernel(const float* __restrict__ tmp, float* __res
     const int tap = m / cinb, ci = chunk * cinb + m % cinb;
     const int ky = (nsplit > 1 ? split : 0) + tap / kw, kx = tap % kw;
     if (ci < cin_real) gw[(((long)co * cin_real + ci) * kh + ky) * kw + kx] = s;
+  }
+  // bias gradient (folded in here to save a launch): the last block adds the per-workgroup bias partials, thread t
+  // sums workers {t/cout, t/cout + 256/cout, ...} of channel t%cout, then a fixed-order sum over the sub-sums
+  if (bpart && blockIdx.x == gridDim.x - 1) {
+    __shared__ float red[256];
+    const int lanes = 256 / cout;  // cout divides 256 (16, 32, 64, 128)
+    const int co = threadIdx.x % cout, sub = threadIdx.x / cout;
+    float s = 0.f;
+    if (sub < lanes)
+      for (int k = sub; k < workers; k += lanes) s += bpart[(long)k * cout + co];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < cout) {
+      float t = 0.f;
+      for (int k = 0; k < lanes; ++k) t += red[k * cout + threadIdx.x];
+      gb[threadIdx.x] = t;
+    }
   }
 }
 // 1024 threads: thread t sums workers {t/cout, t/cout + 1024/cout, ...} of channel t%cout (coalesced rows of bpart),
@@ -1088,8 +1108,8 @@ static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_
                      (const float*)a.part, tmp, (int)workers, elems);
   const long total = (long)C::NCHUNK * C::NSPLIT * C::MROWS * COUT;
   hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)tmp, gw,
-                     C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, KW, KH, COUT, cin_real, C::PART);
-  if (gb) hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)a.bpart, gb, (int)workers, COUT);
+                     C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, KW, KH, COUT, cin_real, C::PART,
+                     (const float*)(gb ? a.bpart : nullptr), gb, (int)workers);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
@@ -1289,8 +1309,8 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, hipStream_t s) {
                      (const float*)a.part, tmp, (int)workers, elems);
   const long total = (long)C::MROWS * 32;
   hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)tmp, gw,
-                     C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, 32, 32, C::PART);
-  if (gb) hipLaunchKernelGGL(bias_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)a.bpart, gb, (int)workers, 32);
+                     C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, 32, 32, C::PART,
+                     (const float*)(gb ? a.bpart : nullptr), gb, (int)workers);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

@@ -218,9 +218,24 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
                                     const float* __restrict__ x, const double* __restrict__ stats,
                                     const float* __restrict__ gamma, const double* __restrict__ red,
                                     float* __restrict__ gx, float* __restrict__ gres, long hw, int c, int act,
-                                    float eps, int nred, int in_act) {
+                                    float eps, int nred, int in_act, const double* __restrict__ gparam,
+                                    float* __restrict__ gg, float* __restrict__ gb, int slots) {
   __shared__ float gam[GN_MAXC];
   const int n = blockIdx.y;
+  // dgamma / dbeta (folded in here to save a launch): wave w of the first 2c/4 blocks of sample 0 sums the `slots`
+  // per-block partials of one parameter in a fixed order
+  if (blockIdx.y == 0 && (int)blockIdx.x * 4 < 2 * c) {
+    const int lane = threadIdx.x & 63;
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < 2 * c; j += gridDim.x * 4) {
+      double s = 0.0;
+      for (int k = lane; k < slots; k += 64) s += gparam[(long)k * 2 * c + j];
+      s = wave_sum_d(s);
+      if (lane == 0) {
+        if (j < c) gg[j] = (float)s;
+        else gb[j - c] = (float)s;
+      }
+    }
+  }
   float mean, rstd;
   const double m = (double)hw * c;
   gn_moments(stats, n, m, eps, &mean, &rstd);
@@ -300,9 +315,8 @@ extern "C" int dis_gn_apply_bwd(const float* gy, const float* y, const float* x,
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nred, n), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma, red,
                      gparam_acc, hw, c, act, eps);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gxg * 2, n), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma,
-                     (const double*)red, gx, gres, hw, c, act, eps, nred, in_act);
-  hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(2 * c), dim3(64), 0, s, (const double*)gparam_acc, grad_gamma,
-                     grad_beta, c, n * nred);
+                     (const double*)red, gx, gres, hw, c, act, eps, nred, in_act, (const double*)gparam_acc, grad_gamma,
+                     grad_beta, n * nred);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
