@@ -566,12 +566,49 @@ __global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned
   }
 }
 
+// Diagnostic build only (make stamp -> libdis_hip_stamp.so, scripts/stamp_bf16x3.py): per-wave s_memtime sums of the
+// phases of conv_bf16x3_kernel, written to a buffer nothing else reads.  The product build contains no stamp.
+#ifdef BX_STAMP
+__device__ unsigned long long bx_stamps[256 * 8 * 8];
+#define BX_T(k)                                                   \
+  {                                                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    st_[k] += now_ - last_;                                       \
+    last_ = now_;                                                 \
+  }
+extern "C" int dis_debug_bx_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bx_stamps), sizeof(bx_stamps));
+}
+#else
+#define BX_T(k)
+#endif
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define BX_OOB 0x80000000u  // byte offset beyond any buffer this kernel addresses (sizes are checked < 2 GiB on the host)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bx_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// Per tile the matrix work is 216 MFMAs per wave; everything else is software-pipelined around it, and everything that
+// rides inside the MFMA loop is straight-line code (no branch: the scheduler can only interleave VALU and memory
+// instructions with MFMAs inside one basic block, and an MFMA leaves half of its issue cycles free):
+//   * the halo of tile t+1 is fetched into registers by buffer loads issued one per tap during the MFMA loop of tile t;
+//     pixels outside the image get an out-of-range buffer offset, which loads zeros (the padding) without a branch,
+//   * the epilogue of tile t-1 (bias, accumulate, activation, GroupNorm statistics, float4 stores) runs from a register
+//     copy of its accumulators during the last taps of tile t; pixels outside the output get an out-of-range offset,
+//     which drops the store.
+// Only the LDS refill (two barriers + split + ds_write) stays serial.
+// The weights are the MFMA's A operand (M = cout) and the pixels its B operand (N = pixel): a lane then holds 4
+// consecutive output channels of one pixel and stores a float4.
+template <int ACT, bool ACCUM, bool STATS>
 __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+#ifdef BX_STAMP
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
   unsigned short* wl = smem16;
   unsigned short* xl = smem16 + BX_W_U16;
-  double* red = (double*)(smem16 + BX_W_U16 + BX_X_U16);
-  for (int i = threadIdx.x; i < BX_W_U16 / 8; i += 512) ((uint4*)wl)[i] = ((const uint4*)a.w)[i];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -580,52 +617,50 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
   const int xcd = blockIdx.x % nxcd, rank = blockIdx.x / nxcd, per = gridDim.x / nxcd;
   const int t_lo = (int)((long)ntiles * xcd / nxcd), t_hi = (int)((long)ntiles * (xcd + 1) / nxcd);
+  // a step of `per` tiles in (n, ty, tx) coordinates
+  const int d_tx = per % tiles_x, d_ty = (per / tiles_x) % tiles_y, d_n = per / (tiles_x * tiles_y);
 
+  // this thread's halo items: (row, col) inside the 18x18 halo and the byte offset from the halo's first pixel.
+  // Items past the end of the halo (last round only) get a row that is outside every image.
   float4 pre[BX_NLOAD];
-  unsigned okmask = 0;
-  int it_r[BX_NLOAD], it_c[BX_NLOAD], it_off[BX_NLOAD], it_lds[BX_NLOAD], it_vv[BX_NLOAD];
+  int it_rc[BX_NLOAD], it_off[BX_NLOAD];
 #pragma unroll
   for (int it = 0; it < BX_NLOAD; ++it) {
-    const int idx = min((int)threadIdx.x + it * 512, BX_NITEMS - 1);
+    const int idx = (int)threadIdx.x + it * 512;
     const int vv = idx & 7, pix = idx >> 3;
-    it_c[it] = pix % BX_IC;
-    it_r[it] = pix / BX_IC;
-    it_vv[it] = vv;
-    it_off[it] = (it_r[it] * a.win + it_c[it]) * 32 + vv * 4;
-    it_lds[it] = pix * BX_PS + vv * 4;
+    const int r = pix / BX_IC, c = pix % BX_IC;
+    it_rc[it] = (idx < BX_NITEMS) ? (r | (c << 16)) : 0x4000;
+    it_off[it] = ((r * a.win + c) * 32 + vv * 4) * 4;
   }
-  auto prefetch = [&](int tile) {
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-    const int iy0 = ty * BX_TR - a.pad_y, ix0 = tx * BX_TC - a.pad_x;
-    const float* xb = a.x + (long)n * a.hin * a.win * 32;
-    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + BX_IR <= a.hin && ix0 + BX_IC <= a.win;
-    if (interior) {
-      const float* xo = xb + ((long)iy0 * a.win + ix0) * 32;
-      okmask = 0xffffffffu;
-#pragma unroll
-      for (int it = 0; it < BX_NLOAD; ++it) pre[it] = *(const float4*)(xo + it_off[it]);
-    } else {
-      okmask = 0;
-#pragma unroll
-      for (int it = 0; it < BX_NLOAD; ++it) {
-        const int iy = iy0 + it_r[it], ix = ix0 + it_c[it];
-        const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-        const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
-        pre[it] = *(const float4*)(xb + ((long)cy * a.win + cx) * 32 + it_vv[it] * 4);
-        okmask |= (ok ? 1u : 0u) << it;
-      }
-    }
+  const unsigned x_bytes = (unsigned)a.hin * a.win * 128u, y_bytes = (unsigned)a.hf * a.wf * 128u;
+  // halo fetch state of the tile being prefetched (all wave-uniform)
+  const float* pf_x = a.x;
+  unsigned pf_bytes = 0;
+  int pf_iy0 = 0, pf_ix0 = 0, pf_off0 = 0;
+  auto pf_setup = [&](int n, int ty, int tx, bool live) {
+    pf_iy0 = ty * BX_TR - a.pad_y;
+    pf_ix0 = tx * BX_TC - a.pad_x;
+    pf_off0 = (pf_iy0 * a.win + pf_ix0) * 128;
+    pf_x = a.x + (long)n * a.hin * a.win * 32;
+    pf_bytes = live ? x_bytes : 0u;  // no next tile: every load is out of range
+  };
+  auto pf_issue = [&](int it) {
+    const int iy = pf_iy0 + (it_rc[it] & 0xffff), ix = pf_ix0 + (it_rc[it] >> 16);
+    const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+    const unsigned off = ok ? (unsigned)(pf_off0 + it_off[it]) : BX_OOB;
+    pre[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(pf_x, pf_bytes), off, 0, 0));
   };
   auto stage = [&]() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the halo loads (one unconditional wait, not one per divergent item)
 #pragma unroll
     for (int it = 0; it < BX_NLOAD; ++it) {
       if ((int)threadIdx.x + it * 512 < BX_NITEMS) {
-        const bool ok = (okmask >> it) & 1u;
-        const float4 v = ok ? pre[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = pre[it];
         unsigned a1, a2, a3, b1, b2, b3;
         split3_pair(v.x, v.y, a1, a2, a3);
         split3_pair(v.z, v.w, b1, b2, b3);
-        unsigned short* p = xl + it_lds[it];
+        const int idx = (int)threadIdx.x + it * 512;
+        unsigned short* p = xl + (idx >> 3) * BX_PS + (idx & 7) * 4;
         *(uint2*)(p) = make_uint2(a1, b1);
         *(uint2*)(p + 32) = make_uint2(a2, b2);
         *(uint2*)(p + 64) = make_uint2(a3, b3);
@@ -634,24 +669,113 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   };
 
   int tile = t_lo + rank;
-  if (tile < t_hi) prefetch(tile);
-  f32x4 acc[2][2];
-  double s1 = 0.0, s2 = 0.0;
-  int stat_n = -1;
-  float bias_v[2];
+  int cn = 0, cty = 0, ctx = 0;  // coordinates of `tile`
+  if (tile < t_hi) {
+    ctx = tile % tiles_x, cty = (tile / tiles_x) % tiles_y, cn = tile / (tiles_x * tiles_y);
+    pf_setup(cn, cty, ctx, true);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) bias_v[nt] = a.bias ? a.bias[nt * 16 + li] : 0.f;
-  const long ypix = (long)a.osx * 32;
+    for (int it = 0; it < BX_NLOAD; ++it) pf_issue(it);  // in flight while the weights are copied
+  }
+  for (int i = threadIdx.x; i < BX_W_U16 / 8; i += 512) ((uint4*)wl)[i] = ((const uint4*)a.w)[i];
+
+  f32x4 acc[2][2], outv[2][2];
+  float4 prevy[4];
+  double s1 = 0.0, s2 = 0.0;
+  float t1 = 0.f, t2 = 0.f;
+  int stat_n = -1;
+  float4 bias_v[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+    bias_v[nt] = a.bias ? *(const float4*)(a.bias + nt * 16 + lg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int yrow = a.osy * a.wf * 128;  // bytes between output rows of this launch
+  const int y_lane = ((wave * 2 * a.osy * a.wf + li * a.osx) * 32 + lg * 4) * 4;
+
+  // deferred epilogue state (tile t-1): wave-uniform sample base, per-lane byte offsets of its two rows (or BX_OOB)
+  const float* prev_y = a.y;
+  unsigned prev_off[2] = {BX_OOB, BX_OOB};
+  int prev_n = -1;
+  double* red = (double*)(smem16 + BX_W_U16 + BX_X_U16);
+  auto stats_flush = [&]() {  // (block-uniform: every wave of the workgroup walks the same tile sequence)
+    // one atomic pair per workgroup: with one per wave the ~8k same-address fp64 atomics at the end of a launch cost 20 us
+    const double r1 = block_sum_d(s1, red);
+    const double r2 = block_sum_d(s2, red);
+    if (threadIdx.x == 0) {
+      atomic_add_d(a.stats + 2 * stat_n, r1);
+      atomic_add_d(a.stats + 2 * stat_n + 1, r2);
+    }
+    s1 = 0.0;
+    s2 = 0.0;
+  };
+  auto stats_sample = [&]() {  // the statistics are per sample: flush when the deferred tile starts a new one
+    if (STATS && prev_n >= 0 && prev_n != stat_n) {
+      if (stat_n >= 0) stats_flush();
+      stat_n = prev_n;
+    }
+  };
+  auto epi_load = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      prevy[i] = __builtin_bit_cast(
+          float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(prev_y, y_bytes), prev_off[i >> 1] + (i & 1) * 64, 0, 0));
+  };
+  auto epi_piece = [&](int i) {
+    const int mt = i >> 1, nt = i & 1;
+    float o[4];  // (the bias is already in: the accumulators start from it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = outv[mt][nt][r];
+    if (ACCUM) o[0] += prevy[i].x, o[1] += prevy[i].y, o[2] += prevy[i].z, o[3] += prevy[i].w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (ACT == DIS_ACT_SELU) {
+        // act_apply without a select (the compiler turns one into EXEC-masked arms): for x > 0 the second term is
+        // sa * (exp(0) - 1) = 0 exactly, for x <= 0 the first is 0, so the sum equals the selected arm bit for bit
+        const float e = __builtin_amdgcn_exp2f(fminf(o[r], 0.f) * 1.44269504088896340736f);
+        o[r] = SELU_SCALE_F * fmaxf(o[r], 0.f) + (SELU_SCALE_F * SELU_ALPHA_F) * (e - 1.f);
+      } else if (ACT == DIS_ACT_RELU) {
+        o[r] = fmaxf(o[r], 0.f);
+      }
+    }
+    const bool live = prev_off[mt] != BX_OOB;
+    u32x4 ov;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ov[r] = __float_as_uint(o[r]);
+    __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(prev_y, y_bytes), prev_off[mt] + nt * 64, 0, 0);
+    if (STATS) {
+      const float q1 = (o[0] + o[1]) + (o[2] + o[3]);
+      const float q2 = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+      t1 += live ? q1 : 0.f;
+      t2 += live ? q2 : 0.f;
+    }
+  };
 
   while (tile < t_hi) {
+    // where this tile's outputs go
+    const int vy0 = cty * BX_TR + wave * 2, vx0 = ctx * BX_TC + li;
+    const int tile_yoff = ((cty * BX_TR * a.osy + a.ooy) * a.wf + ctx * BX_TC * a.osx + a.oox) * 128 + y_lane;
+    const float* cur_y = a.y + (long)cn * a.hf * a.wf * 32;
+    unsigned cur_off[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) cur_off[mt] = (vx0 < a.wv && vy0 + mt < a.hv) ? (unsigned)(tile_yoff + mt * yrow) : BX_OOB;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){bias_v[nt].x, bias_v[nt].y, bias_v[nt].z, bias_v[nt].w};
+    stats_sample();
+    BX_T(0)
+    __syncthreads();  // every wave has finished reading the previous halo tile
+    BX_T(1)
     stage();
+    BX_T(2)
     __syncthreads();
-    if (tile + per < t_hi) prefetch(tile + per);
+    BX_T(3)
+    const int ntile = tile + per;
+    int ntx = ctx + d_tx, nty = cty + d_ty, nn = cn + d_n;
+    if (ntx >= tiles_x) ntx -= tiles_x, ++nty;
+    if (nty >= tiles_y) nty -= tiles_y, ++nn;
+    pf_setup(nn, nty, ntx, ntile < t_hi);
+    t1 = 0.f;
+    t2 = 0.f;
+    BX_T(4)
 
     s16x8 fa[2][3][2], fb[2][3][2];  // [buffer][plane][mt|nt]
     auto load_frag = [&](int tap, s16x8 (&A)[3][2], s16x8 (&B)[3][2]) {
@@ -669,7 +793,18 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       if (tap + 1 < 9) load_frag(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
+      // fence: LDS reads, MFMAs and global memory instructions keep their tap (the next tap's fragments are requested
+      // before this tap's MFMAs, loads and stores are spread over the taps); VALU and SALU may move across
+      __builtin_amdgcn_sched_barrier(0x6);
+      // memory work riding under the MFMAs (straight-line): accumulate-mode reads, the next halo, the deferred stores
+      if (ACCUM && tap == 0) epi_load();
+      // (an MFMA leaves ~8 issue cycles free, i.e. ~40 VALU per wave and tap: one epilogue piece with SELU and statistics
+      // fills a tap, so the pieces take taps 1, 3, 5, 7 and the halo loads go two by two into taps 0, 2, 4)
+      if (tap == 0 || tap == 2 || tap == 4) {
+        pf_issue(tap);
+        pf_issue(tap + 1);
+      }
+      if (tap & 1) epi_piece(tap >> 1);
       const int b = tap & 1;
       // smallest terms first
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
@@ -680,75 +815,43 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[b][PA[q]][mt]),
-                                                                 __builtin_bit_cast(bf16x8, fb[b][PB[q]][nt]),
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[b][PB[q]][nt]),
+                                                                 __builtin_bit_cast(bf16x8, fa[b][PA[q]][mt]),
                                                                  acc[mt][nt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // epilogue (as conv_fwd_kernel)
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-    if (a.stats && n != stat_n) {
-      if (stat_n >= 0) {
-        const double r1 = block_sum_d(s1, red);
-        const double r2 = block_sum_d(s2, red);
-        if (threadIdx.x == 0) {
-          atomic_add_d(a.stats + 2 * stat_n, r1);
-          atomic_add_d(a.stats + 2 * stat_n + 1, r2);
-        }
-      }
-      stat_n = n;
-      s1 = 0.0;
-      s2 = 0.0;
-    }
-    float t1 = 0.f, t2 = 0.f;
-    const int vy0 = ty * BX_TR + wave * 2, vx0 = tx * BX_TC + lg * 4;
-    float* ybase = a.y + (((long)n * a.hf + ((long)vy0 * a.osy + a.ooy)) * a.wf + ((long)vx0 * a.osx + a.oox)) * 32 + li;
-    const long yrow = (long)a.osy * a.wf * 32;
-    const bool full = (ty + 1) * BX_TR <= a.hv && (tx + 1) * BX_TC <= a.wv;
-    auto emit = [&](auto actc, auto accc) {
-      constexpr int ACT = decltype(actc)::value;
-      constexpr bool ACC = decltype(accc)::value != 0;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (full || (vy0 + mt < a.hv && vx0 + r < a.wv)) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              float* yp = ybase + mt * yrow + r * ypix + nt * 16;
-              float pre_v = acc[mt][nt][r] + bias_v[nt];
-              if (ACC) pre_v += *yp;
-              const float v = act_apply(pre_v, ACT);
-              *yp = v;
-              t1 += v;
-              t2 += v * v;
-            }
-          }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    if (a.accum) {
-      if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{}, I1{});
-      else if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{}, I1{});
-      else emit(std::integral_constant<int, DIS_ACT_NONE>{}, I1{});
-    } else {
-      if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{}, I0{});
-      else if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{}, I0{});
-      else emit(std::integral_constant<int, DIS_ACT_NONE>{}, I0{});
+      __builtin_amdgcn_sched_barrier(0x6);
     }
     s1 += (double)t1;
     s2 += (double)t2;
-    tile += per;
-  }
-  if (a.stats && stat_n >= 0) {
-    const double r1 = block_sum_d(s1, red);
-    const double r2 = block_sum_d(s2, red);
-    if (threadIdx.x == 0) {
-      atomic_add_d(a.stats + 2 * stat_n, r1);
-      atomic_add_d(a.stats + 2 * stat_n + 1, r2);
+    BX_T(5)
+
+    // hand the finished tile over to the deferred epilogue
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      prev_off[mt] = cur_off[mt];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) outv[mt][nt] = acc[mt][nt];
     }
+    prev_y = cur_y;
+    prev_n = cn;
+    cn = nn, cty = nty, ctx = ntx;
+    tile = ntile;
+    BX_T(6)
   }
+  // the last tile's epilogue
+  stats_sample();
+  t1 = 0.f;
+  t2 = 0.f;
+  if (ACCUM) epi_load();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) epi_piece(i);
+  s1 += (double)t1;
+  s2 += (double)t2;
+  if (STATS && stat_n >= 0) stats_flush();
+#ifdef BX_STAMP
+  BX_T(7)
+  if (lane == 0 && blockIdx.x < 256)
+    for (int k = 0; k < 8; ++k) bx_stamps[(blockIdx.x * 8 + wave) * 8 + k] = st_[k];
+#endif
 }
 
 extern "C" int dis_conv2d_pack_weights_bf16x3(const float* w_oihw, void* packed, int cout, int cin, int k, int mode,
@@ -778,20 +881,40 @@ extern "C" int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const
   a.xscale = nullptr;
   a.yscale = nullptr;
   if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       BX_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  // the kernel addresses x and y per sample through buffer descriptors with 31-bit byte offsets
+  if ((long)hin * win * 128 >= 0x7fff0000L || (long)hout * wout * 128 >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
   const int tiles_x = (wout + BX_TC - 1) / BX_TC, tiles_y = (hout + BX_TR - 1) / BX_TR;
   const long ntiles = (long)n * tiles_y * tiles_x;
   long grid = num_cus();
+#ifdef BX_STAMP
+  if (getenv("BX_GRID")) grid = atol(getenv("BX_GRID"));
+#endif
   if (grid > ntiles) grid = ntiles;
   if (grid >= 8) grid -= grid % 8;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(conv_bf16x3_kernel, dim3((unsigned)grid), dim3(512), BX_LDS_BYTES, (hipStream_t)stream, a);
+  static bool attr_set[12] = {};
+  auto launch = [&](auto kern, int v) -> hipError_t {
+    bool& set = attr_set[v];
+    if (!set) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_BYTES);
+      if (e != hipSuccess) return e;
+      set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), BX_LDS_BYTES, (hipStream_t)stream, a);
+    return hipSuccess;
+  };
+  hipError_t le;
+  const int variant = (a.act * 2 + a.accum) * 2 + (stats ? 1 : 0);
+  switch (variant) {
+#define BX_CASE(ACT_, ACC_, ST_) \
+  case ((ACT_)*2 + (ACC_)) * 2 + (ST_): le = launch(conv_bf16x3_kernel<ACT_, (ACC_) != 0, (ST_) != 0>, variant); break;
+    BX_CASE(DIS_ACT_NONE, 0, 0) BX_CASE(DIS_ACT_NONE, 0, 1) BX_CASE(DIS_ACT_NONE, 1, 0) BX_CASE(DIS_ACT_NONE, 1, 1)
+    BX_CASE(DIS_ACT_SELU, 0, 0) BX_CASE(DIS_ACT_SELU, 0, 1) BX_CASE(DIS_ACT_SELU, 1, 0) BX_CASE(DIS_ACT_SELU, 1, 1)
+    BX_CASE(DIS_ACT_RELU, 0, 0) BX_CASE(DIS_ACT_RELU, 0, 1) BX_CASE(DIS_ACT_RELU, 1, 0) BX_CASE(DIS_ACT_RELU, 1, 1)
+#undef BX_CASE
+    default: return DIS_ERR_UNSUPPORTED;
+  }
+  if (le != hipSuccess) return (int)le;
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
