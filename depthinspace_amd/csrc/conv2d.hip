@@ -793,9 +793,6 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       if (tap + 1 < 9) load_frag(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
-      // fence: LDS reads, MFMAs and global memory instructions keep their tap (the next tap's fragments are requested
-      // before this tap's MFMAs, loads and stores are spread over the taps); VALU and SALU may move across
-      __builtin_amdgcn_sched_barrier(0x6);
       // memory work riding under the MFMAs (straight-line): accumulate-mode reads, the next halo, the deferred stores
       if (ACCUM && tap == 0) epi_load();
       // (an MFMA leaves ~8 issue cycles free, i.e. ~40 VALU per wave and tap: one epilogue piece with SELU and statistics
@@ -818,7 +815,23 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[b][PB[q]][nt]),
                                                                  __builtin_bit_cast(bf16x8, fa[b][PA[q]][mt]),
                                                                  acc[mt][nt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0x6);
+      // issue order inside the tap: every MFMA is followed by what fits into the issue cycles it leaves free - one of
+      // the next tap's 12 fragment reads behind each of the first 12, a few VALU instructions behind each of the rest -
+      // so that a wave keeps the matrix pipe busy even while its SIMD partner waits at a barrier
+#pragma unroll
+      for (int g = 0; g < 12; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // VALU
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // the tap's halo loads
+#pragma unroll
+      for (int g = 0; g < 12; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // the tap's store
+      __builtin_amdgcn_sched_barrier(0);
     }
     s1 += (double)t1;
     s2 += (double)t2;
