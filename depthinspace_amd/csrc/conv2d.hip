@@ -1147,6 +1147,11 @@ __global__ void wgrad_reduce1_kernel(const float* __restrict__ part, float* __re
   tmp[(long)sp * elems + e] = s;
 }
 // level 2: sum the 16 partial sums and scatter into OIHW
+// grid: the element loop is grid-stride; the bias part needs cout/8 <= 16 blocks
+static inline int wgrad_reduce2_grid(long total, bool bias) {
+  const int g = dis_ew_grid(total, 256);
+  return (bias && g < 16) ? 16 : g;
+}
 __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ tmp, float* __restrict__ gw,
                                                              int cinb, int nchunk, int nsplit, int khb, int kw, int kh,
                                                              int cout, int cin_real, int partsz,
@@ -1170,21 +1175,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
     const int ky = (nsplit > 1 ? split : 0) + tap / kw, kx = tap % kw;
     if (ci < cin_real) gw[(((long)co * cin_real + ci) * kh + ky) * kw + kx] = s;
   }
-  // bias gradient (folded in here to save a launch): the last block adds the per-workgroup bias partials, thread t
-  // sums workers {t/cout, t/cout + 256/cout, ...} of channel t%cout, then a fixed-order sum over the sub-sums
-  if (bpart && blockIdx.x == gridDim.x - 1) {
+  // bias gradient (folded in here to save a launch): block b < cout/8 adds the per-workgroup bias partials of channels
+  // 8b..8b+7; thread t sums workers {t/8, t/8 + 32, ...} of channel 8b + t%8, then a fixed-order sum over the 32 sub-sums
+  if (bpart && (int)blockIdx.x * 8 < cout) {
     __shared__ float red[256];
-    const int lanes = 256 / cout;  // cout divides 256 (16, 32, 64, 128)
-    const int co = threadIdx.x % cout, sub = threadIdx.x / cout;
+    const int co = blockIdx.x * 8 + (threadIdx.x & 7), sub = threadIdx.x >> 3;
     float s = 0.f;
-    if (sub < lanes)
-      for (int k = sub; k < workers; k += lanes) s += bpart[(long)k * cout + co];
+    for (int k = sub; k < workers; k += 32) s += bpart[(long)k * cout + co];
     red[threadIdx.x] = s;
     __syncthreads();
-    if ((int)threadIdx.x < cout) {
+    if (threadIdx.x < 8) {
       float t = 0.f;
-      for (int k = 0; k < lanes; ++k) t += red[k * cout + threadIdx.x];
-      gb[threadIdx.x] = t;
+      for (int k = 0; k < 32; ++k) t += red[k * 8 + threadIdx.x];
+      gb[co] = t;
     }
   }
 }
@@ -1243,7 +1246,7 @@ static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(dis_cdiv(elems, 256), WG_RSPLIT), dim3(256), 0, s,
                      (const float*)a.part, tmp, (int)workers, elems);
   const long total = (long)C::NCHUNK * C::NSPLIT * C::MROWS * COUT;
-  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)tmp, gw,
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(wgrad_reduce2_grid(total, gb != nullptr)), dim3(256), 0, s, (const float*)tmp, gw,
                      C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, KW, KH, COUT, cin_real, C::PART,
                      (const float*)(gb ? a.bpart : nullptr), gb, (int)workers);
   DIS_CHECK_LAUNCH();
@@ -1444,7 +1447,7 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, hipStream_t s) {
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(dis_cdiv(elems, 256), WG_RSPLIT), dim3(256), 0, s,
                      (const float*)a.part, tmp, (int)workers, elems);
   const long total = (long)C::MROWS * 32;
-  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)tmp, gw,
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(wgrad_reduce2_grid(total, gb != nullptr)), dim3(256), 0, s, (const float*)tmp, gw,
                      C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, 32, 32, C::PART,
                      (const float*)(gb ? a.bpart : nullptr), gb, (int)workers);
   DIS_CHECK_LAUNCH();

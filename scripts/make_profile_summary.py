@@ -20,7 +20,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = 'conv_bf16x3_kernel(ConvArgs)'
+DOMINANT = 'conv_bf16x3_kernel<'  # every <ACT, ACCUM, STATS> instance of the template
 
 
 def main(tag):
@@ -70,14 +70,29 @@ def main(tag):
                 'HBM columns: PMC passes of one eager step (`scripts/prof_round.sh`), FETCH_SIZE doubled as '
                 'MI355X_MICROARCH.md prescribes for gfx950; wait/active columns are fractions of SQ_WAVE_CYCLES.\n\n')
         f.write('\n'.join(lines) + '\n')
-    m = mem.get(DOMINANT)
-    if m:
-        rd, wr = float(m['FETCH_SIZE']) * 2 * 1024, float(m['WRITE_SIZE']) * 1024
-        json.dump({'kernel': DOMINANT, 'hbm_bytes_per_launch': rd + wr, 'read_bytes': rd, 'write_bytes': wr,
-                   'launches_averaged': int(m['Calls']),
+    fam = [m for k, m in mem.items() if DOMINANT in k]
+    if fam:
+        calls = sum(int(m['Calls']) for m in fam)
+        rd = sum(float(m['FETCH_SIZE']) * 2 * 1024 * int(m['Calls']) for m in fam) / calls
+        wr = sum(float(m['WRITE_SIZE']) * 1024 * int(m['Calls']) for m in fam) / calls
+        json.dump({'kernel': 'conv_bf16x3_kernel<ACT, ACCUM, STATS> (all instances, launch-weighted)',
+                   'hbm_bytes_per_launch': rd + wr, 'read_bytes': rd, 'write_bytes': wr,
+                   'launches_averaged': calls,
                    'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over one eager step; '
                              'FETCH_SIZE (KB) doubled (gfx950 counts 64 B per 128-B request), WRITE_SIZE (KB) as read',
                    'source': f'profiles/{tag}_pmc_mem.csv'}, open(os.path.join(dst, 'roofline_traffic.json'), 'w'), indent=1)
+    # family totals of the template kernels (the ranking above lists every instance on its own line)
+    famt = {}
+    for r in stats:
+        base = r['Name'].split('<')[0].replace('void ', '')
+        if '<' in r['Name']:
+            e = famt.setdefault(base, [0, 0.0])
+            e[0] += int(r['Calls'])
+            e[1] += float(r['TotalDurationNs'])
+    with open(os.path.join(dst, f'{tag}_kernels.md'), 'a') as f:
+        f.write('\n## template families (all instances)\n\n| family | launches/step | ms/step | avg us |\n|---|---|---|---|\n')
+        for base, (c, t) in sorted(famt.items(), key=lambda kv: -kv[1][1])[:12]:
+            f.write(f'| `{base}` | {c/nsteps:.1f} | {t/1e6/nsteps:.3f} | {t/1e3/c:.1f} |\n')
     print('wrote profiles/', tag)
 
 
