@@ -38,6 +38,7 @@ struct ConvArgs {
   int accum;  // epilogue adds the previous contents of y (before the activation): y = act(y_old + conv + bias)
   const float* xscale;  // optional (n,hin,win,NCHUNK): input pixel x chunk multiplier applied when the halo is staged
   const float* yscale;  // optional (n,hf,wf,COUT/32): output pixel x 32-channel-group multiplier (before bias/accum)
+  int wmode;  // bf16x3 kernel only: -1 = w is packed; 0 / 1 = w is OIHW fp32, split in the kernel (forward / input gradient)
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -676,7 +677,32 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < BX_NLOAD; ++it) pf_issue(it);  // in flight while the weights are copied
   }
-  for (int i = threadIdx.x; i < BX_W_U16 / 8; i += 512) ((uint4*)wl)[i] = ((const uint4*)a.w)[i];
+  if (a.wmode < 0) {
+    for (int i = threadIdx.x; i < BX_W_U16 / 8; i += 512) ((uint4*)wl)[i] = ((const uint4*)a.w)[i];
+  } else {
+    // OIHW fp32 weights: split here instead of in a launch of their own (152 small launches per training step
+    // otherwise).  Coalesced copy into the (still unused) halo region, rows padded to 289 floats so that the gather
+    // below is conflict-free, then every thread builds (tap, 8-channel group, cout) units of 3 x 8 bf16.
+    float* ws = (float*)xl;
+    for (int i = threadIdx.x; i < 32 * 288; i += 512) ws[(i / 288) * 289 + i % 288] = a.w[i];
+    __syncthreads();
+    for (int u = threadIdx.x; u < 9 * 4 * 32; u += 512) {
+      const int co = u & 31, g = (u >> 5) & 3, tap = u >> 7;
+      unsigned pl[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c0 = g * 8 + 2 * j;
+        // mode 0: W[co][c][tap];  mode 1 (input gradient): W[c][co][8 - tap] (channels swapped, taps flipped)
+        const float v0 = a.wmode == 0 ? ws[co * 289 + c0 * 9 + tap] : ws[c0 * 289 + co * 9 + (8 - tap)];
+        const float v1 = a.wmode == 0 ? ws[co * 289 + (c0 + 1) * 9 + tap] : ws[(c0 + 1) * 289 + co * 9 + (8 - tap)];
+        split3_pair(v0, v1, pl[0][j], pl[1][j], pl[2][j]);
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *(uint4*)(wl + (((tap * 3 + p) * 4 + g) * 32 + co) * 8) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+    }
+    // (the first __syncthreads of the tile loop orders these reads of `ws` before the halo is staged over it)
+  }
 
   f32x4 acc[2][2], outv[2][2];
   float4 prevy[4];
@@ -877,9 +903,9 @@ extern "C" int dis_conv2d_pack_weights_bf16x3(const float* w_oihw, void* packed,
   return DIS_OK;
 }
 
-extern "C" int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y, double* stats,
-                                     int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act,
-                                     void* stream) {
+static int launch_conv_bf16x3(const float* x, const void* w_packed, int wmode, const float* bias, float* y, double* stats,
+                              int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act,
+                              void* stream) {
   if (!x || !w_packed || !y) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0 || pad < 0) return DIS_ERR_BAD_SHAPE;
   if (cin != 32 || cout != 32 || k != 3 || stride != 1) return DIS_ERR_UNSUPPORTED;
@@ -893,6 +919,7 @@ extern "C" int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const
   a.accum = (act & DIS_CONV_ACCUM) ? 1 : 0;
   a.xscale = nullptr;
   a.yscale = nullptr;
+  a.wmode = wmode;
   if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
   // the kernel addresses x and y per sample through buffer descriptors with 31-bit byte offsets
   if ((long)hin * win * 128 >= 0x7fff0000L || (long)hout * wout * 128 >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
@@ -930,6 +957,18 @@ extern "C" int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const
   if (le != hipSuccess) return (int)le;
   DIS_CHECK_LAUNCH();
   return DIS_OK;
+}
+
+extern "C" int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y, double* stats,
+                                     int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act,
+                                     void* stream) {
+  return launch_conv_bf16x3(x, w_packed, -1, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act, stream);
+}
+extern "C" int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, int mode, const float* bias, float* y,
+                                          double* stats, int n, int hin, int win, int cin, int cout, int k, int stride,
+                                          int pad, int act, void* stream) {
+  if (mode < 0 || mode > 1) return DIS_ERR_UNSUPPORTED;
+  return launch_conv_bf16x3(x, w_oihw, mode, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -447,9 +447,8 @@ def _conv_fwd_any(x, weight, cin_pad, mode, bias, y, stats, n, hin, win, cin, co
     """dis_conv2d_fwd, or its bf16x3 form (fp32 accuracy on the bf16 matrix cores) for the 32->32 3x3 stride-1 shape.
     `weight` is the unpacked OIHW tensor, `mode` the packing mode (0 forward, 1 stride-1 input gradient)."""
     if BF16X3 and cin == 32 and cout == 32 and k == 3 and stride == 1 and tuple(weight.shape) == (32, 32, 3, 3):
-        packed = torch.empty(9 * 3 * 4 * 32 * 8, dtype=torch.int16, device=weight.device)
-        lib.call('dis_conv2d_pack_weights_bf16x3', weight, packed, 32, 32, 3, mode)
-        lib.call('dis_conv2d_fwd_bf16x3', x, packed, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act)
+        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, weight, mode, bias, y, stats, n, hin, win, cin, cout, k, stride, pad,
+                 act)
     else:
         lib.call('dis_conv2d_fwd', x, _pack_w(weight, cin_pad, mode), bias, y, stats, n, hin, win, cin, cout, k, stride,
                  pad, act)

@@ -198,6 +198,11 @@ int dis_conv2d_fwd(const float* x, const float* w_packed, const float* bias, flo
 int dis_conv2d_pack_weights_bf16x3(const float* w_oihw, void* packed, int cout, int cin, int k, int mode, void* stream);
 int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y, double* stats, int n, int hin,
                           int win, int cin, int cout, int k, int stride, int pad, int act, void* stream);
+/* The same with the OIHW fp32 weights handed over as they are (mode 0: forward, 1: stride-1 input gradient): the kernel
+ * splits them into its LDS-resident bf16 planes itself, which saves the packing launch per convolution call. */
+int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, int mode, const float* bias, float* y, double* stats,
+                               int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act,
+                               void* stream);
 
 /* dis_conv2d_fwd with per-pixel multipliers fused into the kernel (both optional, may be NULL):
  *   xscale (n,hin,win,NCHUNK): x[pixel][chunk c] is multiplied by xscale[pixel][c] while it is staged (NCHUNK = cin/32

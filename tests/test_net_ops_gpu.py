@@ -349,3 +349,44 @@ def test_conv_bf16x3_is_fp32_accurate(h, w):
     for e32, e3 in zip(res['fp32'], res['bf16x3']):
         assert e3 < 3e-6, res
         assert e3 < 4 * e32 + 1e-7, res
+
+
+@pytest.mark.parametrize('h,w,pad', [(27, 45, 1), (16, 16, 1), (8, 19, 0), (33, 64, 2)])
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_conv_bf16x3_variants_agree(h, w, pad, act):
+    """Every form of the bf16x3 convolution kernel computes the same thing: weights handed over packed or as OIHW
+    (forward and input-gradient order), with and without GroupNorm statistics, writing or accumulating into y; ragged
+    tile edges, a single tile, no padding, padding wider than the halo."""
+    from depthinspace_amd import lib
+    g = torch.Generator().manual_seed(h * 1000 + w * 10 + act)
+    n = 3
+    x = torch.randn(n, h, w, 32, generator=g).cuda()
+    wt = (torch.randn(32, 32, 3, 3, generator=g) * 0.06).cuda()
+    b = torch.randn(32, generator=g).cuda()
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    for mode in (0, 1):
+        pk = torch.empty(9 * 3 * 4 * 32 * 8, dtype=torch.int16, device='cuda')
+        lib.call('dis_conv2d_pack_weights_bf16x3', wt, pk, 32, 32, 3, mode)
+        y0 = torch.empty(n, ho, wo, 32, device='cuda')
+        lib.call('dis_conv2d_fwd_bf16x3', x, pk, b, y0, None, n, h, w, 32, 32, 3, 1, pad, act)
+        # fp64 reference of the same convolution (mode 1 = channels swapped, taps flipped)
+        wr = wt.double().cpu() if mode == 0 else wt.double().cpu().transpose(0, 1).flip(2, 3)
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wr, b.double().cpu(), padding=pad)
+        ref = F.selu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
+        assert relerr(y0.permute(0, 3, 1, 2), ref) < 3e-6
+        # OIHW weights split inside the kernel: bit-identical to the packed path
+        y1 = torch.empty_like(y0)
+        st = torch.zeros(2 * n, dtype=torch.float64, device='cuda')
+        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, mode, b, y1, st, n, h, w, 32, 32, 3, 1, pad, act)
+        assert torch.equal(y0, y1)
+        # statistics of what was written
+        s_ref = torch.stack([y1.double().sum(dim=(1, 2, 3)), (y1.double() ** 2).sum(dim=(1, 2, 3))], dim=1).reshape(-1)
+        assert torch.allclose(st, s_ref, rtol=1e-6, atol=1e-4)
+        # accumulate mode: y = act(y_old + conv + bias)
+        yold = torch.randn(n, ho, wo, 32, generator=g).cuda()
+        y2 = yold.clone()
+        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, mode, b, y2, None, n, h, w, 32, 32, 3, 1, pad, act | 0x100)
+        pre = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wr, b.double().cpu(), padding=pad) + \
+            yold.permute(0, 3, 1, 2).double().cpu()
+        ref2 = F.selu(pre) if act == 1 else (F.relu(pre) if act == 2 else pre)
+        assert relerr(y2.permute(0, 3, 1, 2), ref2) < 3e-6
