@@ -1335,42 +1335,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   for (int j = 0; j < 9; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);  // channels 4*(tid&7).. of the gy pixels this thread stages
 
+  // halo / gradient items of this thread; pixels outside the image get an out-of-range buffer offset, which loads the
+  // zero padding without a branch, a clamp or a mask (as in conv_bf16x3_kernel)
   float4 prex[WX_NLX], preg[WX_NLG];
-  unsigned okx = 0, okg = 0;
-  int ix_r[WX_NLX], ix_c[WX_NLX], ix_lds[WX_NLX], ix_vv[WX_NLX];
+  int ix_rc[WX_NLX], ix_off[WX_NLX], ig_rc[WX_NLG], ig_off[WX_NLG];
 #pragma unroll
   for (int it = 0; it < WX_NLX; ++it) {
-    const int idx = min((int)threadIdx.x + it * 256, WX_NIX - 1);
+    const int idx = (int)threadIdx.x + it * 256;
     const int vv = idx & 7, pix = idx >> 3;
-    ix_c[it] = pix % WX_IC;
-    ix_r[it] = pix / WX_IC;
-    ix_vv[it] = vv;
-    ix_lds[it] = pix * BX_PS + vv * 4;
+    const int r = pix / WX_IC, c = pix % WX_IC;
+    ix_rc[it] = (idx < WX_NIX) ? (r | (c << 16)) : 0x4000;
+    ix_off[it] = ((r * a.win + c) * 32 + vv * 4) * 4;
   }
+#pragma unroll
+  for (int it = 0; it < WX_NLG; ++it) {
+    const int idx = threadIdx.x + it * 256;
+    const int vv = idx & 7, pix = idx >> 3;
+    ig_rc[it] = (pix >> 4) | ((pix & 15) << 16);
+    ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * 32 + vv * 4) * 4;
+  }
+  const unsigned x_bytes = (unsigned)a.hin * a.win * 128u, g_bytes = (unsigned)a.hout * a.wout * 128u;
   auto prefetch = [&](int tile) __attribute__((always_inline)) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * 8 - a.pad, ix0 = tx * 16 - a.pad;
     const float* xb = a.x + (long)n * a.hin * a.win * 32;
-    okx = 0;
-    okg = 0;
+    const int xoff0 = (iy0 * a.win + ix0) * 128;
 #pragma unroll
     for (int it = 0; it < WX_NLX; ++it) {
-      const int iy = iy0 + ix_r[it], ix = ix0 + ix_c[it];
-      const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-      const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
-      prex[it] = *(const float4*)(xb + ((long)cy * a.win + cx) * 32 + ix_vv[it] * 4);
-      okx |= (ok ? 1u : 0u) << it;
+      const int iy = iy0 + (ix_rc[it] & 0xffff), ix = ix0 + (ix_rc[it] >> 16);
+      const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+      prex[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                bx_rsrc(xb, x_bytes), ok ? (unsigned)(xoff0 + ix_off[it]) : BX_OOB, 0, 0));
     }
     const float* gb = a.gy + (long)n * a.hout * a.wout * 32;
+    const int goff0 = (ty * 8 * a.wout + tx * 16) * 128;
 #pragma unroll
     for (int it = 0; it < WX_NLG; ++it) {
-      const int idx = threadIdx.x + it * 256;
-      const int vv = idx & 7, pix = idx >> 3;
-      const int oy = ty * 8 + (pix >> 4), ox = tx * 16 + (pix & 15);
+      const int oy = ty * 8 + (ig_rc[it] & 0xffff), ox = tx * 16 + (ig_rc[it] >> 16);
       const bool ok = oy < a.hout && ox < a.wout;
-      const int cy = min(oy, a.hout - 1), cx = min(ox, a.wout - 1);
-      preg[it] = *(const float4*)(gb + ((long)cy * a.wout + cx) * 32 + vv * 4);
-      okg |= (ok ? 1u : 0u) << it;
+      preg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                bx_rsrc(gb, g_bytes), ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
     }
   };
   auto put3 = [&](unsigned short* p, const float4& v) __attribute__((always_inline)) {
@@ -1382,14 +1386,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
     *(uint2*)(p + 64) = make_uint2(a3, b3);
   };
   auto stage = [&]() __attribute__((always_inline)) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one unconditional wait for the prefetched tile
 #pragma unroll
-    for (int it = 0; it < WX_NLX; ++it)
-      if ((int)threadIdx.x + it * 256 < WX_NIX) put3(xl + ix_lds[it], ((okx >> it) & 1u) ? prex[it] : z);
+    for (int it = 0; it < WX_NLX; ++it) {
+      const int idx = (int)threadIdx.x + it * 256;
+      if (idx < WX_NIX) put3(xl + (idx >> 3) * BX_PS + (idx & 7) * 4, prex[it]);
+    }
 #pragma unroll
     for (int it = 0; it < WX_NLG; ++it) {
       const int idx = threadIdx.x + it * 256;
-      const float4 v = ((okg >> it) & 1u) ? preg[it] : z;
+      const float4 v = preg[it];
       bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
       put3(gl + (idx >> 3) * BX_PS + (idx & 7) * 4, v);
     }
@@ -1397,41 +1403,69 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
 
   if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
   auto run = [&](auto wc) __attribute__((always_inline)) {
-    constexpr int W = decltype(wc)::value, T0 = 9 * W;
+    constexpr int W = decltype(wc)::value, T0 = 9 * W, MB0 = T0 >> 1;  // 5 row blocks MB0 .. MB0+4 (1 or 2 tiles each)
+    // operand fetch (hardware-transposing reads) of k-step ks: lane group lg covers tile row 2 ks + lg/2, 8 columns
+    auto load_fb = [&](int ks, s16x8 (&F)[3][2]) __attribute__((always_inline)) {
+      const int pr = 2 * ks + (lg >> 1), pc0 = 8 * (lg & 1);
+      const unsigned short* gq = gl + (pr * 16 + pc0 + tq) * BX_PS + tp * 4;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) F[p][nb] = tr_read8(gq + p * 32 + nb * 16, gq + 4 * BX_PS + p * 32 + nb * 16);
+    };
+    auto load_fa = [&](int ks, int mb, s16x8 (&F)[3]) __attribute__((always_inline)) {
+      const int pr = 2 * ks + (lg >> 1), pc0 = 8 * (lg & 1);
+      const int tap = mb >> 1, half = mb & 1, ky = tap / 3, kx = tap - 3 * ky;
+      const unsigned short* xq = xl + ((pr + ky) * WX_IC + pc0 + tq + kx) * BX_PS + half * 16 + tp * 4;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) F[p] = tr_read8(xq + p * 32, xq + 4 * BX_PS + p * 32);
+    };
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       __syncthreads();
       stage();
       __syncthreads();
       if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
-#pragma unroll 1
-      for (int ks = 0; ks < 4; ++ks) {
-        // this lane group's 8 pixels of the k-step: tile row pr, columns pc0 .. pc0+7; tr-read rows tq (+4)
-        const int pr = 2 * ks + (lg >> 1), pc0 = 8 * (lg & 1);
-        s16x8 fb[3][2];  // gy operands: 3 planes x both cout blocks
-        const unsigned short* gq = gl + (pr * 16 + pc0 + tq) * BX_PS + tp * 4;
+      // 20 units (4 k-steps x 5 row blocks), software-pipelined: the operands of unit u+1 are requested before the
+      // MFMAs of unit u are issued, and the reads are spread between those MFMAs
+      s16x8 fa[2][3], fb[2][3][2];
+      load_fb(0, fb[0]);
+      load_fa(0, MB0, fa[0]);
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) fb[p][nb] = tr_read8(gq + p * 32 + nb * 16, gq + 4 * BX_PS + p * 32 + nb * 16);
-        s16x8 fa[3];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-          constexpr int dummy = 0;
-          const int t = T0 + j, mb = t >> 1, nb = t & 1;  // compile-time after unrolling
-          if (j == 0 || nb == 0) {
-            const int tap = mb >> 1, half = mb & 1, ky = tap / 3, kx = tap - 3 * ky;
-            const unsigned short* xq = xl + ((pr + ky) * WX_IC + pc0 + tq + kx) * BX_PS + half * 16 + tp * 4;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) fa[p] = tr_read8(xq + p * 32, xq + 4 * BX_PS + p * 32);
-          }
-          constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-          constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-          for (int q = 0; q < 6; ++q)
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[PA[q]]),
-                                                             __builtin_bit_cast(bf16x8, fb[PB[q]][nb]), acc[j], 0, 0, 0);
-          (void)dummy;
+      for (int u = 0; u < 20; ++u) {
+        const int ks = u / 5, gi = u % 5, mb = MB0 + gi;
+        int nread = 0;
+        if (u + 1 < 20) {
+          const int ks2 = (u + 1) / 5, gi2 = (u + 1) % 5;
+          if (gi2 == 0) load_fb(ks2, fb[ks2 & 1]), nread += 12;
+          load_fa(ks2, MB0 + gi2, fa[(u + 1) & 1]);
+          nread += 6;
         }
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+        constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+        int nm = 0;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const int t = 2 * mb + nb;
+          if (t >= T0 && t < T0 + 9) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+              acc[t - T0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[u & 1][PA[q]]),
+                                                                    __builtin_bit_cast(bf16x8, fb[ks & 1][PB[q]][nb]),
+                                                                    acc[t - T0], 0, 0, 0);
+            nm += 6;
+          }
+        }
+        // issue order: MFMA, then up to ceil(nread / nm) of the next unit's reads
+        const int per = nm ? (nread + nm - 1) / nm : 0;
+#pragma unroll
+        for (int g = 0; g < 12; ++g)
+          if (g < nm) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (per == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (per == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            else if (per == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // partial slab of this workgroup: [m = mb*16 + row][co]
@@ -1467,6 +1501,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
 
 static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, hipStream_t s) {
   using C = WgCfg<32, 32, 3, 3, 1>;
+  // x and gy are addressed per sample through buffer descriptors with 31-bit byte offsets
+  if ((long)a.hin * a.win * 128 >= 0x7fff0000L || (long)a.hout * a.wout * 128 >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

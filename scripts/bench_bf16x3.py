@@ -17,6 +17,14 @@ def t(act,stats,bias):
     for _ in range(50): lib.call('dis_conv2d_fwd_bf16x3',x,pk,bias,y,stats,n,h,w,32,32,3,1,1,act)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/50*1e3
+gy=torch.randn(n,h,w,32,device=dev); gw=torch.empty_like(wt); gb=torch.empty(32,device=dev)
+ws=torch.empty(lib.fn('dis_conv2d_wgrad_workspace')(32,32,3,1),device=dev)
+def tw():
+    e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): lib.call('dis_conv2d_wgrad_bf16x3',x,gy,gw,gb,ws,n,h,w,32,32,32,3,1,1)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)/50*1e3
 cfg=[('selu+stats',1,st),('selu',1,None),('none',0,None),('none+stats',0,st),('accum',0x100,None)]
 for _ in range(100): lib.call('dis_conv2d_fwd_bf16x3',x,pk,b,y,st,n,h,w,32,32,3,1,1,1)
 res={k:[] for k,_,_ in cfg}
@@ -24,4 +32,5 @@ for rep in range(5):
     for k,a,s in cfg:
         y.zero_()
         res[k].append(t(a,s,b))
+res['wgrad (3 launches)']=[tw() for _ in range(5)]
 for k in res: print(os.environ.get('TAG',''), k, ' '.join(f'{v:.1f}' for v in res[k]))
