@@ -447,7 +447,7 @@ def _conv_fwd_any(x, weight, cin_pad, mode, bias, y, stats, n, hin, win, cin, co
     """dis_conv2d_fwd, or its bf16x3 form (fp32 accuracy on the bf16 matrix cores) for 3x3 stride-1 layers with 16 / 32
     channels on both sides.  `weight` is the module's OIHW tensor, `mode` the weight order (0 forward, 1 stride-1 input
     gradient); `cin` / `cout` are the channel counts of x and y in THIS call (swapped for the input gradient)."""
-    if BF16X3 and cin in (16, 32) and cout in (16, 32) and k == 3 and stride == 1:
+    if BF16X3 and cin == 32 and cout == 32 and k == 3 and stride == 1:
         lib.call('dis_conv2d_fwd_bf16x3_oihw', x, weight, mode, weight.shape[0], weight.shape[1], bias, y, stats, n, hin,
                  win, cin, cout, k, stride, pad, act)
     else:

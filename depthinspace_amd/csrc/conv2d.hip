@@ -39,6 +39,7 @@ struct ConvArgs {
   const float* xscale;  // optional (n,hin,win,NCHUNK): input pixel x chunk multiplier applied when the halo is staged
   const float* yscale;  // optional (n,hf,wf,COUT/32): output pixel x 32-channel-group multiplier (before bias/accum)
   int wmode;  // bf16x3 kernel only: -1 = w is packed; 0 / 1 = w is OIHW fp32, split in the kernel (forward / input gradient)
+  int w_o, w_i;  // ... and its leading dims
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -550,20 +551,54 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned& p1, unsi
 #define BX_NITEMS (BX_IR * BX_IC * 8)
 #define BX_NLOAD ((BX_NITEMS + 511) / 512)
 
-// packed[tap][plane][lg][co][j] (16-bit) = plane of W(tap, ci = 8*lg + j, co);  modes as pack_weights_kernel (0 fwd, 1 dgrad)
-__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int mode) {
-  const int total = 9 * 32 * 32;
+// Compile-time geometry of conv_bf16x3_kernel<CIN, COUT, ...> (CIN, COUT in {16, 32}; 3x3, stride 1).
+//   K of one MFMA is 32: with 32 input channels a k-step is one tap, with 16 it is a PAIR of taps (lane groups 0,1 take
+//   the first tap's channels 0-7 / 8-15, groups 2,3 the second tap's; the 10th tap has zero weights).
+template <int CIN, int COUT>
+struct BxCfg {
+  static constexpr int CV = CIN / 4;                 // float4s per pixel
+  static constexpr int PS = 3 * CIN + 8;             // LDS pixel stride (16-bit units): 3 planes + 16 B pad (104 / 56:
+                                                     // both make 16 consecutive pixels hit 16 distinct 16-B bank groups)
+  static constexpr int NT = COUT / 16;               // cout blocks of a wave's tile
+  static constexpr int KS = CIN == 32 ? 9 : 5;       // k-steps
+  static constexpr int W_U16 = KS * 3 * 4 * COUT * 8;  // packed[kstep][plane][lg][co][8]
+  static constexpr int X_U16 = BX_IR * BX_IC * PS;
+  static constexpr int LDS_BYTES = W_U16 * 2 + X_U16 * 2 + 64;
+  static constexpr int NITEMS = BX_IR * BX_IC * CV;
+  static constexpr int NLOAD = (NITEMS + 511) / 512;  // 6 / 3
+  static constexpr int NPIECE = 2 * NT;               // epilogue float4 stores per lane and tile
+  // k-step of epilogue piece i and of halo load i (spread so that no k-step carries more than ~40 VALU)
+  static constexpr int piece_ks(int i) { return KS == 9 ? 2 * i + 1 : i + 1; }
+  static constexpr int load_ks(int i) { return KS == 9 ? 2 * (i / 2) : i; }
+};
+
+// packed[kstep][plane][lg][co][j] = plane of W(tap, ci, co) with (tap, ci) = (kstep, 8 lg + j) for 32 input channels and
+// (2 kstep + lg/2, 8 (lg%2) + j) for 16;  mode 0: W(tap,ci,co) = w[co][ci][tap], mode 1 (input gradient):
+// w[ci][co][8-tap].  w is OIHW with dims (wo, wi); channels beyond them (zero-padded inputs) get zero weights.
+template <int CIN, int COUT>
+__device__ __forceinline__ float bx_weight(const float* w, int stride_row, int mode, int wo, int wi, int ks, int lg, int j,
+                                           int co) {
+  const int tap = CIN == 32 ? ks : 2 * ks + (lg >> 1);
+  const int c = CIN == 32 ? 8 * lg + j : 8 * (lg & 1) + j;
+  if (tap > 8) return 0.f;
+  if (mode == 0) return (co < wo && c < wi) ? w[co * stride_row + c * 9 + tap] : 0.f;
+  return (c < wo && co < wi) ? w[c * stride_row + co * 9 + (8 - tap)] : 0.f;
+}
+
+template <int CIN, int COUT>
+__global__ void pack_weights_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int mode,
+                                           int wo, int wi) {
+  using C = BxCfg<CIN, COUT>;
+  const int total = C::KS * 4 * COUT * 8;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int co = i % 32, c = (i / 32) % 32, tap = i / 1024;
-    const int ky = tap / 3, kx = tap % 3;
-    const float v = (mode == 0) ? w[((co * 32 + c) * 3 + ky) * 3 + kx] : w[((c * 32 + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
+    const int j = i & 7, co = (i >> 3) % COUT, lg = (i / (8 * COUT)) & 3, ks = i / (32 * COUT);
+    const float v = bx_weight<CIN, COUT>(w, wi * 9, mode, wo, wi, ks, lg, j, co);
     unsigned h1, h2, h3;
     split3(v, h1, h2, h3);
-    const int lg = c >> 3, j = c & 7;
-    const int base = ((tap * 3 * 4 + lg) * 32 + co) * 8 + j;
+    const int base = ((ks * 3 * 4 + lg) * COUT + co) * 8 + j;
     packed[base] = (unsigned short)h1;
-    packed[base + 4 * 32 * 8] = (unsigned short)h2;
-    packed[base + 2 * 4 * 32 * 8] = (unsigned short)h3;
+    packed[base + 4 * COUT * 8] = (unsigned short)h2;
+    packed[base + 2 * 4 * COUT * 8] = (unsigned short)h3;
   }
 }
 
@@ -590,26 +625,28 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bx_rsrc(const void* p, unsigne
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
-// Per tile the matrix work is 216 MFMAs per wave; everything else is software-pipelined around it, and everything that
-// rides inside the MFMA loop is straight-line code (no branch: the scheduler can only interleave VALU and memory
-// instructions with MFMAs inside one basic block, and an MFMA leaves half of its issue cycles free):
-//   * the halo of tile t+1 is fetched into registers by buffer loads issued one per tap during the MFMA loop of tile t;
-//     pixels outside the image get an out-of-range buffer offset, which loads zeros (the padding) without a branch,
+// Per tile the matrix work is 216 MFMAs per wave (32 -> 32); everything else is software-pipelined around it, and
+// everything that rides inside the MFMA loop is straight-line code (no branch: the scheduler can only interleave VALU and
+// memory instructions with MFMAs inside one basic block, and an MFMA leaves half of its issue cycles free):
+//   * the halo of tile t+1 is fetched into registers by buffer loads issued during the MFMA loop of tile t; pixels
+//     outside the image get an out-of-range buffer offset, which loads zeros (the padding) without a branch,
 //   * the epilogue of tile t-1 (bias, accumulate, activation, GroupNorm statistics, float4 stores) runs from a register
-//     copy of its accumulators during the last taps of tile t; pixels outside the output get an out-of-range offset,
-//     which drops the store.
+//     copy of its accumulators during tile t; pixels outside the output get an out-of-range offset, which drops the
+//     store.
 // Only the LDS refill (two barriers + split + ds_write) stays serial.
 // The weights are the MFMA's A operand (M = cout) and the pixels its B operand (N = pixel): a lane then holds 4
 // consecutive output channels of one pixel and stores a float4.
-template <int ACT, bool ACCUM, bool STATS>
+template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS>
 __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
+  using C = BxCfg<CIN, COUT>;
+  constexpr int PS = C::PS, NT = C::NT, KS = C::KS, NLOAD = C::NLOAD, NPIECE = C::NPIECE, CV = C::CV;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
 #ifdef BX_STAMP
   unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
   unsigned short* wl = smem16;
-  unsigned short* xl = smem16 + BX_W_U16;
+  unsigned short* xl = smem16 + C::W_U16;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -623,17 +660,17 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
 
   // this thread's halo items: (row, col) inside the 18x18 halo and the byte offset from the halo's first pixel.
   // Items past the end of the halo (last round only) get a row that is outside every image.
-  float4 pre[BX_NLOAD];
-  int it_rc[BX_NLOAD], it_off[BX_NLOAD];
+  float4 pre[NLOAD];
+  int it_rc[NLOAD], it_off[NLOAD];
 #pragma unroll
-  for (int it = 0; it < BX_NLOAD; ++it) {
+  for (int it = 0; it < NLOAD; ++it) {
     const int idx = (int)threadIdx.x + it * 512;
-    const int vv = idx & 7, pix = idx >> 3;
+    const int vv = idx % CV, pix = idx / CV;
     const int r = pix / BX_IC, c = pix % BX_IC;
-    it_rc[it] = (idx < BX_NITEMS) ? (r | (c << 16)) : 0x4000;
-    it_off[it] = ((r * a.win + c) * 32 + vv * 4) * 4;
+    it_rc[it] = (idx < C::NITEMS) ? (r | (c << 16)) : 0x4000;
+    it_off[it] = ((r * a.win + c) * CIN + vv * 4) * 4;
   }
-  const unsigned x_bytes = (unsigned)a.hin * a.win * 128u, y_bytes = (unsigned)a.hf * a.wf * 128u;
+  const unsigned x_bytes = (unsigned)a.hin * a.win * (CIN * 4u), y_bytes = (unsigned)a.hf * a.wf * (COUT * 4u);
   // halo fetch state of the tile being prefetched (all wave-uniform)
   const float* pf_x = a.x;
   unsigned pf_bytes = 0;
@@ -641,8 +678,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   auto pf_setup = [&](int n, int ty, int tx, bool live) {
     pf_iy0 = ty * BX_TR - a.pad_y;
     pf_ix0 = tx * BX_TC - a.pad_x;
-    pf_off0 = (pf_iy0 * a.win + pf_ix0) * 128;
-    pf_x = a.x + (long)n * a.hin * a.win * 32;
+    pf_off0 = (pf_iy0 * a.win + pf_ix0) * (CIN * 4);
+    pf_x = a.x + (long)n * a.hin * a.win * CIN;
     pf_bytes = live ? x_bytes : 0u;  // no next tile: every load is out of range
   };
   auto pf_issue = [&](int it) {
@@ -654,17 +691,17 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   auto stage = [&]() {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the halo loads (one unconditional wait, not one per divergent item)
 #pragma unroll
-    for (int it = 0; it < BX_NLOAD; ++it) {
-      if ((int)threadIdx.x + it * 512 < BX_NITEMS) {
+    for (int it = 0; it < NLOAD; ++it) {
+      if ((int)threadIdx.x + it * 512 < C::NITEMS) {
         const float4 v = pre[it];
         unsigned a1, a2, a3, b1, b2, b3;
         split3_pair(v.x, v.y, a1, a2, a3);
         split3_pair(v.z, v.w, b1, b2, b3);
         const int idx = (int)threadIdx.x + it * 512;
-        unsigned short* p = xl + (idx >> 3) * BX_PS + (idx & 7) * 4;
+        unsigned short* p = xl + (idx / CV) * PS + (idx % CV) * 4;
         *(uint2*)(p) = make_uint2(a1, b1);
-        *(uint2*)(p + 32) = make_uint2(a2, b2);
-        *(uint2*)(p + 64) = make_uint2(a3, b3);
+        *(uint2*)(p + CIN) = make_uint2(a2, b2);
+        *(uint2*)(p + 2 * CIN) = make_uint2(a3, b3);
       }
     }
   };
@@ -675,52 +712,51 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     ctx = tile % tiles_x, cty = (tile / tiles_x) % tiles_y, cn = tile / (tiles_x * tiles_y);
     pf_setup(cn, cty, ctx, true);
 #pragma unroll
-    for (int it = 0; it < BX_NLOAD; ++it) pf_issue(it);  // in flight while the weights are copied
+    for (int it = 0; it < NLOAD; ++it) pf_issue(it);  // in flight while the weights are copied
   }
   if (a.wmode < 0) {
-    for (int i = threadIdx.x; i < BX_W_U16 / 8; i += 512) ((uint4*)wl)[i] = ((const uint4*)a.w)[i];
+    for (int i = threadIdx.x; i < C::W_U16 / 8; i += 512) ((uint4*)wl)[i] = ((const uint4*)a.w)[i];
   } else {
-    // OIHW fp32 weights: split here instead of in a launch of their own (152 small launches per training step
-    // otherwise).  Coalesced copy into the (still unused) halo region, rows padded to 289 floats so that the gather
-    // below is conflict-free, then every thread builds (tap, 8-channel group, cout) units of 3 x 8 bf16.
+    // OIHW fp32 weights: split here instead of in a launch of their own.  Coalesced copy into the (still unused) halo
+    // region, rows padded by one float so that the gather below is conflict-free, then every thread builds
+    // (k-step, lane group, cout) units of 3 x 8 bf16.
     float* ws = (float*)xl;
-    for (int i = threadIdx.x; i < 32 * 288; i += 512) ws[(i / 288) * 289 + i % 288] = a.w[i];
+    const int row = a.w_i * 9, nw = a.w_o * row;
+    for (int i = threadIdx.x; i < nw; i += 512) ws[(i / row) * (row + 1) + i % row] = a.w[i];
     __syncthreads();
-    for (int u = threadIdx.x; u < 9 * 4 * 32; u += 512) {
-      const int co = u & 31, g = (u >> 5) & 3, tap = u >> 7;
+    for (int u = threadIdx.x; u < KS * 4 * COUT; u += 512) {
+      const int co = u % COUT, g = (u / COUT) & 3, ks = u / (4 * COUT);
       unsigned pl[3][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int c0 = g * 8 + 2 * j;
-        // mode 0: W[co][c][tap];  mode 1 (input gradient): W[c][co][8 - tap] (channels swapped, taps flipped)
-        const float v0 = a.wmode == 0 ? ws[co * 289 + c0 * 9 + tap] : ws[c0 * 289 + co * 9 + (8 - tap)];
-        const float v1 = a.wmode == 0 ? ws[co * 289 + (c0 + 1) * 9 + tap] : ws[(c0 + 1) * 289 + co * 9 + (8 - tap)];
+        const float v0 = bx_weight<CIN, COUT>(ws, row + 1, a.wmode, a.w_o, a.w_i, ks, g, 2 * j, co);
+        const float v1 = bx_weight<CIN, COUT>(ws, row + 1, a.wmode, a.w_o, a.w_i, ks, g, 2 * j + 1, co);
         split3_pair(v0, v1, pl[0][j], pl[1][j], pl[2][j]);
       }
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        *(uint4*)(wl + (((tap * 3 + p) * 4 + g) * 32 + co) * 8) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+        *(uint4*)(wl + (((ks * 3 + p) * 4 + g) * COUT + co) * 8) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
     }
     // (the first __syncthreads of the tile loop orders these reads of `ws` before the halo is staged over it)
   }
 
-  f32x4 acc[2][2], outv[2][2];
-  float4 prevy[4];
+  f32x4 acc[2][NT], outv[2][NT];
+  float4 prevy[NPIECE];
   double s1 = 0.0, s2 = 0.0;
   float t1 = 0.f, t2 = 0.f;
   int stat_n = -1;
-  float4 bias_v[2];
+  float4 bias_v[NT];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+  for (int nt = 0; nt < NT; ++nt)
     bias_v[nt] = a.bias ? *(const float4*)(a.bias + nt * 16 + lg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int yrow = a.osy * a.wf * 128;  // bytes between output rows of this launch
-  const int y_lane = ((wave * 2 * a.osy * a.wf + li * a.osx) * 32 + lg * 4) * 4;
+  const int yrow = a.osy * a.wf * (COUT * 4);  // bytes between output rows of this launch
+  const int y_lane = ((wave * 2 * a.osy * a.wf + li * a.osx) * COUT + lg * 4) * 4;
 
   // deferred epilogue state (tile t-1): wave-uniform sample base, per-lane byte offsets of its two rows (or BX_OOB)
   const float* prev_y = a.y;
   unsigned prev_off[2] = {BX_OOB, BX_OOB};
   int prev_n = -1;
-  double* red = (double*)(smem16 + BX_W_U16 + BX_X_U16);
+  double* red = (double*)(smem16 + C::W_U16 + C::X_U16);
   auto stats_flush = [&]() {  // (block-uniform: every wave of the workgroup walks the same tile sequence)
     // one atomic pair per workgroup: with one per wave the ~8k same-address fp64 atomics at the end of a launch cost 20 us
     const double r1 = block_sum_d(s1, red);
@@ -740,12 +776,12 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   };
   auto epi_load = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      prevy[i] = __builtin_bit_cast(
-          float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(prev_y, y_bytes), prev_off[i >> 1] + (i & 1) * 64, 0, 0));
+    for (int i = 0; i < NPIECE; ++i)
+      prevy[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                bx_rsrc(prev_y, y_bytes), prev_off[i / NT] + (i % NT) * 64, 0, 0));
   };
   auto epi_piece = [&](int i) {
-    const int mt = i >> 1, nt = i & 1;
+    const int mt = i / NT, nt = i % NT;
     float o[4];  // (the bias is already in: the accumulators start from it)
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = outv[mt][nt][r];
@@ -774,18 +810,22 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     }
   };
 
+  // per-lane LDS offsets (16-bit units) of the pixel operand: row of the wave, column li, channel group of the lane
+  const int xa_lane = (wave * 2 * BX_IC + li) * PS + (CIN == 32 ? lg * 8 : (lg & 1) * 8);
+  const bool hi_tap = (lg >> 1) != 0;  // CIN == 16: lane groups 2, 3 take the second tap of the pair
+
   while (tile < t_hi) {
     // where this tile's outputs go
     const int vy0 = cty * BX_TR + wave * 2, vx0 = ctx * BX_TC + li;
-    const int tile_yoff = ((cty * BX_TR * a.osy + a.ooy) * a.wf + ctx * BX_TC * a.osx + a.oox) * 128 + y_lane;
-    const float* cur_y = a.y + (long)cn * a.hf * a.wf * 32;
+    const int tile_yoff = ((cty * BX_TR * a.osy + a.ooy) * a.wf + ctx * BX_TC * a.osx + a.oox) * (COUT * 4) + y_lane;
+    const float* cur_y = a.y + (long)cn * a.hf * a.wf * COUT;
     unsigned cur_off[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) cur_off[mt] = (vx0 < a.wv && vy0 + mt < a.hv) ? (unsigned)(tile_yoff + mt * yrow) : BX_OOB;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){bias_v[nt].x, bias_v[nt].y, bias_v[nt].z, bias_v[nt].w};
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){bias_v[nt].x, bias_v[nt].y, bias_v[nt].z, bias_v[nt].w};
     stats_sample();
     BX_T(0)
     __syncthreads();  // every wave has finished reading the previous halo tile
@@ -803,32 +843,36 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     t2 = 0.f;
     BX_T(4)
 
-    s16x8 fa[2][3][2], fb[2][3][2];  // [buffer][plane][mt|nt]
-    auto load_frag = [&](int tap, s16x8 (&A)[3][2], s16x8 (&B)[3][2]) {
-      const int ky = tap / 3, kx = tap % 3;
+    s16x8 fa[2][3][2], fb[2][3][NT];  // [buffer][plane][mt|nt]
+    auto load_frag = [&](int ks, s16x8 (&A)[3][2], s16x8 (&B)[3][NT]) {
+      int xoff;
+      if (CIN == 32) {
+        xoff = ((ks / 3) * BX_IC + ks % 3) * PS;
+      } else {
+        const int t0 = 2 * ks, t1_ = 2 * ks + 1 > 8 ? 8 : 2 * ks + 1;  // (the 10th tap reads tap 8's pixels: zero weights)
+        xoff = hi_tap ? ((t1_ / 3) * BX_IC + t1_ % 3) * PS : ((t0 / 3) * BX_IC + t0 % 3) * PS;
+      }
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          A[p][mt] = *(const s16x8*)(xl + ((wave * 2 + mt + ky) * BX_IC + li + kx) * BX_PS + p * 32 + lg * 8);
+        for (int mt = 0; mt < 2; ++mt) A[p][mt] = *(const s16x8*)(xl + xa_lane + xoff + mt * BX_IC * PS + p * CIN);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) B[p][nt] = *(const s16x8*)(wl + (((tap * 3 + p) * 4 + lg) * 32 + nt * 16 + li) * 8);
+        for (int nt = 0; nt < NT; ++nt) B[p][nt] = *(const s16x8*)(wl + (((ks * 3 + p) * 4 + lg) * COUT + nt * 16 + li) * 8);
       }
     };
     load_frag(0, fa[0], fb[0]);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      if (tap + 1 < 9) load_frag(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) load_frag(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
       // memory work riding under the MFMAs (straight-line): accumulate-mode reads, the next halo, the deferred stores
-      if (ACCUM && tap == 0) epi_load();
-      // (an MFMA leaves ~8 issue cycles free, i.e. ~40 VALU per wave and tap: one epilogue piece with SELU and statistics
-      // fills a tap, so the pieces take taps 1, 3, 5, 7 and the halo loads go two by two into taps 0, 2, 4)
-      if (tap == 0 || tap == 2 || tap == 4) {
-        pf_issue(tap);
-        pf_issue(tap + 1);
-      }
-      if (tap & 1) epi_piece(tap >> 1);
-      const int b = tap & 1;
+      if (ACCUM && ks == 0) epi_load();
+#pragma unroll
+      for (int it = 0; it < NLOAD; ++it)
+        if (C::load_ks(it) == ks) pf_issue(it);
+#pragma unroll
+      for (int i = 0; i < NPIECE; ++i)
+        if (C::piece_ks(i) == ks) epi_piece(i);
+      const int b = ks & 1;
       // smallest terms first
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
       constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
@@ -837,26 +881,25 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[b][PB[q]][nt]),
                                                                  __builtin_bit_cast(bf16x8, fa[b][PA[q]][mt]),
                                                                  acc[mt][nt], 0, 0, 0);
-      // issue order inside the tap: every MFMA is followed by what fits into the issue cycles it leaves free - one of
-      // the next tap's 12 fragment reads behind each of the first 12, a few VALU instructions behind each of the rest -
-      // so that a wave keeps the matrix pipe busy even while its SIMD partner waits at a barrier
+      // issue order inside the k-step: every MFMA is followed by what fits into the issue cycles it leaves free - one
+      // of the next k-step's fragment reads behind each of the first MFMAs, a few VALU instructions behind the rest
+      constexpr int NM = 12 * NT, NR = 3 * (2 + NT);
 #pragma unroll
-      for (int g = 0; g < 12; ++g) {
+      for (int g = 0; g < NM; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // VALU
+        if (g < NR) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // VALU
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+        if (g == NR) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // the k-step's halo loads
       }
-      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // the tap's halo loads
-#pragma unroll
-      for (int g = 0; g < 12; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // the tap's store
+      __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // the k-step's store
       __builtin_amdgcn_sched_barrier(0);
     }
     s1 += (double)t1;
@@ -868,7 +911,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     for (int mt = 0; mt < 2; ++mt) {
       prev_off[mt] = cur_off[mt];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) outv[mt][nt] = acc[mt][nt];
+      for (int nt = 0; nt < NT; ++nt) outv[mt][nt] = acc[mt][nt];
     }
     prev_y = cur_y;
     prev_n = cn;
@@ -882,7 +925,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   t2 = 0.f;
   if (ACCUM) epi_load();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) epi_piece(i);
+  for (int i = 0; i < NPIECE; ++i) epi_piece(i);
   s1 += (double)t1;
   s2 += (double)t2;
   if (STATS && stat_n >= 0) stats_flush();
@@ -893,26 +936,69 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
 #endif
 }
 
+// (cin, cout) -> kernel instance
+template <int CIN, int COUT>
+static hipError_t bx_launch(const ConvArgs& a, bool stats, long grid, hipStream_t stream) {
+  using C = BxCfg<CIN, COUT>;
+  const int variant = (a.act * 2 + a.accum) * 2 + (stats ? 1 : 0);
+  static bool attr_set[12] = {};
+  auto launch = [&](auto kern) -> hipError_t {
+    bool& set = attr_set[variant];
+    if (!set) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+      if (e != hipSuccess) return e;
+      set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
+    return hipSuccess;
+  };
+  switch (variant) {
+#define BX_CASE(ACT_, ACC_, ST_) \
+  case ((ACT_)*2 + (ACC_)) * 2 + (ST_): return launch(conv_bf16x3_kernel<CIN, COUT, ACT_, (ACC_) != 0, (ST_) != 0>);
+    BX_CASE(DIS_ACT_NONE, 0, 0) BX_CASE(DIS_ACT_NONE, 0, 1) BX_CASE(DIS_ACT_NONE, 1, 0) BX_CASE(DIS_ACT_NONE, 1, 1)
+    BX_CASE(DIS_ACT_SELU, 0, 0) BX_CASE(DIS_ACT_SELU, 0, 1) BX_CASE(DIS_ACT_SELU, 1, 0) BX_CASE(DIS_ACT_SELU, 1, 1)
+    BX_CASE(DIS_ACT_RELU, 0, 0) BX_CASE(DIS_ACT_RELU, 0, 1) BX_CASE(DIS_ACT_RELU, 1, 0) BX_CASE(DIS_ACT_RELU, 1, 1)
+#undef BX_CASE
+  }
+  return hipErrorInvalidValue;
+}
+
+static bool bx_shape_ok(int cin, int cout, int k, int stride) {
+  return (cin == 16 || cin == 32) && (cout == 16 || cout == 32) && k == 3 && stride == 1;
+}
+
+extern "C" long dis_conv2d_pack_bf16x3_size(int cin, int cout) {
+  if (!bx_shape_ok(cin, cout, 3, 1)) return DIS_ERR_UNSUPPORTED;
+  return (cin == 32 ? 9 : 5) * 3 * 4 * cout * 8;  // 16-bit words
+}
+
+/* w_oihw has dims (w_o, w_i, 3, 3); mode 0: conv w_i -> w_o channels (cin >= w_i zero-padded inputs, cout == w_o);
+ * mode 1: its input gradient (cin == w_o, cout >= w_i). */
 extern "C" int dis_conv2d_pack_weights_bf16x3(const float* w_oihw, void* packed, int cout, int cin, int k, int mode,
                                               void* stream) {
   if (!w_oihw || !packed) return DIS_ERR_NULL;
-  if (cout != 32 || cin != 32 || k != 3 || mode < 0 || mode > 1) return DIS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(pack_weights_bf16x3_kernel, dim3(36), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                     (unsigned short*)packed, mode);
+  if (!bx_shape_ok(cin, cout, k, 1) || mode < 0 || mode > 1) return DIS_ERR_UNSUPPORTED;
+  const int wo = mode == 0 ? cout : cin, wi = mode == 0 ? cin : cout;
+  unsigned short* pk = (unsigned short*)packed;
+  hipStream_t s = (hipStream_t)stream;
+  if (cin == 32 && cout == 32) hipLaunchKernelGGL((pack_weights_bf16x3_kernel<32, 32>), dim3(36), dim3(256), 0, s, w_oihw, pk, mode, wo, wi);
+  else if (cin == 16 && cout == 16) hipLaunchKernelGGL((pack_weights_bf16x3_kernel<16, 16>), dim3(36), dim3(256), 0, s, w_oihw, pk, mode, wo, wi);
+  else if (cin == 16 && cout == 32) hipLaunchKernelGGL((pack_weights_bf16x3_kernel<16, 32>), dim3(36), dim3(256), 0, s, w_oihw, pk, mode, wo, wi);
+  else hipLaunchKernelGGL((pack_weights_bf16x3_kernel<32, 16>), dim3(36), dim3(256), 0, s, w_oihw, pk, mode, wo, wi);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
 
-static int launch_conv_bf16x3(const float* x, const void* w_packed, int wmode, const float* bias, float* y, double* stats,
-                              int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act,
-                              void* stream) {
-  if (!x || !w_packed || !y) return DIS_ERR_NULL;
+static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o, int w_i, const float* bias, float* y,
+                              double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad,
+                              int act, void* stream) {
+  if (!x || !w || !y) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0 || pad < 0) return DIS_ERR_BAD_SHAPE;
-  if (cin != 32 || cout != 32 || k != 3 || stride != 1) return DIS_ERR_UNSUPPORTED;
+  if (!bx_shape_ok(cin, cout, k, stride)) return DIS_ERR_UNSUPPORTED;
   const int hout = hin + 2 * pad - 2, wout = win + 2 * pad - 2;
   if (hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
   ConvArgs a;
-  a.x = x; a.w = (const float*)w_packed; a.bias = bias; a.y = y; a.stats = stats;
+  a.x = x; a.w = (const float*)w; a.bias = bias; a.y = y; a.stats = stats;
   a.n = n; a.hin = hin; a.win = win; a.hv = hout; a.wv = wout; a.pad_y = pad; a.pad_x = pad;
   a.hf = hout; a.wf = wout; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
   a.act = act & 0xff;
@@ -920,9 +1006,11 @@ static int launch_conv_bf16x3(const float* x, const void* w_packed, int wmode, c
   a.xscale = nullptr;
   a.yscale = nullptr;
   a.wmode = wmode;
+  a.w_o = w_o;
+  a.w_i = w_i;
   if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
   // the kernel addresses x and y per sample through buffer descriptors with 31-bit byte offsets
-  if ((long)hin * win * 128 >= 0x7fff0000L || (long)hout * wout * 128 >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
+  if ((long)hin * win * cin * 4 >= 0x7fff0000L || (long)hout * wout * cout * 4 >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
   const int tiles_x = (wout + BX_TC - 1) / BX_TC, tiles_y = (hout + BX_TR - 1) / BX_TR;
   const long ntiles = (long)n * tiles_y * tiles_x;
   long grid = num_cus();
@@ -932,28 +1020,11 @@ static int launch_conv_bf16x3(const float* x, const void* w_packed, int wmode, c
   if (grid > ntiles) grid = ntiles;
   if (grid >= 8) grid -= grid % 8;
   if (grid < 1) grid = 1;
-  static bool attr_set[12] = {};
-  auto launch = [&](auto kern, int v) -> hipError_t {
-    bool& set = attr_set[v];
-    if (!set) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_BYTES);
-      if (e != hipSuccess) return e;
-      set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), BX_LDS_BYTES, (hipStream_t)stream, a);
-    return hipSuccess;
-  };
   hipError_t le;
-  const int variant = (a.act * 2 + a.accum) * 2 + (stats ? 1 : 0);
-  switch (variant) {
-#define BX_CASE(ACT_, ACC_, ST_) \
-  case ((ACT_)*2 + (ACC_)) * 2 + (ST_): le = launch(conv_bf16x3_kernel<ACT_, (ACC_) != 0, (ST_) != 0>, variant); break;
-    BX_CASE(DIS_ACT_NONE, 0, 0) BX_CASE(DIS_ACT_NONE, 0, 1) BX_CASE(DIS_ACT_NONE, 1, 0) BX_CASE(DIS_ACT_NONE, 1, 1)
-    BX_CASE(DIS_ACT_SELU, 0, 0) BX_CASE(DIS_ACT_SELU, 0, 1) BX_CASE(DIS_ACT_SELU, 1, 0) BX_CASE(DIS_ACT_SELU, 1, 1)
-    BX_CASE(DIS_ACT_RELU, 0, 0) BX_CASE(DIS_ACT_RELU, 0, 1) BX_CASE(DIS_ACT_RELU, 1, 0) BX_CASE(DIS_ACT_RELU, 1, 1)
-#undef BX_CASE
-    default: return DIS_ERR_UNSUPPORTED;
-  }
+  if (cin == 32 && cout == 32) le = bx_launch<32, 32>(a, stats != nullptr, grid, (hipStream_t)stream);
+  else if (cin == 16 && cout == 16) le = bx_launch<16, 16>(a, stats != nullptr, grid, (hipStream_t)stream);
+  else if (cin == 16 && cout == 32) le = bx_launch<16, 32>(a, stats != nullptr, grid, (hipStream_t)stream);
+  else le = bx_launch<32, 16>(a, stats != nullptr, grid, (hipStream_t)stream);
   if (le != hipSuccess) return (int)le;
   DIS_CHECK_LAUNCH();
   return DIS_OK;
@@ -962,14 +1033,18 @@ static int launch_conv_bf16x3(const float* x, const void* w_packed, int wmode, c
 extern "C" int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y, double* stats,
                                      int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act,
                                      void* stream) {
-  return launch_conv_bf16x3(x, w_packed, -1, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act, stream);
+  return launch_conv_bf16x3(x, w_packed, -1, 0, 0, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act, stream);
 }
-extern "C" int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, int mode, const float* bias, float* y,
-                                          double* stats, int n, int hin, int win, int cin, int cout, int k, int stride,
-                                          int pad, int act, void* stream) {
-  if (mode < 0 || mode > 1) return DIS_ERR_UNSUPPORTED;
-  return launch_conv_bf16x3(x, w_oihw, mode, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act, stream);
+/* w_oihw (w_o, w_i, 3, 3) as stored by the module: mode 0 needs cout == w_o and cin >= w_i (zero-padded input channels),
+ * mode 1 (input gradient of that conv) cin == w_o and cout >= w_i. */
+extern "C" int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, int mode, int w_o, int w_i, const float* bias,
+                                          float* y, double* stats, int n, int hin, int win, int cin, int cout, int k,
+                                          int stride, int pad, int act, void* stream) {
+  if (mode < 0 || mode > 1 || w_o <= 0 || w_i <= 0 || w_o > 32 || w_i > 32) return DIS_ERR_UNSUPPORTED;
+  if (mode == 0 ? (cout != w_o || cin < w_i) : (cin != w_o || cout < w_i)) return DIS_ERR_BAD_SHAPE;
+  return launch_conv_bf16x3(x, w_oihw, mode, w_o, w_i, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act, stream);
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // weight gradient:  dW[(tap,ci)][co] = sum_pixels X[pixel+tap][ci] * G[pixel][co]

@@ -49,7 +49,8 @@ SIGS = {
     'dis_conv2d_fwd': 'pppppiiiiiiiiip',
     'dis_conv2d_pack_weights_bf16x3': 'ppiiiip',
     'dis_conv2d_fwd_bf16x3': 'pppppiiiiiiiiip',
-    'dis_conv2d_fwd_bf16x3_oihw': 'ppipppiiiiiiiiip',
+    'dis_conv2d_fwd_bf16x3_oihw': 'ppiiipppiiiiiiiiip',
+    'dis_conv2d_pack_bf16x3_size': 'ii',
     'dis_conv2d_fwd_scaled': 'ppppppp' + 'iiiiiiiii' + 'p',
     'dis_conv2d_wgrad_scaled': 'pppppp' + 'iiiiiiiii' + 'p',
     'dis_slot_weights': 'pplip',
@@ -81,7 +82,8 @@ SIGS = {
     'dis_adam_step': 'pppplffffifp',
 }
 _RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
-             'dis_colsum_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_gather_csr_workspace'}
+             'dis_colsum_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_gather_csr_workspace',
+             'dis_conv2d_pack_bf16x3_size'}
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
 _lib = None

@@ -191,18 +191,24 @@ int dis_conv2d_pack_weights(const float* w_oihw, float* packed, int cout, int ci
  * The stride-1 input gradient is the same call on gy with mode-1 packed weights (cin/cout swapped). */
 int dis_conv2d_fwd(const float* x, const float* w_packed, const float* bias, float* y, double* stats, int n,
                    int hin, int win, int cin, int cout, int k, int stride, int pad, int act, void* stream);
-/* The same convolution for the dominant FuseNet shape (cin = cout = 32, k = 3, stride 1; also its input gradient with
- * mode-1 weights) computed on the bf16 matrix cores at fp32 accuracy: every operand is split into three bf16 terms
- * (24 significant bits) and each product is accumulated as six bf16 x bf16 terms in the fp32 MFMA accumulator; the
- * dropped terms are <= 2^-24 relative, one fp32 rounding.  `packed` holds 9*3*4*32*8 16-bit words. */
+/* The same convolution for 3x3 stride-1 layers with 16 or 32 input and output channels (the FuseNet ResNet blocks; also
+ * their input gradients with mode-1 weights) computed on the bf16 matrix cores at fp32 accuracy: every operand is split
+ * into three bf16 terms (24 significant bits) and each product is accumulated as six bf16 x bf16 terms in the fp32 MFMA
+ * accumulator; the dropped terms are <= 2^-24 relative, one fp32 rounding.
+ * dis_conv2d_pack_bf16x3_size(cin, cout): 16-bit words of `packed` (negative: unsupported shape).
+ * dis_conv2d_pack_weights_bf16x3: w_oihw is (cout, cin, 3, 3) for mode 0 and (cin, cout, 3, 3) for mode 1 (the weights
+ * of the convolution whose input gradient is computed: channels swapped, taps flipped). */
+long dis_conv2d_pack_bf16x3_size(int cin, int cout);
 int dis_conv2d_pack_weights_bf16x3(const float* w_oihw, void* packed, int cout, int cin, int k, int mode, void* stream);
 int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y, double* stats, int n, int hin,
                           int win, int cin, int cout, int k, int stride, int pad, int act, void* stream);
-/* The same with the OIHW fp32 weights handed over as they are (mode 0: forward, 1: stride-1 input gradient): the kernel
- * splits them into its LDS-resident bf16 planes itself, which saves the packing launch per convolution call. */
-int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, int mode, const float* bias, float* y, double* stats,
-                               int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act,
-                               void* stream);
+/* The same with the module's OIHW fp32 weights (w_o, w_i, 3, 3) handed over as they are: the kernel splits them into its
+ * LDS-resident bf16 planes itself, which saves the packing launch per convolution call.  mode 0: forward (cout == w_o,
+ * cin >= w_i: x may carry zero-padded extra channels); mode 1: input gradient of that convolution (cin == w_o,
+ * cout >= w_i). */
+int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, int mode, int w_o, int w_i, const float* bias, float* y,
+                               double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad,
+                               int act, void* stream);
 
 /* dis_conv2d_fwd with per-pixel multipliers fused into the kernel (both optional, may be NULL):
  *   xscale (n,hin,win,NCHUNK): x[pixel][chunk c] is multiplied by xscale[pixel][c] while it is staged (NCHUNK = cin/32

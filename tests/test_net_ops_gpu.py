@@ -353,22 +353,25 @@ def test_conv_bf16x3_is_fp32_accurate(h, w):
 
 @pytest.mark.parametrize('h,w,pad', [(27, 45, 1), (16, 16, 1), (8, 19, 0), (33, 64, 2)])
 @pytest.mark.parametrize('act', [0, 1, 2])
-def test_conv_bf16x3_variants_agree(h, w, pad, act):
-    """Every form of the bf16x3 convolution kernel computes the same thing: weights handed over packed or as OIHW
-    (forward and input-gradient order), with and without GroupNorm statistics, writing or accumulating into y; ragged
-    tile edges, a single tile, no padding, padding wider than the halo."""
+@pytest.mark.parametrize('cin,cout', [(32, 32), (16, 16), (16, 32), (32, 16)])
+def test_conv_bf16x3_variants_agree(h, w, pad, act, cin, cout):
+    """Every form of the bf16x3 convolution kernel computes the same thing: 16 / 32 channels on either side, weights
+    handed over packed or as OIHW (forward and input-gradient order), with and without GroupNorm statistics, writing or
+    accumulating into y; ragged tile edges, a single tile, no padding, padding wider than the halo."""
     from depthinspace_amd import lib
-    g = torch.Generator().manual_seed(h * 1000 + w * 10 + act)
+    g = torch.Generator().manual_seed(h * 1000 + w * 10 + act + cin * 7 + cout)
     n = 3
-    x = torch.randn(n, h, w, 32, generator=g).cuda()
-    wt = (torch.randn(32, 32, 3, 3, generator=g) * 0.06).cuda()
-    b = torch.randn(32, generator=g).cuda()
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    b = torch.randn(cout, generator=g).cuda()
     ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
     for mode in (0, 1):
-        pk = torch.empty(9 * 3 * 4 * 32 * 8, dtype=torch.int16, device='cuda')
-        lib.call('dis_conv2d_pack_weights_bf16x3', wt, pk, 32, 32, 3, mode)
-        y0 = torch.empty(n, ho, wo, 32, device='cuda')
-        lib.call('dis_conv2d_fwd_bf16x3', x, pk, b, y0, None, n, h, w, 32, 32, 3, 1, pad, act)
+        # the module's weight: (cout, cin) for the forward conv, (cin, cout) for the conv whose input gradient this is
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.06).cuda() if mode == 0 else \
+            (torch.randn(cin, cout, 3, 3, generator=g) * 0.06).cuda()
+        pk = torch.empty(lib.fn('dis_conv2d_pack_bf16x3_size')(cin, cout), dtype=torch.int16, device='cuda')
+        lib.call('dis_conv2d_pack_weights_bf16x3', wt, pk, cout, cin, 3, mode)
+        y0 = torch.empty(n, ho, wo, cout, device='cuda')
+        lib.call('dis_conv2d_fwd_bf16x3', x, pk, b, y0, None, n, h, w, cin, cout, 3, 1, pad, act)
         # fp64 reference of the same convolution (mode 1 = channels swapped, taps flipped)
         wr = wt.double().cpu() if mode == 0 else wt.double().cpu().transpose(0, 1).flip(2, 3)
         ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wr, b.double().cpu(), padding=pad)
@@ -377,16 +380,32 @@ def test_conv_bf16x3_variants_agree(h, w, pad, act):
         # OIHW weights split inside the kernel: bit-identical to the packed path
         y1 = torch.empty_like(y0)
         st = torch.zeros(2 * n, dtype=torch.float64, device='cuda')
-        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, mode, b, y1, st, n, h, w, 32, 32, 3, 1, pad, act)
+        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, mode, wt.shape[0], wt.shape[1], b, y1, st, n, h, w, cin, cout, 3, 1,
+                 pad, act)
         assert torch.equal(y0, y1)
         # statistics of what was written
         s_ref = torch.stack([y1.double().sum(dim=(1, 2, 3)), (y1.double() ** 2).sum(dim=(1, 2, 3))], dim=1).reshape(-1)
         assert torch.allclose(st, s_ref, rtol=1e-6, atol=1e-4)
         # accumulate mode: y = act(y_old + conv + bias)
-        yold = torch.randn(n, ho, wo, 32, generator=g).cuda()
+        yold = torch.randn(n, ho, wo, cout, generator=g).cuda()
         y2 = yold.clone()
-        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, mode, b, y2, None, n, h, w, 32, 32, 3, 1, pad, act | 0x100)
+        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, mode, wt.shape[0], wt.shape[1], b, y2, None, n, h, w, cin, cout, 3,
+                 1, pad, act | 0x100)
         pre = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wr, b.double().cpu(), padding=pad) + \
             yold.permute(0, 3, 1, 2).double().cpu()
         ref2 = F.selu(pre) if act == 1 else (F.relu(pre) if act == 2 else pre)
         assert relerr(y2.permute(0, 3, 1, 2), ref2) < 3e-6
+
+
+def test_conv_bf16x3_zero_padded_input_channels():
+    """First-layer case: x carries 16 channels of which the module's conv reads the first 5 (w_i < cin)."""
+    from depthinspace_amd import lib
+    g = torch.Generator().manual_seed(5)
+    n, h, w = 2, 21, 35
+    x = torch.randn(n, h, w, 16, generator=g).cuda()
+    wt = (torch.randn(16, 5, 3, 3, generator=g) * 0.1).cuda()
+    b = torch.randn(16, generator=g).cuda()
+    y = torch.empty(n, h, w, 16, device='cuda')
+    lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, 0, 16, 5, b, y, None, n, h, w, 16, 16, 3, 1, 1, 0)
+    ref = F.conv2d(x[..., :5].permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), b.double().cpu(), padding=1)
+    assert relerr(y.permute(0, 3, 1, 2), ref) < 3e-6
