@@ -1368,24 +1368,29 @@ static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16x3 weight gradient of the 32 -> 32 3x3 stride-1 convolution (same operand split as conv_bf16x3_kernel).
+// bf16x3 weight gradient of the 3x3 stride-1 convolutions with 16 / 32 channels on either side (same operand split as
+// conv_bf16x3_kernel).
 // GEMM view dW[(tap,ci)][co] = sum_pixels X[pixel+tap][ci] * G[pixel][co]: the contraction runs over PIXELS, so both
 // MFMA operands need, per lane, 8 consecutive pixels of one channel.  The LDS images stay [pixel][plane][channel]
 // (written exactly like the forward kernel's halo tile) and the operands are fetched with the hardware transposing
 // read ds_read_b64_tr_b16 (4 pixel rows x 16 channels per 16-lane group, delivered channel-major).
-// Workgroup = 4 waves, tile = 8x16 output pixels (4 k-steps of 32 pixels); the 36 accumulator tiles (18 (tap,ci/16)
-// row blocks x 2 cout blocks) are split over the waves, 9 each, and stay in registers across all tiles; no cross-wave
-// reduction.  Partial slabs / bias partials use the layout of conv_wgrad_kernel, so its reducers finish the job.
+// Workgroup = 4 waves, tile = 8x16 output pixels (4 k-steps of 32 pixels); the (9 CIN/16) x (COUT/16) accumulator tiles
+// are split over the waves (9 each for 32 -> 32) and stay in registers across all tiles; no cross-wave reduction.
+// Partial slabs / bias partials use the layout of conv_wgrad_kernel, so its reducers finish the job.
 // ------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define WX_IR 10
 #define WX_IC 18
-#define WX_X_U16 (WX_IR * WX_IC * BX_PS)
-#define WX_G_U16 (128 * BX_PS)
-#define WX_LDS_BYTES ((WX_X_U16 + WX_G_U16) * 2 + 1024 * 4)
-#define WX_NIX (WX_IR * WX_IC * 8)
-#define WX_NLX ((WX_NIX + 255) / 256)
-#define WX_NLG 4  // 128 pixels x 8 float4 / 256 threads
+template <int CIN, int COUT>
+struct WxCfg {
+  static constexpr int PSX = 3 * CIN + 8, PSG = 3 * COUT + 8;  // LDS pixel strides (16-bit units), as BxCfg::PS
+  static constexpr int CVX = CIN / 4, CVG = COUT / 4;
+  static constexpr int X_U16 = WX_IR * WX_IC * PSX, G_U16 = 128 * PSG;
+  static constexpr int LDS_BYTES = (X_U16 + G_U16) * 2 + 1024 * 4;
+  static constexpr int NIX = WX_IR * WX_IC * CVX, NLX = (NIX + 255) / 256;
+  static constexpr int NLG = 128 * CVG / 256;
+  static constexpr int MB = 9 * CIN / 16, NB = COUT / 16, T = MB * NB, TW = (T + 3) / 4;  // tiles, tiles per wave
+};
 
 __device__ __forceinline__ s16x8 tr_read8(const unsigned short* p0, const unsigned short* p1) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
@@ -1393,163 +1398,171 @@ __device__ __forceinline__ s16x8 tr_read8(const unsigned short* p0, const unsign
   return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
+  using C = WxCfg<CIN, COUT>;
+  constexpr int PSX = C::PSX, PSG = C::PSG, NLX = C::NLX, NLG = C::NLG, NB = C::NB, TW = C::TW;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   unsigned short* xl = smem16;
-  unsigned short* gl = smem16 + WX_X_U16;
-  float* bred = (float*)(smem16 + WX_X_U16 + WX_G_U16);  // 1024 floats: bias partial reduction
+  unsigned short* gl = smem16 + C::X_U16;
+  float* bred = (float*)(smem16 + C::X_U16 + C::G_U16);  // 1024 floats: bias partial reduction
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lg = lane >> 4, l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3;  // tr-read role: row tq, column chunk tp
   const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + 7) / 8;
   const int ntiles = a.n * tiles_y * tiles_x;
 
-  // my 9 accumulator tiles: t = 9*wave + j -> (mb = t >> 1, nb = t & 1); mb = tap*2 + half.  The per-wave tile set is
-  // a compile-time constant inside run<W>() below (static register indexing of the accumulators).
-  f32x4 acc[9];
+  // my accumulator tiles: t = TW*wave + j -> (mb = t / NB, nb = t % NB); mb = (tap, 16-channel half of the input).  The
+  // per-wave tile set is a compile-time constant inside run<W>() below (static register indexing of the accumulators).
+  f32x4 acc[TW];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);  // channels 4*(tid&7).. of the gy pixels this thread stages
+  for (int j = 0; j < TW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);  // channels 4*(tid % CVG).. of the gy pixels this thread stages
 
   // halo / gradient items of this thread; pixels outside the image get an out-of-range buffer offset, which loads the
   // zero padding without a branch, a clamp or a mask (as in conv_bf16x3_kernel)
-  float4 prex[WX_NLX], preg[WX_NLG];
-  int ix_rc[WX_NLX], ix_off[WX_NLX], ig_rc[WX_NLG], ig_off[WX_NLG];
+  float4 prex[NLX], preg[NLG];
+  int ix_rc[NLX], ix_off[NLX], ig_rc[NLG], ig_off[NLG];
 #pragma unroll
-  for (int it = 0; it < WX_NLX; ++it) {
+  for (int it = 0; it < NLX; ++it) {
     const int idx = (int)threadIdx.x + it * 256;
-    const int vv = idx & 7, pix = idx >> 3;
+    const int vv = idx % C::CVX, pix = idx / C::CVX;
     const int r = pix / WX_IC, c = pix % WX_IC;
-    ix_rc[it] = (idx < WX_NIX) ? (r | (c << 16)) : 0x4000;
-    ix_off[it] = ((r * a.win + c) * 32 + vv * 4) * 4;
+    ix_rc[it] = (idx < C::NIX) ? (r | (c << 16)) : 0x4000;
+    ix_off[it] = ((r * a.win + c) * CIN + vv * 4) * 4;
   }
 #pragma unroll
-  for (int it = 0; it < WX_NLG; ++it) {
+  for (int it = 0; it < NLG; ++it) {
     const int idx = threadIdx.x + it * 256;
-    const int vv = idx & 7, pix = idx >> 3;
+    const int vv = idx % C::CVG, pix = idx / C::CVG;
     ig_rc[it] = (pix >> 4) | ((pix & 15) << 16);
-    ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * 32 + vv * 4) * 4;
+    ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * COUT + vv * 4) * 4;
   }
-  const unsigned x_bytes = (unsigned)a.hin * a.win * 128u, g_bytes = (unsigned)a.hout * a.wout * 128u;
+  const unsigned x_bytes = (unsigned)a.hin * a.win * (CIN * 4u), g_bytes = (unsigned)a.hout * a.wout * (COUT * 4u);
   auto prefetch = [&](int tile) __attribute__((always_inline)) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * 8 - a.pad, ix0 = tx * 16 - a.pad;
-    const float* xb = a.x + (long)n * a.hin * a.win * 32;
-    const int xoff0 = (iy0 * a.win + ix0) * 128;
+    const float* xb = a.x + (long)n * a.hin * a.win * CIN;
+    const int xoff0 = (iy0 * a.win + ix0) * (CIN * 4);
 #pragma unroll
-    for (int it = 0; it < WX_NLX; ++it) {
+    for (int it = 0; it < NLX; ++it) {
       const int iy = iy0 + (ix_rc[it] & 0xffff), ix = ix0 + (ix_rc[it] >> 16);
       const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
       prex[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(xb, x_bytes), ok ? (unsigned)(xoff0 + ix_off[it]) : BX_OOB, 0, 0));
     }
-    const float* gb = a.gy + (long)n * a.hout * a.wout * 32;
-    const int goff0 = (ty * 8 * a.wout + tx * 16) * 128;
+    const float* gb = a.gy + (long)n * a.hout * a.wout * COUT;
+    const int goff0 = (ty * 8 * a.wout + tx * 16) * (COUT * 4);
 #pragma unroll
-    for (int it = 0; it < WX_NLG; ++it) {
+    for (int it = 0; it < NLG; ++it) {
       const int oy = ty * 8 + (ig_rc[it] & 0xffff), ox = tx * 16 + (ig_rc[it] >> 16);
       const bool ok = oy < a.hout && ox < a.wout;
       preg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(gb, g_bytes), ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
     }
   };
-  auto put3 = [&](unsigned short* p, const float4& v) __attribute__((always_inline)) {
+  auto put3 = [&](unsigned short* p, const float4& v, int plane) __attribute__((always_inline)) {
     unsigned a1, a2, a3, b1, b2, b3;
     split3_pair(v.x, v.y, a1, a2, a3);
     split3_pair(v.z, v.w, b1, b2, b3);
     *(uint2*)(p) = make_uint2(a1, b1);
-    *(uint2*)(p + 32) = make_uint2(a2, b2);
-    *(uint2*)(p + 64) = make_uint2(a3, b3);
+    *(uint2*)(p + plane) = make_uint2(a2, b2);
+    *(uint2*)(p + 2 * plane) = make_uint2(a3, b3);
   };
   auto stage = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one unconditional wait for the prefetched tile
 #pragma unroll
-    for (int it = 0; it < WX_NLX; ++it) {
+    for (int it = 0; it < NLX; ++it) {
       const int idx = (int)threadIdx.x + it * 256;
-      if (idx < WX_NIX) put3(xl + (idx >> 3) * BX_PS + (idx & 7) * 4, prex[it]);
+      if (idx < C::NIX) put3(xl + (idx / C::CVX) * PSX + (idx % C::CVX) * 4, prex[it], CIN);
     }
 #pragma unroll
-    for (int it = 0; it < WX_NLG; ++it) {
+    for (int it = 0; it < NLG; ++it) {
       const int idx = threadIdx.x + it * 256;
       const float4 v = preg[it];
       bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-      put3(gl + (idx >> 3) * BX_PS + (idx & 7) * 4, v);
+      put3(gl + (idx / C::CVG) * PSG + (idx % C::CVG) * 4, v, COUT);
     }
   };
 
   if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
   auto run = [&](auto wc) __attribute__((always_inline)) {
-    constexpr int W = decltype(wc)::value, T0 = 9 * W, MB0 = T0 >> 1;  // 5 row blocks MB0 .. MB0+4 (1 or 2 tiles each)
+    constexpr int W = decltype(wc)::value, T0 = TW * W, T1 = (T0 + TW < C::T) ? T0 + TW : C::T;
+    constexpr int NTW = T1 > T0 ? T1 - T0 : 0;                            // tiles of this wave (0: it only stages)
+    constexpr int MB0 = T0 / NB, NG = NTW ? (T1 - 1) / NB - MB0 + 1 : 0;  // row blocks MB0 .. MB0+NG-1
+    constexpr int NU = 4 * NG, NGD = NG ? NG : 1;                         // units per tile: 4 k-steps x NG row blocks
     // operand fetch (hardware-transposing reads) of k-step ks: lane group lg covers tile row 2 ks + lg/2, 8 columns
-    auto load_fb = [&](int ks, s16x8 (&F)[3][2]) __attribute__((always_inline)) {
+    auto load_fb = [&](int ks, s16x8 (&F)[3][NB]) __attribute__((always_inline)) {
       const int pr = 2 * ks + (lg >> 1), pc0 = 8 * (lg & 1);
-      const unsigned short* gq = gl + (pr * 16 + pc0 + tq) * BX_PS + tp * 4;
+      const unsigned short* gq = gl + (pr * 16 + pc0 + tq) * PSG + tp * 4;
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) F[p][nb] = tr_read8(gq + p * 32 + nb * 16, gq + 4 * BX_PS + p * 32 + nb * 16);
+        for (int nb = 0; nb < NB; ++nb) F[p][nb] = tr_read8(gq + p * COUT + nb * 16, gq + 4 * PSG + p * COUT + nb * 16);
     };
     auto load_fa = [&](int ks, int mb, s16x8 (&F)[3]) __attribute__((always_inline)) {
       const int pr = 2 * ks + (lg >> 1), pc0 = 8 * (lg & 1);
-      const int tap = mb >> 1, half = mb & 1, ky = tap / 3, kx = tap - 3 * ky;
-      const unsigned short* xq = xl + ((pr + ky) * WX_IC + pc0 + tq + kx) * BX_PS + half * 16 + tp * 4;
+      const int tap = CIN == 32 ? mb >> 1 : mb, half = CIN == 32 ? mb & 1 : 0, ky = tap / 3, kx = tap - 3 * ky;
+      const unsigned short* xq = xl + ((pr + ky) * WX_IC + pc0 + tq + kx) * PSX + half * 16 + tp * 4;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F[p] = tr_read8(xq + p * 32, xq + 4 * BX_PS + p * 32);
+      for (int p = 0; p < 3; ++p) F[p] = tr_read8(xq + p * CIN, xq + 4 * PSX + p * CIN);
     };
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       __syncthreads();
       stage();
       __syncthreads();
       if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
-      // 20 units (4 k-steps x 5 row blocks), software-pipelined: the operands of unit u+1 are requested before the
-      // MFMAs of unit u are issued, and the reads are spread between those MFMAs
-      s16x8 fa[2][3], fb[2][3][2];
-      load_fb(0, fb[0]);
-      load_fa(0, MB0, fa[0]);
+      if (NTW > 0) {
+        // NU units, software-pipelined: the operands of unit u+1 are requested before the MFMAs of unit u are issued,
+        // and the reads are spread between those MFMAs
+        s16x8 fa[2][3], fb[2][3][NB];
+        load_fb(0, fb[0]);
+        load_fa(0, MB0, fa[0]);
 #pragma unroll
-      for (int u = 0; u < 20; ++u) {
-        const int ks = u / 5, gi = u % 5, mb = MB0 + gi;
-        int nread = 0;
-        if (u + 1 < 20) {
-          const int ks2 = (u + 1) / 5, gi2 = (u + 1) % 5;
-          if (gi2 == 0) load_fb(ks2, fb[ks2 & 1]), nread += 12;
-          load_fa(ks2, MB0 + gi2, fa[(u + 1) & 1]);
-          nread += 6;
-        }
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-        constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-        int nm = 0;
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          const int t = 2 * mb + nb;
-          if (t >= T0 && t < T0 + 9) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-              acc[t - T0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[u & 1][PA[q]]),
-                                                                    __builtin_bit_cast(bf16x8, fb[ks & 1][PB[q]][nb]),
-                                                                    acc[t - T0], 0, 0, 0);
-            nm += 6;
+        for (int u = 0; u < NU; ++u) {
+          const int ks = u / NGD, gi = u % NGD, mb = MB0 + gi;
+          int nread = 0;
+          if (u + 1 < NU) {
+            const int ks2 = (u + 1) / NGD, gi2 = (u + 1) % NGD;
+            if (gi2 == 0) load_fb(ks2, fb[ks2 & 1]), nread += 6 * NB;
+            load_fa(ks2, MB0 + gi2, fa[(u + 1) & 1]);
+            nread += 6;
           }
-        }
-        // issue order: MFMA, then up to ceil(nread / nm) of the next unit's reads
-        const int per = nm ? (nread + nm - 1) / nm : 0;
+          constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+          constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+          int nm = 0;
 #pragma unroll
-        for (int g = 0; g < 12; ++g)
-          if (g < nm) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (per == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            else if (per == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            else if (per == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          for (int nb = 0; nb < NB; ++nb) {
+            const int t = NB * mb + nb;
+            if (t >= T0 && t < T1) {
+#pragma unroll
+              for (int q = 0; q < 6; ++q)
+                acc[t - T0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[u & 1][PA[q]]),
+                                                                      __builtin_bit_cast(bf16x8, fb[ks & 1][PB[q]][nb]),
+                                                                      acc[t - T0], 0, 0, 0);
+              nm += 6;
+            }
           }
-        __builtin_amdgcn_sched_barrier(0);
+          // issue order: MFMA, then up to ceil(nread / nm) of the next unit's reads
+          const int per = nm ? (nread + nm - 1) / nm : 0;
+#pragma unroll
+          for (int g = 0; g < 12; ++g)
+            if (g < nm) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (per == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              else if (per == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              else if (per == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     // partial slab of this workgroup: [m = mb*16 + row][co]
-    float* out = a.part + (long)blockIdx.x * (18 * 16 * 32);
+    float* out = a.part + (long)blockIdx.x * (C::MB * 16 * COUT);
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const int t = T0 + j, mb = t >> 1, nb = t & 1;
+    for (int j = 0; j < NTW; ++j) {
+      const int t = T0 + j, mb = t / NB, nb = t % NB;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[(mb * 16 + lg * 4 + r) * 32 + nb * 16 + l16] = acc[j][r];
+      for (int r = 0; r < 4; ++r) out[(mb * 16 + lg * 4 + r) * COUT + nb * 16 + l16] = acc[j][r];
     }
   };
   switch (wave) {  // wave-uniform; every branch executes the same barriers
@@ -1560,28 +1573,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   }
   if (a.bpart) {
     __syncthreads();
-    const int vv = threadIdx.x & 7, row = threadIdx.x >> 3;  // 32 rows of partial sums per channel group
-    bred[(row * 8 + vv) * 4 + 0] = bsum.x;
-    bred[(row * 8 + vv) * 4 + 1] = bsum.y;
-    bred[(row * 8 + vv) * 4 + 2] = bsum.z;
-    bred[(row * 8 + vv) * 4 + 3] = bsum.w;
+    const int vv = threadIdx.x % C::CVG, row = threadIdx.x / C::CVG;  // 256 / CVG rows of partial sums per channel chunk
+    bred[row * COUT + vv * 4 + 0] = bsum.x;
+    bred[row * COUT + vv * 4 + 1] = bsum.y;
+    bred[row * COUT + vv * 4 + 2] = bsum.z;
+    bred[row * COUT + vv * 4 + 3] = bsum.w;
     __syncthreads();
-    if (threadIdx.x < 32) {
+    if (threadIdx.x < COUT) {
       float sum = 0.f;
-      for (int r = 0; r < 32; ++r) sum += bred[r * 32 + threadIdx.x];
-      a.bpart[(long)blockIdx.x * 32 + threadIdx.x] = sum;
+      for (int r = 0; r < 256 / C::CVG; ++r) sum += bred[r * COUT + threadIdx.x];
+      a.bpart[(long)blockIdx.x * COUT + threadIdx.x] = sum;
     }
   }
 }
 
-static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, hipStream_t s) {
-  using C = WgCfg<32, 32, 3, 3, 1>;
+template <int CIN, int COUT>
+static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hipStream_t s) {
+  using C = WgCfg<CIN, COUT, 3, 3, 1>;
+  using X = WxCfg<CIN, COUT>;
+  static_assert(C::NCHUNK == 1 && C::NSPLIT == 1 && C::PART == X::MB * 16 * COUT, "slab layout of conv_wgrad_kernel");
   // x and gy are addressed per sample through buffer descriptors with 31-bit byte offsets
-  if ((long)a.hin * a.win * 128 >= 0x7fff0000L || (long)a.hout * a.wout * 128 >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
+  if ((long)a.hin * a.win * CIN * 4 >= 0x7fff0000L || (long)a.hout * a.wout * COUT * 4 >= 0x7fff0000L)
+    return DIS_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       WX_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_bf16x3_kernel<CIN, COUT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, X::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -1593,12 +1610,12 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, hipStream_t s) {
   const long elems = C::PART;
   float* tmp = a.part + (long)WG_WORKERS * elems;
   a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
-  hipLaunchKernelGGL(conv_wgrad_bf16x3_kernel, dim3((unsigned)workers), dim3(256), WX_LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<CIN, COUT>), dim3((unsigned)workers), dim3(256), X::LDS_BYTES, s, a);
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(dis_cdiv(elems, 256), WG_RSPLIT), dim3(256), 0, s,
                      (const float*)a.part, tmp, (int)workers, elems);
-  const long total = (long)C::MROWS * 32;
+  const long total = (long)C::MROWS * COUT;
   hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(wgrad_reduce2_grid(total, gb != nullptr)), dim3(256), 0, s, (const float*)tmp, gw,
-                     C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, 32, 32, C::PART,
+                     C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, COUT, cin_real, C::PART,
                      (const float*)(gb ? a.bpart : nullptr), gb, (int)workers);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
@@ -1644,14 +1661,18 @@ extern "C" int dis_conv2d_wgrad_bf16x3(const float* x, const float* gy, float* g
                                        int pad, void* stream) {
   if (!x || !gy || !grad_w || !workspace) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0) return DIS_ERR_BAD_SHAPE;
-  if (cin_pad != 32 || cin_real != 32 || cout != 32 || k != 3 || stride != 1) return DIS_ERR_UNSUPPORTED;
+  if (!bx_shape_ok(cin_pad, cout, k, stride) || cin_real <= 0 || cin_real > cin_pad) return DIS_ERR_UNSUPPORTED;
   const int hout = hin + 2 * pad - 2, wout = win + 2 * pad - 2;
   if (hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
   WgArgs a;
   a.x = x; a.gy = gy; a.part = workspace; a.bpart = nullptr;
   a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
   a.xscale = nullptr;
-  return launch_wgrad_bf16x3(a, grad_w, grad_b, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (cin_pad == 32 && cout == 32) return launch_wgrad_bf16x3<32, 32>(a, grad_w, grad_b, cin_real, s);
+  if (cin_pad == 16 && cout == 16) return launch_wgrad_bf16x3<16, 16>(a, grad_w, grad_b, cin_real, s);
+  if (cin_pad == 16 && cout == 32) return launch_wgrad_bf16x3<16, 32>(a, grad_w, grad_b, cin_real, s);
+  return launch_wgrad_bf16x3<32, 16>(a, grad_w, grad_b, cin_real, s);
 }
 
 extern "C" int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace,

@@ -309,42 +309,45 @@ def test_adam_matches_torch():
 
 
 @pytest.mark.parametrize('h,w', [(37, 45), (64, 48)])
-def test_conv_bf16x3_is_fp32_accurate(h, w):
-    """The 32->32 3x3 convolution on the bf16 matrix cores (3-way operand split, 6 products, fp32 accumulate) must be
-    as close to an fp64 reference as the exact-fp32 MFMA kernel is: forward, input gradient and weight gradient."""
+@pytest.mark.parametrize('cin,cout,cin_real', [(32, 32, 32), (16, 16, 16), (16, 32, 16), (32, 16, 32), (16, 16, 3)])
+def test_conv_bf16x3_is_fp32_accurate(h, w, cin, cout, cin_real):
+    """The 3x3 convolutions on the bf16 matrix cores (3-way operand split, 6 products, fp32 accumulate) must be as close
+    to an fp64 reference as the exact-fp32 MFMA kernels are: forward, input gradient and weight gradient, for 16 / 32
+    channels on either side and for a first layer whose x carries zero-padded extra channels (cin_real < cin)."""
     from depthinspace_amd import lib, ops
-    g = torch.Generator().manual_seed(h * 100 + w)
+    g = torch.Generator().manual_seed(h * 100 + w + cin + 3 * cout + cin_real)
     n = 3
-    x = torch.randn(n, h, w, 32, generator=g).cuda()
-    wt = (torch.randn(32, 32, 3, 3, generator=g) * 0.06).cuda()
-    b = torch.randn(32, generator=g).cuda()
-    gy = torch.randn(n, h, w, 32, generator=g).cuda()
-    xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    x = torch.randn(n, h, w, cin, generator=g)
+    x[..., cin_real:] = 0
+    x = x.cuda()
+    wt = (torch.randn(cout, cin_real, 3, 3, generator=g) * 0.06).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    gy = torch.randn(n, h, w, cout, generator=g).cuda()
+    xr = x[..., :cin_real].permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
     wr = wt.double().cpu().requires_grad_(True)
     br = b.double().cpu().requires_grad_(True)
     yr = F.conv2d(xr, wr, br, padding=1)
     yr.backward(gy.permute(0, 3, 1, 2).double().cpu())
     res = {}
     for tag in ('fp32', 'bf16x3'):
-        y = torch.empty(n, h, w, 32, device='cuda')
-        gx = torch.empty_like(x)
+        y = torch.empty(n, h, w, cout, device='cuda')
+        gx = torch.zeros_like(x)
         gw = torch.empty_like(wt)
-        gb = torch.empty(32, device='cuda')
-        ws = torch.empty(lib.fn('dis_conv2d_wgrad_workspace')(32, 32, 3, 1), device='cuda')
+        gb = torch.empty(cout, device='cuda')
+        ws = torch.empty(lib.fn('dis_conv2d_wgrad_workspace')(cin, cout, 3, 1), device='cuda')
         if tag == 'fp32':
-            lib.call('dis_conv2d_fwd', x, ops._pack_w(wt, 32, 0), b, y, None, n, h, w, 32, 32, 3, 1, 1, 0)
-            lib.call('dis_conv2d_fwd', gy, ops._pack_w(wt, 32, 1), None, gx, None, n, h, w, 32, 32, 3, 1, 1, 0)
-            lib.call('dis_conv2d_wgrad', x, gy, gw, gb, ws, n, h, w, 32, 32, 32, 3, 1, 1)
+            lib.call('dis_conv2d_fwd', x, ops._pack_w(wt, cin, 0), b, y, None, n, h, w, cin, cout, 3, 1, 1, 0)
+            if cin_real == cin:
+                lib.call('dis_conv2d_fwd', gy, ops._pack_w(wt, cin, 1), None, gx, None, n, h, w, cout, cin, 3, 1, 1, 0)
+            lib.call('dis_conv2d_wgrad', x, gy, gw, gb, ws, n, h, w, cin, cin_real, cout, 3, 1, 1)
         else:
-            pk = torch.empty(9 * 3 * 4 * 32 * 8, dtype=torch.int16, device='cuda')
-            lib.call('dis_conv2d_pack_weights_bf16x3', wt, pk, 32, 32, 3, 0)
-            lib.call('dis_conv2d_fwd_bf16x3', x, pk, b, y, None, n, h, w, 32, 32, 3, 1, 1, 0)
-            pk1 = torch.empty_like(pk)
-            lib.call('dis_conv2d_pack_weights_bf16x3', wt, pk1, 32, 32, 3, 1)
-            lib.call('dis_conv2d_fwd_bf16x3', gy, pk1, None, gx, None, n, h, w, 32, 32, 3, 1, 1, 0)
-            lib.call('dis_conv2d_wgrad_bf16x3', x, gy, gw, gb, ws, n, h, w, 32, 32, 32, 3, 1, 1)
-        res[tag] = (relerr(y.permute(0, 3, 1, 2), yr), relerr(gx.permute(0, 3, 1, 2), xr.grad), relerr(gw, wr.grad),
-                    relerr(gb, br.grad))
+            lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, 0, cout, cin_real, b, y, None, n, h, w, cin, cout, 3, 1, 1, 0)
+            if cin_real == cin:
+                lib.call('dis_conv2d_fwd_bf16x3_oihw', gy, wt, 1, cout, cin_real, None, gx, None, n, h, w, cout, cin, 3, 1,
+                         1, 0)
+            lib.call('dis_conv2d_wgrad_bf16x3', x, gy, gw, gb, ws, n, h, w, cin, cin_real, cout, 3, 1, 1)
+        egx = relerr(gx[..., :cin_real].permute(0, 3, 1, 2), xr.grad) if cin_real == cin else 0.0
+        res[tag] = (relerr(y.permute(0, 3, 1, 2), yr), egx, relerr(gw, wr.grad), relerr(gb, br.grad))
     print('max rel err vs fp64 (y, gx, gw, gb): fp32-MFMA', res['fp32'], ' bf16x3', res['bf16x3'])
     for e32, e3 in zip(res['fp32'], res['bf16x3']):
         assert e3 < 3e-6, res
