@@ -109,6 +109,7 @@ struct __attribute__((aligned(16))) C3Lds {
   float X[4][C3_GP * C3_XS];
   float H[4][C3_GP * C3_HS];
   long F[4][C3_GP];
+  float4 D[4][C3_NB * C3_GP];  // neighbour descriptors of the group a wave works on: (lx, ly, lz, element index | -1)
 };
 
 __device__ __forceinline__ float selu_f(float x) {
@@ -145,6 +146,33 @@ __device__ __forceinline__ C3Nb c3_neighbor(const float4* __restrict__ geom, con
   r.lx = q.x - ctr.x;
   r.ly = q.y - ctr.y;
   r.lz = q.z - ctr.z;
+  return r;
+}
+
+// The neighbour of (pixel, n) is found through two dependent loads (selection index -> geometry); the feature row is a
+// third.  Building the 9 x 16 descriptors of a group once, three per lane with all chains in flight together, and
+// reading them back from LDS takes those chains out of the per-neighbour loops (the kernels are latency-bound there).
+__device__ __forceinline__ void c3_build_desc(float4* D, const float4* __restrict__ geom,
+                                              const unsigned char* __restrict__ idx, const C3Dims& d, long ic, bool pv,
+                                              int oy, int ox, long tb, const float4& ctr, int li, int lg) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int n = lg + 4 * k;
+    if (n < C3_NB) {
+      const C3Nb nb = c3_neighbor(geom, idx, d, ic, n, pv, oy, ox, tb, ctr);
+      D[n * C3_GP + li] = make_float4(nb.lx, nb.ly, nb.lz, __int_as_float(nb.foff >= 0 ? (int)(nb.foff / C3_C) : -1));
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ C3Nb c3_desc(const float4* D, int n, int li) {
+  const float4 v = D[n * C3_GP + li];
+  C3Nb r;
+  r.lx = v.x;
+  r.ly = v.y;
+  r.lz = v.z;
+  const int e = __float_as_int(v.w);
+  r.foff = e >= 0 ? (long)e * C3_C : -1;
   return r;
 }
 
@@ -208,9 +236,10 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(const float4* __restric
     const long tb = ic / ((long)d.wo * d.ho);
     const float4 ctr = geom[(tb * d.h * d.w + (long)(oy * d.stride) * d.w + ox * d.stride) * C3_TL];
     f32x4 agg[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    c3_build_desc(L.D[wave], geom, idx, d, ic, pv, oy, ox, tb, ctr, Q.li, Q.lg);
 #pragma unroll 3
     for (int n = 0; n < C3_NB; ++n) {
-      const C3Nb nb = c3_neighbor(geom, idx, d, ic, n, pv, oy, ox, tb, ctr);
+      const C3Nb nb = c3_desc(L.D[wave], n, Q.li);
       f32x4 fv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
       if (nb.foff >= 0) {
         fv[0] = *(const f32x4*)(wf + nb.foff + Q.lg * 4);
@@ -222,6 +251,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(const float4* __restric
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) agg[mt] += h2[mt] * fv[mt];
     }
+    __builtin_amdgcn_wave_barrier();  // (the next group's descriptors overwrite D)
     // y[px][c'] = selu(sum_c agg[px][c] * w[c][c'])
     f32x4 out[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -297,9 +327,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_bwd_kernel(const float4* __rest
     // ---- recompute the forward aggregate (h1/h2 are recomputed again per neighbour below: cheaper than holding
     //      72 registers of h2 across the group, which spilled and halved the occupancy)
     f32x4 agg[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    c3_build_desc(L.D[wave], geom, idx, d, ic, pv, oy, ox, tb, ctr, Q.li, Q.lg);
 #pragma unroll 3
     for (int n = 0; n < C3_NB; ++n) {
-      const C3Nb nb = c3_neighbor(geom, idx, d, ic, n, pv, oy, ox, tb, ctr);
+      const C3Nb nb = c3_desc(L.D[wave], n, Q.li);
       f32x4 fv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
       if (nb.foff >= 0) {
         fv[0] = *(const f32x4*)(wf + nb.foff + Q.lg * 4);
@@ -361,14 +392,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_bwd_kernel(const float4* __rest
         for (int nt = 0; nt < 2; ++nt)
           accW[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aggD[mt][r], gpreD[nt][r], accW[mt][nt], 0, 0, 0);
 
-    // ---- neighbours
+    // ---- neighbours (feature rows fetched one neighbour ahead)
+    C3Nb nbn = c3_desc(L.D[wave], 0, Q.li);
+    f32x4 fvn[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    if (nbn.foff >= 0) {
+      fvn[0] = *(const f32x4*)(wf + nbn.foff + Q.lg * 4);
+      fvn[1] = *(const f32x4*)(wf + nbn.foff + 16 + Q.lg * 4);
+    }
 #pragma unroll 1
     for (int n = 0; n < C3_NB; ++n) {
-      const C3Nb nb = c3_neighbor(geom, idx, d, ic, n, pv, oy, ox, tb, ctr);
-      f32x4 fv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-      if (nb.foff >= 0) {
-        fv[0] = *(const f32x4*)(wf + nb.foff + Q.lg * 4);
-        fv[1] = *(const f32x4*)(wf + nb.foff + 16 + Q.lg * 4);
+      const C3Nb nb = nbn;
+      const f32x4 fv[2] = {fvn[0], fvn[1]};
+      if (n + 1 < C3_NB) {
+        nbn = c3_desc(L.D[wave], n + 1, Q.li);
+        fvn[0] = fvn[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (nbn.foff >= 0) {
+          fvn[0] = *(const f32x4*)(wf + nbn.foff + Q.lg * 4);
+          fvn[1] = *(const f32x4*)(wf + nbn.foff + 16 + Q.lg * 4);
+        }
       }
       float h1[4];
       f32x4 h2[2];
