@@ -41,15 +41,26 @@ extern "C" int dis_add_act_fwd(const float* a, const float* b, float* y, int act
 // ------------------------------------------------------------------------------------------------
 // statistics
 // ------------------------------------------------------------------------------------------------
-__global__ void gn_stats_kernel(const float4* __restrict__ x, double* __restrict__ stats, long per4) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float4* __restrict__ x, double* __restrict__ stats,
+                                                       long per4) {
   __shared__ double sm[8];
   const int n = blockIdx.y;
   const float4* p = x + (long)n * per4;
   double s1 = 0.0, s2 = 0.0;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per4; i += (long)gridDim.x * blockDim.x) {
-    const float4 v = p[i];
-    s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-    s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  // 4 float4s per thread and round: their 16 values are summed in fp32 (exact enough: 16 terms), the running sums in
+  // fp64.  Few blocks per sample: the launch ends in one fp64 atomic pair per block on the sample's two addresses.
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per4; i += 4 * stride) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long j = i + k * stride;
+      const float4 v = j < per4 ? p[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      t1 += (v.x + v.y) + (v.z + v.w);
+      t2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    s1 += (double)t1;
+    s2 += (double)t2;
   }
   const double r1 = block_sum_d(s1, sm), r2 = block_sum_d(s2, sm);
   if (threadIdx.x == 0) {
@@ -61,8 +72,9 @@ extern "C" int dis_gn_stats(const float* x, double* stats, int n, long per_sampl
   if (!x || !stats) return DIS_ERR_NULL;
   if (n <= 0 || per_sample <= 0) return DIS_ERR_BAD_SHAPE;
   if (per_sample % 4 != 0) return DIS_ERR_UNSUPPORTED;
-  int gx = dis_ew_grid(per_sample / 4, 256);
-  if (gx > 256) gx = 256;
+  int gx = dis_ew_grid(per_sample / 16, 256);  // >= 4 float4s per thread
+  const int cap = n >= 16 ? 32 : (n >= 4 ? 64 : 256);  // ~512+ blocks in all
+  if (gx > cap) gx = cap;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, (const float4*)x, stats,
                      per_sample / 4);
   DIS_CHECK_LAUNCH();
