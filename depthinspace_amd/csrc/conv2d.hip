@@ -1754,67 +1754,87 @@ __global__ void head_gpre_kernel(const float* __restrict__ y, const float* __res
   }
 }
 
-// gx (gather over the 9 taps) and the weight/bias reductions (per-thread fp32 partials -> fp64 atomics)
+// Input gradient and weight / bias gradient of the head in one pass.  One thread per (pixel q, 4-channel group): with
+// g[o] the pre-sigmoid gradient at the 9 output pixels o = q - (tap - 1) that see q,
+//   gx[q][c]   = sum_tap g[o] w[tap][c]          dW[tap][c] += g[o] x[q][c]          db += g[q]
+// so x is read once (coalesced float4 rows) and the neighbourhood only through the 1-channel g.  Per-thread fp32
+// partials -> fp64 sums over the lanes that share a channel group -> one slab per block (head_reduce_kernel adds the
+// slabs in a fixed order: deterministic, no atomics).
+#define HEAD_SLABS 512
 template <int CIN>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ gp, float* __restrict__ gx,
-                                                         double* __restrict__ acc, int n, int h, int wd) {
-  __shared__ float ws[9 * CIN];
-  __shared__ double red[4];
+                                                         double* __restrict__ slab, int n, int h, int wd) {
+  constexpr int NQ = CIN / 4, NP = 9 * CIN + 1;
+  __shared__ float4 ws[9 * NQ];
+  __shared__ double red[4][NP];
   for (int i = threadIdx.x; i < 9 * CIN; i += blockDim.x) {
     const int tap = i / CIN, ci = i % CIN;
-    ws[i] = w[ci * 9 + tap];
+    ((float*)ws)[i] = w[ci * 9 + tap];
   }
   __syncthreads();
-  float gw[9][CIN];
+  const int quad = threadIdx.x % NQ;
+  float4 gw[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) gw[t][c] = 0.f;
+  for (int t = 0; t < 9; ++t) gw[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   float gb = 0.f;
-  const long total = (long)n * h * wd;
+  const long total = (long)n * h * wd * NQ;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % wd), py = (int)((i / wd) % h);
-    const long nb = i / ((long)h * wd);
-    const float g = gp[i];
-    gb += g;
-    float gxa[CIN];
+    const long q = i / NQ;
+    const int px = (int)(q % wd), py = (int)((q / wd) % h);
+    const long nb = q / ((long)h * wd);
+    const float4 xv = *(const float4*)(x + q * CIN + quad * 4);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) gxa[c] = 0.f;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        // weight gradient: gw[tap][ci] += gpre[p] * x[p + tap - 1][ci]
-        const int iy = py + ky - 1, ix = px + kx - 1;
-        if (iy >= 0 && iy < h && ix >= 0 && ix < wd) {
-          const float* p = x + ((nb * h + iy) * wd + ix) * CIN;
-#pragma unroll
-          for (int c = 0; c < CIN; ++c) gw[ky * 3 + kx][c] += g * p[c];
-        }
-        // input gradient: gx[p][ci] += gpre[p - tap + 1] * w[tap][ci]
         const int oy = py - ky + 1, ox = px - kx + 1;
-        if (oy >= 0 && oy < h && ox >= 0 && ox < wd) {
-          const float go = gp[(nb * h + oy) * wd + ox];
-          const float* wt = ws + (ky * 3 + kx) * CIN;
-#pragma unroll
-          for (int c = 0; c < CIN; ++c) gxa[c] += go * wt[c];
-        }
+        const bool ok = oy >= 0 && oy < h && ox >= 0 && ox < wd;
+        const float g = ok ? gp[(nb * h + (ok ? oy : 0)) * wd + (ok ? ox : 0)] : 0.f;
+        const int t = ky * 3 + kx;
+        const float4 wt = ws[t * NQ + quad];
+        o.x += g * wt.x, o.y += g * wt.y, o.z += g * wt.z, o.w += g * wt.w;
+        gw[t].x += g * xv.x, gw[t].y += g * xv.y, gw[t].z += g * xv.z, gw[t].w += g * xv.w;
+        if (t == 4 && quad == 0) gb += g;
       }
-    }
-    float4* o = (float4*)(gx + i * CIN);
-#pragma unroll
-    for (int v = 0; v < CIN / 4; ++v) o[v] = make_float4(gxa[v * 4], gxa[v * 4 + 1], gxa[v * 4 + 2], gxa[v * 4 + 3]);
+    *(float4*)(gx + q * CIN + quad * 4) = o;
   }
+  // lanes with the same channel group: l % NQ == quad (NQ divides 64)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto quad_sum = [&](double v) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int off = 32; off >= NQ; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+  };
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) {
-      const double r = block_sum_d((double)gw[t][c], red);
-      if (threadIdx.x == 0) atomic_add_d(acc + c * 9 + t, r);
+  for (int t = 0; t < 9; ++t) {
+    const double r0 = quad_sum((double)gw[t].x), r1 = quad_sum((double)gw[t].y), r2 = quad_sum((double)gw[t].z),
+                 r3 = quad_sum((double)gw[t].w);
+    if (lane < NQ) {
+      red[wave][(lane * 4 + 0) * 9 + t] = r0;
+      red[wave][(lane * 4 + 1) * 9 + t] = r1;
+      red[wave][(lane * 4 + 2) * 9 + t] = r2;
+      red[wave][(lane * 4 + 3) * 9 + t] = r3;
     }
-  const double rb = block_sum_d((double)gb, red);
-  if (threadIdx.x == 0) atomic_add_d(acc + 9 * CIN, rb);
+  }
+  const double rb = wave_sum_d((double)gb);
+  if (lane == 0) red[wave][9 * CIN] = rb;
+  __syncthreads();
+  for (int i = threadIdx.x; i < NP; i += blockDim.x)
+    slab[(long)blockIdx.x * NP + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+// grad_w (cin*9, [ci][tap]) and grad_b from the block slabs
+__global__ __launch_bounds__(64) void head_reduce_kernel(const double* __restrict__ slab, float* __restrict__ gw,
+                                                         float* __restrict__ gb, int nslab, int np) {
+  const int i = blockIdx.x;  // one parameter per (single-wave) block
+  double s = 0.0;
+  for (int k = threadIdx.x; k < nslab; k += 64) s += slab[(long)k * np + i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) {
+    if (i < np - 1) gw[i] = (float)s;
+    else gb[0] = (float)s;
+  }
 }
 
 extern "C" int dis_disp_head_fwd(const float* x, const float* w, const float* b, float* y, int n, int h, int wd,
@@ -1827,20 +1847,25 @@ extern "C" int dis_disp_head_fwd(const float* x, const float* w, const float* b,
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
+extern "C" long dis_disp_head_bwd_workspace(int n, int h, int wd, int cin) {
+  if (n <= 0 || h <= 0 || wd <= 0 || cin != 16) return DIS_ERR_UNSUPPORTED;
+  return (((long)n * h * wd + 1) & ~1L) + 2L * HEAD_SLABS * (9 * cin + 1);  // floats: pre-sigmoid gradient + fp64 slabs
+}
 extern "C" int dis_disp_head_bwd(const float* x, const float* w, const float* y, const float* gy, float* gx,
-                                 float* grad_w, float* grad_b, float* workspace, double* acc, int n, int h, int wd,
-                                 int cin, float alpha, void* stream) {
-  if (!x || !w || !y || !gy || !gx || !grad_w || !grad_b || !workspace || !acc) return DIS_ERR_NULL;
+                                 float* grad_w, float* grad_b, float* workspace, int n, int h, int wd, int cin,
+                                 float alpha, void* stream) {
+  if (!x || !w || !y || !gy || !gx || !grad_w || !grad_b || !workspace) return DIS_ERR_NULL;
   if (n <= 0 || h <= 0 || wd <= 0) return DIS_ERR_BAD_SHAPE;
   if (cin != 16) return DIS_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)n * h * wd;
   hipLaunchKernelGGL(head_gpre_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, y, gy, workspace, alpha, total);
-  int grid = dis_ew_grid(total, 256);
-  if (grid > 512) grid = 512;
-  hipLaunchKernelGGL(head_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, w, (const float*)workspace, gx, acc, n, h, wd);
-  hipLaunchKernelGGL(cast_d2f_kernel, dim3(1), dim3(256), 0, s, (const double*)acc, grad_w, 9 * cin);
-  hipLaunchKernelGGL(cast_d2f_kernel, dim3(1), dim3(64), 0, s, (const double*)(acc + 9 * cin), grad_b, 1);
+  int grid = dis_ew_grid(total * (cin / 4), 256);
+  if (grid > HEAD_SLABS) grid = HEAD_SLABS;
+  double* slab = (double*)(workspace + ((total + 1) & ~1L));  // 8-byte aligned behind the gradient plane
+  hipLaunchKernelGGL(head_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, w, (const float*)workspace, gx, slab, n, h, wd);
+  hipLaunchKernelGGL(head_reduce_kernel, dim3(9 * cin + 1), dim3(64), 0, s, (const double*)slab, grad_w, grad_b, grid,
+                     9 * cin + 1);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

@@ -59,7 +59,8 @@ SIGS = {
     'dis_conv2d_wgrad_bf16x3': 'pppppiiiiiiiiip',
     'dis_conv2d_dgrad_strided': 'ppppiiiiiiiiip',
     'dis_disp_head_fwd': 'ppppiiiiffp',
-    'dis_disp_head_bwd': 'ppppppppp' + 'iiiifp',
+    'dis_disp_head_bwd': 'pppppppp' + 'iiiifp',
+    'dis_disp_head_bwd_workspace': 'iiii',
     'dis_act_bwd': 'pppilp',
     'dis_gn_stats': 'ppilp',
     'dis_gn_apply': 'ppppppiliifp',
@@ -83,7 +84,7 @@ SIGS = {
 }
 _RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
              'dis_colsum_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_gather_csr_workspace',
-             'dis_conv2d_pack_bf16x3_size'}
+             'dis_conv2d_pack_bf16x3_size', 'dis_disp_head_bwd_workspace'}
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
 _lib = None

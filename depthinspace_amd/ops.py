@@ -684,9 +684,8 @@ class _DispHead(torch.autograd.Function):
         gx = torch.empty_like(x)
         gw = torch.empty_like(weight)
         gb = torch.empty(1, dtype=torch.float32, device=x.device)
-        ws = torch.empty(n * h * w, dtype=torch.float32, device=x.device)
-        acc = _zeros_d(9 * cin + 1, x.device)
-        lib.call('dis_disp_head_bwd', x, weight, y, _c(gy), gx, gw, gb, ws, acc, n, h, w, cin, ctx.alpha)
+        ws = torch.empty(lib.fn('dis_disp_head_bwd_workspace')(n, h, w, cin), dtype=torch.float32, device=x.device)
+        lib.call('dis_disp_head_bwd', x, weight, y, _c(gy), gx, gw, gb, ws, n, h, w, cin, ctx.alpha)
         return gx, gw, gb, None, None
 
 

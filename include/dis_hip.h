@@ -251,10 +251,10 @@ int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, float* gx, fl
 int dis_disp_head_fwd(const float* x, const float* w, const float* b, float* y, int n, int h, int wd, int cin,
                       float alpha, float offset, void* stream);
 /* gy (n,1,h,w) gradient wrt y; y is the forward output.  gx (n,h,w,cin) overwritten; grad_w/grad_b overwritten.
- * workspace: n*h*wd floats (pre-sigmoid gradient). */
+ * workspace: dis_disp_head_bwd_workspace(n,h,wd,cin) floats (8-byte aligned: pre-sigmoid gradient + fp64 block slabs). */
+long dis_disp_head_bwd_workspace(int n, int h, int wd, int cin);
 int dis_disp_head_bwd(const float* x, const float* w, const float* y, const float* gy, float* gx, float* grad_w,
-                      float* grad_b, float* workspace, double* acc /* (cin*9+1) zeroed doubles */, int n, int h,
-                      int wd, int cin, float alpha, void* stream);
+                      float* grad_b, float* workspace, int n, int h, int wd, int cin, float alpha, void* stream);
 
 /* dy *= act'(y) given the activation OUTPUT y (SELU and ReLU are invertible enough for that). In place ok. */
 int dis_act_bwd(const float* gy, const float* y, float* gpre, int act, long count, void* stream);
