@@ -21,6 +21,15 @@ static inline int dis_ew_grid(long work_items, int block) {
   return (int)g;
 }
 
+// grid size for a grid-stride kernel that ENDS in same-address fp64 atomics (one per block): those serialise at ~7 ns
+// each, so 2048 blocks cost more in their tail than the loop saves; 2 blocks per CU keep the latency hidden
+static inline int dis_red_grid(long work_items, int block) {
+  long g = (work_items + block - 1) / block;
+  if (g > 512) g = 512;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

@@ -342,7 +342,7 @@ extern "C" int dis_weighted_mean_fwd(const float* x, const float* w, double* acc
   if (!x || !acc || !out) return DIS_ERR_NULL;
   if (count <= 0) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(weighted_sum_kernel, dim3(dis_ew_grid(count, 256)), dim3(256), 0, s, x, w, acc, count);
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(dis_red_grid(count, 256)), dim3(256), 0, s, x, w, acc, count);
   hipLaunchKernelGGL(ratio_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)acc, out, 0.0);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
@@ -381,7 +381,7 @@ extern "C" int dis_l1_mean_fwd(const float* a, const float* b, double* acc, floa
   if (!a || !b || !acc || !out) return DIS_ERR_NULL;
   if (count <= 0) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(l1_sum_kernel, dim3(dis_ew_grid(count, 256)), dim3(256), 0, s, a, b, acc, count);
+  hipLaunchKernelGGL(l1_sum_kernel, dim3(dis_red_grid(count, 256)), dim3(256), 0, s, a, b, acc, count);
   hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)acc, out, (double)count);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
@@ -417,11 +417,18 @@ __global__ __launch_bounds__(SM_TX* SM_TY) void smooth_kernel(const float* __res
   __shared__ float td[(SM_TY + 4) * (SM_TX + 4)];
   __shared__ float tam[(SM_TY + 4) * (SM_TX + 4)];
   __shared__ double sm[8];
-  const int n = blockIdx.z;
-  const int x0 = blockIdx.x * SM_TX, y0 = blockIdx.y * SM_TY;
+  const int tiles_x = (w + SM_TX - 1) / SM_TX, tiles_y = (h + SM_TY - 1) / SM_TY;
+  const long ntiles = (long)n_total * tiles_y * tiles_x;
   const int tw = SM_TX + 4, th = SM_TY + 4;
+  const int lx = threadIdx.x % SM_TX, ly = threadIdx.x / SM_TX;
+  double local = 0.0;
+  // workgroups walk the tiles (mode 0 ends in one fp64 atomic per workgroup, not one per tile)
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int n = (int)(tile / ((long)tiles_y * tiles_x));
+  const int x0 = (int)(tile % tiles_x) * SM_TX, y0 = (int)((tile / tiles_x) % tiles_y) * SM_TY;
   const float* idp = disp + (long)n * h * w;
   const float* iam = amb + (long)n * h * w;
+  __syncthreads();  // the previous tile's LDS reads are done
   for (int i = threadIdx.x; i < tw * th; i += blockDim.x) {
     int ty = i / tw, tx = i - ty * tw;
     int gy = min(max(y0 + ty - 2, 0), h - 1), gx = min(max(x0 + tx - 2, 0), w - 1);
@@ -429,9 +436,7 @@ __global__ __launch_bounds__(SM_TX* SM_TY) void smooth_kernel(const float* __res
     tam[i] = iam[(long)gy * w + gx];
   }
   __syncthreads();
-  const int lx = threadIdx.x % SM_TX, ly = threadIdx.x / SM_TX;
   const int px = x0 + lx, py = y0 + ly;
-  double local = 0.0;
   if (px < w && py < h) {
     float gx = 0.f, gy = 0.f, ax = 0.f, ay = 0.f;
     for (int dy = 0; dy < 5; ++dy)
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(SM_TX* SM_TY) void smooth_kernel(const float* __res
       }
     float e_x = expf(-fabsf(255.f * ax)), e_y = expf(-fabsf(255.f * ay));
     if (mode == 0) {
-      local = (double)fabsf(gx * e_x) + (double)fabsf(gy * e_y);
+      local += (double)fabsf(gx * e_x) + (double)fabsf(gy * e_y);
     } else {
       const float g = gscale[0] / (float)((long)n_total * 2 * h * w);
       float vx = gx * e_x, vy = gy * e_y;
@@ -454,6 +459,7 @@ __global__ __launch_bounds__(SM_TX* SM_TY) void smooth_kernel(const float* __res
       splanes[o + (long)h * w] = (vy > 0.f ? g : (vy < 0.f ? -g : 0.f)) * e_y;
     }
   }
+  }  // tiles
   if (mode == 0) {
     double r = block_sum_d(local, sm);
     if (threadIdx.x == 0) atomic_add_d(acc, r);
@@ -497,7 +503,7 @@ extern "C" int dis_smooth_loss_fwd(const float* disp, const float* amb, double* 
   if (!disp || !amb || !acc || !out) return DIS_ERR_NULL;
   if (n <= 0 || h < 3 || w < 3) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(dis_cdiv(w, SM_TX), dis_cdiv(h, SM_TY), n);
+  const dim3 grid(dis_red_grid((long)n * dis_cdiv(w, SM_TX) * dis_cdiv(h, SM_TY), 1));
   hipLaunchKernelGGL(smooth_kernel, grid, dim3(SM_TX * SM_TY), 0, s, disp, amb, acc, (const float*)nullptr,
                      (float*)nullptr, n, h, w, 0);
   hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)acc, out,
@@ -510,7 +516,7 @@ extern "C" int dis_smooth_loss_bwd(const float* disp, const float* amb, const fl
   if (!disp || !amb || !gscale || !grad_disp || !workspace) return DIS_ERR_NULL;
   if (n <= 0 || h < 3 || w < 3) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(dis_cdiv(w, SM_TX), dis_cdiv(h, SM_TY), n);
+  const dim3 grid(dis_ew_grid((long)n * dis_cdiv(w, SM_TX) * dis_cdiv(h, SM_TY), 1));
   hipLaunchKernelGGL(smooth_kernel, grid, dim3(SM_TX * SM_TY), 0, s, disp, amb, (double*)nullptr, gscale, workspace,
                      n, h, w, 1);
   hipLaunchKernelGGL(smooth_bwd_gather_kernel, dim3(dis_ew_grid((long)n * h * w, 256)), dim3(256), 0, s,
@@ -747,7 +753,7 @@ extern "C" int dis_geo_loss_fwd(const float* depth0, const float* depth1, const 
   GeoCam cam;
   fill_cam(cam, K_host, Kinv_host);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(geo_loss_fwd_kernel, dim3(dis_ew_grid((long)bs * h * w, 256)), dim3(256), 0, s, depth0, depth1,
+  hipLaunchKernelGGL(geo_loss_fwd_kernel, dim3(dis_red_grid((long)bs * h * w, 256)), dim3(256), 0, s, depth0, depth1,
                      flow0, flow1, amb0, amb1, primary_depth1, R0, t0, R1, t1, cam, clampv, mask_out, acc, bs, h, w);
   hipLaunchKernelGGL(ratio_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)acc, out, 1e-8);
   DIS_CHECK_LAUNCH();
