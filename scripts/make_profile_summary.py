@@ -20,7 +20,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = 'conv_bf16x3_kernel<'  # every <ACT, ACCUM, STATS> instance of the template
+DOMINANT = 'conv_bf16x3_kernel<32, 32,'  # every <ACT, ACCUM, STATS> instance of the 32 -> 32 kernel (bench.py's roofline)
 
 
 def main(tag):
@@ -75,7 +75,7 @@ def main(tag):
         calls = sum(int(m['Calls']) for m in fam)
         rd = sum(float(m['FETCH_SIZE']) * 2 * 1024 * int(m['Calls']) for m in fam) / calls
         wr = sum(float(m['WRITE_SIZE']) * 1024 * int(m['Calls']) for m in fam) / calls
-        json.dump({'kernel': 'conv_bf16x3_kernel<ACT, ACCUM, STATS> (all instances, launch-weighted)',
+        json.dump({'kernel': 'conv_bf16x3_kernel<32, 32, ACT, ACCUM, STATS> (all instances, launch-weighted)',
                    'hbm_bytes_per_launch': rd + wr, 'read_bytes': rd, 'write_bytes': wr,
                    'launches_averaged': calls,
                    'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over one eager step; '
