@@ -542,20 +542,42 @@ __global__ __launch_bounds__(256) void csr_scan3_kernel(int* __restrict__ cursor
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = bsum[nblk];
 }
-// sort every destination's (short) list by source row: fixed summation order in the gather
+// sort every destination's (short) list by source row: fixed summation order in the gather.  Lists of up to 16
+// entries (all of them in practice: 3 source frames x 4 bilinear corners, plus overlaps) are sorted in registers by
+// rank - every entry is read once and written once, at list start + number of entries that sort before it (rows are
+// unique within a list up to exact duplicates, which the index tie-break orders); longer lists fall back to an
+// insertion sort in memory.
+#define CSR_SORT_MAX 16
 __global__ void csr_sort_kernel(const int* __restrict__ offsets, int* __restrict__ entries, long nd) {
   for (long d = blockIdx.x * (long)blockDim.x + threadIdx.x; d < nd; d += (long)gridDim.x * blockDim.x) {
     const int lo = offsets[d], hi = offsets[d + 1];
-    for (int a = lo + 1; a < hi; ++a) {
-      const int kr = entries[2 * (long)a], kw = entries[2 * (long)a + 1];
-      int bpos = a - 1;
-      while (bpos >= lo && entries[2 * (long)bpos] > kr) {
-        entries[2 * (long)bpos + 2] = entries[2 * (long)bpos];
-        entries[2 * (long)bpos + 3] = entries[2 * (long)bpos + 1];
-        --bpos;
+    const int len = hi - lo;
+    if (len <= 1) continue;
+    if (len <= CSR_SORT_MAX) {
+      int2 e[CSR_SORT_MAX];
+      const int2* src = (const int2*)entries + lo;
+#pragma unroll
+      for (int k = 0; k < CSR_SORT_MAX; ++k) e[k] = k < len ? src[k] : make_int2(0x7fffffff, 0);
+      int2* dst = (int2*)entries + lo;
+#pragma unroll
+      for (int k = 0; k < CSR_SORT_MAX; ++k) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < CSR_SORT_MAX; ++j) rank += (e[j].x < e[k].x || (e[j].x == e[k].x && j < k)) ? 1 : 0;
+        if (k < len) dst[rank] = e[k];
       }
-      entries[2 * (long)bpos + 2] = kr;
-      entries[2 * (long)bpos + 3] = kw;
+    } else {
+      for (int a = lo + 1; a < hi; ++a) {
+        const int kr = entries[2 * (long)a], kw = entries[2 * (long)a + 1];
+        int bpos = a - 1;
+        while (bpos >= lo && entries[2 * (long)bpos] > kr) {
+          entries[2 * (long)bpos + 2] = entries[2 * (long)bpos];
+          entries[2 * (long)bpos + 3] = entries[2 * (long)bpos + 1];
+          --bpos;
+        }
+        entries[2 * (long)bpos + 2] = kr;
+        entries[2 * (long)bpos + 3] = kw;
+      }
     }
   }
 }
