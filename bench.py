@@ -227,9 +227,9 @@ def main():
             # dis_conv2d_fwd[_bf16x3] int args: (n, hin, win, cin, cout, k, stride, pad, act); same kernel for the
             # forward 32->32 3x3 convs and their input gradients
             sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_conv2d_fwd_bf16x3' and ia[3:7] == (32, 32, 3, 1)]
-            # (the product path hands the OIHW weights to the kernel: same int args behind `mode, w_o, w_i`; the 32 -> 32 instance)
-            sel += [(ia[3:], ms) for name, ia, ms in rec
-                    if name == 'dis_conv2d_fwd_bf16x3_oihw' and ia[6:10] == (32, 32, 3, 1)]
+            # (the product path hands the OIHW weights to the kernel: same int args behind `mode, w_o, w_i, w_row_stride`; the 32 -> 32 instance)
+            sel += [(ia[4:], ms) for name, ia, ms in rec
+                    if name == 'dis_conv2d_fwd_bf16x3_oihw' and ia[7:11] == (32, 32, 3, 1)]
             kname = ('conv_bf16x3_kernel (fp32 conv as 6 bf16 products per MAC on v_mfma_f32_16x16x32_bf16, fp32 '
                      'accumulate; TFLOP/s are fp32-equivalent algorithmic flops)')
             peak, peak_note = PEAK_BF16_MFMA_TFLOPS / 6.0, 'bf16 MFMA dense peak (2500 TFLOP/s) / 6 products per fp32 MAC'

@@ -40,6 +40,7 @@ struct ConvArgs {
   const float* yscale;  // optional (n,hf,wf,COUT/32): output pixel x 32-channel-group multiplier (before bias/accum)
   int wmode;  // bf16x3 kernel only: -1 = w is packed; 0 / 1 = w is OIHW fp32, split in the kernel (forward / input gradient)
   int w_o, w_i;  // ... and its leading dims
+  int w_rs;      // ... and the floats between its rows (w_i * 9 if dense; larger for a slice w[:, a:b] of a wider weight)
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     // (k-step, lane group, cout) units of 3 x 8 bf16.
     float* ws = (float*)xl;
     const int row = a.w_i * 9, nw = a.w_o * row;
-    for (int i = threadIdx.x; i < nw; i += 512) ws[(i / row) * (row + 1) + i % row] = a.w[i];
+    for (int i = threadIdx.x; i < nw; i += 512) ws[(i / row) * (row + 1) + i % row] = a.w[(i / row) * a.w_rs + i % row];
     __syncthreads();
     for (int u = threadIdx.x; u < KS * 4 * COUT; u += 512) {
       const int co = u % COUT, g = (u / COUT) & 3, ks = u / (4 * COUT);
@@ -989,7 +990,7 @@ extern "C" int dis_conv2d_pack_weights_bf16x3(const float* w_oihw, void* packed,
   return DIS_OK;
 }
 
-static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o, int w_i, const float* bias, float* y,
+static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o, int w_i, int w_rs, const float* bias, float* y,
                               double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad,
                               int act, void* stream) {
   if (!x || !w || !y) return DIS_ERR_NULL;
@@ -1008,6 +1009,7 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
   a.wmode = wmode;
   a.w_o = w_o;
   a.w_i = w_i;
+  a.w_rs = w_rs;
   if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
   // the kernel addresses x and y per sample through buffer descriptors with 31-bit byte offsets
   if ((long)hin * win * cin * 4 >= 0x7fff0000L || (long)hout * wout * cout * 4 >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
@@ -1033,16 +1035,20 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
 extern "C" int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bias, float* y, double* stats,
                                      int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act,
                                      void* stream) {
-  return launch_conv_bf16x3(x, w_packed, -1, 0, 0, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act, stream);
+  return launch_conv_bf16x3(x, w_packed, -1, 0, 0, 0, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act, stream);
 }
 /* w_oihw (w_o, w_i, 3, 3) as stored by the module: mode 0 needs cout == w_o and cin >= w_i (zero-padded input channels),
- * mode 1 (input gradient of that conv) cin == w_o and cout >= w_i. */
-extern "C" int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, int mode, int w_o, int w_i, const float* bias,
-                                          float* y, double* stats, int n, int hin, int win, int cin, int cout, int k,
-                                          int stride, int pad, int act, void* stream) {
+ * mode 1 (input gradient of that conv) cin == w_o and cout >= w_i.  w_row_stride: floats between consecutive w_o rows
+ * (0 or w_i*9: dense; larger when w_oihw points into a slice w[:, a:b] of a wider weight). */
+extern "C" int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, int mode, int w_o, int w_i, int w_row_stride,
+                                          const float* bias, float* y, double* stats, int n, int hin, int win, int cin,
+                                          int cout, int k, int stride, int pad, int act, void* stream) {
   if (mode < 0 || mode > 1 || w_o <= 0 || w_i <= 0 || w_o > 32 || w_i > 32) return DIS_ERR_UNSUPPORTED;
   if (mode == 0 ? (cout != w_o || cin < w_i) : (cin != w_o || cout < w_i)) return DIS_ERR_BAD_SHAPE;
-  return launch_conv_bf16x3(x, w_oihw, mode, w_o, w_i, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act, stream);
+  if (w_row_stride == 0) w_row_stride = w_i * 9;
+  if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
+  return launch_conv_bf16x3(x, w_oihw, mode, w_o, w_i, w_row_stride, bias, y, stats, n, hin, win, cin, cout, k, stride,
+                            pad, act, stream);
 }
 
 

@@ -49,7 +49,7 @@ SIGS = {
     'dis_conv2d_fwd': 'pppppiiiiiiiiip',
     'dis_conv2d_pack_weights_bf16x3': 'ppiiiip',
     'dis_conv2d_fwd_bf16x3': 'pppppiiiiiiiiip',
-    'dis_conv2d_fwd_bf16x3_oihw': 'ppiiipppiiiiiiiiip',
+    'dis_conv2d_fwd_bf16x3_oihw': 'ppiiiipppiiiiiiiiip',
     'dis_conv2d_pack_bf16x3_size': 'ii',
     'dis_conv2d_fwd_scaled': 'ppppppp' + 'iiiiiiiii' + 'p',
     'dis_conv2d_wgrad_scaled': 'pppppp' + 'iiiiiiiii' + 'p',

@@ -110,6 +110,25 @@ def _sink(param):
     return g, g
 
 
+def _sink_block(params):
+    """Gradient sink for a kernel that writes the gradients of several parameters as ONE contiguous block (Conv3D's
+    five arrays): -> flat float view covering all of them if they are registered, unused so far and adjacent in the
+    flat gradient buffer in this order, else None (the caller then returns separate tensors to autograd)."""
+    es = []
+    for p_ in params:
+        e = _GRAD_SINK.get(p_.data_ptr())
+        if (e is None or e[1] or e[0].shape != p_.shape or p_.grad is None or p_.grad.data_ptr() != e[0].data_ptr()):
+            return None
+        es.append(e)
+    for a, b in zip(es[:-1], es[1:]):
+        if b[0].data_ptr() != a[0].data_ptr() + a[0].numel() * 4:
+            return None
+    for e in es:
+        e[1] = True
+    first = es[0][0]
+    return torch.as_strided(first, (sum(e[0].numel() for e in es),), (1,), first.storage_offset())
+
+
 # --------------------------------------------------------------------------------------------------
 # LCN
 # --------------------------------------------------------------------------------------------------
@@ -308,6 +327,7 @@ class _GeoLossDir(torch.autograd.Function):
         ctx.save_for_backward(depth0, depth1, flow0, R0, t0, R1, t1, mask, acc)
         ctx.cfg = (K, Kinv, float(clamp))
         ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)  # no zero tensor for the mask's (non-existent) gradient
         return out, mask
 
     @staticmethod
@@ -448,10 +468,12 @@ def _conv_fwd_any(x, weight, cin_pad, mode, bias, y, stats, n, hin, win, cin, co
     channels on both sides.  `weight` is the module's OIHW tensor, `mode` the weight order (0 forward, 1 stride-1 input
     gradient); `cin` / `cout` are the channel counts of x and y in THIS call (swapped for the input gradient)."""
     if BF16X3 and cin in (16, 32) and cout in (16, 32) and k == 3 and stride == 1:
-        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, weight, mode, weight.shape[0], weight.shape[1], bias, y, stats, n, hin,
-                 win, cin, cout, k, stride, pad, act)
+        # `weight` may be a slice w[:, a:b] of a wider weight (conv2d_multi): the kernel reads it through its row stride
+        assert weight.stride(1) == 9 and weight.stride(2) == 3 and weight.stride(3) == 1
+        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, weight, mode, weight.shape[0], weight.shape[1], weight.stride(0), bias, y,
+                 stats, n, hin, win, cin, cout, k, stride, pad, act)
     else:
-        lib.call('dis_conv2d_fwd', x, _pack_w(weight, cin_pad, mode), bias, y, stats, n, hin, win, cin, cout, k, stride,
+        lib.call('dis_conv2d_fwd', x, _pack_w(_c(weight), cin_pad, mode), bias, y, stats, n, hin, win, cin, cout, k, stride,
                  pad, act)
 
 
@@ -475,6 +497,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.join = join
         if want_stats:
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)  # no zero tensor for the statistics' (non-existent) gradient
             return y, stats
         return y, None
 
@@ -545,7 +568,7 @@ class _Conv2dMulti(torch.autograd.Function):
         off = 0
         for i, x in enumerate(xs):
             last = i == len(xs) - 1
-            wi = weight[:, off:off + cs[i]].contiguous()
+            wi = weight[:, off:off + cs[i]]  # a view: no copy
             a = (act if last else ACT_NONE) | (CONV_ACCUM if i > 0 else 0)
             _conv_fwd_any(x, wi, cs[i], 0, bias if i == 0 else None, y, stats if last else None, n, h, w, cs[i], cout, k, 1,
                           pad, a)
@@ -557,6 +580,7 @@ class _Conv2dMulti(torch.autograd.Function):
         ctx.bias_ref = bias
         if want_stats:
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)  # no zero tensor for the statistics' (non-existent) gradient
             return y, stats
         return y, None
 
@@ -578,14 +602,14 @@ class _Conv2dMulti(torch.autograd.Function):
         gxs = []
         off = 0
         for i, x in enumerate(xs):
-            wi = weight[:, off:off + cs[i]].contiguous()
+            wi = weight[:, off:off + cs[i]]  # a view: no copy
             gx = None
             if ctx.needs_input_grad[6 + i]:
                 gx = torch.empty_like(x)
                 _conv_fwd_any(gpre, wi, cs[i], 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cs[i], k, 1,
                               k - 1 - pad, ACT_NONE)
             gxs.append(gx)
-            gwi = torch.empty_like(wi)
+            gwi = torch.empty((cout, cs[i], k, k), dtype=torch.float32, device=x.device)
             wsz = lib.fn('dis_conv2d_wgrad_workspace')(cs[i], cout, k, 1)
             if wsz < 0:
                 raise lib.DisHipError(f'conv2d_multi wgrad: unsupported shape cin={cs[i]} cout={cout} k={k}')
@@ -624,6 +648,7 @@ class _Conv2dScaledIn(torch.autograd.Function):
         ctx.join = join
         if want_stats:
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)  # no zero tensor for the statistics' (non-existent) gradient
             return y, stats
         return y, None
 
@@ -1020,12 +1045,15 @@ class _Conv3dKnn(torch.autograd.Function):
         join = ctx.join
         second = join is not None and join.buf is not None
         gwf = join.take(wf.shape) if second else torch.zeros_like(wf)  # the scatter accumulates (float atomics)
-        gp = torch.empty(1632, dtype=torch.float32, device=wf.device)
+        sunk = _sink_block((d1w, d1b, d2w, d2b, w))  # the kernel's parameter-gradient block IS the flat buffer's order
+        gp = sunk if sunk is not None else torch.empty(1632, dtype=torch.float32, device=wf.device)
         acc = torch.empty(lib.fn('dis_conv3d_knn_bwd_workspace')(), dtype=torch.float32, device=wf.device)
         lib.call('dis_conv3d_knn_bwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, _c(gy), gwf, gp, acc, tl, bs, h, wd,
                  ctx.stride)
         if join is not None and not second:
             gwf = join.first(gwf)
+        if sunk is not None:
+            return (None, gwf, None, None, None, None, None, None, None, None)
         return (None, gwf, gp[0:48].view(16, 3), gp[48:64], gp[64:576].view(32, 16), gp[576:608],
                 gp[608:1632].view(32, 32), None, None, None)
 

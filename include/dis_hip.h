@@ -205,10 +205,11 @@ int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bia
 /* The same with the module's OIHW fp32 weights (w_o, w_i, 3, 3) handed over as they are: the kernel splits them into its
  * LDS-resident bf16 planes itself, which saves the packing launch per convolution call.  mode 0: forward (cout == w_o,
  * cin >= w_i: x may carry zero-padded extra channels); mode 1: input gradient of that convolution (cin == w_o,
- * cout >= w_i). */
-int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, int mode, int w_o, int w_i, const float* bias, float* y,
-                               double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad,
-                               int act, void* stream);
+ * cout >= w_i).  w_row_stride: floats between consecutive w_o rows (0 = dense = w_i*9; larger when w_oihw points at
+ * w[:, a:b] inside a wider weight, as for the parts of a convolution over concatenated inputs). */
+int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, int mode, int w_o, int w_i, int w_row_stride,
+                               const float* bias, float* y, double* stats, int n, int hin, int win, int cin, int cout,
+                               int k, int stride, int pad, int act, void* stream);
 
 /* dis_conv2d_fwd with per-pixel multipliers fused into the kernel (both optional, may be NULL):
  *   xscale (n,hin,win,NCHUNK): x[pixel][chunk c] is multiplied by xscale[pixel][c] while it is staged (NCHUNK = cin/32

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Which host code launches the small ATen kernels (adds, fills, copies) of a DIS-MF step: torch.profiler over one eager
-step, ATen ops with a device kernel grouped by (op, innermost repo source line).   python scripts/torch_glue_profile.py"""
+"""Which tensors the small ATen kernels (adds, fills, copies) of a DIS-MF step work on: torch.profiler over one eager
+step, ATen ops with a device kernel grouped by (op, input shapes).   python scripts/torch_glue_profile.py"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -37,22 +37,17 @@ for _ in range(2):
     step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
 agg = collections.Counter()
 tim = collections.Counter()
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for ev in prof.key_averages(group_by_stack_n=12):
+for ev in prof.key_averages(group_by_input_shape=True):
     dt = getattr(ev, 'self_device_time_total', 0) or getattr(ev, 'self_cuda_time_total', 0)
     if not ev.key.startswith('aten::') or dt <= 0:
         continue
-    where = '?'
-    for fr in ev.stack or []:
-        if 'depthinspace_amd/' in fr or 'bench.py' in fr:
-            where = fr.split('repo/')[-1]
-            break
-    agg[(ev.key, where)] += ev.count
-    tim[(ev.key, where)] += dt
-for (name, where), c in sorted(agg.items(), key=lambda kv: -tim[kv[0]])[:45]:
-    print(f'{c:4d} x {name:22s} {tim[(name, where)]:8.0f} us  {where[:110]}')
+    k = (ev.key, str(ev.input_shapes)[:90])
+    agg[k] += ev.count
+    tim[k] += dt
+for (name, where), c in sorted(agg.items(), key=lambda kv: -tim[kv[0]])[:60]:
+    print(f'{c:4d} x {name:22s} {tim[(name, where)]:8.0f} us  {where}')

@@ -341,9 +341,9 @@ def test_conv_bf16x3_is_fp32_accurate(h, w, cin, cout, cin_real):
                 lib.call('dis_conv2d_fwd', gy, ops._pack_w(wt, cin, 1), None, gx, None, n, h, w, cout, cin, 3, 1, 1, 0)
             lib.call('dis_conv2d_wgrad', x, gy, gw, gb, ws, n, h, w, cin, cin_real, cout, 3, 1, 1)
         else:
-            lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, 0, cout, cin_real, b, y, None, n, h, w, cin, cout, 3, 1, 1, 0)
+            lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, 0, cout, cin_real, 0, b, y, None, n, h, w, cin, cout, 3, 1, 1, 0)
             if cin_real == cin:
-                lib.call('dis_conv2d_fwd_bf16x3_oihw', gy, wt, 1, cout, cin_real, None, gx, None, n, h, w, cout, cin, 3, 1,
+                lib.call('dis_conv2d_fwd_bf16x3_oihw', gy, wt, 1, cout, cin_real, 0, None, gx, None, n, h, w, cout, cin, 3, 1,
                          1, 0)
             lib.call('dis_conv2d_wgrad_bf16x3', x, gy, gw, gb, ws, n, h, w, cin, cin_real, cout, 3, 1, 1)
         egx = relerr(gx[..., :cin_real].permute(0, 3, 1, 2), xr.grad) if cin_real == cin else 0.0
@@ -383,7 +383,7 @@ def test_conv_bf16x3_variants_agree(h, w, pad, act, cin, cout):
         # OIHW weights split inside the kernel: bit-identical to the packed path
         y1 = torch.empty_like(y0)
         st = torch.zeros(2 * n, dtype=torch.float64, device='cuda')
-        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, mode, wt.shape[0], wt.shape[1], b, y1, st, n, h, w, cin, cout, 3, 1,
+        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, mode, wt.shape[0], wt.shape[1], 0, b, y1, st, n, h, w, cin, cout, 3, 1,
                  pad, act)
         assert torch.equal(y0, y1)
         # statistics of what was written
@@ -392,7 +392,7 @@ def test_conv_bf16x3_variants_agree(h, w, pad, act, cin, cout):
         # accumulate mode: y = act(y_old + conv + bias)
         yold = torch.randn(n, ho, wo, cout, generator=g).cuda()
         y2 = yold.clone()
-        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, mode, wt.shape[0], wt.shape[1], b, y2, None, n, h, w, cin, cout, 3,
+        lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, mode, wt.shape[0], wt.shape[1], 0, b, y2, None, n, h, w, cin, cout, 3,
                  1, pad, act | 0x100)
         pre = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wr, b.double().cpu(), padding=pad) + \
             yold.permute(0, 3, 1, 2).double().cpu()
@@ -409,6 +409,6 @@ def test_conv_bf16x3_zero_padded_input_channels():
     wt = (torch.randn(16, 5, 3, 3, generator=g) * 0.1).cuda()
     b = torch.randn(16, generator=g).cuda()
     y = torch.empty(n, h, w, 16, device='cuda')
-    lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, 0, 16, 5, b, y, None, n, h, w, 16, 16, 3, 1, 1, 0)
+    lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, 0, 16, 5, 0, b, y, None, n, h, w, 16, 16, 3, 1, 1, 0)
     ref = F.conv2d(x[..., :5].permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), b.double().cpu(), padding=1)
     assert relerr(y.permute(0, 3, 1, 2), ref) < 3e-6
