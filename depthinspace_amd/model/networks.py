@@ -282,14 +282,17 @@ class Multi_Frame_Flow_Consistency_Loss(ProjectionBaseLoss):
         self.mod_name = 'Multi_Frame_Flow_Consistency_Loss'
         self.clamp = clamp  # stored but unused, as in the reference
 
-    def fwd(self, depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1, primary_depth1):
+    def fwd(self, depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1, primary_depth1, accs=None):
         val, _ = ops.geo_loss_dir(depth0, depth1, flow0, flow1, amb0, amb1, primary_depth1, R0, t0, R1, t1,
-                                  self._K_host, self._Ki_host, -1.0)
+                                  self._K_host, self._Ki_host, -1.0, accs)
         return val
 
-    def tforward(self, depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1, primary_depth0, primary_depth1):
-        l0 = self.fwd(depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1, primary_depth1)
-        l1 = self.fwd(depth1, depth0, R1, t1, R0, t0, flow1, flow0, amb1, amb0, primary_depth0)
+    def tforward(self, depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1, primary_depth0, primary_depth1,
+                 accs=None):
+        """accs (not in the reference): optional (ops.GradAccum of depth0, of depth1), see ops.GradAccum."""
+        l0 = self.fwd(depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1, primary_depth1, accs)
+        l1 = self.fwd(depth1, depth0, R1, t1, R0, t0, flow1, flow0, amb1, amb0, primary_depth0,
+                      (accs[1], accs[0]) if accs is not None else None)
         return l0 + l1
 
 

@@ -85,6 +85,33 @@ class GradJoin(object):
         return b.view(shape)
 
 
+class GradAccum(object):
+    """Shared gradient buffer of a tensor with SEVERAL consumers whose backward kernels accumulate (+= / atomics) into
+    their output, e.g. a frame's depth map in the 6 directional flow-consistency terms it takes part in.  Every consumer
+    calls use() in its forward; in backward it accumulates into buffer(like) and returns done() to autograd: None for
+    all but the consumer that runs last, which hands over the sum.  One zero fill and no autograd adds instead of one
+    fill per consumer and a chain of `g1 + g2`.  Create one per tensor and forward pass."""
+
+    def __init__(self):
+        self.buf = None
+        self.pending = 0
+
+    def use(self):
+        self.pending += 1
+
+    def buffer(self, like):
+        if self.buf is None:
+            self.buf = torch.zeros_like(like)
+        return self.buf
+
+    def done(self):
+        self.pending -= 1
+        if self.pending == 0:
+            b, self.buf = self.buf, None
+            return b
+        return None
+
+
 def register_grad_sinks(params):
     _GRAD_SINK.clear()
     for p in params:
@@ -312,7 +339,11 @@ class _GeoLossDir(torch.autograd.Function):
     """One direction of the flow-consistency loss (dis_geo_loss_fwd/bwd)."""
 
     @staticmethod
-    def forward(ctx, depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1, K, Kinv, clamp):
+    def forward(ctx, depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1, K, Kinv, clamp, accs):
+        ctx.accs = accs  # optional (GradAccum of depth0, GradAccum of depth1)
+        if accs is not None:
+            accs[0].use()
+            accs[1].use()
         ts = [_c(t) for t in (depth0, depth1, flow0, flow1, amb0, amb1)]
         depth0, depth1, flow0, flow1, amb0, amb1 = ts
         pdepth1 = _c(pdepth1) if pdepth1 is not None else None
@@ -335,16 +366,20 @@ class _GeoLossDir(torch.autograd.Function):
         depth0, depth1, flow0, R0, t0, R1, t1, mask, acc = ctx.saved_tensors
         K, Kinv, clamp = ctx.cfg
         bs, _, h, w = depth0.shape
-        g0 = torch.zeros_like(depth0)
-        g1 = torch.zeros_like(depth1)
+        accs = ctx.accs
+        g0 = accs[0].buffer(depth0) if accs is not None else torch.zeros_like(depth0)
+        g1 = accs[1].buffer(depth1) if accs is not None else torch.zeros_like(depth1)
         lib.call('dis_geo_loss_bwd', depth0, depth1, flow0, R0, t0, R1, t1, K, Kinv, clamp, mask, acc, _c(g), g0, g1,
-                 bs, h, w)
-        return (g0, g1) + (None,) * 12
+                 bs, h, w)  # accumulates into g0 (+=) and g1 (atomics)
+        if accs is not None:
+            g0, g1 = accs[0].done(), accs[1].done()
+        return (g0, g1) + (None,) * 13
 
 
-def geo_loss_dir(depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1, K, Kinv, clamp=-1.0):
-    """K, Kinv: lib.host_floats(9).  Returns (loss, mask)."""
-    return _GeoLossDir.apply(depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1, K, Kinv, clamp)
+def geo_loss_dir(depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1, K, Kinv, clamp=-1.0, accs=None):
+    """K, Kinv: lib.host_floats(9).  accs: optional (GradAccum, GradAccum) shared gradient buffers of depth0 / depth1.
+    Returns (loss, mask)."""
+    return _GeoLossDir.apply(depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1, K, Kinv, clamp, accs)
 
 
 # --------------------------------------------------------------------------------------------------
