@@ -80,12 +80,16 @@ extern "C" int dis_lcn_fwd(const float* x, float* out_lcn, float* out_std, int n
 #define PH_TY 8
 #define PH_MAXP 7
 
-__device__ __forceinline__ float census_h(float d, float eps) { return 0.5f * (1.f + d / sqrtf(d * d + eps)); }
-// d/dd of census_h
-__device__ __forceinline__ float census_dh(float d, float eps) {
-  float q = d * d + eps;
-  return 0.5f * eps / (q * sqrtf(q));
-}
+// soft sign of the census transform, h(d) = 0.5 (1 + d / sqrt(d^2 + eps)), and its derivative 0.5 eps (d^2 + eps)^-3/2.
+// Both go through ONE v_rsq_f32 (1 ulp; q >= eps > 0): the kernels are bound by exactly this arithmetic (81 taps x 2
+// soft signs per pixel), and an IEEE sqrt + an IEEE division per soft sign cost ~4x as many instructions.
+__device__ __forceinline__ float census_rsq(float d, float eps) { return __builtin_amdgcn_rsqf(d * d + eps); }
+// h(a) - h(b) given the two reciprocal roots (the 0.5 (1 + .) parts cancel)
+__device__ __forceinline__ float census_hdiff(float a, float ra, float b, float rb) { return 0.5f * (a * ra - b * rb); }
+__device__ __forceinline__ float census_dh_r(float r, float eps) { return (0.5f * eps) * (r * r * r); }
+// the reference's own evaluation order (IEEE sqrt and division): used only to decide the SIGN of h(a) - h(b) when the
+// fast difference is within rounding of zero, so that |.|' takes the same branch as the reference's autograd
+__device__ __forceinline__ float census_h_exact(float d, float eps) { return 0.5f * (1.f + d / sqrtf(d * d + eps)); }
 
 template <int TYPE>
 __global__ __launch_bounds__(PH_TX* PH_TY) void photometric_fwd_kernel(const float* __restrict__ es,
@@ -122,7 +126,8 @@ __global__ __launch_bounds__(PH_TX* PH_TY) void photometric_fwd_kernel(const flo
         } else if (TYPE == 1) {
           r = fabsf(e - t);
         } else {
-          float diff = census_h(e - ec, eps) - census_h(t - tc, eps);
+          const float de = e - ec, dt = t - tc;
+          const float diff = census_hdiff(de, census_rsq(de, eps), dt, census_rsq(dt, eps));
           r = (TYPE == 2) ? diff * diff : fabsf(diff);
         }
         acc += r;
@@ -208,9 +213,12 @@ __global__ __launch_bounds__(PH_TX* PH_TY) void photometric_bwd_kernel(const flo
             //     h(-d) = 1 - h(d) and h' is even, so diff' = -diff and term (b) = +g_k * s * h'(des): both roles share
             //     one evaluation of the two soft signs (half the sqrt/div work of evaluating them separately).
             float des = ek - e, dta = tk - t;
-            float diff = census_h(des, eps) - census_h(dta, eps);
+            const float re = census_rsq(des, eps);
+            float diff = census_hdiff(des, re, dta, census_rsq(dta, eps));
+            if (TYPE == 3 && fabsf(diff) < 1e-5f && (des != 0.f || dta != 0.f))  // (rare: ~1e-5 of the taps)
+              diff = census_h_exact(des, eps) - census_h_exact(dta, eps);
             float s = (TYPE == 2) ? 2.f * diff : (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
-            acc += (mult * g + gk) * (s * census_dh(des, eps));
+            acc += (mult * g + gk) * (s * census_dh_r(re, eps));
           }
         }
       }
