@@ -41,6 +41,7 @@ struct ConvArgs {
   int wmode;  // bf16x3 kernel only: -1 = w is packed; 0 / 1 = w is OIHW fp32, split in the kernel (forward / input gradient)
   int w_o, w_i;  // ... and its leading dims
   int w_rs;      // ... and the floats between its rows (w_i * 9 if dense; larger for a slice w[:, a:b] of a wider weight)
+  const float* xact;  // bf16x3 kernel, INACT instances: activation OUTPUT at x's positions; x is multiplied by act'(xact)
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -637,7 +638,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bx_rsrc(const void* p, unsigne
 // Only the LDS refill (two barriers + split + ds_write) stays serial.
 // The weights are the MFMA's A operand (M = cout) and the pixels its B operand (N = pixel): a lane then holds 4
 // consecutive output channels of one pixel and stores a float4.
-template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS>
+// INACT != 0 (input-gradient launches of a conv that had an activation): x is the gradient wrt the activation's OUTPUT
+// and a.xact that output; the halo is staged as x * act'(xact), which replaces a separate pass over the tensor.
+template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0>
 __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   using C = BxCfg<CIN, COUT>;
   constexpr int PS = C::PS, NT = C::NT, KS = C::KS, NLOAD = C::NLOAD, NPIECE = C::NPIECE, CV = C::CV;
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
 
   // this thread's halo items: (row, col) inside the 18x18 halo and the byte offset from the halo's first pixel.
   // Items past the end of the halo (last round only) get a row that is outside every image.
-  float4 pre[NLOAD];
+  float4 pre[NLOAD], pre2[INACT ? NLOAD : 1];
   int it_rc[NLOAD], it_off[NLOAD];
 #pragma unroll
   for (int it = 0; it < NLOAD; ++it) {
@@ -688,13 +691,21 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
     const unsigned off = ok ? (unsigned)(pf_off0 + it_off[it]) : BX_OOB;
     pre[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(pf_x, pf_bytes), off, 0, 0));
+    if (INACT)
+      pre2[it] = __builtin_bit_cast(
+          float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.xact + (pf_x - a.x), pf_bytes), off, 0, 0));
   };
   auto stage = [&]() {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the halo loads (one unconditional wait, not one per divergent item)
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
       if ((int)threadIdx.x + it * 512 < C::NITEMS) {
-        const float4 v = pre[it];
+        float4 v = pre[it];
+        if (INACT) {
+          const float4 q = pre2[it];
+          v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
+          v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
+        }
         unsigned a1, a2, a3, b1, b2, b3;
         split3_pair(v.x, v.y, a1, a2, a3);
         split3_pair(v.z, v.w, b1, b2, b3);
@@ -939,12 +950,12 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
 
 // (cin, cout) -> kernel instance
 template <int CIN, int COUT>
-static hipError_t bx_launch(const ConvArgs& a, bool stats, long grid, hipStream_t stream) {
+static hipError_t bx_launch(const ConvArgs& a, bool stats, int inact, long grid, hipStream_t stream) {
   using C = BxCfg<CIN, COUT>;
   const int variant = (a.act * 2 + a.accum) * 2 + (stats ? 1 : 0);
-  static bool attr_set[12] = {};
+  static bool attr_set[12 + 4] = {};
   auto launch = [&](auto kern) -> hipError_t {
-    bool& set = attr_set[variant];
+    bool& set = attr_set[inact ? 12 + (inact - 1) * 2 + a.accum : variant];
     if (!set) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
       if (e != hipSuccess) return e;
@@ -953,6 +964,14 @@ static hipError_t bx_launch(const ConvArgs& a, bool stats, long grid, hipStream_
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
     return hipSuccess;
   };
+  if (inact) {  // input gradient with the activation gradient fused into the staging: no epilogue activation, no statistics
+    if (a.act != DIS_ACT_NONE || stats) return hipErrorInvalidValue;
+    if (inact == DIS_ACT_SELU)
+      return a.accum ? launch(conv_bf16x3_kernel<CIN, COUT, DIS_ACT_NONE, true, false, DIS_ACT_SELU>)
+                     : launch(conv_bf16x3_kernel<CIN, COUT, DIS_ACT_NONE, false, false, DIS_ACT_SELU>);
+    return a.accum ? launch(conv_bf16x3_kernel<CIN, COUT, DIS_ACT_NONE, true, false, DIS_ACT_RELU>)
+                   : launch(conv_bf16x3_kernel<CIN, COUT, DIS_ACT_NONE, false, false, DIS_ACT_RELU>);
+  }
   switch (variant) {
 #define BX_CASE(ACT_, ACC_, ST_) \
   case ((ACT_)*2 + (ACC_)) * 2 + (ST_): return launch(conv_bf16x3_kernel<CIN, COUT, ACT_, (ACC_) != 0, (ST_) != 0>);
@@ -992,7 +1011,7 @@ extern "C" int dis_conv2d_pack_weights_bf16x3(const float* w_oihw, void* packed,
 
 static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o, int w_i, int w_rs, const float* bias, float* y,
                               double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad,
-                              int act, void* stream) {
+                              int act, void* stream, const float* xact = nullptr, int inact = 0) {
   if (!x || !w || !y) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0 || pad < 0) return DIS_ERR_BAD_SHAPE;
   if (!bx_shape_ok(cin, cout, k, stride)) return DIS_ERR_UNSUPPORTED;
@@ -1010,6 +1029,8 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
   a.w_o = w_o;
   a.w_i = w_i;
   a.w_rs = w_rs;
+  a.xact = xact;
+  if (inact < 0 || inact > DIS_ACT_RELU || (inact && !xact)) return DIS_ERR_UNSUPPORTED;
   if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
   // the kernel addresses x and y per sample through buffer descriptors with 31-bit byte offsets
   if ((long)hin * win * cin * 4 >= 0x7fff0000L || (long)hout * wout * cout * 4 >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
@@ -1023,10 +1044,10 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
   if (grid >= 8) grid -= grid % 8;
   if (grid < 1) grid = 1;
   hipError_t le;
-  if (cin == 32 && cout == 32) le = bx_launch<32, 32>(a, stats != nullptr, grid, (hipStream_t)stream);
-  else if (cin == 16 && cout == 16) le = bx_launch<16, 16>(a, stats != nullptr, grid, (hipStream_t)stream);
-  else if (cin == 16 && cout == 32) le = bx_launch<16, 32>(a, stats != nullptr, grid, (hipStream_t)stream);
-  else le = bx_launch<32, 16>(a, stats != nullptr, grid, (hipStream_t)stream);
+  if (cin == 32 && cout == 32) le = bx_launch<32, 32>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
+  else if (cin == 16 && cout == 16) le = bx_launch<16, 16>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
+  else if (cin == 16 && cout == 32) le = bx_launch<16, 32>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
+  else le = bx_launch<32, 16>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
   if (le != hipSuccess) return (int)le;
   DIS_CHECK_LAUNCH();
   return DIS_OK;
@@ -1049,6 +1070,21 @@ extern "C" int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, i
   if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
   return launch_conv_bf16x3(x, w_oihw, mode, w_o, w_i, w_row_stride, bias, y, stats, n, hin, win, cin, cout, k, stride,
                             pad, act, stream);
+}
+/* Input gradient of a 3x3 stride-1 convolution that was followed by an activation, with the activation's gradient fused
+ * in: gx (+)= conv_T(gy * act'(y), w) where y (same shape as gy) is the activation's output.  Replaces dis_act_bwd +
+ * dis_conv2d_fwd_bf16x3_oihw(mode 1).  w_oihw (w_o, w_i, 3, 3) is the forward convolution's weight: gy has w_o channels,
+ * gx cout >= w_i.  accumulate != 0 adds into gx. */
+extern "C" int dis_conv2d_dgrad_bf16x3_act(const float* gy, const float* y, int act, const float* w_oihw, int w_o, int w_i,
+                                           int w_row_stride, float* gx, int n, int hin, int win, int cin, int cout,
+                                           int pad, int accumulate, void* stream) {
+  if (!y) return DIS_ERR_NULL;
+  if (act != DIS_ACT_SELU && act != DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
+  if (w_o <= 0 || w_i <= 0 || w_o > 32 || w_i > 32 || cin != w_o || cout < w_i) return DIS_ERR_BAD_SHAPE;
+  if (w_row_stride == 0) w_row_stride = w_i * 9;
+  if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
+  return launch_conv_bf16x3(gy, w_oihw, 1, w_o, w_i, w_row_stride, nullptr, gx, nullptr, n, hin, win, cin, cout, 3, 1, pad,
+                            accumulate ? DIS_CONV_ACCUM : 0, stream, y, act);
 }
 
 
@@ -1092,6 +1128,7 @@ struct WgArgs {
   float* bpart;  // [worker][COUT] bias partial sums (written by chunk 0 / split 0 workgroups), may be null
   int n, hin, win, hout, wout, pad;
   const float* xscale;  // optional (n,hin,win,NCHUNK) multiplier of x (see ConvArgs::xscale)
+  const float* gact;    // bf16x3 kernel, INACT instances: activation OUTPUT at gy's positions; gy is multiplied by act'(gact)
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -1404,7 +1441,7 @@ __device__ __forceinline__ s16x8 tr_read8(const unsigned short* p0, const unsign
   return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int INACT = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   using C = WxCfg<CIN, COUT>;
   constexpr int PSX = C::PSX, PSG = C::PSG, NLX = C::NLX, NLG = C::NLG, NB = C::NB, TW = C::TW;
@@ -1426,7 +1463,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
 
   // halo / gradient items of this thread; pixels outside the image get an out-of-range buffer offset, which loads the
   // zero padding without a branch, a clamp or a mask (as in conv_bf16x3_kernel)
-  float4 prex[NLX], preg[NLG];
+  float4 prex[NLX], preg[NLG], preg2[INACT ? NLG : 1];  // (INACT: gy is staged as gy * act'(gact), as in conv_bf16x3_kernel)
   int ix_rc[NLX], ix_off[NLX], ig_rc[NLG], ig_off[NLG];
 #pragma unroll
   for (int it = 0; it < NLX; ++it) {
@@ -1464,6 +1501,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
       const bool ok = oy < a.hout && ox < a.wout;
       preg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(gb, g_bytes), ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
+      if (INACT)
+        preg2[it] = __builtin_bit_cast(
+            float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.gact + (gb - a.gy), g_bytes),
+                                                          ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
     }
   };
   auto put3 = [&](unsigned short* p, const float4& v, int plane) __attribute__((always_inline)) {
@@ -1484,7 +1525,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
       const int idx = threadIdx.x + it * 256;
-      const float4 v = preg[it];
+      float4 v = preg[it];
+      if (INACT) {
+        const float4 q = preg2[it];
+        v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
+        v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
+      }
       bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
       put3(gl + (idx / C::CVG) * PSG + (idx % C::CVG) * 4, v, COUT);
     }
@@ -1593,7 +1639,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   }
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int INACT = 0>
 static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hipStream_t s) {
   using C = WgCfg<CIN, COUT, 3, 3, 1>;
   using X = WxCfg<CIN, COUT>;
@@ -1603,7 +1649,7 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
     return DIS_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_bf16x3_kernel<CIN, COUT>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_bf16x3_kernel<CIN, COUT, INACT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, X::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -1616,7 +1662,7 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
   const long elems = C::PART;
   float* tmp = a.part + (long)WG_WORKERS * elems;
   a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
-  hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<CIN, COUT>), dim3((unsigned)workers), dim3(256), X::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<CIN, COUT, INACT>), dim3((unsigned)workers), dim3(256), X::LDS_BYTES, s, a);
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(dis_cdiv(elems, 256), WG_RSPLIT), dim3(256), 0, s,
                      (const float*)a.part, tmp, (int)workers, elems);
   const long total = (long)C::MROWS * COUT;
@@ -1662,23 +1708,45 @@ extern "C" long dis_conv2d_wgrad_workspace(int cin, int cout, int k, int stride)
 }
 
 // same contract as dis_conv2d_wgrad (and the same workspace size) for cin = cout = 32, k = 3, stride 1
-extern "C" int dis_conv2d_wgrad_bf16x3(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace,
-                                       int n, int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride,
-                                       int pad, void* stream) {
+static int wgrad_bf16x3_entry(const float* x, const float* gy, const float* gact, int inact, float* grad_w, float* grad_b,
+                              float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k,
+                              int stride, int pad, void* stream) {
   if (!x || !gy || !grad_w || !workspace) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0) return DIS_ERR_BAD_SHAPE;
   if (!bx_shape_ok(cin_pad, cout, k, stride) || cin_real <= 0 || cin_real > cin_pad) return DIS_ERR_UNSUPPORTED;
+  if (inact && (!gact || (inact != DIS_ACT_SELU && inact != DIS_ACT_RELU))) return DIS_ERR_UNSUPPORTED;
   const int hout = hin + 2 * pad - 2, wout = win + 2 * pad - 2;
   if (hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
   WgArgs a;
   a.x = x; a.gy = gy; a.part = workspace; a.bpart = nullptr;
   a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
   a.xscale = nullptr;
+  a.gact = gact;
   hipStream_t s = (hipStream_t)stream;
-  if (cin_pad == 32 && cout == 32) return launch_wgrad_bf16x3<32, 32>(a, grad_w, grad_b, cin_real, s);
-  if (cin_pad == 16 && cout == 16) return launch_wgrad_bf16x3<16, 16>(a, grad_w, grad_b, cin_real, s);
-  if (cin_pad == 16 && cout == 32) return launch_wgrad_bf16x3<16, 32>(a, grad_w, grad_b, cin_real, s);
-  return launch_wgrad_bf16x3<32, 16>(a, grad_w, grad_b, cin_real, s);
+#define WX_DISPATCH(CI, CO)                                                                                      \
+  if (cin_pad == CI && cout == CO) {                                                                             \
+    if (inact == DIS_ACT_SELU) return launch_wgrad_bf16x3<CI, CO, DIS_ACT_SELU>(a, grad_w, grad_b, cin_real, s); \
+    if (inact == DIS_ACT_RELU) return launch_wgrad_bf16x3<CI, CO, DIS_ACT_RELU>(a, grad_w, grad_b, cin_real, s); \
+    return launch_wgrad_bf16x3<CI, CO, 0>(a, grad_w, grad_b, cin_real, s);                                       \
+  }
+  WX_DISPATCH(32, 32) WX_DISPATCH(16, 16) WX_DISPATCH(16, 32) WX_DISPATCH(32, 16)
+#undef WX_DISPATCH
+  return DIS_ERR_UNSUPPORTED;
+}
+extern "C" int dis_conv2d_wgrad_bf16x3(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace,
+                                       int n, int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride,
+                                       int pad, void* stream) {
+  return wgrad_bf16x3_entry(x, gy, nullptr, 0, grad_w, grad_b, workspace, n, hin, win, cin_pad, cin_real, cout, k, stride,
+                            pad, stream);
+}
+/* The same for a convolution that was followed by an activation: gy is the gradient wrt the activation's OUTPUT y, and
+ * the kernel stages gy * act'(y) (weight and bias gradient of the pre-activation).  Replaces dis_act_bwd + the above. */
+extern "C" int dis_conv2d_wgrad_bf16x3_act(const float* x, const float* gy, const float* y, int act, float* grad_w,
+                                           float* grad_b, float* workspace, int n, int hin, int win, int cin_pad,
+                                           int cin_real, int cout, int k, int stride, int pad, void* stream) {
+  if (!y || act == DIS_ACT_NONE) return DIS_ERR_UNSUPPORTED;
+  return wgrad_bf16x3_entry(x, gy, y, act, grad_w, grad_b, workspace, n, hin, win, cin_pad, cin_real, cout, k, stride, pad,
+                            stream);
 }
 
 extern "C" int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace,

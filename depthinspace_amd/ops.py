@@ -512,6 +512,10 @@ def _conv_fwd_any(x, weight, cin_pad, mode, bias, y, stats, n, hin, win, cin, co
                  pad, act)
 
 
+def _bx_shape(cin, cout, k, stride):
+    return BF16X3 and cin in (16, 32) and cout in (16, 32) and k == 3 and stride == 1
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre=False, join=None):
@@ -543,7 +547,9 @@ class _Conv2d(torch.autograd.Function):
         n, hin, win, cin_pad = x.shape
         cout, cin, k, _ = weight.shape
         gy = _c(gy)
-        if act != ACT_NONE:
+        # bf16x3 shapes: the activation gradient is applied while gy is staged (dgrad and wgrad kernels), no separate pass
+        fuse_act = act != ACT_NONE and _bx_shape(cin_pad, cout, k, stride)
+        if act != ACT_NONE and not fuse_act:
             gpre = torch.empty_like(gy)
             lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
         else:
@@ -554,7 +560,10 @@ class _Conv2d(torch.autograd.Function):
             join = ctx.join
             second = join is not None and join.buf is not None
             gx = join.take(x.shape) if second else torch.empty_like(x)
-            if stride == 1:
+            if fuse_act:
+                lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, weight, cout, cin, weight.stride(0), gx, n, gy.shape[1],
+                         gy.shape[2], cout, cin, k - 1 - pad, 1 if second else 0)
+            elif stride == 1:
                 _conv_fwd_any(gpre, weight, cin, 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cin, k, 1,
                               k - 1 - pad, ACT_NONE | (CONV_ACCUM if second else 0))
             else:
@@ -569,7 +578,11 @@ class _Conv2d(torch.autograd.Function):
         if wsz < 0:
             raise lib.DisHipError(f'conv2d wgrad: unsupported shape cin={cin_pad} cout={cout} k={k} s={stride}')
         ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
-        _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
+        if fuse_act:
+            lib.call('dis_conv2d_wgrad_bf16x3_act', x, gy, y, act, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride,
+                     pad)
+        else:
+            _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
         return gx, gw_ret, gb_ret, None, None, None, None, None, None, None
 
 
@@ -627,7 +640,8 @@ class _Conv2dMulti(torch.autograd.Function):
         cout, cin, k, _ = weight.shape
         n, h, w, _ = xs[0].shape
         gy = _c(gy)
-        if act != ACT_NONE:
+        fuse_act = act != ACT_NONE and all(_bx_shape(c_, cout, k, 1) for c_ in cs)  # see _Conv2d.backward
+        if act != ACT_NONE and not fuse_act:
             gpre = torch.empty_like(gy)
             lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
         else:
@@ -641,15 +655,23 @@ class _Conv2dMulti(torch.autograd.Function):
             gx = None
             if ctx.needs_input_grad[6 + i]:
                 gx = torch.empty_like(x)
-                _conv_fwd_any(gpre, wi, cs[i], 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cs[i], k, 1,
-                              k - 1 - pad, ACT_NONE)
+                if fuse_act:
+                    lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, wi, cout, cs[i], wi.stride(0), gx, n, gy.shape[1],
+                             gy.shape[2], cout, cs[i], k - 1 - pad, 0)
+                else:
+                    _conv_fwd_any(gpre, wi, cs[i], 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cs[i], k, 1,
+                                  k - 1 - pad, ACT_NONE)
             gxs.append(gx)
             gwi = torch.empty((cout, cs[i], k, k), dtype=torch.float32, device=x.device)
             wsz = lib.fn('dis_conv2d_wgrad_workspace')(cs[i], cout, k, 1)
             if wsz < 0:
                 raise lib.DisHipError(f'conv2d_multi wgrad: unsupported shape cin={cs[i]} cout={cout} k={k}')
             ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
-            _conv_wgrad_any(x, gpre, gwi, gb if (i == 0 and has_bias) else None, ws, n, h, w, cs[i], cs[i], cout, k, 1, pad)
+            gbi = gb if (i == 0 and has_bias) else None
+            if fuse_act:
+                lib.call('dis_conv2d_wgrad_bf16x3_act', x, gy, y, act, gwi, gbi, ws, n, h, w, cs[i], cs[i], cout, k, 1, pad)
+            else:
+                _conv_wgrad_any(x, gpre, gwi, gbi, ws, n, h, w, cs[i], cs[i], cout, k, 1, pad)
             gw[:, off:off + cs[i]].copy_(gwi)  # small strided memory move into the (flat) weight-gradient slice
             off += cs[i]
         return (gw_ret, gb_ret, None, None, None, None) + tuple(gxs)

@@ -210,6 +210,12 @@ int dis_conv2d_fwd_bf16x3(const float* x, const void* w_packed, const float* bia
 int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, int mode, int w_o, int w_i, int w_row_stride,
                                const float* bias, float* y, double* stats, int n, int hin, int win, int cin, int cout,
                                int k, int stride, int pad, int act, void* stream);
+/* Input gradient of such a convolution when it was followed by an activation, with the activation's gradient fused in:
+ * gx (+)= conv_T(gy * act'(y), w), y (same shape as gy) = the activation's output, w_oihw (w_o, w_i, 3, 3) the forward
+ * weight (gy has cin == w_o channels, gx cout >= w_i).  Replaces dis_act_bwd + the mode-1 call above. */
+int dis_conv2d_dgrad_bf16x3_act(const float* gy, const float* y, int act, const float* w_oihw, int w_o, int w_i,
+                                int w_row_stride, float* gx, int n, int hin, int win, int cin, int cout, int pad,
+                                int accumulate, void* stream);
 
 /* dis_conv2d_fwd with per-pixel multipliers fused into the kernel (both optional, may be NULL):
  *   xscale (n,hin,win,NCHUNK): x[pixel][chunk c] is multiplied by xscale[pixel][c] while it is staged (NCHUNK = cin/32
@@ -233,11 +239,16 @@ long dis_conv2d_wgrad_workspace(int cin_pad, int cout, int k, int stride);
 int dis_conv2d_wgrad_scaled(const float* x, const float* xscale, const float* gy, float* grad_w, float* grad_b,
                             float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k,
                             int stride, int pad, void* stream);
-/* bf16x3 form (fp32 accuracy on the bf16 matrix cores, transposing LDS reads) for cin = cout = 32, k = 3, stride 1;
- * same arguments, workspace and determinism as dis_conv2d_wgrad. */
+/* bf16x3 form (fp32 accuracy on the bf16 matrix cores, transposing LDS reads) for k = 3, stride 1 and 16 / 32 channels on
+ * either side; same arguments, workspace and determinism as dis_conv2d_wgrad. */
 int dis_conv2d_wgrad_bf16x3(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
                             int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,
                             void* stream);
+/* The same for a convolution that was followed by an activation (act = DIS_ACT_SELU / RELU): gy is the gradient wrt the
+ * activation's OUTPUT y and the kernel stages gy * act'(y).  Replaces dis_act_bwd + dis_conv2d_wgrad_bf16x3. */
+int dis_conv2d_wgrad_bf16x3_act(const float* x, const float* gy, const float* y, int act, float* grad_w, float* grad_b,
+                                float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k,
+                                int stride, int pad, void* stream);
 int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
                      int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,
                      void* stream);

@@ -412,3 +412,34 @@ def test_conv_bf16x3_zero_padded_input_channels():
     lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, 0, 16, 5, 0, b, y, None, n, h, w, 16, 16, 3, 1, 1, 0)
     ref = F.conv2d(x[..., :5].permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), b.double().cpu(), padding=1)
     assert relerr(y.permute(0, 3, 1, 2), ref) < 3e-6
+
+
+@pytest.mark.parametrize('cin,cout', [(32, 32), (16, 16), (16, 32), (32, 16)])
+@pytest.mark.parametrize('act', [1, 2])
+def test_conv_bf16x3_fused_activation_gradient(cin, cout, act):
+    """Backward of conv -> activation with the activation gradient applied while gy is staged (dis_conv2d_dgrad_bf16x3_act,
+    dis_conv2d_wgrad_bf16x3_act) is bit-identical to dis_act_bwd followed by the plain kernels."""
+    from depthinspace_amd import lib
+    g = torch.Generator().manual_seed(cin * 100 + cout + act)
+    n, h, w = 2, 29, 37
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.06).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    y = torch.empty(n, h, w, cout, device='cuda')
+    lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, 0, cout, cin, 0, b, y, None, n, h, w, cin, cout, 3, 1, 1, act)
+    gy = torch.randn(n, h, w, cout, generator=g).cuda()
+    gpre = torch.empty_like(gy)
+    lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
+    ws = torch.empty(lib.fn('dis_conv2d_wgrad_workspace')(cin, cout, 3, 1), device='cuda')
+    for accumulate in (0, 1):
+        base = torch.randn(n, h, w, cin, generator=g).cuda()
+        gx0, gx1 = base.clone(), base.clone()
+        lib.call('dis_conv2d_fwd_bf16x3_oihw', gpre, wt, 1, cout, cin, 0, None, gx0, None, n, h, w, cout, cin, 3, 1, 1,
+                 0x100 if accumulate else 0)
+        lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, wt, cout, cin, 0, gx1, n, h, w, cout, cin, 1, accumulate)
+        assert torch.equal(gx0, gx1)
+    gw0, gw1 = torch.empty_like(wt), torch.empty_like(wt)
+    gb0, gb1 = torch.empty(cout, device='cuda'), torch.empty(cout, device='cuda')
+    lib.call('dis_conv2d_wgrad_bf16x3', x, gpre, gw0, gb0, ws, n, h, w, cin, cin, cout, 3, 1, 1)
+    lib.call('dis_conv2d_wgrad_bf16x3_act', x, gy, y, act, gw1, gb1, ws, n, h, w, cin, cin, cout, 3, 1, 1)
+    assert torch.equal(gw0, gw1) and torch.equal(gb0, gb1)
