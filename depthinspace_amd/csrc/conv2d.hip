@@ -1348,27 +1348,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
     }
   }
 }
-// 1024 threads: thread t sums workers {t/cout, t/cout + 1024/cout, ...} of channel t%cout (coalesced rows of bpart),
-// then the 1024/cout partial sums of a channel are added in a fixed order (deterministic).
-__global__ __launch_bounds__(1024) void bias_reduce_kernel(const float* __restrict__ bpart, float* __restrict__ gb,
-                                                           int workers, int cout) {
-  __shared__ float red[1024];
-  const int lanes = 1024 / cout;  // cout divides 1024 (16, 32, 64, ...)
-  const int co = threadIdx.x % cout, sub = threadIdx.x / cout;
-  float s = 0.f;
-  if (sub < lanes)
-    for (int k = sub; k < workers; k += lanes) s += bpart[(long)k * cout + co];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x < cout) {
-    float t = 0.f;
-    for (int k = 0; k < lanes; ++k) t += red[k * cout + threadIdx.x];
-    gb[threadIdx.x] = t;
-  }
-}
-__global__ void cast_d2f_kernel(const double* __restrict__ a, float* __restrict__ o, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = (float)a[i];
-}
 
 #define WG_WORKERS 512
 

@@ -297,18 +297,6 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
     op[i] = o;
   }
 }
-// dgamma / dbeta: one wave per (channel, kind); sums the `slots` block partials in a fixed order
-__global__ void gn_param_reduce_kernel(const double* __restrict__ part, float* __restrict__ gg, float* __restrict__ gb,
-                                       int c, int slots) {
-  const int j = blockIdx.x;  // 0..2c-1
-  double s = 0.0;
-  for (int k = threadIdx.x; k < slots; k += 64) s += part[(long)k * 2 * c + j];
-  s = wave_sum_d(s);
-  if (threadIdx.x == 0) {
-    if (j < c) gg[j] = (float)s;
-    else gb[j - c] = (float)s;
-  }
-}
 
 extern "C" long dis_gn_bwd_workspace(int n, int c) { return (n > 0 && c > 0) ? (long)n * GN_BWD_BLOCKS * (2 + 2 * c) : -1; }
 
