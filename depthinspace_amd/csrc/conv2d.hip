@@ -1291,54 +1291,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   }
 }
 
-// level 1: every thread sums a contiguous range of slabs for one element -> tmp[split16][elements]
+// Slab reduce: sums the per-workgroup partial slabs and scatters into OIHW in one launch.  A block = 64 output elements
+// x 4 waves; wave w adds slabs [w nslabs/4, (w+1) nslabs/4) of its lane's element (coalesced 256-B rows), the four
+// partial sums are added in a fixed order (deterministic).  WG_RSPLIT only sizes the (now unused) level-1 scratch that
+// sits between the slabs and the bias partials in the workspace layout.
 #define WG_RSPLIT 16
-__global__ void wgrad_reduce1_kernel(const float* __restrict__ part, float* __restrict__ tmp, int nslabs,
-                                     long elems) {
-  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (e >= elems) return;
-  const int sp = blockIdx.y;
-  const int lo = (int)((long)nslabs * sp / WG_RSPLIT), hi = (int)((long)nslabs * (sp + 1) / WG_RSPLIT);
-  float s = 0.f;
-  for (int k = lo; k < hi; ++k) s += part[(long)k * elems + e];
-  tmp[(long)sp * elems + e] = s;
-}
-// level 2: sum the 16 partial sums and scatter into OIHW
-// grid: the element loop is grid-stride; the bias part needs cout/8 <= 16 blocks
-static inline int wgrad_reduce2_grid(long total, bool bias) {
-  const int g = dis_ew_grid(total, 256);
-  return (bias && g < 16) ? 16 : g;
-}
-__global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ tmp, float* __restrict__ gw,
-                                                             int cinb, int nchunk, int nsplit, int khb, int kw, int kh,
-                                                             int cout, int cin_real, int partsz,
-                                                             const float* __restrict__ bpart, float* __restrict__ gb,
-                                                             int workers) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
+                                                            int cinb, int nchunk, int nsplit, int khb, int kw, int kh,
+                                                            int cout, int cin_real, int partsz,
+                                                            const float* __restrict__ bpart, float* __restrict__ gb,
+                                                            int workers) {
+  __shared__ float red[256];
   const int mrows = khb * kw * cinb;
   const long total = (long)nchunk * nsplit * mrows * cout;
   const long elems = (long)nchunk * nsplit * partsz;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int co = (int)(i % cout);
-    long r = i / cout;
-    const int m = (int)(r % mrows);
-    r /= mrows;
-    const int split = (int)(r % nsplit);
-    const int chunk = (int)(r / nsplit);
-    const float* p = tmp + ((long)chunk * nsplit + split) * partsz + (long)m * cout + co;
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+    const long i = base + ln;
     float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < WG_RSPLIT; ++k) s += p[k * elems];
-    const int tap = m / cinb, ci = chunk * cinb + m % cinb;
-    const int ky = (nsplit > 1 ? split : 0) + tap / kw, kx = tap % kw;
-    if (ci < cin_real) gw[(((long)co * cin_real + ci) * kh + ky) * kw + kx] = s;
+    int co = 0, m = 0, split = 0, chunk = 0;
+    if (i < total) {
+      co = (int)(i % cout);
+      long r = i / cout;
+      m = (int)(r % mrows);
+      r /= mrows;
+      split = (int)(r % nsplit);
+      chunk = (int)(r / nsplit);
+      const float* p = part + ((long)chunk * nsplit + split) * partsz + (long)m * cout + co;
+      const int lo = (int)((long)workers * wv / 4), hi = (int)((long)workers * (wv + 1) / 4);
+      int k = lo;
+      for (; k + 3 < hi; k += 4)  // 4 independent loads in flight
+        s += (p[(long)k * elems] + p[(long)(k + 1) * elems]) + (p[(long)(k + 2) * elems] + p[(long)(k + 3) * elems]);
+      for (; k < hi; ++k) s += p[(long)k * elems];
+    }
+    __syncthreads();
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (wv == 0 && i < total) {
+      const float t = (red[ln] + red[64 + ln]) + (red[128 + ln] + red[192 + ln]);
+      const int tap = m / cinb, ci = chunk * cinb + m % cinb;
+      const int ky = (nsplit > 1 ? split : 0) + tap / kw, kx = tap % kw;
+      if (ci < cin_real) gw[(((long)co * cin_real + ci) * kh + ky) * kw + kx] = t;
+    }
   }
-  // bias gradient (folded in here to save a launch): block b < cout/8 adds the per-workgroup bias partials of channels
-  // 8b..8b+7; thread t sums workers {t/8, t/8 + 32, ...} of channel 8b + t%8, then a fixed-order sum over the 32 sub-sums
+  // bias gradient: block b < cout/8 adds the per-workgroup bias partials of channels 8b..8b+7; thread t sums workers
+  // {t/8, t/8 + 32, ...} of channel 8b + t%8, then a fixed-order sum over the 32 sub-sums
   if (bpart && (int)blockIdx.x * 8 < cout) {
-    __shared__ float red[256];
     const int co = blockIdx.x * 8 + (threadIdx.x & 7), sub = threadIdx.x >> 3;
     float s = 0.f;
     for (int k = sub; k < workers; k += 32) s += bpart[(long)k * cout + co];
+    __syncthreads();
     red[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < 8) {
@@ -1348,7 +1350,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
     }
   }
 }
-
+static inline int wgrad_reduce_grid(long total, bool bias) {
+  long g = (total + 63) / 64;
+  if (g > 1024) g = 1024;
+  return (bias && g < 16) ? 16 : (int)g;  // the bias part needs cout/8 <= 16 blocks
+}
 #define WG_WORKERS 512
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -1379,11 +1385,9 @@ static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_
   float* tmp = a.part + (long)WG_WORKERS * elems;
   a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
   hipLaunchKernelGGL(kern, dim3((unsigned)workers, C::NCHUNK, C::NSPLIT), dim3(256), C::LDS_BYTES, s, a);
-  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(dis_cdiv(elems, 256), WG_RSPLIT), dim3(256), 0, s,
-                     (const float*)a.part, tmp, (int)workers, elems);
   const long total = (long)C::NCHUNK * C::NSPLIT * C::MROWS * COUT;
-  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(wgrad_reduce2_grid(total, gb != nullptr)), dim3(256), 0, s, (const float*)tmp, gw,
-                     C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, KW, KH, COUT, cin_real, C::PART,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(256), 0, s,
+                     (const float*)a.part, gw, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, KW, KH, COUT, cin_real, C::PART,
                      (const float*)(gb ? a.bpart : nullptr), gb, (int)workers);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
@@ -1642,11 +1646,9 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
   float* tmp = a.part + (long)WG_WORKERS * elems;
   a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
   hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<CIN, COUT, INACT>), dim3((unsigned)workers), dim3(256), X::LDS_BYTES, s, a);
-  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(dis_cdiv(elems, 256), WG_RSPLIT), dim3(256), 0, s,
-                     (const float*)a.part, tmp, (int)workers, elems);
   const long total = (long)C::MROWS * COUT;
-  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(wgrad_reduce2_grid(total, gb != nullptr)), dim3(256), 0, s, (const float*)tmp, gw,
-                     C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, COUT, cin_real, C::PART,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(256), 0, s,
+                     (const float*)a.part, gw, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, COUT, cin_real, C::PART,
                      (const float*)(gb ? a.bpart : nullptr), gb, (int)workers);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
