@@ -233,7 +233,9 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
                                     float eps, int nred, int in_act, const double* __restrict__ gparam,
                                     float* __restrict__ gg, float* __restrict__ gb, int slots) {
   __shared__ float gam[GN_MAXC];
-  const int n = blockIdx.y;
+  // Samples and elements are walked in the REVERSE of pass 1's order: what pass 1 read last is what the Infinity Cache
+  // still holds, so this pass starts on cached data instead of evicting it first.
+  const int n = gridDim.y - 1 - blockIdx.y;
   // dgamma / dbeta (folded in here to save a launch): wave w of the first 2c/4 blocks of sample 0 sums the `slots`
   // per-block partials of one parameter in a fixed order
   if (blockIdx.y == 0 && (int)blockIdx.x * 4 < 2 * c) {
@@ -275,7 +277,8 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
   const float4* xp = (const float4*)(x + (long)n * hw * c);
   float4* op = (float4*)(gx + (long)n * hw * c);
   float4* rp = gres ? (float4*)(gres + (long)n * hw * c) : nullptr;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per4; i += (long)gridDim.x * blockDim.x) {
+  for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < per4; j += (long)gridDim.x * blockDim.x) {
+    const long i = per4 - 1 - j;
     const int g = (int)(i % cg) * 4;
     float4 gv = gp[i];
     if (act != DIS_ACT_NONE) {
