@@ -1896,14 +1896,15 @@ extern "C" int dis_disp_head_fwd(const float* x, const float* w, const float* b,
                                  int cin, float alpha, float offset, void* stream) {
   if (!x || !w || !b || !y) return DIS_ERR_NULL;
   if (n <= 0 || h <= 0 || wd <= 0) return DIS_ERR_BAD_SHAPE;
-  if (cin != 16) return DIS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(head_fwd_kernel<16>, dim3(dis_ew_grid((long)n * h * wd, 256)), dim3(256), 0, (hipStream_t)stream,
-                     x, w, b, y, n, h, wd, alpha, offset);
+  const dim3 grid(dis_ew_grid((long)n * h * wd, 256));
+  if (cin == 16) hipLaunchKernelGGL(head_fwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, n, h, wd, alpha, offset);
+  else if (cin == 32) hipLaunchKernelGGL(head_fwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, n, h, wd, alpha, offset);
+  else return DIS_ERR_UNSUPPORTED;
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
 extern "C" long dis_disp_head_bwd_workspace(int n, int h, int wd, int cin) {
-  if (n <= 0 || h <= 0 || wd <= 0 || cin != 16) return DIS_ERR_UNSUPPORTED;
+  if (n <= 0 || h <= 0 || wd <= 0 || (cin != 16 && cin != 32)) return DIS_ERR_UNSUPPORTED;
   return (((long)n * h * wd + 1) & ~1L) + 2L * HEAD_SLABS * (9 * cin + 1);  // floats: pre-sigmoid gradient + fp64 slabs
 }
 extern "C" int dis_disp_head_bwd(const float* x, const float* w, const float* y, const float* gy, float* gx,
@@ -1911,14 +1912,15 @@ extern "C" int dis_disp_head_bwd(const float* x, const float* w, const float* y,
                                  float alpha, void* stream) {
   if (!x || !w || !y || !gy || !gx || !grad_w || !grad_b || !workspace) return DIS_ERR_NULL;
   if (n <= 0 || h <= 0 || wd <= 0) return DIS_ERR_BAD_SHAPE;
-  if (cin != 16) return DIS_ERR_UNSUPPORTED;
+  if (cin != 16 && cin != 32) return DIS_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)n * h * wd;
   hipLaunchKernelGGL(head_gpre_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, y, gy, workspace, alpha, total);
   int grid = dis_ew_grid(total * (cin / 4), 256);
   if (grid > HEAD_SLABS) grid = HEAD_SLABS;
   double* slab = (double*)(workspace + ((total + 1) & ~1L));  // 8-byte aligned behind the gradient plane
-  hipLaunchKernelGGL(head_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, w, (const float*)workspace, gx, slab, n, h, wd);
+  if (cin == 16) hipLaunchKernelGGL(head_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, w, (const float*)workspace, gx, slab, n, h, wd);
+  else hipLaunchKernelGGL(head_bwd_kernel<32>, dim3(grid), dim3(256), 0, s, x, w, (const float*)workspace, gx, slab, n, h, wd);
   hipLaunchKernelGGL(head_reduce_kernel, dim3(9 * cin + 1), dim3(64), 0, s, (const double*)slab, grad_w, grad_b, grid,
                      9 * cin + 1);
   DIS_CHECK_LAUNCH();

@@ -885,9 +885,13 @@ class _HeadG(torch.autograd.Function):
         n, h, w, cin = x.shape
         k = weight.shape[2]
         y = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
-        _convg_run(CONVG_CONV, x, weight, bias, y.view(n, h, w, 1), n, h, w, cin, weight.shape[1], h, w, 1, 1, k, 1,
-                   k // 2, ACT_NONE)
-        lib.call('dis_sigmoid_affine_fwd', y, y, float(alpha), float(offset), y.numel())
+        ctx.direct = k == 3 and cin in (16, 32) and weight.shape[1] == cin  # the one-pass head kernels (16 / 32 channels)
+        if ctx.direct:
+            lib.call('dis_disp_head_fwd', x, weight, bias, y, n, h, w, cin, float(alpha), float(offset))
+        else:
+            _convg_run(CONVG_CONV, x, weight, bias, y.view(n, h, w, 1), n, h, w, cin, weight.shape[1], h, w, 1, 1, k, 1,
+                       k // 2, ACT_NONE)
+            lib.call('dis_sigmoid_affine_fwd', y, y, float(alpha), float(offset), y.numel())
         ctx.save_for_backward(x, weight, y)
         ctx.alpha = float(alpha)
         return y
@@ -898,6 +902,13 @@ class _HeadG(torch.autograd.Function):
         n, h, w, cin = x.shape
         k = weight.shape[2]
         cin_w = weight.shape[1]
+        if ctx.direct:
+            gx = torch.empty_like(x)
+            gw = torch.empty_like(weight)
+            gb = torch.empty(1, dtype=torch.float32, device=x.device)
+            ws = torch.empty(lib.fn('dis_disp_head_bwd_workspace')(n, h, w, cin), dtype=torch.float32, device=x.device)
+            lib.call('dis_disp_head_bwd', x, weight, y, _c(gy), gx, gw, gb, ws, n, h, w, cin, ctx.alpha)
+            return gx, gw, gb, None, None
         gpre4 = torch.empty((n, h, w, 4), dtype=torch.float32, device=x.device)
         lib.call('dis_sigmoid_affine_bwd', y, _c(gy), gpre4, ctx.alpha, n * h * w)
         gx = torch.empty_like(x)

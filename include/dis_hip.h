@@ -259,7 +259,7 @@ int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, float* gx, fl
                              int win, int cin, int cout, int k, int stride, int pad, int accumulate, void* stream);
 
 /* Head: Conv2d(cin,1,3,pad 1) + alpha*sigmoid(x - offset) (reference networks.py:121-125,140-149;
- * multi_frame_networks.py:157,265).  x nhwc (n,h,w,cin); w (1,cin,3,3); y planar (n,1,h,w). */
+ * multi_frame_networks.py:157,265), cin = 16 or 32.  x nhwc (n,h,w,cin); w (1,cin,3,3); y planar (n,1,h,w). */
 int dis_disp_head_fwd(const float* x, const float* w, const float* b, float* y, int n, int h, int wd, int cin,
                       float alpha, float offset, void* stream);
 /* gy (n,1,h,w) gradient wrt y; y is the forward output.  gx (n,h,w,cin) overwritten; grad_w/grad_b overwritten.
