@@ -860,6 +860,14 @@ class _ConvG(torch.autograd.Function):
         if transposed:
             _convg_wgrad(gpre, hout, wout, cout, cout, x, hin, win, cin_mem, cin_w, gw, n, k, stride, pad)
         else:
+            # shapes whose whole (tap, cin) x cout accumulator fits a workgroup's registers go through the one-pass kernels
+            # of conv2d.hip (x and gy are read once instead of once per tap; the bias gradient comes out of the same pass)
+            wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin_mem, cout, k, stride)
+            if wsz >= 0 and gpre.shape[-1] == cout:
+                ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
+                gb = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+                _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_mem, cin_w, cout, k, stride, pad)
+                return gx, gw_ret, gb, None, None, None, None, None, None
             _convg_wgrad(x, hin, win, cin_mem, cin_w, gpre, hout, wout, cout, cout, gw, n, k, stride, pad)
         gb = _colsum(gpre, cout) if has_bias else None
         return gx, gw_ret, gb, None, None, None, None, None, None
