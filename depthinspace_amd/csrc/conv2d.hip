@@ -1673,6 +1673,8 @@ static int dispatch_wgrad(const WgArgs& a, float* gw, float* gb, int cin_real, i
   WG_CASE(32, 32, 4, 2)
   WG_CASE(4, 32, 7, 2)   // DispNetS conv1 (2 -> 32, k7 s2): all 49 taps in one pass over the pixels
   WG_CASE(32, 32, 7, 1)  // DispNetS conv1b
+  WG_CASE(20, 16, 3, 1)  // DispNetS iconv1 (17 -> 16 at full resolution)
+  WG_CASE(68, 32, 3, 1)  // DispNetS iconv2 (65 -> 32)
   return DIS_ERR_UNSUPPORTED;
 }
 
@@ -1689,6 +1691,8 @@ extern "C" long dis_conv2d_wgrad_workspace(int cin, int cout, int k, int stride)
   WS_CASE(32, 32, 4, 2)
   WS_CASE(4, 32, 7, 2)
   WS_CASE(32, 32, 7, 1)
+  WS_CASE(20, 16, 3, 1)
+  WS_CASE(68, 32, 3, 1)
   return -1;
 }
 
