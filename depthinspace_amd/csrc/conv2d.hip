@@ -510,38 +510,6 @@ extern "C" int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, fl
 //   workgroup = 8 waves = 16x16 output pixels, wave = 2 rows x all 32 couts; weights (3 planes) resident in LDS,
 //   the halo tile is split into its 3 bf16 planes when it is written to LDS.
 // ------------------------------------------------------------------------------------------------
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ unsigned f2bf_bits(float x) {
-  unsigned u = __float_as_uint(x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ float bf_bits2f(unsigned h) { return __uint_as_float(h << 16); }
-// x -> 3 bf16 planes (bits)
-__device__ __forceinline__ void split3(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
-  h1 = f2bf_bits(x);
-  const float r1 = x - bf_bits2f(h1);
-  h2 = f2bf_bits(r1);
-  const float r2 = r1 - bf_bits2f(h2);
-  h3 = f2bf_bits(r2);
-}
-
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// two fp32 values -> three packed bf16 pairs (v_cvt_pk_bf16_f32: round to nearest even)
-__device__ __forceinline__ void split3_pair(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
-  const f32x2 v = {x, y};
-  const bf16x2 h1 = __builtin_convertvector(v, bf16x2);
-  const f32x2 r1 = v - __builtin_convertvector(h1, f32x2);
-  const bf16x2 h2 = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(h2, f32x2);
-  const bf16x2 h3 = __builtin_convertvector(r2, bf16x2);
-  p1 = __builtin_bit_cast(unsigned, h1);
-  p2 = __builtin_bit_cast(unsigned, h2);
-  p3 = __builtin_bit_cast(unsigned, h3);
-}
-
 #define BX_PS 104  // LDS pixel stride in 16-bit units: 3 planes x 32 channels + 8 pad (208 B: conflict-free b128 rows)
 #define BX_TR 16
 #define BX_TC 16

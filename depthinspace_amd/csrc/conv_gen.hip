@@ -20,6 +20,7 @@
 //     tile (one tap) x TX x-channels x TG g-channels per workgroup, k = 32 pixels per step, split-K over
 //     pixel ranges into partial slabs that a second kernel sums in a fixed order (deterministic).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -193,6 +194,211 @@ __global__ void convg_pack_kernel(PackArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16x3 form of the forward-like kernel (fp32 results on the bf16 matrix cores: 3-way operand split, 6 products per
+// MAC, see conv2d.hip) for layers with >= 32 input channels.  Same tile, addressing, modes and epilogue as
+// convg_fwd_kernel; a k-step is 32 channels of one tap:
+//   A tile  128 pixels x 32 channels, split when it is written to LDS as [pixel][plane][channel] (208-B pixel stride),
+//   B tile  32 channels x BN couts, PRE-split by convg3_pack_kernel into [plane][k-group][cout][8] 16-bit words,
+//   6 x 2 x BN/16 MFMAs (v_mfma_f32_16x16x32_bf16) per wave and k-step.
+// The tiles take 74 KB of LDS (2 workgroups per CU instead of 5), so the global-memory latency is covered inside the
+// workgroup: the operands of k-step s+3 are requested into a ring of three register sets while k-step s runs, and
+// k-step s+1 is split and written to the other LDS buffer behind the MFMAs of k-step s.
+// ------------------------------------------------------------------------------------------------
+#define CG3_CK 32
+#define CG3_PS 104  // LDS pixel stride in 16-bit units (3 planes x 32 channels + 8 pad)
+struct Pack3Args {
+  const float* w;
+  unsigned short* packed;  // [tap][chunk][nblk][plane][lg][bn][8]
+  int ntaps, nchunk, nblk, bn, ci_real, co_real;
+  long s_ci, s_co;
+  short tsrc[CG_MAXTAPS];
+};
+__global__ void convg3_pack_kernel(Pack3Args a) {
+  const long total = (long)a.ntaps * a.nchunk * a.nblk * 4 * a.bn * 8;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7);
+    long r = i >> 3;
+    const int col = (int)(r % a.bn);
+    r /= a.bn;
+    const int lg = (int)(r & 3);
+    r >>= 2;
+    const int nb = (int)(r % a.nblk);
+    r /= a.nblk;
+    const int chunk = (int)(r % a.nchunk);
+    const int tap = (int)(r / a.nchunk);
+    const int ci = chunk * CG3_CK + lg * 8 + j, co = nb * a.bn + col;
+    float v = 0.f;
+    if (ci < a.ci_real && co < a.co_real) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
+    unsigned h1, h2, h3;
+    split3(v, h1, h2, h3);
+    const long plane = 4L * a.bn * 8;
+    const long base = (((long)(tap * a.nchunk + chunk) * a.nblk + nb) * 3) * plane + ((long)lg * a.bn + col) * 8 + j;
+    a.packed[base] = (unsigned short)h1;
+    a.packed[base + plane] = (unsigned short)h2;
+    a.packed[base + 2 * plane] = (unsigned short)h3;
+  }
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void convg3_fwd_kernel(GenArgs a) {
+  constexpr int NT = BN / 16;
+  constexpr int A_U16 = CG_BM * CG3_PS, B_U16 = 3 * 4 * BN * 8;  // per buffer
+  constexpr int NBQ = (3 * 4 * BN + 255) / 256;                   // uint4s of the B tile per thread
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (A_U16 + B_U16)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int M = a.n * a.hv * a.wv;
+  const int nb = blockIdx.x % a.nblk, m0 = (blockIdx.x / a.nblk) * CG_BM;
+
+  // loader role: thread owns channel group pq (4 channels) of pixels p0 + 32 j of the tile
+  const int pq = tid & 7, p0 = tid >> 3;
+  long pbase[4];
+  int piy[4], pix[4];
+  bool pval[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + p0 + j * 32;
+    pval[j] = m < M;
+    const int mm = pval[j] ? m : 0;
+    const int vx = mm % a.wv, t = mm / a.wv, vy = t % a.hv, nn = t / a.hv;
+    pbase[j] = (long)nn * a.hin * a.win;
+    piy[j] = vy * a.S;
+    pix[j] = vx * a.S;
+  }
+  // ring of three register sets; unconditional (clamped) loads, zeroed when written to LDS
+  float4 ra[3][4];
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 rb[3][NBQ];
+  unsigned rokm[3] = {0, 0, 0};
+  const u32x4* wq = (const u32x4*)a.w;
+  const int nk = a.ntaps * a.nchunk;
+  int ptap = 0, pchunk = 0, pnext = 0;  // cursor of the next k-step to request
+  auto prefetch = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    if (pnext >= nk) return;
+    const int dy = a.tdy[ptap], dx = a.tdx[ptap];
+    const int c = pchunk * CG3_CK + pq * 4;
+    const int cc = min(c, a.cin - 4);
+    unsigned okm = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iy = piy[j] + dy, ix = pix[j] + dx;
+      const bool ok = pval[j] && c < a.cin && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+      okm |= (ok ? 1u : 0u) << j;
+      const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
+      ra[set][j] = *(const float4*)(a.x + (pbase[j] + (long)cy * a.win + cx) * a.ldx + a.xoff + cc);
+    }
+    rokm[set] = okm;
+    const long wb = ((long)(ptap * a.nchunk + pchunk) * a.nblk + nb) * (3 * 4 * BN);
+#pragma unroll
+    for (int q = 0; q < NBQ; ++q) rb[set][q] = wq[wb + min(tid + q * 256, 3 * 4 * BN - 1)];
+    ++pnext;
+    if (++pchunk == a.nchunk) {
+      pchunk = 0;
+      ++ptap;
+    }
+  };
+  auto stage = [&](auto setc, int buf) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    unsigned short* A = smem + buf * (A_U16 + B_U16);
+    unsigned short* B = A + A_U16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = ((rokm[set] >> j) & 1u) ? ra[set][j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      unsigned a1, a2, a3, b1, b2, b3;
+      split3_pair(v.x, v.y, a1, a2, a3);
+      split3_pair(v.z, v.w, b1, b2, b3);
+      unsigned short* p = A + (p0 + j * 32) * CG3_PS + pq * 4;
+      *(uint2*)(p) = make_uint2(a1, b1);
+      *(uint2*)(p + 32) = make_uint2(a2, b2);
+      *(uint2*)(p + 64) = make_uint2(a3, b3);
+    }
+#pragma unroll
+    for (int q = 0; q < NBQ; ++q)
+      if (tid + q * 256 < 3 * 4 * BN) ((u32x4*)B)[tid + q * 256] = rb[set][q];
+  };
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  prefetch(S0{});
+  prefetch(S1{});
+  prefetch(S2{});
+  stage(S0{}, 0);
+  __syncthreads();
+  // one k-step: request k-step s+3 into the set that held k-step s, run the MFMAs of k-step s, stage k-step s+1
+  auto body = [&](int s, auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    prefetch(setc);
+    const unsigned short* A = smem + (s & 1) * (A_U16 + B_U16);
+    const unsigned short* B = A + A_U16;
+    s16x8 fa[3][2], fb[3][NT];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        fa[p][mt] = *(const s16x8*)(A + (wave * 32 + mt * 16 + li) * CG3_PS + p * 32 + lg * 8);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[p][nt] = *(const s16x8*)(B + ((p * 4 + lg) * BN + nt * 16 + li) * 8);
+    }
+    // smallest terms first
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[PA[q]][mt]),
+                                                               __builtin_bit_cast(bf16x8, fb[PB[q]][nt]), acc[mt][nt], 0,
+                                                               0, 0);
+    if (s + 1 < nk) stage(std::integral_constant<int, (set + 1) % 3>{}, (s + 1) & 1);
+    __syncthreads();
+  };
+  for (int ks = 0; ks < nk; ks += 3) {
+    body(ks, S0{});
+    if (ks + 1 < nk) body(ks + 1, S1{});
+    if (ks + 2 < nk) body(ks + 2, S2{});
+  }
+
+  // epilogue (as convg_fwd_kernel): bias + activation, masked store of the real output channels
+  float bias_v[NT];
+  bool cok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = nb * BN + nt * 16 + li;
+    cok[nt] = co < a.cout;
+    bias_v[nt] = (a.bias && cok[nt]) ? a.bias[co] : 0.f;
+  }
+  auto emit = [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wave * 32 + mt * 16 + lg * 4 + r;
+        if (m >= M) continue;
+        const int vx = m % a.wv, t = m / a.wv, vy = t % a.hv, nn = t / a.hv;
+        float* yp = a.y + (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff +
+                    nb * BN + li;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if (cok[nt]) yp[nt * 16] = act_apply(acc[mt][nt][r] + bias_v[nt], ACT);
+      }
+    }
+  };
+  if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{});
+  else if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{});
+  else emit(std::integral_constant<int, DIS_ACT_NONE>{});
+}
+
 static int cg_bn(int cout) { return cout > 32 ? 64 : (cout > 16 ? 32 : 16); }
 
 // one launch of the forward-like kernel (packs its weights first)
@@ -202,6 +408,25 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
   if ((long)a.n * a.hv * a.wv <= 0) return DIS_OK;
   const int bn = cg_bn(a.cout);
   a.nblk = (a.cout + bn - 1) / bn;
+  static const bool use3 = !(getenv("DIS_CONV_BF16X3") && getenv("DIS_CONV_BF16X3")[0] == '0');
+  if (use3 && a.cin >= CG3_CK) {  // bf16x3 form: 32-channel k-steps, weights pre-split
+    a.nchunk = (a.cin + CG3_CK - 1) / CG3_CK;
+    Pack3Args p3;
+    p3.w = w_raw; p3.packed = (unsigned short*)wpack; p3.ntaps = a.ntaps; p3.nchunk = a.nchunk; p3.nblk = a.nblk;
+    p3.bn = bn; p3.ci_real = ci_real; p3.co_real = co_real; p3.s_ci = s_ci; p3.s_co = s_co;
+    for (int t = 0; t < a.ntaps; ++t) p3.tsrc[t] = tsrc[t];
+    const long ptotal3 = (long)a.ntaps * a.nchunk * a.nblk * 4 * bn * 8;
+    hipLaunchKernelGGL(convg3_pack_kernel, dim3(dis_ew_grid(ptotal3, 256)), dim3(256), 0, s, p3);
+    a.w = wpack;
+    const long M3 = (long)a.n * a.hv * a.wv;
+    const long grid3 = ((M3 + CG_BM - 1) / CG_BM) * a.nblk;
+    if (grid3 > 2147483647L) return DIS_ERR_BAD_SHAPE;
+    if (bn == 64) hipLaunchKernelGGL(convg3_fwd_kernel<64>, dim3((unsigned)grid3), dim3(256), 0, s, a);
+    else if (bn == 32) hipLaunchKernelGGL(convg3_fwd_kernel<32>, dim3((unsigned)grid3), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(convg3_fwd_kernel<16>, dim3((unsigned)grid3), dim3(256), 0, s, a);
+    DIS_CHECK_LAUNCH();
+    return DIS_OK;
+  }
   a.nchunk = (a.cin + CG_CK - 1) / CG_CK;
   PackArgs p;
   p.w = w_raw; p.packed = wpack; p.ntaps = a.ntaps; p.nchunk = a.nchunk; p.nblk = a.nblk; p.bn = bn;
@@ -223,8 +448,10 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
 extern "C" long dis_convg_pack_workspace(int cin, int cout, int k) {
   if (cin <= 0 || cout <= 0 || k <= 0 || k * k > CG_MAXTAPS) return -1;
   const int bn = cg_bn(cout);
-  const long nblk = (cout + bn - 1) / bn, nchunk = (cin + CG_CK - 1) / CG_CK;
-  return (long)k * k * nchunk * nblk * 16 * bn;
+  const long nblk = (cout + bn - 1) / bn, nchunk = (cin + CG_CK - 1) / CG_CK, nchunk3 = (cin + CG3_CK - 1) / CG3_CK;
+  const long f32 = (long)k * k * nchunk * nblk * 16 * bn;        // fp32 fragment image
+  const long b3 = (long)k * k * nchunk3 * nblk * (3 * 4 * 8 / 2) * bn;  // 3 bf16 planes (16-bit words / 2 = floats)
+  return f32 > b3 ? f32 : b3;
 }
 
 static int floordiv2(int v) { return (v >= 0) ? v / 2 : -((-v + 1) / 2); }
