@@ -243,6 +243,8 @@ def main():
             # k, stride, pad, act): every launch of the streaming kernel family convg_fwd_kernel<BN>; algorithmic
             # flops use the real channel counts and the spatial size of the strided side
             sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_convg_run']
+            if ops.BF16X3:  # layers with >= 32 input channels run convg3_fwd_kernel (bf16x3): the dominant kernel
+                sel = [(ia, ms) for ia, ms in sel if ia[8] >= 32]
 
             def gflops(ia):
                 mode, n, hin, win, cw, hout, wout, cow, k = ia[0], ia[5], ia[6], ia[7], ia[9], ia[10], ia[11], ia[13], ia[14]
@@ -250,6 +252,11 @@ def main():
                 return 2.0 * n * hw * cw * cow * k * k
             fl = sum(gflops(ia) for ia, _ in sel)
             kname = 'convg_fwd_kernel<BN> (fp32 MFMA 16x16x4, all conv / dgrad / transposed-conv launches)'
+            if ops.BF16X3:
+                kname = ('convg3_fwd_kernel<BN> (fp32 conv as 6 bf16 products per MAC on v_mfma_f32_16x16x32_bf16; all '
+                         'conv / dgrad / transposed-conv launches with >= 32 input channels; TFLOP/s are fp32-equivalent '
+                         'algorithmic flops)')
+                peak, peak_note = PEAK_BF16_MFMA_TFLOPS / 6.0, 'bf16 MFMA dense peak (2500 TFLOP/s) / 6 products per fp32 MAC'
         tm = sum(ms for _, ms in sel) * 1e-3
         if sel:
             ach = fl / tm / 1e12
@@ -288,11 +295,14 @@ def main():
                                    f'default-pattern synthetic, fwd+losses+bwd+Adam, epoch>={args.epoch}',
                        'global_batch': world * args.bs, 'parallelism': f'dp{world}', 'hip_graph': bool(use_graph),
                        'backend': (args.backend if world > 1 else None),
-                       'conv_arithmetic': ('fp32 results everywhere; the 32->32 3x3 convs (fwd, dgrad, wgrad) run as '
-                                           'bf16x3 (3-way bf16 operand split, 6 products, fp32 accumulate: error vs fp64 '
-                                           '<= the exact-fp32 MFMA kernel, tests/test_net_ops_gpu.py), all other convs on '
-                                           'v_mfma_f32_16x16x4_f32' if (mf and ops.BF16X3) else
-                                           'v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains)')},
+                       'conv_arithmetic': (('fp32 results everywhere; the 3x3 stride-1 convs with 16 / 32 channels (fwd, '
+                                            'dgrad, wgrad) run as bf16x3 (3-way bf16 operand split, 6 products, fp32 '
+                                            'accumulate: error vs fp64 <= the exact-fp32 MFMA kernel, '
+                                            'tests/test_net_ops_gpu.py), all other convs on v_mfma_f32_16x16x4_f32' if mf else
+                                            'fp32 results everywhere; forward / input-gradient convs with >= 32 input '
+                                            'channels run as bf16x3 (3-way bf16 operand split, 6 products, fp32 accumulate), '
+                                            'the others and the streaming weight gradients on v_mfma_f32_16x16x4_f32')
+                                           if ops.BF16X3 else 'v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains)')},
             'roofline': roof, 'cpu_baseline': cpu, 'loss_terms': losses, 'kernel_ms_one_eager_step': kernel_ms,
         }
         print(json.dumps(res))
