@@ -119,3 +119,10 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned& p1, unsi
   p3 = __builtin_bit_cast(unsigned, h3);
 }
 
+// buffer-descriptor addressing: a load at an out-of-range offset returns 0 (zero padding without a branch), a store there
+// is dropped
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define BX_OOB 0x80000000u  // byte offset beyond any buffer this kernel addresses (sizes are checked < 2 GiB on the host)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bx_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}

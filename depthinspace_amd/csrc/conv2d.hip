@@ -589,11 +589,6 @@ extern "C" int dis_debug_bx_stamps(unsigned long long* host) {
 #define BX_T(k)
 #endif
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define BX_OOB 0x80000000u  // byte offset beyond any buffer this kernel addresses (sizes are checked < 2 GiB on the host)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t bx_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
 
 // Per tile the matrix work is 216 MFMAs per wave (32 -> 32); everything else is software-pipelined around it, and
 // everything that rides inside the MFMA loop is straight-line code (no branch: the scheduler can only interleave VALU and

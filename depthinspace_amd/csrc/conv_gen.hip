@@ -42,6 +42,7 @@ struct GenArgs {
   int osy, ooy, osx, oox;           // output pixel = (vy*osy+ooy, vx*osx+oox)
   int act, ntaps, nblk;
   short tdy[CG_MAXTAPS], tdx[CG_MAXTAPS];
+  unsigned x_bytes;  // convg3 only: size of the x tensor in bytes (buffer descriptor range)
 };
 
 template <int BN>
@@ -243,8 +244,8 @@ __global__ void convg3_pack_kernel(Pack3Args a) {
 template <int BN>
 __global__ __launch_bounds__(256, 2) void convg3_fwd_kernel(GenArgs a) {
   constexpr int NT = BN / 16;
-  constexpr int A_U16 = CG_BM * CG3_PS, B_U16 = 3 * 4 * BN * 8;  // per buffer
-  constexpr int NBQ = (3 * 4 * BN + 255) / 256;                   // uint4s of the B tile per thread
+  constexpr int NBQ = (3 * 4 * BN + 255) / 256;                   // 16-byte vectors of the B tile per thread
+  constexpr int A_U16 = CG_BM * CG3_PS, B_U16 = NBQ * 256 * 8;    // per buffer (B padded to whole rounds of the block)
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (A_U16 + B_U16)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int M = a.n * a.hv * a.wv;
@@ -265,11 +266,11 @@ __global__ __launch_bounds__(256, 2) void convg3_fwd_kernel(GenArgs a) {
     piy[j] = vy * a.S;
     pix[j] = vx * a.S;
   }
-  // ring of three register sets; unconditional (clamped) loads, zeroed when written to LDS
+  // ring of three register sets.  x is addressed through a buffer descriptor over the whole tensor: a tap outside the
+  // image (or a channel group beyond cin) gets an out-of-range offset and loads the zero padding - no clamp, no mask,
+  // no branch, so that the staging below is straight-line code the scheduler can spread between the MFMAs
   float4 ra[3][4];
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   u32x4 rb[3][NBQ];
-  unsigned rokm[3] = {0, 0, 0};
   const u32x4* wq = (const u32x4*)a.w;
   const int nk = a.ntaps * a.nchunk;
   int ptap = 0, pchunk = 0, pnext = 0;  // cursor of the next k-step to request
@@ -278,17 +279,13 @@ __global__ __launch_bounds__(256, 2) void convg3_fwd_kernel(GenArgs a) {
     if (pnext >= nk) return;
     const int dy = a.tdy[ptap], dx = a.tdx[ptap];
     const int c = pchunk * CG3_CK + pq * 4;
-    const int cc = min(c, a.cin - 4);
-    unsigned okm = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int iy = piy[j] + dy, ix = pix[j] + dx;
-      const bool ok = pval[j] && c < a.cin && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-      okm |= (ok ? 1u : 0u) << j;
-      const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
-      ra[set][j] = *(const float4*)(a.x + (pbase[j] + (long)cy * a.win + cx) * a.ldx + a.xoff + cc);
+      const bool ok = pval[j] && c < a.cin && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+      const unsigned off = ok ? (unsigned)(((pbase[j] + (long)iy * a.win + ix) * a.ldx + a.xoff + c) * 4) : BX_OOB;
+      ra[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.x, a.x_bytes), off, 0, 0));
     }
-    rokm[set] = okm;
     const long wb = ((long)(ptap * a.nchunk + pchunk) * a.nblk + nb) * (3 * 4 * BN);
 #pragma unroll
     for (int q = 0; q < NBQ; ++q) rb[set][q] = wq[wb + min(tid + q * 256, 3 * 4 * BN - 1)];
@@ -304,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void convg3_fwd_kernel(GenArgs a) {
     unsigned short* B = A + A_U16;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float4 v = ((rokm[set] >> j) & 1u) ? ra[set][j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = ra[set][j];
       unsigned a1, a2, a3, b1, b2, b3;
       split3_pair(v.x, v.y, a1, a2, a3);
       split3_pair(v.z, v.w, b1, b2, b3);
@@ -314,8 +311,7 @@ __global__ __launch_bounds__(256, 2) void convg3_fwd_kernel(GenArgs a) {
       *(uint2*)(p + 64) = make_uint2(a3, b3);
     }
 #pragma unroll
-    for (int q = 0; q < NBQ; ++q)
-      if (tid + q * 256 < 3 * 4 * BN) ((u32x4*)B)[tid + q * 256] = rb[set][q];
+    for (int q = 0; q < NBQ; ++q) ((u32x4*)B)[tid + q * 256] = rb[set][q];  // (B is padded to NBQ * 256 vectors)
   };
 
   f32x4 acc[2][NT];
@@ -359,7 +355,16 @@ __global__ __launch_bounds__(256, 2) void convg3_fwd_kernel(GenArgs a) {
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[PA[q]][mt]),
                                                                __builtin_bit_cast(bf16x8, fb[PB[q]][nt]), acc[mt][nt], 0,
                                                                0, 0);
-    if (s + 1 < nk) stage(std::integral_constant<int, (set + 1) % 3>{}, (s + 1) & 1);
+    // (unconditional: behind the last k-step it writes stale registers into the buffer nobody reads any more; without a
+    // branch the split / ds_write instructions share the MFMAs' basic block and are issued between them)
+    stage(std::integral_constant<int, (set + 1) % 3>{}, (s + 1) & 1);
+    constexpr int NM = 12 * NT;
+#pragma unroll
+    for (int g = 0; g < NM; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, (100 + NM - 1) / NM + 1, 0);  // its share of the split VALU
+      if (g % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+    }
     __syncthreads();
   };
   for (int ks = 0; ks < nk; ks += 3) {
@@ -409,7 +414,9 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
   const int bn = cg_bn(a.cout);
   a.nblk = (a.cout + bn - 1) / bn;
   static const bool use3 = !(getenv("DIS_CONV_BF16X3") && getenv("DIS_CONV_BF16X3")[0] == '0');
-  if (use3 && a.cin >= CG3_CK) {  // bf16x3 form: 32-channel k-steps, weights pre-split
+  const long xb3 = (long)a.n * a.hin * a.win * a.ldx * 4;  // the bf16x3 kernel addresses x with 31-bit byte offsets
+  if (use3 && a.cin >= CG3_CK && xb3 < 0x7fff0000L) {  // bf16x3 form: 32-channel k-steps, weights pre-split
+    a.x_bytes = (unsigned)xb3;
     a.nchunk = (a.cin + CG3_CK - 1) / CG3_CK;
     Pack3Args p3;
     p3.w = w_raw; p3.packed = (unsigned short*)wpack; p3.ntaps = a.ntaps; p3.nchunk = a.nchunk; p3.nblk = a.nblk;
