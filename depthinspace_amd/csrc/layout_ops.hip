@@ -364,15 +364,20 @@ __global__ void gather_warped_feat_fwd_kernel(const float* __restrict__ feat, co
       const int y = (int)(p / w), x = (int)(p - (long)y * w);
       const float2 f = *(const float2*)(flows + ((((long)t * tl + j) * bs + b) * hw + p) * 2);
       const Taps tp = make_taps(f.x + (float)x, f.y + (float)y, h, w);
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 a = tp.v00 ? *(const float4*)(src + ((long)tp.y0 * w + tp.x0) * c) : z;
-      const float4 bq = tp.v01 ? *(const float4*)(src + ((long)tp.y0 * w + tp.x0 + 1) * c) : z;
-      const float4 cq = tp.v10 ? *(const float4*)(src + ((long)(tp.y0 + 1) * w + tp.x0) * c) : z;
-      const float4 d = tp.v11 ? *(const float4*)(src + ((long)(tp.y0 + 1) * w + tp.x0 + 1) * c) : z;
-      v.x = a.x * tp.w00 + bq.x * tp.w01 + cq.x * tp.w10 + d.x * tp.w11;
-      v.y = a.y * tp.w00 + bq.y * tp.w01 + cq.y * tp.w10 + d.y * tp.w11;
-      v.z = a.z * tp.w00 + bq.z * tp.w01 + cq.z * tp.w10 + d.z * tp.w11;
-      v.w = a.w * tp.w00 + bq.w * tp.w01 + cq.w * tp.w10 + d.w * tp.w11;
+      // taps outside the image: clamped address and zero weight (0 * finite = 0 exactly, so the sum is the one over
+      // the valid taps) - a `valid ? load : zero` select turns into a select of POINTERS with the zero in scratch
+      const int xa = min(max(tp.x0, 0), w - 1), xb = min(max(tp.x0 + 1, 0), w - 1);
+      const int ya = min(max(tp.y0, 0), h - 1), yb = min(max(tp.y0 + 1, 0), h - 1);
+      const float w00 = tp.v00 ? tp.w00 : 0.f, w01 = tp.v01 ? tp.w01 : 0.f;
+      const float w10 = tp.v10 ? tp.w10 : 0.f, w11 = tp.v11 ? tp.w11 : 0.f;
+      const float4 a = *(const float4*)(src + ((long)ya * w + xa) * c);
+      const float4 bq = *(const float4*)(src + ((long)ya * w + xb) * c);
+      const float4 cq = *(const float4*)(src + ((long)yb * w + xa) * c);
+      const float4 d = *(const float4*)(src + ((long)yb * w + xb) * c);
+      v.x = a.x * w00 + bq.x * w01 + cq.x * w10 + d.x * w11;
+      v.y = a.y * w00 + bq.y * w01 + cq.y * w10 + d.y * w11;
+      v.z = a.z * w00 + bq.z * w01 + cq.z * w10 + d.z * w11;
+      v.w = a.w * w00 + bq.w * w01 + cq.w * w10 + d.w * w11;
     }
     *(float4*)(out + ((((long)t * bs + b) * hw + p) * tl + s) * c + g * 4) = v;
   }
