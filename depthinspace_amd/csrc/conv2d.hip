@@ -1255,16 +1255,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 }
 
 // Slab reduce: sums the per-workgroup partial slabs and scatters into OIHW in one launch.  A block = 64 output elements
-// x 4 waves; wave w adds slabs [w nslabs/4, (w+1) nslabs/4) of its lane's element (coalesced 256-B rows), the four
-// partial sums are added in a fixed order (deterministic).  WG_RSPLIT only sizes the (now unused) level-1 scratch that
-// sits between the slabs and the bias partials in the workspace layout.
+// x 16 waves; wave w adds slabs [w nslabs/16, (w+1) nslabs/16) of its lane's element (coalesced 256-B rows, 8 loads in
+// flight: the kernel is bound by the latency of its strided reads, hence the many short ranges), the sixteen partial sums
+// are added in a fixed order (deterministic).  WG_RSPLIT only sizes the (now unused) level-1 scratch that sits between
+// the slabs and the bias partials in the workspace layout.
 #define WG_RSPLIT 16
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
-                                                            int cinb, int nchunk, int nsplit, int khb, int kw, int kh,
-                                                            int cout, int cin_real, int partsz,
-                                                            const float* __restrict__ bpart, float* __restrict__ gb,
-                                                            int workers) {
-  __shared__ float red[256];
+#define WG_RW 16  // waves per block of the reduce
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
+                                                             int cinb, int nchunk, int nsplit, int khb, int kw, int kh,
+                                                             int cout, int cin_real, int partsz,
+                                                             const float* __restrict__ bpart, float* __restrict__ gb,
+                                                             int workers) {
+  __shared__ float red[64 * WG_RW];
   const int mrows = khb * kw * cinb;
   const long total = (long)nchunk * nsplit * mrows * cout;
   const long elems = (long)nchunk * nsplit * partsz;
@@ -1281,34 +1283,40 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       split = (int)(r % nsplit);
       chunk = (int)(r / nsplit);
       const float* p = part + ((long)chunk * nsplit + split) * partsz + (long)m * cout + co;
-      const int lo = (int)((long)workers * wv / 4), hi = (int)((long)workers * (wv + 1) / 4);
+      const int lo = (int)((long)workers * wv / WG_RW), hi = (int)((long)workers * (wv + 1) / WG_RW);
       int k = lo;
-      for (; k + 3 < hi; k += 4)  // 4 independent loads in flight
-        s += (p[(long)k * elems] + p[(long)(k + 1) * elems]) + (p[(long)(k + 2) * elems] + p[(long)(k + 3) * elems]);
+      for (; k + 7 < hi; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long)(k + u) * elems];
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
       for (; k < hi; ++k) s += p[(long)k * elems];
     }
     __syncthreads();
     red[threadIdx.x] = s;
     __syncthreads();
     if (wv == 0 && i < total) {
-      const float t = (red[ln] + red[64 + ln]) + (red[128 + ln] + red[192 + ln]);
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WG_RW; ++w) t += red[w * 64 + ln];
       const int tap = m / cinb, ci = chunk * cinb + m % cinb;
       const int ky = (nsplit > 1 ? split : 0) + tap / kw, kx = tap % kw;
       if (ci < cin_real) gw[(((long)co * cin_real + ci) * kh + ky) * kw + kx] = t;
     }
   }
   // bias gradient: block b < cout/8 adds the per-workgroup bias partials of channels 8b..8b+7; thread t sums workers
-  // {t/8, t/8 + 32, ...} of channel 8b + t%8, then a fixed-order sum over the 32 sub-sums
+  // {t/8, t/8 + 128, ...} of channel 8b + t%8, then a fixed-order sum over the 128 sub-sums
   if (bpart && (int)blockIdx.x * 8 < cout) {
     const int co = blockIdx.x * 8 + (threadIdx.x & 7), sub = threadIdx.x >> 3;
     float s = 0.f;
-    for (int k = sub; k < workers; k += 32) s += bpart[(long)k * cout + co];
+    for (int k = sub; k < workers; k += 128) s += bpart[(long)k * cout + co];
     __syncthreads();
     red[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < 8) {
       float t = 0.f;
-      for (int k = 0; k < 32; ++k) t += red[k * 8 + threadIdx.x];
+      for (int k = 0; k < 128; ++k) t += red[k * 8 + threadIdx.x];
       gb[co] = t;
     }
   }
@@ -1349,7 +1357,7 @@ static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_
   a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
   hipLaunchKernelGGL(kern, dim3((unsigned)workers, C::NCHUNK, C::NSPLIT), dim3(256), C::LDS_BYTES, s, a);
   const long total = (long)C::NCHUNK * C::NSPLIT * C::MROWS * COUT;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(256), 0, s,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(64 * WG_RW), 0, s,
                      (const float*)a.part, gw, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, KW, KH, COUT, cin_real, C::PART,
                      (const float*)(gb ? a.bpart : nullptr), gb, (int)workers);
   DIS_CHECK_LAUNCH();
@@ -1610,7 +1618,7 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
   a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
   hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<CIN, COUT, INACT>), dim3((unsigned)workers), dim3(256), X::LDS_BYTES, s, a);
   const long total = (long)C::MROWS * COUT;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(256), 0, s,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(64 * WG_RW), 0, s,
                      (const float*)a.part, gw, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, COUT, cin_real, C::PART,
                      (const float*)(gb ? a.bpart : nullptr), gb, (int)workers);
   DIS_CHECK_LAUNCH();
