@@ -749,18 +749,19 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
       stat_n = prev_n;
     }
   };
-  auto epi_load = [&]() {
+  // accumulate mode: the old values of a tile's outputs are fetched at the START of its own MFMA loop (a whole tile of
+  // latency cover) and added when the finished accumulators are handed to the deferred epilogue
+  auto epi_load = [&](const float* yb, const unsigned (&off)[2]) {
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i)
-      prevy[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                bx_rsrc(prev_y, y_bytes), prev_off[i / NT] + (i % NT) * 64, 0, 0));
+      prevy[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(yb, y_bytes),
+                                                                                  off[i / NT] + (i % NT) * 64, 0, 0));
   };
   auto epi_piece = [&](int i) {
     const int mt = i / NT, nt = i % NT;
     float o[4];  // (the bias is already in: the accumulators start from it)
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = outv[mt][nt][r];
-    if (ACCUM) o[0] += prevy[i].x, o[1] += prevy[i].y, o[2] += prevy[i].z, o[3] += prevy[i].w;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (ACT == DIS_ACT_SELU) {
@@ -839,8 +840,9 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (ks + 1 < KS) load_frag(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-      // memory work riding under the MFMAs (straight-line): accumulate-mode reads, the next halo, the deferred stores
-      if (ACCUM && ks == 0) epi_load();
+      // memory work riding under the MFMAs (straight-line): accumulate-mode reads (this tile's), the next halo, the
+      // deferred stores
+      if (ACCUM && ks == 0) epi_load(cur_y, cur_off);
 #pragma unroll
       for (int it = 0; it < NLOAD; ++it)
         if (C::load_ks(it) == ks) pf_issue(it);
@@ -886,7 +888,13 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     for (int mt = 0; mt < 2; ++mt) {
       prev_off[mt] = cur_off[mt];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) outv[mt][nt] = acc[mt][nt];
+      for (int nt = 0; nt < NT; ++nt) {
+        outv[mt][nt] = acc[mt][nt];
+        if (ACCUM) {
+          const float4 q = prevy[mt * NT + nt];
+          outv[mt][nt] += (f32x4){q.x, q.y, q.z, q.w};
+        }
+      }
     }
     prev_y = cur_y;
     prev_n = cn;
@@ -898,7 +906,6 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   stats_sample();
   t1 = 0.f;
   t2 = 0.f;
-  if (ACCUM) epi_load();
 #pragma unroll
   for (int i = 0; i < NPIECE; ++i) epi_piece(i);
   s1 += (double)t1;
