@@ -819,29 +819,10 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     t2 = 0.f;
     BX_T(4)
 
-    s16x8 fa[2][3][2], fb[2][3][NT];  // [buffer][plane][mt|nt]
-    auto load_frag = [&](int ks, s16x8 (&A)[3][2], s16x8 (&B)[3][NT]) {
-      int xoff;
-      if (CIN == 32) {
-        xoff = ((ks / 3) * BX_IC + ks % 3) * PS;
-      } else {
-        const int t0 = 2 * ks, t1_ = 2 * ks + 1 > 8 ? 8 : 2 * ks + 1;  // (the 10th tap reads tap 8's pixels: zero weights)
-        xoff = hi_tap ? ((t1_ / 3) * BX_IC + t1_ % 3) * PS : ((t0 / 3) * BX_IC + t0 % 3) * PS;
-      }
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) A[p][mt] = *(const s16x8*)(xl + xa_lane + xoff + mt * BX_IC * PS + p * CIN);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) B[p][nt] = *(const s16x8*)(wl + (((ks * 3 + p) * 4 + lg) * COUT + nt * 16 + li) * 8);
-      }
-    };
-    load_frag(0, fa[0], fb[0]);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) load_frag(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-      // memory work riding under the MFMAs (straight-line): accumulate-mode reads (this tile's), the next halo, the
-      // deferred stores
+    // memory work riding under the MFMAs of k-step ks (straight-line): accumulate-mode reads (this tile's), the next
+    // halo, the deferred stores
+    auto ride = [&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
       if (ACCUM && ks == 0) epi_load(cur_y, cur_off);
 #pragma unroll
       for (int it = 0; it < NLOAD; ++it)
@@ -849,22 +830,11 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < NPIECE; ++i)
         if (C::piece_ks(i) == ks) epi_piece(i);
-      const int b = ks & 1;
-      // smallest terms first
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-      constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-      for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[b][PB[q]][nt]),
-                                                                 __builtin_bit_cast(bf16x8, fa[b][PA[q]][mt]),
-                                                                 acc[mt][nt], 0, 0, 0);
-      // issue order inside the k-step: every MFMA is followed by what fits into the issue cycles it leaves free - one
-      // of the next k-step's fragment reads behind each of the first MFMAs, a few VALU instructions behind the rest
-      constexpr int NM = 12 * NT, NR = 3 * (2 + NT);
+    };
+    // issue order inside a k-step: every MFMA is followed by what fits into the issue cycles it leaves free - one of
+    // the next k-step's NR fragment reads behind each of the first MFMAs, a few VALU instructions behind the rest
+    auto pattern = [&](auto nrc) {
+      constexpr int NM = 12 * NT, NR = decltype(nrc)::value;
 #pragma unroll
       for (int g = 0; g < NM; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
@@ -878,6 +848,92 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
       }
       __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // the k-step's store
       __builtin_amdgcn_sched_barrier(0);
+    };
+    // smallest terms first
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    if constexpr (CIN == 32) {
+      // k-step = tap, walked column by column (kx outer, ky inner): the wave's two output rows r, r+1 read halo rows
+      // r+ky and r+1+ky, so one column of taps needs only the 4 row fragments r..r+3 (read once, 36 pixel-fragment
+      // reads per tile instead of 54).  LDS bandwidth is what the MFMA rate competes with in this kernel: 12 b128 reads
+      // per 24 MFMAs keep the LDS port exactly as busy as the matrix unit.
+      s16x8 R[2][4][3];      // [kx parity][halo row][plane]
+      s16x8 fb[2][3][NT];    // [buffer][plane][nt]
+      auto load_row = [&](int kx, int j) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) R[kx & 1][j][p] = *(const s16x8*)(xl + xa_lane + (j * BX_IC + kx) * PS + p * CIN);
+      };
+      auto load_w = [&](int ks, s16x8 (&B)[3][NT]) {
+        const int wt = (ks % 3) * 3 + ks / 3;  // the weights are packed tap-major (ky * 3 + kx)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) B[p][nt] = *(const s16x8*)(wl + (((wt * 3 + p) * 4 + lg) * COUT + nt * 16 + li) * 8);
+      };
+      load_row(0, 0);
+      load_row(0, 1);
+      load_w(0, fb[0]);
+      auto step = [&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        constexpr int kx = ks / 3, ky = ks % 3, nkx = (ks + 1) / 3, nky = (ks + 1) % 3;
+        if (ks + 1 < KS) {
+          if (nky == 0) {
+            load_row(nkx, 0);
+            load_row(nkx, 1);
+          } else {
+            load_row(nkx, nky + 1);
+          }
+          load_w(ks + 1, fb[(ks + 1) & 1]);
+        }
+        ride(ksc);
+        constexpr int b = ks & 1;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[b][PB[q]][nt]),
+                                                                   __builtin_bit_cast(bf16x8, R[kx & 1][ky + mt][PA[q]]),
+                                                                   acc[mt][nt], 0, 0, 0);
+        pattern(std::integral_constant<int, (ks + 1 < KS ? (nky == 0 ? 6 : 3) + 3 * NT : 0)>{});
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+    } else {
+      s16x8 fa[2][3][2], fb[2][3][NT];  // [buffer][plane][mt|nt]
+      auto load_frag = [&](int ks, s16x8 (&A)[3][2], s16x8 (&B)[3][NT]) {
+        // k-step = a PAIR of taps (the 10th tap reads tap 8's pixels: zero weights)
+        const int t0 = 2 * ks, t1_ = 2 * ks + 1 > 8 ? 8 : 2 * ks + 1;
+        const int xoff = hi_tap ? ((t1_ / 3) * BX_IC + t1_ % 3) * PS : ((t0 / 3) * BX_IC + t0 % 3) * PS;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) A[p][mt] = *(const s16x8*)(xl + xa_lane + xoff + mt * BX_IC * PS + p * CIN);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) B[p][nt] = *(const s16x8*)(wl + (((ks * 3 + p) * 4 + lg) * COUT + nt * 16 + li) * 8);
+        }
+      };
+      load_frag(0, fa[0], fb[0]);
+      auto step = [&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        if (ks + 1 < KS) load_frag(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+        ride(ksc);
+        constexpr int b = ks & 1;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[b][PB[q]][nt]),
+                                                                   __builtin_bit_cast(bf16x8, fa[b][PA[q]][mt]),
+                                                                   acc[mt][nt], 0, 0, 0);
+        pattern(std::integral_constant<int, 3 * (2 + NT)>{});
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{});
     }
     s1 += (double)t1;
     s2 += (double)t2;
