@@ -95,12 +95,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define C3_XS 36   // LDS row stride of the 16x32 transposition tile
 #define C3_HS 20   // LDS row stride of the 16x16 transposition tile
 
-// parameter-gradient layout (floats): dense1_w 48, dense1_b 16, dense2_w 512, dense2_b 32, w 1024
-#define C3_OFF_W1 0
-#define C3_OFF_B1 48
-#define C3_OFF_W2 64
-#define C3_OFF_B2 576
-#define C3_OFF_W 608
+// parameter-gradient layout (floats): w 1024, dense1_w 48, dense1_b 16, dense2_w 512, dense2_b 32 - the order of
+// Conv3D's parameters() (own parameter first, then the sub-modules), i.e. of the trainer's flat gradient buffer, so the
+// reducer can write straight into it
+#define C3_OFF_W 0
+#define C3_OFF_W1 1024
+#define C3_OFF_B1 1072
+#define C3_OFF_W2 1088
+#define C3_OFF_B2 1600
 #define C3_NPARAM 1632
 
 struct __attribute__((aligned(16))) C3Lds {

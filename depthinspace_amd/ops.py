@@ -1121,7 +1121,7 @@ class _Conv3dKnn(torch.autograd.Function):
         join = ctx.join
         second = join is not None and join.buf is not None
         gwf = join.take(wf.shape) if second else torch.zeros_like(wf)  # the scatter accumulates (float atomics)
-        sunk = _sink_block((d1w, d1b, d2w, d2b, w))  # the kernel's parameter-gradient block IS the flat buffer's order
+        sunk = _sink_block((w, d1w, d1b, d2w, d2b))  # the kernel's parameter-gradient block IS the flat buffer's order
         gp = sunk if sunk is not None else torch.empty(1632, dtype=torch.float32, device=wf.device)
         acc = torch.empty(lib.fn('dis_conv3d_knn_bwd_workspace')(), dtype=torch.float32, device=wf.device)
         lib.call('dis_conv3d_knn_bwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, _c(gy), gwf, gp, acc, tl, bs, h, wd,
@@ -1130,8 +1130,8 @@ class _Conv3dKnn(torch.autograd.Function):
             gwf = join.first(gwf)
         if sunk is not None:
             return (None, gwf, None, None, None, None, None, None, None, None)
-        return (None, gwf, gp[0:48].view(16, 3), gp[48:64], gp[64:576].view(32, 16), gp[576:608],
-                gp[608:1632].view(32, 32), None, None, None)
+        return (None, gwf, gp[1024:1072].view(16, 3), gp[1072:1088], gp[1088:1600].view(32, 16), gp[1600:1632],
+                gp[0:1024].view(32, 32), None, None, None)
 
 
 def conv3d_knn(geom, wf, d1w, d1b, d2w, d2b, w, idx, stride, join=None):

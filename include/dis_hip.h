@@ -319,7 +319,8 @@ int dis_conv3d_knn_fwd(const float* geom, const float* wf, const float* dense1_w
                        const float* dense2_w, const float* dense2_b, const float* w, const unsigned char* idx,
                        float* y, int tl, int bs, int h, int wd, int stride, void* stream);
 /* gy: gradient wrt y (post-SELU).  grad_wf (zeroed) scatter-added (float atomics, 128-B rows).  gparams:
- * 16*3+16+32*16+32+32*32 floats overwritten in that order (dense1_w, dense1_b, dense2_w, dense2_b, w).
+ * 32*32+16*3+16+32*16+32 floats overwritten in that order (w, dense1_w, dense1_b, dense2_w, dense2_b: the order of
+ * the module's parameters()).
  * workspace: dis_conv3d_knn_bwd_workspace() floats (per-block partial slabs, summed in a fixed order). */
 long dis_conv3d_knn_bwd_workspace(void);
 int dis_conv3d_knn_bwd(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
