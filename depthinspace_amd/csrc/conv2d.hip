@@ -1155,6 +1155,10 @@ struct WgArgs {
   int n, hin, win, hout, wout, pad;
   const float* xscale;  // optional (n,hin,win,NCHUNK) multiplier of x (see ConvArgs::xscale)
   const float* gact;    // bf16x3 kernel, INACT instances: activation OUTPUT at gy's positions; gy is multiplied by act'(gact)
+  // bf16x3 kernel, GEN instance (channel-slice pairs of a wide layer, dis_convg_wgrad): a pixel of x / gy occupies
+  // ldx / ldg floats, the layer's channels start at xoff / goff and there are cx / cg of them; blockIdx.y = gb * npx + cb
+  // selects x channels [32 cb, 32 cb + 32) and gy channels [32 gb, 32 gb + 32)
+  int ldx, xoff, cx, ldg, goff, cg, npx;
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -1458,9 +1462,14 @@ __device__ __forceinline__ s16x8 tr_read8(const unsigned short* p0, const unsign
   return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int CIN, int COUT, int INACT = 0>
+template <int CIN, int COUT, int INACT = 0, bool GEN = false>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   using C = WxCfg<CIN, COUT>;
+  static_assert(!GEN || (CIN == 32 && COUT == 32 && INACT == 0), "slice-pair form: 32 x 32 channel blocks");
+  // pixel strides (floats) and first channel of this workgroup's slices
+  const int ldx = GEN ? a.ldx : CIN, ldg = GEN ? a.ldg : COUT;
+  const int cb = GEN ? (int)blockIdx.y % a.npx : 0, gbk = GEN ? (int)blockIdx.y / a.npx : 0;
+  const int xc0 = GEN ? a.xoff + 32 * cb : 0, gc0 = GEN ? a.goff + 32 * gbk : 0;
   constexpr int PSX = C::PSX, PSG = C::PSG, NLX = C::NLX, NLG = C::NLG, NB = C::NB, TW = C::TW;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   unsigned short* xl = smem16;
@@ -1487,22 +1496,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
     const int idx = (int)threadIdx.x + it * 256;
     const int vv = idx % C::CVX, pix = idx / C::CVX;
     const int r = pix / WX_IC, c = pix % WX_IC;
-    ix_rc[it] = (idx < C::NIX) ? (r | (c << 16)) : 0x4000;
-    ix_off[it] = ((r * a.win + c) * CIN + vv * 4) * 4;
+    // (channels past the layer's last one - ragged last slice - get the out-of-image row too: they load zeros)
+    ix_rc[it] = (idx < C::NIX && (!GEN || 32 * cb + vv * 4 < a.cx)) ? (r | (c << 16)) : 0x4000;
+    ix_off[it] = ((r * a.win + c) * ldx + xc0 + vv * 4) * 4;
   }
 #pragma unroll
   for (int it = 0; it < NLG; ++it) {
     const int idx = threadIdx.x + it * 256;
     const int vv = idx % C::CVG, pix = idx / C::CVG;
-    ig_rc[it] = (pix >> 4) | ((pix & 15) << 16);
-    ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * COUT + vv * 4) * 4;
+    ig_rc[it] = (!GEN || 32 * gbk + vv * 4 < a.cg) ? ((pix >> 4) | ((pix & 15) << 16)) : 0x4000;
+    ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * ldg + gc0 + vv * 4) * 4;
   }
-  const unsigned x_bytes = (unsigned)a.hin * a.win * (CIN * 4u), g_bytes = (unsigned)a.hout * a.wout * (COUT * 4u);
+  const unsigned x_bytes = (unsigned)a.hin * a.win * (ldx * 4u), g_bytes = (unsigned)a.hout * a.wout * (ldg * 4u);
   auto prefetch = [&](int tile) __attribute__((always_inline)) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * 8 - a.pad, ix0 = tx * 16 - a.pad;
-    const float* xb = a.x + (long)n * a.hin * a.win * CIN;
-    const int xoff0 = (iy0 * a.win + ix0) * (CIN * 4);
+    const float* xb = a.x + (long)n * a.hin * a.win * ldx;
+    const int xoff0 = (iy0 * a.win + ix0) * (ldx * 4);
 #pragma unroll
     for (int it = 0; it < NLX; ++it) {
       const int iy = iy0 + (ix_rc[it] & 0xffff), ix = ix0 + (ix_rc[it] >> 16);
@@ -1510,8 +1520,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
       prex[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(xb, x_bytes), ok ? (unsigned)(xoff0 + ix_off[it]) : BX_OOB, 0, 0));
     }
-    const float* gb = a.gy + (long)n * a.hout * a.wout * COUT;
-    const int goff0 = (ty * 8 * a.wout + tx * 16) * (COUT * 4);
+    const float* gb = a.gy + (long)n * a.hout * a.wout * ldg;
+    const int goff0 = (ty * 8 * a.wout + tx * 16) * (ldg * 4);
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
       const int oy = ty * 8 + (ig_rc[it] & 0xffff), ox = tx * 16 + (ig_rc[it] >> 16);
@@ -1626,7 +1636,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
       }
     }
     // partial slab of this workgroup: [m = mb*16 + row][co]
-    float* out = a.part + (long)blockIdx.x * (C::MB * 16 * COUT);
+    float* out = a.part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (C::MB * 16 * COUT);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       const int t = T0 + j, mb = t / NB, nb = t % NB;
@@ -1684,6 +1694,74 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(64 * WG_RW), 0, s,
                      (const float*)a.part, gw, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, COUT, cin_real, C::PART,
                      (const float*)(gb ? a.bpart : nullptr), gb, (int)workers);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ---- wide layers as 32 x 32 channel-slice pairs (the DispNetS 3x3 stride-1 layers, called from dis_convg_wgrad) ----
+// gw[g][x][tap] = sum over the pair's worker slabs; slab element [tap * 32 + xc][gc] (WxCfg<32, 32>: m = 16 mb + row,
+// mb = 2 tap + half).  Fixed summation order: deterministic.
+__global__ __launch_bounds__(256) void wgrad_pairs_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
+                                                                  int workers, int npx, int npairs, int cxw, int cgw) {
+  const long total = (long)npairs * 9216;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % 9216), pair = (int)(i / 9216);
+    const int gc = e & 31, xc = (e >> 5) & 31, tap = e >> 10;
+    const int x = 32 * (pair % npx) + xc, g = 32 * (pair / npx) + gc;
+    if (x >= cxw || g >= cgw) continue;
+    const float* p = part + (long)pair * workers * 9216 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < workers; k += 4) {
+      s0 += p[(long)k * 9216];
+      s1 += p[(long)(k + 1) * 9216];
+      s2 += p[(long)(k + 2) * 9216];
+      s3 += p[(long)(k + 3) * 9216];
+    }
+    for (; k < workers; ++k) s0 += p[(long)k * 9216];
+    gw[((long)g * cxw + x) * 9 + tap] = (s0 + s1) + (s2 + s3);
+  }
+}
+
+static void wgrad_pairs_plan(int n, int h, int w, int cX, int cG, int* npx, int* ngb, int* wpp) {
+  *npx = (cX + 31) / 32;
+  *ngb = (cG + 31) / 32;
+  const long ntiles = (long)n * ((h + 7) / 8) * ((w + 15) / 16);
+  long per = (2L * 256 + (long)*npx * *ngb - 1) / ((long)*npx * *ngb);  // ~2 workgroups per CU in all
+  if (per > ntiles) per = ntiles;
+  if (per < 1) per = 1;
+  *wpp = (int)per;
+}
+// eligibility and workspace (floats) of the slice-pair form; -1: use the fp32 kernel
+long dis_wgrad_pairs_workspace(int n, int h, int w, int cX, int cG, int ldX, int ldG, int k, int stride, int pad) {
+  static const bool use3 = !(getenv("DIS_CONV_BF16X3") && getenv("DIS_CONV_BF16X3")[0] == '0');
+  if (!use3 || k != 3 || stride != 1 || pad != 1 || cX < 32 || cG < 32) return -1;
+  if ((long)h * w * ldX * 4 >= 0x7fff0000L || (long)h * w * ldG * 4 >= 0x7fff0000L) return -1;
+  int npx, ngb, wpp;
+  wgrad_pairs_plan(n, h, w, cX, cG, &npx, &ngb, &wpp);
+  return (long)npx * ngb * wpp * 9216;
+}
+int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int cX, int cX_w, const float* G, int ldG, int goff, int cG,
+                        int cG_w, float* grad_w, float* workspace, int n, int h, int w, hipStream_t s) {
+  using XC = WxCfg<32, 32>;
+  auto kern = conv_wgrad_bf16x3_kernel<32, 32, 0, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XC::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  int npx, ngb, wpp;
+  wgrad_pairs_plan(n, h, w, cX, cG, &npx, &ngb, &wpp);
+  WgArgs a;
+  a.x = X; a.gy = G; a.part = workspace; a.bpart = nullptr;
+  a.n = n; a.hin = h; a.win = w; a.hout = h; a.wout = w; a.pad = 1;
+  a.xscale = nullptr; a.gact = nullptr;
+  a.ldx = ldX; a.xoff = xoff; a.cx = cX; a.ldg = ldG; a.goff = goff; a.cg = cG; a.npx = npx;
+  hipLaunchKernelGGL(kern, dim3((unsigned)wpp, (unsigned)(npx * ngb)), dim3(256), XC::LDS_BYTES, s, a);
+  const long total = (long)npx * ngb * 9216;
+  hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)workspace,
+                     grad_w, wpp, npx, npx * ngb, cX_w, cG_w);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

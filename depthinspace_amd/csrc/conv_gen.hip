@@ -709,12 +709,22 @@ static void wg_plan(int n, int hG, int wG, int cX, int cG, int k, int* nxb, int*
   *mper = (int)mp;
 }
 
+// conv2d.hip: the 3x3 stride-1 layers with >= 32 channels on both sides run as 32 x 32 channel-slice pairs on the
+// one-pass bf16x3 kernel (x halo and gy tile staged once for all 9 taps, accumulators in registers)
+long dis_wgrad_pairs_workspace(int n, int h, int w, int cX, int cG, int ldX, int ldG, int k, int stride, int pad);
+int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int cX, int cX_w, const float* G, int ldG, int goff, int cG,
+                        int cG_w, float* grad_w, float* workspace, int n, int h, int w, hipStream_t s);
+
 extern "C" long dis_convg_wgrad_workspace(int n, int hG, int wG, int cX, int cG, int k) {
   if (n <= 0 || hG <= 0 || wG <= 0 || cX <= 0 || cG <= 0 || k <= 0 || k * k > CG_MAXTAPS) return -1;
   int nxb, ngb, nsplit, mper, mtw, ntw;
   wg_plan(n, hG, wG, cX, cG, k, &nxb, &ngb, &nsplit, &mper);
   wg_tiles(cX, cG, &mtw, &ntw);
-  return (long)nsplit * k * k * (nxb * 32 * mtw) * (ngb * 32 * ntw);
+  const long f32 = (long)nsplit * k * k * (nxb * 32 * mtw) * (ngb * 32 * ntw);
+  // (the slice-pair form, if dis_convg_wgrad takes it for this layer: stride / pad are not known here, so size for it
+  // whenever the channel counts and k allow it)
+  const long b3 = dis_wgrad_pairs_workspace(n, hG, wG, cX, cG, 4, 4, k, 1, 1);
+  return b3 > f32 ? b3 : f32;
 }
 
 extern "C" int dis_convg_wgrad(const float* X, int ldX, int xoff, int hX, int wX, int cX, int cX_w, const float* G,
@@ -729,6 +739,8 @@ extern "C" int dis_convg_wgrad(const float* X, int ldX, int xoff, int hX, int wX
   if (k * k > CG_MAXTAPS || (stride != 1 && stride != 2)) return DIS_ERR_UNSUPPORTED;
   if ((long)n * hG * wG > 2147483647L - 64) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  if (hX == hG && wX == wG && dis_wgrad_pairs_workspace(n, hG, wG, cX, cG, ldX, ldG, k, stride, pad) >= 0)
+    return dis_wgrad_pairs_run(X, ldX, xoff, cX, cX_w, G, ldG, goff, cG, cG_w, grad_w, workspace, n, hG, wG, s);
   WgGenArgs a;
   a.X = X; a.G = G; a.part = workspace;
   a.n = n; a.hX = hX; a.wX = wX; a.ldX = ldX; a.xoff = xoff; a.cX = cX;
