@@ -1443,18 +1443,29 @@ static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_
 // Partial slabs / bias partials use the layout of conv_wgrad_kernel, so its reducers finish the job.
 // ------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-#define WX_IR 10
-#define WX_IC 18
-template <int CIN, int COUT>
+// K x K taps, stride S, TR x 16 output pixels per tile (TR / 2 k-steps of 32 pixels).  The FuseNet instances are
+// K = 3, S = 1, TR = 8; the slice-pair instances of DispNetS also use 5 x 5 taps and stride 2.
+template <int CIN, int COUT, int K = 3, int S = 1, int TR = 8>
 struct WxCfg {
   static constexpr int PSX = 3 * CIN + 8, PSG = 3 * COUT + 8;  // LDS pixel strides (16-bit units), as BxCfg::PS
   static constexpr int CVX = CIN / 4, CVG = COUT / 4;
-  static constexpr int X_U16 = WX_IR * WX_IC * PSX, G_U16 = 128 * PSG;
+  static constexpr int IR = (TR - 1) * S + K, IC = 15 * S + K;  // halo of the x tile
+  static constexpr int X_U16 = IR * IC * PSX, G_U16 = TR * 16 * PSG;
   static constexpr int LDS_BYTES = (X_U16 + G_U16) * 2 + 1024 * 4;
-  static constexpr int NIX = WX_IR * WX_IC * CVX, NLX = (NIX + 255) / 256;
-  static constexpr int NLG = 128 * CVG / 256;
-  static constexpr int MB = 9 * CIN / 16, NB = COUT / 16, T = MB * NB, TW = (T + 3) / 4;  // tiles, tiles per wave
+  static constexpr int NIX = IR * IC * CVX, NLX = (NIX + 255) / 256;
+  static constexpr int NLG = TR * 16 * CVG / 256;
+  static constexpr int KSN = TR / 2;                                                          // k-steps per tile
+  static constexpr int MB = K * K * CIN / 16, NB = COUT / 16, T = MB * NB, TW = (T + 3) / 4;  // tiles, tiles per wave
+  static_assert(TR % 2 == 0 && (TR * 16 * CVG) % 256 == 0, "tile geometry");
 };
+
+template <int I, int N, class F>
+__device__ __forceinline__ void wx_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    wx_static_for<I + 1, N>(f);
+  }
+}
 
 __device__ __forceinline__ s16x8 tr_read8(const unsigned short* p0, const unsigned short* p1) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
@@ -1462,9 +1473,11 @@ __device__ __forceinline__ s16x8 tr_read8(const unsigned short* p0, const unsign
   return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int CIN, int COUT, int INACT = 0, bool GEN = false>
+template <int CIN, int COUT, int INACT = 0, bool GEN = false, int K = 3, int S = 1, int TR = 8>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
-  using C = WxCfg<CIN, COUT>;
+  using C = WxCfg<CIN, COUT, K, S, TR>;
+  constexpr int WX_IC = C::IC;
+  static_assert(GEN || (K == 3 && S == 1 && TR == 8), "the FuseNet form");
   static_assert(!GEN || (CIN == 32 && COUT == 32 && INACT == 0), "slice-pair form: 32 x 32 channel blocks");
   // pixel strides (floats) and first channel of this workgroup's slices
   const int ldx = GEN ? a.ldx : CIN, ldg = GEN ? a.ldg : COUT;
@@ -1477,7 +1490,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   float* bred = (float*)(smem16 + C::X_U16 + C::G_U16);  // 1024 floats: bias partial reduction
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lg = lane >> 4, l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3;  // tr-read role: row tq, column chunk tp
-  const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + 7) / 8;
+  const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + TR - 1) / TR;
   const int ntiles = a.n * tiles_y * tiles_x;
 
   // my accumulator tiles: t = TW*wave + j -> (mb = t / NB, nb = t % NB); mb = (tap, 16-channel half of the input).  The
@@ -1510,7 +1523,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   const unsigned x_bytes = (unsigned)a.hin * a.win * (ldx * 4u), g_bytes = (unsigned)a.hout * a.wout * (ldg * 4u);
   auto prefetch = [&](int tile) __attribute__((always_inline)) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-    const int iy0 = ty * 8 - a.pad, ix0 = tx * 16 - a.pad;
+    const int iy0 = ty * (TR * S) - a.pad, ix0 = tx * (16 * S) - a.pad;
     const float* xb = a.x + (long)n * a.hin * a.win * ldx;
     const int xoff0 = (iy0 * a.win + ix0) * (ldx * 4);
 #pragma unroll
@@ -1521,10 +1534,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
                                                 bx_rsrc(xb, x_bytes), ok ? (unsigned)(xoff0 + ix_off[it]) : BX_OOB, 0, 0));
     }
     const float* gb = a.gy + (long)n * a.hout * a.wout * ldg;
-    const int goff0 = (ty * 8 * a.wout + tx * 16) * (ldg * 4);
+    const int goff0 = (ty * TR * a.wout + tx * 16) * (ldg * 4);
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
-      const int oy = ty * 8 + (ig_rc[it] & 0xffff), ox = tx * 16 + (ig_rc[it] >> 16);
+      const int oy = ty * TR + (ig_rc[it] & 0xffff), ox = tx * 16 + (ig_rc[it] >> 16);
       const bool ok = oy < a.hout && ox < a.wout;
       preg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(gb, g_bytes), ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
@@ -1568,7 +1581,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
     constexpr int W = decltype(wc)::value, T0 = TW * W, T1 = (T0 + TW < C::T) ? T0 + TW : C::T;
     constexpr int NTW = T1 > T0 ? T1 - T0 : 0;                            // tiles of this wave (0: it only stages)
     constexpr int MB0 = T0 / NB, NG = NTW ? (T1 - 1) / NB - MB0 + 1 : 0;  // row blocks MB0 .. MB0+NG-1
-    constexpr int NU = 4 * NG, NGD = NG ? NG : 1;                         // units per tile: 4 k-steps x NG row blocks
+    constexpr int NU = C::KSN * NG, NGD = NG ? NG : 1;                    // units per tile: k-steps x NG row blocks
     // operand fetch (hardware-transposing reads) of k-step ks: lane group lg covers tile row 2 ks + lg/2, 8 columns
     auto load_fb = [&](int ks, s16x8 (&F)[3][NB]) __attribute__((always_inline)) {
       const int pr = 2 * ks + (lg >> 1), pc0 = 8 * (lg & 1);
@@ -1580,10 +1593,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
     };
     auto load_fa = [&](int ks, int mb, s16x8 (&F)[3]) __attribute__((always_inline)) {
       const int pr = 2 * ks + (lg >> 1), pc0 = 8 * (lg & 1);
-      const int tap = CIN == 32 ? mb >> 1 : mb, half = CIN == 32 ? mb & 1 : 0, ky = tap / 3, kx = tap - 3 * ky;
-      const unsigned short* xq = xl + ((pr + ky) * WX_IC + pc0 + tq + kx) * PSX + half * 16 + tp * 4;
+      const int tap = CIN == 32 ? mb >> 1 : mb, half = CIN == 32 ? mb & 1 : 0, ky = tap / K, kx = tap - K * ky;
+      const unsigned short* xq = xl + ((pr * S + ky) * WX_IC + (pc0 + tq) * S + kx) * PSX + half * 16 + tp * 4;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F[p] = tr_read8(xq + p * CIN, xq + 4 * PSX + p * CIN);
+      for (int p = 0; p < 3; ++p) F[p] = tr_read8(xq + p * CIN, xq + 4 * S * PSX + p * CIN);
     };
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       __syncthreads();
@@ -1596,9 +1609,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
         s16x8 fa[2][3], fb[2][3][NB];
         load_fb(0, fb[0]);
         load_fa(0, MB0, fa[0]);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-          const int ks = u / NGD, gi = u % NGD, mb = MB0 + gi;
+        // (compile-time recursion, not a loop: a loop of this size is only partially unrolled, which would index the
+        // accumulator array dynamically and put it into scratch)
+        wx_static_for<0, NU>([&](auto uc) __attribute__((always_inline)) {
+          constexpr int u = decltype(uc)::value;
+          constexpr int ks = u / NGD, gi = u % NGD, mb = MB0 + gi;
           int nread = 0;
           if (u + 1 < NU) {
             const int ks2 = (u + 1) / NGD, gi2 = (u + 1) % NGD;
@@ -1632,7 +1647,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
               else if (per == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
             }
           __builtin_amdgcn_sched_barrier(0);
-        }
+        });
       }
     }
     // partial slab of this workgroup: [m = mb*16 + row][co]
@@ -1698,72 +1713,93 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
   return DIS_OK;
 }
 
-// ---- wide layers as 32 x 32 channel-slice pairs (the DispNetS 3x3 stride-1 layers, called from dis_convg_wgrad) ----
-// gw[g][x][tap] = sum over the pair's worker slabs; slab element [tap * 32 + xc][gc] (WxCfg<32, 32>: m = 16 mb + row,
+// ---- wide layers as 32 x 32 channel-slice pairs (DispNetS, called from dis_convg_wgrad) ----
+// gw[g][x][tap] = sum over the pair's worker slabs; slab element [tap * 32 + xc][gc] (WxCfg<32, 32, K>: m = 16 mb + row,
 // mb = 2 tap + half).  Fixed summation order: deterministic.
 __global__ __launch_bounds__(256) void wgrad_pairs_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
-                                                                  int workers, int npx, int npairs, int cxw, int cgw) {
-  const long total = (long)npairs * 9216;
+                                                                  int workers, int npx, int npairs, int cxw, int cgw,
+                                                                  int kk) {
+  const int psz = kk * 1024;
+  const long total = (long)npairs * psz;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i % 9216), pair = (int)(i / 9216);
+    const int e = (int)(i % psz), pair = (int)(i / psz);
     const int gc = e & 31, xc = (e >> 5) & 31, tap = e >> 10;
     const int x = 32 * (pair % npx) + xc, g = 32 * (pair / npx) + gc;
     if (x >= cxw || g >= cgw) continue;
-    const float* p = part + (long)pair * workers * 9216 + e;
+    const float* p = part + (long)pair * workers * psz + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0;
     for (; k + 3 < workers; k += 4) {
-      s0 += p[(long)k * 9216];
-      s1 += p[(long)(k + 1) * 9216];
-      s2 += p[(long)(k + 2) * 9216];
-      s3 += p[(long)(k + 3) * 9216];
+      s0 += p[(long)k * psz];
+      s1 += p[(long)(k + 1) * psz];
+      s2 += p[(long)(k + 2) * psz];
+      s3 += p[(long)(k + 3) * psz];
     }
-    for (; k < workers; ++k) s0 += p[(long)k * 9216];
-    gw[((long)g * cxw + x) * 9 + tap] = (s0 + s1) + (s2 + s3);
+    for (; k < workers; ++k) s0 += p[(long)k * psz];
+    gw[((long)g * cxw + x) * kk + tap] = (s0 + s1) + (s2 + s3);
   }
 }
 
-static void wgrad_pairs_plan(int n, int h, int w, int cX, int cG, int* npx, int* ngb, int* wpp) {
+// tile rows of the (k, stride) instances: stride 2 halves the tile so that two workgroups still share a CU's LDS
+static int wgrad_pairs_tr(int k, int stride) {
+  if (stride == 1 && (k == 3 || k == 5)) return 8;
+  if (stride == 2 && (k == 3 || k == 5)) return 4;
+  return 0;
+}
+static void wgrad_pairs_plan(int n, int hG, int wG, int cX, int cG, int tr, int* npx, int* ngb, int* wpp) {
   *npx = (cX + 31) / 32;
   *ngb = (cG + 31) / 32;
-  const long ntiles = (long)n * ((h + 7) / 8) * ((w + 15) / 16);
+  const long ntiles = (long)n * ((hG + tr - 1) / tr) * ((wG + 15) / 16);
   long per = (2L * 256 + (long)*npx * *ngb - 1) / ((long)*npx * *ngb);  // ~2 workgroups per CU in all
   if (per > ntiles) per = ntiles;
   if (per < 1) per = 1;
   *wpp = (int)per;
 }
 // eligibility and workspace (floats) of the slice-pair form; -1: use the fp32 kernel
-long dis_wgrad_pairs_workspace(int n, int h, int w, int cX, int cG, int ldX, int ldG, int k, int stride, int pad) {
+long dis_wgrad_pairs_workspace(int n, int hX, int wX, int hG, int wG, int cX, int cG, int ldX, int ldG, int k,
+                               int stride) {
   static const bool use3 = !(getenv("DIS_CONV_BF16X3") && getenv("DIS_CONV_BF16X3")[0] == '0');
-  if (!use3 || k != 3 || stride != 1 || pad != 1 || cX < 32 || cG < 32) return -1;
-  if ((long)h * w * ldX * 4 >= 0x7fff0000L || (long)h * w * ldG * 4 >= 0x7fff0000L) return -1;
+  const int tr = wgrad_pairs_tr(k, stride);
+  if (!use3 || tr == 0 || cX < 16 || cG < 32) return -1;  // (a 16-channel x slice fills half of its block)
+  if ((long)hX * wX * ldX * 4 >= 0x7fff0000L || (long)hG * wG * ldG * 4 >= 0x7fff0000L) return -1;
   int npx, ngb, wpp;
-  wgrad_pairs_plan(n, h, w, cX, cG, &npx, &ngb, &wpp);
-  return (long)npx * ngb * wpp * 9216;
+  wgrad_pairs_plan(n, hG, wG, cX, cG, tr, &npx, &ngb, &wpp);
+  return (long)npx * ngb * wpp * k * k * 1024;
 }
-int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int cX, int cX_w, const float* G, int ldG, int goff, int cG,
-                        int cG_w, float* grad_w, float* workspace, int n, int h, int w, hipStream_t s) {
-  using XC = WxCfg<32, 32>;
-  auto kern = conv_wgrad_bf16x3_kernel<32, 32, 0, true>;
+template <int K, int S, int TR>
+static int wgrad_pairs_launch(WgArgs a, float* grad_w, int cX_w, int cG_w, int ngb, int wpp, hipStream_t s) {
+  using XC = WxCfg<32, 32, K, S, TR>;
+  static_assert(XC::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+  auto kern = conv_wgrad_bf16x3_kernel<32, 32, 0, true, K, S, TR>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XC::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  int npx, ngb, wpp;
-  wgrad_pairs_plan(n, h, w, cX, cG, &npx, &ngb, &wpp);
-  WgArgs a;
-  a.x = X; a.gy = G; a.part = workspace; a.bpart = nullptr;
-  a.n = n; a.hin = h; a.win = w; a.hout = h; a.wout = w; a.pad = 1;
-  a.xscale = nullptr; a.gact = nullptr;
-  a.ldx = ldX; a.xoff = xoff; a.cx = cX; a.ldg = ldG; a.goff = goff; a.cg = cG; a.npx = npx;
-  hipLaunchKernelGGL(kern, dim3((unsigned)wpp, (unsigned)(npx * ngb)), dim3(256), XC::LDS_BYTES, s, a);
-  const long total = (long)npx * ngb * 9216;
-  hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)workspace,
-                     grad_w, wpp, npx, npx * ngb, cX_w, cG_w);
+  hipLaunchKernelGGL(kern, dim3((unsigned)wpp, (unsigned)(a.npx * ngb)), dim3(256), XC::LDS_BYTES, s, a);
+  const long total = (long)a.npx * ngb * K * K * 1024;
+  hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)a.part,
+                     grad_w, wpp, a.npx, a.npx * ngb, cX_w, cG_w, K * K);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
+}
+int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int hX, int wX, int cX, int cX_w, const float* G, int ldG,
+                        int goff, int hG, int wG, int cG, int cG_w, float* grad_w, float* workspace, int n, int k,
+                        int stride, int pad, hipStream_t s) {
+  const int tr = wgrad_pairs_tr(k, stride);
+  int npx, ngb, wpp;
+  wgrad_pairs_plan(n, hG, wG, cX, cG, tr, &npx, &ngb, &wpp);
+  WgArgs a;
+  a.x = X; a.gy = G; a.part = workspace; a.bpart = nullptr;
+  a.n = n; a.hin = hX; a.win = wX; a.hout = hG; a.wout = wG; a.pad = pad;
+  a.xscale = nullptr; a.gact = nullptr;
+  a.ldx = ldX; a.xoff = xoff; a.cx = cX; a.ldg = ldG; a.goff = goff; a.cg = cG; a.npx = npx;
+  if (k == 3 && stride == 1) return wgrad_pairs_launch<3, 1, 8>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
+  if (k == 5 && stride == 1) return wgrad_pairs_launch<5, 1, 8>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
+  if (k == 3 && stride == 2) return wgrad_pairs_launch<3, 2, 4>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
+  if (k == 5 && stride == 2) return wgrad_pairs_launch<5, 2, 4>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
+  return DIS_ERR_UNSUPPORTED;
 }
 
 #define WG_CASE(CI, CO, K_, S_) \
@@ -1786,7 +1822,6 @@ static int dispatch_wgrad(const WgArgs& a, float* gw, float* gb, int cin_real, i
   WG_CASE(4, 32, 7, 2)   // DispNetS conv1 (2 -> 32, k7 s2): all 49 taps in one pass over the pixels
   WG_CASE(32, 32, 7, 1)  // DispNetS conv1b
   WG_CASE(20, 16, 3, 1)  // DispNetS iconv1 (17 -> 16 at full resolution)
-  WG_CASE(68, 32, 3, 1)  // DispNetS iconv2 (65 -> 32)
   return DIS_ERR_UNSUPPORTED;
 }
 
@@ -1804,7 +1839,6 @@ extern "C" long dis_conv2d_wgrad_workspace(int cin, int cout, int k, int stride)
   WS_CASE(4, 32, 7, 2)
   WS_CASE(32, 32, 7, 1)
   WS_CASE(20, 16, 3, 1)
-  WS_CASE(68, 32, 3, 1)
   return -1;
 }
 
