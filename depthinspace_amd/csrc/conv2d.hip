@@ -42,6 +42,11 @@ struct ConvArgs {
   int w_o, w_i;  // ... and its leading dims
   int w_rs;      // ... and the floats between its rows (w_i * 9 if dense; larger for a slice w[:, a:b] of a wider weight)
   const float* xact;  // bf16x3 kernel, INACT instances: activation OUTPUT at x's positions; x is multiplied by act'(xact)
+  // bf16x3 kernel, GEN instances (32-channel slices of wider tensors, dis_convg_run): x / y point at the slice's first
+  // channel, a pixel occupies ldx / ldy floats, cx / cy channels of the slice exist (the rest load zeros / are not
+  // stored), x_sub / y_sub = floats between the tensor's start and the slice's (for the buffer range), nbias = bias
+  // entries that exist
+  int ldx, ldy, cx, cy, x_sub, y_sub, nbias;
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -603,9 +608,11 @@ extern "C" int dis_debug_bx_stamps(unsigned long long* host) {
 // consecutive output channels of one pixel and stores a float4.
 // INACT != 0 (input-gradient launches of a conv that had an activation): x is the gradient wrt the activation's OUTPUT
 // and a.xact that output; the halo is staged as x * act'(xact), which replaces a separate pass over the tensor.
-template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0>
+template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool GEN = false>
 __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   using C = BxCfg<CIN, COUT>;
+  static_assert(!GEN || (!STATS && INACT == 0), "slice form: plain convolution / input gradient");
+  const int ldx = GEN ? a.ldx : CIN, ldy = GEN ? a.ldy : COUT;  // floats per pixel
   constexpr int PS = C::PS, NT = C::NT, KS = C::KS, NLOAD = C::NLOAD, NPIECE = C::NPIECE, CV = C::CV;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
 #ifdef BX_STAMP
@@ -634,10 +641,12 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     const int idx = (int)threadIdx.x + it * 512;
     const int vv = idx % CV, pix = idx / CV;
     const int r = pix / BX_IC, c = pix % BX_IC;
-    it_rc[it] = (idx < C::NITEMS) ? (r | (c << 16)) : 0x4000;
-    it_off[it] = ((r * a.win + c) * CIN + vv * 4) * 4;
+    // (GEN: channels the slice does not have get the out-of-image row too - they load zeros)
+    it_rc[it] = (idx < C::NITEMS && (!GEN || vv * 4 < a.cx)) ? (r | (c << 16)) : 0x4000;
+    it_off[it] = ((r * a.win + c) * ldx + vv * 4) * 4;
   }
-  const unsigned x_bytes = (unsigned)a.hin * a.win * (CIN * 4u), y_bytes = (unsigned)a.hf * a.wf * (COUT * 4u);
+  const unsigned x_bytes = GEN ? ((unsigned)a.hin * a.win * ldx - a.x_sub) * 4u : (unsigned)a.hin * a.win * (CIN * 4u);
+  const unsigned y_bytes = GEN ? ((unsigned)a.hf * a.wf * ldy - a.y_sub) * 4u : (unsigned)a.hf * a.wf * (COUT * 4u);
   // halo fetch state of the tile being prefetched (all wave-uniform)
   const float* pf_x = a.x;
   unsigned pf_bytes = 0;
@@ -645,8 +654,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   auto pf_setup = [&](int n, int ty, int tx, bool live) {
     pf_iy0 = ty * BX_TR - a.pad_y;
     pf_ix0 = tx * BX_TC - a.pad_x;
-    pf_off0 = (pf_iy0 * a.win + pf_ix0) * (CIN * 4);
-    pf_x = a.x + (long)n * a.hin * a.win * CIN;
+    pf_off0 = (pf_iy0 * a.win + pf_ix0) * (ldx * 4);
+    pf_x = a.x + (long)n * a.hin * a.win * ldx;
     pf_bytes = live ? x_bytes : 0u;  // no next tile: every load is out of range
   };
   auto pf_issue = [&](int it) {
@@ -721,11 +730,15 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   float t1 = 0.f, t2 = 0.f;
   int stat_n = -1;
   float4 bias_v[NT];
+  bool yok[NT];  // GEN: this lane's 4 output channels of block nt exist in the slice
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-    bias_v[nt] = a.bias ? *(const float4*)(a.bias + nt * 16 + lg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int yrow = a.osy * a.wf * (COUT * 4);  // bytes between output rows of this launch
-  const int y_lane = ((wave * 2 * a.osy * a.wf + li * a.osx) * COUT + lg * 4) * 4;
+  for (int nt = 0; nt < NT; ++nt) {
+    yok[nt] = !GEN || nt * 16 + lg * 4 < a.cy;
+    bias_v[nt] = (a.bias && (!GEN || nt * 16 + lg * 4 < a.nbias)) ? *(const float4*)(a.bias + nt * 16 + lg * 4)
+                                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int yrow = a.osy * a.wf * (ldy * 4);  // bytes between output rows of this launch
+  const int y_lane = ((wave * 2 * a.osy * a.wf + li * a.osx) * ldy + lg * 4) * 4;
 
   // deferred epilogue state (tile t-1): wave-uniform sample base, per-lane byte offsets of its two rows (or BX_OOB)
   const float* prev_y = a.y;
@@ -754,8 +767,9 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   auto epi_load = [&](const float* yb, const unsigned (&off)[2]) {
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i)
-      prevy[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(yb, y_bytes),
-                                                                                  off[i / NT] + (i % NT) * 64, 0, 0));
+      prevy[i] = __builtin_bit_cast(
+          float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(yb, y_bytes),
+                                                        yok[i % NT] ? off[i / NT] + (i % NT) * 64 : BX_OOB, 0, 0));
   };
   auto epi_piece = [&](int i) {
     const int mt = i / NT, nt = i % NT;
@@ -777,7 +791,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     u32x4 ov;
 #pragma unroll
     for (int r = 0; r < 4; ++r) ov[r] = __float_as_uint(o[r]);
-    __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(prev_y, y_bytes), prev_off[mt] + nt * 64, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(prev_y, y_bytes), yok[nt] ? prev_off[mt] + nt * 64 : BX_OOB, 0, 0);
     if (STATS) {
       const float q1 = (o[0] + o[1]) + (o[2] + o[3]);
       const float q2 = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
@@ -793,8 +807,8 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   while (tile < t_hi) {
     // where this tile's outputs go
     const int vy0 = cty * BX_TR + wave * 2, vx0 = ctx * BX_TC + li;
-    const int tile_yoff = ((cty * BX_TR * a.osy + a.ooy) * a.wf + ctx * BX_TC * a.osx + a.oox) * (COUT * 4) + y_lane;
-    const float* cur_y = a.y + (long)cn * a.hf * a.wf * COUT;
+    const int tile_yoff = ((cty * BX_TR * a.osy + a.ooy) * a.wf + ctx * BX_TC * a.osx + a.oox) * (ldy * 4) + y_lane;
+    const float* cur_y = a.y + (long)cn * a.hf * a.wf * ldy;
     unsigned cur_off[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) cur_off[mt] = (vx0 < a.wv && vy0 + mt < a.hv) ? (unsigned)(tile_yoff + mt * yrow) : BX_OOB;
@@ -1113,6 +1127,82 @@ extern "C" int dis_conv2d_dgrad_bf16x3_act(const float* gy, const float* y, int 
                             accumulate ? DIS_CONV_ACCUM : 0, stream, y, act);
 }
 
+
+// ---- 3x3 stride-1 pad-1 layers of the general family (DispNetS) as 32 x 32 channel-slice launches of the kernel above
+// (called from dis_convg_run; conv_gen.hip).  Input-channel slices after the first accumulate into y; the bias enters
+// with the first slice and the activation with the last.  dgrad != 0: x is the gradient wrt the conv's output and w its
+// weight [cin_w][cout_w][3][3] (DIS_CONVG_CONV_DGRAD), else w is [cout_w][cin_w][3][3].
+long dis_bx_slices_ok(int n, int h, int wd, int cin, int cout, int ldx, int ldy, int xoff, int yoff, int k, int stride,
+                      int pad, int act) {
+  static const bool use3 = !(getenv("DIS_CONV_BF16X3") && getenv("DIS_CONV_BF16X3")[0] == '0');
+  if (!use3 || k != 3 || stride != 1 || pad != 1 || cin < 16 || cout < 16) return 0;
+  if ((cin & 3) || (cout & 3) || (ldx & 3) || (ldy & 3) || (xoff & 3) || (yoff & 3)) return 0;
+  if (act != DIS_ACT_NONE && act != DIS_ACT_RELU) return 0;
+  if ((long)h * wd * ldx * 4 >= 0x7fff0000L || (long)h * wd * ldy * 4 >= 0x7fff0000L) return 0;
+  // one launch per slice pair: worth it for the few-channel layers at high resolution only (the deep layers have
+  // hundreds of pairs over a handful of tiles: the streaming kernel stays their path)
+  const long pairs = (long)((cin + 31) / 32) * ((cout + 31) / 32);
+  if (pairs > 10 || (long)n * h * wd < 400000L) return 0;
+  return 1;
+}
+int dis_bx_slices_run(int dgrad, const float* x, int ldx, int xoff, int cin, int cin_w, const float* w,
+                      const float* bias, float* y, int ldy, int yoff, int cout, int cout_w, int n, int h, int wd, int act,
+                      hipStream_t stream) {
+  using C = BxCfg<32, 32>;
+  const int ncb = (cin + 31) / 32, ngb = (cout + 31) / 32;
+  // input slices that have real weights (the rest are zero-padded lanes and contribute nothing)
+  const int ncb_w = (cin_w + 31) / 32;
+  const int tiles_x = (wd + BX_TC - 1) / BX_TC, tiles_y = (h + BX_TR - 1) / BX_TR;
+  const long ntiles = (long)n * tiles_y * tiles_x;
+  long grid = num_cus();
+  if (grid > ntiles) grid = ntiles;
+  if (grid >= 8) grid -= grid % 8;
+  if (grid < 1) grid = 1;
+  static bool attr_set[4] = {};
+  for (int gb = 0; gb < ngb; ++gb)
+    for (int cb = 0; cb < (ncb_w < ncb ? ncb_w : ncb); ++cb) {
+      const bool first = cb == 0, last = cb == (ncb_w < ncb ? ncb_w : ncb) - 1;
+      ConvArgs a;
+      a.x = x + xoff + 32 * cb; a.bias = (first && bias) ? bias + 32 * gb : nullptr; a.y = y + yoff + 32 * gb; a.stats = nullptr;
+      a.n = n; a.hin = h; a.win = wd; a.hv = h; a.wv = wd; a.pad_y = 1; a.pad_x = 1;
+      a.hf = h; a.wf = wd; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
+      a.act = last ? act : DIS_ACT_NONE;
+      a.accum = first ? 0 : 1;
+      a.xscale = nullptr; a.yscale = nullptr; a.xact = nullptr;
+      a.ldx = ldx; a.ldy = ldy;
+      a.cx = cin - 32 * cb < 32 ? cin - 32 * cb : 32;
+      a.cy = cout - 32 * gb < 32 ? cout - 32 * gb : 32;
+      a.x_sub = xoff + 32 * cb; a.y_sub = yoff + 32 * gb;
+      const int wi_in = cin_w - 32 * cb < 32 ? cin_w - 32 * cb : 32;      // real input channels of the slice
+      int wo_out = cout_w - 32 * gb < 32 ? cout_w - 32 * gb : 32;        // real output channels of the slice
+      if (wo_out < 0) wo_out = 0;
+      a.nbias = wo_out;
+      if (!dgrad) {
+        a.wmode = 0; a.w = w + ((long)32 * gb * cin_w + 32 * cb) * 9; a.w_o = wo_out; a.w_i = wi_in; a.w_rs = cin_w * 9;
+      } else {
+        a.wmode = 1; a.w = w + ((long)32 * cb * cout_w + 32 * gb) * 9; a.w_o = wi_in; a.w_i = wo_out; a.w_rs = cout_w * 9;
+      }
+      if (wo_out == 0) { a.w = w; a.w_o = 0; a.w_i = 0; }  // zero-padded output lanes only: written as zeros (+0 bias)
+      const int variant = (a.act == DIS_ACT_RELU ? 2 : 0) + a.accum;
+      auto launch = [&](auto kern) -> hipError_t {
+        if (!attr_set[variant]) {
+          hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+          if (e != hipSuccess) return e;
+          attr_set[variant] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
+        return hipSuccess;
+      };
+      hipError_t le;
+      if (variant == 0) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_NONE, false, false, 0, true>);
+      else if (variant == 1) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_NONE, true, false, 0, true>);
+      else if (variant == 2) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_RELU, false, false, 0, true>);
+      else le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_RELU, true, false, 0, true>);
+      if (le != hipSuccess) return (int)le;
+    }
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // weight gradient:  dW[(tap,ci)][co] = sum_pixels X[pixel+tap][ci] * G[pixel][co]
