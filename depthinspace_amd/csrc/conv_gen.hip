@@ -43,6 +43,9 @@ struct GenArgs {
   int act, ntaps, nblk;
   short tdy[CG_MAXTAPS], tdx[CG_MAXTAPS];
   unsigned x_bytes;  // convg3 only: size of the x tensor in bytes (buffer descriptor range)
+  // fp32 kernel, 4-channel inputs (DispNetS conv1: 2 -> 32, 7x7): a 16-wide k-chunk is FOUR TAPS x 4 channels instead of
+  // one tap's 4 channels + 12 zeros; ntaps then counts tap groups and ntaps_real the taps
+  int tpack, ntaps_real;
 };
 
 template <int BN>
@@ -75,13 +78,16 @@ __global__ __launch_bounds__(256) void convg_fwd_kernel(GenArgs a) {
   bool rok[2] = {false, false};
   const int wtid = (tid < BN * 4) ? tid : 0;
   auto prefetch = [&](int tap, int chunk) {
-    const int dy = a.tdy[tap], dx = a.tdx[tap];
-    const int c = chunk * CG_CK + pq * 4;
+    // (tap-packed form: quarter pq of the chunk is tap 4*tap + pq, channels 0..3)
+    const int tsel = a.tpack ? min(4 * tap + pq, a.ntaps_real - 1) : tap;
+    const bool tok = !a.tpack || 4 * tap + pq < a.ntaps_real;
+    const int dy = a.tdy[tsel], dx = a.tdx[tsel];
+    const int c = a.tpack ? 0 : chunk * CG_CK + pq * 4;
     const int cc = min(c, a.cin - 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int iy = piy[j] + dy, ix = pix[j] + dx;
-      rok[j] = pval[j] && c < a.cin && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+      rok[j] = pval[j] && tok && c < a.cin && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
       const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
       ra[j] = *(const float4*)(a.x + (pbase[j] + (long)cy * a.win + cx) * a.ldx + a.xoff + cc);
     }
@@ -172,6 +178,7 @@ struct PackArgs {
   const float* w;
   float* packed;
   int ntaps, nchunk, nblk, bn, ci_real, co_real;
+  int tpack, ntaps_real;  // see GenArgs
   long s_ci, s_co;
   short tsrc[CG_MAXTAPS];
 };
@@ -188,9 +195,10 @@ __global__ void convg_pack_kernel(PackArgs a) {
     r /= a.nblk;
     const int chunk = (int)(r % a.nchunk);
     const int tap = (int)(r / a.nchunk);
-    const int ci = chunk * CG_CK + lg * 4 + e, co = nb * a.bn + col;
+    const int ci = a.tpack ? e : chunk * CG_CK + lg * 4 + e, co = nb * a.bn + col;
+    const int ts = a.tpack ? 4 * tap + lg : tap;
     float v = 0.f;
-    if (ci < a.ci_real && co < a.co_real) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
+    if (ci < a.ci_real && co < a.co_real && (!a.tpack || ts < a.ntaps_real)) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[ts]];
     a.packed[i] = v;
   }
 }
@@ -435,10 +443,14 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
     return DIS_OK;
   }
   a.nchunk = (a.cin + CG_CK - 1) / CG_CK;
+  a.tpack = (a.cin == 4 && a.ntaps > 4) ? 1 : 0;
+  a.ntaps_real = a.ntaps;
   PackArgs p;
+  for (int t = 0; t < a.ntaps; ++t) p.tsrc[t] = tsrc[t];
+  if (a.tpack) a.ntaps = (a.ntaps_real + 3) / 4;
   p.w = w_raw; p.packed = wpack; p.ntaps = a.ntaps; p.nchunk = a.nchunk; p.nblk = a.nblk; p.bn = bn;
   p.ci_real = ci_real; p.co_real = co_real; p.s_ci = s_ci; p.s_co = s_co;
-  for (int t = 0; t < a.ntaps; ++t) p.tsrc[t] = tsrc[t];
+  p.tpack = a.tpack; p.ntaps_real = a.ntaps_real;
   const long ptotal = (long)a.ntaps * a.nchunk * a.nblk * 16 * bn;
   hipLaunchKernelGGL(convg_pack_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
   a.w = wpack;
