@@ -14,7 +14,7 @@ H, W = 512, 432
 
 def relerr(a, b):
     a = a.detach().double()
-    b = b.detach().double()
+    b = b.detach().double().to(a.device)
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
@@ -97,3 +97,87 @@ def test_mf_forward_fullsize_matches_oracle():
     print('full-size DIS-MF forward vs oracle: disp L1', l1, 'max', mx)
     assert l1 < 1e-4, (l1, mx)
     assert torch.equal(outs[0], outs[1])
+
+
+# the DispNetS layers that run as 32-channel slice launches of the halo-resident bf16x3 kernel only do so at high
+# resolution (>= 400k pixels, <= 10 slice pairs): cin (weight), cin_mem, cout, n, h, w
+SLICE_SHAPES = [
+    (17, 20, 16, 2, H, W),      # iconv1 at full resolution: one ragged slice on either side
+    (65, 68, 32, 8, 256, 216),  # iconv2: three input slices accumulate, the last one has 4 channels
+    (129, 132, 64, 32, 128, 108),  # iconv3: 5 x 2 slice pairs
+]
+
+
+@pytest.mark.parametrize('cin,cin_mem,cout,n,h,w', SLICE_SHAPES)
+def test_convg_slice_launches_match_torch(cin, cin_mem, cout, n, h, w):
+    """forward (bias + ReLU), input gradient and weight gradient of a 3x3 stride-1 DispNetS layer on the slice path vs
+    torch's CPU convolution on the same values"""
+    import torch.nn.functional as F
+    from depthinspace_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, br, padding=1)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+    xp = torch.zeros(n, h, w, cin_mem)
+    xp[..., :cin] = x.permute(0, 2, 3, 1)
+    xd = xp.cuda().requires_grad_(True)
+    wd, bd = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    with torch.no_grad():
+        assert relerr(ops.convg(xd, wd, bd, 1, 1, ops.ACT_RELU).permute(0, 3, 1, 2), F.relu(y)) < 2e-5
+    # the gradients are checked without the ReLU: among 10^7 outputs a few lie within rounding of 0, where the two
+    # implementations may take different sides of the kink
+    yd = ops.convg(xd, wd, bd, 1, 1, ops.ACT_NONE)
+    assert relerr(yd.permute(0, 3, 1, 2), y) < 2e-5
+    yd.backward(go.permute(0, 2, 3, 1).contiguous().cuda())
+    assert relerr(xd.grad[..., :cin].permute(0, 3, 1, 2), xr.grad) < 5e-5
+    assert float(xd.grad[..., cin:].abs().max()) == 0.0
+    assert relerr(wd.grad, wr.grad) < 5e-5
+    assert relerr(bd.grad, br.grad) < 5e-5
+
+
+def test_convg_channel_slices_of_wider_buffers():
+    """the (pointer, ld, off) form of the C-ABI on the slice paths: x and y are channel ranges of wider buffers
+    (concatenations in place); everything outside the written range must stay untouched"""
+    import torch.nn.functional as F
+    from depthinspace_amd import lib, ops
+    g = torch.Generator().manual_seed(21)
+    n, h, w, cin, cout = 2, H, W, 20, 16
+    ldx, xoff, ldy, yoff = 40, 8, 48, 16
+    xw = torch.randn(n, h, w, ldx, generator=g)
+    wt = torch.randn(cout, 17, 3, 3, generator=g) / 12.0
+    b = torch.randn(cout, generator=g) * 0.1
+    xs = xw[..., xoff:xoff + 17].permute(0, 3, 1, 2).contiguous()
+    y_ref = F.relu(F.conv2d(xs, wt, b, padding=1)).permute(0, 2, 3, 1)
+    yw = torch.full((n, h, w, ldy), 7.0).cuda()
+    xd, wd, bd = xw.cuda(), wt.cuda(), b.cuda()
+    wp = torch.empty(lib.fn('dis_convg_pack_workspace')(cin, cout, 3), dtype=torch.float32, device='cuda')
+    lib.call('dis_convg_run', ops.CONVG_CONV, xd, ldx, xoff, wd, bd, yw, ldy, yoff, wp, n, h, w, cin, 17, h, w, cout, cout,
+             3, 1, 1, ops.ACT_RELU)
+    assert relerr(yw[..., yoff:yoff + cout].cpu(), y_ref) < 2e-5
+    assert bool((yw[..., :yoff] == 7.0).all()) and bool((yw[..., yoff + cout:] == 7.0).all())
+    # input gradient into channels [8, 28) of a 40-channel buffer: real channels 8..24, zero lanes 25..27
+    gy = torch.randn(n, h, w, ldy, generator=g)
+    gs = gy[..., yoff:yoff + cout].permute(0, 3, 1, 2).contiguous()
+    gx_ref = F.conv_transpose2d(gs, wt, padding=1).permute(0, 2, 3, 1)
+    gxw = torch.full((n, h, w, ldx), -3.0).cuda()
+    lib.call('dis_convg_run', ops.CONVG_CONV_DGRAD, gy.cuda(), ldy, yoff, wd, None, gxw, ldx, xoff, wp, n, h, w, cout, cout,
+             h, w, cin, 17, 3, 1, 1, ops.ACT_NONE)
+    assert relerr(gxw[..., xoff:xoff + 17].cpu(), gx_ref) < 5e-5
+    assert float(gxw[..., xoff + 17:xoff + cin].abs().max()) == 0.0
+    assert bool((gxw[..., :xoff] == -3.0).all()) and bool((gxw[..., xoff + cin:] == -3.0).all())
+    # weight gradient from the two channel ranges (slice-pair kernel: x needs >= 16, gy >= 32 channels)
+    n2, h2, w2, cx, cg = 2, 24, 20, 36, 64
+    xw2 = torch.randn(n2, h2, w2, 48, generator=g)
+    gw2 = torch.randn(n2, h2, w2, 80, generator=g)
+    xs2 = xw2[..., 4:4 + 33].permute(0, 3, 1, 2).contiguous()
+    gs2 = gw2[..., 12:12 + cg].permute(0, 3, 1, 2).contiguous()
+    wz = torch.zeros(cg, 33, 3, 3, requires_grad=True)
+    (F.conv2d(xs2, wz, padding=1) * gs2).sum().backward()
+    gwd = torch.empty(cg, 33, 3, 3, device='cuda')
+    ws = torch.empty(lib.fn('dis_convg_wgrad_workspace')(n2, h2, w2, cx, cg, 3), dtype=torch.float32, device='cuda')
+    lib.call('dis_convg_wgrad', xw2.cuda(), 48, 4, h2, w2, cx, 33, gw2.cuda(), 80, 12, h2, w2, cg, cg, gwd, ws, n2, 3, 1, 1)
+    assert relerr(gwd.cpu(), wz.grad) < 5e-5
