@@ -1535,17 +1535,17 @@ static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 // K x K taps, stride S, TR x 16 output pixels per tile (TR / 2 k-steps of 32 pixels).  The FuseNet instances are
 // K = 3, S = 1, TR = 8; the slice-pair instances of DispNetS also use 5 x 5 taps and stride 2.
-template <int CIN, int COUT, int K = 3, int S = 1, int TR = 8>
+template <int CIN, int COUT, int K = 3, int S = 1, int TR = 8, int KH = K>
 struct WxCfg {
   static constexpr int PSX = 3 * CIN + 8, PSG = 3 * COUT + 8;  // LDS pixel strides (16-bit units), as BxCfg::PS
   static constexpr int CVX = CIN / 4, CVG = COUT / 4;
-  static constexpr int IR = (TR - 1) * S + K, IC = 15 * S + K;  // halo of the x tile
+  static constexpr int IR = (TR - 1) * S + KH, IC = 15 * S + K;  // halo of the x tile (KH of the K tap rows per workgroup)
   static constexpr int X_U16 = IR * IC * PSX, G_U16 = TR * 16 * PSG;
   static constexpr int LDS_BYTES = (X_U16 + G_U16) * 2 + 1024 * 4;
   static constexpr int NIX = IR * IC * CVX, NLX = (NIX + 255) / 256;
   static constexpr int NLG = TR * 16 * CVG / 256;
   static constexpr int KSN = TR / 2;                                                          // k-steps per tile
-  static constexpr int MB = K * K * CIN / 16, NB = COUT / 16, T = MB * NB, TW = (T + 3) / 4;  // tiles, tiles per wave
+  static constexpr int MB = KH * K * CIN / 16, NB = COUT / 16, T = MB * NB, TW = (T + 3) / 4;  // tiles, tiles per wave
   static_assert(TR % 2 == 0 && (TR * 16 * CVG) % 256 == 0, "tile geometry");
 };
 
@@ -1563,9 +1563,10 @@ __device__ __forceinline__ s16x8 tr_read8(const unsigned short* p0, const unsign
   return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int CIN, int COUT, int INACT = 0, bool GEN = false, int K = 3, int S = 1, int TR = 8>
+template <int CIN, int COUT, int INACT = 0, bool GEN = false, int K = 3, int S = 1, int TR = 8, int KH = K>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
-  using C = WxCfg<CIN, COUT, K, S, TR>;
+  using C = WxCfg<CIN, COUT, K, S, TR, KH>;
+  const int ky0 = KH < K ? (int)blockIdx.z * KH : 0;  // first tap row of this workgroup (7x7: two groups of 4 rows)
   constexpr int WX_IC = C::IC;
   static_assert(GEN || (K == 3 && S == 1 && TR == 8), "the FuseNet form");
   static_assert(!GEN || (CIN == 32 && COUT == 32 && INACT == 0), "slice-pair form: 32 x 32 channel blocks");
@@ -1613,7 +1614,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   const unsigned x_bytes = (unsigned)a.hin * a.win * (ldx * 4u), g_bytes = (unsigned)a.hout * a.wout * (ldg * 4u);
   auto prefetch = [&](int tile) __attribute__((always_inline)) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-    const int iy0 = ty * (TR * S) - a.pad, ix0 = tx * (16 * S) - a.pad;
+    const int iy0 = ty * (TR * S) - a.pad + ky0, ix0 = tx * (16 * S) - a.pad;
     const float* xb = a.x + (long)n * a.hin * a.win * ldx;
     const int xoff0 = (iy0 * a.win + ix0) * (ldx * 4);
 #pragma unroll
@@ -1741,7 +1742,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
       }
     }
     // partial slab of this workgroup: [m = mb*16 + row][co]
-    float* out = a.part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (C::MB * 16 * COUT);
+    float* out = a.part + (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (C::MB * 16 * COUT);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       const int t = T0 + j, mb = t / NB, nb = t % NB;
@@ -1806,17 +1807,19 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
 // ---- wide layers as 32 x 32 channel-slice pairs (DispNetS, called from dis_convg_wgrad) ----
 // gw[g][x][tap] = sum over the pair's worker slabs; slab element [tap * 32 + xc][gc] (WxCfg<32, 32, K>: m = 16 mb + row,
 // mb = 2 tap + half).  Fixed summation order: deterministic.
+// Tap-row groups (k = 7): slabs are [group][pair][worker][kh * k * 1024]; group z holds tap rows z * kh ...
 __global__ __launch_bounds__(256) void wgrad_pairs_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
                                                                   int workers, int npx, int npairs, int cxw, int cgw,
-                                                                  int kk) {
-  const int psz = kk * 1024;
-  const long total = (long)npairs * psz;
+                                                                  int k, int kh) {
+  const int psz = kh * k * 1024, kk = k * k, ngrp = (k + kh - 1) / kh;
+  const long total = (long)ngrp * npairs * psz;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i % psz), pair = (int)(i / psz);
-    const int gc = e & 31, xc = (e >> 5) & 31, tap = e >> 10;
+    const int e = (int)(i % psz), pair = (int)((i / psz) % npairs), grp = (int)(i / ((long)psz * npairs));
+    const int gc = e & 31, xc = (e >> 5) & 31, tl = e >> 10;
+    const int ky = grp * kh + tl / k, tap = ky * k + tl % k;
     const int x = 32 * (pair % npx) + xc, g = 32 * (pair / npx) + gc;
-    if (x >= cxw || g >= cgw) continue;
-    const float* p = part + (long)pair * workers * psz + e;
+    if (x >= cxw || g >= cgw || ky >= k) continue;
+    const float* p = part + ((long)grp * npairs + pair) * workers * psz + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0;
     for (; k + 3 < workers; k += 4) {
@@ -1832,7 +1835,7 @@ __global__ __launch_bounds__(256) void wgrad_pairs_reduce_kernel(const float* __
 
 // tile rows of the (k, stride) instances: stride 2 halves the tile so that two workgroups still share a CU's LDS
 static int wgrad_pairs_tr(int k, int stride) {
-  if (stride == 1 && (k == 3 || k == 5)) return 8;
+  if (stride == 1 && (k == 3 || k == 5 || k == 7)) return 8;
   if (stride == 2 && (k == 3 || k == 5)) return 4;
   return 0;
 }
@@ -1840,7 +1843,7 @@ static void wgrad_pairs_plan(int n, int hG, int wG, int cX, int cG, int tr, int*
   *npx = (cX + 31) / 32;
   *ngb = (cG + 31) / 32;
   const long ntiles = (long)n * ((hG + tr - 1) / tr) * ((wG + 15) / 16);
-  long per = (2L * 256 + (long)*npx * *ngb - 1) / ((long)*npx * *ngb);  // ~2 workgroups per CU in all
+  long per = (2L * num_cus() + (long)*npx * *ngb - 1) / ((long)*npx * *ngb);  // ~2 workgroups per CU in all
   if (per > ntiles) per = ntiles;
   if (per < 1) per = 1;
   *wpp = (int)per;
@@ -1854,23 +1857,24 @@ long dis_wgrad_pairs_workspace(int n, int hX, int wX, int hG, int wG, int cX, in
   if ((long)hX * wX * ldX * 4 >= 0x7fff0000L || (long)hG * wG * ldG * 4 >= 0x7fff0000L) return -1;
   int npx, ngb, wpp;
   wgrad_pairs_plan(n, hG, wG, cX, cG, tr, &npx, &ngb, &wpp);
-  return (long)npx * ngb * wpp * k * k * 1024;
+  return (long)npx * ngb * wpp * (k == 7 ? 2 * 4 * 7 : k * k) * 1024;  // (7x7: two groups of 4 tap rows)
 }
-template <int K, int S, int TR>
+template <int K, int S, int TR, int KH = K>
 static int wgrad_pairs_launch(WgArgs a, float* grad_w, int cX_w, int cG_w, int ngb, int wpp, hipStream_t s) {
-  using XC = WxCfg<32, 32, K, S, TR>;
+  using XC = WxCfg<32, 32, K, S, TR, KH>;
   static_assert(XC::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
-  auto kern = conv_wgrad_bf16x3_kernel<32, 32, 0, true, K, S, TR>;
+  constexpr int NGRP = (K + KH - 1) / KH;
+  auto kern = conv_wgrad_bf16x3_kernel<32, 32, 0, true, K, S, TR, KH>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XC::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)wpp, (unsigned)(a.npx * ngb)), dim3(256), XC::LDS_BYTES, s, a);
-  const long total = (long)a.npx * ngb * K * K * 1024;
+  hipLaunchKernelGGL(kern, dim3((unsigned)wpp, (unsigned)(a.npx * ngb), NGRP), dim3(256), XC::LDS_BYTES, s, a);
+  const long total = (long)NGRP * a.npx * ngb * KH * K * 1024;
   hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)a.part,
-                     grad_w, wpp, a.npx, a.npx * ngb, cX_w, cG_w, K * K);
+                     grad_w, wpp, a.npx, a.npx * ngb, cX_w, cG_w, K, KH);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
@@ -1889,6 +1893,7 @@ int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int hX, int wX, int c
   if (k == 5 && stride == 1) return wgrad_pairs_launch<5, 1, 8>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
   if (k == 3 && stride == 2) return wgrad_pairs_launch<3, 2, 4>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
   if (k == 5 && stride == 2) return wgrad_pairs_launch<5, 2, 4>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
+  if (k == 7 && stride == 1) return wgrad_pairs_launch<7, 1, 8, 4>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
   return DIS_ERR_UNSUPPORTED;
 }
 
@@ -1910,7 +1915,6 @@ static int dispatch_wgrad(const WgArgs& a, float* gw, float* gb, int cin_real, i
   WG_CASE(128, 32, 1, 1)
   WG_CASE(32, 32, 4, 2)
   WG_CASE(4, 32, 7, 2)   // DispNetS conv1 (2 -> 32, k7 s2): all 49 taps in one pass over the pixels
-  WG_CASE(32, 32, 7, 1)  // DispNetS conv1b
   WG_CASE(20, 16, 3, 1)  // DispNetS iconv1 (17 -> 16 at full resolution)
   return DIS_ERR_UNSUPPORTED;
 }
@@ -1927,7 +1931,6 @@ extern "C" long dis_conv2d_wgrad_workspace(int cin, int cout, int k, int stride)
   WS_CASE(128, 32, 1, 1)
   WS_CASE(32, 32, 4, 2)
   WS_CASE(4, 32, 7, 2)
-  WS_CASE(32, 32, 7, 1)
   WS_CASE(20, 16, 3, 1)
   return -1;
 }
