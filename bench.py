@@ -245,10 +245,10 @@ def main():
             sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_convg_run']
             if ops.BF16X3:  # layers with >= 32 input channels run convg3_fwd_kernel (bf16x3): the dominant kernel
                 def sliced(ia):  # ... except the 3x3 stride-1 layers csrc/conv2d.hip:dis_bx_slices_ok() sends to the
-                    # halo-resident kernel as 32-channel slice launches (iconv1/2/3 forward and input gradient)
+                    # halo-resident kernel as 32-channel slice launches (iconv1/2/3, conv1b: forward and input gradient)
                     mode, n, hin, win, cin, cout, k, stride = ia[0], ia[5], ia[6], ia[7], ia[8], ia[12], ia[14], ia[15]
-                    pairs = ((cin + 31) // 32) * ((cout + 31) // 32)
-                    return mode in (0, 1) and k == 3 and stride == 1 and pairs <= 10 and n * hin * win >= 400000
+                    pairs = ((cin + 31) // 32) * ((cout + 31) // 32) * (7 if k == 7 else 1)
+                    return mode in (0, 1) and k in (3, 7) and stride == 1 and pairs <= 10 and n * hin * win >= 400000
                 sel = [(ia, ms) for ia, ms in sel if ia[8] >= 32 and not sliced(ia)]
 
             def gflops(ia):

@@ -47,6 +47,7 @@ struct ConvArgs {
   // stored), x_sub / y_sub = floats between the tensor's start and the slice's (for the buffer range), nbias = bias
   // entries that exist
   int ldx, ldy, cx, cy, x_sub, y_sub, nbias;
+  int wtap0, wtap_step;  // tap-row instances (1 x 7 window of a 7x7 weight): see the weight prologue
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -515,36 +516,31 @@ extern "C" int dis_conv2d_dgrad_strided(const float* gy, const float* w_oihw, fl
 //   workgroup = 8 waves = 16x16 output pixels, wave = 2 rows x all 32 couts; weights (3 planes) resident in LDS,
 //   the halo tile is split into its 3 bf16 planes when it is written to LDS.
 // ------------------------------------------------------------------------------------------------
-#define BX_PS 104  // LDS pixel stride in 16-bit units: 3 planes x 32 channels + 8 pad (208 B: conflict-free b128 rows)
-#define BX_TR 16
+#define BX_TR 16  // output tile (pixels); LDS pixel stride: BxCfg::PS
 #define BX_TC 16
-#define BX_IR 18
-#define BX_IC 18
-#define BX_W_U16 (9 * 3 * 4 * 32 * 8)
-#define BX_X_U16 (BX_IR * BX_IC * BX_PS)
-#define BX_LDS_BYTES (BX_W_U16 * 2 + BX_X_U16 * 2 + 64)
-#define BX_NITEMS (BX_IR * BX_IC * 8)
-#define BX_NLOAD ((BX_NITEMS + 511) / 512)
 
 // Compile-time geometry of conv_bf16x3_kernel<CIN, COUT, ...> (CIN, COUT in {16, 32}; 3x3, stride 1).
 //   K of one MFMA is 32: with 32 input channels a k-step is one tap, with 16 it is a PAIR of taps (lane groups 0,1 take
 //   the first tap's channels 0-7 / 8-15, groups 2,3 the second tap's; the 10th tap has zero weights).
-template <int CIN, int COUT>
+template <int CIN, int COUT, int KHT = 3, int KWT = 3>
 struct BxCfg {
+  // KHT x KWT = tap window of ONE launch: 3 x 3, or (slice launches of a 7x7 layer, one per tap row) 1 x 7
+  static_assert((KHT == 3 && KWT == 3) || (KHT == 1 && KWT == 7 && CIN == 32), "tap windows of conv_bf16x3_kernel");
+  static constexpr int IR = BX_TR + KHT - 1, IC = BX_TC + KWT - 1;  // halo tile
   static constexpr int CV = CIN / 4;                 // float4s per pixel
   static constexpr int PS = 3 * CIN + 8;             // LDS pixel stride (16-bit units): 3 planes + 16 B pad (104 / 56:
                                                      // both make 16 consecutive pixels hit 16 distinct 16-B bank groups)
   static constexpr int NT = COUT / 16;               // cout blocks of a wave's tile
-  static constexpr int KS = CIN == 32 ? 9 : 5;       // k-steps
+  static constexpr int KS = CIN == 32 ? KHT * KWT : 5;  // k-steps
   static constexpr int W_U16 = KS * 3 * 4 * COUT * 8;  // packed[kstep][plane][lg][co][8]
-  static constexpr int X_U16 = BX_IR * BX_IC * PS;
+  static constexpr int X_U16 = IR * IC * PS;
   static constexpr int LDS_BYTES = W_U16 * 2 + X_U16 * 2 + 64;
-  static constexpr int NITEMS = BX_IR * BX_IC * CV;
+  static constexpr int NITEMS = IR * IC * CV;
   static constexpr int NLOAD = (NITEMS + 511) / 512;  // 6 / 3
   static constexpr int NPIECE = 2 * NT;               // epilogue float4 stores per lane and tile
   // k-step of epilogue piece i and of halo load i (spread so that no k-step carries more than ~40 VALU)
-  static constexpr int piece_ks(int i) { return KS == 9 ? 2 * i + 1 : i + 1; }
-  static constexpr int load_ks(int i) { return KS == 9 ? 2 * (i / 2) : i; }
+  static constexpr int piece_ks(int i) { return KS == 9 ? 2 * i + 1 : (KS == 7 ? (i < 2 ? 2 * i + 1 : 2 * i) : i + 1); }
+  static constexpr int load_ks(int i) { return KS >= 7 ? 2 * (i / 2) : i; }
 };
 
 // packed[kstep][plane][lg][co][j] = plane of W(tap, ci, co) with (tap, ci) = (kstep, 8 lg + j) for 32 input channels and
@@ -608,10 +604,12 @@ extern "C" int dis_debug_bx_stamps(unsigned long long* host) {
 // consecutive output channels of one pixel and stores a float4.
 // INACT != 0 (input-gradient launches of a conv that had an activation): x is the gradient wrt the activation's OUTPUT
 // and a.xact that output; the halo is staged as x * act'(xact), which replaces a separate pass over the tensor.
-template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool GEN = false>
+template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool GEN = false, int KHT = 3, int KWT = 3>
 __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
-  using C = BxCfg<CIN, COUT>;
+  using C = BxCfg<CIN, COUT, KHT, KWT>;
+  constexpr int BX_IC = C::IC;
   static_assert(!GEN || (!STATS && INACT == 0), "slice form: plain convolution / input gradient");
+  static_assert(GEN || (KHT == 3 && KWT == 3), "tap rows are a slice-launch form");
   const int ldx = GEN ? a.ldx : CIN, ldy = GEN ? a.ldy : COUT;  // floats per pixel
   constexpr int PS = C::PS, NT = C::NT, KS = C::KS, NLOAD = C::NLOAD, NPIECE = C::NPIECE, CV = C::CV;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
@@ -698,7 +696,30 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) pf_issue(it);  // in flight while the weights are copied
   }
-  if (a.wmode < 0) {
+  if (KWT == 7) {
+    // tap row of a 7x7 weight (w_o x w_i x 49 floats, rows w_rs apart): tap kx of this launch is element
+    // wtap0 + kx * wtap_step of a (row, column) pair's 49 (forward: row ky left to right; input gradient: the mirrored
+    // row right to left).  7 k floats per workgroup, L2-resident: gathered directly, no LDS staging.
+    for (int u = threadIdx.x; u < KS * 4 * COUT; u += 512) {
+      const int co = u % COUT, g = (u / COUT) & 3, ks = u / (4 * COUT);
+      unsigned pl[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = 8 * g + 2 * j + e;
+          const int t = a.wtap0 + ks * a.wtap_step;
+          if (a.wmode == 0) v[e] = (co < a.w_o && c < a.w_i) ? a.w[(long)co * a.w_rs + c * 49 + t] : 0.f;
+          else v[e] = (c < a.w_o && co < a.w_i) ? a.w[(long)c * a.w_rs + co * 49 + t] : 0.f;
+        }
+        split3_pair(v[0], v[1], pl[0][j], pl[1][j], pl[2][j]);
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *(uint4*)(wl + (((ks * 3 + p) * 4 + g) * COUT + co) * 8) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+    }
+  } else if (a.wmode < 0) {
     for (int i = threadIdx.x; i < C::W_U16 / 8; i += 512) ((uint4*)wl)[i] = ((const uint4*)a.w)[i];
   } else {
     // OIHW fp32 weights: split here instead of in a launch of their own.  Coalesced copy into the (still unused) halo
@@ -878,7 +899,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
         for (int p = 0; p < 3; ++p) R[kx & 1][j][p] = *(const s16x8*)(xl + xa_lane + (j * BX_IC + kx) * PS + p * CIN);
       };
       auto load_w = [&](int ks, s16x8 (&B)[3][NT]) {
-        const int wt = (ks % 3) * 3 + ks / 3;  // the weights are packed tap-major (ky * 3 + kx)
+        const int wt = (ks % KHT) * KWT + ks / KHT;  // the weights are packed tap-major (ky * KWT + kx)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -889,7 +910,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
       load_w(0, fb[0]);
       auto step = [&](auto ksc) {
         constexpr int ks = decltype(ksc)::value;
-        constexpr int kx = ks / 3, ky = ks % 3, nkx = (ks + 1) / 3, nky = (ks + 1) % 3;
+        constexpr int kx = ks / KHT, ky = ks % KHT, nkx = (ks + 1) / KHT, nky = (ks + 1) % KHT;
         if (ks + 1 < KS) {
           if (nky == 0) {
             load_row(nkx, 0);
@@ -914,7 +935,11 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
       step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-      step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+      step(std::integral_constant<int, 6>{});
+      if constexpr (KS == 9) {
+        step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{});
+      }
     } else {
       s16x8 fa[2][3][2], fb[2][3][NT];  // [buffer][plane][mt|nt]
       auto load_frag = [&](int ks, s16x8 (&A)[3][2], s16x8 (&B)[3][NT]) {
@@ -1135,20 +1160,23 @@ extern "C" int dis_conv2d_dgrad_bf16x3_act(const float* gy, const float* y, int 
 long dis_bx_slices_ok(int n, int h, int wd, int cin, int cout, int ldx, int ldy, int xoff, int yoff, int k, int stride,
                       int pad, int act) {
   static const bool use3 = !(getenv("DIS_CONV_BF16X3") && getenv("DIS_CONV_BF16X3")[0] == '0');
-  if (!use3 || k != 3 || stride != 1 || pad != 1 || cin < 16 || cout < 16) return 0;
+  if (!use3 || !((k == 3 && pad == 1) || (k == 7 && pad == 3)) || stride != 1 || cin < 16 || cout < 16) return 0;
   if ((cin & 3) || (cout & 3) || (ldx & 3) || (ldy & 3) || (xoff & 3) || (yoff & 3)) return 0;
   if (act != DIS_ACT_NONE && act != DIS_ACT_RELU) return 0;
   if ((long)h * wd * ldx * 4 >= 0x7fff0000L || (long)h * wd * ldy * 4 >= 0x7fff0000L) return 0;
   // one launch per slice pair: worth it for the few-channel layers at high resolution only (the deep layers have
   // hundreds of pairs over a handful of tiles: the streaming kernel stays their path)
   const long pairs = (long)((cin + 31) / 32) * ((cout + 31) / 32);
-  if (pairs > 10 || (long)n * h * wd < 400000L) return 0;
+  if (pairs * (k == 7 ? 7 : 1) > 10 || (long)n * h * wd < 400000L) return 0;  // (7x7: one launch per tap row)
   return 1;
 }
 int dis_bx_slices_run(int dgrad, const float* x, int ldx, int xoff, int cin, int cin_w, const float* w,
-                      const float* bias, float* y, int ldy, int yoff, int cout, int cout_w, int n, int h, int wd, int act,
-                      hipStream_t stream) {
+                      const float* bias, float* y, int ldy, int yoff, int cout, int cout_w, int n, int h, int wd, int k,
+                      int act, hipStream_t stream) {
   using C = BxCfg<32, 32>;
+  using C7 = BxCfg<32, 32, 1, 7>;
+  static_assert(C7::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+  const int kk = k * k, nrow = k == 7 ? 7 : 1;  // launches per slice pair
   const int ncb = (cin + 31) / 32, ngb = (cout + 31) / 32;
   // input slices that have real weights (the rest are zero-padded lanes and contribute nothing)
   const int ncb_w = (cin_w + 31) / 32;
@@ -1158,16 +1186,20 @@ int dis_bx_slices_run(int dgrad, const float* x, int ldx, int xoff, int cin, int
   if (grid > ntiles) grid = ntiles;
   if (grid >= 8) grid -= grid % 8;
   if (grid < 1) grid = 1;
-  static bool attr_set[4] = {};
+  static bool attr_set[8] = {};
   for (int gb = 0; gb < ngb; ++gb)
-    for (int cb = 0; cb < (ncb_w < ncb ? ncb_w : ncb); ++cb) {
-      const bool first = cb == 0, last = cb == (ncb_w < ncb ? ncb_w : ncb) - 1;
+    for (int cb = 0; cb < (ncb_w < ncb ? ncb_w : ncb); ++cb)
+     for (int tr = 0; tr < nrow; ++tr) {
+      const bool first = cb == 0 && tr == 0, last = cb == (ncb_w < ncb ? ncb_w : ncb) - 1 && tr == nrow - 1;
       ConvArgs a;
       a.x = x + xoff + 32 * cb; a.bias = (first && bias) ? bias + 32 * gb : nullptr; a.y = y + yoff + 32 * gb; a.stats = nullptr;
-      a.n = n; a.hin = h; a.win = wd; a.hv = h; a.wv = wd; a.pad_y = 1; a.pad_x = 1;
+      a.n = n; a.hin = h; a.win = wd; a.hv = h; a.wv = wd;
+      a.pad_y = k == 7 ? 3 - tr : 1;  // tap row tr of a 7x7 window reads input rows vy + tr - 3
+      a.pad_x = k == 7 ? 3 : 1;
       a.hf = h; a.wf = wd; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
       a.act = last ? act : DIS_ACT_NONE;
       a.accum = first ? 0 : 1;
+      if (!first) a.bias = nullptr;
       a.xscale = nullptr; a.yscale = nullptr; a.xact = nullptr;
       a.ldx = ldx; a.ldy = ldy;
       a.cx = cin - 32 * cb < 32 ? cin - 32 * cb : 32;
@@ -1178,23 +1210,31 @@ int dis_bx_slices_run(int dgrad, const float* x, int ldx, int xoff, int cin, int
       if (wo_out < 0) wo_out = 0;
       a.nbias = wo_out;
       if (!dgrad) {
-        a.wmode = 0; a.w = w + ((long)32 * gb * cin_w + 32 * cb) * 9; a.w_o = wo_out; a.w_i = wi_in; a.w_rs = cin_w * 9;
+        a.wmode = 0; a.w = w + ((long)32 * gb * cin_w + 32 * cb) * kk; a.w_o = wo_out; a.w_i = wi_in; a.w_rs = cin_w * kk;
+        a.wtap0 = tr * 7; a.wtap_step = 1;
       } else {
-        a.wmode = 1; a.w = w + ((long)32 * cb * cout_w + 32 * gb) * 9; a.w_o = wi_in; a.w_i = wo_out; a.w_rs = cout_w * 9;
+        a.wmode = 1; a.w = w + ((long)32 * cb * cout_w + 32 * gb) * kk; a.w_o = wi_in; a.w_i = wo_out; a.w_rs = cout_w * kk;
+        a.wtap0 = (6 - tr) * 7 + 6; a.wtap_step = -1;  // the mirrored window
       }
       if (wo_out == 0) { a.w = w; a.w_o = 0; a.w_i = 0; }  // zero-padded output lanes only: written as zeros (+0 bias)
       const int variant = (a.act == DIS_ACT_RELU ? 2 : 0) + a.accum;
+      const int lds = k == 7 ? C7::LDS_BYTES : C::LDS_BYTES, slot = variant + (k == 7 ? 4 : 0);
       auto launch = [&](auto kern) -> hipError_t {
-        if (!attr_set[variant]) {
-          hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (!attr_set[slot]) {
+          hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
           if (e != hipSuccess) return e;
-          attr_set[variant] = true;
+          attr_set[slot] = true;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, a);
         return hipSuccess;
       };
       hipError_t le;
-      if (variant == 0) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_NONE, false, false, 0, true>);
+      if (k == 7) {
+        if (variant == 0) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_NONE, false, false, 0, true, 1, 7>);
+        else if (variant == 1) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_NONE, true, false, 0, true, 1, 7>);
+        else if (variant == 2) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_RELU, false, false, 0, true, 1, 7>);
+        else le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_RELU, true, false, 0, true, 1, 7>);
+      } else if (variant == 0) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_NONE, false, false, 0, true>);
       else if (variant == 1) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_NONE, true, false, 0, true>);
       else if (variant == 2) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_RELU, false, false, 0, true>);
       else le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_RELU, true, false, 0, true>);

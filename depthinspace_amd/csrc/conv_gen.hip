@@ -479,8 +479,8 @@ static int floordiv2(int v) { return (v >= 0) ? v / 2 : -((-v + 1) / 2); }
 long dis_bx_slices_ok(int n, int h, int wd, int cin, int cout, int ldx, int ldy, int xoff, int yoff, int k, int stride,
                       int pad, int act);
 int dis_bx_slices_run(int dgrad, const float* x, int ldx, int xoff, int cin, int cin_w, const float* w,
-                      const float* bias, float* y, int ldy, int yoff, int cout, int cout_w, int n, int h, int wd, int act,
-                      hipStream_t stream);
+                      const float* bias, float* y, int ldy, int yoff, int cout, int cout_w, int n, int h, int wd, int k,
+                      int act, hipStream_t stream);
 
 extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const float* w, const float* bias,
                              float* y, int ldy, int yoff, float* wpack, int n, int hin, int win, int cin,
@@ -497,7 +497,7 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
   if ((mode == DIS_CONVG_CONV || mode == DIS_CONVG_CONV_DGRAD) && hin == hout && win == wout &&
       dis_bx_slices_ok(n, hin, win, cin, cout, ldx, ldy, xoff, yoff, k, stride, pad, act))
     return dis_bx_slices_run(mode == DIS_CONVG_CONV_DGRAD, x, ldx, xoff, cin, cin_w, w, bias, y, ldy, yoff, cout, cout_w,
-                             n, hin, win, act, s);
+                             n, hin, win, k, act, s);
   GenArgs a;
   a.x = x; a.w = nullptr; a.bias = bias; a.y = y;
   a.n = n; a.hin = hin; a.win = win; a.ldx = ldx; a.xoff = xoff; a.cin = cin;

@@ -346,8 +346,8 @@ int dis_conv3d_knn_bwd(const float* geom, const float* wf, const float* dense1_w
  *                         w is the transposed conv's weight [cout_w][cin_w][k][k]
  * wpack: workspace of dis_convg_pack_workspace(cin,cout,k) floats (x4 for the two phase-decomposed cases:
  * CONV_DGRAD and TCONV with stride 2).
- * Routing (same results, same contract): 3x3 stride-1 CONV / CONV_DGRAD calls with <= 10 32x32 channel-slice pairs and
- * >= 400k pixels run as slice launches of the halo-resident bf16x3 kernel; everything else streams. */
+ * Routing (same results, same contract): 3x3 (and 7x7, one launch per tap row) stride-1 CONV / CONV_DGRAD calls with
+ * <= 10 32x32 channel-slice launches and >= 400k pixels run on the halo-resident bf16x3 kernel; everything else streams. */
 #define DIS_CONVG_CONV 0
 #define DIS_CONVG_CONV_DGRAD 1
 #define DIS_CONVG_TCONV 2
@@ -362,7 +362,7 @@ int dis_convg_run(int mode, const float* x, int ldx, int xoff, const float* w, c
  *   conv:            X = layer input,              G = gradient wrt the pre-activation output  -> (cout,cin,k,k)
  *   transposed conv: X = gradient wrt its output,  G = layer input                             -> (cin,cout,k,k)
  * workspace: dis_convg_wgrad_workspace(n,hG,wG,cX,cG,k) floats.
- * Routing: k in {3,5}, stride in {1,2}, cX >= 16, cG >= 32 run as 32x32 channel-slice pairs of the one-pass bf16x3
+ * Routing: k in {3,5} with stride in {1,2} and k = 7 with stride 1, cX >= 16, cG >= 32 run as 32x32 channel-slice pairs of the one-pass bf16x3
  * kernel (x and G staged once for all taps); other shapes on the fp32 split-K kernel (one pass per tap). */
 long dis_convg_wgrad_workspace(int n, int hG, int wG, int cX, int cG, int k);
 int dis_convg_wgrad(const float* X, int ldX, int xoff, int hX, int wX, int cX, int cX_w, const float* G, int ldG,
