@@ -20,6 +20,68 @@ extern "C" int dis_act_bwd(const float* gy, const float* y, float* gpre, int act
   return DIS_OK;
 }
 
+// The same on channel ranges of wider nhwc buffers (DispNetS: conv outputs live inside the concatenation buffers of the
+// decoder): gy / y pixels are ldg / ldy floats apart, gpre is dense (npix, c).  act == DIS_ACT_NONE copies.
+__global__ void act_bwd_ld_kernel(const float* __restrict__ gy, int ldg, const float* __restrict__ y, int ldy,
+                                  float4* __restrict__ gp, int act, long npix, int c4) {
+  const long total = npix * c4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long px = i / c4;
+    const int q = (int)(i - px * c4) * 4;
+    const float4 g = *(const float4*)(gy + px * ldg + q);
+    if (act == DIS_ACT_NONE) {
+      gp[i] = g;
+    } else {
+      const float4 v = *(const float4*)(y + px * ldy + q);
+      gp[i] = make_float4(g.x * act_grad_from_out(v.x, act), g.y * act_grad_from_out(v.y, act),
+                          g.z * act_grad_from_out(v.z, act), g.w * act_grad_from_out(v.w, act));
+    }
+  }
+}
+extern "C" int dis_act_bwd_ld(const float* gy, int ldg, const float* y, int ldy, float* gpre, int act, long npix, int c,
+                              void* stream) {
+  if (!gy || !gpre || (act != DIS_ACT_NONE && !y)) return DIS_ERR_NULL;
+  if (npix <= 0 || c <= 0 || ldg < c || (act != DIS_ACT_NONE && ldy < c)) return DIS_ERR_BAD_SHAPE;
+  if ((c & 3) || (ldg & 3) || (ldy & 3) || ((uintptr_t)gy & 15) || ((uintptr_t)y & 15)) return DIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(act_bwd_ld_kernel, dim3(dis_ew_grid(npix * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream, gy,
+                     ldg, y ? y : gy, ldy, (float4*)gpre, act, npix, c / 4);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// dst[pixel * ldd + j] = src[pixel * lds + j] for j < c, 0 for c <= j < c + czero: writes a tensor into a channel range
+// of a wider nhwc buffer (the up-sampled disparity channel of the DispNetS concatenations and the zero lanes that pad
+// them to a multiple of 4 channels) without an ATen in-place op on the buffer.
+__global__ void copy_channels_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, long npix,
+                                     int c, int czero) {
+  const int ct = c + czero;
+  const long total = npix * ct;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long px = i / ct;
+    const int j = (int)(i - px * ct);
+    dst[px * ldd + j] = j < c ? src[px * lds + j] : 0.f;
+  }
+}
+// (1 channel + 3 zero lanes, 16-byte aligned: one float4 store per pixel)
+__global__ void copy_channel_pad4_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+                                         long npix) {
+  for (long px = blockIdx.x * (long)blockDim.x + threadIdx.x; px < npix; px += (long)gridDim.x * blockDim.x)
+    *(float4*)(dst + px * ldd) = make_float4(src[px * lds], 0.f, 0.f, 0.f);
+}
+extern "C" int dis_copy_channels(const float* src, int lds, float* dst, int ldd, long npix, int c, int czero,
+                                 void* stream) {
+  if (!src || !dst) return DIS_ERR_NULL;
+  if (npix <= 0 || c <= 0 || czero < 0 || lds < c || ldd < c + czero) return DIS_ERR_BAD_SHAPE;
+  if (c == 1 && czero == 3 && !(ldd & 3) && !((uintptr_t)dst & 15))
+    hipLaunchKernelGGL(copy_channel_pad4_kernel, dim3(dis_ew_grid(npix, 256)), dim3(256), 0, (hipStream_t)stream, src, lds,
+                       dst, ldd, npix);
+  else
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(dis_ew_grid(npix * (c + czero), 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, lds, dst, ldd, npix, c, czero);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 __global__ void add_act_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ y,
                                int act, long count4) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count4; i += (long)gridDim.x * blockDim.x) {

@@ -64,6 +64,8 @@ SIGS = {
     'dis_disp_head_bwd': 'pppppppp' + 'iiiifp',
     'dis_disp_head_bwd_workspace': 'iiii',
     'dis_act_bwd': 'pppilp',
+    'dis_act_bwd_ld': 'pipipilip',
+    'dis_copy_channels': 'pipiliip',
     'dis_gn_stats': 'ppilp',
     'dis_gn_apply': 'ppppppiliifp',
     'dis_gn_bwd_workspace': 'ii',

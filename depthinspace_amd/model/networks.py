@@ -124,19 +124,32 @@ class DispNetS(TimedModule):
         self.predict_disp1 = facs[0](up[6], imsizes[0])
 
     @staticmethod
-    def _conv(x, p, stride=1, need_dgrad=True):
+    def _conv(x, p, stride=1, need_dgrad=True, out=None):
         k = p.weight.shape[2]
-        return ops.convg(x, p.weight, p.bias, stride, (k - 1) // 2, ops.ACT_RELU, need_dgrad)
+        return ops.convg(x, p.weight, p.bias, stride, (k - 1) // 2, ops.ACT_RELU, need_dgrad, out)
 
     @staticmethod
-    def _down(x, slots, need_dgrad=True):
-        """downsample_conv (:222-228)"""
-        return DispNetS._conv(DispNetS._conv(x, slots[0], 2, need_dgrad), slots[2], 1)
+    def _down(x, slots, need_dgrad=True, skip=None):
+        """downsample_conv (:222-228).  skip = (channels in front of this stage's output in the decoder concatenation
+        that will use it, total channels there): the stage then writes its output straight into that buffer."""
+        a = DispNetS._conv(x, slots[0], 2, need_dgrad)
+        if skip is None:
+            return DispNetS._conv(a, slots[2], 1), None
+        off, total = skip
+        cb = ops.ConcatBuf(a.shape[0], a.shape[1], a.shape[2], total, a.device)
+        slot = cb.slot(off, slots[2].weight.shape[0])
+        if slots[2].weight.shape[2] == 7:
+            # the 7x7 layer runs as seven accumulating tap-row launches: they read-modify-write their output, which is
+            # cheaper on a dense tensor; one copy into the slot afterwards
+            return ops.write_channels(DispNetS._conv(a, slots[2], 1), slot), cb
+        return DispNetS._conv(a, slots[2], 1, out=slot), cb
 
     @staticmethod
-    def _up(x, slots, like):
-        """upconv (:236-240) + crop_like (:242-244)"""
-        return ops.convg_transposed(x, slots[0].weight, slots[0].bias, (like.shape[1], like.shape[2]), 1, ops.ACT_RELU)
+    def _up(x, slots, cb):
+        """upconv (:236-240) + crop_like (:242-244), written into channels [0, cout) of the concatenation buffer cb"""
+        cout = slots[0].weight.shape[1]
+        return ops.convg_transposed(x, slots[0].weight, slots[0].bias, (cb.buf.shape[1], cb.buf.shape[2]), 1, ops.ACT_RELU,
+                                    out=cb.slot(0, cout))
 
     @staticmethod
     def _head(x, m):
@@ -168,23 +181,39 @@ class DispNetS(TimedModule):
         HW = H * W
         flat = x.view(-1)
         x4 = ops.pack4_nhwc([(flat[c * HW:], C * HW) for c in range(C)], N, H, W)
-        e1 = self._down(x4, self.conv1, need_dgrad=False)
-        e2 = self._down(e1, self.conv2)
-        e3 = self._down(e2, self.conv3)
-        e4 = self._down(e3, self.conv4)
-        e5 = self._down(e4, self.conv5)
-        e6 = self._down(e5, self.conv6)
-        e7 = self._down(e6, self.conv7)
-        i7 = self._conv(self._cat((self._up(e7, self.upconv7, e6), e6)), self.iconv7[0])
-        i6 = self._conv(self._cat((self._up(i7, self.upconv6, e5), e5)), self.iconv6[0])
-        i5 = self._conv(self._cat((self._up(i6, self.upconv5, e4), e4)), self.iconv5[0])
-        i4 = self._conv(self._cat((self._up(i5, self.upconv4, e3), e3)), self.iconv4[0])
+        # The decoder's concatenations (:262-288: upconv output, encoder skip, up-sampled disparity) are never copied
+        # together: every encoder stage writes its output straight into the buffer of the concatenation that will use
+        # it (behind the channels of that level's upconv), the upconv and the disparity channel follow in place.
+        up = {lvl: getattr(self, f'upconv{lvl}')[0].weight.shape[1] for lvl in range(1, 8)}
+        enc = {i: getattr(self, f'conv{i}')[2].weight.shape[0] for i in range(1, 8)}
+        e, cb = {0: x4}, {}
+        for i in range(1, 7):  # stage i is the skip of decoder level i + 1 (levels 2, 3 also carry a disparity channel)
+            lvl = i + 1
+            total = up[lvl] + enc[i] + (1 if lvl in (2, 3) else 0)
+            e[i], cb[lvl] = self._down(e[i - 1], getattr(self, f'conv{i}'), need_dgrad=(i > 1), skip=(up[lvl], total))
+        e[7], _ = self._down(e[6], self.conv7)
+        cb[1] = ops.ConcatBuf(N, H, W, up[1] + 1, x4.device)
+
+        def level(lvl, below, disp=None):
+            parts = [(self._up(below, getattr(self, f'upconv{lvl}'), cb[lvl]), 0)]
+            if lvl > 1:
+                parts.append((e[lvl - 1], up[lvl]))
+            if disp is not None:
+                off = up[lvl] + (enc[lvl - 1] if lvl > 1 else 0)
+                # (the disparity channel is the last part: the buffer's zero padding lanes are written with it)
+                parts.append((ops.write_channels(self._up2_like(disp, cb[lvl].buf), cb[lvl].slot(off, 1), True), off))
+            return self._conv(cb[lvl].joined(parts), getattr(self, f'iconv{lvl}')[0])
+
+        i7 = level(7, e[7])
+        i6 = level(6, i7)
+        i5 = level(5, i6)
+        i4 = level(4, i5)
         d4 = self._head(i4, self.predict_disp4)
-        i3 = self._conv(self._cat((self._up(i4, self.upconv3, e2), e2, self._up2_like(d4, e2))), self.iconv3[0])
+        i3 = level(3, i4, d4)
         d3 = self._head(i3, self.predict_disp3)
-        i2 = self._conv(self._cat((self._up(i3, self.upconv2, e1), e1, self._up2_like(d3, e1))), self.iconv2[0])
+        i2 = level(2, i3, d3)
         d2 = self._head(i2, self.predict_disp2)
-        i1 = self._conv(self._cat((self._up(i2, self.upconv1, x4), self._up2_like(d2, x4))), self.iconv1[0])
+        i1 = level(1, i2, d2)
         d1 = self._head(i1, self.predict_disp1)
         rs = lambda d: ops.resize_planar(d, (H, W), False)
         return (d1, rs(d2), rs(d3), rs(d4))

@@ -781,13 +781,92 @@ def disp_head(x, weight, bias, alpha, offset=3.0):
 CONVG_CONV, CONVG_CONV_DGRAD, CONVG_TCONV, CONVG_TCONV_DGRAD = 0, 1, 2, 3
 
 
+def _ld(t):
+    """pixel stride (floats) of an nhwc tensor that is dense or a channel range of a wider dense nhwc buffer
+    (ConcatBuf.slot), None for any other layout"""
+    if t.dim() == 4 and t.is_contiguous():
+        return t.shape[3]
+    if t.dim() != 4 or t.stride(3) != 1:
+        return None
+    ld = t.stride(2)
+    n, h, w, c = t.shape
+    if (ld < c or ld % 4 or t.stride(1) != w * ld or t.stride(0) != h * w * ld or t.data_ptr() % 16):
+        return None
+    return ld
+
+
+def _nhwc(t):
+    """t as the kernels can address it: itself if _ld(t) applies, else a dense copy"""
+    return t if _ld(t) is not None else t.contiguous()
+
+
+class ConcatBuf(object):
+    """Channel concatenation without the copy (the reference concatenates decoder inputs with torch.cat,
+    model/networks.py:262-288): ONE nhwc buffer per concatenation, zero-padded to a multiple of 4 channels; every
+    producer writes its channel range in place (convg(..., out=buf.slot(off, c)), write_channels) and hands the range
+    on as an ordinary tensor (a view); joined(parts) returns the whole buffer as the consumer's input and routes the
+    gradient ranges back to the parts.  All writes go through the C ABI, never through ATen in-place ops: the views
+    saved for backward keep their version."""
+
+    def __init__(self, n, h, w, c, device):
+        self.c = c
+        ld = (c + 3) // 4 * 4
+        self.buf = torch.empty((n, h, w, ld), dtype=torch.float32, device=device)
+        self.pad = ld - c  # zero lanes behind the last channel: written together with it (write_channels)
+
+    def slot(self, off, c):
+        assert off % 4 == 0 and off + c <= self.c
+        return (self.buf, off, c)
+
+    def joined(self, parts):
+        """parts: [(tensor written into the buffer, channel offset)]"""
+        return _CatFrom.apply(self, tuple(o for _, o in parts), *[p for p, _ in parts])
+
+
+class _CatFrom(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cbuf, offs, *parts):
+        ctx.offs = offs
+        ctx.cs = tuple(p.shape[3] for p in parts)
+        return cbuf.buf.view(cbuf.buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None) + tuple(g[..., o:o + c] for o, c in zip(ctx.offs, ctx.cs))
+
+
+class _WriteChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, slot, zero_tail):
+        buf, off, c = slot
+        n, h, w, cs = src.shape
+        assert cs == c and tuple(buf.shape[:3]) == (n, h, w)
+        src = _nhwc(src)
+        if not src.is_cuda or src.dtype != torch.float32:
+            raise RuntimeError('depthinspace_amd ops need float32 CUDA(HIP) tensors: the HIP path is the only path')
+        dst = buf[..., off:off + c]
+        lib.call('dis_copy_channels', src, _ld(src), dst, buf.shape[3], n * h * w, c,
+                 buf.shape[3] - off - c if zero_tail else 0)
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None
+
+
+def write_channels(src, slot, zero_tail=False):
+    """copy the nhwc tensor src into a ConcatBuf slot; returns the slot's view (differentiable).  zero_tail: also zero the
+    buffer's padding lanes behind the slot (the slot must be the concatenation's last part)."""
+    return _WriteChannels.apply(src, slot, zero_tail)
+
+
 def _convg_run(mode, x, w, bias, y, n, hin, win, cin, cin_w, hout, wout, cout, cout_w, k, stride, pad, act):
     per = lib.fn('dis_convg_pack_workspace')(cin, cout, k)
     if per < 0:
         raise lib.DisHipError(f'convg: unsupported shape cin={cin} cout={cout} k={k}')
     phases = 4 if (mode in (CONVG_CONV_DGRAD, CONVG_TCONV) and stride == 2) else 1
     wp = torch.empty(per * phases, dtype=torch.float32, device=x.device)
-    lib.call('dis_convg_run', mode, x, x.shape[-1], 0, w, bias, y, y.shape[-1], 0, wp, n, hin, win, cin, cin_w, hout,
+    lib.call('dis_convg_run', mode, x, _ld(x), 0, w, bias, y, _ld(y), 0, wp, n, hin, win, cin, cin_w, hout,
              wout, cout, cout_w, k, stride, pad, act)
 
 
@@ -796,14 +875,14 @@ def _convg_wgrad(X, hX, wX, cX, cX_w, G, hG, wG, cG, cG_w, gw, n, k, stride, pad
     if wsz < 0:
         raise lib.DisHipError('convg wgrad: unsupported shape')
     ws = torch.empty(wsz, dtype=torch.float32, device=X.device)
-    lib.call('dis_convg_wgrad', X, X.shape[-1], 0, hX, wX, cX, cX_w, G, G.shape[-1], 0, hG, wG, cG, cG_w, gw, ws, n, k,
+    lib.call('dis_convg_wgrad', X, _ld(X), 0, hX, wX, cX, cX_w, G, _ld(G), 0, hG, wG, cG, cG_w, gw, ws, n, k,
              stride, pad)
 
 
 def _colsum(G, c_real):
     """sum over all pixels of the first c_real channels of an nhwc tensor"""
-    ld = G.shape[-1]
-    npix = G.numel() // ld
+    ld = _ld(G)
+    npix = G.shape[0] * G.shape[1] * G.shape[2]
     out = torch.empty(c_real, dtype=torch.float32, device=G.device)
     ws = torch.empty(lib.fn('dis_colsum_workspace')(c_real), dtype=torch.float32, device=G.device)
     lib.call('dis_colsum', G, ld, 0, npix, c_real, out, ws)
@@ -816,9 +895,11 @@ class _ConvG(torch.autograd.Function):
     padding lanes; their gradient is returned as zeros)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, transposed, out_hw, need_dgrad):
-        x, weight = _c(x), _c(weight)
-        _chk(x, weight, bias)
+    def forward(ctx, x, weight, bias, stride, pad, act, transposed, out_hw, need_dgrad, out=None):
+        x, weight = _nhwc(x), _c(weight)  # (x may be a channel range of a ConcatBuf)
+        _chk(weight, bias)
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError('depthinspace_amd ops need float32 CUDA(HIP) tensors: the HIP path is the only path')
         n, hin, win, cin_mem = x.shape
         if transposed:
             cin_w, cout, k, _ = weight.shape
@@ -830,7 +911,13 @@ class _ConvG(torch.autograd.Function):
             hout, wout = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
         if cin_mem % 4 or cin_w > cin_mem or cout % 4:
             raise RuntimeError(f'convg: bad channel counts cin_mem={cin_mem} cin_w={cin_w} cout={cout}')
-        y = torch.empty((n, hout, wout, cout), dtype=torch.float32, device=x.device)
+        if out is None:
+            y = torch.empty((n, hout, wout, cout), dtype=torch.float32, device=x.device)
+        else:  # write into a ConcatBuf slot: (buffer, channel offset, channels)
+            buf, off, c = out
+            if c != cout or tuple(buf.shape[:3]) != (n, hout, wout):
+                raise RuntimeError(f'convg: out slot {tuple(buf.shape)}[{off}:{off + c}] does not fit ({n},{hout},{wout},{cout})')
+            y = buf[..., off:off + c]
         _convg_run(CONVG_TCONV if transposed else CONVG_CONV, x, weight, bias, y, n, hin, win, cin_mem, cin_w, hout,
                    wout, cout, cout, k, stride, pad, act)
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
@@ -842,18 +929,22 @@ class _ConvG(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         stride, pad, act, transposed, has_bias, need_dgrad = ctx.cfg
         n, hin, win, cin_mem = x.shape
-        gy = _c(gy)
+        gy = _nhwc(gy)
         _, hout, wout, cout = gy.shape
         k = weight.shape[2]
         cin_w = weight.shape[0] if transposed else weight.shape[1]
-        if act != ACT_NONE:
-            gpre = torch.empty_like(gy)
-            lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
+        if act != ACT_NONE or not gy.is_contiguous():
+            # (gy / y may be channel ranges of wider buffers: the gradient of a concatenation, an output written into one)
+            gpre = torch.empty(gy.shape, dtype=torch.float32, device=gy.device)
+            if gy.is_contiguous() and (y is None or y.is_contiguous()):
+                lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
+            else:
+                lib.call('dis_act_bwd_ld', gy, _ld(gy), y, _ld(y) if y is not None else 0, gpre, act, n * hout * wout, cout)
         else:
             gpre = gy
         gx = None
         if need_dgrad and ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
+            gx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
             _convg_run(CONVG_TCONV_DGRAD if transposed else CONVG_CONV_DGRAD, gpre, weight, None, gx, n, hout, wout,
                        cout, cout, hin, win, cin_mem, cin_w, k, stride, pad, ACT_NONE)
         gw, gw_ret = _sink(weight)
@@ -863,24 +954,25 @@ class _ConvG(torch.autograd.Function):
             # shapes whose whole (tap, cin) x cout accumulator fits a workgroup's registers go through the one-pass kernels
             # of conv2d.hip (x and gy are read once instead of once per tap; the bias gradient comes out of the same pass)
             wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin_mem, cout, k, stride)
-            if wsz >= 0 and gpre.shape[-1] == cout:
+            if wsz >= 0 and gpre.shape[-1] == cout and x.is_contiguous():
                 ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
                 gb = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
                 _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_mem, cin_w, cout, k, stride, pad)
-                return gx, gw_ret, gb, None, None, None, None, None, None
+                return gx, gw_ret, gb, None, None, None, None, None, None, None
             _convg_wgrad(x, hin, win, cin_mem, cin_w, gpre, hout, wout, cout, cout, gw, n, k, stride, pad)
         gb = _colsum(gpre, cout) if has_bias else None
-        return gx, gw_ret, gb, None, None, None, None, None, None
+        return gx, gw_ret, gb, None, None, None, None, None, None, None
 
 
-def convg(x, weight, bias, stride=1, pad=0, act=ACT_NONE, need_dgrad=True):
-    """Conv2d on an nhwc tensor through the streaming MFMA kernel (any channel count that is a multiple of 4)."""
-    return _ConvG.apply(x, weight, bias, stride, pad, act, False, None, need_dgrad)
+def convg(x, weight, bias, stride=1, pad=0, act=ACT_NONE, need_dgrad=True, out=None):
+    """Conv2d on an nhwc tensor through the streaming MFMA kernel (any channel count that is a multiple of 4).
+    out: optional ConcatBuf.slot the result is written into (the returned tensor is that channel range)."""
+    return _ConvG.apply(x, weight, bias, stride, pad, act, False, None, need_dgrad, out)
 
 
-def convg_transposed(x, weight, bias, out_hw, pad=1, act=ACT_NONE):
+def convg_transposed(x, weight, bias, out_hw, pad=1, act=ACT_NONE, out=None):
     """ConvTranspose2d(k=3, stride=2, padding=pad, output_padding=1) cropped to out_hw (crop_like)."""
-    return _ConvG.apply(x, weight, bias, 2, pad, act, True, tuple(out_hw), True)
+    return _ConvG.apply(x, weight, bias, 2, pad, act, True, tuple(out_hw), True, out)
 
 
 class _HeadG(torch.autograd.Function):

@@ -270,6 +270,14 @@ int dis_disp_head_bwd(const float* x, const float* w, const float* y, const floa
 
 /* dy *= act'(y) given the activation OUTPUT y (SELU and ReLU are invertible enough for that). In place ok. */
 int dis_act_bwd(const float* gy, const float* y, float* gpre, int act, long count, void* stream);
+/* The same on channel ranges of wider nhwc buffers: gy / y pixels are ldg / ldy floats apart (c % 4 == 0, 16-byte
+ * aligned), gpre is dense (npix, c); act == DIS_ACT_NONE gathers gy.  Host side: ops._ConvG.backward when a layer's
+ * output lives inside a decoder concatenation buffer (the reference concatenates with torch.cat, networks.py:262-288). */
+int dis_act_bwd_ld(const float* gy, int ldg, const float* y, int ldy, float* gpre, int act, long npix, int c,
+                   void* stream);
+/* dst[pixel*ldd + j] = src[pixel*lds + j] for j < c and 0 for c <= j < c + czero: a tensor written into a channel range
+ * of a wider nhwc buffer, followed by czero zero lanes (the padding of a concatenation to a multiple of 4 channels). */
+int dis_copy_channels(const float* src, int lds, float* dst, int ldd, long npix, int c, int czero, void* stream);
 
 /* GroupNorm(num_groups=1) statistics: stats (n,2) zeroed doubles <- sum, sumsq over (h,w,c) per sample. */
 int dis_gn_stats(const float* x, double* stats, int n, long per_sample, void* stream);
