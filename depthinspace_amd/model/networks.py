@@ -334,12 +334,14 @@ class Single_Frame_Flow_Consistency_Loss(ProjectionBaseLoss):
         self.mod_name = 'Single_Frame_Flow_Consistency_Loss'
         self.clamp = clamp
 
-    def fwd(self, depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1):
+    def fwd(self, depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1, accs=None):
         val, mask = ops.geo_loss_dir(depth0, depth1, flow0, flow1, amb0, amb1, None, R0, t0, R1, t1,
-                                     self._K_host, self._Ki_host, float(self.clamp))
+                                     self._K_host, self._Ki_host, float(self.clamp), accs)
         return val, mask, None
 
-    def tforward(self, depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1):
-        l0, mask0, orig_mask = self.fwd(depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1)
-        l1, mask1, _ = self.fwd(depth1, depth0, R1, t1, R0, t0, flow1, flow0, amb1, amb0)
+    def tforward(self, depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1, accs=None):
+        """accs (not in the reference): optional (ops.GradAccum of depth0, of depth1), see ops.GradAccum."""
+        l0, mask0, orig_mask = self.fwd(depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1, accs)
+        l1, mask1, _ = self.fwd(depth1, depth0, R1, t1, R0, t0, flow1, flow0, amb1, amb0,
+                                (accs[1], accs[0]) if accs is not None else None)
         return l0 + l1, mask0, mask1, orig_mask

@@ -60,11 +60,16 @@ class Worker(multi_frame_worker.Worker):
         ge_num = self.track_length * (self.track_length - 1) / 2
         depth = self.d2ds[0](out[0])
         ge_loss = self.ge_losses[0]
+        # one unbind (backward: one stack) instead of a select per use, and one shared gradient buffer per frame for the
+        # 6 directional terms it takes part in (their backward kernels accumulate): as in multi_frame_worker
+        ds = depth.unbind(0)
+        accs = [ops.GradAccum() for _ in ds] if depth.requires_grad else None
         for tidx0 in range(depth.shape[0]):
             for tidx1 in range(tidx0 + 1, depth.shape[0]):
-                val, _, _, _ = ge_loss(depth[tidx0], depth[tidx1], R[tidx0], t[tidx0], R[tidx1], t[tidx1],
+                val, _, _, _ = ge_loss(ds[tidx0], ds[tidx1], R[tidx0], t[tidx0], R[tidx1], t[tidx1],
                                        flow_out[f'flow_{tidx0}{tidx1}'], flow_out[f'flow_{tidx1}{tidx0}'],
-                                       amb[tidx0], amb[tidx1])
+                                       amb[tidx0], amb[tidx1],
+                                       accs=(accs[tidx0], accs[tidx1]) if accs is not None else None)
                 vals.append(val * 0.2 / ge_num)
         # pseudo ground truth (DIS-FTSF)
         if self.use_pseudo_gt:
