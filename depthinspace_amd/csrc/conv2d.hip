@@ -1609,11 +1609,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   const int ky0 = KH < K ? (int)blockIdx.z * KH : 0;  // first tap row of this workgroup (7x7: two groups of 4 rows)
   constexpr int WX_IC = C::IC;
   static_assert(GEN || (K == 3 && S == 1 && TR == 8), "the FuseNet form");
-  static_assert(!GEN || (CIN == 32 && COUT == 32 && INACT == 0), "slice-pair form: 32 x 32 channel blocks");
+  static_assert(!GEN || (CIN == 32 && (COUT == 32 || COUT == 16) && INACT == 0), "slice-pair form: 32 x 32 (x 16) blocks");
   // pixel strides (floats) and first channel of this workgroup's slices
   const int ldx = GEN ? a.ldx : CIN, ldg = GEN ? a.ldg : COUT;
   const int cb = GEN ? (int)blockIdx.y % a.npx : 0, gbk = GEN ? (int)blockIdx.y / a.npx : 0;
-  const int xc0 = GEN ? a.xoff + 32 * cb : 0, gc0 = GEN ? a.goff + 32 * gbk : 0;
+  const int xc0 = GEN ? a.xoff + 32 * cb : 0, gc0 = GEN ? a.goff + COUT * gbk : 0;
   constexpr int PSX = C::PSX, PSG = C::PSG, NLX = C::NLX, NLG = C::NLG, NB = C::NB, TW = C::TW;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   unsigned short* xl = smem16;
@@ -1648,7 +1648,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   for (int it = 0; it < NLG; ++it) {
     const int idx = threadIdx.x + it * 256;
     const int vv = idx % C::CVG, pix = idx / C::CVG;
-    ig_rc[it] = (!GEN || 32 * gbk + vv * 4 < a.cg) ? ((pix >> 4) | ((pix & 15) << 16)) : 0x4000;
+    ig_rc[it] = (!GEN || COUT * gbk + vv * 4 < a.cg) ? ((pix >> 4) | ((pix & 15) << 16)) : 0x4000;
     ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * ldg + gc0 + vv * 4) * 4;
   }
   const unsigned x_bytes = (unsigned)a.hin * a.win * (ldx * 4u), g_bytes = (unsigned)a.hout * a.wout * (ldg * 4u);
@@ -1850,25 +1850,26 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
 // Tap-row groups (k = 7): slabs are [group][pair][worker][kh * k * 1024]; group z holds tap rows z * kh ...
 __global__ __launch_bounds__(256) void wgrad_pairs_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
                                                                   int workers, int npx, int npairs, int cxw, int cgw,
-                                                                  int k, int kh) {
-  const int psz = kh * k * 1024, kk = k * k, ngrp = (k + kh - 1) / kh;
+                                                                  int k, int kh, int cob) {
+  // (cob = gy channels per block: 32, or 16 for a layer with 16 output channels)
+  const int psz = kh * k * 32 * cob, kk = k * k, ngrp = (k + kh - 1) / kh;
   const long total = (long)ngrp * npairs * psz;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int e = (int)(i % psz), pair = (int)((i / psz) % npairs), grp = (int)(i / ((long)psz * npairs));
-    const int gc = e & 31, xc = (e >> 5) & 31, tl = e >> 10;
+    const int gc = e % cob, xc = (e / cob) & 31, tl = e / (32 * cob);
     const int ky = grp * kh + tl / k, tap = ky * k + tl % k;
-    const int x = 32 * (pair % npx) + xc, g = 32 * (pair / npx) + gc;
+    const int x = 32 * (pair % npx) + xc, g = cob * (pair / npx) + gc;
     if (x >= cxw || g >= cgw || ky >= k) continue;
     const float* p = part + ((long)grp * npairs + pair) * workers * psz + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < workers; k += 4) {
-      s0 += p[(long)k * psz];
-      s1 += p[(long)(k + 1) * psz];
-      s2 += p[(long)(k + 2) * psz];
-      s3 += p[(long)(k + 3) * psz];
+    int wk = 0;
+    for (; wk + 3 < workers; wk += 4) {
+      s0 += p[(long)wk * psz];
+      s1 += p[(long)(wk + 1) * psz];
+      s2 += p[(long)(wk + 2) * psz];
+      s3 += p[(long)(wk + 3) * psz];
     }
-    for (; k < workers; ++k) s0 += p[(long)k * psz];
+    for (; wk < workers; ++wk) s0 += p[(long)wk * psz];
     gw[((long)g * cxw + x) * kk + tap] = (s0 + s1) + (s2 + s3);
   }
 }
@@ -1879,9 +1880,11 @@ static int wgrad_pairs_tr(int k, int stride) {
   if (stride == 2 && (k == 3 || k == 5)) return 4;
   return 0;
 }
+// (a layer with exactly 16 output channels at 3x3 / stride 1 - iconv1 - runs the 32 x 16 instance)
+static int wgrad_pairs_cob(int cG, int k, int stride) { return (cG == 16 && k == 3 && stride == 1) ? 16 : 32; }
 static void wgrad_pairs_plan(int n, int hG, int wG, int cX, int cG, int tr, int* npx, int* ngb, int* wpp) {
   *npx = (cX + 31) / 32;
-  *ngb = (cG + 31) / 32;
+  *ngb = cG == 16 ? 1 : (cG + 31) / 32;
   const long ntiles = (long)n * ((hG + tr - 1) / tr) * ((wG + 15) / 16);
   long per = (2L * num_cus() + (long)*npx * *ngb - 1) / ((long)*npx * *ngb);  // ~2 workgroups per CU in all
   if (per > ntiles) per = ntiles;
@@ -1893,18 +1896,19 @@ long dis_wgrad_pairs_workspace(int n, int hX, int wX, int hG, int wG, int cX, in
                                int stride) {
   static const bool use3 = !(getenv("DIS_CONV_BF16X3") && getenv("DIS_CONV_BF16X3")[0] == '0');
   const int tr = wgrad_pairs_tr(k, stride);
-  if (!use3 || tr == 0 || cX < 16 || cG < 32) return -1;  // (a 16-channel x slice fills half of its block)
+  // (a 16-channel x slice fills half of its block)
+  if (!use3 || tr == 0 || cX < 16 || (cG < 32 && wgrad_pairs_cob(cG, k, stride) != 16)) return -1;
   if ((long)hX * wX * ldX * 4 >= 0x7fff0000L || (long)hG * wG * ldG * 4 >= 0x7fff0000L) return -1;
   int npx, ngb, wpp;
   wgrad_pairs_plan(n, hG, wG, cX, cG, tr, &npx, &ngb, &wpp);
   return (long)npx * ngb * wpp * (k == 7 ? 2 * 4 * 7 : k * k) * 1024;  // (7x7: two groups of 4 tap rows)
 }
-template <int K, int S, int TR, int KH = K>
+template <int K, int S, int TR, int KH = K, int COB = 32>
 static int wgrad_pairs_launch(WgArgs a, float* grad_w, int cX_w, int cG_w, int ngb, int wpp, hipStream_t s) {
-  using XC = WxCfg<32, 32, K, S, TR, KH>;
+  using XC = WxCfg<32, COB, K, S, TR, KH>;
   static_assert(XC::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
   constexpr int NGRP = (K + KH - 1) / KH;
-  auto kern = conv_wgrad_bf16x3_kernel<32, 32, 0, true, K, S, TR, KH>;
+  auto kern = conv_wgrad_bf16x3_kernel<32, COB, 0, true, K, S, TR, KH>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XC::LDS_BYTES);
@@ -1912,9 +1916,9 @@ static int wgrad_pairs_launch(WgArgs a, float* grad_w, int cX_w, int cG_w, int n
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)wpp, (unsigned)(a.npx * ngb), NGRP), dim3(256), XC::LDS_BYTES, s, a);
-  const long total = (long)NGRP * a.npx * ngb * KH * K * 1024;
+  const long total = (long)NGRP * a.npx * ngb * KH * K * 32 * COB;
   hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)a.part,
-                     grad_w, wpp, a.npx, a.npx * ngb, cX_w, cG_w, K, KH);
+                     grad_w, wpp, a.npx, a.npx * ngb, cX_w, cG_w, K, KH, COB);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
@@ -1929,6 +1933,8 @@ int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int hX, int wX, int c
   a.n = n; a.hin = hX; a.win = wX; a.hout = hG; a.wout = wG; a.pad = pad;
   a.xscale = nullptr; a.gact = nullptr;
   a.ldx = ldX; a.xoff = xoff; a.cx = cX; a.ldg = ldG; a.goff = goff; a.cg = cG; a.npx = npx;
+  if (k == 3 && stride == 1 && wgrad_pairs_cob(cG, k, stride) == 16)
+    return wgrad_pairs_launch<3, 1, 8, 3, 16>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
   if (k == 3 && stride == 1) return wgrad_pairs_launch<3, 1, 8>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
   if (k == 5 && stride == 1) return wgrad_pairs_launch<5, 1, 8>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
   if (k == 3 && stride == 2) return wgrad_pairs_launch<3, 2, 4>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
@@ -1955,7 +1961,6 @@ static int dispatch_wgrad(const WgArgs& a, float* gw, float* gb, int cin_real, i
   WG_CASE(128, 32, 1, 1)
   WG_CASE(32, 32, 4, 2)
   WG_CASE(4, 32, 7, 2)   // DispNetS conv1 (2 -> 32, k7 s2): all 49 taps in one pass over the pixels
-  WG_CASE(20, 16, 3, 1)  // DispNetS iconv1 (17 -> 16 at full resolution)
   return DIS_ERR_UNSUPPORTED;
 }
 
@@ -1971,7 +1976,6 @@ extern "C" long dis_conv2d_wgrad_workspace(int cin, int cout, int k, int stride)
   WS_CASE(128, 32, 1, 1)
   WS_CASE(32, 32, 4, 2)
   WS_CASE(4, 32, 7, 2)
-  WS_CASE(20, 16, 3, 1)
   return -1;
 }
 
