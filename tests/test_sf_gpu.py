@@ -224,3 +224,69 @@ def test_sf_step_matches_reference(golden_dir, name):
             new_ref = torch.from_numpy(G['new:' + k])
             assert float((named[k].detach().cpu() - new_ref).abs().max()) <= 2.1e-4, k
     print(name, 'worst grad rel err', worst)
+
+
+def test_act_bwd_and_copy_on_channel_ranges():
+    """dis_act_bwd_ld / dis_copy_channels: channel ranges of wider nhwc buffers (the in-place decoder concatenations)"""
+    from depthinspace_amd import lib, ops
+    g = torch.Generator().manual_seed(5)
+    npix, c, ldg, ldy = 1000, 24, 40, 32
+    gyw = torch.randn(npix, ldg, generator=g).cuda()
+    yw = torch.randn(npix, ldy, generator=g).cuda()
+    gy, y = gyw[:, 8:8 + c], yw[:, 4:4 + c]
+    for act in (ops.ACT_RELU, ops.ACT_SELU, ops.ACT_NONE):
+        gp = torch.empty(npix, c, device='cuda')
+        lib.call('dis_act_bwd_ld', gy, ldg, y if act != ops.ACT_NONE else None, ldy, gp, act, npix, c)
+        ref = torch.empty(npix, c, device='cuda')
+        if act == ops.ACT_NONE:
+            ref.copy_(gy)
+        else:
+            lib.call('dis_act_bwd', gy.contiguous(), y.contiguous(), ref, act, npix * c)
+        assert torch.equal(gp, ref)
+    # one channel + 3 zero lanes (the float4 path) and a general range with a zero tail
+    dst = torch.full((npix, 20), 9.0, device='cuda')
+    src = torch.randn(npix, 1, generator=g).cuda()
+    lib.call('dis_copy_channels', src, 1, dst[:, 16:], 20, npix, 1, 3)
+    assert torch.equal(dst[:, 16:17], src) and float(dst[:, 17:].abs().max()) == 0.0 and bool((dst[:, :16] == 9.0).all())
+    dst = torch.full((npix, 20), 9.0, device='cuda')
+    src = torch.randn(npix, 5, generator=g).cuda()
+    lib.call('dis_copy_channels', src, 5, dst[:, 6:], 20, npix, 5, 2)
+    assert torch.equal(dst[:, 6:11], src) and float(dst[:, 11:13].abs().max()) == 0.0
+    assert bool((dst[:, :6] == 9.0).all()) and bool((dst[:, 13:] == 9.0).all())
+    assert lib.fn('dis_copy_channels')(None, 1, None, 4, 10, 1, 0, None) != 0
+
+
+def test_concat_buf_routes_gradients():
+    """ops.ConcatBuf: convs write their channel range of one buffer, the joined tensor feeds the consumer, and the
+    gradient ranges come back to the producers (compared with torch.cat on the same values)"""
+    from depthinspace_amd import ops
+    g = torch.Generator().manual_seed(9)
+    n, h, w = 2, 12, 10
+    x = torch.randn(n, h, w, 8, generator=g).cuda().requires_grad_(True)
+    w1 = (torch.randn(16, 8, 3, 3, generator=g) * 0.2).cuda().requires_grad_(True)
+    w2 = (torch.randn(8, 8, 3, 3, generator=g) * 0.2).cuda().requires_grad_(True)
+    w3 = (torch.randn(4, 25, 3, 3, generator=g) * 0.2).cuda().requires_grad_(True)
+    d = torch.randn(n, h, w, 1, generator=g).cuda().requires_grad_(True)
+
+    def run(inplace):
+        for t in (x, w1, w2, w3, d):
+            t.grad = None
+        if inplace:
+            cb = ops.ConcatBuf(n, h, w, 25, x.device)
+            a = ops.convg(x, w1, None, 1, 1, ops.ACT_RELU, out=cb.slot(0, 16))
+            b = ops.convg(x, w2, None, 1, 1, ops.ACT_RELU, out=cb.slot(16, 8))
+            dd = ops.write_channels(d, cb.slot(24, 1), True)
+            cat = cb.joined([(a, 0), (b, 16), (dd, 24)])
+        else:
+            a = ops.convg(x, w1, None, 1, 1, ops.ACT_RELU)
+            b = ops.convg(x, w2, None, 1, 1, ops.ACT_RELU)
+            cat = torch.cat([a, b, d, torch.zeros(n, h, w, 3, device=x.device)], dim=3)
+        y = ops.convg(cat, w3, None, 1, 1, ops.ACT_NONE)
+        (y * y).sum().backward()
+        return y.detach().clone(), [t.grad.clone() for t in (x, w1, w2, w3, d)]
+
+    y0, g0 = run(False)
+    y1, g1 = run(True)
+    assert relerr(y1, y0) < 1e-6
+    for a, b in zip(g1, g0):
+        assert relerr(a, b) < 1e-5
