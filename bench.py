@@ -56,8 +56,9 @@ def conv_flops(n, ho, wo, cin, cout, k):
     return 2.0 * n * ho * wo * cin * cout * k * k
 
 
-def cpu_baseline(arch='multi_frame'):
-    """Oracle step on the host cores: 1 step, bs=1 (4 frames), full resolution."""
+def cpu_baseline(arch='multi_frame', timed_steps=2):
+    """Oracle training step on the host cores: 1 warm-up + `timed_steps` timed steps (Adam state carried along), bs=1
+    (one 4-frame track), full resolution.  The bounded sample of BASELINE.md section 3; reported, never the target."""
     from depthinspace_amd import synth
     from oracle import dis_oracle as O
     settings = synth.make_settings(H, W)
@@ -65,13 +66,23 @@ def cpu_baseline(arch='multi_frame'):
     params = O.init_params(O.mf_param_shapes() if arch == 'multi_frame' else O.sf_param_shapes(), seed=0)
     ctx = O.StepContext(settings)
     st = {'step': 0, 'm': {}, 'v': {}}
-    t0 = time.time()
-    O.train_step(ctx, arch, params, {k: torch.from_numpy(v) for k, v in batch.items()}, adam_state=st, epoch=2)
-    dt = time.time() - t0
+    tb = {k: torch.from_numpy(v) for k, v in batch.items()}
+    nthr = torch.get_num_threads()
+    want = int(os.environ.get('DIS_CPU_BASELINE_THREADS', str(min(nthr, 32))))  # past ~32 threads the small convs slow down
+    torch.set_num_threads(want)
+    try:
+        times = []
+        for i in range(1 + timed_steps):
+            t0 = time.time()
+            O.train_step(ctx, arch, params, tb, adam_state=st, epoch=2)
+            times.append(time.time() - t0)
+    finally:
+        torch.set_num_threads(nthr)
+    dt = sum(times[1:]) / timed_steps
     tag = 'DIS-MF' if arch == 'multi_frame' else 'DIS-SF'
-    return {'value': TL / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 training step of the CPU oracle, {tag} bs=1 (4 frames) 512x432 fp32, {dt:.1f} s, '
-                      f'torch threads={torch.get_num_threads()} of os.cpu_count()={os.cpu_count()}'}
+    return {'value': TL / dt, 'unit': 'frames/s', 'cores': want, 'kind': 'port',
+            'sample': f'CPU oracle training step, {tag} bs=1 (one 4-frame track) 512x432 fp32: 1 warm-up ({times[0]:.1f} s) + '
+                      f'{timed_steps} timed steps (mean {dt:.1f} s), torch threads={want} of os.cpu_count()={os.cpu_count()}'}
 
 
 def main():
@@ -84,6 +95,7 @@ def main():
                     help='multi_frame = BASELINE.json metric (config 3/4); single_frame = DIS-SF (config 2, run in fp32)')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of one hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-eager-leg', action='store_true', help='skip the eager-launch timing of the same step')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the '
                          'multi-rank code path on a box with fewer GPUs than ranks)')
@@ -132,65 +144,20 @@ def main():
     opt = FlatAdam(net.parameters(), lr=1e-4, world_size=world)
     batch = make_device_batch(settings, args.bs, 1234 + rank, dev)  # weak scaling: own tracks per rank
 
-    loss_buf = torch.zeros(16, device=dev)
+    from depthinspace_amd.trainer import GraphedStep
+    # the product's own step object: Worker.train_epoch(use_graph=True) runs the same one (trainer.GraphedStep)
+    stepper = GraphedStep(worker, net, opt, batch, use_graph=not args.no_graph, warmup=max(1, min(args.warmup, 2)))
 
-    def fwd_bwd():
-        worker.copy_data(batch, device=dev, requires_grad=False, train=True)
-        opt.zero_grad()
-        flow = worker.read_optical_flow(train=True)
-        out = worker.net_forward(net, flow)
-        errs = worker.loss_forward(out, True, flow)
-        total = sum(errs)
-        total.backward()
-        loss_buf[:len(errs)].copy_(torch.stack([e.detach() for e in errs]))
-        return len(errs)
-
-    def step_eager():
-        n = fwd_bwd()
-        opt.step()
-        return n
-
-    use_graph = not args.no_graph
-    nterms = 0
-    # ---- warm-up (eager; also sizes the caching allocator and initialises kernel attributes)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(max(1, min(args.warmup, 2)) if use_graph else args.warmup):
-            nterms = step_eager()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-
-    g_fb = g_opt = None
-    if use_graph:
-        try:
-            g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fb):
-                nterms = fwd_bwd()
-                if world == 1:
-                    opt.step(all_reduce=False)
-            if world > 1:
-                g_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_opt):
-                    opt.step(all_reduce=False)
-        except Exception as e:  # pragma: no cover
-            if rank == 0:
-                print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
-            g_fb = g_opt = None
-            use_graph = False
-            torch.cuda.synchronize()
+    def fwd_bwd():  # (roofline leg below)
+        stepper._forward_loss().backward()
 
     def step():
-        if g_fb is None:
-            step_eager()
-        else:
-            g_fb.replay()
-            if world > 1:
-                opt.all_reduce_grads()
-                g_opt.replay()
+        stepper.run()
 
-    for _ in range(max(0, args.warmup - 2) if use_graph else 0):
+    # ---- warm-up (the first graph-mode call runs eager warm-up steps, then captures)
+    for _ in range(max(1, args.warmup)):
         step()
+    use_graph = stepper.use_graph
 
     def barrier():
         if world > 1:
@@ -208,15 +175,36 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
-    losses = [float(v) for v in loss_buf[:nterms].cpu()]
+    nterms = stepper.nterms
+    losses = stepper.losses()
+    adam_steps = opt.step_count
+
+    # ---- the same loop launched eagerly (what Worker.train_step does without DIS_TRAIN_GRAPH): reported beside the headline
+    eager_fps = None
+    if rank == 0 and world == 1 and use_graph and not args.no_eager_leg:
+        est = GraphedStep(worker, net, opt, batch, use_graph=False)
+        for _ in range(2):
+            est.run()
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        ne = max(3, min(10, args.steps))
+        for _ in range(ne):
+            est.run()
+        torch.cuda.synchronize()
+        eager_fps = args.bs * TL * ne / (time.perf_counter() - te)
 
     # ---- roofline leg: HIP events around every launch of the dominant kernel during one eager step
     roof = None
+    hbm = None
+    kernel_ms = None
     if rank == 0:
+        snap = [t.clone() for t in (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev)]
         lib.profile_start()
         fwd_bwd()                    # rank-local: no collective here (only rank 0 runs this leg)
         opt.step(all_reduce=False)
         rec = lib.profile_stop()
+        for t, c in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev), snap):
+            t.copy_(c)               # the profiled extra step is undone: replicas stay identical
         per = {}
         for name, ia, ms in rec:
             per.setdefault(name, [0, 0.0])
@@ -281,6 +269,41 @@ def main():
                     'launches_per_step': len(sel),
                     'avg_launch_ms': tm * 1e3 / len(sel), 'flop_per_launch_avg': fl / len(sel),
                     'share_of_step_kernel_time': tm / (sum(ms for _, _, ms in rec) * 1e-3)}
+        # ---- HBM-bound kernels of the per-pixel path (north star: achieved GB/s of the warp / loss kernels): algorithmic
+        # bytes (SURVEY.md section 8(d) per-pixel table; every tensor read / written once) / HIP-event time of every launch
+        def hbm_row(label, names, nbytes, note):
+            sel_ = [(ia, ms) for name, ia, ms in rec if name in names]
+            if not sel_:
+                return None
+            by = sum(nbytes(ia) for ia, _ in sel_)
+            ms_ = sum(ms for _, ms in sel_)
+            return {'kernel': label, 'bound': 'hbm', 'launches_per_step': len(sel_), 'ms_per_step': round(ms_, 4),
+                    'algorithmic_bytes_per_step': by, 'achieved': by / (ms_ * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS,
+                    'unit': 'GB/s', 'frac': by / (ms_ * 1e-3) / 1e9 / PEAK_HBM_GBS, 'bytes_model': note}
+        hbm = []
+        if mf:
+            # int args (tl, bs, h, w, c): out (tl,bs,h,w,tl,c) written, feat rows read once per slot, flows 8 B per warped slot
+            hbm.append(hbm_row('gather_warped_feat_fwd (feature warp, 4 slots / px)', ('dis_gather_warped_feat_fwd',),
+                               lambda ia: ia[0] * ia[1] * ia[2] * ia[3] * ia[0] * (8.0 * ia[4] + 8.0),
+                               '(8C+8) B per pixel and slot, C = 32'))
+            hbm.append(hbm_row('gather_warped_feat_bwd_csr (feature warp backward)', ('dis_gather_warped_feat_bwd_csr',),
+                               lambda ia: ia[0] * ia[1] * ia[2] * ia[3] * ia[0] * (8.0 * ia[4] + 8.0),
+                               '(8C+8) B per pixel and slot, C = 32'))
+        # dis_gn_apply (n, hw, c, act): x read, y written (+ residual read); dis_gn_apply_bwd: two passes over gy, y/x -> gx
+        hbm.append(hbm_row('gn_apply (GroupNorm forward apply)', ('dis_gn_apply',),
+                           lambda ia: 8.0 * ia[0] * ia[1] * ia[2], '8 B per element (residual reads not counted)'))
+        hbm.append(hbm_row('gn_apply_bwd (GroupNorm backward: reduce + apply)', ('dis_gn_apply_bwd',),
+                           lambda ia: 24.0 * ia[0] * ia[1] * ia[2], '24 B per element (two passes)'))
+        # dis_geo_loss_fwd (bs, h, w): 36 B / px; bwd ~20 B / px
+        hbm.append(hbm_row('geo_loss_fwd (reprojection + 4 warps + masks + masked mean, per direction)',
+                           ('dis_geo_loss_fwd',), lambda ia: 36.0 * ia[0] * ia[1] * ia[2], '36 B per pixel'))
+        hbm.append(hbm_row('geo_loss_bwd', ('dis_geo_loss_bwd',), lambda ia: 20.0 * ia[0] * ia[1] * ia[2], '20 B per pixel'))
+        hbm.append(hbm_row('photometric_fwd (census 9x9)', ('dis_photometric_fwd',),
+                           lambda ia: 12.0 * ia[0] * ia[2] * ia[3], '12 B per pixel (VALU-bound: 81 taps x rsqrt)'))
+        hbm.append(hbm_row('photometric_bwd', ('dis_photometric_bwd',),
+                           lambda ia: 16.0 * ia[0] * ia[2] * ia[3], '16 B per pixel (VALU-bound)'))
+        hbm.append(hbm_row('lcn_fwd', ('dis_lcn_fwd',), lambda ia: 12.0 * ia[0] * ia[1] * ia[2], '12 B per pixel'))
+        hbm = [r for r in hbm if r is not None]
         top = sorted(per.items(), key=lambda kv: -kv[1][1])[:12]
         kernel_ms = {k: {'calls': v[0], 'ms': round(v[1], 3)} for k, v in top}
     cpu = None
@@ -308,7 +331,9 @@ def main():
                                             'channels run as bf16x3 (3-way bf16 operand split, 6 products, fp32 accumulate), '
                                             'the others and the streaming weight gradients on v_mfma_f32_16x16x4_f32')
                                            if ops.BF16X3 else 'v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains)')},
-            'roofline': roof, 'cpu_baseline': cpu, 'loss_terms': losses, 'kernel_ms_one_eager_step': kernel_ms,
+            'roofline': roof, 'roofline_hbm_kernels': hbm, 'cpu_baseline': cpu, 'loss_terms': losses,
+            'eager_launch_frames_per_s': eager_fps, 'adam_steps_taken': adam_steps, 'step_mode': stepper.mode,
+            'kernel_ms_one_eager_step': kernel_ms,
         }
         print(json.dumps(res))
     if world > 1:

@@ -3,7 +3,7 @@
 //
 // Data layout is built for this gather: geom (tl,bs,h,w,tl,4) keeps xyz+mask of the 4 slots of a pixel
 // in one 64-B line, wf (tl,bs,h,w,tl,32) keeps each slot's 32 features in one 128-B line.
-//   kernel 1 (select):    one lane per output pixel: 36 keys, masked top-9 (lowest candidate id wins ties)
+//   kernel 1 (select):    one lane per output pixel: 36 keys, masked top-9 exactly as torch.topk picks them
 //   kernel 2 (forward):   one wave per group of 16 output pixels.  Every per-pixel matrix product (dense2 16->32 per
 //                         neighbour, the 32x32 mix) runs on the matrix cores (v_mfma_f32_16x16x4_f32) in a
 //                         "pixel on the lane" layout: lane (li,lg) owns pixel li and channels {16*mt + 4*lg + r},
@@ -15,6 +15,7 @@
 //                         wave; feature gradients leave as 128-B float-atomic rows.  Parameter gradients are
 //                         reduced through per-block slabs (deterministic, no atomics).
 #include "common.h"
+#include "nth_select.h"
 #include <float.h>
 
 #define C3_TL 4
@@ -27,7 +28,20 @@ struct C3Dims {
   int tl, bs, h, w, ho, wo, stride;
 };
 
-__global__ void conv3d_select_kernel(const float4* __restrict__ geom, unsigned char* __restrict__ idx, C3Dims d) {
+// One lane per output pixel.  The 36 keys are the reference's, operation for operation (multi_frame_networks.py:490-497:
+// plane = xyz / (z + 1e-12), squared distance to candidate 16 summed x, y, z; -ffp-contract=off keeps every rounding),
+// and the 9 neighbours are the ones torch.topk(largest=False, sorted=False) returns on the CPU, in its order: ATen runs
+// std::nth_element on the (key, id) row, restated in nth_select.h, so tied keys (masked candidates all share one fill
+// value; equidistant planar candidates) resolve exactly as in the reference.
+#define C3_SEL_T 64
+struct C3SelView {
+  NthPair* base;
+  __device__ __forceinline__ NthPair& operator[](int i) const { return base[i * C3_SEL_T]; }
+};
+__global__ __launch_bounds__(C3_SEL_T) void conv3d_select_kernel(const float4* __restrict__ geom,
+                                                                 unsigned char* __restrict__ idx, C3Dims d) {
+  __shared__ NthPair sq[C3_NCAND * C3_SEL_T];
+  const C3SelView q{sq + threadIdx.x};
   const long total = (long)d.tl * d.bs * d.ho * d.wo;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ox = (int)(i % d.wo);
@@ -38,13 +52,6 @@ __global__ void conv3d_select_kernel(const float4* __restrict__ geom, unsigned c
     const float4 ctr = g[((long)cy * d.w + cx) * C3_TL];
     const float cden = ctr.z + 1e-12f;
     const float pcx = ctr.x / cden, pcy = ctr.y / cden, pcz = ctr.z / cden;
-    float bk[C3_NB];
-    int bi[C3_NB];
-#pragma unroll
-    for (int k = 0; k < C3_NB; ++k) {
-      bk[k] = INFINITY;
-      bi[k] = 255;
-    }
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = cy - 1 + ky;
       for (int kx = 0; kx < 3; ++kx) {
@@ -52,30 +59,21 @@ __global__ void conv3d_select_kernel(const float4* __restrict__ geom, unsigned c
         const bool inb = iy >= 0 && iy < d.h && ix >= 0 && ix < d.w;
 #pragma unroll
         for (int s = 0; s < C3_TL; ++s) {
-          float4 q = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding: xyz = 0, mask = 0
-          if (inb) q = g[((long)iy * d.w + ix) * C3_TL + s];
-          const float den = q.z + 1e-12f;
-          const float dx = q.x / den - pcx, dy = q.y / den - pcy, dz = q.z / den - pcz;
+          float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding: xyz = 0, mask = 0
+          if (inb) qv = g[((long)iy * d.w + ix) * C3_TL + s];
+          const float den = qv.z + 1e-12f;
+          const float dx = qv.x / den - pcx, dy = qv.y / den - pcy, dz = qv.z / den - pcz;
           float key = (dx * dx + dy * dy) + dz * dz;
-          key = fminf(key, 0.5f * FLT_MAX);
-          if (!(q.w > 0.5f)) key = FLT_MAX;  // masked: the reference's max+1 fill, all such keys tie
+          // masked: the reference fills max(dist) + 1, one value above every valid key; FLT_MAX orders the same way
+          if (!(qv.w > 0.5f)) key = FLT_MAX;
           const int id = (ky * 3 + kx) * C3_TL + s;
-          // branch-free insertion into the ascending list (static register indexing); strict '<' keeps
-          // the earlier (lower) candidate id in front on ties
-#pragma unroll
-          for (int k = C3_NB - 1; k >= 0; --k) {
-            const bool less_prev = (k > 0) && (key < bk[k > 0 ? k - 1 : 0]);
-            const bool less_cur = key < bk[k];
-            const float nk = less_prev ? bk[k > 0 ? k - 1 : 0] : (less_cur ? key : bk[k]);
-            const int ni = less_prev ? bi[k > 0 ? k - 1 : 0] : (less_cur ? id : bi[k]);
-            bk[k] = nk;
-            bi[k] = ni;
-          }
+          q[id] = NthPair{key, id};
         }
       }
     }
+    nth_element_pairs(q, C3_NCAND, C3_NB - 1);
 #pragma unroll
-    for (int k = 0; k < C3_NB; ++k) idx[i * C3_NB + k] = (unsigned char)bi[k];
+    for (int k = 0; k < C3_NB; ++k) idx[i * C3_NB + k] = (unsigned char)q[k].id;
   }
 }
 
@@ -535,7 +533,7 @@ extern "C" int dis_conv3d_knn_select(const float* geom, unsigned char* idx_out, 
   int rc = c3_dims(&d, tl, bs, h, wd, stride);
   if (rc != DIS_OK) return rc;
   const long total = (long)tl * bs * d.ho * d.wo;
-  hipLaunchKernelGGL(conv3d_select_kernel, dim3(dis_ew_grid(total, 128)), dim3(128), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(conv3d_select_kernel, dim3(dis_ew_grid(total, C3_SEL_T)), dim3(C3_SEL_T), 0, (hipStream_t)stream,
                      (const float4*)geom, idx_out, d);
   DIS_CHECK_LAUNCH();
   return DIS_OK;

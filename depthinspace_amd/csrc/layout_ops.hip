@@ -116,6 +116,22 @@ __device__ __forceinline__ Lerp resize_src(int dst, float scale, int in, int ali
   L.l0 = 1.f - L.l1;
   return L;
 }
+// One bilinear output value with the roundings of ATen's CPU upsample_bilinear2d (UpSampleKernel.cpp).  The resized
+// depth / flow / xyz / mask pyramids feed thresholded masks and Conv3D's neighbour keys (index-class outputs), so the
+// value must be the reference's bit for bit.  ATen has two kernels and picks by output size
+// (_use_vectorized_kernel_cond_2d: out_h + out_w <= 128): the vectorized one multiplies the two 1-D weights first and
+// sums the four taps as fma(d, w11, fma(c, w10, fma(a, w00, b * w01))); the generic one nests
+// fma(top, ly0, bot * ly1) with top = fma(a, lx0, b * lx1).  (tests/bitexact.py restates both and is checked against
+// torch bit for bit.)  a,b = row i0 at columns i0,i1;  c,d = row i1.
+__device__ __forceinline__ float bilerp_aten(float a, float b, float c, float d, const Lerp& Ly, const Lerp& Lx,
+                                             bool small) {
+  if (small) {
+    const float w00 = Ly.l0 * Lx.l0, w01 = Ly.l0 * Lx.l1, w10 = Ly.l1 * Lx.l0, w11 = Ly.l1 * Lx.l1;
+    return __fmaf_rn(d, w11, __fmaf_rn(c, w10, __fmaf_rn(a, w00, b * w01)));
+  }
+  const float top = __fmaf_rn(a, Lx.l0, b * Lx.l1), bot = __fmaf_rn(c, Lx.l0, d * Lx.l1);
+  return __fmaf_rn(top, Ly.l0, bot * Ly.l1);
+}
 
 // nhwc, channels in groups of VEC floats
 template <int VEC>
@@ -248,6 +264,7 @@ __global__ void resize_planar_fwd_kernel(const float* __restrict__ x, float* __r
                                          int c_for_scale) {
   const long total = (long)nc * hout * wout;
   const float sy = resize_scale(hin, hout, ac), sx = resize_scale(win, wout, ac);
+  const bool small = hout + wout <= 128;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ox = (int)(i % wout);
     long p = i / wout;
@@ -255,8 +272,8 @@ __global__ void resize_planar_fwd_kernel(const float* __restrict__ x, float* __r
     const int pl = (int)(p / hout);
     const Lerp Ly = resize_src(oy, sy, hin, ac), Lx = resize_src(ox, sx, win, ac);
     const float* base = x + (long)pl * hin * win;
-    float v = Ly.l0 * (Lx.l0 * base[(long)Ly.i0 * win + Lx.i0] + Lx.l1 * base[(long)Ly.i0 * win + Lx.i1]) +
-              Ly.l1 * (Lx.l0 * base[(long)Ly.i1 * win + Lx.i0] + Lx.l1 * base[(long)Ly.i1 * win + Lx.i1]);
+    float v = bilerp_aten(base[(long)Ly.i0 * win + Lx.i0], base[(long)Ly.i0 * win + Lx.i1],
+                          base[(long)Ly.i1 * win + Lx.i0], base[(long)Ly.i1 * win + Lx.i1], Ly, Lx, small);
     if (c_for_scale > 0) v *= ((pl % c_for_scale) == 0) ? scale0 : scale1;
     y[i] = v;
   }
@@ -683,10 +700,13 @@ __device__ __forceinline__ void xyz_in_view(const GeomCam& cam, int us, int vs, 
   core_ray(cam.Ki, us * x, vs * y, ray);
 #pragma unroll
   for (int c = 0; c < 3; ++c) a[c] = d * ray[c] - tj[c];
+  // torch.matmul on the CPU accumulates K = 3 as fma(a2, b2, fma(a1, b1, a0 * b0)); the masks and Conv3D's neighbour
+  // keys derived from these coordinates are index-class outputs, so the chain is reproduced exactly (tests/bitexact.py)
 #pragma unroll
-  for (int c = 0; c < 3; ++c) wv[c] = a[0] * Rj[0 * 3 + c] + a[1] * Rj[1 * 3 + c] + a[2] * Rj[2 * 3 + c];
+  for (int c = 0; c < 3; ++c) wv[c] = __fmaf_rn(a[2], Rj[2 * 3 + c], __fmaf_rn(a[1], Rj[1 * 3 + c], a[0] * Rj[0 * 3 + c]));
 #pragma unroll
-  for (int c = 0; c < 3; ++c) o[c] = (wv[0] * Rt[c * 3 + 0] + wv[1] * Rt[c * 3 + 1] + wv[2] * Rt[c * 3 + 2]) + tt[c];
+  for (int c = 0; c < 3; ++c)
+    o[c] = __fmaf_rn(wv[2], Rt[c * 3 + 2], __fmaf_rn(wv[1], Rt[c * 3 + 1], wv[0] * Rt[c * 3 + 0])) + tt[c];
 }
 
 __global__ void mf_geometry_kernel(const float* __restrict__ depth, const float* __restrict__ R,
@@ -727,12 +747,13 @@ __global__ void mf_geometry_kernel(const float* __restrict__ depth, const float*
           const int tx = tp.x0 + (k & 1), ty = tp.y0 + (k >> 1);
           float q[3];
           xyz_in_view(cam, us, vs, tx, ty, dj[(long)ty * w + tx], Rj, tj, Rt, tt, q);
-          acc[0] += q[0] * wgt;
-          acc[1] += q[1] * wgt;
-          acc[2] += q[2] * wgt;
+          // grid_sample's tap sum fma(se, w, fma(sw, w, fma(ne, w, nw * w))); a tap outside the image adds fma(0, w, acc) = acc
+          acc[0] = __fmaf_rn(q[0], wgt, acc[0]);
+          acc[1] = __fmaf_rn(q[1], wgt, acc[1]);
+          acc[2] = __fmaf_rn(q[2], wgt, acc[2]);
           const float2 g = *(const float2*)(fl1 + ((long)ty * w + tx) * 2);
-          f10x += g.x * wgt;
-          f10y += g.y * wgt;
+          f10x = __fmaf_rn(g.x, wgt, f10x);
+          f10y = __fmaf_rn(g.y, wgt, f10y);
         }
       }
       const float sx = f0.x + f10x, sy = f0.y + f10y;
@@ -763,6 +784,7 @@ __global__ void mf_geometry_resize_kernel(const float4* __restrict__ x, float4* 
                                           int win, int hout, int wout, int slots) {
   const long total = (long)n * hout * wout * slots;
   const float sy = resize_scale(hin, hout, 1), sx = resize_scale(win, wout, 1);
+  const bool small = hout + wout <= 128;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int s = (int)(i % slots);
     long p = i / slots;
@@ -775,10 +797,10 @@ __global__ void mf_geometry_resize_kernel(const float4* __restrict__ x, float4* 
     const float4 a = base[((long)Ly.i0 * win + Lx.i0) * slots], bq = base[((long)Ly.i0 * win + Lx.i1) * slots];
     const float4 c = base[((long)Ly.i1 * win + Lx.i0) * slots], d = base[((long)Ly.i1 * win + Lx.i1) * slots];
     float4 o;
-    o.x = Ly.l0 * (Lx.l0 * a.x + Lx.l1 * bq.x) + Ly.l1 * (Lx.l0 * c.x + Lx.l1 * d.x);
-    o.y = Ly.l0 * (Lx.l0 * a.y + Lx.l1 * bq.y) + Ly.l1 * (Lx.l0 * c.y + Lx.l1 * d.y);
-    o.z = Ly.l0 * (Lx.l0 * a.z + Lx.l1 * bq.z) + Ly.l1 * (Lx.l0 * c.z + Lx.l1 * d.z);
-    const float m = Ly.l0 * (Lx.l0 * a.w + Lx.l1 * bq.w) + Ly.l1 * (Lx.l0 * c.w + Lx.l1 * d.w);
+    o.x = bilerp_aten(a.x, bq.x, c.x, d.x, Ly, Lx, small);
+    o.y = bilerp_aten(a.y, bq.y, c.y, d.y, Ly, Lx, small);
+    o.z = bilerp_aten(a.z, bq.z, c.z, d.z, Ly, Lx, small);
+    const float m = bilerp_aten(a.w, bq.w, c.w, d.w, Ly, Lx, small);
     o.w = m > 0.5f ? 1.f : 0.f;
     y[i] = o;
   }

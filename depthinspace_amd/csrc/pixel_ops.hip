@@ -404,6 +404,55 @@ extern "C" int dis_l1_mean_bwd(const float* a, const float* b, const float* gsca
   return DIS_OK;
 }
 
+// real-data warm-up term (reference model/multi_frame_worker.py:168-173, single_frame_worker.py:158-163):
+//   valid = sgm > thresh;  val = sum(|o - sgm + noise| * valid) / sum(valid)
+__global__ void sgm_l1_sum_kernel(const float* __restrict__ o, const float* __restrict__ sgm,
+                                  const float* __restrict__ noise, float thresh, double* __restrict__ acc, long count) {
+  __shared__ double sm[8];
+  double s0 = 0.0, s1 = 0.0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float m = sgm[i] > thresh ? 1.f : 0.f;
+    s0 += (double)(fabsf((o[i] - sgm[i]) + noise[i]) * m);
+    s1 += (double)m;
+  }
+  double r0 = block_sum_d(s0, sm);
+  double r1 = block_sum_d(s1, sm);
+  if (threadIdx.x == 0) {
+    atomic_add_d(acc, r0);
+    atomic_add_d(acc + 1, r1);
+  }
+}
+__global__ void sgm_l1_bwd_kernel(const float* __restrict__ o, const float* __restrict__ sgm,
+                                  const float* __restrict__ noise, float thresh, const double* __restrict__ acc,
+                                  const float* __restrict__ gscale, float* __restrict__ go, long count) {
+  const float g = gscale[0] / (float)acc[1];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float d = (o[i] - sgm[i]) + noise[i];
+    const float m = sgm[i] > thresh ? 1.f : 0.f;
+    go[i] = m * (d > 0.f ? g : (d < 0.f ? -g : 0.f));
+  }
+}
+extern "C" int dis_sgm_l1_fwd(const float* out_disp, const float* sgm_disp, const float* noise, float thresh,
+                              double* acc, float* out, long count, void* stream) {
+  if (!out_disp || !sgm_disp || !noise || !acc || !out) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sgm_l1_sum_kernel, dim3(dis_red_grid(count, 256)), dim3(256), 0, s, out_disp, sgm_disp, noise,
+                     thresh, acc, count);
+  hipLaunchKernelGGL(ratio_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)acc, out, 0.0);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_sgm_l1_bwd(const float* out_disp, const float* sgm_disp, const float* noise, float thresh,
+                              const double* acc, const float* gscale, float* grad_out_disp, long count, void* stream) {
+  if (!out_disp || !sgm_disp || !noise || !acc || !gscale || !grad_out_disp) return DIS_ERR_NULL;
+  if (count <= 0) return DIS_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(sgm_l1_bwd_kernel, dim3(dis_ew_grid(count, 256)), dim3(256), 0, (hipStream_t)stream, out_disp,
+                     sgm_disp, noise, thresh, acc, gscale, grad_out_disp, count);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Sobel-5 smoothness (reference model/networks.py:411-431, 693-731)
 // ------------------------------------------------------------------------------------------------
@@ -542,7 +591,8 @@ __global__ void d2d_kernel(const float* __restrict__ disp, const float* __restri
     float d = disp[i];
     float r = (d > 0.f ? d : 0.f) + 1e-12f;
     if (!backward) {
-      out[i] = bf / r;
+      // torch evaluates `python_float / tensor` as tensor.reciprocal() * float (Tensor.__rtruediv__): two roundings
+      out[i] = (1.f / r) * bf;
     } else {
       out[i] = d > 0.f ? -gdepth[i] * bf / (r * r) : 0.f;
     }
@@ -580,15 +630,20 @@ __device__ __forceinline__ void pixel_ray(const float* Ki, int u, int v, float* 
   for (int c = 0; c < 3; ++c)
     r[c] = (float)((double)u * (double)Ki[c * 3 + 0] + (double)v * (double)Ki[c * 3 + 1] + (double)Ki[c * 3 + 2]);
 }
+// The masks this kernel thresholds are index-class outputs, so every value that reaches a comparison is rounded exactly
+// as the reference's CPU run rounds it (tests/bitexact.py restates these chains in numpy and is checked against the oracle
+// bit for bit): torch.bmm accumulates a K = 3 product as the fused chain fma(a2, b2, fma(a1, b1, a0 * b0)), grid_sample
+// sums its four taps as fma(se, w, fma(sw, w, fma(ne, w, nw * w))).  The library is built with -ffp-contract=off, so
+// the only fused operations are the explicit ones.
 // row vector times 3x3 (row-major M): out_c = sum_k a_k M[k][c]
 __device__ __forceinline__ void vec_mat(const float* a, const float* M, float* o) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) o[c] = a[0] * M[0 * 3 + c] + a[1] * M[1 * 3 + c] + a[2] * M[2 * 3 + c];
+  for (int c = 0; c < 3; ++c) o[c] = __fmaf_rn(a[2], M[2 * 3 + c], __fmaf_rn(a[1], M[1 * 3 + c], a[0] * M[0 * 3 + c]));
 }
 // row vector times M^T: out_c = sum_k a_k M[c][k]
 __device__ __forceinline__ void vec_matT(const float* a, const float* M, float* o) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) o[c] = a[0] * M[c * 3 + 0] + a[1] * M[c * 3 + 1] + a[2] * M[c * 3 + 2];
+  for (int c = 0; c < 3; ++c) o[c] = __fmaf_rn(a[2], M[c * 3 + 2], __fmaf_rn(a[1], M[c * 3 + 1], a[0] * M[c * 3 + 0]));
 }
 
 struct Bilin {
@@ -619,7 +674,7 @@ __device__ __forceinline__ float bilin_fetch(const float* img, const Bilin& b, i
   float c = b.v01 ? img[(long)b.y0 * w + b.x0 + 1] : 0.f;
   float d = b.v10 ? img[(long)(b.y0 + 1) * w + b.x0] : 0.f;
   float e = b.v11 ? img[(long)(b.y0 + 1) * w + b.x0 + 1] : 0.f;
-  return a * b.nw + c * b.ne + d * b.sw + e * b.se;
+  return __fmaf_rn(e, b.se, __fmaf_rn(d, b.sw, __fmaf_rn(c, b.ne, a * b.nw)));
 }
 
 // z (and optionally uv) of pixel (u,v) of camera A with depth d, reprojected into camera B
@@ -681,8 +736,8 @@ __global__ void geo_loss_fwd_kernel(const float* __restrict__ depth0, const floa
           float q[3];
           reproject(cam, tx, ty, pd[(long)ty * w + tx], rB, tB, rA, tA, q);
           float den = (q[2] > 0.f ? q[2] : 0.f) + 1e-12f;
-          wu += (q[0] / den) * wgt;
-          wv += (q[1] / den) * wgt;
+          wu = __fmaf_rn(q[0] / den, wgt, wu);  // (the first valid tap: fma(v, w, 0) = v * w)
+          wv = __fmaf_rn(q[1] / den, wgt, wv);
         }
       }
       const float du = wu - (float)x, dv = wv - (float)y;
@@ -782,6 +837,123 @@ extern "C" int dis_geo_loss_bwd(const float* depth0, const float* depth1, const 
   hipLaunchKernelGGL(geo_loss_bwd_kernel, dim3(dis_ew_grid((long)bs * h * w, 256)), dim3(256), 0,
                      (hipStream_t)stream, depth0, depth1, flow0, R0, t0, R1, t1, cam, clampv, mask, acc, gscale,
                      grad_depth0, grad_depth1, bs, h, w);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// training-time image augmentation on the device (reference data/data_manipulation.py:114-195 with the dataset's settings
+// data/dataset.py:67-70: max_shift 0 -> no affine part, max_blur 0.5, max_noise 3, max_sp_noise 5e-4), applied to the
+// IR image and the ambient image of every frame after the host->device copy instead of by cv2 / numpy in the loader
+// processes.  Per image i, params[i] = {blur flag, sigma_im, sigma_amb, noise_im, noise_amb, sp_ratio (<0: none)}, drawn by
+// the caller; the per-pixel randomness comes from a counter-based generator keyed by (seed, image, pixel, stream).
+//   1. 5x5 Gaussian blur (cv2.GaussianBlur: kernel exp(-x^2 / 2 sigma^2) normalised, BORDER_REFLECT_101), image and ambient
+//      with their own sigma                                                              [blur flag]
+//   2. + N(0,1) * noise / 255, image and ambient with their own amplitude
+//   3. salt (-> the ORIGINAL image's max) then pepper (-> its min), each pixel with probability sp_ratio; image only
+//      (the reference sets int(N * ratio) coordinates drawn with replacement: the same marginal distribution)
+//   4. clip to [0, 1]
+// ------------------------------------------------------------------------------------------------
+#define AUG_NP 6
+__device__ __forceinline__ unsigned aug_hash(unsigned x) {  // lowbias32
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float aug_uniform(unsigned long long seed, unsigned img, unsigned pix, unsigned stream) {
+  unsigned h = aug_hash((unsigned)seed ^ aug_hash((unsigned)(seed >> 32) + 0x9e3779b9U * (stream + 1)));
+  h = aug_hash(h ^ aug_hash(img * 0x85ebca6bU + 0xc2b2ae35U) ^ aug_hash(pix + 0x27d4eb2fU * stream));
+  return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+}
+__device__ __forceinline__ float aug_normal(unsigned long long seed, unsigned img, unsigned pix, unsigned stream) {
+  const float u1 = aug_uniform(seed, img, pix, 2 * stream), u2 = aug_uniform(seed, img, pix, 2 * stream + 1);
+  return sqrtf(-2.f * logf(u1)) * cosf(6.28318530718f * u2);
+}
+__device__ __forceinline__ int aug_reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+__global__ void aug_minmax_kernel(const float* __restrict__ im, unsigned* __restrict__ mm, int n, long hw) {
+  // images are >= 0, so the unsigned bit pattern orders like the value; mm[2i] = min bits (init 0x7f800000), mm[2i+1] = max
+  const int i = blockIdx.y;
+  unsigned lo = 0x7f800000u, hi = 0u;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < hw; p += (long)gridDim.x * blockDim.x) {
+    const unsigned b = __float_as_uint(fmaxf(im[(long)i * hw + p], 0.f));
+    lo = min(lo, b);
+    hi = max(hi, b);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, (unsigned)__shfl_xor((int)lo, o));
+    hi = max(hi, (unsigned)__shfl_xor((int)hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(mm + 2 * i, lo);
+    atomicMax(mm + 2 * i + 1, hi);
+  }
+}
+__global__ void aug_init_minmax_kernel(unsigned* __restrict__ mm, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    mm[2 * i] = 0x7f800000u;
+    mm[2 * i + 1] = 0u;
+  }
+}
+__device__ __forceinline__ float aug_blur5(const float* __restrict__ img, int x, int y, int h, int w, float sigma) {
+  float k[5], ks = 0.f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const float d = (float)(i - 2);
+    k[i] = expf(-(d * d) / (2.f * sigma * sigma));
+    ks += k[i];
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy) {
+    const int yy = aug_reflect101(y + dy - 2, h);
+    float row = 0.f;
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) row += k[dx] * img[(long)yy * w + aug_reflect101(x + dx - 2, w)];
+    acc += k[dy] * row;
+  }
+  return acc / (ks * ks);
+}
+__global__ void augment_kernel(const float* __restrict__ im, const float* __restrict__ amb,
+                               const float* __restrict__ params, const unsigned* __restrict__ mm,
+                               const long long* __restrict__ seed_dev, float* __restrict__ out_im,
+                               float* __restrict__ out_amb, int n, int h, int w) {
+  const long hw = (long)h * w, total = (long)n * hw;
+  const unsigned long long seed = (unsigned long long)seed_dev[0];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / hw);
+    const long p = i - (long)b * hw;
+    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const float* P = params + (long)b * AUG_NP;
+    float vi = im[i], va = amb[i];
+    if (P[0] > 0.5f) {
+      vi = aug_blur5(im + (long)b * hw, x, y, h, w, P[1]);
+      va = aug_blur5(amb + (long)b * hw, x, y, h, w, P[2]);
+    }
+    vi += aug_normal(seed, (unsigned)b, (unsigned)p, 0) * (P[3] / 255.f);
+    va += aug_normal(seed, (unsigned)b, (unsigned)p, 1) * (P[4] / 255.f);
+    if (P[5] >= 0.f) {
+      if (aug_uniform(seed, (unsigned)b, (unsigned)p, 8) < P[5]) vi = __uint_as_float(mm[2 * b + 1]);
+      if (aug_uniform(seed, (unsigned)b, (unsigned)p, 9) < P[5]) vi = __uint_as_float(mm[2 * b]);
+    }
+    out_im[i] = fminf(fmaxf(vi, 0.f), 1.f);
+    out_amb[i] = fminf(fmaxf(va, 0.f), 1.f);
+  }
+}
+extern "C" int dis_augment(const float* im, const float* amb, const float* params, const long long* seed,
+                           unsigned* minmax_ws, float* out_im, float* out_amb, int n, int h, int w, void* stream) {
+  if (!im || !amb || !params || !seed || !minmax_ws || !out_im || !out_amb) return DIS_ERR_NULL;
+  if (n <= 0 || h < 3 || w < 3) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const long hw = (long)h * w;
+  hipLaunchKernelGGL(aug_init_minmax_kernel, dim3(dis_cdiv(n, 64)), dim3(64), 0, s, minmax_ws, n);
+  hipLaunchKernelGGL(aug_minmax_kernel, dim3((unsigned)min((long)64, dis_cdiv(hw, 256)), n), dim3(256), 0, s, im, minmax_ws,
+                     n, hw);
+  hipLaunchKernelGGL(augment_kernel, dim3(dis_ew_grid((long)n * hw, 256)), dim3(256), 0, s, im, amb, params,
+                     (const unsigned*)minmax_ws, seed, out_im, out_amb, n, h, w);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

@@ -41,8 +41,29 @@ def build(src_png):
     return out.astype(np.float16)
 
 
+def build_real(src_png):
+    """The `real` pattern as the reference's settings.pkl holds it (BASELINE config 5): no rotation / flip
+    (reference data/data_manipulation.py:61-69 applies them to the default pattern only), projector and camera share
+    K so the remap of data/create_syn_data.py:315-328 is the identity, then `post_process('real', ...)`
+    (data/data_manipulation.py:91-105): crop [128:-128, 108:-108] -> 1024x864 and cv2.resize(INTER_LINEAR) to 512x432,
+    which at an exact factor of 2 is the mean of each 2x2 block.  Channel mean is taken here (the workers only ever use
+    pattern.mean(axis=2), reference model/multi_frame_worker.py:57-59)."""
+    from PIL import Image
+    pat = np.asarray(Image.open(src_png)).astype(np.float32) / 255.0
+    if pat.ndim == 3:
+        pat = pat.mean(axis=2)
+    assert pat.shape == (1280, 1080), pat.shape
+    pat = pat[128:-128, 108:-108]
+    out = 0.25 * (pat[0::2, 0::2] + pat[0::2, 1::2] + pat[1::2, 0::2] + pat[1::2, 1::2])
+    assert out.shape == (512, 432)
+    return out.astype(np.float16)
+
+
 if __name__ == '__main__':
     here = os.path.dirname(os.path.abspath(__file__))
     out = build('/root/reference/data/default_pattern.png')
     np.savez_compressed(os.path.join(here, 'default_pattern_512x432.npz'), pattern=out)
     print(out.shape, out.dtype, float(out.min()), float(out.max()), float((out > 0.5).mean()))
+    out = build_real('/root/reference/data/real_pattern.png')
+    np.savez_compressed(os.path.join(here, 'real_pattern_512x432.npz'), pattern=out)
+    print('real', out.shape, out.dtype, float(out.min()), float(out.max()), float((out > 0.5).mean()))

@@ -24,6 +24,8 @@ SIGS = {
     'dis_weighted_mean_bwd': 'pppplp',
     'dis_l1_mean_fwd': 'pppplp',
     'dis_l1_mean_bwd': 'pppplp',
+    'dis_sgm_l1_fwd': 'pppfpplp',
+    'dis_sgm_l1_bwd': 'pppfppplp',
     'dis_smooth_loss_fwd': 'ppppiiip',
     'dis_smooth_loss_bwd': 'pppppiiip',
     'dis_disp_to_depth_fwd': 'ppflp',
@@ -84,7 +86,9 @@ SIGS = {
     'dis_colsum': 'piilippp',
     'dis_sigmoid_affine_fwd': 'ppfflp',
     'dis_sigmoid_affine_bwd': 'pppflp',
+    'dis_augment': 'pppppppiiip',
     'dis_adam_step': 'pppplffffifp',
+    'dis_adam_step_dev': 'pppplffffpfp',
 }
 _RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
              'dis_colsum_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_gather_csr_workspace',

@@ -2,6 +2,7 @@
 (loss construction :50-85, net_forward :87-101, loss_forward / weighting :103-175).
 Visualisation callbacks (write_img, matplotlib) are out of scope."""
 import itertools
+import logging
 
 import numpy as np
 import torch
@@ -16,19 +17,34 @@ class Worker(worker.Worker):
         super().__init__(args, **kwargs)
         self.disparity_loss = networks.DisparitySmoothLoss()
 
-    def _make_dataset(self, n, seed, pseudo):
+    # which pre-saved disparities the stage reads (reference :46-52: DIS-MF trains on the DIS-SF output)
+    load_primary_data = True
+    n_sgm_draws = 1  # noise draws of the real-data warm-up term per step (:168-173: scale 0 only)
+
+    def _train_pseudo_gt(self):
+        return False  # reference :47: load_pseudo_gt=False for the multi-frame train set
+
+    def _make_dataset(self, paths, train, pseudo, n_synth, seed):
+        """the on-disk tracks of DATA_DIR (reference data/dataset.py TrackSynDataset; .npz mirror of the HDF5 schema) or,
+        only when the worker was constructed from a `settings` object without a data root (tests, bench, demo runs), the
+        in-memory synthetic scenes of synth.py"""
+        if self.data_root is not None:
+            from ..data.dataset import TrackNpzDataset
+            return TrackNpzDataset(self.settings_path, paths, track_length=self.track_length, train=train, data_aug=train,
+                                   load_flow_data=True, load_primary_data=self.load_primary_data, load_pseudo_gt=pseudo,
+                                   data_type=self.data_type)
         from ..data.dataset import SyntheticTrackDataset
-        return SyntheticTrackDataset(self.settings, n, self.track_length, seed=seed, load_primary_data=True,
-                                     load_pseudo_gt=pseudo)
+        return SyntheticTrackDataset(self.settings, n_synth, self.track_length, seed=seed,
+                                     load_primary_data=self.load_primary_data, load_pseudo_gt=pseudo)
 
     def get_train_set(self):
-        return self._make_dataset(64, 1234, False)
+        return self._make_dataset(getattr(self, 'train_paths', None), True, self._train_pseudo_gt(), 64, 1234)
 
     def get_test_sets(self):
         test_sets = worker.TestSets()
-        test_set = self._make_dataset(8, 99, self.use_pseudo_gt)
+        test_set = self._make_dataset(getattr(self, 'test_paths', None), False, self.use_pseudo_gt, 8, 99)
         test_sets.append('simple', test_set, test_frequency=1)
-        self.build_losses(test_set)
+        self.build_losses(test_set, device=self.train_device)
         return test_sets
 
     def build_losses(self, test_set=None, device='cuda'):
@@ -101,5 +117,34 @@ class Worker(worker.Worker):
             if self.current_epoch < 2:
                 vals.append(ops.l1_mean(out[0], self.data['primary_disp']) * 0.1)
             if self.current_epoch < self.warmup_epochs and self.data_type == 'real':
-                raise NotImplementedError('real-data SGM warm-up term (reference :168-173) is not on the synthetic path')
+                vals.append(self.sgm_warmup_term(out[0]) * 0.1)
         return vals
+
+    def sgm_warmup_term(self, o, k=0):
+        """reference :168-173 / single_frame_worker.py:158-163: masked L1 to the SGM disparities (valid where > 30) with
+        1.5 * N(0,1) noise drawn on the HOST generator and copied over, exactly like the reference's
+        `torch.randn(o.size()).cuda()`; a captured step supplies draw k as data['_sgm_noise<k>'] instead."""
+        sgm = self.data['sgm_disp']
+        noise = self.data.get(f'_sgm_noise{k}')
+        if noise is None:
+            noise = (1.5 * torch.randn(o.size())).to(o.device)
+        return ops.sgm_l1(o, sgm, noise, 30.0)
+
+    # ------------------------------------------------------------------ evaluation (reference :176-186, :236-263)
+    def callback_test_start(self, epoch, set_idx):
+        from ..co import metric
+        self.metric = metric.MultipleMetric(metric.DistanceMetric(vec_length=1),
+                                            metric.OutlierFractionMetric(vec_length=1, thresholds=[0.1, 0.5, 1, 2, 5]))
+
+    def callback_test_add(self, epoch, set_idx, batch_idx, n_batches, output, masks):
+        if not (isinstance(output, tuple) or isinstance(output, list)):
+            output = [output]
+        gt = self.data['disp0']
+        es = output[0].detach() * (gt > 0)      # reference numpy_in_out :176-186, kept on the device
+        self.metric.add(es.reshape(-1, 1), gt.reshape(-1, 1))
+
+    def callback_test_stop(self, epoch, set_idx, loss):
+        vals = self.metric.get()   # merged over the ranks
+        logging.info(', '.join(f'{k}={v:.5f}' for k, v in vals.items()))
+        for k, v in vals.items():
+            self.metric_add_test(epoch, set_idx, k, v)

@@ -15,13 +15,11 @@ class Worker(multi_frame_worker.Worker):
     """Shares the dataset / loss-object construction with the multi-frame worker (the reference duplicates that
     code, single_frame_worker.py:50-85 == multi_frame_worker.py:50-85 up to the geometric-loss class)."""
 
-    def _make_dataset(self, n, seed, pseudo):
-        from ..data.dataset import SyntheticTrackDataset
-        return SyntheticTrackDataset(self.settings, n, self.track_length, seed=seed, load_primary_data=False,
-                                     load_pseudo_gt=pseudo)
+    load_primary_data = False  # reference single_frame_worker.py:46-52
+    n_sgm_draws = 4            # one noise draw per output scale (:158-163)
 
-    def get_train_set(self):
-        return self._make_dataset(64, 1234, self.use_pseudo_gt)
+    def _train_pseudo_gt(self):
+        return self.use_pseudo_gt
 
     def _ge_loss_cls(self):
         return networks.Single_Frame_Flow_Consistency_Loss
@@ -76,5 +74,6 @@ class Worker(multi_frame_worker.Worker):
             for s, o in zip(itertools.count(), out):
                 vals.append(ops.l1_mean(o, self.data['pseudo_gt']) * (0.1 / (2 ** s)))
         if train and self.data_type == 'real' and self.current_epoch < self.warmup_epochs:
-            raise NotImplementedError('real-data SGM warm-up term (reference :158-163) is not on the synthetic path')
+            for s, o in zip(itertools.count(), out):  # every scale, a fresh noise draw each (reference :158-163)
+                vals.append(self.sgm_warmup_term(o, s) * 0.1)
         return vals

@@ -63,6 +63,8 @@ def _zeros_d(n, dev):
 # (saves one temporary + one `grad += g` launch per parameter, ~236 per DIS-MF step); any further use in the same step
 # falls back to returning the gradient for autograd to accumulate.  FlatAdam.zero_grad() re-arms the flags.
 _GRAD_SINK = {}
+_SINK_NOTIFY = None   # FlatAdam._notify when the bucketed all-reduce is active: told about every finished flat-buffer write
+_SINK_PENDING = []    # parameters handed to a kernel by _sink() in the backward that is running
 
 
 class GradJoin(object):
@@ -112,8 +114,13 @@ class GradAccum(object):
         return None
 
 
-def register_grad_sinks(params):
+def register_grad_sinks(params, notify=None):
+    """notify(param): called once the kernel that writes a parameter's gradient straight into the flat buffer has been
+    launched (autograd never sees that gradient, so a post-accumulate hook would not fire for it)."""
+    global _SINK_NOTIFY
     _GRAD_SINK.clear()
+    _SINK_NOTIFY = notify
+    del _SINK_PENDING[:]
     for p in params:
         if p.grad is not None:
             _GRAD_SINK[p.data_ptr()] = [p.grad, False]
@@ -122,6 +129,16 @@ def register_grad_sinks(params):
 def reset_grad_sinks():
     for e in _GRAD_SINK.values():
         e[1] = False
+    del _SINK_PENDING[:]
+
+
+def _sinks_written():
+    """end of a backward that used _sink(): its kernels are enqueued, the flat-buffer gradients it wrote are final"""
+    if _SINK_PENDING:
+        if _SINK_NOTIFY is not None:
+            for p_ in _SINK_PENDING:
+                _SINK_NOTIFY(p_)
+        del _SINK_PENDING[:]
 
 
 def _sink(param):
@@ -132,6 +149,7 @@ def _sink(param):
     if (e is not None and not e[1] and e[0].shape == param.shape and param.grad is not None
             and param.grad.data_ptr() == e[0].data_ptr()):
         e[1] = True
+        _SINK_PENDING.append(param)
         return e[0], None
     g = torch.empty_like(param)
     return g, g
@@ -152,6 +170,7 @@ def _sink_block(params):
             return None
     for e in es:
         e[1] = True
+    _SINK_PENDING.extend(params)
     first = es[0][0]
     return torch.as_strided(first, (sum(e[0].numel() for e in es),), (1,), first.storage_offset())
 
@@ -169,6 +188,38 @@ def lcn(x, radius=5, eps=0.05):
     std = torch.empty_like(x)
     lib.call('dis_lcn_fwd', x, out, std, n, h, w, int(radius), float(eps))
     return out, std
+
+
+def draw_augment_params(n, rng, max_blur=0.5, max_noise=3.0, max_sp_noise=0.0005):
+    """the per-image random choices of the reference's augment_image (data/data_manipulation.py:161-177) with the
+    dataset's settings (data/dataset.py:67-70), drawn with a numpy RandomState in the reference's order:
+    (n, 6) float32 {blur flag, sigma_im, sigma_amb, noise_im, noise_amb, sp_ratio or -1}"""
+    import numpy as np
+    out = np.zeros((n, 6), np.float32)
+    for i in range(n):
+        if rng.uniform(0, 1) < 0.5:
+            out[i, 0] = 1.0
+            out[i, 1] = rng.uniform(0.2, max_blur)
+            out[i, 2] = rng.uniform(0.2, max_blur)
+        out[i, 3] = rng.uniform(0.0, max_noise)
+        out[i, 4] = rng.uniform(0.0, max_noise)
+        out[i, 5] = rng.uniform(0.0, max_sp_noise) if rng.uniform(0, 1) < 0.5 else -1.0
+    return out
+
+
+def augment(im, amb, params, seed):
+    """device-side training augmentation (dis_augment): im, amb (..., H, W) float32; params (n,6) float32 and seed (1,) int64
+    DEVICE tensors (n = number of H x W planes).  Returns (im_aug, amb_aug); no gradient (inputs are data)."""
+    im, amb, params = _c(im), _c(amb), _c(params)
+    _chk(im, amb, params)
+    h, w = im.shape[-2:]
+    n = im.numel() // (h * w)
+    if tuple(params.shape) != (n, 6) or seed.dtype != torch.int64 or not seed.is_cuda or amb.shape != im.shape:
+        raise RuntimeError('augment: params must be (n,6) float32, seed a CUDA int64 tensor, amb shaped like im')
+    ws = torch.empty(2 * n, dtype=torch.int32, device=im.device)
+    out_im, out_amb = torch.empty_like(im), torch.empty_like(amb)
+    lib.call('dis_augment', im, amb, params, seed, ws, out_im, out_amb, n, h, w)
+    return out_im, out_amb
 
 
 # --------------------------------------------------------------------------------------------------
@@ -284,6 +335,31 @@ class _L1Mean(torch.autograd.Function):
 
 def l1_mean(a, b):
     return _L1Mean.apply(a, b)
+
+
+class _SgmL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, o, sgm, noise, thresh):
+        o, sgm, noise = _c(o), _c(sgm), _c(noise)
+        _chk(o, sgm, noise)
+        acc = _zeros_d(2, o.device)
+        out = torch.empty((), dtype=torch.float32, device=o.device)
+        lib.call('dis_sgm_l1_fwd', o, sgm, noise, float(thresh), acc, out, o.numel())
+        ctx.save_for_backward(o, sgm, noise, acc)
+        ctx.thresh = float(thresh)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        o, sgm, noise, acc = ctx.saved_tensors
+        go = torch.empty_like(o)
+        lib.call('dis_sgm_l1_bwd', o, sgm, noise, ctx.thresh, acc, _c(g), go, o.numel())
+        return go, None, None, None
+
+
+def sgm_l1(o, sgm_disp, noise, thresh=30.0):
+    """sum(|o - sgm + noise| * (sgm > thresh)) / sum(sgm > thresh)  (the `real`-data warm-up term)"""
+    return _SgmL1.apply(o, sgm_disp, noise, thresh)
 
 
 class _SmoothLoss(torch.autograd.Function):
@@ -583,6 +659,7 @@ class _Conv2d(torch.autograd.Function):
                      pad)
         else:
             _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
+        _sinks_written()
         return gx, gw_ret, gb_ret, None, None, None, None, None, None, None
 
 
@@ -674,6 +751,7 @@ class _Conv2dMulti(torch.autograd.Function):
                 _conv_wgrad_any(x, gpre, gwi, gbi, ws, n, h, w, cs[i], cs[i], cout, k, 1, pad)
             gw[:, off:off + cs[i]].copy_(gwi)  # small strided memory move into the (flat) weight-gradient slice
             off += cs[i]
+        _sinks_written()
         return (gw_ret, gb_ret, None, None, None, None) + tuple(gxs)
 
 
@@ -731,6 +809,7 @@ class _Conv2dScaledIn(torch.autograd.Function):
         wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin, cout, k, stride)
         ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
         lib.call('dis_conv2d_wgrad_scaled', x, xscale, gy, gw, gb, ws, n, hin, win, cin, cin, cout, k, stride, pad)
+        _sinks_written()
         return gx, None, gw_ret, gb_ret, None, None, None, None, None
 
 
@@ -958,9 +1037,11 @@ class _ConvG(torch.autograd.Function):
                 ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
                 gb = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
                 _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_mem, cin_w, cout, k, stride, pad)
+                _sinks_written()
                 return gx, gw_ret, gb, None, None, None, None, None, None, None
             _convg_wgrad(x, hin, win, cin_mem, cin_w, gpre, hout, wout, cout, cout, gw, n, k, stride, pad)
         gb = _colsum(gpre, cout) if has_bias else None
+        _sinks_written()
         return gx, gw_ret, gb, None, None, None, None, None, None, None
 
 
@@ -1065,6 +1146,7 @@ class _GroupNorm(torch.autograd.Function):
                 gres = ctx.join.first(gres)
             else:  # the other consumer ran first (not the case in the networks here): plain accumulation
                 gres = ctx.join.take(gres.shape).add_(gres)
+        _sinks_written()
         return gx, None, gg_ret, gb_ret, gres, None, None, None, None
 
 
@@ -1220,6 +1302,7 @@ class _Conv3dKnn(torch.autograd.Function):
                  ctx.stride)
         if join is not None and not second:
             gwf = join.first(gwf)
+        _sinks_written()
         if sunk is not None:
             return (None, gwf, None, None, None, None, None, None, None, None)
         return (None, gwf, gp[1024:1072].view(16, 3), gp[1072:1088], gp[1088:1600].view(32, 16), gp[1600:1632],
@@ -1234,6 +1317,16 @@ def conv3d_knn(geom, wf, d1w, d1b, d2w, d2b, w, idx, stride, join=None):
 # --------------------------------------------------------------------------------------------------
 # optimiser
 # --------------------------------------------------------------------------------------------------
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """Adam with the step counter / bias corrections in the 4 x int32 device tensor `state` (advanced by the call):
+    safe to capture in a hipGraph."""
+    _chk(param, grad, exp_avg, exp_avg_sq)
+    if not state.is_cuda or state.dtype != torch.int32 or state.numel() < 4:
+        raise RuntimeError('adam_step_dev: state must be a 4-element int32 CUDA(HIP) tensor')
+    lib.call('dis_adam_step_dev', param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(beta1), float(beta2),
+             float(eps), state, float(grad_scale))
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     _chk(param, grad, exp_avg, exp_avg_sq)
     lib.call('dis_adam_step', param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(beta1), float(beta2),

@@ -18,12 +18,27 @@ _PLANE_N = np.array([0.15, -0.10, 1.0])
 _PLANE_C = 3.0
 _BLEND = 0.6
 
+# BASELINE config 5 ("real-pattern dataset"): the camera the reference's settings.pkl holds for --pattern_type real,
+# i.e. K_processed and the baseline of reference data/create_syn_data.py:286-296 + data/data_manipulation.py:91-105
+# (focal length and principal point of the 1280x1080 sensor after the [128:-128, 108:-108] crop and the 2x down-scale).
+REAL_K = np.array([[1112.1806640625 / 2, 0.0, (517.0896606445312 - 108) / 2],
+                   [0.0, 1112.1806640625 / 2, (649.6329956054688 - 128) / 2], [0.0, 0.0, 1.0]], dtype=np.float32)
+REAL_BASELINE = 0.0246
+# second scene type: a non-planar surface  n.X = c + A sin(p X_x) cos(q X_y)
+_BUMP_A, _BUMP_P, _BUMP_Q = 0.15, 4.0, 3.0
+
 _here = os.path.dirname(os.path.abspath(__file__))
 
 
 def load_default_pattern():
     """(512, 432) float32 default dot pattern mapped into the camera (see data/make_pattern_fixture.py)."""
     path = os.path.join(_here, 'data', 'default_pattern_512x432.npz')
+    return np.load(path)['pattern'].astype(np.float32)
+
+
+def load_real_pattern():
+    """(512, 432) float32 `real` pattern after the reference's post_process (see data/make_pattern_fixture.py)."""
+    path = os.path.join(_here, 'data', 'real_pattern_512x432.npz')
     return np.load(path)['pattern'].astype(np.float32)
 
 
@@ -58,30 +73,54 @@ class Settings(object):
         self.pattern = pattern  # (H, W, 3) float32
 
 
-def make_settings(height=DEFAULT_H, width=DEFAULT_W, crop_offset=None):
+def make_settings(height=DEFAULT_H, width=DEFAULT_W, crop_offset=None, pattern='default'):
     """Settings for the full 512x432 camera or a (height,width) crop of it.
 
     A crop keeps the focal length and shifts the principal point; crop_offset=(y0,x0) defaults to centred.
+    pattern: 'default' (the synthetic default-pattern camera) or 'real' (BASELINE config 5: real pattern, K_processed,
+    baseline 0.0246).
     """
-    pat = load_default_pattern()
+    if pattern not in ('default', 'real'):
+        raise ValueError(pattern)
+    pat = load_default_pattern() if pattern == 'default' else load_real_pattern()
     if crop_offset is None:
         crop_offset = ((DEFAULT_H - height) // 2, (DEFAULT_W - width) // 2)
     y0, x0 = crop_offset
     assert 0 <= y0 and y0 + height <= DEFAULT_H and 0 <= x0 and x0 + width <= DEFAULT_W
-    K = DEFAULT_K.copy()
+    K = (DEFAULT_K if pattern == 'default' else REAL_K).copy()
     K[0, 2] -= x0
     K[1, 2] -= y0
     pat = pat[y0:y0 + height, x0:x0 + width]
     pat3 = np.ascontiguousarray(np.stack([pat, pat, pat], axis=2))
-    return Settings((height, width), K, DEFAULT_BASELINE, pat3)
+    return Settings((height, width), K, DEFAULT_BASELINE if pattern == 'default' else REAL_BASELINE, pat3)
 
 
-def make_batch(settings, bs, tl=4, seed=1234, with_flow=True, with_primary=True, with_pseudo_gt=False):
+def _surface_depth(ray, R, t, scene):
+    """depth along every ray of camera (R, t) to the scene surface; X_w = (d*ray - t) R."""
+    tR = t @ R
+    den = (ray @ R) @ _PLANE_N
+    d = (_PLANE_C + _PLANE_N @ tR) / den
+    if scene == 'plane':
+        return d
+    for _ in range(60):  # fixed point of  n.X_w(d) = c + bump(X_w(d));  contraction factor <= A*max(p,q)/|n_z| = 0.6
+        Xw = (d[:, None] * ray - t[None]) @ R
+        bump = _BUMP_A * np.sin(_BUMP_P * Xw[:, 0]) * np.cos(_BUMP_Q * Xw[:, 1])
+        d = (_PLANE_C + bump + _PLANE_N @ tR) / den
+    return d
+
+
+def make_batch(settings, bs, tl=4, seed=1234, with_flow=True, with_primary=True, with_pseudo_gt=False, scene='plane',
+               motion=1.0):
     """Returns a dict of float32 numpy arrays in loader layout `(bs, tl, ...)`.
 
     keys: im0, ambient0, disp0 (bs,tl,1,H,W); R (bs,tl,3,3); t (bs,tl,3);
           flow_ij (bs,1,2,H,W) for ordered i!=j; primary_disp, pseudo_gt (bs,tl,1,H,W).
+    scene: 'plane'  or 'bumps' (non-planar surface); motion scales the camera jitter
+    (rotation +-0.02 rad, translation +-0.05 m at 1.0).  Flows are the exact rigid flow of the surface point
+    (occlusions are not modelled).
     """
+    if scene not in ('plane', 'bumps'):
+        raise ValueError(scene)
     rng = np.random.RandomState(seed)
     H, W = settings.imsize
     K = settings.K.astype(np.float64)
@@ -103,10 +142,10 @@ def make_batch(settings, bs, tl=4, seed=1234, with_flow=True, with_primary=True,
     for b in range(bs):
         Rs, ts, depths, xyzw = [], [], [], []
         for i in range(tl):
-            R = _rodrigues(rng.uniform(-0.02, 0.02, 3))
-            t = rng.uniform(-0.05, 0.05, 3)
-            # X_w = (d*ray - t) R on the plane n.X_w = c
-            d = (_PLANE_C + _PLANE_N @ (t @ R)) / ((ray @ R) @ _PLANE_N)
+            R = _rodrigues(rng.uniform(-0.02, 0.02, 3) * motion)
+            t = rng.uniform(-0.05, 0.05, 3) * motion
+            # X_w = (d*ray - t) R on the surface (plane: n.X_w = c)
+            d = _surface_depth(ray, R, t, scene)
             Xw = (d[:, None] * ray - t[None]) @ R
             disp = settings.baseline * f / d
             amb = 0.5 + 0.25 * np.sin(6 * Xw[:, 0]) * np.cos(5 * Xw[:, 1])

@@ -80,6 +80,14 @@ int dis_l1_mean_fwd(const float* a, const float* b, double* acc, float* out, lon
 /* grad_a = gscale[0] * sign(a-b) / count */
 int dis_l1_mean_bwd(const float* a, const float* b, const float* gscale, float* grad_a, long count, void* stream);
 
+/* Real-data warm-up term (reference model/multi_frame_worker.py:168-173, single_frame_worker.py:158-163):
+ * valid = sgm_disp > thresh (30); out = sum(|out_disp - sgm_disp + noise| * valid) / sum(valid).  noise is the caller's
+ * 1.5 * N(0,1) draw (the reference draws it on the host generator and copies it over).  acc: 2 zeroed doubles. */
+int dis_sgm_l1_fwd(const float* out_disp, const float* sgm_disp, const float* noise, float thresh, double* acc,
+                   float* out, long count, void* stream);
+int dis_sgm_l1_bwd(const float* out_disp, const float* sgm_disp, const float* noise, float thresh, const double* acc,
+                   const float* gscale, float* grad_out_disp, long count, void* stream);
+
 /* DisparitySmoothLoss, reference model/networks.py:411-431 with SobelFilter(ksize=5) :693-731.
  * disp, amb: (n,1,h,w).  acc: 1 zeroed double; out: 1 float = mean over (n,2,h,w). */
 int dis_smooth_loss_fwd(const float* disp, const float* amb, double* acc, float* out, int n, int h, int w,
@@ -386,12 +394,28 @@ int dis_colsum(const float* G, int ldG, int goff, long npix, int c, float* out, 
 int dis_sigmoid_affine_fwd(const float* x, float* y, float alpha, float offset, long count, void* stream);
 int dis_sigmoid_affine_bwd(const float* y, const float* gy, float* gpre4, float alpha, long count, void* stream);
 
+/* ---------------------------------------------------------------- augmentation -------------- */
+
+/* Training-time augmentation of the IR and ambient images on the device (reference data/data_manipulation.py:114-195 with
+ * data/dataset.py:67-70: no affine part, 5x5 Gaussian blur sigma in [0.2,0.5], Gaussian noise <= 3/255, salt-and-pepper
+ * <= 5e-4, clip to [0,1]).  im / amb / outputs: (n, h, w) planes.  params: n x 6 floats on the DEVICE
+ * {blur flag, sigma_im, sigma_amb, noise_im, noise_amb, sp_ratio or < 0}; seed: one int64 on the device (both may be
+ * static buffers of a captured step); minmax_ws: 2n uint32 workspace.  Not bit-comparable with numpy's generator by
+ * construction; tests check the distributions. */
+int dis_augment(const float* im, const float* amb, const float* params, const long long* seed, unsigned* minmax_ws,
+                float* out_im, float* out_amb, int n, int h, int w, void* stream);
+
 /* ---------------------------------------------------------------- optimiser ----------------- */
 
 /* torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) on a flat fp32 buffer (reference train_val.py:55-56).
  * step_count is the 1-based step index; grads are multiplied by grad_scale first (1/world_size for DP). */
 int dis_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, float lr,
                   float beta1, float beta2, float eps, int step_count, float grad_scale, void* stream);
+/* The same update with the step counter on the device: state = 4 x 32 bit {int steps taken, float 1-beta1^t,
+ * float sqrt(1-beta2^t), unused}, advanced by the call itself.  Safe to capture in a hipGraph: replay k applies
+ * step k's bias correction (dis_adam_step would replay the capture-time correction). */
+int dis_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, float lr,
+                      float beta1, float beta2, float eps, int* state, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -104,13 +104,17 @@ def maxdiff(a, b):
     return float((a.detach() - b.detach()).abs().max())
 
 
-def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=False, random_batch=False, full_grads=False):
+def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=False, random_batch=False, full_grads=False,
+                  pattern='default', scene='plane', motion=1.0, save_ckpt=False):
     from depthinspace_amd import synth
     from oracle import dis_oracle as O
     H, W = size
-    settings = synth.make_settings(H, W)
-    mk = synth.make_random_batch if random_batch else synth.make_batch
-    batch = mk(settings, bs, 4, seed=bseed, with_pseudo_gt=use_pseudo_gt)
+    settings = synth.make_settings(H, W, pattern=pattern)
+    if random_batch:
+        assert scene == 'plane' and motion == 1.0
+        batch = synth.make_random_batch(settings, bs, 4, seed=bseed, with_pseudo_gt=use_pseudo_gt)
+    else:
+        batch = synth.make_batch(settings, bs, 4, seed=bseed, with_pseudo_gt=use_pseudo_gt, scene=scene, motion=motion)
     shapes = O.mf_param_shapes() if arch == 'multi_frame' else O.sf_param_shapes()
     params = O.init_params(shapes, seed=pseed)
 
@@ -133,12 +137,43 @@ def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=Fals
     w.copy_data(to_torch_batch(batch), 'cpu', False, True)
     opt.zero_grad()
     flow = w.read_optical_flow(True)
-    out = w.net_forward(net, flow)
+    # record what the reference's own torch.topk calls return (Conv3D, multi_frame_networks.py:498): 32 calls per
+    # forward = 4 blocks x (conv3d_1, conv3d_2) x 4 target frames, each (bs*ho*wo, 9, 1)
+    ref_topk = []
+    _topk = torch.topk
+
+    def _rec_topk(*a, **k):
+        r = _topk(*a, **k)
+        ref_topk.append(r[1].detach().clone())
+        return r
+    torch.topk = _rec_topk
+    try:
+        out = w.net_forward(net, flow)
+    finally:
+        torch.topk = _topk
     vals = w.loss_forward(out, True, flow)
     sum(vals).backward()
     ref_grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in net.named_parameters()}
     opt.step()
     ref_new = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    ckpt = None
+    if save_ckpt:
+        # what the reference's Worker.train writes after an epoch (model/worker.py:376-402), here after this one step ...
+        ckpt = {'epoch': epoch, 'min_err': {'simple': 1e9}, 'state_dict': {k: v.clone() for k, v in net.state_dict().items()},
+                'optimizer': opt.state_dict(), 'cpu_rng_state': torch.get_rng_state()}
+        import copy
+        ckpt = copy.deepcopy(ckpt)
+        # ... and what the reference computes in its NEXT step from that state (same batch): pins the resumed optimiser
+        w.copy_data(to_torch_batch(batch), 'cpu', False, True)
+        opt.zero_grad()
+        flow2 = w.read_optical_flow(True)
+        out2 = w.net_forward(net, flow2)
+        vals2 = w.loss_forward(out2, True, flow2)
+        sum(vals2).backward()
+        opt.step()
+        step2 = {'vals': np.array([float(v) for v in vals2], dtype=np.float64),
+                 'out0': (out2[0] if isinstance(out2, (list, tuple)) else out2).detach().numpy().copy(),
+                 'new': {k: v.detach().clone().numpy() for k, v in net.state_dict().items() if v.numel() <= 4096}}
     ref_data = {k: v.detach().clone() for k, v in w.data.items() if k in ('im0', 'std0')}
     outs = out if isinstance(out, (list, tuple)) else [out]
 
@@ -165,7 +200,8 @@ def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=Fals
     print(f'[{arch} {H}x{W} bs={bs} epoch={epoch} pgt={use_pseudo_gt} rnd={random_batch}] oracle-vs-reference:', rep)
 
     fx = {'arch': arch, 'H': H, 'W': W, 'bs': bs, 'pseed': pseed, 'bseed': bseed, 'epoch': epoch,
-          'use_pseudo_gt': int(use_pseudo_gt), 'random_batch': int(random_batch),
+          'use_pseudo_gt': int(use_pseudo_gt), 'random_batch': int(random_batch), 'pattern': pattern, 'scene': scene,
+          'motion': float(motion),
           'vals': np.array([float(v) for v in vals], dtype=np.float64)}
     for i, o in enumerate(outs):
         fx[f'out{i}'] = o.detach().numpy()
@@ -182,6 +218,14 @@ def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=Fals
             for b in range(1, 4):
                 assert bool((torch.sort(per_block[b], -1)[0] == torch.sort(per_block[0], -1)[0]).all())
             fx[f'knn_idx_{tag}'] = per_block[0].numpy().astype(np.uint8)
+            # ... and they ARE the reference module's own torch.topk output, element for element and in its order
+            # (the checkpointed reference forward is not re-run here: 32 recorded calls, block-major, layer, target)
+            assert len(ref_topk) == 32, len(ref_topk)
+            li = 0 if lname == 'conv3d_1' else 1
+            for b in range(4):
+                for ti in range(4):
+                    r = ref_topk[b * 8 + li * 4 + ti]
+                    assert bool((r.view(per_block[b][ti].shape) == per_block[b][ti]).all()), (lname, b, ti)
             keysrt = torch.sort(torch.stack([c['key'] for c in tap if c['name'] == f'blocks.0.{lname}'], 0), -1)[0]
             k9, k10 = keysrt[..., 8].double(), keysrt[..., 9].double()
             fx[f'knn_margin_{tag}'] = ((k10 - k9) / torch.clamp(k10, min=1e-30)).float().numpy()
@@ -226,6 +270,12 @@ def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=Fals
         if full_grads or g.numel() <= 4096:
             fx['grad:' + k] = g.numpy()
             fx['new:' + k] = ref_new[k].numpy()
+    if ckpt is not None:
+        fx['step2_vals'] = step2['vals']
+        fx['step2_out0'] = step2['out0']
+        for k, v in step2['new'].items():
+            fx['step2_new:' + k] = v
+        fx['_ckpt'] = ckpt
     return fx, rep
 
 
@@ -369,6 +419,19 @@ def op_goldens(ref):
         rep[f'ge_{nm}'] = max(abs(float(val) - float(v2)), maxdiff(dd.grad, d3.grad))
     fx['ge_disp'] = disp_pert.numpy()
     fx['ge_seed'] = 3
+    # evaluation metrics of test_epoch / retest (reference co/metric.py:104-154, as the workers construct them,
+    # model/multi_frame_worker.py:236-240): three add() calls of unequal length, values in disparity range
+    import co.metric as RM
+    met = RM.MultipleMetric(RM.DistanceMetric(vec_length=1),
+                            RM.OutlierFractionMetric(vec_length=1, thresholds=[0.1, 0.5, 1, 2, 5]))
+    for k in range(3):
+        es = (torch.rand(1500 + 37 * k, 1, generator=g) * 8).numpy()
+        gt = (es + (torch.randn(es.shape, generator=g) * (0.05 + 0.6 * k)).numpy()).astype(np.float32)
+        met.add(es, gt)
+        fx[f'met_es{k}'], fx[f'met_gt{k}'] = es, gt
+    vals = met.get()
+    fx['met_keys'] = np.array(list(vals.keys()))
+    fx['met_vals'] = np.array([vals[k] for k in vals], dtype=np.float64)
     print('[ops] oracle-vs-reference:', rep)
     return fx, rep
 
@@ -382,16 +445,29 @@ def main():
     np.savez_compressed(os.path.join(GOLD, 'ops.npz'), **fx)
     cases = [
         ('mf_64_bs1', dict(arch='multi_frame', size=(64, 64), bs=1, pseed=11, bseed=1234, epoch=0, full_grads=True)),
-        ('mf_64_bs2_rnd', dict(arch='multi_frame', size=(64, 64), bs=2, pseed=12, bseed=99, epoch=2, random_batch=True)),
+        ('mf_64_bs2_rnd', dict(arch='multi_frame', size=(64, 64), bs=2, pseed=12, bseed=99, epoch=2, random_batch=True,
+                               save_ckpt=True)),
         ('mf_128_bs1', dict(arch='multi_frame', size=(128, 128), bs=1, pseed=13, bseed=1234, epoch=2)),
         ('sf_64_bs1', dict(arch='single_frame', size=(64, 64), bs=1, pseed=21, bseed=1234)),
         ('sf_128_bs1_pgt', dict(arch='single_frame', size=(128, 128), bs=1, pseed=22, bseed=1234, use_pseudo_gt=True)),
+        # crop_like trims here (reference model/networks.py:242-263): W 108 -> 54 -> 27 -> 14 -> 7 -> 4 -> 2 -> 1, so upconv
+        # outputs 28 -> 27 and 8 -> 7 (and 2 -> 1 at the deepest level) are cut exactly as at 512x432
+        ('sf_128x108_bs1', dict(arch='single_frame', size=(128, 108), bs=1, pseed=23, bseed=77)),
+        # non-degenerate scene: non-planar surface, 1.5x camera motion (few exactly tied top-k keys)
+        ('mf_128_bumps', dict(arch='multi_frame', size=(128, 128), bs=1, pseed=14, bseed=4321, epoch=2, scene='bumps',
+                              motion=1.5)),
+        # BASELINE config 5: DIS-FTSF (pseudo-GT) on the real pattern, K_processed, baseline 0.0246
+        ('sf_128_real_pgt', dict(arch='single_frame', size=(128, 128), bs=1, pseed=24, bseed=555, use_pseudo_gt=True,
+                                 pattern='real')),
     ]
     only = sys.argv[1:]
     for name, kw in cases:
         if only and name not in only:
             continue
         fx, rep = run_step_case(ref, **kw)
+        ckpt = fx.pop('_ckpt', None)
+        if ckpt is not None:  # a reference-format state.dict (torch.save, like model/worker.py:387-389)
+            torch.save(ckpt, os.path.join(GOLD, name + '_ref_state.dict'))
         np.savez_compressed(os.path.join(GOLD, name + '.npz'), **fx)
         print(name, 'written', os.path.getsize(os.path.join(GOLD, name + '.npz')) // 1024, 'KiB')
 

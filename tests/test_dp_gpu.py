@@ -1,0 +1,149 @@
+"""Data parallelism through the real entry-point classes on the GPU: 2 ranks (gloo; both on the one GPU of the test box, the
+collective's transport is not what is tested) run Worker.train_step with trainer.FlatAdam's bucketed, overlapped all-reduce.
+The reduced gradient must equal the sum of the two ranks' single-process gradients (DDP semantics: per-rank masked-mean
+losses, mean of the gradients - SURVEY.md section 8(e)), buckets must be in flight before backward returns, replicas must
+stay identical, and the hipGraph form of the step (trainer.GraphedStep, two backward segments with the tail bucket
+reduced underneath the second) must land on the same parameters as the eager form."""
+import argparse
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _args(arch, bs):
+    return argparse.Namespace(use_pseudo_gt=False, lcn_radius=5, track_length=4, data_type='synthetic', architecture=arch,
+                              epochs=1, warmup_epochs=150, train_batch_size=bs, max_disp=128)
+
+
+def _rank(rank, world, port, arch, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'] = str(rank), str(world), '0'
+    try:
+        from depthinspace_amd.trainer import FlatAdam, GraphedStep, init_distributed
+        assert init_distributed('gloo') == (rank, world, 0)
+        from depthinspace_amd import synth
+        from depthinspace_amd.model import multi_frame_networks, multi_frame_worker, single_frame_worker, networks
+        H = W = 64
+        settings = synth.make_settings(H, W)
+        torch.manual_seed(0)
+        if arch == 'multi_frame':
+            w = multi_frame_worker.Worker(_args(arch, 1), settings=settings)
+            net = multi_frame_networks.FuseNet((H, W), settings.K, settings.baseline).cuda()
+        else:
+            w = single_frame_worker.Worker(_args(arch, 1), settings=settings)
+            net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=w.imsizes).cuda()
+        assert (w.rank, w.world_size, w.is_main) == (rank, world, rank == 0)
+        w.build_losses()
+        w.current_epoch = 2
+        opt = FlatAdam(net.parameters(), lr=1e-4, bucket_mb=(0.25 if arch == 'multi_frame' else 16.0))
+        assert opt.world_size == world and opt.overlap and len(opt.buckets) >= 3
+        batches = [{k: torch.from_numpy(v) for k, v in synth.make_batch(settings, 1, 4, seed=1234 + r).items()}
+                   for r in range(world)]
+
+        def local_grads():
+            opt.overlap = False   # plain single-process backward passes, no collective
+            gs = []
+            for r in range(world):
+                w.copy_data(batches[r], device=w.train_device, requires_grad=False, train=True)
+                opt.zero_grad()
+                flow = w.read_optical_flow(True)
+                sum(w.loss_forward(w.net_forward(net, flow), True, flow)).backward()
+                gs.append(opt.flat_g.clone())
+            opt.overlap = True
+            return gs
+
+        def close(a, b):
+            scale = float(b.abs().max()) + 1e-20
+            return float((a - b).abs().max()) / scale
+
+        res = {}
+        early = []
+        for step in range(3):
+            gs = local_grads()
+            opt.zero_grad()
+            # ---- the product's step; peek at the bucket state between backward and the optimiser
+            orig = opt.step
+            def spy(all_reduce=True):
+                early.append(sum(opt._reduced))
+                return orig(all_reduce)
+            opt.step = spy
+            w.train_step(net, opt, batches[rank])
+            opt.step = orig
+            torch.cuda.synchronize()
+            res[f'grad_err{step}'] = close(opt.flat_g, gs[0] + gs[1])
+        res['early'] = early
+        res['nbuckets'] = len(opt.buckets)
+        # identical replicas
+        chk = torch.stack([opt.flat_p.double().sum(), opt.flat_p.double().abs().sum()])
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        res['replicas_equal'] = bool(torch.equal(both[0], both[1]))
+        res['steps'] = opt.step_count
+        # ---- hipGraph form of the same DP step vs the eager form, from the same state
+        snap = [t.clone() for t in (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev)]
+        for _ in range(2):
+            w.train_step(net, opt, batches[rank])
+        torch.cuda.synchronize()
+        p_eager = opt.flat_p.clone()
+        for t, c in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev), snap):
+            t.copy_(c)
+        gstep = GraphedStep(w, net, opt, batches[rank], use_graph=True, warmup=1)
+        # (the capture's eager warm-up step is a real step: undo it so both forms take exactly two steps)
+        gstep.run()
+        torch.cuda.synchronize()
+        for t, c in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev), snap):
+            t.copy_(c)
+        for _ in range(2):
+            gstep.run()
+        torch.cuda.synchronize()
+        res['graph_mode'] = gstep.mode
+        res['graph_vs_eager'] = float((opt.flat_p - p_eager).abs().max())
+        res['graph_steps'] = opt.step_count
+        q.put((rank, res))
+    except Exception as e:
+        import traceback
+        q.put((rank, {'error': traceback.format_exc()}))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('arch', ['multi_frame', 'single_frame'])
+def test_two_rank_train_step(arch):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, world, port, arch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    for r in range(world):
+        assert 'error' not in res[r], res[r]['error']
+        # reduced gradient == sum of the ranks' own gradients (float atomics in two scatter kernels: tolerance, not bits)
+        for step in range(3):
+            assert res[r][f'grad_err{step}'] < 2e-5, (r, step, res[r])
+        # step 0 learns the notification pattern; from step 1 on (almost) every bucket is in flight before backward returns
+        assert res[r]['early'][0] == 0 and all(e >= res[r]['nbuckets'] - 1 for e in res[r]['early'][1:]), res[r]
+        assert res[r]['replicas_equal'] and res[r]['steps'] == 3
+        assert res[r]['graph_mode'] == ('graph-2seg' if arch == 'multi_frame' else 'graph-1seg'), res[r]
+        assert res[r]['graph_vs_eager'] < 5e-6 and res[r]['graph_steps'] == 5, res[r]
+    print(arch, res[0])

@@ -200,40 +200,73 @@ def test_gather_warped_feat():
     assert torch.equal(grads[0], grads[1])
 
 
-def test_mf_geometry_and_mask_weight():
+@pytest.mark.parametrize('cfg', [(64, 48, 2, 8, True, {}), (128, 128, 1, 4321, False, dict(scene='bumps', motion=1.5)),
+                                 (256, 216, 1, 5, False, {})])
+def test_mf_geometry_masks_and_selection_bit_exact(cfg):
+    """Index-class outputs of FuseNet's parameter-free part: the geometry pyramids, the fb masks and Conv3D's neighbour
+    sets of the HIP path equal tests/bitexact.py (the rounding-exact numpy statement, itself equal to the oracle and to
+    the reference's torch.topk output: tests/test_bitexact_cpu.py) BIT FOR BIT - no tolerance, no excluded near-ties.
+    (64x48 -> 32x24 / 16x12 runs ATen's small-output resize arithmetic, 256x216 -> 128x108 / 64x54 the generic one.)"""
     from depthinspace_amd import ops, synth, lib
-    st = synth.make_settings(64, 48)
-    b = synth.make_random_batch(st, 2, 4, seed=8)
+    from tests import bitexact as B
+    H, W, bs, seed, rnd, kw = cfg
+    st = synth.make_settings(H, W)
+    b = synth.make_random_batch(st, bs, 4, seed=seed) if rnd else synth.make_batch(st, bs, 4, seed=seed, **kw)
     tb = {k: torch.from_numpy(v).transpose(0, 1).contiguous() if v.ndim > 2 else torch.from_numpy(v) for k, v in b.items()}
-    tl, bs, H, W = 4, 2, 64, 48
+    tl = 4
     h, w = H // 2, W // 2
-    depth = O.disp_to_depth(tb['primary_disp'], float(st.K[0, 0]), st.baseline)
-    depth_core = O.resize_ac(depth, (h, w))
+    bf = float(st.K[0, 0]) * st.baseline
+    eq = np.array_equal
+    # disparity -> depth -> core depth / core flows
+    depth = ops.disp_to_depth(tb['primary_disp'].cuda(), bf)
+    e_depth = B.disp_to_depth(tb['primary_disp'].numpy(), float(st.K[0, 0]), st.baseline)
+    assert eq(depth.cpu().numpy(), e_depth)
+    depth_core = ops.resize_planar(depth.view(tl, bs, H, W), (h, w), True)
+    e_dc = B.resize_ac(e_depth, h, w)
+    assert eq(depth_core.cpu().numpy(), e_dc[:, :, 0])
     flow = {k: v[0] for k, v in tb.items() if k.startswith('flow_')}
-    flow_core = O.resize_flow(flow, (h, w))
-    wxyz, wmask = O.mf_geometry(depth_core, O.mf_core_rays(st.K, H, W), tb['R'], tb['t'], flow_core)
-    fl = _stack_flows(flow_core, tl, bs, h, w).permute(0, 1, 3, 4, 2).contiguous().cuda()
+    ff = _stack_flows(flow, tl, bs, H, W).cuda()
+    fc_p = ops.resize_planar(ff, (h, w), True, flow_scale=(float(w) / float(W), float(h) / float(H)))
+    e_fc = {k: B.resize_flow(v.numpy(), h, w) for k, v in flow.items()}
+    for i in range(tl):
+        for j in range(tl):
+            if i != j:
+                assert eq(fc_p[i * tl + j].cpu().numpy(), e_fc[f'flow_{i}{j}']), (i, j)
+    # geometry + masks
+    fl = ops.planar_to_nhwc(fc_p.view(tl * tl * bs, 2, h, w)).view(tl * tl, bs, h, w, 2)
     Ki = lib.host_floats(np.linalg.inv(st.K).reshape(-1))
-    geom = ops.mf_geometry(depth_core[:, :, 0].contiguous().cuda(), tb['R'].cuda(), tb['t'].cuda(), fl, Ki, 2, 2)
-    gx = geom[..., :3].permute(0, 4, 1, 5, 2, 3).cpu()  # (tl,slot,bs,3,h,w)
-    gm = geom[..., 3].permute(0, 4, 1, 2, 3).unsqueeze(3).cpu()  # (tl,slot,bs,1,h,w)
-    assert relerr(gx, wxyz) < 2e-6
-    assert float((gm != wmask).float().mean()) < 1e-3
+    geom = ops.mf_geometry(depth_core, tb['R'].cuda(), tb['t'].cuda(), fl, Ki, W // w, H // h)
+    ex, em = B.mf_geometry(e_dc, O.mf_core_rays(st.K, H, W).numpy(), tb['R'].numpy(), tb['t'].numpy(), e_fc)
+    gx = geom[..., :3].permute(0, 4, 1, 5, 2, 3).cpu().numpy()  # (tl,slot,bs,3,h,w)
+    gm = geom[..., 3].permute(0, 4, 1, 2, 3).unsqueeze(3).cpu().numpy()  # (tl,slot,bs,1,h,w)
+    assert eq(gm, em), float((gm != em).mean())
+    assert eq(gx, ex), float((gx != ex).mean())
+    # the oracle agrees too (it does on any host whose torch build rounds like the fixture host's)
+    depth_o = O.disp_to_depth(tb['primary_disp'], float(st.K[0, 0]), st.baseline)
+    wxyz, wmask = O.mf_geometry(O.resize_ac(depth_o, (h, w)), O.mf_core_rays(st.K, H, W), tb['R'], tb['t'],
+                                O.resize_flow(flow, (h, w)))
+    host_same = eq(wxyz.numpy(), ex)
+    assert eq(wmask.numpy(), em) or not host_same
+    if not host_same:
+        print('note: this host rounds torch CPU kernels differently from the fixture host; oracle agreement skipped')
+        assert relerr(torch.from_numpy(gx), wxyz) < 2e-6
     # quarter resolution
-    q = (h // 2, w // 2)
-    gq = ops.mf_geometry_resize(geom, q)
-    rx = O.resize_ac(wxyz, q)
-    rm = (O.resize_ac(wmask, q) > 0.5).float()
-    assert relerr(gq[..., :3].permute(0, 4, 1, 5, 2, 3).cpu(), rx) < 2e-6
-    assert float((gq[..., 3].permute(0, 4, 1, 2, 3).unsqueeze(3).cpu() != rm).float().mean()) < 1e-3
+    hq, wq = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    gq = ops.mf_geometry_resize(geom, (hq, wq))
+    exq = B.resize_ac(ex, hq, wq)
+    emq = (B.resize_ac(em, hq, wq) > 0.5).astype(np.float32)
+    assert eq(gq[..., :3].permute(0, 4, 1, 5, 2, 3).cpu().numpy(), exq)
+    assert eq(gq[..., 3].permute(0, 4, 1, 2, 3).unsqueeze(3).cpu().numpy(), emq)
+    # Conv3D neighbour sets: torch.topk's ids in torch.topk's order
+    assert eq(ops.conv3d_select(geom, 2).cpu().numpy(), B.conv3d_select(ex, em, 2))
+    assert eq(ops.conv3d_select(gq, 1).cpu().numpy(), B.conv3d_select(exq, emq, 1))
     # slot weighting
     g = torch.Generator().manual_seed(1)
     wf = torch.randn(tl, tl, bs, 8, h, w, generator=g)
-    ref = wf * wmask / wmask.mean(dim=1, keepdim=True)
+    wm = torch.from_numpy(em)
+    ref = wf * wm / wm.mean(dim=1, keepdim=True)
     out = ops.mask_weight_slots(wf.permute(0, 2, 4, 5, 1, 3).contiguous().cuda(), geom)
-    msk_ok = (gm == wmask).all()
-    if bool(msk_ok):
-        assert relerr(out.permute(0, 4, 1, 5, 2, 3), ref) < 1e-6
+    assert relerr(out.permute(0, 4, 1, 5, 2, 3), ref) < 1e-6
 
 
 @pytest.mark.parametrize('stride', [1, 2])
@@ -263,7 +296,7 @@ def test_conv3d_golden(golden_dir, stride):
     assert relerr(out[1].permute(0, 3, 1, 2), ref) < 2e-5
     assert float(G[f'c3_s{stride}_margin_min']) > 0  # goldens have no top-k ties
     sel = np.sort(idx[1].cpu().numpy().astype(np.int16), axis=-1)
-    assert (sel == G[f'c3_s{stride}_idx_sorted']).mean() > 0.9999
+    assert np.array_equal(sel, G[f'c3_s{stride}_idx_sorted'])  # every neighbour set, exactly
     gfeat = torch.from_numpy(G[f'c3_s{stride}_gfeat'])  # (tl(slot),bs,C,h,w)
     assert relerr(wf.grad[1].permute(3, 0, 4, 1, 2), gfeat) < 5e-5
     for k_ in ('w', 'dense1.0.weight', 'dense1.0.bias', 'dense2.0.weight', 'dense2.0.bias', 'bn.weight', 'bn.bias'):
@@ -306,6 +339,63 @@ def test_adam_matches_torch():
         opt.step()
         ops.adam_step(pd, gr.cuda(), m, v, step)
         assert float((pd.cpu() - pr.detach()).abs().max()) < 2e-7
+
+
+def test_adam_graph_replay_matches_torch():
+    """ONE captured optimiser step replayed k times == k steps of torch.optim.Adam: the step counter and the bias
+    corrections live on the device (dis_adam_step_dev), so replay k applies step k's correction.  Also FlatAdam's
+    state_dict round-trips through torch.optim.Adam's own layout."""
+    from depthinspace_amd.trainer import FlatAdam
+    g = torch.Generator().manual_seed(4)
+    shapes = [(8, 4, 3, 3), (8,), (33,)]
+    ps = [torch.randn(s_, generator=g) for s_ in shapes]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    topt = torch.optim.Adam(ref, lr=1e-3)
+    mine = [torch.nn.Parameter(p.clone().cuda()) for p in ps]
+    opt = FlatAdam(mine, lr=1e-3)
+    grads = [[torch.randn(s_, generator=g) * 10 ** (-k) for s_ in shapes] for k in range(6)]
+    gin = torch.zeros_like(opt.flat_g)   # static input of the captured step
+
+    def load(k):
+        gin[:opt.n].copy_(torch.cat([t.reshape(-1) for t in grads[k]]).cuda())
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # one eager step (k = 0) before the capture, as in bench.py
+        load(0)
+        opt.flat_g.copy_(gin)
+        opt.step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    load(1)
+    with torch.cuda.graph(graph):
+        opt.flat_g.copy_(gin)
+        opt.step(all_reduce=False)
+    for k in range(2, 5):   # the capture itself executed nothing: replays are steps 2, 3, 4 (k = 1 .. 3 of the data)
+        load(k - 1)
+        graph.replay()
+    torch.cuda.synchronize()
+    assert opt.step_count == 4
+    for k in range(4):
+        for r, gr in zip(ref, grads[k]):
+            r.grad = gr.clone()
+        topt.step()
+    for a, b in zip(mine, ref):
+        assert float((a.detach().cpu() - b.detach()).abs().max()) < 5e-7
+    # state_dict in torch.optim.Adam's layout: loads into torch.optim.Adam and back
+    sd = opt.state_dict()
+    t2 = torch.optim.Adam([p.clone().requires_grad_(True) for p in ps], lr=1e-3)
+    t2.load_state_dict({'state': {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+                                  for k, v in sd['state'].items()}, 'param_groups': sd['param_groups']})
+    tsd = topt.state_dict()
+    for i in range(len(shapes)):
+        assert float((sd['state'][i]['exp_avg'].cpu() - tsd['state'][i]['exp_avg']).abs().max()) < 1e-7
+        assert float(sd['state'][i]['step']) == float(tsd['state'][i]['step']) == 4.0
+    opt2 = FlatAdam([torch.nn.Parameter(p.clone().cuda()) for p in ps], lr=1e-3)
+    opt2.load_state_dict(tsd)   # a reference-format optimizer state (torch.optim.Adam.state_dict())
+    assert opt2.step_count == 4
+    assert float((opt2.exp_avg[:opt2.n] - opt.exp_avg[:opt.n]).abs().max()) < 1e-7
+    assert float((opt2.exp_avg_sq[:opt2.n] - opt.exp_avg_sq[:opt.n]).abs().max()) < 1e-9
 
 
 @pytest.mark.parametrize('h,w', [(37, 45), (64, 48)])

@@ -163,3 +163,39 @@ def test_geo_loss_golden(G, mode):
     ref = torch.from_numpy(G[f'ge_{mode}_grad'])
     scale = float(ref.abs().max())
     close(disp.grad, ref, 2e-5 * scale, 1e-4, what='grad')
+
+
+@pytest.mark.parametrize('cfg', [(48, 56, 2, 3, True), (64, 64, 1, 1234, False), (130, 94, 1, 7, True)])
+@pytest.mark.parametrize('mode', ['mf', 'sf'])
+def test_geo_loss_masks_bit_exact(cfg, mode):
+    """The fb / vc / rf masks of the flow-consistency losses (reference model/networks.py:584-595, 644-651) are index-class
+    outputs: the HIP kernel's mask equals tests/bitexact.py (== the oracle, tests/test_bitexact_cpu.py) on EVERY pixel."""
+    from depthinspace_amd import ops, synth, lib
+    from tests import bitexact as B
+    H, W, bs, seed, rnd = cfg
+    st = synth.make_settings(H, W)
+    b = (synth.make_random_batch if rnd else synth.make_batch)(st, bs, 4, seed=seed)
+    tb = {k: torch.from_numpy(v).transpose(0, 1).contiguous() if v.ndim > 2 else torch.from_numpy(v) for k, v in b.items()}
+    K = lib.host_floats(st.K.reshape(-1))
+    Ki = lib.host_floats(np.linalg.inv(st.K).reshape(-1))
+    bf = float(st.K[0, 0]) * st.baseline
+    g = torch.Generator().manual_seed(5)
+    disp = tb['disp0'] + 0.05 * torch.randn(tb['disp0'].shape, generator=g)
+    depth = ops.disp_to_depth(disp.cuda(), bf)
+    pdepth = ops.disp_to_depth(tb['primary_disp'].cuda(), bf)
+    e_depth = B.disp_to_depth(disp.numpy(), float(st.K[0, 0]), st.baseline)
+    e_pdepth = B.disp_to_depth(tb['primary_disp'].numpy(), float(st.K[0, 0]), st.baseline)
+    assert np.array_equal(depth.cpu().numpy(), e_depth)
+    ray = O.make_rays(st.K, H, W).numpy()
+    c = lambda t: t.contiguous().cuda()
+    R, t = tb['R'].cuda(), tb['t'].cuda()
+    for i, j in ((0, 1), (2, 0), (3, 2)):
+        f0, f1 = tb[f'flow_{i}{j}'][0], tb[f'flow_{j}{i}'][0]
+        a0, a1 = tb['ambient0'][i], tb['ambient0'][j]
+        _, mask = ops.geo_loss_dir(depth[i], depth[j], c(f0), c(f1), c(a0), c(a1), pdepth[j] if mode == 'mf' else None,
+                                   R[i], t[i], R[j], t[j], K, Ki, -1.0 if mode == 'mf' else 0.1)
+        m, _ = B.flow_consistency_mask(st.K, ray, e_depth[i], tb['R'][i].numpy(), tb['t'][i].numpy(), tb['R'][j].numpy(),
+                                       tb['t'][j].numpy(), f0.numpy(), f1.numpy(), a0.numpy(), a1.numpy(),
+                                       primary_depth1=e_pdepth[j] if mode == 'mf' else None)
+        assert np.array_equal(mask.cpu().numpy(), m), (i, j, float((mask.cpu().numpy() != m).mean()))
+        assert 0.02 < float(m.mean()) < 0.999 or not rnd  # the random batch exercises both outcomes

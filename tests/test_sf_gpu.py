@@ -175,15 +175,19 @@ def make_args(bs, use_pseudo_gt):
                               max_disp=128)
 
 
-@pytest.mark.parametrize('name', ['sf_64_bs1', 'sf_128_bs1_pgt'])
+@pytest.mark.parametrize('name', ['sf_64_bs1', 'sf_128_bs1_pgt', 'sf_128x108_bs1', 'sf_128_real_pgt'])
 def test_sf_step_matches_reference(golden_dir, name):
+    """whole DIS-SF / DIS-FTSF step vs fixtures generated by the imported reference.  sf_128x108_bs1: widths
+    108,54,27,14,7,4,2,1 - crop_like (reference model/networks.py:242-263) trims 28->27, 8->7 and 2->1 exactly as at
+    512x432.  sf_128_real_pgt: BASELINE config 5 (real pattern, K_processed, baseline 0.0246, pseudo-GT terms)."""
     from depthinspace_amd import synth
     from depthinspace_amd.model import networks, single_frame_worker
     from depthinspace_amd.trainer import FlatAdam
     G = np.load(os.path.join(golden_dir, name + '.npz'))
     H, W, bs, pgt = int(G['H']), int(G['W']), int(G['bs']), bool(int(G['use_pseudo_gt']))
-    settings = synth.make_settings(H, W)
-    batch = synth.make_batch(settings, bs, 4, seed=int(G['bseed']), with_pseudo_gt=pgt)
+    settings = synth.make_settings(H, W, pattern=str(G['pattern']))
+    batch = synth.make_batch(settings, bs, 4, seed=int(G['bseed']), with_pseudo_gt=pgt, scene=str(G['scene']),
+                             motion=float(G['motion']))
     params = O.init_params(O.sf_param_shapes(), seed=int(G['pseed']))
     w = single_frame_worker.Worker(make_args(bs, pgt), settings=settings)
     w.build_losses()

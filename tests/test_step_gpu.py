@@ -16,23 +16,31 @@ def make_args(arch, bs):
                               architecture=arch, epochs=1, warmup_epochs=150, train_batch_size=bs, max_disp=128)
 
 
-def run_hip_step(G, force_reference_knn=True):
+def golden_batch(G):
+    """regenerate the fixture's inputs from its seeds / recipe fields"""
     from depthinspace_amd import synth
+    H, W, bs = int(G['H']), int(G['W']), int(G['bs'])
+    settings = synth.make_settings(H, W, pattern=str(G['pattern']))
+    pgt = bool(int(G['use_pseudo_gt']))
+    if int(G['random_batch']):
+        batch = synth.make_random_batch(settings, bs, 4, seed=int(G['bseed']), with_pseudo_gt=pgt)
+    else:
+        batch = synth.make_batch(settings, bs, 4, seed=int(G['bseed']), with_pseudo_gt=pgt, scene=str(G['scene']),
+                                 motion=float(G['motion']))
+    return settings, batch
+
+
+def run_hip_step(G, force_reference_knn=False):
     from depthinspace_amd.model import multi_frame_networks, multi_frame_worker
     from depthinspace_amd.trainer import FlatAdam
     H, W, bs = int(G['H']), int(G['W']), int(G['bs'])
-    settings = synth.make_settings(H, W)
-    mk = synth.make_random_batch if int(G['random_batch']) else synth.make_batch
-    batch = mk(settings, bs, 4, seed=int(G['bseed']))
+    settings, batch = golden_batch(G)
     params = O.init_params(O.mf_param_shapes(), seed=int(G['pseed']))
     net = multi_frame_networks.FuseNet(imsize=(H, W), K=settings.K, baseline=settings.baseline, track_length=4,
                                        max_disp=128)
     net.load_state_dict({k: v.detach() for k, v in params.items()})
     net = net.cuda()
-    if force_reference_knn:
-        # Conv3D's top-9 is ill-conditioned in the reference itself (a 2e-7 input perturbation moves the
-        # reference's own output by `ulp_sens_free`, see oracle/make_golden.py and DESIGN.md); arithmetic parity is
-        # therefore pinned with the reference's neighbour sets, and the HIP selection is tested separately below.
+    if force_reference_knn:  # diagnostic only: no test uses it (the HIP selection IS the reference's, see below)
         net.knn_index_override = (torch.from_numpy(G['knn_idx_core']).cuda(), torch.from_numpy(G['knn_idx_quarter']).cuda())
     w = multi_frame_worker.Worker(make_args('multi_frame', bs), settings=settings)
     w.build_losses()
@@ -43,10 +51,18 @@ def run_hip_step(G, force_reference_knn=True):
     return net, opt, errs, out
 
 
-@pytest.mark.parametrize('name', ['mf_64_bs1', 'mf_64_bs2_rnd', 'mf_128_bs1'])
+MF_GOLDENS = ['mf_64_bs1', 'mf_64_bs2_rnd', 'mf_128_bs1', 'mf_128_bumps']
+
+
+@pytest.mark.parametrize('name', MF_GOLDENS)
 def test_mf_step_matches_reference(golden_dir, name):
+    """FREE-RUNNING: nothing from the oracle or the goldens is injected into the HIP step."""
     G = np.load(os.path.join(golden_dir, name + '.npz'))
     net, opt, errs, out = run_hip_step(G)
+    assert net.knn_index_override is None
+    # (i) index-class output: Conv3D's neighbour ids == the reference module's own torch.topk output, every id, in order
+    assert np.array_equal(net.last_knn_index[0].cpu().numpy(), G['knn_idx_core'])
+    assert np.array_equal(net.last_knn_index[1].cpu().numpy(), G['knn_idx_quarter'])
     # (ii) network output: disparity L1 vs reference < 1e-4 (north-star tolerance)
     ref_out = torch.from_numpy(G['out0'])
     l1 = float((out.detach().cpu() - ref_out).abs().mean())
@@ -83,23 +99,3 @@ def test_mf_step_matches_reference(golden_dir, name):
     print(name, 'disp L1', l1, 'max', mx, 'worst grad rel err', worst)
 
 
-@pytest.mark.parametrize('name', ['mf_64_bs1', 'mf_64_bs2_rnd', 'mf_128_bs1'])
-def test_mf_free_running_knn_selection(golden_dir, name):
-    """HIP neighbour selection on its own geometry vs the reference's: identical wherever the reference's top-9
-    is well conditioned (relative gap between the 9th and 10th key > 1e-3); the free-running output stays within
-    a small multiple of the reference's own sensitivity to a 1-ulp input perturbation."""
-    G = np.load(os.path.join(golden_dir, name + '.npz'))
-    net, opt, errs, out = run_hip_step(G, force_reference_knn=False)
-    for tag, k in (('core', 0), ('quarter', 1)):
-        mine = np.sort(net.last_knn_index[k].cpu().numpy(), axis=-1)
-        ref = np.sort(G[f'knn_idx_{tag}'], axis=-1)
-        same = (mine == ref).all(axis=-1)
-        good = G[f'knn_margin_{tag}'] > 1e-3
-        assert same[good].all(), (tag, float(same[good].mean()))
-        print(name, tag, 'agreement overall', float(same.mean()), 'well-conditioned fraction', float(good.mean()))
-    ref_out = torch.from_numpy(G['out0'])
-    l1 = float((out.detach().cpu() - ref_out).abs().mean())
-    mx = float((out.detach().cpu() - ref_out).abs().max())
-    sens_l1, sens_max = [float(v) for v in G['ulp_sens_free']]
-    print(name, 'free-running disp L1', l1, 'max', mx, '| reference 1-ulp sensitivity L1', sens_l1, 'max', sens_max)
-    assert l1 < 10 * sens_l1 + 1e-4, (l1, sens_l1)

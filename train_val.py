@@ -2,8 +2,17 @@
 
     python train_val.py --architecture multi_frame|single_frame --train_batch_size 4 [--cmd retrain|resume|retest|test_init]
 
-Without a DATA_DIR/settings.pkl (config.json) it trains on the in-memory synthetic default-pattern scenes of
-`depthinspace_amd.synth` (the reference's HDF5 dataset layer is out of scope)."""
+With a config.json (DATA_DIR, OUTPUT_DIR) it trains on the tracks under DATA_DIR (the reference's on-disk schema, .npz
+mirror: depthinspace_amd/data/dataset.py), which is how the three stages chain: DIS-SF -> presave_disp -> DIS-MF ->
+presave_disp -> DIS-FTSF.  Without one it trains on the in-memory synthetic default-pattern scenes of
+`depthinspace_amd.synth` (demo / smoke runs).
+
+Data parallel (new; the reference is single-GPU): one process per GPU,
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train_val.py --architecture ...
+
+every rank trains on its own shard of the tracks, gradients are all-reduced over RCCL (bucketed, overlapped with the
+backward pass), rank 0 writes the checkpoints.  DIS_TRAIN_GRAPH=1 captures the step in hipGraphs."""
 import os
 import sys
 
@@ -12,12 +21,13 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 from depthinspace_amd.co.args import parse_args
 from depthinspace_amd.model import multi_frame_worker, multi_frame_networks, single_frame_worker, networks
-from depthinspace_amd.trainer import FlatAdam
+from depthinspace_amd.trainer import FlatAdam, init_distributed
 from depthinspace_amd import synth
 
 
 def main():
     args = parse_args()
+    rank, world, local_rank = init_distributed()  # before the first HIP call of the process
     if args.use_pseudo_gt and args.architecture != 'single_frame':
         print('Using pseudo-gt is only possible in single-frame architecture')
         raise NotImplementedError
@@ -32,8 +42,10 @@ def main():
         net = multi_frame_networks.FuseNet(imsize=worker.imsizes[0], K=worker.K, baseline=worker.baseline,
                                            track_length=worker.track_length,
                                            max_disp=args.max_disp).to(worker.train_device)
-    optimizer = FlatAdam(net.parameters(), lr=1e-4)
+    optimizer = FlatAdam(net.parameters(), lr=1e-4)   # world size / process group from torch.distributed
     worker.do(net, optimizer, cmd=args.cmd, epoch=args.epoch)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':
