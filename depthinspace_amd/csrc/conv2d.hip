@@ -1463,14 +1463,15 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
                                                              int cout, int cin_real, int partsz,
                                                              const float* __restrict__ bpart, float* __restrict__ gb,
                                                              int workers) {
-  __shared__ float red[64 * WG_RW];
+  __shared__ double red[64 * WG_RW];  // (fp64 sums over the slabs: a weight gradient is a sum of ~1e5 signed per-pixel terms
+                                      // at full resolution, and the slab sum is where fp32 would lose the most)
   const int mrows = khb * kw * cinb;
   const long total = (long)nchunk * nsplit * mrows * cout;
   const long elems = (long)nchunk * nsplit * partsz;
   const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
   for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
     const long i = base + ln;
-    float s = 0.f;
+    double s = 0.0;
     int co = 0, m = 0, split = 0, chunk = 0;
     if (i < total) {
       co = (int)(i % cout);
@@ -1486,35 +1487,36 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = p[(long)(k + u) * elems];
-        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        s += (((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3])) +
+             (((double)v[4] + (double)v[5]) + ((double)v[6] + (double)v[7]));
       }
-      for (; k < hi; ++k) s += p[(long)k * elems];
+      for (; k < hi; ++k) s += (double)p[(long)k * elems];
     }
     __syncthreads();
     red[threadIdx.x] = s;
     __syncthreads();
     if (wv == 0 && i < total) {
-      float t = 0.f;
+      double t = 0.0;
 #pragma unroll
       for (int w = 0; w < WG_RW; ++w) t += red[w * 64 + ln];
       const int tap = m / cinb, ci = chunk * cinb + m % cinb;
       const int ky = (nsplit > 1 ? split : 0) + tap / kw, kx = tap % kw;
-      if (ci < cin_real) gw[(((long)co * cin_real + ci) * kh + ky) * kw + kx] = t;
+      if (ci < cin_real) gw[(((long)co * cin_real + ci) * kh + ky) * kw + kx] = (float)t;
     }
   }
   // bias gradient: block b < cout/8 adds the per-workgroup bias partials of channels 8b..8b+7; thread t sums workers
   // {t/8, t/8 + 128, ...} of channel 8b + t%8, then a fixed-order sum over the 128 sub-sums
   if (bpart && (int)blockIdx.x * 8 < cout) {
     const int co = blockIdx.x * 8 + (threadIdx.x & 7), sub = threadIdx.x >> 3;
-    float s = 0.f;
-    for (int k = sub; k < workers; k += 128) s += bpart[(long)k * cout + co];
+    double s = 0.0;
+    for (int k = sub; k < workers; k += 128) s += (double)bpart[(long)k * cout + co];
     __syncthreads();
     red[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < 8) {
-      float t = 0.f;
+      double t = 0.0;
       for (int k = 0; k < 128; ++k) t += red[k * 8 + threadIdx.x];
-      gb[co] = t;
+      gb[co] = (float)t;
     }
   }
 }
@@ -1861,16 +1863,16 @@ __global__ __launch_bounds__(256) void wgrad_pairs_reduce_kernel(const float* __
     const int x = 32 * (pair % npx) + xc, g = cob * (pair / npx) + gc;
     if (x >= cxw || g >= cgw || ky >= k) continue;
     const float* p = part + ((long)grp * npairs + pair) * workers * psz + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // fp64 over the worker slabs (see wgrad_reduce_kernel)
     int wk = 0;
     for (; wk + 3 < workers; wk += 4) {
-      s0 += p[(long)wk * psz];
-      s1 += p[(long)(wk + 1) * psz];
-      s2 += p[(long)(wk + 2) * psz];
-      s3 += p[(long)(wk + 3) * psz];
+      s0 += (double)p[(long)wk * psz];
+      s1 += (double)p[(long)(wk + 1) * psz];
+      s2 += (double)p[(long)(wk + 2) * psz];
+      s3 += (double)p[(long)(wk + 3) * psz];
     }
-    for (; wk < workers; ++wk) s0 += p[(long)wk * psz];
-    gw[((long)g * cxw + x) * kk + tap] = (s0 + s1) + (s2 + s3);
+    for (; wk < workers; ++wk) s0 += (double)p[(long)wk * psz];
+    gw[((long)g * cxw + x) * kk + tap] = (float)((s0 + s1) + (s2 + s3));
   }
 }
 

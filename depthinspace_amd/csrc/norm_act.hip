@@ -203,15 +203,16 @@ extern "C" int dis_gn_apply(const float* x, const double* stats, const float* ga
 // Every block writes its partial sums to its own workspace slot (no atomics: 4096 blocks x 66 fp64 atomics on 96
 // addresses used to cost more than the memory pass itself); the second pass and a small reducer add them up in a
 // fixed order (deterministic).
-#define GN_BWD_BLOCKS 64
+#define GN_BWD_BLOCKS 64      // reduce blocks per sample when a launch covers many samples ...
+#define GN_BWD_BLOCKS_MAX 512  // ... and when it covers one (a launch should bring >= 512 blocks)
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                      const float* __restrict__ x, const double* __restrict__ stats,
                                      const float* __restrict__ gamma, double* __restrict__ red,
-                                     double* __restrict__ gparam, long hw, int c, int act, float eps) {
+                                     double* __restrict__ gparam, long hw, int c, int act, float eps, int n0) {
   __shared__ float gam[GN_MAXC];
   __shared__ double sm[8];
   __shared__ float pg[256 * 4], pb[256 * 4];
-  const int n = blockIdx.y;
+  const int n = n0 + blockIdx.y;  // (this launch covers samples n0 .. n0 + gridDim.y - 1)
   float mean, rstd;
   gn_moments(stats, n, (double)hw * c, eps, &mean, &rstd);
   if (threadIdx.x < c) gam[threadIdx.x] = gamma[threadIdx.x];
@@ -293,14 +294,14 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
                                     const float* __restrict__ gamma, const double* __restrict__ red,
                                     float* __restrict__ gx, float* __restrict__ gres, long hw, int c, int act,
                                     float eps, int nred, int in_act, const double* __restrict__ gparam,
-                                    float* __restrict__ gg, float* __restrict__ gb, int slots) {
+                                    float* __restrict__ gg, float* __restrict__ gb, int slots, int n0) {
   __shared__ float gam[GN_MAXC];
   // Samples and elements are walked in the REVERSE of pass 1's order: what pass 1 read last is what the Infinity Cache
   // still holds, so this pass starts on cached data instead of evicting it first.
-  const int n = gridDim.y - 1 - blockIdx.y;
-  // dgamma / dbeta (folded in here to save a launch): wave w of the first 2c/4 blocks of sample 0 sums the `slots`
-  // per-block partials of one parameter in a fixed order
-  if (blockIdx.y == 0 && (int)blockIdx.x * 4 < 2 * c) {
+  const int n = n0 + gridDim.y - 1 - blockIdx.y;
+  // dgamma / dbeta (folded in here to save a launch; slots > 0 only in the LAST group's launch, when every partial exists):
+  // wave w of the first 2c/4 blocks of one sample sums the `slots` per-block partials of one parameter in a fixed order
+  if (slots > 0 && blockIdx.y == 0 && (int)blockIdx.x * 4 < 2 * c) {
     const int lane = threadIdx.x & 63;
     for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < 2 * c; j += gridDim.x * 4) {
       double s = 0.0;
@@ -363,7 +364,17 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
   }
 }
 
-extern "C" long dis_gn_bwd_workspace(int n, int c) { return (n > 0 && c > 0) ? (long)n * GN_BWD_BLOCKS * (2 + 2 * c) : -1; }
+extern "C" long dis_gn_bwd_workspace(int n, int c) { return (n > 0 && c > 0) ? (long)n * GN_BWD_BLOCKS_MAX * (2 + 2 * c) : -1; }
+
+// Samples per reduce / apply launch pair.  Measured and rejected (round 2): running the two passes over sample GROUPS small
+// enough for the 256 MiB Infinity Cache (reduce group, apply group, next group ...), so that the second pass would find what
+// the first just read, made the backward SLOWER (7.4 -> 9.7 ms per DIS-MF step: 2 - 16x the launches, grids of 64 - 512
+// blocks, no measurable cache benefit).  One group = the whole batch.
+static int gn_bwd_group(int n, long per_sample_elems, int tensors) {
+  (void)per_sample_elems;
+  (void)tensors;
+  return n;
+}
 
 extern "C" int dis_gn_apply_bwd(const float* gy, const float* y, const float* x, const double* stats,
                                 const float* gamma, float* gx, float* gres, float* grad_gamma, float* grad_beta,
@@ -376,12 +387,20 @@ extern "C" int dis_gn_apply_bwd(const float* gy, const float* y, const float* x,
   hipStream_t s = (hipStream_t)stream;
   int gxg = dis_ew_grid(hw * (c / 4), 256);
   if (gxg > 256) gxg = 256;
-  const int nred = GN_BWD_BLOCKS;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nred, n), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma, red,
-                     gparam_acc, hw, c, act, eps);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gxg * 2, n), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma,
-                     (const double*)red, gx, gres, hw, c, act, eps, nred, in_act, (const double*)gparam_acc, grad_gamma,
-                     grad_beta, n * nred);
+  const int grp = gn_bwd_group(n, hw * c, act != DIS_ACT_NONE ? 3 : 2);
+  int nred = (GN_BWD_BLOCKS_MAX + grp - 1) / grp;  // blocks per sample: ~512 blocks per launch
+  nred = (nred + 7) / 8 * 8;
+  if (nred < GN_BWD_BLOCKS) nred = GN_BWD_BLOCKS;
+  if (nred > GN_BWD_BLOCKS_MAX) nred = GN_BWD_BLOCKS_MAX;
+  for (int n0 = 0; n0 < n; n0 += grp) {
+    const int ng = n0 + grp <= n ? grp : n - n0;
+    const bool last = n0 + ng == n;
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nred, ng), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma, red,
+                       gparam_acc, hw, c, act, eps, n0);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gxg * 2, ng), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma,
+                       (const double*)red, gx, gres, hw, c, act, eps, nred, in_act, (const double*)gparam_acc,
+                       grad_gamma, grad_beta, last ? n * nred : 0, n0);
+  }
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdis_hip.so')
 
-# signature strings: p = pointer (device or host), i = int, l = long, f = float; the return type is int
+# signature strings: p = pointer (device or host), i = int, l = long, f = float, d = double; the return type is int
 # unless listed in _RET_LONG.  Keep in sync with include/dis_hip.h (tests/test_abi.py checks the symbol set).
 SIGS = {
     'dis_abi_version': '',
@@ -87,14 +87,14 @@ SIGS = {
     'dis_sigmoid_affine_fwd': 'ppfflp',
     'dis_sigmoid_affine_bwd': 'pppflp',
     'dis_augment': 'pppppppiiip',
-    'dis_adam_step': 'pppplffffifp',
-    'dis_adam_step_dev': 'pppplffffpfp',
+    'dis_adam_step': 'pppplfddfifp',
+    'dis_adam_step_dev': 'pppplfddfpfp',
 }
 _RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
              'dis_colsum_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_gather_csr_workspace',
              'dis_conv2d_pack_bf16x3_size', 'dis_disp_head_bwd_workspace'}
 
-_CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
+_CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float, 'd': ctypes.c_double}
 _lib = None
 
 

@@ -201,12 +201,6 @@ class FuseNet(TimedModule):
         self.max_disp = max_disp
         self.knn_index_override = None  # diagnostics only (externally supplied neighbour sets); no test or entry point sets it
         self.last_knn_index = None
-        # data-parallel segment cut (trainer.GraphedStep): the core feature map in front of the full-resolution tail and the
-        # sub-modules behind it, whose parameters END parameters() (so their gradients are one trailing range of the flat
-        # gradient buffer that can be all-reduced while the rest of the backward pass runs)
-        self.dp_cut = None
-        self.dp_tail_modules = ('amb_conv', 'amb_res1', 'amb_res2', 'ref_conv', 'ref_res1', 'ref_res2', 'ref_res3',
-                                'final_conv', 'predict_disp')
         C = channels
         self.conv1 = Slots({1: ConvParams(4, C // 2, 4)})
         self.conv2 = Slots({1: ConvParams(C // 2, C // 2, 3)})
@@ -288,7 +282,5 @@ class FuseNet(TimedModule):
             feat = block(feat, geom, geom_q, flows, flows_q, idx, idx_q, csr, csr_q, wgt)
 
         amb4 = ops.pack4_nhwc([(amb, HW)], N, H, W)
-        core = feat.view(N, h, w, self.channels)
-        self.dp_cut = core if core.requires_grad else None
-        disp = self.post_process(core, amb4)
+        disp = self.post_process(feat.view(N, h, w, self.channels), amb4)
         return disp.view(tl, bs, 1, H, W)

@@ -1138,7 +1138,7 @@ class _GroupNorm(torch.autograd.Function):
         gb, gb_ret = _sink(ctx.beta_ref)
         wtot = lib.fn('dis_gn_bwd_workspace')(n, c)
         ws = torch.empty(wtot, dtype=torch.float64, device=x.device)
-        nred2 = wtot // (2 + 2 * c) * 2
+        nred2 = wtot // (2 + 2 * c) * 2  # (n * blocks-per-sample-max) pairs of per-block sums, then the parameter partials
         red, pacc = ws[:nred2], ws[nred2:]
         lib.call('dis_gn_apply_bwd', gy, y, x, stats, gamma, gx, gres, gg, gb, red, pacc, n, hw, c, act, eps, in_act)
         if gres is not None and ctx.join is not None:

@@ -260,19 +260,21 @@ class FlatAdam(object):
 
 class GraphedStep(object):
     """One training step of a stage worker (`copy_data` + LCN, net_forward, loss_forward, backward, gradient all-reduce,
-    Adam: the body of the reference loop, model/worker.py:499-539) captured in hipGraphs and replayed per batch.
-    bench.py and Worker.train_epoch(use_graph=True) both run THIS object, so the benchmark times the product's own loop.
+    Adam: the body of the reference loop, model/worker.py:499-539) on static device buffers, eager or captured in hipGraphs
+    and replayed per batch.  bench.py and Worker.train_epoch(use_graph=True) both run THIS object, so the benchmark times
+    the product's own loop.
 
-    world_size == 1: one graph.  world_size > 1: the collectives stay eager (RCCL on its own stream) between captured
-    segments.  When the network publishes a cut tensor after its forward (`net.dp_cut`: FuseNet's core feature map in
-    front of the full-resolution tail, whose parameters end the flat buffer), the backward pass is captured as TWO
-    graphs - tail first - and the tail's gradient bucket is all-reduced on the communication stream while the second
-    graph (blocks + stem) runs; otherwise one backward graph, then the all-reduce in `comm_chunks` pieces.
+    use_graph=False: the eager step (what Worker.train_step does): with world_size > 1 FlatAdam's hooks all-reduce every
+      gradient bucket on the communication stream while the backward pass is still running.
+    use_graph=True, world_size == 1: one graph (forward, losses, backward, Adam).
+    use_graph=True, world_size > 1: forward + backward graph, ONE eager all-reduce of the flat gradient (RCCL), Adam graph.
+      (A two-graph backward with the tail bucket reduced underneath the second graph was built and dropped in round 2:
+      it faulted under replay and cannot be validated on RCCL with one GPU; the eager form is the overlapped one.)
     The set of loss terms may change with the epoch (epoch < 2 adds the L1 warm-up term, reference
     model/multi_frame_worker.py:160-165): key() changes and the step is re-captured.
     Batches are copied into static device buffers (run(batch)); `errs` of the last step are in `loss_buf[:nterms]`."""
 
-    def __init__(self, worker, net, opt, example_batch, use_graph=True, segments=None, warmup=2):
+    def __init__(self, worker, net, opt, example_batch, use_graph=True, warmup=2):
         self.worker, self.net, self.opt = worker, net, opt
         self.dev = opt.flat_p.device
         self.static = {k: torch.as_tensor(v).to(self.dev).contiguous().clone() for k, v in example_batch.items()}
@@ -280,14 +282,10 @@ class GraphedStep(object):
         self.nterms = 0
         self.use_graph = use_graph
         self.world = opt.world_size
-        if segments is None:
-            segments = os.environ.get('DIS_DP_SEGMENTS', '1') != '0'
-        self.segments = bool(segments) and self.world > 1
         self.warmup = warmup
         self._key = None
         self._graphs = None
-        self._comm = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
-        self.mode = 'eager'
+        self.mode = 'eager-overlap' if (self.world > 1 and opt.overlap) else 'eager'
 
     # ---- pieces of the step
     def key(self):
@@ -313,18 +311,6 @@ class GraphedStep(object):
         self._forward_loss().backward()
         self.opt.step()
 
-    def _tail_range(self):
-        """flat-buffer range of the parameters behind the network's cut tensor (they must end the buffer)"""
-        names = getattr(self.net, 'dp_tail_modules', None)
-        if not names:
-            return None
-        tail = [p for n in names for p in getattr(self.net, n).parameters()]
-        ids = {id(p) for p in tail}
-        first = min(i for i, p in enumerate(self.opt.params) if id(p) in ids)
-        if any(id(p) not in ids for p in self.opt.params[first:]):
-            return None
-        return tail, self.opt.offsets[first]
-
     def _capture(self):
         opt = self.opt
         side = torch.cuda.Stream(device=self.dev)
@@ -334,47 +320,19 @@ class GraphedStep(object):
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
         if self.world == 1:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g1):
                 self._forward_loss().backward()
                 opt.step(all_reduce=False)
-            self._graphs, self.mode = (g,), 'graph'
+            self._graphs, self.mode = (g1,), 'graph'
             return
-        tr = self._tail_range() if self.segments else None
         g_opt = torch.cuda.CUDAGraph()
-        if tr is not None:
-            tail, lo = tr
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                total = self._forward_loss()
-                cut = self.net.dp_cut
-                torch.autograd.backward(total, inputs=list(tail) + [cut], retain_graph=True)
-            with torch.cuda.graph(g2, pool=g1.pool()):
-                torch.autograd.backward(cut, grad_tensors=cut.grad)
-            with torch.cuda.graph(g_opt, pool=g1.pool()):
-                opt.step(all_reduce=False)
-            del total, cut
-            self._graphs, self.mode, self._tail_lo = (g1, g2, g_opt), 'graph-2seg', lo
-        else:
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                self._forward_loss().backward()
-            with torch.cuda.graph(g_opt, pool=g1.pool()):
-                opt.step(all_reduce=False)
-            self._graphs, self.mode = (g1, g_opt), 'graph-1seg'
-
-    def _allreduce_async(self, lo, hi):
-        """all-reduce flat_g[lo:hi] on the communication stream, ordered after everything enqueued so far"""
-        self._comm.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._comm):
-            return torch.distributed.all_reduce(self.opt.flat_g[lo:hi], group=self.opt.process_group, async_op=True)
-
-    def _join(self, works):
-        with torch.cuda.stream(self._comm):
-            for w in works:
-                w.wait()
-        torch.cuda.current_stream().wait_stream(self._comm)
+        with torch.cuda.graph(g1):
+            self._forward_loss().backward()
+        with torch.cuda.graph(g_opt, pool=g1.pool()):
+            opt.step(all_reduce=False)
+        self._graphs, self.mode = (g1, g_opt), 'graph+allreduce+graph'
 
     # ---- public
     def run(self, batch=None):
@@ -391,24 +349,15 @@ class GraphedStep(object):
             except Exception as e:  # pragma: no cover
                 import sys
                 print(f'[GraphedStep] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
-                self.use_graph, self._graphs, self.mode = False, None, 'eager'
+                self.use_graph, self._graphs = False, None
+                self.mode = 'eager-overlap' if (self.world > 1 and self.opt.overlap) else 'eager'
                 torch.cuda.synchronize()
                 self._eager()
                 return
         gs = self._graphs
-        if self.mode == 'graph':
-            gs[0].replay()
-        elif self.mode == 'graph-2seg':
-            n = self.opt.flat_g.numel()
-            gs[0].replay()
-            w1 = self._allreduce_async(self._tail_lo, n)   # overlaps the second backward graph
-            gs[1].replay()
-            w2 = self._allreduce_async(0, self._tail_lo)
-            self._join([w1, w2])
-            gs[2].replay()
-        else:
-            gs[0].replay()
-            self._join([self._allreduce_async(0, self.opt.flat_g.numel())])
+        gs[0].replay()
+        if self.world > 1:
+            self.opt.all_reduce_grads()   # one collective on the compute stream between the two graphs
             gs[1].replay()
 
     def losses(self):

@@ -408,14 +408,15 @@ int dis_augment(const float* im, const float* amb, const float* params, const lo
 /* ---------------------------------------------------------------- optimiser ----------------- */
 
 /* torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) on a flat fp32 buffer (reference train_val.py:55-56).
- * step_count is the 1-based step index; grads are multiplied by grad_scale first (1/world_size for DP). */
+ * step_count is the 1-based step index; grads are multiplied by grad_scale first (1/world_size for DP).  The betas are
+ * doubles: torch.optim.Adam evaluates (1 - beta) and beta^t on python floats and rounds once. */
 int dis_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, float lr,
-                  float beta1, float beta2, float eps, int step_count, float grad_scale, void* stream);
+                  double beta1, double beta2, float eps, int step_count, float grad_scale, void* stream);
 /* The same update with the step counter on the device: state = 4 x 32 bit {int steps taken, float 1-beta1^t,
  * float sqrt(1-beta2^t), unused}, advanced by the call itself.  Safe to capture in a hipGraph: replay k applies
  * step k's bias correction (dis_adam_step would replay the capture-time correction). */
 int dis_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, float lr,
-                      float beta1, float beta2, float eps, int* state, float grad_scale, void* stream);
+                      double beta1, double beta2, float eps, int* state, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

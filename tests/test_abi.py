@@ -36,7 +36,7 @@ def test_argument_counts_match_header():
         assert n == len(lib.SIGS[name]), (name, n, len(lib.SIGS[name]))
         for decl, code in zip([] if n == 0 else args.split(','), lib.SIGS[name]):
             decl = decl.strip()
-            kind = 'p' if '*' in decl else ('f' if decl.startswith('float') else ('l' if decl.startswith('long') else 'i'))
+            kind = 'p' if '*' in decl else ('f' if decl.startswith('float') else ('d' if decl.startswith('double') else ('l' if decl.startswith('long') else 'i')))
             assert kind == code, (name, decl, code)
 
 

@@ -2,8 +2,8 @@
 collective's transport is not what is tested) run Worker.train_step with trainer.FlatAdam's bucketed, overlapped all-reduce.
 The reduced gradient must equal the sum of the two ranks' single-process gradients (DDP semantics: per-rank masked-mean
 losses, mean of the gradients - SURVEY.md section 8(e)), buckets must be in flight before backward returns, replicas must
-stay identical, and the hipGraph form of the step (trainer.GraphedStep, two backward segments with the tail bucket
-reduced underneath the second) must land on the same parameters as the eager form."""
+stay identical, and the hipGraph form of the step (trainer.GraphedStep: forward + backward graph, one all-reduce, Adam graph)
+must land on the same parameters as the eager form."""
 import argparse
 import os
 import socket
@@ -30,7 +30,15 @@ def _args(arch, bs):
                               epochs=1, warmup_epochs=150, train_batch_size=bs, max_disp=128)
 
 
-def _rank(rank, world, port, arch, q):
+def _rank(rank, world, port, arch, q, logdir):
+    import faulthandler
+    log = open(os.path.join(logdir, f'rank{rank}.log'), 'w')
+    faulthandler.enable(file=log)
+    faulthandler.dump_traceback_later(150, file=log)   # a hung collective leaves its stack behind for the parent to show
+
+    def mark(msg):
+        log.write(msg + '\n')
+        log.flush()
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'] = str(rank), str(world), '0'
@@ -75,7 +83,9 @@ def _rank(rank, world, port, arch, q):
         res = {}
         early = []
         for step in range(3):
+            mark(f'step {step}: local gradients')
             gs = local_grads()
+            mark(f'step {step}: dp train_step')
             opt.zero_grad()
             # ---- the product's step; peek at the bucket state between backward and the optimiser
             orig = opt.step
@@ -95,6 +105,7 @@ def _rank(rank, world, port, arch, q):
         dist.all_gather(both, chk)
         res['replicas_equal'] = bool(torch.equal(both[0], both[1]))
         res['steps'] = opt.step_count
+        mark('eager dp done; graphed form')
         # ---- hipGraph form of the same DP step vs the eager form, from the same state
         snap = [t.clone() for t in (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev)]
         for _ in range(2):
@@ -107,6 +118,7 @@ def _rank(rank, world, port, arch, q):
         # (the capture's eager warm-up step is a real step: undo it so both forms take exactly two steps)
         gstep.run()
         torch.cuda.synchronize()
+        mark(f'captured: {gstep.mode}')
         for t, c in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev), snap):
             t.copy_(c)
         for _ in range(2):
@@ -115,6 +127,8 @@ def _rank(rank, world, port, arch, q):
         res['graph_mode'] = gstep.mode
         res['graph_vs_eager'] = float((opt.flat_p - p_eager).abs().max())
         res['graph_steps'] = opt.step_count
+        mark('done')
+        faulthandler.cancel_dump_traceback_later()
         q.put((rank, res))
     except Exception as e:
         import traceback
@@ -125,17 +139,32 @@ def _rank(rank, world, port, arch, q):
 
 
 @pytest.mark.parametrize('arch', ['multi_frame', 'single_frame'])
-def test_two_rank_train_step(arch):
+def test_two_rank_train_step(arch, tmp_path):
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, world, port, arch, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank, args=(r, world, port, arch, q, str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=600) for _ in range(world))
-    for p in procs:
-        p.join(timeout=120)
+    res = {}
+    try:
+        while len(res) < world:
+            try:
+                r, v = q.get(timeout=240)
+            except Exception:
+                logs = {r: open(os.path.join(str(tmp_path), f'rank{r}.log')).read() for r in range(world)}
+                raise AssertionError('a rank hung or died:\n' + '\n'.join(f'--- rank {r}\n{t[-3000:]}' for r, t in logs.items()))
+            res[r] = v
+            if 'error' in v:  # the other rank may be blocked in a collective: do not wait for it
+                break
+    finally:
+        for p in procs:
+            p.join(timeout=5 if any('error' in v for v in res.values()) else 120)
+            if p.is_alive():
+                p.terminate()
+    for v in res.values():
+        assert 'error' not in v, v['error']
     for r in range(world):
         assert 'error' not in res[r], res[r]['error']
         # reduced gradient == sum of the ranks' own gradients (float atomics in two scatter kernels: tolerance, not bits)
@@ -144,6 +173,6 @@ def test_two_rank_train_step(arch):
         # step 0 learns the notification pattern; from step 1 on (almost) every bucket is in flight before backward returns
         assert res[r]['early'][0] == 0 and all(e >= res[r]['nbuckets'] - 1 for e in res[r]['early'][1:]), res[r]
         assert res[r]['replicas_equal'] and res[r]['steps'] == 3
-        assert res[r]['graph_mode'] == ('graph-2seg' if arch == 'multi_frame' else 'graph-1seg'), res[r]
+        assert res[r]['graph_mode'] == 'graph+allreduce+graph', res[r]
         assert res[r]['graph_vs_eager'] < 5e-6 and res[r]['graph_steps'] == 5, res[r]
     print(arch, res[0])
