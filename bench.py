@@ -94,9 +94,6 @@ def main():
     ap.add_argument('--arch', default='multi_frame', choices=['multi_frame', 'single_frame'],
                     help='multi_frame = BASELINE.json metric (config 3/4); single_frame = DIS-SF (config 2, run in fp32)')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of one hipGraph')
-    ap.add_argument('--dp-graph', action='store_true',
-                    help='--gpus > 1: capture the step (graph, one all-reduce, graph) instead of the default eager step whose '
-                         'bucketed all-reduce overlaps the backward pass')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eager-leg', action='store_true', help='skip the eager-launch timing of the same step')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -152,7 +149,7 @@ def main():
     # N = 1: the captured step.  N > 1: the eager step, whose gradient buckets are all-reduced on a communication stream
     # while the backward pass runs (trainer.FlatAdam); eager launch costs nothing here (same frames/s as the graph at N = 1,
     # `eager_launch_frames_per_s` below)
-    want_graph = (not args.no_graph) and (world == 1 or args.dp_graph)
+    want_graph = (not args.no_graph) and world == 1
     stepper = GraphedStep(worker, net, opt, batch, use_graph=want_graph, warmup=max(1, min(args.warmup, 2)))
 
     def fwd_bwd():  # (roofline leg below)

@@ -703,9 +703,9 @@ __global__ void convg_wgrad_reduce_kernel(const float* __restrict__ part, float*
     const int x = (int)(r % cXw);
     const int tap = (int)(r / cXw);
     const float* p = part + ((long)tap * cXp + x) * cGp + g;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += p[k * slab];
-    gw[((long)g * cXw + x) * ntaps + tap] = s;
+    double s = 0.0;  // fp64 over the split-K slabs (sums of ~1e5 signed per-pixel terms at full resolution)
+    for (int k = 0; k < nsplit; ++k) s += (double)p[k * slab];
+    gw[((long)g * cXw + x) * ntaps + tap] = (float)s;
   }
 }
 
@@ -829,10 +829,10 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ 
                                                        float* __restrict__ out) {
   const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (ch >= c) return;
-  float s = 0.f;
-  for (int k = lane; k < nblocks; k += 64) s += part[(long)k * c + ch];
-  s = wave_sum(s);
-  if (lane == 0) out[ch] = s;
+  double s = 0.0;
+  for (int k = lane; k < nblocks; k += 64) s += (double)part[(long)k * c + ch];
+  s = wave_sum_d(s);
+  if (lane == 0) out[ch] = (float)s;
 }
 
 extern "C" long dis_colsum_workspace(int c) { return c > 0 ? (long)CS_BLOCKS * c : -1; }

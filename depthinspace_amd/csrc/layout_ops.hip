@@ -481,6 +481,9 @@ extern "C" int dis_gather_warped_feat_bwd(const float* grad_out, const float* fl
 //                      [2nd+1, ...)     entries: 2 words each (source row, weight bits), nd*... <= pixels*(tl-1)*4
 // ------------------------------------------------------------------------------------------------
 #define CSR_SCAN_ELEMS 2048
+__global__ void csr_zero_kernel(int* __restrict__ p, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0;
+}
 __global__ void csr_count_fill_kernel(const float* __restrict__ flows, int* __restrict__ cursor,
                                       int* __restrict__ entries, int tl, int bs, int h, int w, int fill) {
   const long hw = (long)h * w;
@@ -649,8 +652,10 @@ extern "C" int dis_gather_csr_build(const float* flows, int* csr, int tl, int bs
   int* entries = csr + 2 * nd + 1;
   int* bsum = csr + csr_words(tl, bs, h, w);
   const int nblk = (int)((nd + CSR_SCAN_ELEMS - 1) / CSR_SCAN_ELEMS);
-  hipError_t e = hipMemsetAsync(cursor, 0, nd * sizeof(int), s);
-  if (e != hipSuccess) return (int)e;
+  // (a kernel, not hipMemsetAsync: captured in a hipGraph, the memset NODE was not reliably ordered in front of the count
+  // kernel once eager launches had run between two replays - cursors were then counted on top of the previous replay's end
+  // positions and the fill pass wrote out of bounds: "Memory access fault by GPU", round 2, scripts/debug_graph_pure.py)
+  hipLaunchKernelGGL(csr_zero_kernel, dim3(dis_ew_grid(nd, 256)), dim3(256), 0, s, cursor, nd);
   const long items = nd * (tl - 1);
   int grid = dis_cdiv(items, 256);
   if (grid > 8192) grid = 8192;

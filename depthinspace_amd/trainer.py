@@ -267,9 +267,11 @@ class GraphedStep(object):
     use_graph=False: the eager step (what Worker.train_step does): with world_size > 1 FlatAdam's hooks all-reduce every
       gradient bucket on the communication stream while the backward pass is still running.
     use_graph=True, world_size == 1: one graph (forward, losses, backward, Adam).
-    use_graph=True, world_size > 1: forward + backward graph, ONE eager all-reduce of the flat gradient (RCCL), Adam graph.
-      (A two-graph backward with the tail bucket reduced underneath the second graph was built and dropped in round 2:
-      it faulted under replay and cannot be validated on RCCL with one GPU; the eager form is the overlapped one.)
+    world_size > 1 always runs the eager form: it is the one whose collectives overlap the backward pass, and it costs
+      nothing (at N = 1 the eager loop reaches the captured loop's frames/s, bench.py `eager_launch_frames_per_s`).
+      Captured multi-rank forms (graph, all-reduce, Adam graph; and a two-graph backward with the tail bucket reduced
+      underneath the second graph) were built in round 2 and REMOVED: DIS-MF's faulted on its second replay in the 2-rank
+      test, and neither can be validated on RCCL with the single GPU of the development box.
     The set of loss terms may change with the epoch (epoch < 2 adds the L1 warm-up term, reference
     model/multi_frame_worker.py:160-165): key() changes and the step is re-captured.
     Batches are copied into static device buffers (run(batch)); `errs` of the last step are in `loss_buf[:nterms]`."""
@@ -280,8 +282,8 @@ class GraphedStep(object):
         self.static = {k: torch.as_tensor(v).to(self.dev).contiguous().clone() for k, v in example_batch.items()}
         self.loss_buf = torch.zeros(32, device=self.dev)
         self.nterms = 0
-        self.use_graph = use_graph
         self.world = opt.world_size
+        self.use_graph = bool(use_graph) and self.world == 1
         self.warmup = warmup
         self._key = None
         self._graphs = None
@@ -321,18 +323,10 @@ class GraphedStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
-        if self.world == 1:
-            with torch.cuda.graph(g1):
-                self._forward_loss().backward()
-                opt.step(all_reduce=False)
-            self._graphs, self.mode = (g1,), 'graph'
-            return
-        g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
             self._forward_loss().backward()
-        with torch.cuda.graph(g_opt, pool=g1.pool()):
             opt.step(all_reduce=False)
-        self._graphs, self.mode = (g1, g_opt), 'graph+allreduce+graph'
+        self._graphs, self.mode = (g1,), 'graph'
 
     # ---- public
     def run(self, batch=None):
@@ -354,11 +348,7 @@ class GraphedStep(object):
                 torch.cuda.synchronize()
                 self._eager()
                 return
-        gs = self._graphs
-        gs[0].replay()
-        if self.world > 1:
-            self.opt.all_reduce_grads()   # one collective on the compute stream between the two graphs
-            gs[1].replay()
+        self._graphs[0].replay()
 
     def losses(self):
         return [float(v) for v in self.loss_buf[:self.nterms].cpu()]

@@ -2,8 +2,7 @@
 collective's transport is not what is tested) run Worker.train_step with trainer.FlatAdam's bucketed, overlapped all-reduce.
 The reduced gradient must equal the sum of the two ranks' single-process gradients (DDP semantics: per-rank masked-mean
 losses, mean of the gradients - SURVEY.md section 8(e)), buckets must be in flight before backward returns, replicas must
-stay identical, and the hipGraph form of the step (trainer.GraphedStep: forward + backward graph, one all-reduce, Adam graph)
-must land on the same parameters as the eager form."""
+stay identical.  (The single-GPU hipGraph form of the step is compared with the eager form in test_graphed_step_matches_eager.)"""
 import argparse
 import os
 import socket
@@ -33,6 +32,7 @@ def _args(arch, bs):
 def _rank(rank, world, port, arch, q, logdir):
     import faulthandler
     log = open(os.path.join(logdir, f'rank{rank}.log'), 'w')
+    os.dup2(log.fileno(), 2)   # C++ / HIP runtime messages of this rank
     faulthandler.enable(file=log)
     faulthandler.dump_traceback_later(150, file=log)   # a hung collective leaves its stack behind for the parent to show
 
@@ -105,27 +105,11 @@ def _rank(rank, world, port, arch, q, logdir):
         dist.all_gather(both, chk)
         res['replicas_equal'] = bool(torch.equal(both[0], both[1]))
         res['steps'] = opt.step_count
-        mark('eager dp done; graphed form')
-        # ---- hipGraph form of the same DP step vs the eager form, from the same state
-        snap = [t.clone() for t in (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev)]
-        for _ in range(2):
-            w.train_step(net, opt, batches[rank])
-        torch.cuda.synchronize()
-        p_eager = opt.flat_p.clone()
-        for t, c in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev), snap):
-            t.copy_(c)
-        gstep = GraphedStep(w, net, opt, batches[rank], use_graph=True, warmup=1)
-        # (the capture's eager warm-up step is a real step: undo it so both forms take exactly two steps)
+        # trainer.GraphedStep with world_size > 1 runs this same eager, overlapped step on static buffers
+        gstep = GraphedStep(w, net, opt, batches[rank], use_graph=True)
+        assert not gstep.use_graph and gstep.mode == 'eager-overlap'
         gstep.run()
         torch.cuda.synchronize()
-        mark(f'captured: {gstep.mode}')
-        for t, c in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev), snap):
-            t.copy_(c)
-        for _ in range(2):
-            gstep.run()
-        torch.cuda.synchronize()
-        res['graph_mode'] = gstep.mode
-        res['graph_vs_eager'] = float((opt.flat_p - p_eager).abs().max())
         res['graph_steps'] = opt.step_count
         mark('done')
         faulthandler.cancel_dump_traceback_later()
@@ -173,6 +157,49 @@ def test_two_rank_train_step(arch, tmp_path):
         # step 0 learns the notification pattern; from step 1 on (almost) every bucket is in flight before backward returns
         assert res[r]['early'][0] == 0 and all(e >= res[r]['nbuckets'] - 1 for e in res[r]['early'][1:]), res[r]
         assert res[r]['replicas_equal'] and res[r]['steps'] == 3
-        assert res[r]['graph_mode'] == 'graph+allreduce+graph', res[r]
-        assert res[r]['graph_vs_eager'] < 5e-6 and res[r]['graph_steps'] == 5, res[r]
+        assert res[r]['graph_steps'] == 4, res[r]
     print(arch, res[0])
+
+
+@pytest.mark.parametrize('arch', ['multi_frame', 'single_frame'])
+def test_graphed_step_matches_eager(arch):
+    """trainer.GraphedStep (the object bench.py and Worker.train_epoch(use_graph=True) run): three replays of the captured step
+    land on the same parameters as three eager steps from the same state, with Adam's device-side step counter advancing."""
+    from depthinspace_amd import synth
+    from depthinspace_amd.model import multi_frame_networks, multi_frame_worker, single_frame_worker, networks
+    from depthinspace_amd.trainer import FlatAdam, GraphedStep
+    H = W = 64
+    settings = synth.make_settings(H, W)
+    torch.manual_seed(0)
+    if arch == 'multi_frame':
+        w = multi_frame_worker.Worker(_args(arch, 1), settings=settings)
+        net = multi_frame_networks.FuseNet((H, W), settings.K, settings.baseline).cuda()
+    else:
+        w = single_frame_worker.Worker(_args(arch, 1), settings=settings)
+        net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=w.imsizes).cuda()
+    w.build_losses()
+    w.current_epoch = 2
+    opt = FlatAdam(net.parameters(), lr=1e-4)
+    batch = {k: torch.from_numpy(v) for k, v in synth.make_batch(settings, 1, 4, seed=77).items()}
+    state = (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev)
+    snap = [t.clone() for t in state]
+    eager = GraphedStep(w, net, opt, batch, use_graph=False)
+    for _ in range(3):
+        eager.run()
+    torch.cuda.synchronize()
+    p_eager, l_eager = opt.flat_p.clone(), eager.losses()
+    assert opt.step_count == 3
+    graphed = GraphedStep(w, net, opt, batch, use_graph=True, warmup=1)
+    graphed.run()   # eager warm-up step + capture + first replay
+    torch.cuda.synchronize()
+    assert graphed.mode == 'graph'
+    for t, c in zip(state, snap):
+        t.copy_(c)
+    for _ in range(3):
+        graphed.run()
+    torch.cuda.synchronize()
+    assert opt.step_count == 3
+    # (two float-atomic scatters in the step: run-to-run rounding noise, amplified by Adam's normalisation of ~0 gradients)
+    assert float((opt.flat_p - p_eager).abs().max()) < 2.5e-4
+    assert float((opt.flat_p - p_eager).abs().mean()) < 2e-6
+    np.testing.assert_allclose(graphed.losses(), l_eager, rtol=2e-3, atol=1e-5)
