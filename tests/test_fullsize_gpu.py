@@ -120,9 +120,13 @@ def test_mf_forward_fullsize_matches_oracle():
 def test_dispnets_fullsize_matches_oracle():
     """Whole DispNetS / DispDecoder at 512x432 (2 images), forward and every parameter gradient, vs the CPU oracle.  At this
     size crop_like trims (W: 432,216,108,54,27,14,7,4: upconv outputs 28->27 and 8->7), which the reference-generated golden
-    sf_128x108_bs1 pins at a smaller size (tests/test_sf_gpu.py).  A first-layer weight gradient sums 110 592 pixels per
-    image behind 30 layers, where the fp32 CPU run itself is only good to a few 1e-3 of the largest entry; the oracle is
-    therefore ALSO run in fp64 and the HIP gradients must be as close to that as the fp32 oracle is (x2), or 2e-3."""
+    sf_128x108_bs1 pins at a smaller size (tests/test_sf_gpu.py).  The gradients are compared with the oracle run in fp64,
+    next to the fp32 oracle's own distance from it.  Two effects set the bars: (1) a first-layer weight gradient sums 110 592
+    signed per-pixel terms per image behind 30 layers (the fp32 CPU run itself is only good to ~1e-3 of the largest entry
+    there); (2) every ReLU whose pre-activation lies within rounding of 0 may land on the other side of the kink than the
+    fp64 run - ONE such element among the 14 M outputs of a full-resolution layer moves a bias gradient (a sum of
+    ~sqrt(N) sigma) by ~1e-3 of its largest entry.  So: relative L2 error < 3e-3 (or 4x the fp32 oracle's), max-norm error
+    < 1e-2 of the largest entry (or 6x the fp32 oracle's)."""
     from depthinspace_amd.model import networks
     params = O.init_params(O.sf_param_shapes(), seed=6)
     g = torch.Generator().manual_seed(12)
@@ -160,8 +164,8 @@ def test_dispnets_fullsize_matches_oracle():
     for r in rows[:8]:
         print('   %-40s %.2e %.2e   %.2e %.2e' % (r[4], r[0], r[1], r[2], r[3]))
     for e, e_cpu, l2, l2_cpu, k in rows:
-        assert l2 < max(2e-3, 4 * l2_cpu), (k, l2, l2_cpu)
-        assert e < max(5e-3, 6 * e_cpu), (k, e, e_cpu)
+        assert l2 < max(3e-3, 4 * l2_cpu), (k, l2, l2_cpu)
+        assert e < max(1e-2, 6 * e_cpu), (k, e, e_cpu)
 
 
 # the DispNetS layers that run as 32-channel slice launches of the halo-resident bf16x3 kernel only do so at high
