@@ -1,0 +1,681 @@
+// DispNetS with bf16 ACTIVATION STORAGE (BASELINE config 2: "DIS-SF bs=8, full-res default-pattern synthetic, bf16"):
+// every nhwc feature map of the encoder-decoder lives in HBM as bf16, the parameters, the gradients of the parameters,
+// the Adam state, the disparities and all losses stay fp32.  A convolution is then ONE bf16 x bf16 product per MAC on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (the fp32-result path, conv_gen.hip / conv2d.hip, spends six), and
+// moves half the bytes.  Results are NOT fp32-accurate: tests compare with the fp32 oracle under a stated looser bound
+// (tests/test_sf_bf16_gpu.py) and bench.py reports the mode under its own label.
+//
+//   convb_fwd_kernel<BN, XB, YB>   the forward-like streaming implicit GEMM of conv_gen.hip (same GenArgs addressing: a tap is
+//       an arbitrary (dy,dx) offset, the output grid may be strided, so one kernel runs conv, both input gradients, the
+//       transposed conv and its input gradient), 128 pixels x BN couts per workgroup, k-step = 32 channels of one tap;
+//       x is bf16 (XB) or fp32 (network input, head gradient), y is bf16 (YB) or fp32 (head pre-activation).
+//       The weights are the MFMA's A operand and the pixels its B operand, so a lane ends up with 4 consecutive output
+//       channels of one pixel: one 8-byte (bf16) / 16-byte (fp32) store.
+//   convb_wgrad_kernel<MTW, NTW, XB, GB>   weight gradient: split-K slabs over pixel ranges, fp32 MFMA on the values the
+//       bf16 tensors hold (exact products of bf16 values, fp32 accumulation), fp64 slab sums.
+//   element-wise helpers on bf16 nhwc tensors (activation gradient, channel copies, column sums).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+#define CB_MAXTAPS 49
+#define CB_BM 128
+#define CB_CK 32
+#define CB_AS 40  // LDS pixel stride of the A tile (16-bit units): 32 channels + 8 pad (16 consecutive pixels: 16 distinct slots)
+
+__device__ __forceinline__ unsigned cb_pack2(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32: round to nearest even
+}
+__device__ __forceinline__ float cb_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float cb_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+
+struct GenArgsB {
+  const void* x;
+  const bf16_t* w;  // packed [tap][chunk][nblk][lg][BN][8]
+  const float* bias;
+  void* y;
+  int n, hin, win, ldx, xoff, cin;  // channels [xoff, xoff+cin) of a pixel of ldx ELEMENTS
+  int nchunk;                       // ceil(cin / 32)
+  int hv, wv, S;
+  int hf, wf, ldy, yoff, cout;
+  int osy, ooy, osx, oox;
+  int act, ntaps, nblk;
+  short tdy[CB_MAXTAPS], tdx[CB_MAXTAPS];
+  unsigned x_bytes;
+};
+
+template <int BN, bool XB, bool YB>
+__global__ __launch_bounds__(256, 2) void convb_fwd_kernel(GenArgsB a) {
+  constexpr int NT = BN / 16;
+  constexpr int A_U16 = CB_BM * CB_AS, B_U16 = 4 * BN * 8;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (A_U16 + B_U16)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int M = a.n * a.hv * a.wv;
+  const int nb = blockIdx.x % a.nblk, m0 = (blockIdx.x / a.nblk) * CB_BM;
+
+  // loader role: thread owns channel group pq (8 channels) of pixels p0 and p0 + 64 of the tile
+  const int pq = tid & 3, p0 = tid >> 2;
+  long pbase[2];
+  int piy[2], pix[2];
+  bool pval[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + p0 + j * 64;
+    pval[j] = m < M;
+    const int mm = pval[j] ? m : 0;
+    const int vx = mm % a.wv, t = mm / a.wv, vy = t % a.hv, nn = t / a.hv;
+    pbase[j] = (long)nn * a.hin * a.win;
+    piy[j] = vy * a.S;
+    pix[j] = vx * a.S;
+  }
+  // ring of three register sets; taps outside the image / channel groups beyond cin get an out-of-range buffer offset
+  u32x4 ra[3][2], ra2[3][XB ? 1 : 2], rb[3];
+  const u32x4* wq = (const u32x4*)a.w;
+  const int nk = a.ntaps * a.nchunk;
+  const bool wload = tid < 4 * BN;  // 16-byte vectors of the B tile
+  int ptap = 0, pchunk = 0, pnext = 0;
+  auto prefetch = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    if (pnext >= nk) return;
+    const int dy = a.tdy[ptap], dx = a.tdx[ptap];
+    const int c = pchunk * CB_CK + pq * 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int iy = piy[j] + dy, ix = pix[j] + dx;
+      const bool ok = pval[j] && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+      const long e = (pbase[j] + (long)iy * a.win + ix) * a.ldx + a.xoff + c;
+      if (XB) {
+        const unsigned off = (ok && c < a.cin) ? (unsigned)(e * 2) : BX_OOB;
+        ra[set][j] = __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.x, a.x_bytes), off, 0, 0);
+      } else {  // fp32 input: two 16-byte loads of 4 channels each
+        const unsigned o0 = (ok && c < a.cin) ? (unsigned)(e * 4) : BX_OOB;
+        const unsigned o1 = (ok && c + 4 < a.cin) ? (unsigned)(e * 4 + 16) : BX_OOB;
+        ra[set][j] = __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.x, a.x_bytes), o0, 0, 0);
+        ra2[set][XB ? 0 : j] = __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.x, a.x_bytes), o1, 0, 0);
+      }
+    }
+    const long wb = ((long)(ptap * a.nchunk + pchunk) * a.nblk + nb) * (4 * BN);
+    rb[set] = wq[wb + (wload ? tid : 0)];
+    ++pnext;
+    if (++pchunk == a.nchunk) {
+      pchunk = 0;
+      ++ptap;
+    }
+  };
+  auto stage = [&](auto setc, int buf) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    unsigned short* A = smem + buf * (A_U16 + B_U16);
+    unsigned short* B = A + A_U16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      u32x4 v = ra[set][j];
+      if (!XB) {
+        const u32x4 q = ra2[set][XB ? 0 : j];
+        v = (u32x4){cb_pack2(__uint_as_float(v[0]), __uint_as_float(v[1])), cb_pack2(__uint_as_float(v[2]), __uint_as_float(v[3])),
+                    cb_pack2(__uint_as_float(q[0]), __uint_as_float(q[1])), cb_pack2(__uint_as_float(q[2]), __uint_as_float(q[3]))};
+      }
+      *(u32x4*)(A + (p0 + j * 64) * CB_AS + pq * 8) = v;
+    }
+    if (wload) ((u32x4*)B)[tid] = rb[set];
+  };
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  prefetch(S0{});
+  prefetch(S1{});
+  prefetch(S2{});
+  stage(S0{}, 0);
+  __syncthreads();
+  auto body = [&](int s, auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    prefetch(setc);
+    const unsigned short* A = smem + (s & 1) * (A_U16 + B_U16);
+    const unsigned short* B = A + A_U16;
+    s16x8 fa[2], fb[NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) fa[mt] = *(const s16x8*)(A + (wave * 32 + mt * 16 + li) * CB_AS + lg * 8);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) fb[nt] = *(const s16x8*)(B + (lg * BN + nt * 16 + li) * 8);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[nt]),
+                                                             __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+    stage(std::integral_constant<int, (set + 1) % 3>{}, (s + 1) & 1);
+    __syncthreads();
+  };
+  for (int ks = 0; ks < nk; ks += 3) {
+    body(ks, S0{});
+    if (ks + 1 < nk) body(ks + 1, S1{});
+    if (ks + 2 < nk) body(ks + 2, S2{});
+  }
+
+  // epilogue: lane (li, lg) holds couts nb*BN + nt*16 + lg*4 + {0..3} of pixel m0 + wave*32 + mt*16 + li
+  auto emit = [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = m0 + wave * 32 + mt * 16 + li;
+      if (m >= M) continue;
+      const int vx = m % a.wv, t = m / a.wv, vy = t % a.hv, nn = t / a.hv;
+      const long pe = (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = nb * BN + nt * 16 + lg * 4;
+        if (co >= a.cout) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float b = (a.bias && co + r < a.cout) ? a.bias[co + r] : 0.f;
+          o[r] = act_apply(acc[mt][nt][r] + b, ACT);
+        }
+        if (co + 4 <= a.cout) {
+          if (YB) *(uint2*)((bf16_t*)a.y + pe + co) = make_uint2(cb_pack2(o[0], o[1]), cb_pack2(o[2], o[3]));
+          else *(float4*)((float*)a.y + pe + co) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {  // ragged last group (cout not a multiple of 4: the 1-channel heads)
+          for (int r = 0; r < 4 && co + r < a.cout; ++r) {
+            if (YB) ((bf16_t*)a.y)[pe + co + r] = (bf16_t)(cb_pack2(o[r], 0.f) & 0xffffu);
+            else ((float*)a.y)[pe + co + r] = o[r];
+          }
+        }
+      }
+    }
+  };
+  if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{});
+  else if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{});
+  else emit(std::integral_constant<int, DIS_ACT_NONE>{});
+}
+
+// packed[tap][chunk][nb][lg][col][j] = bf16(W(tap, ci = chunk*32 + lg*8 + j, co = nb*BN + col))
+struct PackArgsB {
+  const float* w;
+  bf16_t* packed;
+  int ntaps, nchunk, nblk, bn, ci_real, co_real;
+  long s_ci, s_co;
+  short tsrc[CB_MAXTAPS];
+};
+__global__ void convb_pack_kernel(PackArgsB a) {
+  const long total = (long)a.ntaps * a.nchunk * a.nblk * 4 * a.bn * 8;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7);
+    long r = i >> 3;
+    const int col = (int)(r % a.bn);
+    r /= a.bn;
+    const int lg = (int)(r & 3);
+    r >>= 2;
+    const int nb = (int)(r % a.nblk);
+    r /= a.nblk;
+    const int chunk = (int)(r % a.nchunk);
+    const int tap = (int)(r / a.nchunk);
+    const int ci = chunk * CB_CK + lg * 8 + j, co = nb * a.bn + col;
+    float v = 0.f;
+    if (ci < a.ci_real && co < a.co_real) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
+    a.packed[i] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
+  }
+}
+
+static int cb_bn(int cout) { return cout > 32 ? 64 : (cout > 16 ? 32 : 16); }
+
+template <bool XB, bool YB>
+static void cb_launch(const GenArgsB& a, int bn, long grid, hipStream_t s) {
+  if (bn == 64) hipLaunchKernelGGL((convb_fwd_kernel<64, XB, YB>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  else if (bn == 32) hipLaunchKernelGGL((convb_fwd_kernel<32, XB, YB>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((convb_fwd_kernel<16, XB, YB>), dim3((unsigned)grid), dim3(256), 0, s, a);
+}
+
+static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t* wpack, int ci_real, int co_real, long s_ci,
+                  long s_co, const short* tsrc, hipStream_t s) {
+  if (a.ntaps <= 0) return DIS_OK;
+  const long M = (long)a.n * a.hv * a.wv;
+  if (M <= 0) return DIS_OK;
+  const int bn = cb_bn(a.cout);
+  a.nblk = (a.cout + bn - 1) / bn;
+  const long xb = (long)a.n * a.hin * a.win * a.ldx * (x_bf16 ? 2 : 4);
+  if (xb >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;  // 31-bit byte offsets of the buffer descriptor
+  a.x_bytes = (unsigned)xb;
+  a.nchunk = (a.cin + CB_CK - 1) / CB_CK;
+  PackArgsB p;
+  p.w = w_raw; p.packed = wpack; p.ntaps = a.ntaps; p.nchunk = a.nchunk; p.nblk = a.nblk; p.bn = bn;
+  p.ci_real = ci_real; p.co_real = co_real; p.s_ci = s_ci; p.s_co = s_co;
+  for (int t = 0; t < a.ntaps; ++t) p.tsrc[t] = tsrc[t];
+  const long ptotal = (long)a.ntaps * a.nchunk * a.nblk * 4 * bn * 8;
+  hipLaunchKernelGGL(convb_pack_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
+  a.w = wpack;
+  const long grid = ((M + CB_BM - 1) / CB_BM) * a.nblk;
+  if (grid > 2147483647L) return DIS_ERR_BAD_SHAPE;
+  if (x_bf16 && y_bf16) cb_launch<true, true>(a, bn, grid, s);
+  else if (x_bf16) cb_launch<true, false>(a, bn, grid, s);
+  else if (y_bf16) cb_launch<false, true>(a, bn, grid, s);
+  else cb_launch<false, false>(a, bn, grid, s);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// workspace in 16-bit words for ONE phase
+extern "C" long dis_convb_pack_workspace(int cin, int cout, int k) {
+  if (cin <= 0 || cout <= 0 || k <= 0 || k * k > CB_MAXTAPS) return -1;
+  const int bn = cb_bn(cout);
+  const long nblk = (cout + bn - 1) / bn, nchunk = (cin + CB_CK - 1) / CB_CK;
+  return (long)k * k * nchunk * nblk * 4 * bn * 8;
+}
+
+static int cb_floordiv2(int v) { return (v >= 0) ? v / 2 : -((-v + 1) / 2); }
+
+// Same modes and argument meaning as dis_convg_run (conv_gen.hip); ldx / xoff / ldy / yoff count ELEMENTS of the tensor's
+// own type; x_bf16 / y_bf16 select bf16 (1) or fp32 (0) storage of x / y.  bf16 tensors need ld, offset and cin that
+// are multiples of 8 (16-byte vectors), fp32 ones multiples of 4.  wpack: 4 x dis_convb_pack_workspace 16-bit words.
+extern "C" int dis_convb_run(int mode, const void* x, int x_bf16, int ldx, int xoff, const float* w, const float* bias,
+                             void* y, int y_bf16, int ldy, int yoff, void* wpack, int n, int hin, int win, int cin,
+                             int cin_w, int hout, int wout, int cout, int cout_w, int k, int stride, int pad, int act,
+                             void* stream) {
+  if (!x || !w || !y || !wpack) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || cin <= 0 || cout <= 0 || cin_w <= 0 || cout_w <= 0 ||
+      k <= 0 || pad < 0)
+    return DIS_ERR_BAD_SHAPE;
+  if (k * k > CB_MAXTAPS || (stride != 1 && stride != 2) || mode < 0 || mode > 3) return DIS_ERR_UNSUPPORTED;
+  const int xa = x_bf16 ? 7 : 3, ya = y_bf16 ? 3 : 0;
+  if ((cin & xa) || (xoff & xa) || (ldx & xa) || xoff + cin > ldx || yoff + cout > ldy || cin_w > cin || cout_w > cout)
+    return DIS_ERR_BAD_SHAPE;
+  if (cout % 4 == 0 && ((yoff & 3) || (ldy & 3))) return DIS_ERR_BAD_SHAPE;
+  (void)ya;
+  hipStream_t s = (hipStream_t)stream;
+  GenArgsB a;
+  a.x = x; a.w = nullptr; a.bias = bias; a.y = y;
+  a.n = n; a.hin = hin; a.win = win; a.ldx = ldx; a.xoff = xoff; a.cin = cin;
+  a.hf = hout; a.wf = wout; a.ldy = ldy; a.yoff = yoff; a.cout = cout; a.act = act;
+  short tsrc[CB_MAXTAPS];
+  const long kk = (long)k * k;
+  bf16_t* wp = (bf16_t*)wpack;
+  if (mode == DIS_CONVG_CONV || mode == DIS_CONVG_TCONV_DGRAD) {
+    if (mode == DIS_CONVG_CONV) {
+      if (hout != (hin + 2 * pad - k) / stride + 1 || wout != (win + 2 * pad - k) / stride + 1) return DIS_ERR_BAD_SHAPE;
+    } else if (stride != 2) {
+      return DIS_ERR_UNSUPPORTED;
+    }
+    a.hv = hout; a.wv = wout; a.S = stride; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
+    a.ntaps = k * k;
+    for (int ky = 0; ky < k; ++ky)
+      for (int kx = 0; kx < k; ++kx) {
+        a.tdy[ky * k + kx] = (short)(ky - pad);
+        a.tdx[ky * k + kx] = (short)(kx - pad);
+        tsrc[ky * k + kx] = (short)(ky * k + kx);
+      }
+    return cb_run(a, x_bf16, y_bf16, w, wp, cin_w, cout_w, kk, (long)cin_w * kk, tsrc, s);
+  }
+  const long s_ci = (long)cout_w * kk, s_co = kk;
+  if (stride == 1) {
+    a.hv = hout; a.wv = wout; a.S = 1; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
+    a.ntaps = k * k;
+    for (int ky = 0; ky < k; ++ky)
+      for (int kx = 0; kx < k; ++kx) {
+        a.tdy[ky * k + kx] = (short)(pad - ky);
+        a.tdx[ky * k + kx] = (short)(pad - kx);
+        tsrc[ky * k + kx] = (short)(ky * k + kx);
+      }
+    return cb_run(a, x_bf16, y_bf16, w, wp, cin_w, cout_w, s_ci, s_co, tsrc, s);
+  }
+  const long pstride = dis_convb_pack_workspace(cin, cout, k);
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      GenArgsB b = a;
+      b.hv = (hout - py + 1) / 2; b.wv = (wout - px + 1) / 2; b.S = 1;
+      b.osy = 2; b.ooy = py; b.osx = 2; b.oox = px;
+      int nt = 0;
+      for (int ky = 0; ky < k; ++ky) {
+        if ((py + pad - ky) & 1) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          if ((px + pad - kx) & 1) continue;
+          b.tdy[nt] = (short)cb_floordiv2(py + pad - ky);
+          b.tdx[nt] = (short)cb_floordiv2(px + pad - kx);
+          tsrc[nt] = (short)(ky * k + kx);
+          ++nt;
+        }
+      }
+      b.ntaps = nt;
+      if (b.hv <= 0 || b.wv <= 0) continue;
+      if (nt == 0) return DIS_ERR_UNSUPPORTED;
+      int rc = cb_run(b, x_bf16, y_bf16, w, wp + (long)(py * 2 + px) * pstride, cin_w, cout_w, s_ci, s_co, tsrc, s);
+      if (rc != DIS_OK) return rc;
+    }
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: dW[tap][xc][gc] = sum_pixels X[pixel + tap][xc] * G[pixel][gc], X / G bf16 or fp32
+// (structure of convg_wgrad_kernel: one tap x TX x-channels x TG g-channels per workgroup, 32 pixels per step, split-K slabs)
+// ------------------------------------------------------------------------------------------------
+struct WgArgsB {
+  const void* X;
+  const void* G;
+  float* part;  // [ksplit][tap][cXp][cGp]
+  int n, hX, wX, ldX, xoff, cX;
+  int hG, wG, ldG, goff, cG;
+  int S, pad, k;
+  int nxb, ngb;
+  int mper;
+  int cXp, cGp;
+};
+template <bool BF>
+__device__ __forceinline__ float4 cb_load4(const void* p, long e) {
+  if (BF) {
+    const uint2 v = *(const uint2*)((const bf16_t*)p + e);
+    return make_float4(cb_lo(v.x), cb_hi(v.x), cb_lo(v.y), cb_hi(v.y));
+  }
+  return *(const float4*)((const float*)p + e);
+}
+template <int MTW, int NTW, bool XB, bool GB>
+__global__ __launch_bounds__(256) void convb_wgrad_kernel(WgArgsB a) {
+  constexpr int TX = 32 * MTW, TG = 32 * NTW, XS = TX + 16, GS = TG + 16;
+  constexpr int X_FL = 32 * XS, G_FL = 32 * GS;
+  constexpr int NLX = TX / 32, NLG = TG / 32;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (X_FL + G_FL)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int ntaps = a.k * a.k;
+  const int tap = blockIdx.x % ntaps;
+  const int rest = blockIdx.x / ntaps;
+  const int xb = rest % a.nxb, gb = rest / a.nxb;
+  const int ky = tap / a.k, kx = tap % a.k;
+  const int M = a.n * a.hG * a.wG;
+  const int m_lo = blockIdx.y * a.mper;
+  const int m_hi = min(M, m_lo + a.mper);
+  float4 rx[NLX], rg[NLG];
+  auto prefetch = [&](int mbase) {
+#pragma unroll
+    for (int j = 0; j < NLX; ++j) {
+      const int item = tid + j * 256;
+      const int px = item / (TX / 4), q = item % (TX / 4);
+      const int m = mbase + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c = xb * TX + q * 4;
+      if (m < m_hi && c < a.cX) {
+        const int gx = m % a.wG, t = m / a.wG, gy = t % a.hG, nn = t / a.hG;
+        const int iy = gy * a.S - a.pad + ky, ix = gx * a.S - a.pad + kx;
+        if (iy >= 0 && iy < a.hX && ix >= 0 && ix < a.wX)
+          v = cb_load4<XB>(a.X, (((long)nn * a.hX + iy) * a.wX + ix) * a.ldX + a.xoff + c);
+      }
+      rx[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NLG; ++j) {
+      const int item = tid + j * 256;
+      const int px = item / (TG / 4), q = item % (TG / 4);
+      const int m = mbase + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c = gb * TG + q * 4;
+      if (m < m_hi && c < a.cG) v = cb_load4<GB>(a.G, (long)m * a.ldG + a.goff + c);
+      rg[j] = v;
+    }
+  };
+  auto stage = [&](int buf) {
+    float* Xt = smem + buf * (X_FL + G_FL);
+    float* Gt = Xt + X_FL;
+#pragma unroll
+    for (int j = 0; j < NLX; ++j) {
+      const int item = tid + j * 256;
+      *(float4*)(Xt + (item / (TX / 4)) * XS + (item % (TX / 4)) * 4) = rx[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NLG; ++j) {
+      const int item = tid + j * 256;
+      *(float4*)(Gt + (item / (TG / 4)) * GS + (item % (TG / 4)) * 4) = rg[j];
+    }
+  };
+  f32x4 acc[MTW][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int wx = wave & 1, wg = wave >> 1;
+  if (m_lo < m_hi) {
+    prefetch(m_lo);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int mb = m_lo; mb < m_hi; mb += 32) {
+      const bool more = mb + 32 < m_hi;
+      if (more) prefetch(mb + 32);
+      const float* Xt = smem + buf * (X_FL + G_FL);
+      const float* Gt = Xt + X_FL;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        float av[MTW], bv[NTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) av[mt] = Xt[(kk * 4 + lg) * XS + wx * 16 * MTW + mt * 16 + li];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) bv[nt] = Gt[(kk * 4 + lg) * GS + wg * 16 * NTW + nt * 16 + li];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+      }
+      if (more) stage(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  float* out = a.part + ((long)blockIdx.y * ntaps + tap) * a.cXp * a.cGp;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int xc = xb * TX + wx * 16 * MTW + mt * 16 + lg * 4 + r;
+        const int gc = gb * TG + wg * 16 * NTW + nt * 16 + li;
+        out[(long)xc * a.cGp + gc] = acc[mt][nt][r];
+      }
+}
+__global__ void convb_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int nsplit, int ntaps,
+                                          int cXp, int cGp, int cXw, int cGw) {
+  const long total = (long)ntaps * cXw * cGw;
+  const long slab = (long)ntaps * cXp * cGp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cGw);
+    long r = i / cGw;
+    const int x = (int)(r % cXw);
+    const int tap = (int)(r / cXw);
+    const float* p = part + ((long)tap * cXp + x) * cGp + g;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += (double)p[k * slab];
+    gw[((long)g * cXw + x) * ntaps + tap] = (float)s;
+  }
+}
+static void cbw_tiles(int cX, int cG, int* mtw, int* ntw) {
+  *mtw = cX > 32 ? 2 : 1;
+  *ntw = cG > 32 ? 2 : 1;
+}
+static void cbw_plan(int n, int hG, int wG, int cX, int cG, int k, int* nxb, int* ngb, int* nsplit, int* mper) {
+  int mtw, ntw;
+  cbw_tiles(cX, cG, &mtw, &ntw);
+  const int TX = 32 * mtw, TG = 32 * ntw;
+  *nxb = (cX + TX - 1) / TX;
+  *ngb = (cG + TG - 1) / TG;
+  const long base = (long)k * k * (*nxb) * (*ngb);
+  const long M = (long)n * hG * wG;
+  long sp = (2048 + base - 1) / base;
+  const long maxsp = (M + 255) / 256;
+  if (sp > maxsp) sp = maxsp;
+  if (sp < 1) sp = 1;
+  long mp = (M + sp - 1) / sp;
+  mp = (mp + 31) / 32 * 32;
+  sp = (M + mp - 1) / mp;
+  *nsplit = (int)sp;
+  *mper = (int)mp;
+}
+extern "C" long dis_convb_wgrad_workspace(int n, int hG, int wG, int cX, int cG, int k) {
+  if (n <= 0 || hG <= 0 || wG <= 0 || cX <= 0 || cG <= 0 || k <= 0 || k * k > CB_MAXTAPS) return -1;
+  int nxb, ngb, nsplit, mper, mtw, ntw;
+  cbw_plan(n, hG, wG, cX, cG, k, &nxb, &ngb, &nsplit, &mper);
+  cbw_tiles(cX, cG, &mtw, &ntw);
+  return (long)nsplit * k * k * (nxb * 32 * mtw) * (ngb * 32 * ntw);
+}
+template <bool XB, bool GB>
+static void cbw_launch(const WgArgsB& a, int mtw, int ntw, dim3 grid, hipStream_t s) {
+  if (mtw == 2 && ntw == 2) hipLaunchKernelGGL((convb_wgrad_kernel<2, 2, XB, GB>), grid, dim3(256), 0, s, a);
+  else if (mtw == 2) hipLaunchKernelGGL((convb_wgrad_kernel<2, 1, XB, GB>), grid, dim3(256), 0, s, a);
+  else if (ntw == 2) hipLaunchKernelGGL((convb_wgrad_kernel<1, 2, XB, GB>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((convb_wgrad_kernel<1, 1, XB, GB>), grid, dim3(256), 0, s, a);
+}
+// argument meaning of dis_convg_wgrad (conv_gen.hip); ld / offsets in elements; x_bf16 / g_bf16 as in dis_convb_run
+extern "C" int dis_convb_wgrad(const void* X, int x_bf16, int ldX, int xoff, int hX, int wX, int cX, int cX_w, const void* G,
+                               int g_bf16, int ldG, int goff, int hG, int wG, int cG, int cG_w, float* grad_w,
+                               float* workspace, int n, int k, int stride, int pad, void* stream) {
+  if (!X || !G || !grad_w || !workspace) return DIS_ERR_NULL;
+  if (n <= 0 || hX <= 0 || wX <= 0 || hG <= 0 || wG <= 0 || cX <= 0 || cG <= 0 || cX_w <= 0 || cG_w <= 0 || cX_w > cX ||
+      cG_w > cG || k <= 0 || pad < 0)
+    return DIS_ERR_BAD_SHAPE;
+  if ((cX & 3) || (cG & 3) || (xoff & 3) || (goff & 3) || (ldX & 3) || (ldG & 3) || xoff + cX > ldX || goff + cG > ldG)
+    return DIS_ERR_BAD_SHAPE;
+  if (k * k > CB_MAXTAPS || (stride != 1 && stride != 2)) return DIS_ERR_UNSUPPORTED;
+  if ((long)n * hG * wG > 2147483647L - 64) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  WgArgsB a;
+  a.X = X; a.G = G; a.part = workspace;
+  a.n = n; a.hX = hX; a.wX = wX; a.ldX = ldX; a.xoff = xoff; a.cX = cX;
+  a.hG = hG; a.wG = wG; a.ldG = ldG; a.goff = goff; a.cG = cG;
+  a.S = stride; a.pad = pad; a.k = k;
+  int nsplit, mtw, ntw;
+  cbw_plan(n, hG, wG, cX, cG, k, &a.nxb, &a.ngb, &nsplit, &a.mper);
+  cbw_tiles(cX, cG, &mtw, &ntw);
+  a.cXp = a.nxb * 32 * mtw;
+  a.cGp = a.ngb * 32 * ntw;
+  const dim3 grid((unsigned)(k * k * a.nxb * a.ngb), (unsigned)nsplit);
+  if (x_bf16 && g_bf16) cbw_launch<true, true>(a, mtw, ntw, grid, s);
+  else if (x_bf16) cbw_launch<true, false>(a, mtw, ntw, grid, s);
+  else if (g_bf16) cbw_launch<false, true>(a, mtw, ntw, grid, s);
+  else cbw_launch<false, false>(a, mtw, ntw, grid, s);
+  const long total = (long)k * k * cX_w * cG_w;
+  hipLaunchKernelGGL(convb_wgrad_reduce_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)workspace,
+                     grad_w, nsplit, k * k, a.cXp, a.cGp, cX_w, cG_w);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise helpers on bf16 nhwc tensors
+// ------------------------------------------------------------------------------------------------
+// gpre = gy * act'(y) on channel ranges of wider buffers (4 channels per thread); gy, y, gpre bf16
+__global__ void act_bwd_bf16_kernel(const bf16_t* __restrict__ gy, int ldg, const bf16_t* __restrict__ y, int ldy,
+                                    bf16_t* __restrict__ gp, int act, long npix, int c4) {
+  const long total = npix * c4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long px = i / c4;
+    const int q = (int)(i - px * c4) * 4;
+    const uint2 g = *(const uint2*)(gy + px * ldg + q);
+    if (act == DIS_ACT_NONE) {
+      *(uint2*)(gp + i * 4) = g;
+    } else {
+      const uint2 v = *(const uint2*)(y + px * ldy + q);
+      *(uint2*)(gp + i * 4) = make_uint2(
+          cb_pack2(cb_lo(g.x) * act_grad_from_out(cb_lo(v.x), act), cb_hi(g.x) * act_grad_from_out(cb_hi(v.x), act)),
+          cb_pack2(cb_lo(g.y) * act_grad_from_out(cb_lo(v.y), act), cb_hi(g.y) * act_grad_from_out(cb_hi(v.y), act)));
+    }
+  }
+}
+extern "C" int dis_act_bwd_bf16(const void* gy, int ldg, const void* y, int ldy, void* gpre, int act, long npix, int c,
+                                void* stream) {
+  if (!gy || !gpre || (act != DIS_ACT_NONE && !y)) return DIS_ERR_NULL;
+  if (npix <= 0 || c <= 0 || ldg < c || (act != DIS_ACT_NONE && ldy < c)) return DIS_ERR_BAD_SHAPE;
+  if ((c & 3) || (ldg & 3) || (ldy & 3) || ((uintptr_t)gy & 7) || ((uintptr_t)y & 7) || ((uintptr_t)gpre & 7))
+    return DIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(act_bwd_bf16_kernel, dim3(dis_ew_grid(npix * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)gy, ldg, (const bf16_t*)(y ? y : gy), ldy, (bf16_t*)gpre, act, npix, c / 4);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// dst[pixel * ldd + j] = src[pixel * lds + j] (j < c), 0 for c <= j < c + czero; src fp32 or bf16, dst bf16
+template <bool SB>
+__global__ void copy_channels_bf16_kernel(const void* __restrict__ src, int lds, bf16_t* __restrict__ dst, int ldd,
+                                          long npix, int c, int czero) {
+  const int ct = c + czero;
+  const long total = npix * ct;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long px = i / ct;
+    const int j = (int)(i - px * ct);
+    float v = 0.f;
+    if (j < c) v = SB ? cb_lo(((const bf16_t*)src)[px * lds + j]) : ((const float*)src)[px * lds + j];
+    dst[px * ldd + j] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
+  }
+}
+extern "C" int dis_copy_channels_bf16(const void* src, int src_bf16, int lds, void* dst, int ldd, long npix, int c,
+                                      int czero, void* stream) {
+  if (!src || !dst) return DIS_ERR_NULL;
+  if (npix <= 0 || c <= 0 || czero < 0 || lds < c || ldd < c + czero) return DIS_ERR_BAD_SHAPE;
+  const dim3 grid(dis_ew_grid(npix * (c + czero), 256));
+  if (src_bf16)
+    hipLaunchKernelGGL(copy_channels_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, lds, (bf16_t*)dst,
+                       ldd, npix, c, czero);
+  else
+    hipLaunchKernelGGL(copy_channels_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, lds, (bf16_t*)dst,
+                       ldd, npix, c, czero);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// column sums of a bf16 nhwc tensor (bias gradients): out[ch] = sum_pixels G[pixel][goff + ch], fp32 block partials, fp64 total
+#define CSB_BLOCKS 1024
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ G, int ldG, int goff, long npix, int c,
+                                                           float* __restrict__ part) {
+  __shared__ float red[256];
+  const long lo = npix * blockIdx.x / gridDim.x, hi = npix * (blockIdx.x + 1) / gridDim.x;
+  for (int c0 = 0; c0 < c; c0 += 256) {
+    const int cw = min(256, c - c0);
+    const int rows = 256 / cw > 0 ? 256 / cw : 1;
+    const int ch = threadIdx.x % cw, row = threadIdx.x / cw;
+    float s0 = 0.f, s1 = 0.f;
+    if (row < rows) {
+      const bf16_t* gp = G + goff + c0 + ch;
+      long p = lo + row;
+      for (; p + rows < hi; p += 2L * rows) {
+        s0 += cb_lo(gp[p * ldG]);
+        s1 += cb_lo(gp[(p + rows) * ldG]);
+      }
+      for (; p < hi; p += rows) s0 += cb_lo(gp[p * ldG]);
+    }
+    __syncthreads();
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.x < cw) {
+      float t = 0.f;
+      for (int k = 0; k < rows; ++k) t += red[k * cw + threadIdx.x];
+      part[(long)blockIdx.x * c + c0 + threadIdx.x] = t;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void colsum_bf16_final_kernel(const float* __restrict__ part, int nblocks, int c,
+                                                                 float* __restrict__ out) {
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ch >= c) return;
+  double s = 0.0;
+  for (int k = lane; k < nblocks; k += 64) s += (double)part[(long)k * c + ch];
+  s = wave_sum_d(s);
+  if (lane == 0) out[ch] = (float)s;
+}
+extern "C" long dis_colsum_bf16_workspace(int c) { return c > 0 ? (long)CSB_BLOCKS * c : -1; }
+extern "C" int dis_colsum_bf16(const void* G, int ldG, int goff, long npix, int c, float* out, float* workspace,
+                               void* stream) {
+  if (!G || !out || !workspace) return DIS_ERR_NULL;
+  if (npix <= 0 || c <= 0 || goff < 0 || goff + c > ldG) return DIS_ERR_BAD_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  int nb = (int)((npix + 255) / 256);
+  if (nb > CSB_BLOCKS) nb = CSB_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)G, ldG, goff, npix, c, workspace);
+  hipLaunchKernelGGL(colsum_bf16_final_kernel, dim3(dis_cdiv(c, 4)), dim3(256), 0, s, (const float*)workspace, nb, c, out);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}

@@ -87,11 +87,19 @@ SIGS = {
     'dis_sigmoid_affine_fwd': 'ppfflp',
     'dis_sigmoid_affine_bwd': 'pppflp',
     'dis_augment': 'pppppppiiip',
+    'dis_convb_pack_workspace': 'iii',
+    'dis_convb_run': 'ipiiipppiiip' + 'iiiiiiiiiiiii' + 'p',
+    'dis_convb_wgrad_workspace': 'iiiiii',
+    'dis_convb_wgrad': 'piiiiiiipiiiiiiipp' + 'iiiip',
+    'dis_act_bwd_bf16': 'pipipilip',
+    'dis_copy_channels_bf16': 'piipiliip',
+    'dis_colsum_bf16_workspace': 'i',
+    'dis_colsum_bf16': 'piilippp',
     'dis_adam_step': 'pppplfddfifp',
     'dis_adam_step_dev': 'pppplfddfpfp',
 }
 _RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
-             'dis_colsum_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_gather_csr_workspace',
+             'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_gather_csr_workspace',
              'dis_conv2d_pack_bf16x3_size', 'dis_disp_head_bwd_workspace'}
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float, 'd': ctypes.c_double}

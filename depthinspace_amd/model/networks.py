@@ -100,8 +100,14 @@ class DispNetS(TimedModule):
     `upconv7.0.weight`, `iconv3.0.weight`, `predict_disp4.0.weight`, ...).  Feature maps are nhwc; every conv runs
     on the streaming MFMA kernels of csrc/conv_gen.hip."""
 
-    def __init__(self, channels_in, imsizes, output_facs, coordconv=False, weight_init=False, channel_multiplier=1):
+    def __init__(self, channels_in, imsizes, output_facs, coordconv=False, weight_init=False, channel_multiplier=1,
+                 act_dtype=torch.float32):
         super().__init__(mod_name='DispNetS')
+        # storage type of the nhwc feature maps: float32 (fp32 results, the parity path) or bfloat16 (BASELINE config 2:
+        # one bf16 product per MAC, fp32 accumulate; parameters, disparities and losses stay float32)
+        if act_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(act_dtype)
+        self.act_dtype = act_dtype
         cp = [channel_multiplier * c for c in (32, 64, 128, 256, 512, 512, 512)]
         up = [channel_multiplier * c for c in (512, 512, 256, 128, 64, 32, 16)]
         self.channels_in = channels_in
@@ -123,33 +129,30 @@ class DispNetS(TimedModule):
         self.predict_disp2 = facs[1](up[5], imsizes[1])
         self.predict_disp1 = facs[0](up[6], imsizes[0])
 
-    @staticmethod
-    def _conv(x, p, stride=1, need_dgrad=True, out=None):
+    def _conv(self, x, p, stride=1, need_dgrad=True, out=None):
         k = p.weight.shape[2]
-        return ops.convg(x, p.weight, p.bias, stride, (k - 1) // 2, ops.ACT_RELU, need_dgrad, out)
+        return ops.convg(x, p.weight, p.bias, stride, (k - 1) // 2, ops.ACT_RELU, need_dgrad, out, dtype=self.act_dtype)
 
-    @staticmethod
-    def _down(x, slots, need_dgrad=True, skip=None):
+    def _down(self, x, slots, need_dgrad=True, skip=None):
         """downsample_conv (:222-228).  skip = (channels in front of this stage's output in the decoder concatenation
         that will use it, total channels there): the stage then writes its output straight into that buffer."""
-        a = DispNetS._conv(x, slots[0], 2, need_dgrad)
+        a = self._conv(x, slots[0], 2, need_dgrad)
         if skip is None:
-            return DispNetS._conv(a, slots[2], 1), None
+            return self._conv(a, slots[2], 1), None
         off, total = skip
-        cb = ops.ConcatBuf(a.shape[0], a.shape[1], a.shape[2], total, a.device)
+        cb = ops.ConcatBuf(a.shape[0], a.shape[1], a.shape[2], total, a.device, self.act_dtype)
         slot = cb.slot(off, slots[2].weight.shape[0])
-        if slots[2].weight.shape[2] == 7:
+        if slots[2].weight.shape[2] == 7 and self.act_dtype == torch.float32:
             # the 7x7 layer runs as seven accumulating tap-row launches: they read-modify-write their output, which is
             # cheaper on a dense tensor; one copy into the slot afterwards
-            return ops.write_channels(DispNetS._conv(a, slots[2], 1), slot), cb
-        return DispNetS._conv(a, slots[2], 1, out=slot), cb
+            return ops.write_channels(self._conv(a, slots[2], 1), slot), cb
+        return self._conv(a, slots[2], 1, out=slot), cb
 
-    @staticmethod
-    def _up(x, slots, cb):
+    def _up(self, x, slots, cb):
         """upconv (:236-240) + crop_like (:242-244), written into channels [0, cout) of the concatenation buffer cb"""
         cout = slots[0].weight.shape[1]
         return ops.convg_transposed(x, slots[0].weight, slots[0].bias, (cb.buf.shape[1], cb.buf.shape[2]), 1, ops.ACT_RELU,
-                                    out=cb.slot(0, cout))
+                                    out=cb.slot(0, cout), dtype=self.act_dtype)
 
     @staticmethod
     def _head(x, m):
@@ -192,7 +195,7 @@ class DispNetS(TimedModule):
             total = up[lvl] + enc[i] + (1 if lvl in (2, 3) else 0)
             e[i], cb[lvl] = self._down(e[i - 1], getattr(self, f'conv{i}'), need_dgrad=(i > 1), skip=(up[lvl], total))
         e[7], _ = self._down(e[6], self.conv7)
-        cb[1] = ops.ConcatBuf(N, H, W, up[1] + 1, x4.device)
+        cb[1] = ops.ConcatBuf(N, H, W, up[1] + 1, x4.device, self.act_dtype)
 
         def level(lvl, below, disp=None):
             parts = [(self._up(below, getattr(self, f'upconv{lvl}'), cb[lvl]), 0)]

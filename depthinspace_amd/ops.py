@@ -887,14 +887,16 @@ class ConcatBuf(object):
     gradient ranges back to the parts.  All writes go through the C ABI, never through ATen in-place ops: the views
     saved for backward keep their version."""
 
-    def __init__(self, n, h, w, c, device):
+    def __init__(self, n, h, w, c, device, dtype=torch.float32):
         self.c = c
-        ld = (c + 3) // 4 * 4
-        self.buf = torch.empty((n, h, w, ld), dtype=torch.float32, device=device)
+        q = 8 if dtype == torch.bfloat16 else 4   # 16-byte vectors: 4 floats / 8 bf16
+        ld = (c + q - 1) // q * q
+        self.q = q
+        self.buf = torch.empty((n, h, w, ld), dtype=dtype, device=device)
         self.pad = ld - c  # zero lanes behind the last channel: written together with it (write_channels)
 
     def slot(self, off, c):
-        assert off % 4 == 0 and off + c <= self.c
+        assert off % self.q == 0 and off + c <= self.c
         return (self.buf, off, c)
 
     def joined(self, parts):
@@ -936,6 +938,8 @@ class _WriteChannels(torch.autograd.Function):
 def write_channels(src, slot, zero_tail=False):
     """copy the nhwc tensor src into a ConcatBuf slot; returns the slot's view (differentiable).  zero_tail: also zero the
     buffer's padding lanes behind the slot (the slot must be the concatenation's last part)."""
+    if slot[0].dtype == torch.bfloat16:
+        return _WriteChannelsB.apply(src, slot, zero_tail)
     return _WriteChannels.apply(src, slot, zero_tail)
 
 
@@ -1045,14 +1049,19 @@ class _ConvG(torch.autograd.Function):
         return gx, gw_ret, gb, None, None, None, None, None, None, None
 
 
-def convg(x, weight, bias, stride=1, pad=0, act=ACT_NONE, need_dgrad=True, out=None):
+def convg(x, weight, bias, stride=1, pad=0, act=ACT_NONE, need_dgrad=True, out=None, dtype=torch.float32):
     """Conv2d on an nhwc tensor through the streaming MFMA kernel (any channel count that is a multiple of 4).
-    out: optional ConcatBuf.slot the result is written into (the returned tensor is that channel range)."""
+    out: optional ConcatBuf.slot the result is written into (the returned tensor is that channel range).
+    dtype=torch.bfloat16: bf16 activation storage (the result is bf16; x bf16, or fp32 for the network input)."""
+    if dtype == torch.bfloat16:
+        return _ConvB.apply(x, weight, bias, stride, pad, act, False, None, need_dgrad, out)
     return _ConvG.apply(x, weight, bias, stride, pad, act, False, None, need_dgrad, out)
 
 
-def convg_transposed(x, weight, bias, out_hw, pad=1, act=ACT_NONE, out=None):
+def convg_transposed(x, weight, bias, out_hw, pad=1, act=ACT_NONE, out=None, dtype=torch.float32):
     """ConvTranspose2d(k=3, stride=2, padding=pad, output_padding=1) cropped to out_hw (crop_like)."""
+    if dtype == torch.bfloat16:
+        return _ConvB.apply(x, weight, bias, 2, pad, act, True, tuple(out_hw), True, out)
     return _ConvG.apply(x, weight, bias, 2, pad, act, True, tuple(out_hw), True, out)
 
 
@@ -1101,7 +1110,171 @@ class _HeadG(torch.autograd.Function):
 
 
 def disp_head_g(x, weight, bias, alpha, offset=3.0):
+    if x.dtype == torch.bfloat16:
+        return _HeadB.apply(x, weight, bias, alpha, offset)
     return _HeadG.apply(x, weight, bias, alpha, offset)
+
+
+# --------------------------------------------------------------------------------------------------
+# DispNetS with bf16 activation storage (BASELINE config 2; csrc/conv_bf16.hip): nhwc feature maps are torch.bfloat16,
+# parameters / parameter gradients / disparities stay float32.  One bf16 product per MAC, fp32 accumulation.
+# --------------------------------------------------------------------------------------------------
+BF16 = torch.bfloat16
+
+
+def _isbf(t):
+    return 1 if t.dtype == BF16 else 0
+
+
+def _chk_act(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype not in (torch.float32, BF16):
+            raise RuntimeError('depthinspace_amd bf16 ops need float32 / bfloat16 CUDA(HIP) tensors: the HIP path is the only path')
+        if _ld(t) is None or (t.dtype == BF16 and _ld(t) % 8):
+            raise RuntimeError('expected a dense nhwc tensor or a channel range of one (bf16: channels in multiples of 8)')
+
+
+def _convb_run(mode, x, w, bias, y, n, hin, win, cin, cin_w, hout, wout, cout, cout_w, k, stride, pad, act):
+    per = lib.fn('dis_convb_pack_workspace')(cin, cout, k)
+    if per < 0:
+        raise lib.DisHipError(f'convb: unsupported shape cin={cin} cout={cout} k={k}')
+    wp = torch.empty(per * 4, dtype=torch.int16, device=x.device)
+    ldy = y.stride(2) if y.dim() == 4 else 1
+    lib.call('dis_convb_run', mode, x, _isbf(x), _ld(x), 0, w, bias, y, _isbf(y), ldy, 0, wp, n, hin, win, cin, cin_w,
+             hout, wout, cout, cout_w, k, stride, pad, act)
+
+
+def _convb_wgrad(X, hX, wX, cX, cX_w, G, hG, wG, cG, cG_w, gw, n, k, stride, pad):
+    wsz = lib.fn('dis_convb_wgrad_workspace')(n, hG, wG, cX, cG, k)
+    if wsz < 0:
+        raise lib.DisHipError('convb wgrad: unsupported shape')
+    ws = torch.empty(wsz, dtype=torch.float32, device=X.device)
+    lib.call('dis_convb_wgrad', X, _isbf(X), _ld(X), 0, hX, wX, cX, cX_w, G, _isbf(G), _ld(G), 0, hG, wG, cG, cG_w, gw, ws,
+             n, k, stride, pad)
+
+
+def _colsum_b(G, c_real):
+    npix = G.shape[0] * G.shape[1] * G.shape[2]
+    out = torch.empty(c_real, dtype=torch.float32, device=G.device)
+    ws = torch.empty(lib.fn('dis_colsum_bf16_workspace')(c_real), dtype=torch.float32, device=G.device)
+    lib.call('dis_colsum_bf16', G, _ld(G), 0, npix, c_real, out, ws)
+    return out
+
+
+class _ConvB(torch.autograd.Function):
+    """_ConvG with bf16 activation storage: x fp32 (the network input) or bf16, y bf16 (or a slot of a bf16 ConcatBuf)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act, transposed, out_hw, need_dgrad, out=None):
+        x, weight = _nhwc(x), _c(weight)
+        _chk(weight, bias)
+        _chk_act(x)
+        n, hin, win, cin_mem = x.shape
+        if transposed:
+            cin_w, cout, k, _ = weight.shape
+            hout, wout = out_hw
+            if stride != 2 or hout > 2 * hin or wout > 2 * win:
+                raise RuntimeError('transposed conv: stride 2 and out_hw <= 2x input expected')
+        else:
+            cout, cin_w, k, _ = weight.shape
+            hout, wout = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
+        if cin_w > cin_mem or cout % 8:
+            raise RuntimeError(f'convb: bad channel counts cin_mem={cin_mem} cin_w={cin_w} cout={cout}')
+        if out is None:
+            y = torch.empty((n, hout, wout, cout), dtype=BF16, device=x.device)
+        else:
+            buf, off, c = out
+            if c != cout or tuple(buf.shape[:3]) != (n, hout, wout) or buf.dtype != BF16:
+                raise RuntimeError(f'convb: out slot {tuple(buf.shape)}[{off}:{off + c}] does not fit ({n},{hout},{wout},{cout})')
+            y = buf[..., off:off + c]
+        _convb_run(CONVG_TCONV if transposed else CONVG_CONV, x, weight, bias, y, n, hin, win, cin_mem, cin_w, hout, wout,
+                   cout, cout, k, stride, pad, act)
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        ctx.cfg = (stride, pad, act, transposed, bias is not None, need_dgrad)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        stride, pad, act, transposed, has_bias, need_dgrad = ctx.cfg
+        n, hin, win, cin_mem = x.shape
+        gy = _nhwc(gy)
+        _, hout, wout, cout = gy.shape
+        k = weight.shape[2]
+        cin_w = weight.shape[0] if transposed else weight.shape[1]
+        if act != ACT_NONE or not gy.is_contiguous():
+            gpre = torch.empty(gy.shape, dtype=BF16, device=gy.device)
+            lib.call('dis_act_bwd_bf16', gy, _ld(gy), y, _ld(y) if y is not None else 0, gpre, act, n * hout * wout, cout)
+        else:
+            gpre = gy
+        gx = None
+        if need_dgrad and ctx.needs_input_grad[0]:
+            gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            _convb_run(CONVG_TCONV_DGRAD if transposed else CONVG_CONV_DGRAD, gpre, weight, None, gx, n, hout, wout, cout,
+                       cout, hin, win, cin_mem, cin_w, k, stride, pad, ACT_NONE)
+        gw, gw_ret = _sink(weight)
+        if transposed:
+            _convb_wgrad(gpre, hout, wout, cout, cout, x, hin, win, cin_mem, cin_w, gw, n, k, stride, pad)
+        else:
+            _convb_wgrad(x, hin, win, cin_mem, cin_w, gpre, hout, wout, cout, cout, gw, n, k, stride, pad)
+        gb = _colsum_b(gpre, cout) if has_bias else None
+        _sinks_written()
+        return gx, gw_ret, gb, None, None, None, None, None, None, None
+
+
+class _HeadB(torch.autograd.Function):
+    """_HeadG on a bf16 feature map: Conv2d(cin,1,3,pad 1) + alpha*sigmoid(. - offset); the disparity is float32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, alpha, offset):
+        x, weight, bias = _c(x), _c(weight), _c(bias)
+        _chk(weight, bias)
+        _chk_act(x)
+        n, h, w, cin = x.shape
+        k = weight.shape[2]
+        y = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
+        _convb_run(CONVG_CONV, x, weight, bias, y.view(n, h, w, 1), n, h, w, cin, weight.shape[1], h, w, 1, 1, k, 1, k // 2,
+                   ACT_NONE)
+        lib.call('dis_sigmoid_affine_fwd', y, y, float(alpha), float(offset), y.numel())
+        ctx.save_for_backward(x, weight, y)
+        ctx.alpha = float(alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        n, h, w, cin = x.shape
+        k = weight.shape[2]
+        cin_w = weight.shape[1]
+        gpre4 = torch.empty((n, h, w, 4), dtype=torch.float32, device=x.device)
+        lib.call('dis_sigmoid_affine_bwd', y, _c(gy), gpre4, ctx.alpha, n * h * w)
+        gx = torch.empty_like(x)
+        _convb_run(CONVG_CONV_DGRAD, gpre4, weight, None, gx, n, h, w, 4, 1, h, w, cin, cin_w, k, 1, k // 2, ACT_NONE)
+        gw = torch.empty_like(weight)
+        _convb_wgrad(x, h, w, cin, cin_w, gpre4, h, w, 4, 1, gw, n, k, 1, k // 2)
+        gb = _colsum(gpre4, 1)
+        return gx, gw, gb, None, None
+
+
+class _WriteChannelsB(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, slot, zero_tail):
+        buf, off, c = slot
+        n, h, w, cs = src.shape
+        assert cs == c and tuple(buf.shape[:3]) == (n, h, w) and buf.dtype == BF16
+        src = _nhwc(src)
+        _chk_act(src) if src.dtype == BF16 else None
+        dst = buf[..., off:off + c]
+        lib.call('dis_copy_channels_bf16', src, _isbf(src), src.stride(2), dst, buf.shape[3], n * h * w, c,
+                 buf.shape[3] - off - c if zero_tail else 0)
+        ctx.src_dtype = src.dtype
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g if ctx.src_dtype == BF16 else g.float()), None, None
 
 
 # --------------------------------------------------------------------------------------------------

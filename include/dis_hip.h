@@ -394,6 +394,32 @@ int dis_colsum(const float* G, int ldG, int goff, long npix, int c, float* out, 
 int dis_sigmoid_affine_fwd(const float* x, float* y, float alpha, float offset, long count, void* stream);
 int dis_sigmoid_affine_bwd(const float* y, const float* gy, float* gpre4, float alpha, long count, void* stream);
 
+/* ---------------------------------------------------------------- DispNetS, bf16 activation storage -------- */
+
+/* BASELINE config 2 ("DIS-SF bs=8 ... bf16"): the encoder-decoder's nhwc feature maps are stored as bf16, convolutions
+ * are ONE bf16 x bf16 product per MAC with fp32 accumulation; parameters, their gradients, disparities and losses stay
+ * fp32.  Same modes / argument meaning as dis_convg_run and dis_convg_wgrad (reference model/networks.py:170-295:
+ * Conv2d k7/k5/k3 s1/s2 + ReLU, ConvTranspose2d(k3,s2,p1,op1) + crop_like), with a storage flag per tensor
+ * (x_bf16 / y_bf16 / g_bf16: 1 = bf16, 0 = fp32) and ld / channel offsets counted in ELEMENTS of the tensor's own
+ * type (bf16: multiples of 8, fp32: multiples of 4).  dis_convb_pack_workspace counts 16-bit words per phase (x4). */
+long dis_convb_pack_workspace(int cin, int cout, int k);
+int dis_convb_run(int mode, const void* x, int x_bf16, int ldx, int xoff, const float* w, const float* bias, void* y,
+                  int y_bf16, int ldy, int yoff, void* wpack, int n, int hin, int win, int cin, int cin_w, int hout,
+                  int wout, int cout, int cout_w, int k, int stride, int pad, int act, void* stream);
+long dis_convb_wgrad_workspace(int n, int hG, int wG, int cX, int cG, int k);
+int dis_convb_wgrad(const void* X, int x_bf16, int ldX, int xoff, int hX, int wX, int cX, int cX_w, const void* G,
+                    int g_bf16, int ldG, int goff, int hG, int wG, int cG, int cG_w, float* grad_w, float* workspace, int n,
+                    int k, int stride, int pad, void* stream);
+/* gpre = gy * act'(y) on channel ranges (ldg / ldy elements per pixel) of bf16 nhwc buffers; gpre dense (npix, c) bf16 */
+int dis_act_bwd_bf16(const void* gy, int ldg, const void* y, int ldy, void* gpre, int act, long npix, int c,
+                     void* stream);
+/* dis_copy_channels into a bf16 buffer from an fp32 (src_bf16 = 0) or bf16 source */
+int dis_copy_channels_bf16(const void* src, int src_bf16, int lds, void* dst, int ldd, long npix, int c, int czero,
+                           void* stream);
+/* dis_colsum of a bf16 tensor (bias gradients), fp32 result */
+long dis_colsum_bf16_workspace(int c);
+int dis_colsum_bf16(const void* G, int ldG, int goff, long npix, int c, float* out, float* workspace, void* stream);
+
 /* ---------------------------------------------------------------- augmentation -------------- */
 
 /* Training-time augmentation of the IR and ambient images on the device (reference data/data_manipulation.py:114-195 with
