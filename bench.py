@@ -93,6 +93,9 @@ def main():
     ap.add_argument('--bs', type=int, default=None, help='tracks per GPU (default 4 for multi_frame, 8 for single_frame)')
     ap.add_argument('--arch', default='multi_frame', choices=['multi_frame', 'single_frame'],
                     help='multi_frame = BASELINE.json metric (config 3/4); single_frame = DIS-SF (config 2, run in fp32)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='single_frame only: bf16 = DispNetS with bf16 activation storage (BASELINE config 2; one bf16 product per '
+                         'MAC, fp32 accumulate; parameters / disparities / losses fp32), reported under its own label')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of one hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eager-leg', action='store_true', help='skip the eager-launch timing of the same step')
@@ -103,6 +106,8 @@ def main():
     args = ap.parse_args()
     if args.bs is None:
         args.bs = 4 if args.arch == 'multi_frame' else 8
+    if args.dtype == 'bf16' and args.arch != 'single_frame':
+        raise SystemExit('--dtype bf16 is the DIS-SF configuration (BASELINE config 2); DIS-MF runs fp32')
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -138,7 +143,10 @@ def main():
     else:
         worker = single_frame_worker.Worker(make_args(args.bs, 'single_frame'), settings=settings,
                                             train_device=str(dev))
-        net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=worker.imsizes).to(dev)
+        if args.dtype == 'bf16':
+            net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=worker.imsizes, act_dtype=torch.bfloat16).to(dev)
+        else:
+            net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=worker.imsizes).to(dev)
     worker.build_losses(device=dev)
     worker.current_epoch = args.epoch
     opt = FlatAdam(net.parameters(), lr=1e-4, world_size=world)
@@ -235,7 +243,12 @@ def main():
             # k, stride, pad, act): every launch of the streaming kernel family convg_fwd_kernel<BN>; algorithmic
             # flops use the real channel counts and the spatial size of the strided side
             sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_convg_run']
-            if ops.BF16X3:  # layers with >= 32 input channels run convg3_fwd_kernel (bf16x3): the dominant kernel
+            bf_mode = args.dtype == 'bf16'
+            if bf_mode:
+                # dis_convb_run int args: (mode, x_bf16, ldx, xoff, y_bf16, ldy, yoff, n, hin, win, cin, cin_w, hout, wout, cout,
+                # cout_w, k, stride, pad, act) -> the layout gflops() reads: drop the two storage flags
+                sel = [((ia[0],) + ia[2:4] + ia[5:], ms) for name, ia, ms in rec if name == 'dis_convb_run']
+            if ops.BF16X3 and not bf_mode:  # layers with >= 32 input channels run convg3_fwd_kernel (bf16x3): the dominant kernel
                 def sliced(ia):  # ... except the 3x3 stride-1 layers csrc/conv2d.hip:dis_bx_slices_ok() sends to the
                     # halo-resident kernel as 32-channel slice launches (iconv1/2/3, conv1b: forward and input gradient)
                     mode, n, hin, win, cin, cout, k, stride = ia[0], ia[5], ia[6], ia[7], ia[8], ia[12], ia[14], ia[15]
@@ -249,7 +262,11 @@ def main():
                 return 2.0 * n * hw * cw * cow * k * k
             fl = sum(gflops(ia) for ia, _ in sel)
             kname = 'convg_fwd_kernel<BN> (fp32 MFMA 16x16x4, all conv / dgrad / transposed-conv launches)'
-            if ops.BF16X3:
+            if bf_mode:
+                kname = ('convb_fwd_kernel<BN> (bf16 activations x bf16 weights on v_mfma_f32_16x16x32_bf16, fp32 accumulate: all '
+                         'conv / dgrad / transposed-conv launches of DispNetS)')
+                peak, peak_note = PEAK_BF16_MFMA_TFLOPS, 'bf16 MFMA dense peak'
+            elif ops.BF16X3:
                 kname = ('convg3_fwd_kernel<BN> (fp32 conv as 6 bf16 products per MAC on v_mfma_f32_16x16x32_bf16; all '
                          'conv / dgrad / transposed-conv launches with >= 32 input channels; TFLOP/s are fp32-equivalent '
                          'algorithmic flops)')
@@ -318,10 +335,10 @@ def main():
         frames = world * args.bs * TL * args.steps
         res = {
             'metric': ('DIS-MF train frames/sec bs=4 default-pattern' if mf else
-                       f'DIS-SF train frames/sec bs={args.bs} default-pattern (fp32)'),
+                       f'DIS-SF train frames/sec bs={args.bs} default-pattern ({"bf16 activation storage" if args.dtype == "bf16" else "fp32"})'),
             'value': frames / dt, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': (f'DIS-MF (FuseNet)' if mf else 'DIS-SF (DispNetS)') +
                                    f' training step, bs={args.bs} per GPU x 4 frames, 512x432, '
                                    f'default-pattern synthetic, fwd+losses+bwd+Adam, epoch>={args.epoch}',
@@ -334,7 +351,12 @@ def main():
                                             'fp32 results everywhere; forward / input-gradient convs with >= 32 input '
                                             'channels run as bf16x3 (3-way bf16 operand split, 6 products, fp32 accumulate), '
                                             'the others and the streaming weight gradients on v_mfma_f32_16x16x4_f32')
-                                           if ops.BF16X3 else 'v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains)')},
+                                           if ops.BF16X3 else 'v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains)')
+                       if args.dtype == 'f32' else
+                       ('bf16 ACTIVATION STORAGE (BASELINE config 2): nhwc feature maps in bf16, forward / input-gradient / '
+                        'transposed convs = one bf16 x bf16 product per MAC on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, '
+                        'weight gradients on v_mfma_f32_16x16x4_f32 from the bf16 values; parameters, their gradients, disparities '
+                        'and losses fp32.  Not the parity path: disparity L1 vs the fp32 oracle 0.01 px (tests/test_sf_bf16_gpu.py)')},
             'roofline': roof, 'roofline_hbm_kernels': hbm, 'cpu_baseline': cpu, 'loss_terms': losses,
             'eager_launch_frames_per_s': eager_fps, 'adam_steps_taken': adam_steps, 'step_mode': stepper.mode,
             'kernel_ms_one_eager_step': kernel_ms,

@@ -7,9 +7,10 @@ stated bounds:
   * operator level, EXACT-ARITHMETIC reference: against torch's fp32 convolution of the SAME bf16-rounded operands the
     outputs agree to bf16 output rounding (2^-8 relative, asserted 1.2 * 2^-8 of the largest entry) and the fp32 weight /
     bias gradients to 2e-3;
-  * network level, vs the fp32 CPU oracle on fp32 inputs: full-resolution disparity L1 < 0.25 px on a 0..128 px range
-    (measured 0.02 - 0.09 px with random weights; every layer rounds its output to 8 significant bits), parameter-gradient
-    cosine > 0.98 against the oracle's gradients."""
+  * network level, vs the fp32 CPU oracle on fp32 inputs: full-resolution disparity L1 < 0.05 px on a 0..128 px range
+    (measured on MI355X: 0.0096 px at scale 0, 3e-4 .. 4e-5 px at the coarser scales, random weights; every layer rounds
+    its output to 8 significant bits), parameter-gradient cosine > 0.99 against the oracle's gradients (measured >= 0.9956);
+  * whole step on a reference-generated fixture: loss terms within 1.5 % (measured <= 0.15 %)."""
 import argparse
 import os
 
@@ -117,13 +118,13 @@ def test_dispnets_bf16_vs_fp32_oracle(H, W):
         a, b = p.grad.cpu().double().reshape(-1), params[k].grad.double().reshape(-1)
         cos.append((float(a @ b / (a.norm() * b.norm() + 1e-300)), k))
     print('DispNetS bf16', H, W, 'disparity L1 per scale', l1s, 'worst gradient cosine', min(cos))
-    assert max(l1s) < 0.25, l1s
-    assert min(cos)[0] > 0.98, min(cos)
+    assert max(l1s) < 0.05, l1s
+    assert min(cos)[0] > 0.99, min(cos)
 
 
 def test_sf_step_bf16_vs_reference_golden(golden_dir):
-    """whole DIS-SF step with bf16 activation storage on the reference-generated fixture's inputs: loss terms within 3 %
-    (terms below 1e-3 within 1e-4 absolute), disparity L1 < 0.25 px, and the Adam update moves the same way."""
+    """whole DIS-SF step with bf16 activation storage on the reference-generated fixture's inputs: loss terms within 1.5 %
+    (terms below 1e-3 within 1e-4 absolute), disparity L1 < 0.05 px, and the Adam update moves the same way."""
     from depthinspace_amd import synth
     from depthinspace_amd.model import networks, single_frame_worker
     from depthinspace_amd.trainer import FlatAdam
@@ -146,8 +147,8 @@ def test_sf_step_bf16_vs_reference_golden(golden_dir):
     l1 = [float((o.detach().cpu() - torch.from_numpy(G[f'out{i}'])).abs().mean()) for i, o in enumerate(outs)]
     vals = np.array([float(e.detach()) for e in errs])
     print('bf16 step: disparity L1', l1, 'loss terms', vals, 'reference', G['vals'])
-    assert max(l1) < 0.25
-    assert np.all(np.abs(vals - G['vals']) <= 0.03 * np.abs(G['vals']) + 1e-4)
+    assert max(l1) < 0.05
+    assert np.all(np.abs(vals - G['vals']) <= 0.015 * np.abs(G['vals']) + 1e-4)
     agree = tot = 0
     named = dict(net.named_parameters())
     for k in G.files:
