@@ -98,6 +98,7 @@ def main():
                          'MAC, fp32 accumulate; parameters / disparities / losses fp32), reported under its own label')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of one hipGraph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dump-calls', default=None, help='write the per-call HIP-event times of one eager step to this file')
     ap.add_argument('--no-eager-leg', action='store_true', help='skip the eager-launch timing of the same step')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the '
@@ -217,6 +218,11 @@ def main():
         rec = lib.profile_stop()
         for t, c in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev), snap):
             t.copy_(c)               # the profiled extra step is undone: replicas stay identical
+        if args.dump_calls:
+            os.makedirs(os.path.dirname(os.path.abspath(args.dump_calls)), exist_ok=True)
+            with open(args.dump_calls, 'w') as f:
+                for name, ia, ms in rec:
+                    f.write('%s %.4f %s\n' % (name, ms, ' '.join(str(v) for v in ia)))
         per = {}
         for name, ia, ms in rec:
             per.setdefault(name, [0, 0.0])

@@ -1577,10 +1577,12 @@ static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 // K x K taps, stride S, TR x 16 output pixels per tile (TR / 2 k-steps of 32 pixels).  The FuseNet instances are
 // K = 3, S = 1, TR = 8; the slice-pair instances of DispNetS also use 5 x 5 taps and stride 2.
-template <int CIN, int COUT, int K = 3, int S = 1, int TR = 8, int KH = K>
+// NP = bf16 planes per value (3: fp32 inputs split on the way into LDS; 1: the inputs ARE bf16, conv_bf16.hip), CPI = channels
+// per 16-byte staging item (4 floats / 8 bf16)
+template <int CIN, int COUT, int K = 3, int S = 1, int TR = 8, int KH = K, int NP = 3, int CPI = 4>
 struct WxCfg {
-  static constexpr int PSX = 3 * CIN + 8, PSG = 3 * COUT + 8;  // LDS pixel strides (16-bit units), as BxCfg::PS
-  static constexpr int CVX = CIN / 4, CVG = COUT / 4;
+  static constexpr int PSX = NP * CIN + 8, PSG = NP * COUT + 8;  // LDS pixel strides (16-bit units), as BxCfg::PS
+  static constexpr int CVX = CIN / CPI, CVG = COUT / CPI;
   static constexpr int IR = (TR - 1) * S + KH, IC = 15 * S + K;  // halo of the x tile (KH of the K tap rows per workgroup)
   static constexpr int X_U16 = IR * IC * PSX, G_U16 = TR * 16 * PSG;
   static constexpr int LDS_BYTES = (X_U16 + G_U16) * 2 + 1024 * 4;
@@ -1605,9 +1607,13 @@ __device__ __forceinline__ s16x8 tr_read8(const unsigned short* p0, const unsign
   return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int CIN, int COUT, int INACT = 0, bool GEN = false, int K = 3, int S = 1, int TR = 8, int KH = K>
+template <int CIN, int COUT, int INACT = 0, bool GEN = false, int K = 3, int S = 1, int TR = 8, int KH = K, bool BF = false>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
-  using C = WxCfg<CIN, COUT, K, S, TR, KH>;
+  // BF: x and gy hold bf16 values (a.x / a.gy point at 16-bit elements; ldx / xoff / ldg / goff count elements): one plane,
+  // one product per MAC, no split - the bf16 activation storage mode of DispNetS (conv_bf16.hip)
+  constexpr int NP = BF ? 1 : 3, CPI = BF ? 8 : 4, ES = BF ? 2 : 4;
+  static_assert(!BF || (GEN && INACT == 0), "bf16 inputs: slice-pair form only");
+  using C = WxCfg<CIN, COUT, K, S, TR, KH, NP, CPI>;
   const int ky0 = KH < K ? (int)blockIdx.z * KH : 0;  // first tap row of this workgroup (7x7: two groups of 4 rows)
   constexpr int WX_IC = C::IC;
   static_assert(GEN || (K == 3 && S == 1 && TR == 8), "the FuseNet form");
@@ -1643,22 +1649,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
     const int vv = idx % C::CVX, pix = idx / C::CVX;
     const int r = pix / WX_IC, c = pix % WX_IC;
     // (channels past the layer's last one - ragged last slice - get the out-of-image row too: they load zeros)
-    ix_rc[it] = (idx < C::NIX && (!GEN || 32 * cb + vv * 4 < a.cx)) ? (r | (c << 16)) : 0x4000;
-    ix_off[it] = ((r * a.win + c) * ldx + xc0 + vv * 4) * 4;
+    ix_rc[it] = (idx < C::NIX && (!GEN || 32 * cb + vv * CPI < a.cx)) ? (r | (c << 16)) : 0x4000;
+    ix_off[it] = ((r * a.win + c) * ldx + xc0 + vv * CPI) * ES;
   }
 #pragma unroll
   for (int it = 0; it < NLG; ++it) {
     const int idx = threadIdx.x + it * 256;
     const int vv = idx % C::CVG, pix = idx / C::CVG;
-    ig_rc[it] = (!GEN || COUT * gbk + vv * 4 < a.cg) ? ((pix >> 4) | ((pix & 15) << 16)) : 0x4000;
-    ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * ldg + gc0 + vv * 4) * 4;
+    ig_rc[it] = (!GEN || COUT * gbk + vv * CPI < a.cg) ? ((pix >> 4) | ((pix & 15) << 16)) : 0x4000;
+    ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * ldg + gc0 + vv * CPI) * ES;
   }
-  const unsigned x_bytes = (unsigned)a.hin * a.win * (ldx * 4u), g_bytes = (unsigned)a.hout * a.wout * (ldg * 4u);
+  const unsigned x_bytes = (unsigned)a.hin * a.win * (ldx * (unsigned)ES), g_bytes = (unsigned)a.hout * a.wout * (ldg * (unsigned)ES);
   auto prefetch = [&](int tile) __attribute__((always_inline)) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * (TR * S) - a.pad + ky0, ix0 = tx * (16 * S) - a.pad;
-    const float* xb = a.x + (long)n * a.hin * a.win * ldx;
-    const int xoff0 = (iy0 * a.win + ix0) * (ldx * 4);
+    const char* xb = (const char*)a.x + (long)n * a.hin * a.win * ldx * ES;
+    const int xoff0 = (iy0 * a.win + ix0) * (ldx * ES);
 #pragma unroll
     for (int it = 0; it < NLX; ++it) {
       const int iy = iy0 + (ix_rc[it] & 0xffff), ix = ix0 + (ix_rc[it] >> 16);
@@ -1666,8 +1672,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
       prex[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(xb, x_bytes), ok ? (unsigned)(xoff0 + ix_off[it]) : BX_OOB, 0, 0));
     }
-    const float* gb = a.gy + (long)n * a.hout * a.wout * ldg;
-    const int goff0 = (ty * TR * a.wout + tx * 16) * (ldg * 4);
+    const char* gb = (const char*)a.gy + (long)n * a.hout * a.wout * ldg * ES;
+    const int goff0 = (ty * TR * a.wout + tx * 16) * (ldg * ES);
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
       const int oy = ty * TR + (ig_rc[it] & 0xffff), ox = tx * 16 + (ig_rc[it] >> 16);
@@ -1676,11 +1682,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
                                                 bx_rsrc(gb, g_bytes), ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
       if (INACT)
         preg2[it] = __builtin_bit_cast(
-            float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.gact + (gb - a.gy), g_bytes),
+            float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc((const char*)a.gact + (gb - (const char*)a.gy), g_bytes),
                                                           ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
     }
   };
   auto put3 = [&](unsigned short* p, const float4& v, int plane) __attribute__((always_inline)) {
+    if (BF) {  // 8 bf16 values, as loaded
+      *(float4*)p = v;
+      return;
+    }
     unsigned a1, a2, a3, b1, b2, b3;
     split3_pair(v.x, v.y, a1, a2, a3);
     split3_pair(v.z, v.w, b1, b2, b3);
@@ -1693,7 +1703,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
 #pragma unroll
     for (int it = 0; it < NLX; ++it) {
       const int idx = (int)threadIdx.x + it * 256;
-      if (idx < C::NIX) put3(xl + (idx / C::CVX) * PSX + (idx % C::CVX) * 4, prex[it], CIN);
+      if (idx < C::NIX) put3(xl + (idx / C::CVX) * PSX + (idx % C::CVX) * CPI, prex[it], CIN);
     }
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
@@ -1704,8 +1714,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
         v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
         v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
       }
-      bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-      put3(gl + (idx / C::CVG) * PSG + (idx % C::CVG) * 4, v, COUT);
+      if (!BF) bsum.x += v.x, bsum.y += v.y, bsum.z += v.z, bsum.w += v.w;
+      put3(gl + (idx / C::CVG) * PSG + (idx % C::CVG) * CPI, v, COUT);
     }
   };
 
@@ -1720,7 +1730,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
       const int pr = 2 * ks + (lg >> 1), pc0 = 8 * (lg & 1);
       const unsigned short* gq = gl + (pr * 16 + pc0 + tq) * PSG + tp * 4;
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) F[p][nb] = tr_read8(gq + p * COUT + nb * 16, gq + 4 * PSG + p * COUT + nb * 16);
     };
@@ -1729,7 +1739,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
       const int tap = CIN == 32 ? mb >> 1 : mb, half = CIN == 32 ? mb & 1 : 0, ky = tap / K, kx = tap - K * ky;
       const unsigned short* xq = xl + ((pr * S + ky) * WX_IC + (pc0 + tq) * S + kx) * PSX + half * 16 + tp * 4;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) F[p] = tr_read8(xq + p * CIN, xq + 4 * S * PSX + p * CIN);
+      for (int p = 0; p < NP; ++p) F[p] = tr_read8(xq + p * CIN, xq + 4 * S * PSX + p * CIN);
     };
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       __syncthreads();
@@ -1750,11 +1760,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
           int nread = 0;
           if (u + 1 < NU) {
             const int ks2 = (u + 1) / NGD, gi2 = (u + 1) % NGD;
-            if (gi2 == 0) load_fb(ks2, fb[ks2 & 1]), nread += 6 * NB;
+            if (gi2 == 0) load_fb(ks2, fb[ks2 & 1]), nread += 2 * NP * NB;
             load_fa(ks2, MB0 + gi2, fa[(u + 1) & 1]);
-            nread += 6;
+            nread += 2 * NP;
           }
-          constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+          constexpr int NQ = BF ? 1 : 6;  // products per MAC (bf16 inputs: the one exact product)
+          constexpr int PA[6] = {BF ? 0 : 2, 1, 0, 1, 0, 0};
           constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
           int nm = 0;
 #pragma unroll
@@ -1762,11 +1773,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
             const int t = NB * mb + nb;
             if (t >= T0 && t < T1) {
 #pragma unroll
-              for (int q = 0; q < 6; ++q)
+              for (int q = 0; q < NQ; ++q)
                 acc[t - T0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[u & 1][PA[q]]),
                                                                       __builtin_bit_cast(bf16x8, fb[ks & 1][PB[q]][nb]),
                                                                       acc[t - T0], 0, 0, 0);
-              nm += 6;
+              nm += NQ;
             }
           }
           // issue order: MFMA, then up to ceil(nread / nm) of the next unit's reads
@@ -1895,22 +1906,23 @@ static void wgrad_pairs_plan(int n, int hG, int wG, int cX, int cG, int tr, int*
 }
 // eligibility and workspace (floats) of the slice-pair form; -1: use the fp32 kernel
 long dis_wgrad_pairs_workspace(int n, int hX, int wX, int hG, int wG, int cX, int cG, int ldX, int ldG, int k,
-                               int stride) {
+                               int stride, int bf) {
   static const bool use3 = !(getenv("DIS_CONV_BF16X3") && getenv("DIS_CONV_BF16X3")[0] == '0');
   const int tr = wgrad_pairs_tr(k, stride);
   // (a 16-channel x slice fills half of its block)
   if (!use3 || tr == 0 || cX < 16 || (cG < 32 && wgrad_pairs_cob(cG, k, stride) != 16)) return -1;
   if ((long)hX * wX * ldX * 4 >= 0x7fff0000L || (long)hG * wG * ldG * 4 >= 0x7fff0000L) return -1;
+  if (bf && ((ldX | ldG) & 7)) return -1;  // bf16 inputs: 16-byte staging items of 8 channels
   int npx, ngb, wpp;
   wgrad_pairs_plan(n, hG, wG, cX, cG, tr, &npx, &ngb, &wpp);
   return (long)npx * ngb * wpp * (k == 7 ? 2 * 4 * 7 : k * k) * 1024;  // (7x7: two groups of 4 tap rows)
 }
-template <int K, int S, int TR, int KH = K, int COB = 32>
+template <int K, int S, int TR, int KH = K, int COB = 32, bool BF = false>
 static int wgrad_pairs_launch(WgArgs a, float* grad_w, int cX_w, int cG_w, int ngb, int wpp, hipStream_t s) {
-  using XC = WxCfg<32, COB, K, S, TR, KH>;
+  using XC = WxCfg<32, COB, K, S, TR, KH, BF ? 1 : 3, BF ? 8 : 4>;
   static_assert(XC::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
   constexpr int NGRP = (K + KH - 1) / KH;
-  auto kern = conv_wgrad_bf16x3_kernel<32, COB, 0, true, K, S, TR, KH>;
+  auto kern = conv_wgrad_bf16x3_kernel<32, COB, 0, true, K, S, TR, KH, BF>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XC::LDS_BYTES);
@@ -1926,7 +1938,8 @@ static int wgrad_pairs_launch(WgArgs a, float* grad_w, int cX_w, int cG_w, int n
 }
 int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int hX, int wX, int cX, int cX_w, const float* G, int ldG,
                         int goff, int hG, int wG, int cG, int cG_w, float* grad_w, float* workspace, int n, int k,
-                        int stride, int pad, hipStream_t s) {
+                        int stride, int pad, int bf, hipStream_t s) {
+  // bf: X and G point at bf16 elements (ldX / xoff / ldG / goff in elements, multiples of 8)
   const int tr = wgrad_pairs_tr(k, stride);
   int npx, ngb, wpp;
   wgrad_pairs_plan(n, hG, wG, cX, cG, tr, &npx, &ngb, &wpp);
@@ -1935,6 +1948,17 @@ int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int hX, int wX, int c
   a.n = n; a.hin = hX; a.win = wX; a.hout = hG; a.wout = wG; a.pad = pad;
   a.xscale = nullptr; a.gact = nullptr;
   a.ldx = ldX; a.xoff = xoff; a.cx = cX; a.ldg = ldG; a.goff = goff; a.cg = cG; a.npx = npx;
+  if (bf) {
+    if ((xoff | goff) & 7) return DIS_ERR_UNSUPPORTED;
+    if (k == 3 && stride == 1 && wgrad_pairs_cob(cG, k, stride) == 16)
+      return wgrad_pairs_launch<3, 1, 8, 3, 16, true>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
+    if (k == 3 && stride == 1) return wgrad_pairs_launch<3, 1, 8, 3, 32, true>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
+    if (k == 5 && stride == 1) return wgrad_pairs_launch<5, 1, 8, 5, 32, true>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
+    if (k == 3 && stride == 2) return wgrad_pairs_launch<3, 2, 4, 3, 32, true>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
+    if (k == 5 && stride == 2) return wgrad_pairs_launch<5, 2, 4, 5, 32, true>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
+    if (k == 7 && stride == 1) return wgrad_pairs_launch<7, 1, 8, 4, 32, true>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
+    return DIS_ERR_UNSUPPORTED;
+  }
   if (k == 3 && stride == 1 && wgrad_pairs_cob(cG, k, stride) == 16)
     return wgrad_pairs_launch<3, 1, 8, 3, 16>(a, grad_w, cX_w, cG_w, ngb, wpp, s);
   if (k == 3 && stride == 1) return wgrad_pairs_launch<3, 1, 8>(a, grad_w, cX_w, cG_w, ngb, wpp, s);

@@ -493,6 +493,86 @@ __global__ void convb_wgrad_reduce_kernel(const float* __restrict__ part, float*
     gw[((long)g * cXw + x) * ntaps + tap] = (float)s;
   }
 }
+// ---- weight gradient of a disparity head: ONE gradient channel (cG_w = 1), 3x3, stride 1, x bf16 ----
+// dW[tap][c] = sum_o x[o + tap - pad][c] * g[o] is a reduction with 9 cX outputs: no matrix core needed, HBM-bound on the one
+// read of x.  Thread = (8-channel chunk, pixel slot): per x pixel one 16-byte load and 9 gradient scalars (neighbouring
+// output pixels: served by L1 / L2), 72 register accumulators; lanes of a chunk are folded with xor-shuffles, waves through LDS,
+// workgroups through [block][tap][cX] slabs finished by convb_head_reduce_kernel (fp64, fixed order: deterministic).
+#define CBH_BLOCKS 512
+template <int C8, bool GB>
+__global__ __launch_bounds__(256) void convb_head_wgrad_kernel(const bf16_t* __restrict__ X, int ldX, int xoff,
+                                                               const void* __restrict__ G, int ldG, int goff,
+                                                               float* __restrict__ part, int n, int h, int w, int pad) {
+  constexpr int PPB = 256 / C8, CX = 8 * C8;
+  __shared__ float red[4][9 * CX];
+  const int chunk = threadIdx.x % C8, slot = threadIdx.x / C8;
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  const long npix = (long)n * h * w;
+  for (long p = (long)blockIdx.x * PPB + slot; p < npix; p += (long)gridDim.x * PPB) {
+    const int xx = (int)(p % w);
+    const long r = p / w;
+    const int yy = (int)(r % h);
+    const uint4 v = *(const uint4*)(X + p * ldX + xoff + chunk * 8);
+    const float xv[8] = {cb_lo(v.x), cb_hi(v.x), cb_lo(v.y), cb_hi(v.y), cb_lo(v.z), cb_hi(v.z), cb_lo(v.w), cb_hi(v.w)};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int oy = yy - ky + pad, ox = xx - kx + pad;
+        float g = 0.f;
+        if ((unsigned)oy < (unsigned)h && (unsigned)ox < (unsigned)w) {
+          const long o = p + (long)(pad - ky) * w + (pad - kx);
+          g = GB ? __uint_as_float((unsigned)((const bf16_t*)G)[o * ldG + goff] << 16) : ((const float*)G)[o * ldG + goff];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] = fmaf(g, xv[j], acc[ky * 3 + kx][j]);
+      }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = acc[t][j];
+#pragma unroll
+      for (int m = C8; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+      if (lane < C8) red[wave][t * CX + chunk * 8 + j] = a;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * CX; i += 256)
+    part[(long)blockIdx.x * (9 * CX) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+// gw[0][x][tap] = sum over the workgroup slabs, one wave per output (lanes stride over the slabs in fp64, fixed fold order)
+__global__ __launch_bounds__(256) void convb_head_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
+                                                                int nslab, int cX, int cXw) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= 9 * cXw) return;
+  const int tap = o / cXw, x = o % cXw;
+  double s = 0.0;
+  for (int k = lane; k < nslab; k += 64) s += (double)part[(long)k * (9 * cX) + tap * cX + x];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  if (lane == 0) gw[(long)x * 9 + tap] = (float)s;
+}
+static bool cbh_eligible(int x_bf16, int cX, int cG_w, int k, int stride, int ldX, int xoff) {
+  return x_bf16 && cG_w == 1 && k == 3 && stride == 1 && (cX == 16 || cX == 32 || cX == 64 || cX == 128) &&
+         !((ldX | xoff) & 7);
+}
+template <bool GB>
+static void cbh_launch(int c8, int blocks, const void* X, int ldX, int xoff, const void* G, int ldG, int goff, float* part,
+                       int n, int h, int w, int pad, hipStream_t s) {
+#define CBH_CASE(C8_) \
+  if (c8 == C8_)      \
+    hipLaunchKernelGGL((convb_head_wgrad_kernel<C8_, GB>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)X, ldX, xoff, G, ldG, \
+                       goff, part, n, h, w, pad);
+  CBH_CASE(2) CBH_CASE(4) CBH_CASE(8) CBH_CASE(16)
+#undef CBH_CASE
+}
+
 static void cbw_tiles(int cX, int cG, int* mtw, int* ntw) {
   *mtw = cX > 32 ? 2 : 1;
   *ntw = cG > 32 ? 2 : 1;
@@ -515,12 +595,27 @@ static void cbw_plan(int n, int hG, int wG, int cX, int cG, int k, int* nxb, int
   *nsplit = (int)sp;
   *mper = (int)mp;
 }
+// bf16 x AND bf16 gy, >= 16 / 32 channels, 3x3 / 5x5 / 7x7 taps: the one-pass slice-pair kernel of conv2d.hip in its
+// bf16-input form (conv_wgrad_bf16x3_kernel<..., BF = true>: one bf16 MFMA product per MAC, operands fetched from the
+// [pixel][channel] LDS images with the transposing read)
+long dis_wgrad_pairs_workspace(int n, int hX, int wX, int hG, int wG, int cX, int cG, int ldX, int ldG, int k,
+                               int stride, int bf);
+int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int hX, int wX, int cX, int cX_w, const float* G, int ldG,
+                        int goff, int hG, int wG, int cG, int cG_w, float* grad_w, float* workspace, int n, int k,
+                        int stride, int pad, int bf, hipStream_t s);
+
 extern "C" long dis_convb_wgrad_workspace(int n, int hG, int wG, int cX, int cG, int k) {
   if (n <= 0 || hG <= 0 || wG <= 0 || cX <= 0 || cG <= 0 || k <= 0 || k * k > CB_MAXTAPS) return -1;
   int nxb, ngb, nsplit, mper, mtw, ntw;
   cbw_plan(n, hG, wG, cX, cG, k, &nxb, &ngb, &nsplit, &mper);
   cbw_tiles(cX, cG, &mtw, &ntw);
-  return (long)nsplit * k * k * (nxb * 32 * mtw) * (ngb * 32 * ntw);
+  const long f32 = (long)nsplit * k * k * (nxb * 32 * mtw) * (ngb * 32 * ntw);
+  // (the slice-pair form, if dis_convb_wgrad takes it for this layer: the stride is not known here, so size for both)
+  const long b1 = dis_wgrad_pairs_workspace(n, 1, 1, hG, wG, cX, cG, 8, 8, k, 1, 1);
+  const long b2 = dis_wgrad_pairs_workspace(n, 1, 1, hG, wG, cX, cG, 8, 8, k, 2, 1);
+  long b3 = b1 > b2 ? b1 : b2;
+  if (cG <= 4 && k == 3 && b3 < (long)CBH_BLOCKS * 9 * cX) b3 = (long)CBH_BLOCKS * 9 * cX;  // head form
+  return b3 > f32 ? b3 : f32;
 }
 template <bool XB, bool GB>
 static void cbw_launch(const WgArgsB& a, int mtw, int ntw, dim3 grid, hipStream_t s) {
@@ -542,6 +637,23 @@ extern "C" int dis_convb_wgrad(const void* X, int x_bf16, int ldX, int xoff, int
   if (k * k > CB_MAXTAPS || (stride != 1 && stride != 2)) return DIS_ERR_UNSUPPORTED;
   if ((long)n * hG * wG > 2147483647L - 64) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  if (x_bf16 && g_bf16 && !((xoff | goff) & 7) && xoff + ((cX + 7) & ~7) <= ldX && goff + ((cG + 7) & ~7) <= ldG &&
+      dis_wgrad_pairs_workspace(n, hX, wX, hG, wG, cX, cG, ldX, ldG, k, stride, 1) >= 0)
+    return dis_wgrad_pairs_run((const float*)X, ldX, xoff, hX, wX, cX, cX_w, (const float*)G, ldG, goff, hG, wG, cG,
+                               cG_w, grad_w, workspace, n, k, stride, pad, 1, s);
+  if (cbh_eligible(x_bf16, cX, cG_w, k, stride, ldX, xoff) && hX == hG && wX == wG) {
+    const long npix = (long)n * hG * wG;
+    const int c8 = cX / 8, ppb = 256 / c8;
+    long blocks = (npix + ppb - 1) / ppb;
+    if (blocks > CBH_BLOCKS) blocks = CBH_BLOCKS;
+    if (g_bf16) cbh_launch<true>(c8, (int)blocks, X, ldX, xoff, G, ldG, goff, workspace, n, hG, wG, pad, s);
+    else cbh_launch<false>(c8, (int)blocks, X, ldX, xoff, G, ldG, goff, workspace, n, hG, wG, pad, s);
+    const long tot = 9L * cX_w;
+    hipLaunchKernelGGL(convb_head_reduce_kernel, dim3((unsigned)((tot + 3) / 4)), dim3(256), 0, s, (const float*)workspace,
+                       grad_w, (int)blocks, cX, cX_w);
+    DIS_CHECK_LAUNCH();
+    return DIS_OK;
+  }
   WgArgsB a;
   a.X = X; a.G = G; a.part = workspace;
   a.n = n; a.hX = hX; a.wX = wX; a.ldX = ldX; a.xoff = xoff; a.cX = cX;
@@ -585,6 +697,35 @@ __global__ void act_bwd_bf16_kernel(const bf16_t* __restrict__ gy, int ldg, cons
     }
   }
 }
+// the same with an fp32 result (first layer of DispNetS: its weight gradient runs on the fp32 one-pass kernel, x being fp32)
+__global__ void act_bwd_bf16_f32_kernel(const bf16_t* __restrict__ gy, int ldg, const bf16_t* __restrict__ y, int ldy,
+                                        float* __restrict__ gp, int act, long npix, int c4) {
+  const long total = npix * c4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long px = i / c4;
+    const int q = (int)(i - px * c4) * 4;
+    const uint2 g = *(const uint2*)(gy + px * ldg + q);
+    float4 o = make_float4(cb_lo(g.x), cb_hi(g.x), cb_lo(g.y), cb_hi(g.y));
+    if (act != DIS_ACT_NONE) {
+      const uint2 v = *(const uint2*)(y + px * ldy + q);
+      o.x *= act_grad_from_out(cb_lo(v.x), act), o.y *= act_grad_from_out(cb_hi(v.x), act);
+      o.z *= act_grad_from_out(cb_lo(v.y), act), o.w *= act_grad_from_out(cb_hi(v.y), act);
+    }
+    *(float4*)(gp + i * 4) = o;
+  }
+}
+extern "C" int dis_act_bwd_bf16_f32(const void* gy, int ldg, const void* y, int ldy, float* gpre, int act, long npix, int c,
+                                    void* stream) {
+  if (!gy || !gpre || (act != DIS_ACT_NONE && !y)) return DIS_ERR_NULL;
+  if (npix <= 0 || c <= 0 || ldg < c || (act != DIS_ACT_NONE && ldy < c)) return DIS_ERR_BAD_SHAPE;
+  if ((c & 3) || (ldg & 3) || (ldy & 3) || ((uintptr_t)gy & 7) || ((uintptr_t)y & 7) || ((uintptr_t)gpre & 15))
+    return DIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(act_bwd_bf16_f32_kernel, dim3(dis_ew_grid(npix * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)gy, ldg, (const bf16_t*)(y ? y : gy), ldy, gpre, act, npix, c / 4);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 extern "C" int dis_act_bwd_bf16(const void* gy, int ldg, const void* y, int ldy, void* gpre, int act, long npix, int c,
                                 void* stream) {
   if (!gy || !gpre || (act != DIS_ACT_NONE && !y)) return DIS_ERR_NULL;

@@ -735,10 +735,10 @@ static void wg_plan(int n, int hG, int wG, int cX, int cG, int k, int* nxb, int*
 // conv2d.hip: layers with >= 32 channels on both sides and 3x3 / 5x5 taps run as 32 x 32 channel-slice pairs on the
 // one-pass bf16x3 kernel (x halo and gy tile staged once for all taps, accumulators in registers)
 long dis_wgrad_pairs_workspace(int n, int hX, int wX, int hG, int wG, int cX, int cG, int ldX, int ldG, int k,
-                               int stride);
+                               int stride, int bf);
 int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int hX, int wX, int cX, int cX_w, const float* G, int ldG,
                         int goff, int hG, int wG, int cG, int cG_w, float* grad_w, float* workspace, int n, int k,
-                        int stride, int pad, hipStream_t s);
+                        int stride, int pad, int bf, hipStream_t s);
 
 extern "C" long dis_convg_wgrad_workspace(int n, int hG, int wG, int cX, int cG, int k) {
   if (n <= 0 || hG <= 0 || wG <= 0 || cX <= 0 || cG <= 0 || k <= 0 || k * k > CG_MAXTAPS) return -1;
@@ -747,8 +747,8 @@ extern "C" long dis_convg_wgrad_workspace(int n, int hG, int wG, int cX, int cG,
   wg_tiles(cX, cG, &mtw, &ntw);
   const long f32 = (long)nsplit * k * k * (nxb * 32 * mtw) * (ngb * 32 * ntw);
   // (the slice-pair form, if dis_convg_wgrad takes it for this layer: the stride is not known here, so size for both)
-  const long b1 = dis_wgrad_pairs_workspace(n, 1, 1, hG, wG, cX, cG, 4, 4, k, 1);
-  const long b2 = dis_wgrad_pairs_workspace(n, 1, 1, hG, wG, cX, cG, 4, 4, k, 2);
+  const long b1 = dis_wgrad_pairs_workspace(n, 1, 1, hG, wG, cX, cG, 4, 4, k, 1, 0);
+  const long b2 = dis_wgrad_pairs_workspace(n, 1, 1, hG, wG, cX, cG, 4, 4, k, 2, 0);
   const long b3 = b1 > b2 ? b1 : b2;
   return b3 > f32 ? b3 : f32;
 }
@@ -765,9 +765,9 @@ extern "C" int dis_convg_wgrad(const float* X, int ldX, int xoff, int hX, int wX
   if (k * k > CG_MAXTAPS || (stride != 1 && stride != 2)) return DIS_ERR_UNSUPPORTED;
   if ((long)n * hG * wG > 2147483647L - 64) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (dis_wgrad_pairs_workspace(n, hX, wX, hG, wG, cX, cG, ldX, ldG, k, stride) >= 0)
+  if (dis_wgrad_pairs_workspace(n, hX, wX, hG, wG, cX, cG, ldX, ldG, k, stride, 0) >= 0)
     return dis_wgrad_pairs_run(X, ldX, xoff, hX, wX, cX, cX_w, G, ldG, goff, hG, wG, cG, cG_w, grad_w, workspace, n, k,
-                               stride, pad, s);
+                               stride, pad, 0, s);
   WgGenArgs a;
   a.X = X; a.G = G; a.part = workspace;
   a.n = n; a.hX = hX; a.wX = wX; a.ldX = ldX; a.xoff = xoff; a.cX = cX;

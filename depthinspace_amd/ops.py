@@ -1204,6 +1204,20 @@ class _ConvB(torch.autograd.Function):
         _, hout, wout, cout = gy.shape
         k = weight.shape[2]
         cin_w = weight.shape[0] if transposed else weight.shape[1]
+        if x.dtype == torch.float32 and not transposed and not (need_dgrad and ctx.needs_input_grad[0]) and x.is_contiguous():
+            # the network's first layer (fp32 input, no input gradient): fp32 pre-activation gradient and the one-pass fp32
+            # weight-gradient kernel of conv2d.hip (x and gy read once for all taps, bias gradient from the same pass)
+            wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin_mem, cout, k, stride)
+            if wsz >= 0:
+                gpre = torch.empty(gy.shape, dtype=torch.float32, device=gy.device)
+                lib.call('dis_act_bwd_bf16_f32', gy, _ld(gy), y, _ld(y) if y is not None else 0, gpre, act, n * hout * wout,
+                         cout)
+                gw, gw_ret = _sink(weight)
+                ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
+                gb = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+                _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_mem, cin_w, cout, k, stride, pad)
+                _sinks_written()
+                return None, gw_ret, gb, None, None, None, None, None, None, None
         if act != ACT_NONE or not gy.is_contiguous():
             gpre = torch.empty(gy.shape, dtype=BF16, device=gy.device)
             lib.call('dis_act_bwd_bf16', gy, _ld(gy), y, _ld(y) if y is not None else 0, gpre, act, n * hout * wout, cout)

@@ -413,6 +413,9 @@ int dis_convb_wgrad(const void* X, int x_bf16, int ldX, int xoff, int hX, int wX
 /* gpre = gy * act'(y) on channel ranges (ldg / ldy elements per pixel) of bf16 nhwc buffers; gpre dense (npix, c) bf16 */
 int dis_act_bwd_bf16(const void* gy, int ldg, const void* y, int ldy, void* gpre, int act, long npix, int c,
                      void* stream);
+/* the same with a dense fp32 result (the network's first layer: x is fp32, its weight gradient runs through dis_conv2d_wgrad) */
+int dis_act_bwd_bf16_f32(const void* gy, int ldg, const void* y, int ldy, float* gpre, int act, long npix, int c,
+                         void* stream);
 /* dis_copy_channels into a bf16 buffer from an fp32 (src_bf16 = 0) or bf16 source */
 int dis_copy_channels_bf16(const void* src, int src_bf16, int lds, void* dst, int ldd, long npix, int c, int czero,
                            void* stream);
