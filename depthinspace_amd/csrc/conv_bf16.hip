@@ -738,6 +738,37 @@ extern "C" int dis_act_bwd_bf16(const void* gy, int ldg, const void* y, int ldy,
   return DIS_OK;
 }
 
+// dis_act_bwd_bf16 that also leaves the bias gradient (column sums of the unrounded gpre) behind: the gradient tensor is read
+// once for both.  c / 4 divides 256: a thread keeps its 4 channels while it walks down the pixels.
+#define CSB_BLOCKS 1024
+__global__ __launch_bounds__(256) void act_bwd_bf16_bias_kernel(const bf16_t* __restrict__ gy, int ldg,
+                                                                 const bf16_t* __restrict__ y, int ldy,
+                                                                 bf16_t* __restrict__ gp, int act, long npix, int c4,
+                                                                 float* __restrict__ part) {
+  __shared__ float red[1024];
+  const int chunk = threadIdx.x % c4, rows = 256 / c4, row = threadIdx.x / c4, q = chunk * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long px = (long)blockIdx.x * rows + row; px < npix; px += (long)gridDim.x * rows) {
+    const uint2 g = *(const uint2*)(gy + px * ldg + q);
+    float4 o = make_float4(cb_lo(g.x), cb_hi(g.x), cb_lo(g.y), cb_hi(g.y));
+    if (act != DIS_ACT_NONE) {
+      const uint2 v = *(const uint2*)(y + px * ldy + q);
+      o.x *= act_grad_from_out(cb_lo(v.x), act), o.y *= act_grad_from_out(cb_hi(v.x), act);
+      o.z *= act_grad_from_out(cb_lo(v.y), act), o.w *= act_grad_from_out(cb_hi(v.y), act);
+    }
+    *(uint2*)(gp + (px * c4 + chunk) * 4) = make_uint2(cb_pack2(o.x, o.y), cb_pack2(o.z, o.w));
+    s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
+  }
+  *(float4*)(red + threadIdx.x * 4) = s;
+  __syncthreads();
+  const int c = c4 * 4;
+  for (int t = threadIdx.x; t < c; t += 256) {
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc += red[(r * c4 + (t >> 2)) * 4 + (t & 3)];
+    part[(long)blockIdx.x * c + t] = acc;
+  }
+}
+
 // dst[pixel * ldd + j] = src[pixel * lds + j] (j < c), 0 for c <= j < c + czero; src fp32 or bf16, dst bf16
 template <bool SB>
 __global__ void copy_channels_bf16_kernel(const void* __restrict__ src, int lds, bf16_t* __restrict__ dst, int ldd,
@@ -768,7 +799,6 @@ extern "C" int dis_copy_channels_bf16(const void* src, int src_bf16, int lds, vo
 }
 
 // column sums of a bf16 nhwc tensor (bias gradients): out[ch] = sum_pixels G[pixel][goff + ch], fp32 block partials, fp64 total
-#define CSB_BLOCKS 1024
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ G, int ldG, int goff, long npix, int c,
                                                            float* __restrict__ part) {
   __shared__ float red[256];
@@ -805,6 +835,27 @@ __global__ __launch_bounds__(256) void colsum_bf16_final_kernel(const float* __r
   for (int k = lane; k < nblocks; k += 64) s += (double)part[(long)k * c + ch];
   s = wave_sum_d(s);
   if (lane == 0) out[ch] = (float)s;
+}
+// gpre = gy * act'(y) as dis_act_bwd_bf16, and bias_grad[ch] = sum_pixels gpre[pixel][ch] (fp32, summed before the bf16 rounding of
+// gpre); workspace: dis_colsum_bf16_workspace(c) floats.  c / 4 must divide 256 (DIS_ERR_UNSUPPORTED otherwise: the caller uses
+// dis_act_bwd_bf16 + dis_colsum_bf16)
+extern "C" int dis_act_bwd_bf16_bias(const void* gy, int ldg, const void* y, int ldy, void* gpre, int act, long npix, int c,
+                                     float* bias_grad, float* workspace, void* stream) {
+  if (!gy || !gpre || !bias_grad || !workspace || (act != DIS_ACT_NONE && !y)) return DIS_ERR_NULL;
+  if (npix <= 0 || c <= 0 || ldg < c || (act != DIS_ACT_NONE && ldy < c)) return DIS_ERR_BAD_SHAPE;
+  if ((c & 3) || (ldg & 3) || (ldy & 3) || ((uintptr_t)gy & 7) || ((uintptr_t)y & 7) || ((uintptr_t)gpre & 7) ||
+      c > 1024 || 256 % (c / 4))
+    return DIS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int rows = 256 / (c / 4);
+  long nb = (npix + rows - 1) / rows;
+  if (nb > CSB_BLOCKS) nb = CSB_BLOCKS;
+  hipLaunchKernelGGL(act_bwd_bf16_bias_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)gy, ldg,
+                     (const bf16_t*)(y ? y : gy), ldy, (bf16_t*)gpre, act, npix, c / 4, workspace);
+  hipLaunchKernelGGL(colsum_bf16_final_kernel, dim3(dis_cdiv(c, 4)), dim3(256), 0, s, (const float*)workspace, (int)nb, c,
+                     bias_grad);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
 }
 extern "C" long dis_colsum_bf16_workspace(int c) { return c > 0 ? (long)CSB_BLOCKS * c : -1; }
 extern "C" int dis_colsum_bf16(const void* G, int ldG, int goff, long npix, int c, float* out, float* workspace,

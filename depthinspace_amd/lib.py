@@ -93,6 +93,7 @@ SIGS = {
     'dis_convb_wgrad': 'piiiiiiipiiiiiiipp' + 'iiiip',
     'dis_act_bwd_bf16': 'pipipilip',
     'dis_act_bwd_bf16_f32': 'pipipilip',
+    'dis_act_bwd_bf16_bias': 'pipipilippp',
     'dis_copy_channels_bf16': 'piipiliip',
     'dis_colsum_bf16_workspace': 'i',
     'dis_colsum_bf16': 'piilippp',

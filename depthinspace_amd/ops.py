@@ -1218,9 +1218,17 @@ class _ConvB(torch.autograd.Function):
                 _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_mem, cin_w, cout, k, stride, pad)
                 _sinks_written()
                 return None, gw_ret, gb, None, None, None, None, None, None, None
+        gb = None
         if act != ACT_NONE or not gy.is_contiguous():
             gpre = torch.empty(gy.shape, dtype=BF16, device=gy.device)
-            lib.call('dis_act_bwd_bf16', gy, _ld(gy), y, _ld(y) if y is not None else 0, gpre, act, n * hout * wout, cout)
+            if has_bias and cout <= 1024 and 256 % (cout // 4) == 0:   # bias gradient from the same pass over gy
+                gb = torch.empty(cout, dtype=torch.float32, device=gy.device)
+                ws = torch.empty(lib.fn('dis_colsum_bf16_workspace')(cout), dtype=torch.float32, device=gy.device)
+                lib.call('dis_act_bwd_bf16_bias', gy, _ld(gy), y, _ld(y) if y is not None else 0, gpre, act,
+                         n * hout * wout, cout, gb, ws)
+            else:
+                lib.call('dis_act_bwd_bf16', gy, _ld(gy), y, _ld(y) if y is not None else 0, gpre, act, n * hout * wout,
+                         cout)
         else:
             gpre = gy
         gx = None
@@ -1233,7 +1241,8 @@ class _ConvB(torch.autograd.Function):
             _convb_wgrad(gpre, hout, wout, cout, cout, x, hin, win, cin_mem, cin_w, gw, n, k, stride, pad)
         else:
             _convb_wgrad(x, hin, win, cin_mem, cin_w, gpre, hout, wout, cout, cout, gw, n, k, stride, pad)
-        gb = _colsum_b(gpre, cout) if has_bias else None
+        if has_bias and gb is None:
+            gb = _colsum_b(gpre, cout)
         _sinks_written()
         return gx, gw_ret, gb, None, None, None, None, None, None, None
 

@@ -413,6 +413,10 @@ int dis_convb_wgrad(const void* X, int x_bf16, int ldX, int xoff, int hX, int wX
 /* gpre = gy * act'(y) on channel ranges (ldg / ldy elements per pixel) of bf16 nhwc buffers; gpre dense (npix, c) bf16 */
 int dis_act_bwd_bf16(const void* gy, int ldg, const void* y, int ldy, void* gpre, int act, long npix, int c,
                      void* stream);
+/* dis_act_bwd_bf16 + the bias gradient bias_grad[ch] = sum_pixels gpre[pixel][ch] from the same pass (summed in fp32 before gpre's
+   rounding); workspace: dis_colsum_bf16_workspace(c) floats; c / 4 must divide 256, else DIS_ERR_UNSUPPORTED */
+int dis_act_bwd_bf16_bias(const void* gy, int ldg, const void* y, int ldy, void* gpre, int act, long npix, int c,
+                          float* bias_grad, float* workspace, void* stream);
 /* the same with a dense fp32 result (the network's first layer: x is fp32, its weight gradient runs through dis_conv2d_wgrad) */
 int dis_act_bwd_bf16_f32(const void* gy, int ldg, const void* y, int ldy, float* gpre, int act, long npix, int c,
                          void* stream);
