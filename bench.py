@@ -269,8 +269,9 @@ def main():
             fl = sum(gflops(ia) for ia, _ in sel)
             kname = 'convg_fwd_kernel<BN> (fp32 MFMA 16x16x4, all conv / dgrad / transposed-conv launches)'
             if bf_mode:
-                kname = ('convb_fwd_kernel<BN> (bf16 activations x bf16 weights on v_mfma_f32_16x16x32_bf16, fp32 accumulate: all '
-                         'conv / dgrad / transposed-conv launches of DispNetS)')
+                kname = ('convb_halo_kernel / convb_fwd_kernel (bf16 activations x bf16 weights on v_mfma_f32_16x16x32_bf16, fp32 '
+                         'accumulate: all conv / dgrad / transposed-conv launches of DispNetS; LDS halo tiles for maps of >= 1024 '
+                         'positions, per-tap streaming below; the times include the per-call weight packing)')
                 peak, peak_note = PEAK_BF16_MFMA_TFLOPS, 'bf16 MFMA dense peak'
             elif ops.BF16X3:
                 kname = ('convg3_fwd_kernel<BN> (fp32 conv as 6 bf16 products per MAC on v_mfma_f32_16x16x32_bf16; all '
@@ -361,7 +362,8 @@ def main():
                        if args.dtype == 'f32' else
                        ('bf16 ACTIVATION STORAGE (BASELINE config 2): nhwc feature maps in bf16, forward / input-gradient / '
                         'transposed convs = one bf16 x bf16 product per MAC on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, '
-                        'weight gradients on v_mfma_f32_16x16x4_f32 from the bf16 values; parameters, their gradients, disparities '
+                        'weight gradients likewise (one-pass slice-pair kernel with transposing LDS reads; the first layer and ragged '
+                        'shapes on fp32 MFMA from the bf16 values); parameters, their gradients, disparities '
                         'and losses fp32.  Not the parity path: disparity L1 vs the fp32 oracle 0.01 px (tests/test_sf_bf16_gpu.py)')},
             'roofline': roof, 'roofline_hbm_kernels': hbm, 'cpu_baseline': cpu, 'loss_terms': losses,
             'eager_launch_frames_per_s': eager_fps, 'adam_steps_taken': adam_steps, 'step_mode': stepper.mode,

@@ -46,6 +46,10 @@ struct GenArgsB {
   int act, ntaps, nblk;
   short tdy[CB_MAXTAPS], tdx[CB_MAXTAPS];
   unsigned x_bytes;
+  // halo form (convb_halo_kernel): first tap offsets, halo extent, LDS pixel stride, taps per k-step, k-steps, k-steps per
+  // weight group, tile grid
+  int dy0, dx0, HR, HC, PS, TP, nks, GT, tiles_x, tiles_y;
+  int res, wsz16;  // weights of a cout block resident in LDS (all chunks); 16-bit words of the weight region in front of the halo
 };
 
 template <int BN, bool XB, bool YB>
@@ -226,6 +230,329 @@ __global__ void convb_pack_kernel(PackArgsB a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Halo form of the same convolution family, for feature maps large enough that the per-tap re-read of the input (k*k passes
+// through L2 in the streaming kernel: the bound of every high-resolution layer of DispNetS) dominates: the input halo of an
+// 8 x 16 tile of (virtual) output positions is staged in LDS ONCE per 32-channel chunk and every tap reads its MFMA operand from
+// there at its own offset; only the weights stream (groups of GT k-steps, double-buffered through registers: one barrier per
+// group instead of one per tap).
+//   k-step = TP taps x 32/TP channels (TP = 1, 2, 4 for cin > 16, <= 16, <= 8: narrow inputs - the network's first layer, the
+//   1-channel head gradients, the 16-channel full-resolution layers - fill the MFMA's K = 32 with several taps)
+//   LDS pixel = 32/TP (TP = 4: 16, the upper 8 zero) channels + 8 pad: 80 / 48 bytes, conflict-free for 16 consecutive pixels
+//   wave w = tile rows 2w, 2w+1 x 16 columns; lane (li, lg): column li, k-slice lg
+// ------------------------------------------------------------------------------------------------
+#define CBH_TR 8
+#define CBH_TC 16
+#define CBH_GVEC 1024  // 16-byte vectors of one weight group (16 KB): 4 per thread
+// Persistent workgroups: a unit = (tile, cout block); the units of an XCD's share are walked with a grid stride, and the halo
+// of the NEXT stage (next 32-channel chunk, or the next unit's first) is fetched into registers (NH 16-byte items per thread)
+// while the current stage's MFMAs run; pixels outside the image / channels past cin get an out-of-range buffer offset (zeros).
+template <int BN, bool XB, bool YB, int NH>
+__global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
+  constexpr int NT = BN / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned short hsm[];
+  int* toff = (int*)hsm;                     // 64 ints
+  const int bsz = a.GT * 4 * BN * 8;         // 16-bit words of one weight buffer
+  unsigned short* Bb = hsm + 128;
+  unsigned short* halo = Bb + a.wsz16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int PS = a.PS, HC = a.HC, ipp = (PS - 8) >> 3;
+  // unit -> (cout block, tile): cout block fastest (the blocks of a tile share its halo through L2) when the weights stream,
+  // slowest when they are resident (a workgroup then keeps its block's weights for its whole walk)
+  const int ntile = a.n * a.tiles_y * a.tiles_x;
+  auto unit_nb = [&](int uu) { return a.res ? uu / ntile : uu % a.nblk; };
+  auto unit_tile = [&](int uu) { return a.res ? uu % ntile : uu / a.nblk; };
+  if (tid < 64) {
+    int o = 0;
+    if (tid < a.ntaps) o = ((a.tdy[tid] - a.dy0) * HC + (a.tdx[tid] - a.dx0)) * PS;
+    toff[tid] = o;
+  }
+  // units of this workgroup: XCD x (blockIdx.x % 8) owns a contiguous eighth, so that neighbouring tiles (shared halo rows and
+  // columns) and the cout blocks of one tile meet in the same L2
+  const int units = a.n * a.tiles_y * a.tiles_x * a.nblk;
+  const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
+  const int xcd = blockIdx.x % nxcd, rank = blockIdx.x / nxcd, per = gridDim.x / nxcd;
+  const int u_hi = (int)((long)units * (xcd + 1) / nxcd);
+  int u = (int)((long)units * xcd / nxcd) + rank;
+  if (u >= u_hi) return;
+
+  const int gpt = 4 / a.TP;  // lane groups per tap
+  const int lgq = lg / gpt, cg = lg - lgq * gpt;
+  const int a_lane = (wave * 2 * a.S * HC + li * a.S) * PS + cg * 8;
+  const int rowstep = a.S * HC * PS;
+  const u32x4* wq = (const u32x4*)a.w;  // packed [chunk][nb][kstep][lg][BN][8]
+  const int ngrp = (a.nks + a.GT - 1) / a.GT;
+  u32x4 rb[4];
+  auto pref_b = [&](int nb, int c, int g) __attribute__((always_inline)) {
+    const long base = ((long)(c * a.nblk + nb) * a.nks + g * a.GT) * (4 * BN);
+    const int cnt = min(a.GT, a.nks - g * a.GT) * (4 * BN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      rb[i] = wq[base + (idx < cnt ? idx : 0)];
+    }
+  };
+  // halo items of this thread: (row, column) inside the halo, channel group, LDS offset (fixed for the whole launch)
+  const int nitems = a.HR * HC * ipp;
+  int it_rc[NH], it_cg[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int i = tid + j * 256;
+    const int p = i / ipp, cgi = i - p * ipp;
+    const int r = p / HC, cc = p - r * HC;
+    it_rc[j] = i < nitems ? (r | (cc << 16)) : 0x4000;  // (past the end: a row outside every image)
+    it_cg[j] = cgi * 8 | ((p * PS + cgi * 8) << 8);
+  }
+  u32x4 pre[2][NH], pre2[2][XB ? 1 : NH];  // two register sets: the resident-weight walk keeps two stages in flight
+  auto halo_issue = [&](int uu, int c, auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    int t = unit_tile(uu);
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y, nn = t / a.tiles_y;
+    const int iy0 = ty * CBH_TR * a.S + a.dy0, ix0 = tx * CBH_TC * a.S + a.dx0;
+    const long sbase = (long)nn * a.hin * a.win;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int iy = iy0 + (it_rc[j] & 0xffff), ix = ix0 + (it_rc[j] >> 16);
+      const int ch = c * CB_CK + (it_cg[j] & 0xff);
+      const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win && ch < a.cin;
+      const long e = (sbase + (long)iy * a.win + ix) * a.ldx + a.xoff + ch;
+      if (XB) {
+        pre[set][j] = __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.x, a.x_bytes), ok ? (unsigned)(e * 2) : BX_OOB, 0, 0);
+      } else {
+        pre[set][j] = __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.x, a.x_bytes), ok ? (unsigned)(e * 4) : BX_OOB, 0, 0);
+        pre2[set][XB ? 0 : j] = __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.x, a.x_bytes),
+                                                                 (ok && ch + 4 < a.cin) ? (unsigned)(e * 4 + 16) : BX_OOB, 0, 0);
+      }
+    }
+  };
+  auto halo_write = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      if (tid + j * 256 < nitems) {
+        u32x4 o = pre[set][j];
+        if (!XB) {
+          const u32x4 q = pre2[set][XB ? 0 : j];
+          o = (u32x4){cb_pack2(__uint_as_float(o[0]), __uint_as_float(o[1])), cb_pack2(__uint_as_float(o[2]), __uint_as_float(o[3])),
+                      cb_pack2(__uint_as_float(q[0]), __uint_as_float(q[1])), cb_pack2(__uint_as_float(q[2]), __uint_as_float(q[3]))};
+        }
+        *(u32x4*)(halo + (it_cg[j] >> 8)) = o;
+      }
+    }
+  };
+
+  f32x4 acc[2][NT], bias_v[NT];
+  int bias_nb = -1;
+  // k-steps [0, kn) of a weight block B ([kstep][lg][BN][8]) whose tap offsets start at tq: software-pipelined by hand (a
+  // runtime trip count: the compiler does not) - the operands of k-step kk+1 are requested before the MFMAs of kk issue, its
+  // tap offset one step earlier still
+  auto ksteps = [&](const unsigned short* B, const int* tq, int kn) __attribute__((always_inline)) {
+    const unsigned short* bl = B + (lg * BN + li) * 8;
+    auto frag = [&](int kk, int to, s16x8 (&fa)[2], s16x8 (&fb)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) fa[mt] = *(const s16x8*)(halo + a_lane + mt * rowstep + to);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[nt] = *(const s16x8*)(bl + (kk * 4 * BN + nt * 16) * 8);
+    };
+    auto mac = [&](const s16x8 (&fa)[2], const s16x8 (&fb)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[nt]),
+                                                               __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+    };
+    s16x8 fa0[2], fb0[NT], fa1[2], fb1[NT];
+    int to0 = tq[0], to1 = kn > 1 ? tq[a.TP] : 0;
+    frag(0, to0, fa0, fb0);
+    for (int kk = 0; kk < kn; kk += 2) {
+      if (kk + 1 < kn) frag(kk + 1, to1, fa1, fb1);
+      to0 = kk + 2 < kn ? tq[(kk + 2) * a.TP] : 0;
+      mac(fa0, fb0);
+      if (kk + 1 < kn) {
+        if (kk + 2 < kn) frag(kk + 2, to0, fa0, fb0);
+        to1 = kk + 3 < kn ? tq[(kk + 3) * a.TP] : 0;
+        mac(fa1, fb1);
+      }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  auto load_bias = [&](int nb) __attribute__((always_inline)) {
+    // bias of a cout block (4 consecutive couts per lane and block): requested at the unit's start, added in its epilogue
+    if (nb == bias_nb) return;
+    bias_nb = nb;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = nb * BN + nt * 16 + lg * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < a.cout) bv[r] = a.bias[co + r];
+      }
+      bias_v[nt] = bv;
+    }
+  };
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = acc[1][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  // epilogue: lane (li, lg) holds couts nb*BN + nt*16 + lg*4 + {0..3} of position (ty*8 + wave*2 + mt, tx*16 + li)
+  auto epilogue = [&](int uu, int nb) __attribute__((always_inline)) {
+    int t = unit_tile(uu);
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y, nn = t / a.tiles_y;
+    auto emit = [&](auto actc) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int vy = ty * CBH_TR + wave * 2 + mt, vx = tx * CBH_TC + li;
+        if (vy >= a.hv || vx >= a.wv) continue;
+        const long pe = (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = nb * BN + nt * 16 + lg * 4;
+          if (co >= a.cout) continue;
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[mt][nt][r] + bias_v[nt][r], ACT);
+          if (co + 4 <= a.cout) {
+            if (YB) *(uint2*)((bf16_t*)a.y + pe + co) = make_uint2(cb_pack2(o[0], o[1]), cb_pack2(o[2], o[3]));
+            else *(float4*)((float*)a.y + pe + co) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+            for (int r = 0; r < 4 && co + r < a.cout; ++r) {
+              if (YB) ((bf16_t*)a.y)[pe + co + r] = (bf16_t)(cb_pack2(o[r], 0.f) & 0xffffu);
+              else ((float*)a.y)[pe + co + r] = o[r];
+            }
+          }
+        }
+      }
+    };
+    if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{});
+    else if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{});
+    else emit(std::integral_constant<int, DIS_ACT_NONE>{});
+  };
+
+  if (a.res) {
+    // Resident weights.  The walk is a flat sequence of stages (unit, chunk); the halos of the next TWO stages are in flight
+    // (register sets alternate), because a stage of a narrow high-resolution layer is far shorter than a memory round trip:
+    // one stage of look-ahead leaves the loads exposed, two keep ~2 tiles per workgroup in flight.
+    int u1 = u, c1 = 0, u2 = u, c2 = 0;  // cursors of the stages held by the register sets after the current one
+    auto advance = [&](int& uu, int& cc) __attribute__((always_inline)) {
+      if (cc + 1 < a.nchunk) ++cc;
+      else uu += per, cc = 0;
+    };
+    int c0 = 0;
+    halo_issue(u, 0, S0{});
+    advance(u1, c1);
+    if (u1 < u_hi) halo_issue(u1, c1, S1{});
+    u2 = u1, c2 = c1;
+    advance(u2, c2);
+    int wres_nb = -1;
+    auto stage = [&](auto setc) __attribute__((always_inline)) {
+      const int nb = unit_nb(u);
+      if (c0 == 0) {
+        load_bias(nb);
+        zero_acc();
+      }
+      if (nb != wres_nb) {  // (block-uniform) this cout block's weights, all chunks: once per workgroup and block
+        __syncthreads();
+        const int nv = a.nks * 4 * BN;
+        for (int c = 0; c < a.nchunk; ++c)
+          for (int i = tid; i < nv; i += 256) ((u32x4*)Bb)[c * nv + i] = wq[(long)(c * a.nblk + nb) * nv + i];
+        wres_nb = nb;
+      }
+      __syncthreads();  // every wave is done with the previous stage's halo
+      halo_write(setc);
+      __syncthreads();
+      if (u2 < u_hi) halo_issue(u2, c2, setc);  // the set just consumed takes the stage after next
+      ksteps(Bb + (long)c0 * a.nks * 4 * BN * 8, toff + lgq, a.nks);
+      if (c0 + 1 == a.nchunk) epilogue(u, nb);
+      u = u1, c0 = c1;
+      u1 = u2, c1 = c2;
+      advance(u2, c2);
+    };
+    while (true) {
+      stage(S0{});
+      if (u >= u_hi) break;
+      stage(S1{});
+      if (u >= u_hi) break;
+    }
+    return;
+  }
+
+  // streaming weights: groups of GT k-steps double-buffered through registers, one stage of halo look-ahead
+  halo_issue(u, 0, S0{});
+  pref_b(unit_nb(u), 0, 0);
+  int flat = 0;
+  while (true) {
+    const int nb = unit_nb(u);
+    const int un = u + per;  // this workgroup's next unit
+    load_bias(nb);
+    zero_acc();
+    for (int c = 0; c < a.nchunk; ++c) {
+      __syncthreads();  // every wave is done with the previous stage's halo
+      halo_write(S0{});
+      for (int g = 0; g < ngrp; ++g) {
+        unsigned short* B = Bb + (flat & 1) * bsz;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = tid + i * 256;
+          if (idx < a.GT * 4 * BN) ((u32x4*)B)[idx] = rb[i];
+        }
+        __syncthreads();
+        if (g == 0) {  // next stage's halo
+          if (c + 1 < a.nchunk) halo_issue(u, c + 1, S0{});
+          else if (un < u_hi) halo_issue(un, 0, S0{});
+        }
+        if (g + 1 < ngrp) pref_b(nb, c, g + 1);
+        else if (c + 1 < a.nchunk) pref_b(nb, c + 1, 0);
+        else if (un < u_hi) pref_b(unit_nb(un), 0, 0);
+        ksteps(B, toff + g * a.GT * a.TP + lgq, min(a.GT, a.nks - g * a.GT));
+        ++flat;
+      }
+    }
+    epilogue(u, nb);
+    if (un >= u_hi) break;
+    u = un;
+  }
+}
+
+// packed[chunk][nb][kstep][lg][col][j] = bf16(W(tap, ci, co = nb*BN + col)), (tap, ci) = (kstep*TP + lg / (4/TP),
+// chunk*32 + (lg % (4/TP))*8 + j); taps past the last one and channels past ci_real hold zeros
+struct PackArgsH {
+  const float* w;
+  bf16_t* packed;
+  int ntaps, nchunk, nblk, bn, ci_real, co_real, tp, nks;
+  long s_ci, s_co;
+  short tsrc[CB_MAXTAPS];
+};
+__global__ void convb_pack_halo_kernel(PackArgsH a) {
+  const long total = (long)a.nchunk * a.nblk * a.nks * 4 * a.bn * 8;
+  const int gpt = 4 / a.tp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7);
+    long r = i >> 3;
+    const int col = (int)(r % a.bn);
+    r /= a.bn;
+    const int lg = (int)(r & 3);
+    r >>= 2;
+    const int ks = (int)(r % a.nks);
+    r /= a.nks;
+    const int nb = (int)(r % a.nblk);
+    const int chunk = (int)(r / a.nblk);
+    const int tap = ks * a.tp + lg / gpt;
+    const int ci = chunk * CB_CK + (lg % gpt) * 8 + j, co = nb * a.bn + col;
+    float v = 0.f;
+    if (tap < a.ntaps && ci < a.ci_real && co < a.co_real) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
+    a.packed[i] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
+  }
+}
+
 static int cb_bn(int cout) { return cout > 32 ? 64 : (cout > 16 ? 32 : 16); }
 
 template <bool XB, bool YB>
@@ -233,6 +560,99 @@ static void cb_launch(const GenArgsB& a, int bn, long grid, hipStream_t s) {
   if (bn == 64) hipLaunchKernelGGL((convb_fwd_kernel<64, XB, YB>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else if (bn == 32) hipLaunchKernelGGL((convb_fwd_kernel<32, XB, YB>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((convb_fwd_kernel<16, XB, YB>), dim3((unsigned)grid), dim3(256), 0, s, a);
+}
+
+// halo form: worth it when the image is large (tile quantisation of small maps wastes the tile; their layers are weight-bound
+// anyway) and the halo + weight buffers fit LDS.  Fills the halo fields of a.
+static int cb_num_cus() {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  return ncu;
+}
+static long cb_halo_lds(const GenArgsB& a, int bn);
+static bool cb_halo_plan(GenArgsB& a, int bn) {
+  static const bool off = getenv("DIS_CONVB_HALO") && getenv("DIS_CONVB_HALO")[0] == '0';
+  if (off || (long)a.hv * a.wv < 1024 || a.ntaps > CB_MAXTAPS) return false;
+  int dy0 = a.tdy[0], dy1 = a.tdy[0], dx0 = a.tdx[0], dx1 = a.tdx[0];
+  for (int t = 1; t < a.ntaps; ++t) {
+    dy0 = a.tdy[t] < dy0 ? a.tdy[t] : dy0; dy1 = a.tdy[t] > dy1 ? a.tdy[t] : dy1;
+    dx0 = a.tdx[t] < dx0 ? a.tdx[t] : dx0; dx1 = a.tdx[t] > dx1 ? a.tdx[t] : dx1;
+  }
+  a.dy0 = dy0; a.dx0 = dx0;
+  a.HR = (CBH_TR - 1) * a.S + (dy1 - dy0) + 1;
+  a.HC = (CBH_TC - 1) * a.S + (dx1 - dx0) + 1;
+  a.TP = a.cin <= 8 ? 4 : (a.cin <= 16 ? 2 : 1);
+  a.PS = a.TP == 1 ? 40 : 24;
+  a.nks = (a.ntaps + a.TP - 1) / a.TP;
+  if (a.nks * a.TP > 64) return false;
+  a.GT = CBH_GVEC / (4 * bn);
+  if (a.GT > a.nks) a.GT = a.nks;
+  a.tiles_x = (a.wv + CBH_TC - 1) / CBH_TC;
+  a.tiles_y = (a.hv + CBH_TR - 1) / CBH_TR;
+  if ((long)a.HR * a.HC * ((a.PS - 8) / 8) > 12 * 256) return false;  // halo items per thread (register prefetch)
+  // a cout block's weights (all chunks) stay in LDS when they fit next to the halo: no weight traffic, no group barriers
+  const long wall = (long)a.nchunk * a.nks * 4 * bn * 16, hal = (long)a.HR * a.HC * a.PS * 2;
+  a.res = (256 + wall + hal <= 75 * 1024) ? 1 : 0;  // (two resident workgroups per CU at least: one alone cannot hide its LDS latency)
+  a.wsz16 = (int)((a.res ? wall : 2L * a.GT * 4 * bn * 16) / 2);
+  return cb_halo_lds(a, bn) <= 150 * 1024;
+}
+static long cb_halo_lds(const GenArgsB& a, int bn) { return 256 + 2L * a.wsz16 + (long)a.HR * a.HC * a.PS * 2; }
+template <int BN, bool XB, bool YB, int NH>
+static int cbh_launch2(const GenArgsB& a, long grid, long lds, hipStream_t s) {
+  static bool attr = false;
+  auto kern = convb_halo_kernel<BN, XB, YB, NH>;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, s, a);
+  return DIS_OK;
+}
+template <int BN, bool XB, bool YB>
+static int cbh_launch1(const GenArgsB& a, int nh, long grid, long lds, hipStream_t s) {
+  if (nh <= 4) return cbh_launch2<BN, XB, YB, 4>(a, grid, lds, s);
+  if (nh <= 8) return cbh_launch2<BN, XB, YB, 8>(a, grid, lds, s);
+  return cbh_launch2<BN, XB, YB, 12>(a, grid, lds, s);
+}
+template <bool XB, bool YB>
+static int cbh_launch(const GenArgsB& a, int bn, int nh, long grid, long lds, hipStream_t s) {
+  if (bn == 64) return cbh_launch1<64, XB, YB>(a, nh, grid, lds, s);
+  if (bn == 32) return cbh_launch1<32, XB, YB>(a, nh, grid, lds, s);
+  return cbh_launch1<16, XB, YB>(a, nh, grid, lds, s);
+}
+static int cb_run_halo(GenArgsB a, int x_bf16, int y_bf16, int bn, const float* w_raw, bf16_t* wpack, int ci_real,
+                       int co_real, long s_ci, long s_co, const short* tsrc, hipStream_t s) {
+  PackArgsH p;
+  p.w = w_raw; p.packed = wpack; p.ntaps = a.ntaps; p.nchunk = a.nchunk; p.nblk = a.nblk; p.bn = bn;
+  p.ci_real = ci_real; p.co_real = co_real; p.tp = a.TP; p.nks = a.nks; p.s_ci = s_ci; p.s_co = s_co;
+  for (int t = 0; t < a.ntaps; ++t) p.tsrc[t] = tsrc[t];
+  const long ptotal = (long)a.nchunk * a.nblk * a.nks * 4 * bn * 8;
+  hipLaunchKernelGGL(convb_pack_halo_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
+  a.w = wpack;
+  const long units = (long)a.n * a.tiles_y * a.tiles_x * a.nblk;
+  if (units > 2147483647L) return DIS_ERR_BAD_SHAPE;
+  const long lds = cb_halo_lds(a, bn);
+  // persistent grid: as many workgroups as stay resident (LDS-bound, at most 6 per CU), a multiple of the 8 XCDs
+  long wpc = (150L * 1024) / lds;
+  wpc = wpc > 6 ? 6 : (wpc < 1 ? 1 : wpc);
+  long grid = wpc * cb_num_cus();
+  if (grid > units) grid = units;
+  if (grid >= 8) grid -= grid % 8;
+  const int nh = (int)(((long)a.HR * a.HC * ((a.PS - 8) / 8) + 255) / 256);
+  int rc;
+  if (x_bf16 && y_bf16) rc = cbh_launch<true, true>(a, bn, nh, grid, lds, s);
+  else if (x_bf16) rc = cbh_launch<true, false>(a, bn, nh, grid, lds, s);
+  else if (y_bf16) rc = cbh_launch<false, true>(a, bn, nh, grid, lds, s);
+  else rc = cbh_launch<false, false>(a, bn, nh, grid, lds, s);
+  if (rc != DIS_OK) return rc;
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
 }
 
 static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t* wpack, int ci_real, int co_real, long s_ci,
@@ -246,6 +666,7 @@ static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t
   if (xb >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;  // 31-bit byte offsets of the buffer descriptor
   a.x_bytes = (unsigned)xb;
   a.nchunk = (a.cin + CB_CK - 1) / CB_CK;
+  if (cb_halo_plan(a, bn)) return cb_run_halo(a, x_bf16, y_bf16, bn, w_raw, wpack, ci_real, co_real, s_ci, s_co, tsrc, s);
   PackArgsB p;
   p.w = w_raw; p.packed = wpack; p.ntaps = a.ntaps; p.nchunk = a.nchunk; p.nblk = a.nblk; p.bn = bn;
   p.ci_real = ci_real; p.co_real = co_real; p.s_ci = s_ci; p.s_co = s_co;

@@ -41,6 +41,15 @@ CASES = [
     (17, 24, 16, 3, 1, False, 16, 12, False),    # iconv1
     (64, 64, 32, 3, 2, True, 8, 7, False),       # upconv + crop (15 x 13 of 16 x 14)
     (512, 512, 512, 3, 2, True, 2, 2, False),
+    # maps of >= 1024 output positions run the halo form (convb_halo_kernel): every tap-packing / chunking / stride case
+    (2, 4, 32, 7, 2, False, 72, 80, True),       # 4 taps per k-step (cin <= 8), fp32 input, stride-2 halo
+    (16, 16, 16, 3, 1, False, 40, 36, False),    # 2 taps per k-step (cin <= 16)
+    (17, 24, 16, 3, 1, False, 40, 36, False),    # one chunk, ragged channels
+    (32, 32, 32, 7, 1, False, 36, 40, False),    # 49 k-steps in weight groups
+    (32, 32, 64, 5, 2, False, 72, 70, False),
+    (64, 64, 64, 5, 1, False, 33, 37, False),    # two chunks
+    (129, 136, 64, 3, 1, False, 34, 38, False),  # five chunks, the last one 8 channels wide
+    (64, 64, 32, 3, 2, True, 36, 34, False),     # transposed conv and its input gradient: four tap-parity phases
 ]
 
 
