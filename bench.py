@@ -56,7 +56,7 @@ def conv_flops(n, ho, wo, cin, cout, k):
     return 2.0 * n * ho * wo * cin * cout * k * k
 
 
-def cpu_baseline(arch='multi_frame', timed_steps=2):
+def cpu_baseline(arch='multi_frame', timed_steps=3):
     """Oracle training step on the host cores: 1 warm-up + `timed_steps` timed steps (Adam state carried along), bs=1
     (one 4-frame track), full resolution.  The bounded sample of BASELINE.md section 3; reported, never the target."""
     from depthinspace_amd import synth

@@ -2,7 +2,7 @@
 """Turn one profiling round (gpurun_out/<tag>/, written by scripts/prof_round.sh on the GPU box) into the tracked
 summaries under profiles/:
 
-  <tag>_bench.json / <tag>_bench_sf.json   the bench lines (DIS-MF headline, DIS-SF)
+  <tag>_bench.json / <tag>_bench_sf.json / <tag>_bench_sf_bf16.json   the bench lines (DIS-MF headline, DIS-SF fp32, DIS-SF bf16 storage)
   <tag>_bench_under_rocprof.json           the bench line printed under the profiler
   <tag>_kernel_stats.csv                   rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3`
   <tag>_pmc_sq.csv                         per-kernel averages of the SQ counters (one eager step)
@@ -27,6 +27,7 @@ def main(tag):
     src = os.path.join(ROOT, 'gpurun_out', tag)
     dst = os.path.join(ROOT, 'profiles')
     for a, b in (('bench.json', f'{tag}_bench.json'), ('bench_sf.json', f'{tag}_bench_sf.json'),
+                 ('bench_sf_bf16.json', f'{tag}_bench_sf_bf16.json'),
                  ('bench_prof.json', f'{tag}_bench_under_rocprof.json'),
                  ('trace/run_kernel_stats.csv', f'{tag}_kernel_stats.csv')):
         if os.path.exists(os.path.join(src, a)):
@@ -39,8 +40,10 @@ def main(tag):
                                os.path.join(src, 'write', 'write_counter_collection.csv')], stdout=f)
     stats = list(csv.DictReader(open(os.path.join(dst, f'{tag}_kernel_stats.csv'))))
     prof = json.loads(open(os.path.join(dst, f'{tag}_bench_under_rocprof.json')).read().strip().splitlines()[-1])
-    # the profiled command runs steps + warmup + 1 eager roofline step (+1 capture) of kernels
-    nsteps = prof['steps'] + prof['warmup'] + 1
+    # steps in the trace = launches of the once-per-step Adam counter kernel (warm-up + capture + timed graph replays + the
+    # eager-launch leg + the per-call roofline step); before round 2: steps + warmup + 1
+    adv = [r for r in stats if r['Name'].startswith('adam_advance_kernel')]
+    nsteps = int(adv[0]['Calls']) if adv else prof['steps'] + prof['warmup'] + 1
     sq = {r['Kernel']: r for r in csv.DictReader(open(os.path.join(dst, f'{tag}_pmc_sq.csv')))}
     mem = {r['Kernel']: r for r in csv.DictReader(open(os.path.join(dst, f'{tag}_pmc_mem.csv')))}
     lines = ['| kernel | launches/step | ms/step | avg us | HBM read MB (2xFETCH_SIZE) | HBM write MB | GB/s | L2 hit | '
