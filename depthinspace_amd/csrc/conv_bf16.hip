@@ -202,6 +202,154 @@ __global__ __launch_bounds__(256, 2) void convb_fwd_kernel(GenArgsB a) {
   else emit(std::integral_constant<int, DIS_ACT_NONE>{});
 }
 
+// The same streaming GEMM with 128 channels of one tap per stage, for the deep layers (>= 128 input channels on maps of a few
+// thousand pixels in all): with 32 channels a stage is 8 MFMAs per wave and 12 KB per workgroup, far less than a memory round
+// trip covers, and the layer runs at the latency of its 288 dependent stages (1024 -> 512 at 16 x 14: 0.8 us per stage).  Here
+// a stage is 4 sub-steps (32 MFMAs per wave, 48 KB per workgroup) and TWO stages are in flight in registers while a third is
+// multiplied from a single LDS buffer.  Weights: the packed layout of convb_pack_kernel (sub-step s of a stage = 32-channel
+// chunk 4 stage + s).  x and y bf16.
+#define CB_AS4 136  // LDS pixel stride of the 128-channel A tile (16-bit units): 128 + 8 (16 consecutive pixels: 16 distinct slots)
+template <int BN, bool YB>
+__global__ __launch_bounds__(256) void convb_fwd128_kernel(GenArgsB a) {
+  constexpr int NT = BN / 16;
+  constexpr int A_U16 = CB_BM * CB_AS4, B_U16 = 4 * (4 * BN * 8);
+  __shared__ __attribute__((aligned(16))) unsigned short smem[A_U16 + B_U16];
+  unsigned short* A = smem;
+  unsigned short* B = smem + A_U16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int M = a.n * a.hv * a.wv;
+  const int nb = blockIdx.x % a.nblk, m0 = (blockIdx.x / a.nblk) * CB_BM;
+  // loader role: channel group pq (8 channels of every 32-channel sub-step) of pixels p0 and p0 + 64
+  const int pq = tid & 3, p0 = tid >> 2;
+  long pbase[2];
+  int piy[2], pix[2];
+  bool pval[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + p0 + j * 64;
+    pval[j] = m < M;
+    const int mm = pval[j] ? m : 0;
+    const int vx = mm % a.wv, t = mm / a.wv, vy = t % a.hv, nn = t / a.hv;
+    pbase[j] = (long)nn * a.hin * a.win;
+    piy[j] = vy * a.S;
+    pix[j] = vx * a.S;
+  }
+  const int nst = (a.nchunk + 3) >> 2;  // stages per tap
+  const int nk = a.ntaps * nst;
+  u32x4 ra[2][2][4], rb[2][4];
+  const u32x4* wq = (const u32x4*)a.w;
+  const int bvec = 4 * BN;            // 16-byte vectors of one 32-channel weight block
+  const bool wload = tid < bvec;
+  int ptap = 0, pst = 0, pnext = 0;
+  auto prefetch = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    if (pnext >= nk) return;
+    const int dy = a.tdy[ptap], dx = a.tdx[ptap];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int iy = piy[j] + dy, ix = pix[j] + dx;
+      const bool ok = pval[j] && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+      const long e = (pbase[j] + (long)iy * a.win + ix) * a.ldx + a.xoff + pst * 128 + pq * 8;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int c = pst * 128 + s * 32 + pq * 8;
+        ra[set][j][s] = __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.x, a.x_bytes),
+                                                              (ok && c < a.cin) ? (unsigned)((e + s * 32) * 2) : BX_OOB, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int chunk = pst * 4 + s;
+      const long wb = ((long)(ptap * a.nchunk + (chunk < a.nchunk ? chunk : 0)) * a.nblk + nb) * bvec;
+      u32x4 v = wq[wb + (wload ? tid : 0)];
+      if (chunk >= a.nchunk) v = (u32x4){0u, 0u, 0u, 0u};
+      rb[set][s] = v;
+    }
+    ++pnext;
+    if (++pst == nst) {
+      pst = 0;
+      ++ptap;
+    }
+  };
+  auto stage = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) *(u32x4*)(A + (p0 + j * 64) * CB_AS4 + s * 32 + pq * 8) = ra[set][j][s];
+    if (wload) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ((u32x4*)B)[s * bvec + tid] = rb[set][s];
+    }
+  };
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  prefetch(S0{});
+  prefetch(S1{});
+  auto body = [&](auto setc) __attribute__((always_inline)) {
+    __syncthreads();  // every wave is done with the previous stage's tiles
+    stage(setc);
+    __syncthreads();
+    prefetch(setc);   // the set just written takes the stage after next
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      s16x8 fa[2], fb[NT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) fa[mt] = *(const s16x8*)(A + (wave * 32 + mt * 16 + li) * CB_AS4 + s * 32 + lg * 8);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[nt] = *(const s16x8*)(B + (s * bvec + lg * BN + nt * 16 + li) * 8);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[nt]),
+                                                               __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
+    }
+  };
+  for (int ks = 0; ks < nk; ks += 2) {
+    body(S0{});
+    if (ks + 1 < nk) body(S1{});
+  }
+  auto emit = [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = m0 + wave * 32 + mt * 16 + li;
+      if (m >= M) continue;
+      const int vx = m % a.wv, t = m / a.wv, vy = t % a.hv, nn = t / a.hv;
+      const long pe = (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = nb * BN + nt * 16 + lg * 4;
+        if (co >= a.cout) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float bv = (a.bias && co + r < a.cout) ? a.bias[co + r] : 0.f;
+          o[r] = act_apply(acc[mt][nt][r] + bv, ACT);
+        }
+        if (co + 4 <= a.cout) {
+          if (YB) *(uint2*)((bf16_t*)a.y + pe + co) = make_uint2(cb_pack2(o[0], o[1]), cb_pack2(o[2], o[3]));
+          else *(float4*)((float*)a.y + pe + co) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          for (int r = 0; r < 4 && co + r < a.cout; ++r) {
+            if (YB) ((bf16_t*)a.y)[pe + co + r] = (bf16_t)(cb_pack2(o[r], 0.f) & 0xffffu);
+            else ((float*)a.y)[pe + co + r] = o[r];
+          }
+        }
+      }
+    }
+  };
+  if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{});
+  else if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{});
+  else emit(std::integral_constant<int, DIS_ACT_NONE>{});
+}
+
 // packed[tap][chunk][nb][lg][col][j] = bf16(W(tap, ci = chunk*32 + lg*8 + j, co = nb*BN + col))
 struct PackArgsB {
   const float* w;
@@ -676,6 +824,15 @@ static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t
   a.w = wpack;
   const long grid = ((M + CB_BM - 1) / CB_BM) * a.nblk;
   if (grid > 2147483647L) return DIS_ERR_BAD_SHAPE;
+  static const bool no128 = getenv("DIS_CONVB_128") && getenv("DIS_CONVB_128")[0] == '0';
+  if (x_bf16 && a.cin >= 128 && bn >= 32 && !no128) {  // deep layers: 128-channel stages
+    if (bn == 64 && y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<64, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((convb_fwd128_kernel<64, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else if (y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<32, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((convb_fwd128_kernel<32, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    DIS_CHECK_LAUNCH();
+    return DIS_OK;
+  }
   if (x_bf16 && y_bf16) cb_launch<true, true>(a, bn, grid, s);
   else if (x_bf16) cb_launch<true, false>(a, bn, grid, s);
   else if (y_bf16) cb_launch<false, true>(a, bn, grid, s);
