@@ -155,6 +155,14 @@ def _sink(param):
     return g, g
 
 
+def _sink_opt(param):
+    """_sink for an optional parameter (a bias): (None, None) without one.  Parameter gradients leave through the sinks, not
+    through autograd's AccumulateGrad nodes: one launch less per parameter, and a captured step (trainer.GraphedStep) then never
+    runs an AccumulateGrad node that an earlier, still referenced eager step created on the default stream - joining the
+    legacy default stream into a capture crashes the HIP runtime."""
+    return _sink(param) if param is not None else (None, None)
+
+
 def _sink_block(params):
     """Gradient sink for a kernel that writes the gradients of several parameters as ONE contiguous block (Conv3D's
     five arrays): -> flat float view covering all of them if they are registered, unused so far and adjacent in the
@@ -836,6 +844,7 @@ class _DispHead(torch.autograd.Function):
         lib.call('dis_disp_head_fwd', x, weight, bias, y, n, h, w, cin, float(alpha), float(offset))
         ctx.save_for_backward(x, weight, y)
         ctx.alpha = float(alpha)
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -843,11 +852,12 @@ class _DispHead(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         n, h, w, cin = x.shape
         gx = torch.empty_like(x)
-        gw = torch.empty_like(weight)
-        gb = torch.empty(1, dtype=torch.float32, device=x.device)
+        gw, gw_ret = _sink(weight)
+        gb, gb_ret = _sink(ctx.bias_ref)
         ws = torch.empty(lib.fn('dis_disp_head_bwd_workspace')(n, h, w, cin), dtype=torch.float32, device=x.device)
         lib.call('dis_disp_head_bwd', x, weight, y, _c(gy), gx, gw, gb, ws, n, h, w, cin, ctx.alpha)
-        return gx, gw, gb, None, None
+        _sinks_written()
+        return gx, gw_ret, gb_ret, None, None
 
 
 def disp_head(x, weight, bias, alpha, offset=3.0):
@@ -962,11 +972,12 @@ def _convg_wgrad(X, hX, wX, cX, cX_w, G, hG, wG, cG, cG_w, gw, n, k, stride, pad
              stride, pad)
 
 
-def _colsum(G, c_real):
-    """sum over all pixels of the first c_real channels of an nhwc tensor"""
+def _colsum(G, c_real, out=None):
+    """sum over all pixels of the first c_real channels of an nhwc tensor (into `out` if given)"""
     ld = _ld(G)
     npix = G.shape[0] * G.shape[1] * G.shape[2]
-    out = torch.empty(c_real, dtype=torch.float32, device=G.device)
+    if out is None:
+        out = torch.empty(c_real, dtype=torch.float32, device=G.device)
     ws = torch.empty(lib.fn('dis_colsum_workspace')(c_real), dtype=torch.float32, device=G.device)
     lib.call('dis_colsum', G, ld, 0, npix, c_real, out, ws)
     return out
@@ -1004,6 +1015,7 @@ class _ConvG(torch.autograd.Function):
         _convg_run(CONVG_TCONV if transposed else CONVG_CONV, x, weight, bias, y, n, hin, win, cin_mem, cin_w, hout,
                    wout, cout, cout, k, stride, pad, act)
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        ctx.bias_ref = bias  # (gradient sink lookup)
         ctx.cfg = (stride, pad, act, transposed, bias is not None, need_dgrad)
         return y
 
@@ -1039,14 +1051,16 @@ class _ConvG(torch.autograd.Function):
             wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin_mem, cout, k, stride)
             if wsz >= 0 and gpre.shape[-1] == cout and x.is_contiguous():
                 ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
-                gb = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+                gb, gb_ret = _sink_opt(ctx.bias_ref)
                 _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_mem, cin_w, cout, k, stride, pad)
                 _sinks_written()
-                return gx, gw_ret, gb, None, None, None, None, None, None, None
+                return gx, gw_ret, gb_ret, None, None, None, None, None, None, None
             _convg_wgrad(x, hin, win, cin_mem, cin_w, gpre, hout, wout, cout, cout, gw, n, k, stride, pad)
-        gb = _colsum(gpre, cout) if has_bias else None
+        gb, gb_ret = _sink_opt(ctx.bias_ref)
+        if has_bias:
+            _colsum(gpre, cout, out=gb)
         _sinks_written()
-        return gx, gw_ret, gb, None, None, None, None, None, None, None
+        return gx, gw_ret, gb_ret, None, None, None, None, None, None, None
 
 
 def convg(x, weight, bias, stride=1, pad=0, act=ACT_NONE, need_dgrad=True, out=None, dtype=torch.float32):
@@ -1084,6 +1098,7 @@ class _HeadG(torch.autograd.Function):
             lib.call('dis_sigmoid_affine_fwd', y, y, float(alpha), float(offset), y.numel())
         ctx.save_for_backward(x, weight, y)
         ctx.alpha = float(alpha)
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -1092,21 +1107,22 @@ class _HeadG(torch.autograd.Function):
         n, h, w, cin = x.shape
         k = weight.shape[2]
         cin_w = weight.shape[1]
+        gw, gw_ret = _sink(weight)
+        gb, gb_ret = _sink(ctx.bias_ref)
         if ctx.direct:
             gx = torch.empty_like(x)
-            gw = torch.empty_like(weight)
-            gb = torch.empty(1, dtype=torch.float32, device=x.device)
             ws = torch.empty(lib.fn('dis_disp_head_bwd_workspace')(n, h, w, cin), dtype=torch.float32, device=x.device)
             lib.call('dis_disp_head_bwd', x, weight, y, _c(gy), gx, gw, gb, ws, n, h, w, cin, ctx.alpha)
-            return gx, gw, gb, None, None
+            _sinks_written()
+            return gx, gw_ret, gb_ret, None, None
         gpre4 = torch.empty((n, h, w, 4), dtype=torch.float32, device=x.device)
         lib.call('dis_sigmoid_affine_bwd', y, _c(gy), gpre4, ctx.alpha, n * h * w)
         gx = torch.empty_like(x)
         _convg_run(CONVG_CONV_DGRAD, gpre4, weight, None, gx, n, h, w, 4, 1, h, w, cin, cin_w, k, 1, k // 2, ACT_NONE)
-        gw = torch.empty_like(weight)
         _convg_wgrad(x, h, w, cin, cin_w, gpre4, h, w, 4, 1, gw, n, k, 1, k // 2)
-        gb = _colsum(gpre4, 1)
-        return gx, gw, gb, None, None
+        _colsum(gpre4, 1, out=gb)
+        _sinks_written()
+        return gx, gw_ret, gb_ret, None, None
 
 
 def disp_head_g(x, weight, bias, alpha, offset=3.0):
@@ -1155,9 +1171,10 @@ def _convb_wgrad(X, hX, wX, cX, cX_w, G, hG, wG, cG, cG_w, gw, n, k, stride, pad
              n, k, stride, pad)
 
 
-def _colsum_b(G, c_real):
+def _colsum_b(G, c_real, out=None):
     npix = G.shape[0] * G.shape[1] * G.shape[2]
-    out = torch.empty(c_real, dtype=torch.float32, device=G.device)
+    if out is None:
+        out = torch.empty(c_real, dtype=torch.float32, device=G.device)
     ws = torch.empty(lib.fn('dis_colsum_bf16_workspace')(c_real), dtype=torch.float32, device=G.device)
     lib.call('dis_colsum_bf16', G, _ld(G), 0, npix, c_real, out, ws)
     return out
@@ -1192,6 +1209,7 @@ class _ConvB(torch.autograd.Function):
         _convb_run(CONVG_TCONV if transposed else CONVG_CONV, x, weight, bias, y, n, hin, win, cin_mem, cin_w, hout, wout,
                    cout, cout, k, stride, pad, act)
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        ctx.bias_ref = bias  # (gradient sink lookup)
         ctx.cfg = (stride, pad, act, transposed, bias is not None, need_dgrad)
         return y
 
@@ -1214,15 +1232,16 @@ class _ConvB(torch.autograd.Function):
                          cout)
                 gw, gw_ret = _sink(weight)
                 ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
-                gb = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+                gb, gb_ret = _sink_opt(ctx.bias_ref)
                 _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_mem, cin_w, cout, k, stride, pad)
                 _sinks_written()
-                return None, gw_ret, gb, None, None, None, None, None, None, None
-        gb = None
+                return None, gw_ret, gb_ret, None, None, None, None, None, None, None
+        gb, gb_ret = _sink_opt(ctx.bias_ref)
+        gb_done = False
         if act != ACT_NONE or not gy.is_contiguous():
             gpre = torch.empty(gy.shape, dtype=BF16, device=gy.device)
             if has_bias and cout <= 1024 and 256 % (cout // 4) == 0:   # bias gradient from the same pass over gy
-                gb = torch.empty(cout, dtype=torch.float32, device=gy.device)
+                gb_done = True
                 ws = torch.empty(lib.fn('dis_colsum_bf16_workspace')(cout), dtype=torch.float32, device=gy.device)
                 lib.call('dis_act_bwd_bf16_bias', gy, _ld(gy), y, _ld(y) if y is not None else 0, gpre, act,
                          n * hout * wout, cout, gb, ws)
@@ -1241,10 +1260,10 @@ class _ConvB(torch.autograd.Function):
             _convb_wgrad(gpre, hout, wout, cout, cout, x, hin, win, cin_mem, cin_w, gw, n, k, stride, pad)
         else:
             _convb_wgrad(x, hin, win, cin_mem, cin_w, gpre, hout, wout, cout, cout, gw, n, k, stride, pad)
-        if has_bias and gb is None:
-            gb = _colsum_b(gpre, cout)
+        if has_bias and not gb_done:
+            _colsum_b(gpre, cout, out=gb)
         _sinks_written()
-        return gx, gw_ret, gb, None, None, None, None, None, None, None
+        return gx, gw_ret, gb_ret, None, None, None, None, None, None, None
 
 
 class _HeadB(torch.autograd.Function):
@@ -1263,6 +1282,7 @@ class _HeadB(torch.autograd.Function):
         lib.call('dis_sigmoid_affine_fwd', y, y, float(alpha), float(offset), y.numel())
         ctx.save_for_backward(x, weight, y)
         ctx.alpha = float(alpha)
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -1275,10 +1295,12 @@ class _HeadB(torch.autograd.Function):
         lib.call('dis_sigmoid_affine_bwd', y, _c(gy), gpre4, ctx.alpha, n * h * w)
         gx = torch.empty_like(x)
         _convb_run(CONVG_CONV_DGRAD, gpre4, weight, None, gx, n, h, w, 4, 1, h, w, cin, cin_w, k, 1, k // 2, ACT_NONE)
-        gw = torch.empty_like(weight)
+        gw, gw_ret = _sink(weight)
+        gb, gb_ret = _sink(ctx.bias_ref)
         _convb_wgrad(x, h, w, cin, cin_w, gpre4, h, w, 4, 1, gw, n, k, 1, k // 2)
-        gb = _colsum(gpre4, 1)
-        return gx, gw, gb, None, None
+        _colsum(gpre4, 1, out=gb)
+        _sinks_written()
+        return gx, gw_ret, gb_ret, None, None
 
 
 class _WriteChannelsB(torch.autograd.Function):

@@ -97,6 +97,26 @@ def _rank(rank, world, port, arch, q, logdir):
             opt.step = orig
             torch.cuda.synchronize()
             res[f'grad_err{step}'] = close(opt.flat_g, gs[0] + gs[1])
+            if res[f'grad_err{step}'] > 1e-5:   # diagnostics: which parameters carry the difference, and whose gradient it is
+                want = gs[0] + gs[1]
+                names = [n for n, _ in net.named_parameters()]
+                rows = []
+                for n_, p_, off in zip(names, opt.params, opt.offsets):
+                    sl = slice(off, off + p_.numel())
+                    e = float((opt.flat_g[sl] - want[sl]).abs().max())
+                    rows.append((e / (float(want.abs().max()) + 1e-20), n_, float(want[sl].abs().max())))
+                rows.sort(reverse=True)
+                res[f'worst{step}'] = rows[:6]
+                # my own gradient recomputed now (single process semantics) against the one from local_grads()
+                opt.overlap = False
+                w.copy_data(batches[rank], device=w.train_device, requires_grad=False, train=True)
+                keep = opt.flat_g.clone()
+                opt.zero_grad()
+                flow = w.read_optical_flow(True)
+                sum(w.loss_forward(w.net_forward(net, flow), True, flow)).backward()
+                res[f'own_again{step}'] = close(opt.flat_g, gs[rank])
+                opt.flat_g.copy_(keep)
+                opt.overlap = True
         res['early'] = early
         res['nbuckets'] = len(opt.buckets)
         # identical replicas
@@ -151,6 +171,8 @@ def test_two_rank_train_step(arch, tmp_path):
         assert 'error' not in v, v['error']
     for r in range(world):
         assert 'error' not in res[r], res[r]['error']
+        for k_, v_ in sorted(res[r].items()):
+            print(f'rank {r} {k_}: {v_}')
         # reduced gradient == sum of the ranks' own gradients (float atomics in two scatter kernels: tolerance, not bits)
         for step in range(3):
             assert res[r][f'grad_err{step}'] < 1e-4, (r, step, res[r])

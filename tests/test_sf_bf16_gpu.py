@@ -168,3 +168,44 @@ def test_sf_step_bf16_vs_reference_golden(golden_dir):
             agree += int(((d * d_ref) > 0)[m].sum())
             tot += int(m.sum())
     assert tot > 1000 and agree / tot > 0.9, (agree, tot)
+
+
+def test_worker_trains_and_evaluates_in_bf16():
+    """The entry-point classes with the bf16 network (train_val.py, DIS_ACT_DTYPE=bf16): Worker.train_step for a few steps
+    (losses finite and close to the fp32 network's from the same initial parameters, parameters move), the same step as a
+    hipGraph (trainer.GraphedStep), and a no_grad evaluation forward (float32 disparities)."""
+    from depthinspace_amd import synth
+    from depthinspace_amd.model import single_frame_worker, networks
+    from depthinspace_amd.trainer import FlatAdam, GraphedStep
+    args = argparse.Namespace(use_pseudo_gt=False, lcn_radius=5, track_length=4, data_type='synthetic',
+                              architecture='single_frame', epochs=1, warmup_epochs=150, train_batch_size=1, max_disp=128)
+    H, W = 128, 108
+    settings = synth.make_settings(H, W)
+    w = single_frame_worker.Worker(args, settings=settings)
+    w.build_losses()
+    w.current_epoch = 2
+    batch = {k: torch.from_numpy(v) for k, v in synth.make_batch(settings, 1, 4, seed=5, scene='bumps').items()}
+    losses = {}
+    for name, dt in (('f32', torch.float32), ('bf16', BF)):
+        torch.manual_seed(0)
+        net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=w.imsizes, act_dtype=dt).cuda()
+        opt = FlatAdam(net.parameters(), lr=1e-4)
+        p0 = opt.flat_p.clone()
+        ls = []
+        for _ in range(3):
+            errs, _ = w.train_step(net, opt, batch)
+            ls.append([float(e) for e in errs])
+        losses[name] = np.array(ls)
+        assert np.isfinite(losses[name]).all() and float((opt.flat_p - p0).abs().max()) > 0
+        if dt == BF:
+            g = GraphedStep(w, net, opt, batch, use_graph=True, warmup=1)
+            g.run()
+            g.run()
+            torch.cuda.synchronize()
+            assert g.mode == 'graph' and opt.step_count == 3 + 1 + 2 and np.isfinite(g.losses()).all()
+            with torch.no_grad():
+                w.copy_data(batch, device=w.train_device, requires_grad=False, train=False)
+                out = w.net_forward(net, None)
+            d = out[0] if isinstance(out, (list, tuple)) else out
+            assert d.dtype == torch.float32 and bool(torch.isfinite(d).all())
+    np.testing.assert_allclose(losses['bf16'], losses['f32'], rtol=0.03, atol=2e-4)

@@ -12,7 +12,8 @@ Data parallel (new; the reference is single-GPU): one process per GPU,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train_val.py --architecture ...
 
 every rank trains on its own shard of the tracks, gradients are all-reduced over RCCL (bucketed, overlapped with the
-backward pass), rank 0 writes the checkpoints.  DIS_TRAIN_GRAPH=1 captures the step in hipGraphs."""
+backward pass), rank 0 writes the checkpoints.  DIS_TRAIN_GRAPH=1 captures the step in one hipGraph (single GPU);
+DIS_ACT_DTYPE=bf16 selects bf16 activation storage for the single-frame network."""
 import os
 import sys
 
@@ -36,7 +37,11 @@ def main():
     out_dir = None if os.path.exists(cfg) else os.environ.get('DIS_OUTPUT_DIR', './output')
     if args.architecture == 'single_frame':
         worker = single_frame_worker.Worker(args, settings=settings, output_dir=out_dir)
-        net = networks.DispDecoder(channels_in=2, max_disp=args.max_disp, imsizes=worker.imsizes).to(worker.train_device)
+        # DIS_ACT_DTYPE=bf16: DispNetS with bf16 activation storage (BASELINE config 2; parameters / disparities / losses fp32,
+        # held to its own tolerance - tests/test_sf_bf16_gpu.py).  Default: the fp32 parity path.
+        act = {'fp32': torch.float32, 'f32': torch.float32, 'bf16': torch.bfloat16}[os.environ.get('DIS_ACT_DTYPE', 'fp32')]
+        net = networks.DispDecoder(channels_in=2, max_disp=args.max_disp, imsizes=worker.imsizes,
+                                   act_dtype=act).to(worker.train_device)
     else:
         worker = multi_frame_worker.Worker(args, settings=settings, output_dir=out_dir)
         net = multi_frame_networks.FuseNet(imsize=worker.imsizes[0], K=worker.K, baseline=worker.baseline,
