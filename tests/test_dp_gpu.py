@@ -175,7 +175,7 @@ def test_two_rank_train_step(arch, tmp_path):
             print(f'rank {r} {k_}: {v_}')
         # reduced gradient == sum of the ranks' own gradients (float atomics in two scatter kernels: tolerance, not bits)
         for step in range(3):
-            assert res[r][f'grad_err{step}'] < 1e-4, (r, step, res[r])
+            assert res[r][f'grad_err{step}'] < 1e-5, (r, step, res[r])   # measured <= 3e-7
         # step 0 learns the notification pattern; from step 1 on (almost) every bucket is in flight before backward returns
         assert res[r]['early'][0] == 0 and all(e >= res[r]['nbuckets'] - 1 for e in res[r]['early'][1:]), res[r]
         assert res[r]['replicas_equal'] and res[r]['steps'] == 3
