@@ -289,7 +289,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_bwd_kernel(const float4* __rest
                                                               const unsigned char* __restrict__ idx,
                                                               const float* __restrict__ y, const float* __restrict__ gy,
                                                               float* __restrict__ gwf, float* __restrict__ part,
-                                                              C3Dims d) {
+                                                              C3Dims d, float* __restrict__ stage) {
+  // stage != nullptr: the feature-gradient rows are written to stage[(output pixel * 9 + neighbour) * 32 ..] (plain stores)
+  // instead of being scattered with float atomics; conv3d_feat_gather_kernel sums them per source row in a fixed order
   __shared__ C3Lds L;
   __shared__ float red[4][C3_NPARAM];
   c3_load_weights(L, P);
@@ -468,7 +470,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_bwd_kernel(const float4* __rest
       for (int j = 0; j < C3_GP / 2; ++j) {
         const int px = 2 * j + (lane >> 5), c = lane & 31;
         const long fo = F[px];
-        if (fo >= 0) atomicAdd(gwf + fo + c, X[px * C3_XS + c]);
+        if (fo >= 0) {
+          if (stage) stage[((grp * C3_GP + px) * C3_NB + n) * C3_C + c] = X[px * C3_XS + c];
+          else atomicAdd(gwf + fo + c, X[px * C3_XS + c]);
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -559,11 +564,63 @@ extern "C" int dis_conv3d_knn_fwd(const float* geom, const float* wf, const floa
 
 extern "C" long dis_conv3d_knn_bwd_workspace(void) { return (long)C3_BWD_BLOCKS * C3_NPARAM; }
 
+// grad_wf[row] (+)= sum of the staged rows of the (output pixel, neighbour) entries that selected source row `row`, in the
+// order of the CSR lists (ascending entry id: fixed, so the result is bitwise reproducible).  8 threads per row, 4 channels each.
+__global__ void conv3d_feat_gather_kernel(const float* __restrict__ stage, const int* __restrict__ offsets,
+                                          const int* __restrict__ entries, float* __restrict__ gwf, long nsrc,
+                                          int accumulate) {
+  const long total = nsrc * 8;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long d = i >> 3;
+    const int g = (int)(i & 7);
+    const int lo = offsets[d], hi = offsets[d + 1];
+    float4* out = (float4*)(gwf + d * C3_C + g * 4);
+    if (lo == hi) {
+      if (!accumulate) *out = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    float4 acc = accumulate ? *out : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = lo; e < hi; ++e) {
+      const float4 v = *(const float4*)(stage + (long)entries[e] * C3_C + g * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *out = acc;
+  }
+}
+extern "C" long dis_conv3d_knn_bwd_stage(int tl, int bs, int h, int wd, int stride) {
+  C3Dims d;
+  if (c3_dims(&d, tl, bs, h, wd, stride) != DIS_OK) return -1;
+  return (long)tl * bs * d.ho * d.wo * C3_NB * C3_C;
+}
+
+static int c3_bwd_run(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
+                      const float* dense2_w, const float* dense2_b, const float* w, const unsigned char* idx,
+                      const float* y, const float* gy, float* grad_wf, float* gparams, float* workspace, const int* csr,
+                      float* stage, int accumulate, int tl, int bs, int h, int wd, int stride, void* stream);
 extern "C" int dis_conv3d_knn_bwd(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
                                   const float* dense2_w, const float* dense2_b, const float* w,
                                   const unsigned char* idx, const float* y, const float* gy, float* grad_wf,
                                   float* gparams, float* workspace, int tl, int bs, int h, int wd, int stride,
                                   void* stream) {
+  return c3_bwd_run(geom, wf, dense1_w, dense1_b, dense2_w, dense2_b, w, idx, y, gy, grad_wf, gparams, workspace, nullptr,
+                    nullptr, 1, tl, bs, h, wd, stride, stream);
+}
+// The same with a deterministic feature gradient: csr = dis_conv3d_csr_build(idx, ...) (layout_ops.hip), stage =
+// dis_conv3d_knn_bwd_stage() floats of scratch.  accumulate = 0: grad_wf is written (rows nobody selected get zeros: no
+// zero fill by the caller); 1: the selected rows are added to grad_wf's contents (shared gradient buffer).
+extern "C" int dis_conv3d_knn_bwd_csr(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
+                                      const float* dense2_w, const float* dense2_b, const float* w,
+                                      const unsigned char* idx, const float* y, const float* gy, float* grad_wf,
+                                      float* gparams, float* workspace, const int* csr, float* stage, int accumulate,
+                                      int tl, int bs, int h, int wd, int stride, void* stream) {
+  if (!csr || !stage) return DIS_ERR_NULL;
+  return c3_bwd_run(geom, wf, dense1_w, dense1_b, dense2_w, dense2_b, w, idx, y, gy, grad_wf, gparams, workspace, csr, stage,
+                    accumulate, tl, bs, h, wd, stride, stream);
+}
+static int c3_bwd_run(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
+                      const float* dense2_w, const float* dense2_b, const float* w, const unsigned char* idx,
+                      const float* y, const float* gy, float* grad_wf, float* gparams, float* workspace, const int* csr,
+                      float* stage, int accumulate, int tl, int bs, int h, int wd, int stride, void* stream) {
   if (!geom || !wf || !dense1_w || !dense1_b || !dense2_w || !dense2_b || !w || !idx || !y || !gy || !grad_wf ||
       !gparams || !workspace)
     return DIS_ERR_NULL;
@@ -576,7 +633,12 @@ extern "C" int dis_conv3d_knn_bwd(const float* geom, const float* wf, const floa
   int grid = dis_cdiv(dis_cdiv(total, C3_GP), 4);
   if (grid > C3_BWD_BLOCKS) grid = C3_BWD_BLOCKS;
   hipLaunchKernelGGL(conv3d_bwd_kernel, dim3(grid), dim3(256), 0, s, (const float4*)geom, wf, P, idx, y, gy, grad_wf,
-                     workspace, d);
+                     workspace, d, stage);
+  if (csr) {
+    const long nsrc = (long)tl * bs * h * wd * C3_TL;
+    hipLaunchKernelGGL(conv3d_feat_gather_kernel, dim3(dis_ew_grid(nsrc * 8, 256)), dim3(256), 0, s, (const float*)stage, csr,
+                       csr + 2 * nsrc + 1, grad_wf, nsrc, accumulate);
+  }
   hipLaunchKernelGGL(c3_param_reduce_kernel, dim3(dis_cdiv(C3_NPARAM, 4)), dim3(256), 0, s, (const float*)workspace,
                      gparams, grid);
   DIS_CHECK_LAUNCH();

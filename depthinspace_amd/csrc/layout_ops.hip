@@ -668,6 +668,96 @@ extern "C" int dis_gather_csr_build(const float* flows, int* csr, int tl, int bs
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
+// ---- CSR of the Conv3D neighbour sets by SOURCE row (deterministic feature gradient, conv3d_knn.hip) ----
+// entry = output pixel * 9 + neighbour; its source row = ((tb * h + iy) * w + ix) * 4 + slot with (tap, slot) = (id / 4, id % 4)
+// of the selected candidate id and (iy, ix) = (oy, ox) * stride - 1 + (tap / 3, tap % 3), as c3_neighbor() computes it.
+// csr = [offsets: nsrc + 1][cursor: nsrc][entries: nent][scan scratch], lists sorted by entry id.
+__global__ void c3csr_count_fill_kernel(const unsigned char* __restrict__ idx, int* __restrict__ cursor,
+                                        int* __restrict__ entries, long nent, int ho, int wo, int h, int w, int stride,
+                                        int fill) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < nent; e += (long)gridDim.x * blockDim.x) {
+    const long i = e / 9;
+    const int id = idx[e];
+    const int tap = id >> 2, slot = id & 3;
+    const int ox = (int)(i % wo), oy = (int)((i / wo) % ho);
+    const long tb = i / ((long)wo * ho);
+    const int iy = oy * stride - 1 + tap / 3, ix = ox * stride - 1 + tap % 3;
+    if (iy < 0 || iy >= h || ix < 0 || ix >= w) continue;
+    const long src = ((tb * h + iy) * w + ix) * 4 + slot;
+    const int pos = atomicAdd(cursor + src, 1);
+    if (fill) entries[pos] = (int)e;
+  }
+}
+__global__ void c3csr_sort_kernel(const int* __restrict__ offsets, int* __restrict__ entries, long nd) {
+  for (long d = blockIdx.x * (long)blockDim.x + threadIdx.x; d < nd; d += (long)gridDim.x * blockDim.x) {
+    const int lo = offsets[d], hi = offsets[d + 1];
+    const int len = hi - lo;
+    if (len <= 1) continue;
+    if (len <= CSR_SORT_MAX) {  // rank sort in registers (a source row is selected by at most 9 output pixels)
+      int e[CSR_SORT_MAX];
+#pragma unroll
+      for (int k = 0; k < CSR_SORT_MAX; ++k) e[k] = k < len ? entries[lo + k] : 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < CSR_SORT_MAX; ++k) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < CSR_SORT_MAX; ++j) rank += (e[j] < e[k]) ? 1 : 0;  // (entry ids are unique)
+        if (k < len) entries[lo + rank] = e[k];
+      }
+    } else {
+      for (int a = lo + 1; a < hi; ++a) {
+        const int key = entries[a];
+        int b = a - 1;
+        while (b >= lo && entries[b] > key) {
+          entries[b + 1] = entries[b];
+          --b;
+        }
+        entries[b + 1] = key;
+      }
+    }
+  }
+}
+static int c3csr_dims(int tl, int bs, int h, int w, int stride, long* nsrc, long* nent, int* ho, int* wo) {
+  if (tl != 4 || bs <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2)) return DIS_ERR_BAD_SHAPE;
+  *ho = (h + 2 - 3) / stride + 1;
+  *wo = (w + 2 - 3) / stride + 1;
+  *nsrc = (long)tl * bs * h * w * 4;
+  *nent = (long)tl * bs * *ho * *wo * 9;
+  if (*nsrc >= 2147483647L || *nent >= 2147483647L) return DIS_ERR_UNSUPPORTED;
+  return DIS_OK;
+}
+extern "C" long dis_conv3d_csr_workspace(int tl, int bs, int h, int w, int stride) {
+  long nsrc, nent;
+  int ho, wo;
+  if (c3csr_dims(tl, bs, h, w, stride, &nsrc, &nent, &ho, &wo) != DIS_OK) return -1;
+  return (nsrc + 1) + nsrc + nent + (nsrc + CSR_SCAN_ELEMS - 1) / CSR_SCAN_ELEMS + 1;
+}
+extern "C" int dis_conv3d_csr_build(const unsigned char* idx, int* csr, int tl, int bs, int h, int w, int stride,
+                                    void* stream) {
+  if (!idx || !csr) return DIS_ERR_NULL;
+  long nsrc, nent;
+  int ho, wo;
+  const int rc = c3csr_dims(tl, bs, h, w, stride, &nsrc, &nent, &ho, &wo);
+  if (rc != DIS_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  int* offsets = csr;
+  int* cursor = csr + nsrc + 1;
+  int* entries = csr + 2 * nsrc + 1;
+  int* bsum = entries + nent;
+  const int nblk = (int)((nsrc + CSR_SCAN_ELEMS - 1) / CSR_SCAN_ELEMS);
+  hipLaunchKernelGGL(csr_zero_kernel, dim3(dis_ew_grid(nsrc, 256)), dim3(256), 0, s, cursor, nsrc);
+  int grid = dis_cdiv(nent, 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(c3csr_count_fill_kernel, dim3(grid), dim3(256), 0, s, idx, cursor, entries, nent, ho, wo, h, w, stride, 0);
+  hipLaunchKernelGGL(csr_scan1_kernel, dim3(nblk), dim3(256), 0, s, (const int*)cursor, bsum, nsrc);
+  hipLaunchKernelGGL(csr_scan2_kernel, dim3(1), dim3(64), 0, s, bsum, nblk);
+  hipLaunchKernelGGL(csr_scan3_kernel, dim3(nblk), dim3(256), 0, s, cursor, offsets, (const int*)bsum, nsrc, nblk);
+  hipLaunchKernelGGL(c3csr_count_fill_kernel, dim3(grid), dim3(256), 0, s, idx, cursor, entries, nent, ho, wo, h, w, stride, 1);
+  hipLaunchKernelGGL(c3csr_sort_kernel, dim3(dis_ew_grid(nsrc, 256)), dim3(256), 0, s, (const int*)offsets, entries, nsrc);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 extern "C" int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* csr, const float* init,
                                               float* grad_feat, int tl, int bs, int h, int w, int c, void* stream) {
   if (!grad_out || !csr || !grad_feat) return DIS_ERR_NULL;

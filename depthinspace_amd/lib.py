@@ -78,6 +78,10 @@ SIGS = {
     'dis_conv3d_knn_fwd': 'ppppppppp' + 'iiiiip',
     'dis_conv3d_knn_bwd_workspace': '',
     'dis_conv3d_knn_bwd': 'ppppppp' + 'pppppp' + 'iiiiip',
+    'dis_conv3d_knn_bwd_csr': 'ppppppp' + 'pppppp' + 'ppi' + 'iiiiip',
+    'dis_conv3d_knn_bwd_stage': 'iiiii',
+    'dis_conv3d_csr_workspace': 'iiiii',
+    'dis_conv3d_csr_build': 'ppiiiiip',
     'dis_convg_pack_workspace': 'iii',
     'dis_convg_run': 'ipiipppiip' + 'iiiiiiiiiiiii' + 'p',
     'dis_convg_wgrad_workspace': 'iiiiii',
@@ -101,7 +105,7 @@ SIGS = {
     'dis_adam_step_dev': 'pppplfddfpfp',
 }
 _RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
-             'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_gather_csr_workspace',
+             'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_conv3d_knn_bwd_stage', 'dis_conv3d_csr_workspace', 'dis_gather_csr_workspace',
              'dis_conv2d_pack_bf16x3_size', 'dis_disp_head_bwd_workspace'}
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float, 'd': ctypes.c_double}

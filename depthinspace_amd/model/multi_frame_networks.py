@@ -270,10 +270,16 @@ class FuseNet(TimedModule):
             # layer (the reference repeats the identical top-k in all 8 Conv3D calls).  `knn_index_override`
             # (tests only) substitutes externally supplied neighbour sets, see DESIGN.md "top-k conditioning".
             ov = self.knn_index_override
-            idx = ov[0] if ov is not None else ops.conv3d_select(geom, 2)
-            idx_q = ov[1] if ov is not None else ops.conv3d_select(geom_q, 1)
+            train = torch.is_grad_enabled() or feat.requires_grad
+            # (training: the sets' by-source-row index rides along as idx.c3csr - the Conv3D feature gradient then is a
+            # fixed-order gather instead of a float-atomic scatter; built once, used by the 4 blocks' backward passes)
+            idx = ov[0] if ov is not None else ops.conv3d_select(geom, 2, with_csr=train)
+            idx_q = ov[1] if ov is not None else ops.conv3d_select(geom_q, 1, with_csr=train)
+            if ov is not None and train and ops.CONV3D_CSR:
+                ops.conv3d_csr(idx, geom.shape[2], geom.shape[3], 2)
+                ops.conv3d_csr(idx_q, geom_q.shape[2], geom_q.shape[3], 1)
             # scatter index of the feature warps (data only): built once, shared by the 4 blocks' backward passes
-            csr = ops.gather_csr(flows) if torch.is_grad_enabled() or feat.requires_grad else None
+            csr = ops.gather_csr(flows) if train else None
             csr_q = ops.gather_csr(flows_q) if csr is not None else None
             wgt = ops.slot_weights(geom)
         self.last_knn_index = (idx, idx_q)

@@ -1476,8 +1476,17 @@ def mask_weight_slots(wf, geom, join=None):
     return _MaskWeightSlots.apply(wf, geom, join)
 
 
-def conv3d_select(geom, stride):
-    """top-9 neighbour ids per output pixel (tl,bs,ho,wo,9) uint8; depends on the geometry only."""
+# DIS_CONV3D_CSR=1: Conv3D feature gradient as a fixed-order gather (bitwise reproducible) instead of the float-atomic scatter.
+# Off by default: measured on MI355X it costs 1.0 ms of the 42 ms DIS-MF step (3.04 + 0.37 ms build vs 2.41 ms; 369 vs 378
+# frames/s) - the scatter is 9 whole 128-byte rows per output pixel, which L2 atomics handle at the rate of the plain traffic
+# the staged form needs.
+CONV3D_CSR = _os.environ.get('DIS_CONV3D_CSR', '0') == '1'
+
+
+def conv3d_select(geom, stride, with_csr=False):
+    """top-9 neighbour ids per output pixel (tl,bs,ho,wo,9) uint8; depends on the geometry only.
+    with_csr: also build the by-source-row index of the sets (idx.c3csr) that makes the Conv3D feature gradient a fixed-order
+    gather instead of a float-atomic scatter; shared by every layer that uses the sets."""
     geom = _c(geom)
     _chk(geom)
     tl, bs, h, wd, s, _ = geom.shape
@@ -1485,7 +1494,21 @@ def conv3d_select(geom, stride):
     wo = (wd + 2 - 3) // stride + 1
     idx = torch.empty((tl, bs, ho, wo, 9), dtype=torch.uint8, device=geom.device)
     lib.call('dis_conv3d_knn_select', geom, idx, tl, bs, h, wd, stride)
+    if with_csr and CONV3D_CSR:
+        conv3d_csr(idx, h, wd, stride)
     return idx
+
+
+def conv3d_csr(idx, h, wd, stride):
+    """by-source-row CSR of the neighbour sets `idx` (tl,bs,ho,wo,9), attached to the tensor as idx.c3csr"""
+    tl, bs = idx.shape[0], idx.shape[1]
+    n = lib.fn('dis_conv3d_csr_workspace')(tl, bs, h, wd, stride)
+    if n < 0:
+        raise lib.DisHipError('conv3d csr: unsupported shape')
+    csr = torch.empty(n, dtype=torch.int32, device=idx.device)
+    lib.call('dis_conv3d_csr_build', idx, csr, tl, bs, h, wd, stride)
+    idx.c3csr = csr
+    return csr
 
 
 class _Conv3dKnn(torch.autograd.Function):
@@ -1504,6 +1527,7 @@ class _Conv3dKnn(torch.autograd.Function):
         ctx.save_for_backward(geom, wf, d1w, d1b, d2w, d2b, w, idx, y)
         ctx.stride = stride
         ctx.join = join
+        ctx.c3csr = getattr(idx, 'c3csr', None)
         return y
 
     @staticmethod
@@ -1512,12 +1536,20 @@ class _Conv3dKnn(torch.autograd.Function):
         tl, bs, h, wd, s, c = wf.shape
         join = ctx.join
         second = join is not None and join.buf is not None
-        gwf = join.take(wf.shape) if second else torch.zeros_like(wf)  # the scatter accumulates (float atomics)
         sunk = _sink_block((w, d1w, d1b, d2w, d2b))  # the kernel's parameter-gradient block IS the flat buffer's order
         gp = sunk if sunk is not None else torch.empty(1632, dtype=torch.float32, device=wf.device)
         acc = torch.empty(lib.fn('dis_conv3d_knn_bwd_workspace')(), dtype=torch.float32, device=wf.device)
-        lib.call('dis_conv3d_knn_bwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, _c(gy), gwf, gp, acc, tl, bs, h, wd,
-                 ctx.stride)
+        if ctx.c3csr is not None:
+            # deterministic form: per-entry gradient rows staged, then summed per source row in list order
+            gwf = join.take(wf.shape) if second else torch.empty_like(wf)
+            stage = torch.empty(lib.fn('dis_conv3d_knn_bwd_stage')(tl, bs, h, wd, ctx.stride), dtype=torch.float32,
+                                device=wf.device)
+            lib.call('dis_conv3d_knn_bwd_csr', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, _c(gy), gwf, gp, acc, ctx.c3csr,
+                     stage, 1 if second else 0, tl, bs, h, wd, ctx.stride)
+        else:
+            gwf = join.take(wf.shape) if second else torch.zeros_like(wf)  # the scatter accumulates (float atomics)
+            lib.call('dis_conv3d_knn_bwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, _c(gy), gwf, gp, acc, tl, bs, h, wd,
+                     ctx.stride)
         if join is not None and not second:
             gwf = join.first(gwf)
         _sinks_written()

@@ -343,6 +343,19 @@ int dis_conv3d_knn_bwd(const float* geom, const float* wf, const float* dense1_w
                        const float* dense2_w, const float* dense2_b, const float* w, const unsigned char* idx,
                        const float* y, const float* gy, float* grad_wf, float* gparams, float* workspace, int tl,
                        int bs, int h, int wd, int stride, void* stream);
+/* The same with a DETERMINISTIC feature gradient (no float atomics: bitwise reproducible).  csr = dis_conv3d_csr_build(idx):
+ * the (output pixel, neighbour) entries of the neighbour sets grouped by the source row they selected, lists sorted by entry,
+ * dis_conv3d_csr_workspace(...) ints, built once per geometry and shared by every Conv3D layer that uses the sets.  stage:
+ * dis_conv3d_knn_bwd_stage(...) floats of scratch (the per-entry gradient rows).  accumulate = 0: grad_wf is written, rows
+ * nobody selected get zeros (no zero fill by the caller); 1: the selected rows are added to grad_wf's contents. */
+long dis_conv3d_csr_workspace(int tl, int bs, int h, int w, int stride);
+int dis_conv3d_csr_build(const unsigned char* idx, int* csr, int tl, int bs, int h, int w, int stride, void* stream);
+long dis_conv3d_knn_bwd_stage(int tl, int bs, int h, int wd, int stride);
+int dis_conv3d_knn_bwd_csr(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
+                           const float* dense2_w, const float* dense2_b, const float* w, const unsigned char* idx,
+                           const float* y, const float* gy, float* grad_wf, float* gparams, float* workspace,
+                           const int* csr, float* stage, int accumulate, int tl, int bs, int h, int wd, int stride,
+                           void* stream);
 
 /* ---------------------------------------------------------------- general convolution family (DIS-SF) */
 

@@ -303,6 +303,54 @@ def test_conv3d_golden(golden_dir, stride):
         assert relerr(pd[k_].grad, torch.from_numpy(G[f'c3_s{stride}_g:{k_}'])) < 1e-4, k_
 
 
+@pytest.mark.parametrize('stride', [1, 2])
+def test_conv3d_csr_feature_gradient(golden_dir, stride):
+    """The deterministic (CSR gather) form of the Conv3D feature gradient equals the float-atomic scatter to rounding, in both
+    modes (write / accumulate into a shared buffer), repeats bit for bit, and the golden gradient is met through it."""
+    from depthinspace_amd import ops
+    G = np.load(os.path.join(golden_dir, 'ops.npz'))
+    xyz, feat, mask = [torch.from_numpy(G[k]) for k in ('c3_xyz', 'c3_feat', 'c3_mask')]
+    tl, bs, C, h, w = feat.shape
+    p = O.init_params({k: v for k, v in O.mf_param_shapes().items() if k.startswith('blocks.0.conv3d_1')}, seed=5)
+    pd = {k[len('blocks.0.conv3d_1.'):]: v.detach().cuda() for k, v in p.items()}
+    g = torch.Generator().manual_seed(3)
+    geom1 = torch.cat([xyz, mask], dim=2).permute(1, 3, 4, 0, 2)
+    geom = geom1.unsqueeze(0).expand(tl, -1, -1, -1, -1, -1).contiguous().cuda()
+    wf = torch.randn(tl, bs, h, w, tl, C, generator=g).cuda()
+    idx = ops.conv3d_select(geom, stride)
+    ho, wo = idx.shape[2:4]
+    y = torch.empty((tl, bs, ho, wo, C), device='cuda')
+    args = (geom, wf, pd['dense1.0.weight'], pd['dense1.0.bias'], pd['dense2.0.weight'], pd['dense2.0.bias'], pd['w'], idx)
+    ops.lib.call('dis_conv3d_knn_fwd', *args, y, tl, bs, h, w, stride)
+    gy = torch.randn(y.shape, generator=g).cuda()
+    base = torch.randn(wf.shape, generator=g).cuda()
+    acc = torch.empty(ops.lib.fn('dis_conv3d_knn_bwd_workspace')(), device='cuda')
+    csr = ops.conv3d_csr(idx, h, w, stride)
+    stage = torch.empty(ops.lib.fn('dis_conv3d_knn_bwd_stage')(tl, bs, h, w, stride), device='cuda')
+    # atomic scatter on top of `base`
+    g_at, gp_at = base.clone(), torch.empty(1632, device='cuda')
+    ops.lib.call('dis_conv3d_knn_bwd', *args, y, gy, g_at, gp_at, acc, tl, bs, h, w, stride)
+    outs = []
+    for rep in range(2):
+        g_acc, gp = base.clone(), torch.empty(1632, device='cuda')
+        ops.lib.call('dis_conv3d_knn_bwd_csr', *args, y, gy, g_acc, gp, acc, csr, stage, 1, tl, bs, h, w, stride)
+        g_wr = torch.full(wf.shape, float('nan'), device='cuda')   # write mode must define every row
+        ops.lib.call('dis_conv3d_knn_bwd_csr', *args, y, gy, g_wr, gp, acc, csr, stage, 0, tl, bs, h, w, stride)
+        outs.append((g_acc, g_wr, gp))
+    g_acc, g_wr, gp = outs[0]
+    scale = float((g_at - base).abs().max())
+    assert scale > 0 and float((g_acc - g_at).abs().max()) < 2e-6 * scale
+    assert bool(torch.isfinite(g_wr).all()) and float((g_wr - (g_at - base)).abs().max()) < 4e-6 * scale
+    assert relerr(gp, gp_at) < 1e-6
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # bitwise reproducible
+    # every entry whose source pixel exists is in exactly one list
+    nsrc = tl * bs * h * w * 4
+    offs = csr[:nsrc + 1].cpu().numpy()
+    ents = csr[2 * nsrc + 1: 2 * nsrc + 1 + offs[-1]].cpu().numpy()
+    assert len(np.unique(ents)) == len(ents) and ents.max() < tl * bs * ho * wo * 9
+    assert all(np.all(np.diff(ents[offs[d]:offs[d + 1]]) > 0) for d in np.flatnonzero(np.diff(offs) > 1)[:2000])
+
+
 def test_disp_head():
     from depthinspace_amd import ops
     g = torch.Generator().manual_seed(2)
