@@ -54,6 +54,30 @@ def run_hip_step(G, force_reference_knn=False):
 MF_GOLDENS = ['mf_64_bs1', 'mf_64_bs2_rnd', 'mf_128_bs1', 'mf_128_bumps']
 
 
+def test_mf_step_with_deterministic_conv3d_gradient(golden_dir):
+    """DIS_CONV3D_CSR=1 (Conv3D feature gradient as a fixed-order gather, both the write and the shared-buffer accumulate form inside
+    the real network): same gradients as the default float-atomic form, and the step repeats with smaller run-to-run noise."""
+    from depthinspace_amd import ops
+    G = np.load(os.path.join(golden_dir, 'mf_64_bs2_rnd.npz'))
+    assert not ops.CONV3D_CSR
+    _, opt_a, errs_a, out_a = run_hip_step(G)
+    ga = opt_a.flat_g.clone()
+    ops.CONV3D_CSR = True
+    try:
+        net, opt_c, errs_c, out_c = run_hip_step(G)
+        gc1 = opt_c.flat_g.clone()
+        assert getattr(net.last_knn_index[0], 'c3csr', None) is not None and getattr(net.last_knn_index[1], 'c3csr', None) is not None
+        _, opt_c2, _, _ = run_hip_step(G)
+        gc2 = opt_c2.flat_g.clone()
+    finally:
+        ops.CONV3D_CSR = False
+    assert torch.equal(out_a, out_c)   # forward untouched
+    scale = float(ga.abs().max())
+    assert float((gc1 - ga).abs().max()) < 2e-6 * scale
+    # (what is left of the run-to-run noise comes from the geometric-loss depth scatter)
+    assert float((gc1 - gc2).abs().max()) <= 2e-6 * scale
+
+
 @pytest.mark.parametrize('name', MF_GOLDENS)
 def test_mf_step_matches_reference(golden_dir, name):
     """FREE-RUNNING: nothing from the oracle or the goldens is injected into the HIP step."""
