@@ -49,6 +49,63 @@ extern "C" int dis_act_bwd_ld(const float* gy, int ldg, const float* y, int ldy,
   return DIS_OK;
 }
 
+// dis_act_bwd_ld that also leaves the bias gradient (column sums of gpre) behind: one pass over the gradient tensor instead of two.
+// c / 4 divides 256: a thread keeps its 4 channels while it walks down the pixels; per-block fp32 partials, fp64 totals.
+#define ABB_BLOCKS 1024
+__global__ __launch_bounds__(256) void act_bwd_ld_bias_kernel(const float* __restrict__ gy, int ldg, const float* __restrict__ y,
+                                                               int ldy, float4* __restrict__ gp, int act, long npix, int c4,
+                                                               float* __restrict__ part) {
+  __shared__ float red[1024];
+  const int chunk = threadIdx.x % c4, rows = 256 / c4, row = threadIdx.x / c4, q = chunk * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long px = (long)blockIdx.x * rows + row; px < npix; px += (long)gridDim.x * rows) {
+    float4 o = *(const float4*)(gy + px * ldg + q);
+    if (act != DIS_ACT_NONE) {
+      const float4 v = *(const float4*)(y + px * ldy + q);
+      o.x *= act_grad_from_out(v.x, act), o.y *= act_grad_from_out(v.y, act);
+      o.z *= act_grad_from_out(v.z, act), o.w *= act_grad_from_out(v.w, act);
+    }
+    gp[px * c4 + chunk] = o;
+    s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
+  }
+  *(float4*)(red + threadIdx.x * 4) = s;
+  __syncthreads();
+  const int c = c4 * 4;
+  for (int t = threadIdx.x; t < c; t += 256) {
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc += red[(r * c4 + (t >> 2)) * 4 + (t & 3)];
+    part[(long)blockIdx.x * c + t] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void act_bias_final_kernel(const float* __restrict__ part, int nblocks, int c,
+                                                              float* __restrict__ out) {
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ch >= c) return;
+  double s = 0.0;
+  for (int k = lane; k < nblocks; k += 64) s += (double)part[(long)k * c + ch];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  if (lane == 0) out[ch] = (float)s;
+}
+extern "C" long dis_act_bwd_ld_bias_workspace(int c) { return c > 0 ? (long)ABB_BLOCKS * c : -1; }
+extern "C" int dis_act_bwd_ld_bias(const float* gy, int ldg, const float* y, int ldy, float* gpre, int act, long npix, int c,
+                                   float* bias_grad, float* workspace, void* stream) {
+  if (!gy || !gpre || !bias_grad || !workspace || (act != DIS_ACT_NONE && !y)) return DIS_ERR_NULL;
+  if (npix <= 0 || c <= 0 || ldg < c || (act != DIS_ACT_NONE && ldy < c)) return DIS_ERR_BAD_SHAPE;
+  if ((c & 3) || (ldg & 3) || (ldy & 3) || ((uintptr_t)gy & 15) || ((uintptr_t)y & 15) || c > 1024 || 256 % (c / 4))
+    return DIS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int rows = 256 / (c / 4);
+  long nb = (npix + rows - 1) / rows;
+  if (nb > ABB_BLOCKS) nb = ABB_BLOCKS;
+  hipLaunchKernelGGL(act_bwd_ld_bias_kernel, dim3((unsigned)nb), dim3(256), 0, s, gy, ldg, y ? y : gy, ldy, (float4*)gpre, act,
+                     npix, c / 4, workspace);
+  hipLaunchKernelGGL(act_bias_final_kernel, dim3(dis_cdiv(c, 4)), dim3(256), 0, s, (const float*)workspace, (int)nb, c,
+                     bias_grad);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 // dst[pixel * ldd + j] = src[pixel * lds + j] for j < c, 0 for c <= j < c + czero: writes a tensor into a channel range
 // of a wider nhwc buffer (the up-sampled disparity channel of the DispNetS concatenations and the zero lanes that pad
 // them to a multiple of 4 channels) without an ATen in-place op on the buffer.

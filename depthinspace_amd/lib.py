@@ -67,6 +67,8 @@ SIGS = {
     'dis_disp_head_bwd_workspace': 'iiii',
     'dis_act_bwd': 'pppilp',
     'dis_act_bwd_ld': 'pipipilip',
+    'dis_act_bwd_ld_bias_workspace': 'i',
+    'dis_act_bwd_ld_bias': 'pipipilippp',
     'dis_copy_channels': 'pipiliip',
     'dis_gn_stats': 'ppilp',
     'dis_gn_apply': 'ppppppiliifp',
@@ -105,7 +107,7 @@ SIGS = {
     'dis_adam_step_dev': 'pppplfddfpfp',
 }
 _RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
-             'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_conv3d_knn_bwd_stage', 'dis_conv3d_csr_workspace', 'dis_gather_csr_workspace',
+             'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_act_bwd_ld_bias_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_conv3d_knn_bwd_stage', 'dis_conv3d_csr_workspace', 'dis_gather_csr_workspace',
              'dis_conv2d_pack_bf16x3_size', 'dis_disp_head_bwd_workspace'}
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float, 'd': ctypes.c_double}

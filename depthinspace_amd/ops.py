@@ -1028,10 +1028,22 @@ class _ConvG(torch.autograd.Function):
         _, hout, wout, cout = gy.shape
         k = weight.shape[2]
         cin_w = weight.shape[0] if transposed else weight.shape[1]
+        # (shapes whose weight gradient runs on the one-pass kernels of conv2d.hip get their bias gradient from that pass)
+        onepass = (not transposed and x.is_contiguous()
+                   and lib.fn('dis_conv2d_wgrad_workspace')(cin_mem, cout, k, stride) >= 0)
+        gb, gb_ret = _sink_opt(ctx.bias_ref)
+        gb_done = False
         if act != ACT_NONE or not gy.is_contiguous():
             # (gy / y may be channel ranges of wider buffers: the gradient of a concatenation, an output written into one)
             gpre = torch.empty(gy.shape, dtype=torch.float32, device=gy.device)
-            if gy.is_contiguous() and (y is None or y.is_contiguous()):
+            if has_bias and not onepass and cout <= 1024 and 256 % (cout // 4) == 0 and gy.data_ptr() % 16 == 0 \
+                    and (y is None or y.data_ptr() % 16 == 0):
+                # activation gradient and bias gradient from one pass over gy
+                gb_done = True
+                ws = torch.empty(lib.fn('dis_act_bwd_ld_bias_workspace')(cout), dtype=torch.float32, device=gy.device)
+                lib.call('dis_act_bwd_ld_bias', gy, _ld(gy), y, _ld(y) if y is not None else 0, gpre, act, n * hout * wout,
+                         cout, gb, ws)
+            elif gy.is_contiguous() and (y is None or y.is_contiguous()):
                 lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
             else:
                 lib.call('dis_act_bwd_ld', gy, _ld(gy), y, _ld(y) if y is not None else 0, gpre, act, n * hout * wout, cout)
@@ -1048,16 +1060,14 @@ class _ConvG(torch.autograd.Function):
         else:
             # shapes whose whole (tap, cin) x cout accumulator fits a workgroup's registers go through the one-pass kernels
             # of conv2d.hip (x and gy are read once instead of once per tap; the bias gradient comes out of the same pass)
-            wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin_mem, cout, k, stride)
-            if wsz >= 0 and gpre.shape[-1] == cout and x.is_contiguous():
+            if onepass:
+                wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin_mem, cout, k, stride)
                 ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
-                gb, gb_ret = _sink_opt(ctx.bias_ref)
                 _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_mem, cin_w, cout, k, stride, pad)
                 _sinks_written()
                 return gx, gw_ret, gb_ret, None, None, None, None, None, None, None
             _convg_wgrad(x, hin, win, cin_mem, cin_w, gpre, hout, wout, cout, cout, gw, n, k, stride, pad)
-        gb, gb_ret = _sink_opt(ctx.bias_ref)
-        if has_bias:
+        if has_bias and not gb_done:
             _colsum(gpre, cout, out=gb)
         _sinks_written()
         return gx, gw_ret, gb_ret, None, None, None, None, None, None, None

@@ -283,6 +283,11 @@ int dis_act_bwd(const float* gy, const float* y, float* gpre, int act, long coun
  * output lives inside a decoder concatenation buffer (the reference concatenates with torch.cat, networks.py:262-288). */
 int dis_act_bwd_ld(const float* gy, int ldg, const float* y, int ldy, float* gpre, int act, long npix, int c,
                    void* stream);
+/* dis_act_bwd_ld + the bias gradient bias_grad[ch] = sum_pixels gpre[pixel][ch] from the same pass (fp32 block partials, fp64
+   totals, fixed order); workspace: dis_act_bwd_ld_bias_workspace(c) floats; c / 4 must divide 256, else DIS_ERR_UNSUPPORTED */
+long dis_act_bwd_ld_bias_workspace(int c);
+int dis_act_bwd_ld_bias(const float* gy, int ldg, const float* y, int ldy, float* gpre, int act, long npix, int c,
+                        float* bias_grad, float* workspace, void* stream);
 /* dst[pixel*ldd + j] = src[pixel*lds + j] for j < c and 0 for c <= j < c + czero: a tensor written into a channel range
  * of a wider nhwc buffer, followed by czero zero lanes (the padding of a concatenation to a multiple of 4 channels). */
 int dis_copy_channels(const float* src, int lds, float* dst, int ldd, long npix, int c, int czero, void* stream);
