@@ -2080,20 +2080,27 @@ extern "C" int dis_conv2d_wgrad_scaled(const float* x, const float* xscale, cons
 // ------------------------------------------------------------------------------------------------
 // disparity head: Conv2d(cin,1,3,pad 1) + alpha*sigmoid(x-offset)  (bandwidth-bound, VALU)
 // ------------------------------------------------------------------------------------------------
+// One thread per (pixel, 4-channel group): consecutive lanes read consecutive 16-byte pieces of a pixel's channel line (one
+// thread per pixel read 16 bytes every CIN * 4: a quarter of every sector used), the CIN / 4 partial dot products of a pixel are
+// folded with xor-shuffles.
 template <int CIN>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                 const float* __restrict__ b, float* __restrict__ y, int n, int h, int wd,
                                 float alpha, float offset) {
-  __shared__ float ws[9 * CIN];
+  constexpr int NQ = CIN / 4;
+  __shared__ float4 ws[9 * NQ];
   for (int i = threadIdx.x; i < 9 * CIN; i += blockDim.x) {
     const int tap = i / CIN, ci = i % CIN;
-    ws[i] = w[ci * 9 + tap];  // (1,cin,3,3) -> [tap][ci]
+    ((float*)ws)[i] = w[ci * 9 + tap];  // (1,cin,3,3) -> [tap][ci]
   }
   __syncthreads();
-  const long total = (long)n * h * wd;
+  const int quad = threadIdx.x % NQ;
+  const float bias = b[0] - offset;
+  const long total = (long)n * h * wd * NQ;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % wd), py = (int)((i / wd) % h);
-    const long nb = i / ((long)h * wd);
+    const long q = i / NQ;
+    const int px = (int)(q % wd), py = (int)((q / wd) % h);
+    const long nb = q / ((long)h * wd);
     float acc = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -2103,17 +2110,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = px + kx - 1;
         if (ix < 0 || ix >= wd) continue;
-        const float4* p = (const float4*)(x + ((nb * h + iy) * wd + ix) * CIN);
-        const float* wt = ws + (ky * 3 + kx) * CIN;
-#pragma unroll
-        for (int v = 0; v < CIN / 4; ++v) {
-          const float4 q = p[v];
-          acc += q.x * wt[v * 4] + q.y * wt[v * 4 + 1] + q.z * wt[v * 4 + 2] + q.w * wt[v * 4 + 3];
-        }
+        const float4 v = *(const float4*)(x + ((nb * h + iy) * wd + ix) * CIN + quad * 4);
+        const float4 wt = ws[(ky * 3 + kx) * NQ + quad];
+        acc += (v.x * wt.x + v.y * wt.y) + (v.z * wt.z + v.w * wt.w);
       }
     }
-    const float z = acc + b[0] - offset;
-    y[i] = alpha / (1.f + expf(-z));
+#pragma unroll
+    for (int off = NQ / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (quad == 0) y[q] = alpha / (1.f + expf(-(acc + bias)));
   }
 }
 
@@ -2213,7 +2217,7 @@ extern "C" int dis_disp_head_fwd(const float* x, const float* w, const float* b,
                                  int cin, float alpha, float offset, void* stream) {
   if (!x || !w || !b || !y) return DIS_ERR_NULL;
   if (n <= 0 || h <= 0 || wd <= 0) return DIS_ERR_BAD_SHAPE;
-  const dim3 grid(dis_ew_grid((long)n * h * wd, 256));
+  const dim3 grid(dis_ew_grid((long)n * h * wd * (cin / 4), 256));
   if (cin == 16) hipLaunchKernelGGL(head_fwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, n, h, wd, alpha, offset);
   else if (cin == 32) hipLaunchKernelGGL(head_fwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, n, h, wd, alpha, offset);
   else return DIS_ERR_UNSUPPORTED;
