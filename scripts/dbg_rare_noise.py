@@ -1,0 +1,68 @@
+"""Diagnostic: evaluate the same DIS-MF step N times in one process and list the passes whose gradient deviates from the first
+by more than rounding noise (which parameters, how much; also the forward output and the loss terms)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from depthinspace_amd import synth
+from depthinspace_amd.model import multi_frame_networks, multi_frame_worker, single_frame_worker, networks
+from depthinspace_amd.trainer import FlatAdam
+
+
+def main():
+    arch = sys.argv[1] if len(sys.argv) > 1 else 'multi_frame'
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+    H = W = 64
+    args = argparse.Namespace(use_pseudo_gt=False, lcn_radius=5, track_length=4, data_type='synthetic', architecture=arch,
+                              epochs=1, warmup_epochs=150, train_batch_size=1, max_disp=128)
+    settings = synth.make_settings(H, W)
+    torch.manual_seed(0)
+    if arch == 'multi_frame':
+        w = multi_frame_worker.Worker(args, settings=settings)
+        net = multi_frame_networks.FuseNet((H, W), settings.K, settings.baseline).cuda()
+    else:
+        w = single_frame_worker.Worker(args, settings=settings)
+        net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=w.imsizes).cuda()
+    w.build_losses()
+    w.current_epoch = 2
+    opt = FlatAdam(net.parameters(), lr=1e-4)
+    batches = [{k: torch.from_numpy(v) for k, v in synth.make_batch(settings, 1, 4, seed=1234 + r).items()} for r in range(2)]
+    names = [n for n, _ in net.named_parameters()]
+    ref = {}
+    nbad = 0
+    for it in range(N):
+        b = it % 2
+        w.copy_data(batches[b], device=w.train_device, requires_grad=False, train=True)
+        opt.zero_grad()
+        flow = w.read_optical_flow(True)
+        out = w.net_forward(net, flow)
+        losses = w.loss_forward(out, True, flow)
+        sum(losses).backward()
+        g = opt.flat_g.clone()
+        o = (out[0] if isinstance(out, (list, tuple)) else out).detach().clone()
+        lv = torch.stack([l.detach() for l in losses]).clone()
+        if b not in ref:
+            ref[b] = (g, o, lv)
+            continue
+        g0, o0, l0 = ref[b]
+        e = float((g - g0).abs().max()) / float(g0.abs().max())
+        if e > 2e-6:
+            nbad += 1
+            rows = []
+            for n_, p_, off in zip(names, opt.params, opt.offsets):
+                sl = slice(off, off + p_.numel())
+                d = float((g[sl] - g0[sl]).abs().max()) / float(g0.abs().max())
+                if d > 1e-6:
+                    rows.append((d, n_))
+            rows.sort(reverse=True)
+            print(f'pass {it} (batch {b}): grad dev {e:.2e}; out dev {float((o - o0).abs().max()):.2e}; loss dev '
+                  f'{float((lv - l0).abs().max()):.2e}; {len(rows)} params > 1e-6; worst: '
+                  + ', '.join(f'{n_}={d:.1e}' for d, n_ in rows[:8]), flush=True)
+    print(f'{arch}: {nbad} deviating passes of {N}')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,42 @@
+"""Diagnostic: dis_conv2d_fwd_scaled (1x1, 128 -> 32, GroupNorm statistics in the epilogue) repeated on fixed inputs while other
+processes share the GPU: do y and the statistics repeat?"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from depthinspace_amd import ops
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    g = torch.Generator().manual_seed(3)
+    n, h, w, cin, cout = 4, 32, 32, 128, 32
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    xs = torch.rand(n, h, w, cin // 32, generator=g).cuda()
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) * 0.1).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    filler = torch.randn(1 << 20, device='cuda')
+    ref = None
+    bad = 0
+    with torch.no_grad():
+        for it in range(N):
+            y, st = ops.conv2d_scaled_in(x, xs, wt, b, 1, 0, want_stats=True)
+            if it % 3 == 0:
+                filler = filler * 1.0000001   # unrelated work in between
+            y, st = y.clone(), st.clone()
+            if ref is None:
+                torch.cuda.synchronize()
+                ref = (y, st)
+                continue
+            if it % 50 == 49 or it == N - 1:
+                torch.cuda.synchronize()
+            if not torch.equal(st, ref[1]) or not torch.equal(y, ref[0]):
+                bad += 1
+                if bad <= 6:
+                    print(f'iter {it}: y equal {bool(torch.equal(y, ref[0]))}; stats diff {(st - ref[1]).tolist()}', flush=True)
+    print(f'{bad} deviating iterations of {N}')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,57 @@
+"""Diagnostic (continued): the same kernel call with the statistics buffer zeroed in different ways."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from depthinspace_amd import ops, lib
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    g = torch.Generator().manual_seed(3)
+    n, h, w, cin, cout = 4, 32, 32, 128, 32
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    xs = torch.rand(n, h, w, cin // 32, generator=g).cuda()
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) * 0.1).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    pw = ops._pack_w(wt, cin, 0)
+    zero_const = torch.zeros(8, dtype=torch.float64, device='cuda')
+    one = torch.ones(8, dtype=torch.float64, device='cuda')
+    filler = torch.randn(1 << 20, device='cuda')
+    bad = {}
+    ref = None
+    NB = 2048 * 256
+    kinds = {'atomic_lost': 0, 'partial_wrong': 0, 'both': 0}
+    st = torch.zeros(8 + 2 * NB, dtype=torch.float64, device='cuda')
+    for it in range(N):
+        y = torch.empty((n, h, w, cout), device='cuda')
+        st.zero_()
+        lib.call('dis_conv2d_fwd_scaled', x, xs, pw, b, y, None, st, n, h, w, cin, cout, 1, 1, 0, ops.ACT_NONE)
+        if it % 3 == 0:
+            filler = filler * 1.0000001
+        stc = st.clone()
+        if ref is None:
+            torch.cuda.synchronize()
+            ref = stc
+            continue
+        if it % 50 == 49:
+            torch.cuda.synchronize()
+        d_at = float((stc[:8] - ref[:8]).abs().max())
+        d_sl = float((stc[8:] - ref[8:]).abs().max())
+        if d_at > 1e-6 or d_sl > 1e-9:
+            k = 'both' if (d_at > 1e-6 and d_sl > 1e-9) else ('atomic_lost' if d_at > 1e-6 else 'partial_wrong')
+            kinds[k] += 1
+            if sum(kinds.values()) <= 4:
+                nz = (stc[8:] - ref[8:]).abs() > 1e-9
+                print(f'iter {it}: atomics diff {d_at:.3e}; slab diff {d_sl:.3e} in {int(nz.sum())} entries '
+                      f'(lanes (wg, lane) {[(int(i) // 512, (int(i) // 2) % 256) for i in nz.nonzero().flatten()[:10]]}); slab-sum vs atomics: '
+                      f'{(stc[8:].view(-1, 2).sum(0)).tolist()} vs {stc[:8].view(-1, 2).sum(0).tolist()}; '
+                      f'values got/ref {[(float(stc[8:][i]), float(ref[8:][i])) for i in nz.nonzero().flatten()[:4]]}', flush=True)
+    print('kinds:', kinds, 'of', N)
+    return
+    print('deviating iterations per zeroing mode:', bad, 'of', N)
+
+
+if __name__ == '__main__':
+    main()
