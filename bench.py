@@ -371,6 +371,7 @@ def main():
         }
         print(json.dumps(res))
     if world > 1:
+        barrier()   # rank 0 ran the per-call roofline leg on its own: leave together
         torch.distributed.destroy_process_group()
 
 

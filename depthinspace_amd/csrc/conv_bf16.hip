@@ -1319,30 +1319,53 @@ extern "C" int dis_act_bwd_bf16(const void* gy, int ldg, const void* y, int ldy,
 // dis_act_bwd_bf16 that also leaves the bias gradient (column sums of the unrounded gpre) behind: the gradient tensor is read
 // once for both.  c / 4 divides 256: a thread keeps its 4 channels while it walks down the pixels.
 #define CSB_BLOCKS 1024
+// V = channels per thread: 8 (16-byte vectors; c, ldg, ldy multiples of 8 and 16-byte aligned pointers) or 4
+template <int V>
 __global__ __launch_bounds__(256) void act_bwd_bf16_bias_kernel(const bf16_t* __restrict__ gy, int ldg,
                                                                  const bf16_t* __restrict__ y, int ldy,
-                                                                 bf16_t* __restrict__ gp, int act, long npix, int c4,
+                                                                 bf16_t* __restrict__ gp, int act, long npix, int cv,
                                                                  float* __restrict__ part) {
-  __shared__ float red[1024];
-  const int chunk = threadIdx.x % c4, rows = 256 / c4, row = threadIdx.x / c4, q = chunk * 4;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  __shared__ float red[256 * V];
+  const int chunk = threadIdx.x % cv, rows = 256 / cv, row = threadIdx.x / cv, q = chunk * V;
+  float s[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) s[j] = 0.f;
+  const int c = cv * V;
   for (long px = (long)blockIdx.x * rows + row; px < npix; px += (long)gridDim.x * rows) {
-    const uint2 g = *(const uint2*)(gy + px * ldg + q);
-    float4 o = make_float4(cb_lo(g.x), cb_hi(g.x), cb_lo(g.y), cb_hi(g.y));
-    if (act != DIS_ACT_NONE) {
-      const uint2 v = *(const uint2*)(y + px * ldy + q);
-      o.x *= act_grad_from_out(cb_lo(v.x), act), o.y *= act_grad_from_out(cb_hi(v.x), act);
-      o.z *= act_grad_from_out(cb_lo(v.y), act), o.w *= act_grad_from_out(cb_hi(v.y), act);
+    unsigned g[V / 2], v[V / 2], o[V / 2];
+    if (V == 8) {
+      const uint4 t = *(const uint4*)(gy + px * ldg + q);
+      g[0] = t.x, g[1] = t.y, g[V / 2 - 2] = t.z, g[V / 2 - 1] = t.w;
+    } else {
+      const uint2 t = *(const uint2*)(gy + px * ldg + q);
+      g[0] = t.x, g[1] = t.y;
     }
-    *(uint2*)(gp + (px * c4 + chunk) * 4) = make_uint2(cb_pack2(o.x, o.y), cb_pack2(o.z, o.w));
-    s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
+    if (act != DIS_ACT_NONE) {
+      if (V == 8) {
+        const uint4 t = *(const uint4*)(y + px * ldy + q);
+        v[0] = t.x, v[1] = t.y, v[V / 2 - 2] = t.z, v[V / 2 - 1] = t.w;
+      } else {
+        const uint2 t = *(const uint2*)(y + px * ldy + q);
+        v[0] = t.x, v[1] = t.y;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V / 2; ++j) {
+      float a = cb_lo(g[j]), b = cb_hi(g[j]);
+      if (act != DIS_ACT_NONE) a *= act_grad_from_out(cb_lo(v[j]), act), b *= act_grad_from_out(cb_hi(v[j]), act);
+      s[2 * j] += a;
+      s[2 * j + 1] += b;
+      o[j] = cb_pack2(a, b);
+    }
+    if (V == 8) *(uint4*)(gp + px * c + q) = make_uint4(o[0], o[1], o[V / 2 - 2], o[V / 2 - 1]);
+    else *(uint2*)(gp + px * c + q) = make_uint2(o[0], o[1]);
   }
-  *(float4*)(red + threadIdx.x * 4) = s;
+#pragma unroll
+  for (int j = 0; j < V; ++j) red[threadIdx.x * V + j] = s[j];
   __syncthreads();
-  const int c = c4 * 4;
   for (int t = threadIdx.x; t < c; t += 256) {
     float acc = 0.f;
-    for (int r = 0; r < rows; ++r) acc += red[(r * c4 + (t >> 2)) * 4 + (t & 3)];
+    for (int r = 0; r < rows; ++r) acc += red[(r * cv + t / V) * V + t % V];
     part[(long)blockIdx.x * c + t] = acc;
   }
 }
@@ -1428,8 +1451,19 @@ extern "C" int dis_act_bwd_bf16_bias(const void* gy, int ldg, const void* y, int
   const int rows = 256 / (c / 4);
   long nb = (npix + rows - 1) / rows;
   if (nb > CSB_BLOCKS) nb = CSB_BLOCKS;
-  hipLaunchKernelGGL(act_bwd_bf16_bias_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)gy, ldg,
-                     (const bf16_t*)(y ? y : gy), ldy, (bf16_t*)gpre, act, npix, c / 4, workspace);
+  const bool v8 = !(c & 7) && !(ldg & 7) && !(ldy & 7) && !((uintptr_t)gy & 15) && !((uintptr_t)y & 15) &&
+                  !((uintptr_t)gpre & 15) && 256 % (c / 8) == 0;
+  if (v8) {
+    const int rows8 = 256 / (c / 8);
+    long nb8 = (npix + rows8 - 1) / rows8;
+    if (nb8 > CSB_BLOCKS) nb8 = CSB_BLOCKS;
+    nb = nb8;
+    hipLaunchKernelGGL(act_bwd_bf16_bias_kernel<8>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)gy, ldg,
+                       (const bf16_t*)(y ? y : gy), ldy, (bf16_t*)gpre, act, npix, c / 8, workspace);
+  } else {
+    hipLaunchKernelGGL(act_bwd_bf16_bias_kernel<4>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)gy, ldg,
+                       (const bf16_t*)(y ? y : gy), ldy, (bf16_t*)gpre, act, npix, c / 4, workspace);
+  }
   hipLaunchKernelGGL(colsum_bf16_final_kernel, dim3(dis_cdiv(c, 4)), dim3(256), 0, s, (const float*)workspace, (int)nb, c,
                      bias_grad);
   DIS_CHECK_LAUNCH();
