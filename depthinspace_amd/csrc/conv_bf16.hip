@@ -49,6 +49,7 @@ struct GenArgsB {
   // halo form (convb_halo_kernel): first tap offsets, halo extent, LDS pixel stride, taps per k-step, k-steps, k-steps per
   // weight group, tile grid
   int dy0, dx0, HR, HC, PS, TP, nks, GT, tiles_x, tiles_y;
+  int trh;         // tile rows: 8 (2 per wave) or 16 (4 per wave)
   int res, wsz16;  // weights of a cout block resident in LDS (all chunks); 16-bit words of the weight region in front of the halo
 };
 
@@ -395,9 +396,11 @@ __global__ void convb_pack_kernel(PackArgsB a) {
 // Persistent workgroups: a unit = (tile, cout block); the units of an XCD's share are walked with a grid stride, and the halo
 // of the NEXT stage (next 32-channel chunk, or the next unit's first) is fetched into registers (NH 16-byte items per thread)
 // while the current stage's MFMAs run; pixels outside the image / channels past cin get an out-of-range buffer offset (zeros).
-template <int BN, bool XB, bool YB, int NH>
+// MT = output rows per wave: 2 (8 x 16 tiles), or 4 (16 x 16 tiles: twice the MFMAs per streamed weight group and a smaller halo
+// overhead - the layers whose weights do not stay resident, 7x7 / 5x5 taps)
+template <int BN, bool XB, bool YB, int NH, int MT>
 __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
-  constexpr int NT = BN / 16;
+  constexpr int NT = BN / 16, TRH = 4 * MT;
   extern __shared__ __attribute__((aligned(16))) unsigned short hsm[];
   int* toff = (int*)hsm;                     // 64 ints
   const int bsz = a.GT * 4 * BN * 8;         // 16-bit words of one weight buffer
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
 
   const int gpt = 4 / a.TP;  // lane groups per tap
   const int lgq = lg / gpt, cg = lg - lgq * gpt;
-  const int a_lane = (wave * 2 * a.S * HC + li * a.S) * PS + cg * 8;
+  const int a_lane = (wave * MT * a.S * HC + li * a.S) * PS + cg * 8;
   const int rowstep = a.S * HC * PS;
   const u32x4* wq = (const u32x4*)a.w;  // packed [chunk][nb][kstep][lg][BN][8]
   const int ngrp = (a.nks + a.GT - 1) / a.GT;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y, nn = t / a.tiles_y;
-    const int iy0 = ty * CBH_TR * a.S + a.dy0, ix0 = tx * CBH_TC * a.S + a.dx0;
+    const int iy0 = ty * TRH * a.S + a.dy0, ix0 = tx * CBH_TC * a.S + a.dx0;
     const long sbase = (long)nn * a.hin * a.win;
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
@@ -491,28 +494,28 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
     }
   };
 
-  f32x4 acc[2][NT], bias_v[NT];
+  f32x4 acc[MT][NT], bias_v[NT];
   int bias_nb = -1;
   // k-steps [0, kn) of a weight block B ([kstep][lg][BN][8]) whose tap offsets start at tq: software-pipelined by hand (a
   // runtime trip count: the compiler does not) - the operands of k-step kk+1 are requested before the MFMAs of kk issue, its
   // tap offset one step earlier still
   auto ksteps = [&](const unsigned short* B, const int* tq, int kn) __attribute__((always_inline)) {
     const unsigned short* bl = B + (lg * BN + li) * 8;
-    auto frag = [&](int kk, int to, s16x8 (&fa)[2], s16x8 (&fb)[NT]) __attribute__((always_inline)) {
+    auto frag = [&](int kk, int to, s16x8 (&fa)[MT], s16x8 (&fb)[NT]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) fa[mt] = *(const s16x8*)(halo + a_lane + mt * rowstep + to);
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = *(const s16x8*)(halo + a_lane + mt * rowstep + to);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) fb[nt] = *(const s16x8*)(bl + (kk * 4 * BN + nt * 16) * 8);
     };
-    auto mac = [&](const s16x8 (&fa)[2], const s16x8 (&fb)[NT]) __attribute__((always_inline)) {
+    auto mac = [&](const s16x8 (&fa)[MT], const s16x8 (&fb)[NT]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[nt]),
                                                                __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
     };
-    s16x8 fa0[2], fb0[NT], fa1[2], fb1[NT];
+    s16x8 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
     int to0 = tq[0], to1 = kn > 1 ? tq[a.TP] : 0;
     frag(0, to0, fa0, fb0);
     for (int kk = 0; kk < kn; kk += 2) {
@@ -546,7 +549,9 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
   };
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = acc[1][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
   // epilogue: lane (li, lg) holds couts nb*BN + nt*16 + lg*4 + {0..3} of position (ty*8 + wave*2 + mt, tx*16 + li)
   auto epilogue = [&](int uu, int nb) __attribute__((always_inline)) {
@@ -557,8 +562,8 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
     auto emit = [&](auto actc) __attribute__((always_inline)) {
       constexpr int ACT = decltype(actc)::value;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int vy = ty * CBH_TR + wave * 2 + mt, vx = tx * CBH_TC + li;
+      for (int mt = 0; mt < MT; ++mt) {
+        const int vy = ty * TRH + wave * MT + mt, vx = tx * CBH_TC + li;
         if (vy >= a.hv || vx >= a.wv) continue;
         const long pe = (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff;
 #pragma unroll
@@ -732,7 +737,8 @@ static bool cb_halo_plan(GenArgsB& a, int bn) {
     dx0 = a.tdx[t] < dx0 ? a.tdx[t] : dx0; dx1 = a.tdx[t] > dx1 ? a.tdx[t] : dx1;
   }
   a.dy0 = dy0; a.dx0 = dx0;
-  a.HR = (CBH_TR - 1) * a.S + (dy1 - dy0) + 1;
+  a.trh = CBH_TR;
+  a.HR = (a.trh - 1) * a.S + (dy1 - dy0) + 1;
   a.HC = (CBH_TC - 1) * a.S + (dx1 - dx0) + 1;
   a.TP = a.cin <= 8 ? 4 : (a.cin <= 16 ? 2 : 1);
   a.PS = a.TP == 1 ? 40 : 24;
@@ -741,19 +747,30 @@ static bool cb_halo_plan(GenArgsB& a, int bn) {
   a.GT = CBH_GVEC / (4 * bn);
   if (a.GT > a.nks) a.GT = a.nks;
   a.tiles_x = (a.wv + CBH_TC - 1) / CBH_TC;
-  a.tiles_y = (a.hv + CBH_TR - 1) / CBH_TR;
+  a.tiles_y = (a.hv + a.trh - 1) / a.trh;
   if ((long)a.HR * a.HC * ((a.PS - 8) / 8) > 12 * 256) return false;  // halo items per thread (register prefetch)
   // a cout block's weights (all chunks) stay in LDS when they fit next to the halo: no weight traffic, no group barriers
   const long wall = (long)a.nchunk * a.nks * 4 * bn * 16, hal = (long)a.HR * a.HC * a.PS * 2;
   a.res = (256 + wall + hal <= 75 * 1024) ? 1 : 0;  // (two resident workgroups per CU at least: one alone cannot hide its LDS latency)
   a.wsz16 = (int)((a.res ? wall : 2L * a.GT * 4 * bn * 16) / 2);
+  if (!a.res && a.hv >= 32) {
+    // streaming weights: 16 x 16 tiles when the larger halo still leaves two workgroups per CU and 12 prefetch items per thread
+    const int hr16 = 15 * a.S + (dy1 - dy0) + 1;
+    const long hal16 = (long)hr16 * a.HC * a.PS * 2;
+    static const bool no16 = getenv("DIS_CONVB_T16") && getenv("DIS_CONVB_T16")[0] == '0';
+    if (!no16 && 256 + 2L * a.wsz16 + hal16 <= 75 * 1024 && (long)hr16 * a.HC * ((a.PS - 8) / 8) <= 12 * 256) {
+      a.trh = 16;
+      a.HR = hr16;
+      a.tiles_y = (a.hv + 15) / 16;
+    }
+  }
   return cb_halo_lds(a, bn) <= 150 * 1024;
 }
 static long cb_halo_lds(const GenArgsB& a, int bn) { return 256 + 2L * a.wsz16 + (long)a.HR * a.HC * a.PS * 2; }
-template <int BN, bool XB, bool YB, int NH>
-static int cbh_launch2(const GenArgsB& a, long grid, long lds, hipStream_t s) {
+template <int BN, bool XB, bool YB, int NH, int MT>
+static int cbh_launch3(const GenArgsB& a, long grid, long lds, hipStream_t s) {
   static bool attr = false;
-  auto kern = convb_halo_kernel<BN, XB, YB, NH>;
+  auto kern = convb_halo_kernel<BN, XB, YB, NH, MT>;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));
     if (e != hipSuccess) return (int)e;
@@ -761,6 +778,11 @@ static int cbh_launch2(const GenArgsB& a, long grid, long lds, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, s, a);
   return DIS_OK;
+}
+template <int BN, bool XB, bool YB, int NH>
+static int cbh_launch2(const GenArgsB& a, long grid, long lds, hipStream_t s) {
+  if (a.trh == 16) return cbh_launch3<BN, XB, YB, NH, 4>(a, grid, lds, s);
+  return cbh_launch3<BN, XB, YB, NH, 2>(a, grid, lds, s);
 }
 template <int BN, bool XB, bool YB>
 static int cbh_launch1(const GenArgsB& a, int nh, long grid, long lds, hipStream_t s) {
