@@ -212,10 +212,12 @@ def main():
     kernel_ms = None
     if rank == 0:
         snap = [t.clone() for t in (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev)]
+        overlap, opt.overlap = opt.overlap, False   # rank-local leg: the gradient buckets must not start all-reduces here
         lib.profile_start()
-        fwd_bwd()                    # rank-local: no collective here (only rank 0 runs this leg)
+        fwd_bwd()                    # (only rank 0 runs this leg)
         opt.step(all_reduce=False)
         rec = lib.profile_stop()
+        opt.overlap = overlap
         for t, c in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev), snap):
             t.copy_(c)               # the profiled extra step is undone: replicas stay identical
         if args.dump_calls:
