@@ -1,6 +1,7 @@
 // GroupNorm(num_groups=1) and activation kernels, nhwc.  Bandwidth-bound elementwise / reduction work:
 // float4 per lane, per-sample statistics in fp64 (sum / sum of squares accumulated with fp64 atomics).
 #include "common.h"
+#include <stdlib.h>
 
 __global__ void act_bwd_kernel(const float4* __restrict__ gy, const float4* __restrict__ y, float4* __restrict__ gp,
                                int act, long count4) {
@@ -211,10 +212,29 @@ __device__ __forceinline__ void gn_moments(const double* stats, int n, double m,
 }
 
 // y = act(x*scale_c + shift_c (+ residual)),  scale_c = rstd*gamma_c, shift_c = beta_c - scale_c*mean
+typedef float gn_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gn_ld4(const float4* p, bool nt) {
+  if (nt) {
+    const gn_v4f t = __builtin_nontemporal_load((const gn_v4f*)p);
+    return make_float4(t[0], t[1], t[2], t[3]);
+  }
+  return *p;
+}
+__device__ __forceinline__ void gn_st4(float4* p, const float4& v, bool nt) {
+  if (nt) __builtin_nontemporal_store((gn_v4f){v.x, v.y, v.z, v.w}, (gn_v4f*)p);
+  else *p = v;
+}
+// Non-temporal loads / stores for the GroupNorm passes (bit 0: forward apply, 1 / 2: backward apply loads / store, 3: backward
+// reduce loads).  These kernels stream 180 - 500 MB per launch; measured A/B on MI355X (DIS-MF bs=4): forward apply 2.86 -> 2.65
+// ms/step, backward 7.18 -> 6.77 ms/step, 396.5 -> 399.9 frames/s with all four.  DIS_GN_NT=0 switches them off.
+static int gn_nt_flags() {
+  static const int f = getenv("DIS_GN_NT") ? atoi(getenv("DIS_GN_NT")) : 15;
+  return f;
+}
 __global__ void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const float* __restrict__ res, float* __restrict__ y, long hw, int c, int act,
-                                float eps) {
+                                float eps, int nt) {
   __shared__ float sc[GN_MAXC], sh[GN_MAXC];
   const int n = blockIdx.y;
   if (threadIdx.x < c) {
@@ -232,14 +252,15 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const double* __res
   float4* yp = (float4*)(y + (long)n * hw * c);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per4; i += (long)gridDim.x * blockDim.x) {
     const int g = (int)(i % cg) * 4;
-    const float4 v = xp[i];
+    const float4 v = gn_ld4(xp + i, nt & 1);
     float4 o = make_float4(v.x * sc[g] + sh[g], v.y * sc[g + 1] + sh[g + 1], v.z * sc[g + 2] + sh[g + 2],
                            v.w * sc[g + 3] + sh[g + 3]);
     if (rp) {
       const float4 r = rp[i];
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
-    yp[i] = make_float4(act_apply(o.x, act), act_apply(o.y, act), act_apply(o.z, act), act_apply(o.w, act));
+    o = make_float4(act_apply(o.x, act), act_apply(o.y, act), act_apply(o.z, act), act_apply(o.w, act));
+    gn_st4(yp + i, o, nt & 1);
   }
 }
 extern "C" int dis_gn_apply(const float* x, const double* stats, const float* gamma, const float* beta,
@@ -250,8 +271,9 @@ extern "C" int dis_gn_apply(const float* x, const double* stats, const float* ga
   if (c % 4 != 0 || c > GN_MAXC) return DIS_ERR_UNSUPPORTED;
   int gx = dis_ew_grid(hw * (c / 4), 256);
   if (gx > 512) gx = 512;
+  const int nt = gn_nt_flags();
   hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, residual,
-                     y, hw, c, act, eps);
+                     y, hw, c, act, eps, nt);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
@@ -265,7 +287,7 @@ extern "C" int dis_gn_apply(const float* x, const double* stats, const float* ga
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                      const float* __restrict__ x, const double* __restrict__ stats,
                                      const float* __restrict__ gamma, double* __restrict__ red,
-                                     double* __restrict__ gparam, long hw, int c, int act, float eps, int n0) {
+                                     double* __restrict__ gparam, long hw, int c, int act, float eps, int n0, int nt) {
   __shared__ float gam[GN_MAXC];
   __shared__ double sm[8];
   __shared__ float pg[256 * 4], pb[256 * 4];
@@ -310,9 +332,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     float4 gv[4], yv[4], xv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      gv[u] = gp[i + u * stride];
-      xv[u] = xp[i + u * stride];
-      yv[u] = (act != DIS_ACT_NONE) ? yp[i + u * stride] : gv[u];
+      gv[u] = gn_ld4(gp + i + u * stride, nt & 8);
+      xv[u] = gn_ld4(xp + i + u * stride, nt & 8);
+      yv[u] = (act != DIS_ACT_NONE) ? gn_ld4(yp + i + u * stride, nt & 8) : gv[u];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) body(gv[u], yv[u], xv[u]);
@@ -351,7 +373,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
                                     const float* __restrict__ gamma, const double* __restrict__ red,
                                     float* __restrict__ gx, float* __restrict__ gres, long hw, int c, int act,
                                     float eps, int nred, int in_act, const double* __restrict__ gparam,
-                                    float* __restrict__ gg, float* __restrict__ gb, int slots, int n0) {
+                                    float* __restrict__ gg, float* __restrict__ gb, int slots, int n0, int nt) {
   __shared__ float gam[GN_MAXC];
   // Samples and elements are walked in the REVERSE of pass 1's order: what pass 1 read last is what the Infinity Cache
   // still holds, so this pass starts on cached data instead of evicting it first.
@@ -400,14 +422,14 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
   for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < per4; j += (long)gridDim.x * blockDim.x) {
     const long i = per4 - 1 - j;
     const int g = (int)(i % cg) * 4;
-    float4 gv = gp[i];
+    float4 gv = gn_ld4(gp + i, nt & 2);
     if (act != DIS_ACT_NONE) {
-      const float4 yv = yp[i];
+      const float4 yv = gn_ld4(yp + i, nt & 2);
       gv.x *= act_grad_from_out(yv.x, act); gv.y *= act_grad_from_out(yv.y, act);
       gv.z *= act_grad_from_out(yv.z, act); gv.w *= act_grad_from_out(yv.w, act);
     }
     if (rp) rp[i] = gv;
-    const float4 xv = xp[i];
+    const float4 xv = gn_ld4(xp + i, nt & 2);
     float4 o;
     o.x = rstd * (gv.x * gam[g] - a1 - ((xv.x - mean) * rstd) * a2);
     o.y = rstd * (gv.y * gam[g + 1] - a1 - ((xv.y - mean) * rstd) * a2);
@@ -417,7 +439,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
       o.x *= act_grad_from_out(xv.x, in_act); o.y *= act_grad_from_out(xv.y, in_act);
       o.z *= act_grad_from_out(xv.z, in_act); o.w *= act_grad_from_out(xv.w, in_act);
     }
-    op[i] = o;
+    gn_st4(op + i, o, nt & 4);
   }
 }
 
@@ -453,10 +475,10 @@ extern "C" int dis_gn_apply_bwd(const float* gy, const float* y, const float* x,
     const int ng = n0 + grp <= n ? grp : n - n0;
     const bool last = n0 + ng == n;
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nred, ng), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma, red,
-                       gparam_acc, hw, c, act, eps, n0);
+                       gparam_acc, hw, c, act, eps, n0, gn_nt_flags());
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gxg * 2, ng), dim3(256), 0, s, gy, y ? y : gy, x, stats, gamma,
                        (const double*)red, gx, gres, hw, c, act, eps, nred, in_act, (const double*)gparam_acc,
-                       grad_gamma, grad_beta, last ? n * nred : 0, n0);
+                       grad_gamma, grad_beta, last ? n * nred : 0, n0, gn_nt_flags());
   }
   DIS_CHECK_LAUNCH();
   return DIS_OK;
