@@ -2,6 +2,7 @@
 // Feature maps are nhwc (one 32-channel pixel = one 128-byte line), so every bilinear tap of a warp or
 // a k-NN gather is one fully used cache line; lanes run over channels first => coalesced 16 B/lane.
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // planar <-> nhwc
@@ -358,8 +359,9 @@ __device__ __forceinline__ int slot_frame(int t, int s) { return s == 0 ? t : (s
 //   feat (tl,bs,h,w,c)  flows (tl*tl,bs,h,w,2)  ->  out (tl,bs,h,w,tl,c)
 // one thread = 4 channels of one (target, sample, pixel, slot)
 // ------------------------------------------------------------------------------------------------
+typedef float lo_v4f __attribute__((ext_vector_type(4)));
 __global__ void gather_warped_feat_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ flows,
-                                              float* __restrict__ out, int tl, int bs, int h, int w, int c) {
+                                              float* __restrict__ out, int tl, int bs, int h, int w, int c, int nt) {
   const int cg = c >> 2;
   const long hw = (long)h * w;
   const long total = (long)tl * bs * hw * tl * cg;
@@ -396,7 +398,10 @@ __global__ void gather_warped_feat_fwd_kernel(const float* __restrict__ feat, co
       v.z = a.z * w00 + bq.z * w01 + cq.z * w10 + d.z * w11;
       v.w = a.w * w00 + bq.w * w01 + cq.w * w10 + d.w * w11;
     }
-    *(float4*)(out + ((((long)t * bs + b) * hw + p) * tl + s) * c + g * 4) = v;
+    // (the 4-slot output is written once and read much later: a non-temporal store leaves the caches to the bilinear taps)
+    float* op = out + ((((long)t * bs + b) * hw + p) * tl + s) * c + g * 4;
+    if (nt) __builtin_nontemporal_store((lo_v4f){v.x, v.y, v.z, v.w}, (lo_v4f*)op);
+    else *(float4*)op = v;
   }
 }
 
@@ -448,8 +453,9 @@ extern "C" int dis_gather_warped_feat_fwd(const float* feat, const float* flows,
   if (tl <= 0 || bs <= 0 || h <= 1 || w <= 1 || c <= 0) return DIS_ERR_BAD_SHAPE;
   if (c % 4 != 0) return DIS_ERR_UNSUPPORTED;
   long total = (long)tl * bs * h * w * tl * (c / 4);
+  static const int nt = getenv("DIS_GATHER_NT") ? atoi(getenv("DIS_GATHER_NT")) : 1;
   hipLaunchKernelGGL(gather_warped_feat_fwd_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     feat, flows, out, tl, bs, h, w, c);
+                     feat, flows, out, tl, bs, h, w, c, nt);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
