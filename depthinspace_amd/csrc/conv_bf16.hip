@@ -1355,20 +1355,23 @@ __global__ __launch_bounds__(256) void act_bwd_bf16_bias_kernel(const bf16_t* __
   const int c = cv * V;
   for (long px = (long)blockIdx.x * rows + row; px < npix; px += (long)gridDim.x * rows) {
     unsigned g[V / 2], v[V / 2], o[V / 2];
+    // (gy and y are dead after this pass - the backward of the layer that consumed y has already run: non-temporal loads)
+    typedef unsigned ab_u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned ab_u2 __attribute__((ext_vector_type(2)));
     if (V == 8) {
-      const uint4 t = *(const uint4*)(gy + px * ldg + q);
-      g[0] = t.x, g[1] = t.y, g[V / 2 - 2] = t.z, g[V / 2 - 1] = t.w;
+      const ab_u4 t = __builtin_nontemporal_load((const ab_u4*)(gy + px * ldg + q));
+      g[0] = t[0], g[1] = t[1], g[V / 2 - 2] = t[2], g[V / 2 - 1] = t[3];
     } else {
-      const uint2 t = *(const uint2*)(gy + px * ldg + q);
-      g[0] = t.x, g[1] = t.y;
+      const ab_u2 t = __builtin_nontemporal_load((const ab_u2*)(gy + px * ldg + q));
+      g[0] = t[0], g[1] = t[1];
     }
     if (act != DIS_ACT_NONE) {
       if (V == 8) {
-        const uint4 t = *(const uint4*)(y + px * ldy + q);
-        v[0] = t.x, v[1] = t.y, v[V / 2 - 2] = t.z, v[V / 2 - 1] = t.w;
+        const ab_u4 t = __builtin_nontemporal_load((const ab_u4*)(y + px * ldy + q));
+        v[0] = t[0], v[1] = t[1], v[V / 2 - 2] = t[2], v[V / 2 - 1] = t[3];
       } else {
-        const uint2 t = *(const uint2*)(y + px * ldy + q);
-        v[0] = t.x, v[1] = t.y;
+        const ab_u2 t = __builtin_nontemporal_load((const ab_u2*)(y + px * ldy + q));
+        v[0] = t[0], v[1] = t[1];
       }
     }
 #pragma unroll

@@ -3,6 +3,20 @@
 #include "common.h"
 #include <stdlib.h>
 
+typedef float gn_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gn_ld4(const float4* p, bool nt) {
+  if (nt) {
+    const gn_v4f t = __builtin_nontemporal_load((const gn_v4f*)p);
+    return make_float4(t[0], t[1], t[2], t[3]);
+  }
+  return *p;
+}
+__device__ __forceinline__ void gn_st4(float4* p, const float4& v, bool nt) {
+  if (nt) __builtin_nontemporal_store((gn_v4f){v.x, v.y, v.z, v.w}, (gn_v4f*)p);
+  else *p = v;
+}
+
+
 __global__ void act_bwd_kernel(const float4* __restrict__ gy, const float4* __restrict__ y, float4* __restrict__ gp,
                                int act, long count4) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count4; i += (long)gridDim.x * blockDim.x) {
@@ -60,9 +74,10 @@ __global__ __launch_bounds__(256) void act_bwd_ld_bias_kernel(const float* __res
   const int chunk = threadIdx.x % c4, rows = 256 / c4, row = threadIdx.x / c4, q = chunk * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (long px = (long)blockIdx.x * rows + row; px < npix; px += (long)gridDim.x * rows) {
-    float4 o = *(const float4*)(gy + px * ldg + q);
+    // (gy and y are dead after this pass - the backward of the layer that consumed y has already run: non-temporal loads)
+    float4 o = gn_ld4((const float4*)(gy + px * ldg + q), true);
     if (act != DIS_ACT_NONE) {
-      const float4 v = *(const float4*)(y + px * ldy + q);
+      const float4 v = gn_ld4((const float4*)(y + px * ldy + q), true);
       o.x *= act_grad_from_out(v.x, act), o.y *= act_grad_from_out(v.y, act);
       o.z *= act_grad_from_out(v.z, act), o.w *= act_grad_from_out(v.w, act);
     }
@@ -212,18 +227,6 @@ __device__ __forceinline__ void gn_moments(const double* stats, int n, double m,
 }
 
 // y = act(x*scale_c + shift_c (+ residual)),  scale_c = rstd*gamma_c, shift_c = beta_c - scale_c*mean
-typedef float gn_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 gn_ld4(const float4* p, bool nt) {
-  if (nt) {
-    const gn_v4f t = __builtin_nontemporal_load((const gn_v4f*)p);
-    return make_float4(t[0], t[1], t[2], t[3]);
-  }
-  return *p;
-}
-__device__ __forceinline__ void gn_st4(float4* p, const float4& v, bool nt) {
-  if (nt) __builtin_nontemporal_store((gn_v4f){v.x, v.y, v.z, v.w}, (gn_v4f*)p);
-  else *p = v;
-}
 // Non-temporal loads / stores for the GroupNorm passes (bit 0: forward apply, 1 / 2: backward apply loads / store, 3: backward
 // reduce loads).  These kernels stream 180 - 500 MB per launch; measured A/B on MI355X (DIS-MF bs=4): forward apply 2.86 -> 2.65
 // ms/step, backward 7.18 -> 6.77 ms/step, 396.5 -> 399.9 frames/s with all four.  DIS_GN_NT=0 switches them off.
