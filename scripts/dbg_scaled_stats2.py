@@ -1,4 +1,8 @@
-"""Diagnostic (continued): the same kernel call with the statistics buffer zeroed in different ways."""
+"""Diagnostic (continued): dis_conv2d_fwd_scaled with GroupNorm statistics, repeated on fixed inputs while other processes share the
+GPU (run two copies of this next to `dbg_rare_noise.py multi_frame 400`).  Counts the launches whose statistics deviate.
+The per-lane slab columns are only filled by a diagnostic patch of conv_fwd_kernel's final flush that was used for the analysis in
+DESIGN.md section 4 (each thread stores its s1 / s2 at stats[2n + 2 (blockIdx * 256 + threadIdx) ..]); with the product build
+they stay zero and only the `atomics diff` figure is meaningful."""
 import os
 import sys
 
