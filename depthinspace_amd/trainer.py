@@ -315,11 +315,17 @@ class GraphedStep(object):
 
     def _capture(self):
         opt = self.opt
+        # the warm-up steps (kernel attributes, allocator pools, autograd nodes on the capture-compatible stream) must not train:
+        # parameters, moments and the step counter are put back afterwards, so a graphed run takes exactly the steps an eager one does
+        state = (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.state_dev)
+        snap = [t.clone() for t in state]
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, self.warmup)):
                 self._eager()
+            for t, c in zip(state, snap):
+                t.copy_(c)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()

@@ -228,3 +228,46 @@ def test_sgm_warmup_term():
     (val * 0.1).backward()
     assert abs(float(val) - float(ref)) < 1e-5 * float(ref)
     assert float((od.grad.cpu() - orf.grad).abs().max()) < 1e-9
+
+
+@pytest.mark.parametrize('arch', ['single_frame', 'multi_frame'])
+def test_worker_train_epoch_graph_equals_eager(tmp_path, arch):
+    """Worker(use_graph=True) - the captured step behind DIS_TRAIN_GRAPH=1 - through the real loop (`do('retrain')`: loader, epoch
+    statistics, checkpoint) lands on the same parameters and epoch losses as the eager loop on the same on-disk tracks."""
+    import json
+    from depthinspace_amd import synth
+    from depthinspace_amd.data import dataset as D
+    from depthinspace_amd.model import networks, multi_frame_networks, single_frame_worker, multi_frame_worker
+    from depthinspace_amd.trainer import FlatAdam
+    H = W = 64
+    settings = synth.make_settings(H, W)
+    root = str(tmp_path / 'data')
+    D.write_synthetic_dataset(root, settings, 8, seed=60)
+    if arch == 'multi_frame':   # DIS-MF reads the DIS-SF disparities of the tracks: any stored disparity will do here
+        import numpy as np
+        for p in sorted(os.listdir(root)):
+            d = os.path.join(root, p)
+            if os.path.isdir(d) and os.path.exists(os.path.join(d, 'frames.npz')):
+                f = np.load(os.path.join(d, 'frames.npz'))
+                np.savez(os.path.join(d, 'single_frame_disp.npz'), disp=f['disp'])
+    res = {}
+    for mode in ('eager', 'graph'):
+        out = str(tmp_path / ('out_' + mode))
+        mod = multi_frame_worker if arch == 'multi_frame' else single_frame_worker
+        w = mod.Worker(_args(arch, 1), data_root=root, output_dir=out, num_workers=0, test_batch_size=1, use_graph=(mode == 'graph'))
+        w.device_aug = False          # (the augmentation draws are host-RNG driven: off, so that both runs see the same batches)
+        torch.manual_seed(5)
+        if arch == 'multi_frame':
+            net = multi_frame_networks.FuseNet(imsize=w.imsizes[0], K=w.K, baseline=w.baseline, track_length=4, max_disp=128).cuda()
+        else:
+            net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=w.imsizes).cuda()
+        opt = FlatAdam(net.parameters(), lr=1e-4)
+        w.do(net, opt, cmd='retrain')
+        m = json.load(open(os.path.join(out, arch, 'metrics.json')))
+        res[mode] = (opt.flat_p.clone(), m['0']['train']['loss'], opt.step_count)
+    assert res['eager'][2] == res['graph'][2] > 0
+    # (Adam turns the rounding noise of ~0 gradients into +-lr steps: a few elements may differ by 2 lr per step)
+    d = (res['eager'][0] - res['graph'][0]).abs()
+    assert float(d.max()) <= 2.1e-4 * res['eager'][2] and float(d.mean()) < 2e-6
+    import numpy as np
+    np.testing.assert_allclose(res['graph'][1], res['eager'][1], rtol=5e-3, atol=1e-5)
