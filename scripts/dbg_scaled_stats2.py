@@ -29,12 +29,13 @@ def main():
     kinds = {'atomic_lost': 0, 'partial_wrong': 0, 'both': 0}
     st = torch.zeros(8 + 2 * NB, dtype=torch.float64, device='cuda')
     for it in range(N):
-        y = torch.empty((n, h, w, cout), device='cuda')
+        y = torch.full((n, h, w, cout), float('nan'), device='cuda')   # unwritten outputs stay NaN
         st.zero_()
         lib.call('dis_conv2d_fwd_scaled', x, xs, pw, b, y, None, st, n, h, w, cin, cout, 1, 1, 0, ops.ACT_NONE)
         if it % 3 == 0:
             filler = filler * 1.0000001
         stc = st.clone()
+        ynan = torch.isnan(y).sum()
         if ref is None:
             torch.cuda.synchronize()
             ref = stc
@@ -46,6 +47,7 @@ def main():
         if d_at > 1e-6 or d_sl > 1e-9:
             k = 'both' if (d_at > 1e-6 and d_sl > 1e-9) else ('atomic_lost' if d_at > 1e-6 else 'partial_wrong')
             kinds[k] += 1
+            print(f'iter {it}: unwritten (NaN) outputs in y: {int(ynan)}', flush=True) if sum(kinds.values()) <= 6 else None
             if sum(kinds.values()) <= 4:
                 nz = (stc[8:] - ref[8:]).abs() > 1e-9
                 print(f'iter {it}: atomics diff {d_at:.3e}; slab diff {d_sl:.3e} in {int(nz.sum())} entries '
