@@ -1581,7 +1581,17 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // per 16-byte staging item (4 floats / 8 bf16)
 template <int CIN, int COUT, int K = 3, int S = 1, int TR = 8, int KH = K, int NP = 3, int CPI = 4>
 struct WxCfg {
-  static constexpr int PSX = NP * CIN + 8, PSG = NP * COUT + 8;  // LDS pixel strides (16-bit units), as BxCfg::PS
+  // LDS pixel strides (16-bit units).  The transposing reads (ds_read_b64_tr_b16: two groups of 32 lanes, 64 banks) of one group
+  // touch 8 pixels (4 columns x 2 lane groups), 32 bytes each, `step` pixels apart (1 for gy and stride-1 x, 2 for stride-2 x):
+  // they are conflict-free when the 8 offsets step * p * stride (dwords, mod 64) are distinct multiples of 8, i.e. when
+  // step * stride = 8 * odd (mod 64).  Smallest such stride >= the payload, in 16-byte units (measured before: half of the LDS
+  // cycles of this kernel were bank-conflict cycles with the 8-element pad).
+  static constexpr int ps_for(int payload_u16, int step) {
+    int ps = (payload_u16 + 7) / 8 * 8;
+    while (((step * (ps / 2)) % 16) != 8) ps += 8;
+    return ps;
+  }
+  static constexpr int PSX = ps_for(NP * CIN, S), PSG = ps_for(NP * COUT, 1);
   static constexpr int CVX = CIN / CPI, CVG = COUT / CPI;
   static constexpr int IR = (TR - 1) * S + KH, IC = 15 * S + K;  // halo of the x tile (KH of the K tap rows per workgroup)
   static constexpr int X_U16 = IR * IC * PSX, G_U16 = TR * 16 * PSG;
@@ -1727,19 +1737,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
     constexpr int NU = C::KSN * NG, NGD = NG ? NG : 1;                    // units per tile: k-steps x NG row blocks
     // operand fetch (hardware-transposing reads) of k-step ks: lane group lg covers tile row 2 ks + lg/2, 8 columns
     auto load_fb = [&](int ks, s16x8 (&F)[3][NB]) __attribute__((always_inline)) {
-      const int pr = 2 * ks + (lg >> 1), pc0 = 8 * (lg & 1);
-      const unsigned short* gq = gl + (pr * 16 + pc0 + tq) * PSG + tp * 4;
+      // k-slot <-> pixel: lane group lg takes columns 4 lg .. 4 lg + 3 of tile row 2 ks (first read) and of row 2 ks + 1 (second
+      // read) - the same assignment in load_fa, which is all the contraction needs; the 32 lanes of a read group then cover 8
+      // CONSECUTIVE pixels of one row
+      const unsigned short* gq = gl + (2 * ks * 16 + 4 * lg + tq) * PSG + tp * 4;
 #pragma unroll
       for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) F[p][nb] = tr_read8(gq + p * COUT + nb * 16, gq + 4 * PSG + p * COUT + nb * 16);
+        for (int nb = 0; nb < NB; ++nb) F[p][nb] = tr_read8(gq + p * COUT + nb * 16, gq + 16 * PSG + p * COUT + nb * 16);
     };
     auto load_fa = [&](int ks, int mb, s16x8 (&F)[3]) __attribute__((always_inline)) {
-      const int pr = 2 * ks + (lg >> 1), pc0 = 8 * (lg & 1);
       const int tap = CIN == 32 ? mb >> 1 : mb, half = CIN == 32 ? mb & 1 : 0, ky = tap / K, kx = tap - K * ky;
-      const unsigned short* xq = xl + ((pr * S + ky) * WX_IC + (pc0 + tq) * S + kx) * PSX + half * 16 + tp * 4;
+      const unsigned short* xq = xl + ((2 * ks * S + ky) * WX_IC + (4 * lg + tq) * S + kx) * PSX + half * 16 + tp * 4;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) F[p] = tr_read8(xq + p * CIN, xq + 4 * S * PSX + p * CIN);
+      for (int p = 0; p < NP; ++p) F[p] = tr_read8(xq + p * CIN, xq + S * WX_IC * PSX + p * CIN);
     };
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       __syncthreads();
