@@ -3,6 +3,7 @@
 512x432 default-pattern synthetic data, fp32, on N MI355X of one node (one process per GPU, RCCL).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W      (no launcher: spawns its N ranks itself, one fresh process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
@@ -11,7 +12,10 @@ Prints ONE JSON line on rank 0 (contract in the task description): BASELINE.json
   roofline     : the dominant kernel (MFMA fp32 32->32 3x3 implicit-GEMM conv) against the fp32 matrix peak,
                  duration measured live with HIP events around every launch of that kernel in one step;
   cpu_baseline : the CPU oracle (pure PyTorch restatement of the reference step) timed on the host cores on a
-                 bounded sample (rank 0, N=1 only).
+                 bounded sample (rank 0, N=1 only);
+  disp_l1_vs_ref : mean |disparity(HIP) - disparity(oracle)| on that sample's inputs (the metric's "disp L1 vs ref");
+  ranks_seen / devices_seen / replicas_equal : at N > 1 every rank checks the world size, that no two ranks share a
+                 device (RCCL) and, after the timed loop, that all parameter replicas are bit-identical.
 """
 import argparse
 import json
@@ -72,17 +76,85 @@ def cpu_baseline(arch='multi_frame', timed_steps=3):
     torch.set_num_threads(want)
     try:
         times = []
+        first = None
         for i in range(1 + timed_steps):
             t0 = time.time()
-            O.train_step(ctx, arch, params, tb, adam_state=st, epoch=2)
+            r = O.train_step(ctx, arch, params, tb, adam_state=st, epoch=2)
             times.append(time.time() - t0)
+            if i == 0:   # the warm-up step starts from init_params(seed=0): its disparity is the reference of `disp_l1_vs_ref`
+                out = r['out'] if arch == 'multi_frame' else r['out'][0]
+                first = {'out': out.detach().clone(), 'vals': [float(v.detach()) for v in r['vals']]}
     finally:
         torch.set_num_threads(nthr)
     dt = sum(times[1:]) / timed_steps
     tag = 'DIS-MF' if arch == 'multi_frame' else 'DIS-SF'
     return {'value': TL / dt, 'unit': 'frames/s', 'cores': want, 'kind': 'port',
             'sample': f'CPU oracle training step, {tag} bs=1 (one 4-frame track) 512x432 fp32: 1 warm-up ({times[0]:.1f} s) + '
-                      f'{timed_steps} timed steps (mean {dt:.1f} s), torch threads={want} of os.cpu_count()={os.cpu_count()}'}
+                      f'{timed_steps} timed steps (mean {dt:.1f} s), torch threads={want} of os.cpu_count()={os.cpu_count()}'}, first
+
+
+def hip_first_step(arch, settings, dev, dtype='f32'):
+    """The HIP path on cpu_baseline()'s inputs: bs=1, batch seed 1234, init_params(seed=0), epoch 2 - one forward + losses.
+    Returns (disparity on the host, loss terms, Conv3D neighbour sets or None)."""
+    from depthinspace_amd import synth
+    from depthinspace_amd.model import multi_frame_networks, multi_frame_worker, single_frame_worker, networks
+    from oracle import dis_oracle as O
+    mf = arch == 'multi_frame'
+    params = O.init_params(O.mf_param_shapes() if mf else O.sf_param_shapes(), seed=0)
+    batch = synth.make_batch(settings, 1, TL, seed=1234)
+    if mf:
+        net = multi_frame_networks.FuseNet(imsize=(H, W), K=settings.K, baseline=settings.baseline, track_length=TL, max_disp=128)
+        worker = multi_frame_worker.Worker(make_args(1), settings=settings, train_device=str(dev))
+    else:
+        worker = single_frame_worker.Worker(make_args(1, 'single_frame'), settings=settings, train_device=str(dev))
+        kw = {'act_dtype': torch.bfloat16} if dtype == 'bf16' else {}
+        net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=worker.imsizes, **kw)
+    net.load_state_dict({k: v.detach() for k, v in params.items()})
+    net = net.to(dev)
+    worker.build_losses(device=dev)
+    worker.current_epoch = 2
+    with torch.no_grad():
+        aug, worker.device_aug = worker.device_aug, False   # the oracle step has no augmentation either
+        worker.copy_data({k: torch.from_numpy(v) for k, v in batch.items()}, device=dev, requires_grad=False, train=True)
+        worker.device_aug = aug
+        flow = worker.read_optical_flow(train=True)
+        out = worker.net_forward(net, flow)
+        errs = worker.loss_forward(out, True, flow)
+    torch.cuda.synchronize()
+    o = out if mf else out[0]
+    sets = [t.cpu() for t in net.last_knn_index] if mf else None
+    return o.detach().float().cpu(), [float(e) for e in errs], sets
+
+
+def spawn_ranks(n):
+    """Start `n` copies of this command line, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set; children are fresh interpreter processes (no exec of a GPU-initialised process, nothing inherited).  Rank 0's
+    stdout (the JSON line) passes through.  Returns the largest exit code; a rank that dies takes the others with it."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            try:
+                c = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            alive.remove(p)
+            if c != 0:
+                rc = max(rc, c if c > 0 else 1)
+                for q in alive:   # exactly the children started above
+                    q.terminate()
+    return rc
 
 
 def main():
@@ -110,12 +182,16 @@ def main():
     if args.dtype == 'bf16' and args.arch != 'single_frame':
         raise SystemExit('--dtype bf16 is the DIS-SF configuration (BASELINE config 2); DIS-MF runs fp32')
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: this process never touches a GPU; it starts the N ranks as fresh children
+        # (the environment torch.distributed.run would give them), waits, and leaves with their worst exit code
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                         f'(python bench.py --gpus N spawns them itself; torch.distributed.run --nproc-per-node N works too)')
     ndev = torch.cuda.device_count()
     if local_rank >= ndev and args.backend == 'nccl':
         raise SystemExit(f'rank {rank}: local rank {local_rank} but only {ndev} GPU(s) visible')
@@ -133,6 +209,20 @@ def main():
     from depthinspace_amd.model import multi_frame_networks, multi_frame_worker, single_frame_worker, networks
     from depthinspace_amd.trainer import FlatAdam
     lib.check_all_symbols()
+
+    # ---- the job checks its own shape: N ranks, one device each (RCCL), before anything is timed
+    ranks_seen, devices_seen = [rank], [dev_idx]
+    if world > 1:
+        assert torch.distributed.get_world_size() == args.gpus, (torch.distributed.get_world_size(), args.gpus)
+        me = torch.tensor([rank, dev_idx, torch.cuda.current_device()], dtype=torch.int64,
+                          device=dev if args.backend == 'nccl' else 'cpu')
+        got = [torch.zeros_like(me) for _ in range(world)]
+        torch.distributed.all_gather(got, me)
+        ranks_seen = sorted(int(g[0]) for g in got)
+        devices_seen = [int(g[2]) for g in got]
+        assert ranks_seen == list(range(world)), ranks_seen
+        if args.backend == 'nccl':
+            assert len(set(devices_seen)) == world, ('ranks share a device', devices_seen)
 
     settings = synth.make_settings(H, W)
     torch.manual_seed(0)  # identical initial weights on every rank
@@ -191,6 +281,18 @@ def main():
     nterms = stepper.nterms
     losses = stepper.losses()
     adam_steps = opt.step_count
+    # ---- replicas identical after the timed steps: every rank's parameter checksum (fp64 sum and sum of squares of the flat
+    # parameter buffer, and its step counter) gathered and compared bit for bit
+    replicas_equal = None
+    if world > 1:
+        ck = torch.stack([opt.flat_p.double().sum(), (opt.flat_p.double() ** 2).sum(),
+                          opt.state_dev[0].double()])
+        if args.backend != 'nccl':
+            ck = ck.cpu()
+        cks = [torch.zeros_like(ck) for _ in range(world)]
+        torch.distributed.all_gather(cks, ck)
+        replicas_equal = all(bool(torch.equal(c, cks[0])) for c in cks)
+        assert replicas_equal, ('parameter replicas diverged', [c.tolist() for c in cks])
 
     # ---- the same loop launched eagerly (what Worker.train_step does without DIS_TRAIN_GRAPH): reported beside the headline
     eager_fps = None
@@ -337,8 +439,17 @@ def main():
         top = sorted(per.items(), key=lambda kv: -kv[1][1])[:12]
         kernel_ms = {k: {'calls': v[0], 'ms': round(v[1], 3)} for k, v in top}
     cpu = None
+    l1_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.arch)
+        # BASELINE metric, second half ("disp L1 vs ref"): the HIP forward on the oracle's bs=1 inputs and initial parameters
+        # against the disparity of the oracle's first (warm-up) step; north-star bar 1e-4 px for the fp32 path
+        hip_out, hip_vals, hip_sets = hip_first_step(args.arch, settings, dev, args.dtype)
+        cpu, first = cpu_baseline(args.arch)
+        d = (hip_out.reshape(-1) - first['out'].float().reshape(-1)).abs()
+        l1_ref = {'value': float(d.mean()), 'max': float(d.max()), 'unit': 'px', 'bar': 1e-4 if args.dtype == 'f32' else 0.05,
+                  'loss_terms_max_abs_diff': max(abs(a - b) for a, b in zip(hip_vals, first['vals'])),
+                  'sample': 'bs=1 (one 4-frame track, batch seed 1234, init_params(seed=0)), 512x432: free-running HIP forward vs '
+                            'the free-running CPU oracle of cpu_baseline on this host'}
 
     if rank == 0:
         frames = world * args.bs * TL * args.steps
@@ -367,7 +478,12 @@ def main():
                         'weight gradients likewise (one-pass slice-pair kernel with transposing LDS reads; the first layer and ragged '
                         'shapes on fp32 MFMA from the bf16 values); parameters, their gradients, disparities '
                         'and losses fp32.  Not the parity path: disparity L1 vs the fp32 oracle 0.01 px (tests/test_sf_bf16_gpu.py)')},
-            'roofline': roof, 'roofline_hbm_kernels': hbm, 'cpu_baseline': cpu, 'loss_terms': losses,
+            'roofline': roof, 'roofline_hbm_kernels': hbm, 'cpu_baseline': cpu, 'disp_l1_vs_ref': l1_ref,
+            'ranks_seen': ranks_seen, 'devices_seen': devices_seen, 'replicas_equal': replicas_equal,
+            'multi_gpu_measured': ('this line' if world > 1 and args.backend == 'nccl' else
+                                   'unmeasured (no SCALE record with N > 1 exists yet)' if world == 1 else
+                                   'gloo plumbing run, not a measurement'),
+            'loss_terms': losses,
             'eager_launch_frames_per_s': eager_fps, 'adam_steps_taken': adam_steps, 'step_mode': stepper.mode,
             'kernel_ms_one_eager_step': kernel_ms,
         }
