@@ -15,6 +15,11 @@ def _dist_group():
     return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
 
+def _fallback_device():
+    """where a rank that never saw a sample (empty test shard) builds its empty contribution: the device its peers use"""
+    return torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+
+
 def _gather_cat(x):
     """concatenation of a 1-D tensor over all ranks (sizes may differ)"""
     if not _dist_group():
@@ -112,13 +117,18 @@ class DistanceMetric(Metric):
         self.dists.append(_distances(es, ta, ma, self.vec_length, self.p))
 
     def _all(self):
-        return _gather_cat(torch.cat(self.dists))
+        # a rank without samples (fewer test tracks than ranks) still takes part in the collectives
+        mine = torch.cat(self.dists) if self.dists else torch.empty(0, dtype=torch.float32, device=_fallback_device())
+        return _gather_cat(mine)
 
     def get(self):
         d = self._all()
+        n = d.numel()
+        if n == 0:   # nothing was added on any rank
+            nan = float('nan')
+            return {f'dist{self.name}_{k}': nan for k in ('mean', 'std', 'median', 'q10', 'q90', 'min', 'max')}
         s, _ = torch.sort(d)
         d64 = d.double()
-        n = d.numel()
         mean = float(d64.sum()) / n
         var = float(((d64 - mean) ** 2).sum()) / n
         return {
@@ -150,9 +160,13 @@ class OutlierFractionMetric(DistanceMetric):
         self.total += dist.numel()
 
     def get(self):
-        c = self.counts.clone()
+        if self.counts is None:   # empty shard: zero counts, same collectives as everyone else
+            c = torch.zeros(len(self.thresholds), dtype=torch.int64, device=_fallback_device())
+        else:
+            c = self.counts.clone()
         tot = torch.tensor([self.total], device=c.device, dtype=torch.int64)
         if _dist_group():
             torch.distributed.all_reduce(c)
             torch.distributed.all_reduce(tot)
-        return {f'of{t}': float(int(v)) / float(int(tot)) for t, v in zip(self.thresholds, c)}
+        n = int(tot)
+        return {f'of{t}': (float(int(v)) / float(n) if n > 0 else float('nan')) for t, v in zip(self.thresholds, c)}

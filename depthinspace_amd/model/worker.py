@@ -337,14 +337,12 @@ class Worker(object):
         net.train()
         mean_loss = None
         n_done = 0
-        graphed = None
         stopwatch.start('total')
         for batch_idx, data in enumerate(train_loader):
             if self.max_train_iter > 0 and batch_idx > self.max_train_iter:
                 break
             if self.use_graph:
-                if graphed is None:
-                    graphed = self._graphed_step(net, optimizer, data)
+                graphed = self._graphed_step(net, optimizer, data)
                 data = dict(data)
                 if self.device_aug:
                     im = data['im0']
@@ -369,6 +367,8 @@ class Worker(object):
         stopwatch.stop('total')
         logging.info('timings: %s' % stopwatch)
         self.last_epoch_stats = {'steps': n_done, 'seconds': float(stopwatch.get('total')),
+                                 'step_mode': (self._graphed[1].mode if self.use_graph and getattr(self, '_graphed', None)
+                                               else 'eager'),
                                  'frames_per_s': (n_done * self.train_batch_size * self.track_length * self.world_size /
                                                   max(float(stopwatch.get('total')), 1e-9))}
         if mean_loss is not None and self.world_size > 1:
@@ -382,6 +382,18 @@ class Worker(object):
         return mean_loss
 
     def _graphed_step(self, net, optimizer, example_batch):
+        """the captured step of this (net, optimizer, batch shapes): built once and kept across epochs (static buffers,
+        warm-up steps and the capture are paid once; GraphedStep.key() re-captures when the set of loss terms changes)"""
+        from ..trainer import GraphedStep
+        sig = (id(net), id(optimizer), tuple((k, tuple(torch.as_tensor(v).shape)) for k, v in sorted(example_batch.items())))
+        cached = getattr(self, '_graphed', None)
+        if cached is not None and cached[0] == sig:
+            return cached[1]
+        gs = self._build_graphed_step(net, optimizer, example_batch)
+        self._graphed = (sig, gs)
+        return gs
+
+    def _build_graphed_step(self, net, optimizer, example_batch):
         from ..trainer import GraphedStep
         ex = dict(example_batch)
         if self.device_aug:
@@ -390,7 +402,9 @@ class Worker(object):
         if self.data_type == 'real':
             for k in range(self.n_sgm_draws):
                 ex[f'_sgm_noise{k}'] = torch.zeros_like(torch.as_tensor(ex['sgm_disp']))
-        return GraphedStep(self, net, optimizer, ex, use_graph=True)
+        # DIS_TRAIN_GRAPH=1 asked for the captured step explicitly: a failing capture raises instead of training eagerly
+        return GraphedStep(self, net, optimizer, ex, use_graph=True,
+                           strict=os.environ.get('DIS_TRAIN_GRAPH', '') == '1')
 
     def test(self, epoch, net, test_sets):
         errs = {}
@@ -466,8 +480,14 @@ class Worker(object):
                 torch.set_rng_state(state['cpu_rng_state'])
             if 'gpu_rng_state' in state and torch.cuda.is_available():
                 torch.cuda.set_rng_state(state['gpu_rng_state'].cpu())
-        if self.world_size > 1 and hasattr(optimizer, 'broadcast_parameters'):
-            optimizer.broadcast_parameters(0)  # identical replicas whatever each rank initialised / loaded
+        if self.world_size > 1:
+            if hasattr(optimizer, 'broadcast_parameters'):
+                optimizer.broadcast_parameters(0)  # identical replicas whatever each rank initialised / loaded
+            # ... and ONE resume point: without a shared file system only rank 0 may have found state.dict; the epoch decides
+            # the number of epochs left and the set of loss terms (warm-up terms), i.e. the collectives every rank issues
+            meta = [epoch, min_err]
+            torch.distributed.broadcast_object_list(meta, src=0)
+            epoch, min_err = meta
         for epoch in range(epoch, self.epochs):
             self.current_epoch = epoch
             self.callback_train_new_epoch(epoch, net, optimizer)
@@ -478,13 +498,13 @@ class Worker(object):
                               'optimizer': optimizer.state_dict(), 'cpu_rng_state': torch.get_rng_state(),
                               'gpu_rng_state': torch.cuda.get_rng_state()}
                 logging.info(f'save state to {state_path}')
-                torch.save(state_dict, str(state_path))
+                _atomic_save(state_dict, state_path)
                 for name in errs:
                     err = sum(errs[name])
                     if err < min_err[name]:
                         min_err[name] = err
-                        torch.save(state_dict, str(self.exp_output_dir / f'state_set_{name}_best.dict'))
-                torch.save(net.state_dict(), str(self.get_net_path(epoch)))
+                        _atomic_save(state_dict, self.exp_output_dir / f'state_set_{name}_best.dict')
+                _atomic_save(net.state_dict(), self.get_net_path(epoch))
             if scheduler is not None:
                 scheduler.step()
             if self.world_size > 1:
@@ -512,6 +532,14 @@ class Worker(object):
             self.test(-1, net, self.get_test_sets())
         else:
             raise Exception('invalid cmd')
+
+
+def _atomic_save(obj, path):
+    """torch.save to a temporary file in the same directory, then rename over `path`: a crash while writing leaves the
+    previous checkpoint intact (the reference overwrites its only state.dict in place, model/worker.py:376-402)"""
+    tmp = str(path) + '.tmp'
+    torch.save(obj, tmp)
+    os.replace(tmp, str(path))
 
 
 class TestSet(object):

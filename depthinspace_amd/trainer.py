@@ -276,8 +276,10 @@ class GraphedStep(object):
     model/multi_frame_worker.py:160-165): key() changes and the step is re-captured.
     Batches are copied into static device buffers (run(batch)); `errs` of the last step are in `loss_buf[:nterms]`."""
 
-    def __init__(self, worker, net, opt, example_batch, use_graph=True, warmup=2):
+    def __init__(self, worker, net, opt, example_batch, use_graph=True, warmup=2, strict=False):
         self.worker, self.net, self.opt = worker, net, opt
+        self.strict = strict          # True: a failing capture raises instead of falling back to eager launches
+        self.capture_error = None     # why the step runs eagerly although a graph was asked for
         self.dev = opt.flat_p.device
         self.static = {k: torch.as_tensor(v).to(self.dev).contiguous().clone() for k, v in example_batch.items()}
         self.loss_buf = torch.zeros(32, device=self.dev)
@@ -347,10 +349,13 @@ class GraphedStep(object):
             try:
                 self._capture()
             except Exception as e:  # pragma: no cover
-                import sys
-                print(f'[GraphedStep] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
+                if self.strict:
+                    raise
+                import logging
+                self.capture_error = f'{type(e).__name__}: {e}'
+                logging.warning(f'[GraphedStep] hipGraph capture failed ({self.capture_error}); running eagerly')
                 self.use_graph, self._graphs = False, None
-                self.mode = 'eager-overlap' if (self.world > 1 and self.opt.overlap) else 'eager'
+                self.mode = 'eager (capture failed)'
                 torch.cuda.synchronize()
                 self._eager()
                 return

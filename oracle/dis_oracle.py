@@ -588,8 +588,16 @@ def _common_losses(ctx, outs, data, smooth_w):
     return vals
 
 
-def mf_loss_forward(ctx, out, data, flow, train=True, epoch=0):
-    """reference model/multi_frame_worker.py:103-175 (synthetic data branch)."""
+def sgm_warmup_term(o, sgm, noise):
+    """reference model/multi_frame_worker.py:168-173, single_frame_worker.py:158-163 (`real` data, epoch < warmup_epochs):
+    masked L1 to the SGM disparities where they exceed 30.  The reference draws `1.5 * torch.randn(o.size())` on the host
+    inside the expression; here the draw (already scaled by 1.5) is an input so that the term is a function."""
+    valid = (sgm > 30).float()
+    return torch.sum(torch.abs(o - sgm + noise) * valid) / torch.sum(valid)
+
+
+def mf_loss_forward(ctx, out, data, flow, train=True, epoch=0, data_type='synthetic', warmup_epochs=150):
+    """reference model/multi_frame_worker.py:103-175."""
     outs = [out]
     vals = _common_losses(ctx, outs, data, 0.8)
     R, t, amb = data['R'], data['t'], data['ambient0']
@@ -604,11 +612,13 @@ def mf_loss_forward(ctx, out, data, flow, train=True, epoch=0):
             vals.append(v * 0.2 / ge_num)
     if train and epoch < 2:
         vals.append(torch.mean(torch.abs(out - data['primary_disp'])) * 0.1)
+    if train and epoch < warmup_epochs and data_type == 'real':
+        vals.append(sgm_warmup_term(out, data['sgm_disp'], data['_sgm_noise0']) * 0.1)
     return vals
 
 
-def sf_loss_forward(ctx, outs, data, flow, train=True, use_pseudo_gt=False):
-    """reference model/single_frame_worker.py:101-165 (synthetic data branch)."""
+def sf_loss_forward(ctx, outs, data, flow, train=True, use_pseudo_gt=False, epoch=0, data_type='synthetic', warmup_epochs=150):
+    """reference model/single_frame_worker.py:101-165."""
     vals = _common_losses(ctx, outs, data, 0.4)
     R, t, amb = data['R'], data['t'], data['ambient0']
     depth = disp_to_depth(outs[0], ctx.focal, ctx.baseline)
@@ -622,6 +632,9 @@ def sf_loss_forward(ctx, outs, data, flow, train=True, use_pseudo_gt=False):
     if use_pseudo_gt:
         for s, o in enumerate(outs):
             vals.append(torch.mean(torch.abs(o - data['pseudo_gt'])) * 0.1 / (2 ** s))
+    if train and data_type == 'real' and epoch < warmup_epochs:
+        for s, o in enumerate(outs):   # every scale, its own draw
+            vals.append(sgm_warmup_term(o, data['sgm_disp'], data[f'_sgm_noise{s}']) * 0.1)
     return vals
 
 
@@ -645,7 +658,7 @@ def adam_step(params, grads, state, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
             params[name].addcdiv_(m, denom, value=-lr / bc1)
 
 
-def train_step(ctx, arch, params, batch, adam_state=None, epoch=0, use_pseudo_gt=False, lr=1e-4):
+def train_step(ctx, arch, params, batch, adam_state=None, epoch=0, use_pseudo_gt=False, lr=1e-4, data_type='synthetic'):
     """One iteration of Worker.train_epoch (reference model/worker.py:499-539) on CPU.
     Returns dict(out, vals, grads).  If adam_state is given, also applies the Adam update."""
     for v in params.values():
@@ -654,10 +667,10 @@ def train_step(ctx, arch, params, batch, adam_state=None, epoch=0, use_pseudo_gt
     flow = read_optical_flow(data, ctx.tl)
     if arch == 'multi_frame':
         out = mf_net_forward(ctx, params, data, flow)
-        vals = mf_loss_forward(ctx, out, data, flow, True, epoch)
+        vals = mf_loss_forward(ctx, out, data, flow, True, epoch, data_type=data_type)
     else:
         out = sf_net_forward(ctx, params, data)
-        vals = sf_loss_forward(ctx, out, data, flow, True, use_pseudo_gt)
+        vals = sf_loss_forward(ctx, out, data, flow, True, use_pseudo_gt, epoch=epoch, data_type=data_type)
     sum(vals).backward()
     grads = {k: v.grad for k, v in params.items() if v.requires_grad}
     if adam_state is not None:

@@ -104,8 +104,19 @@ def maxdiff(a, b):
     return float((a.detach() - b.detach()).abs().max())
 
 
+def make_sgm_disp(batch, seed):
+    """a stand-in for the SGM disparities of the `real` dataset: the primary disparity plus noise, shifted so that the
+    values straddle the validity threshold (30) - the mask of the warm-up term is neither empty nor full at fixture size"""
+    g = np.random.RandomState(seed)
+    d = batch['primary_disp'].astype(np.float32)
+    sgm = d - np.float32(np.median(d)) + np.float32(31.0) + g.normal(0, 2.0, d.shape).astype(np.float32)
+    frac = float((sgm > 30).mean())
+    assert 0.2 < frac < 0.9, frac
+    return np.ascontiguousarray(sgm.astype(np.float32))
+
+
 def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=False, random_batch=False, full_grads=False,
-                  pattern='default', scene='plane', motion=1.0, save_ckpt=False):
+                  pattern='default', scene='plane', motion=1.0, save_ckpt=False, real_sgm=False):
     from depthinspace_amd import synth
     from oracle import dis_oracle as O
     H, W = size
@@ -117,6 +128,8 @@ def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=Fals
         batch = synth.make_batch(settings, bs, 4, seed=bseed, with_pseudo_gt=use_pseudo_gt, scene=scene, motion=motion)
     shapes = O.mf_param_shapes() if arch == 'multi_frame' else O.sf_param_shapes()
     params = O.init_params(shapes, seed=pseed)
+    if real_sgm:
+        batch['sgm_disp'] = make_sgm_disp(batch, bseed + 1)
 
     # ---- reference
     if arch == 'multi_frame':
@@ -133,6 +146,8 @@ def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=Fals
     net.load_state_dict({k: v.detach().clone() for k, v in params.items()})
     net.train()
     w = ref_worker(ref, arch, settings, epoch, use_pseudo_gt)
+    if real_sgm:
+        w.data_type = 'real'   # `real` data, epoch < warmup_epochs: the SGM warm-up term (multi_frame_worker.py:168-173)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     w.copy_data(to_torch_batch(batch), 'cpu', False, True)
     opt.zero_grad()
@@ -151,7 +166,21 @@ def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=Fals
         out = w.net_forward(net, flow)
     finally:
         torch.topk = _topk
-    vals = w.loss_forward(out, True, flow)
+    # the SGM term draws its noise inside the loss expression (`1.5 * torch.randn(o.size()).cuda()`): the draws of the
+    # reference's own run are recorded (a hook, as for torch.topk) and become inputs of the fixture
+    sgm_draws = []
+    _randn = torch.randn
+
+    def _rec_randn(*a, **k):
+        r = _randn(*a, **k)
+        sgm_draws.append(r.detach().clone())
+        return r
+    torch.randn = _rec_randn
+    try:
+        vals = w.loss_forward(out, True, flow)
+    finally:
+        torch.randn = _randn
+    assert len(sgm_draws) == ((1 if arch == 'multi_frame' else 4) if real_sgm else 0), len(sgm_draws)
     sum(vals).backward()
     ref_grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in net.named_parameters()}
     opt.step()
@@ -181,7 +210,11 @@ def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=Fals
     ctx = O.StepContext(settings)
     st = {'step': 0, 'm': {}, 'v': {}}
     O.CONV3D_TAP = [] if arch == 'multi_frame' else None
-    res = O.train_step(ctx, arch, params, to_torch_batch(batch), adam_state=st, epoch=epoch, use_pseudo_gt=use_pseudo_gt)
+    obatch = to_torch_batch(batch)
+    for k, dr in enumerate(sgm_draws):   # loader layout (bs, tl, ...), scaled as the expression scales it
+        obatch[f'_sgm_noise{k}'] = (1.5 * dr).transpose(0, 1).contiguous()
+    res = O.train_step(ctx, arch, params, obatch, adam_state=st, epoch=epoch, use_pseudo_gt=use_pseudo_gt,
+                       data_type='real' if real_sgm else 'synthetic')
     tap, O.CONV3D_TAP = O.CONV3D_TAP, None
     o_outs = res['out'] if isinstance(res['out'], (list, tuple)) else [res['out']]
     rep = {'out': max(maxdiff(a, b) for a, b in zip(outs, o_outs)),
@@ -201,8 +234,13 @@ def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=Fals
 
     fx = {'arch': arch, 'H': H, 'W': W, 'bs': bs, 'pseed': pseed, 'bseed': bseed, 'epoch': epoch,
           'use_pseudo_gt': int(use_pseudo_gt), 'random_batch': int(random_batch), 'pattern': pattern, 'scene': scene,
-          'motion': float(motion),
+          'motion': float(motion), 'torch_threads': torch.get_num_threads(),
           'vals': np.array([float(v) for v in vals], dtype=np.float64)}
+    if real_sgm:
+        fx['real_sgm'] = 1
+        fx['sgm_disp'] = batch['sgm_disp']
+        for k, dr in enumerate(sgm_draws):
+            fx[f'sgm_noise{k}'] = obatch[f'_sgm_noise{k}'].numpy()   # = 1.5 * the reference's k-th torch.randn draw
     for i, o in enumerate(outs):
         fx[f'out{i}'] = o.detach().numpy()
     fx['std0_sum'] = np.float64(ref_data['std0'].double().sum())
@@ -459,6 +497,12 @@ def main():
         # BASELINE config 5: DIS-FTSF (pseudo-GT) on the real pattern, K_processed, baseline 0.0246
         ('sf_128_real_pgt', dict(arch='single_frame', size=(128, 128), bs=1, pseed=24, bseed=555, use_pseudo_gt=True,
                                  pattern='real')),
+        # `real` data during the warm-up epochs: the masked-L1 SGM term with the reference's own noise draws recorded
+        # (model/multi_frame_worker.py:168-173: one draw; model/single_frame_worker.py:158-163: one per output scale)
+        ('mf_64_real_sgm', dict(arch='multi_frame', size=(64, 64), bs=1, pseed=15, bseed=808, epoch=2, pattern='real',
+                                real_sgm=True)),
+        ('sf_64_real_sgm', dict(arch='single_frame', size=(64, 64), bs=1, pseed=25, bseed=809, epoch=2, pattern='real',
+                                real_sgm=True)),
     ]
     only = sys.argv[1:]
     for name, kw in cases:

@@ -3,7 +3,7 @@ processes share the GPU: do y and the statistics repeat?"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from depthinspace_amd import ops
 

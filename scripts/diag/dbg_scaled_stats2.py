@@ -6,7 +6,7 @@ they stay zero and only the `atomics diff` figure is meaningful."""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from depthinspace_amd import ops, lib
 

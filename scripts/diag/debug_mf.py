@@ -1,6 +1,6 @@
 """Stage-by-stage comparison of the HIP FuseNet forward against the CPU oracle (debug aid)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, torch.nn.functional as F
 from oracle import dis_oracle as O
 from depthinspace_amd import synth, ops

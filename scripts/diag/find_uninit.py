@@ -1,11 +1,11 @@
 """Diagnostic: run one DIS-MF / DIS-SF training step with every torch.empty() buffer pre-filled with NaN
 (torch.utils.deterministic.fill_uninitialized_memory) and report which outputs / parameter gradients turn NaN, i.e.
-where the step reads memory it never wrote.    python scripts/find_uninit.py [multi_frame|single_frame] [H W]"""
+where the step reads memory it never wrote.    python scripts/diag/find_uninit.py [multi_frame|single_frame] [H W]"""
 import argparse
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 torch.use_deterministic_algorithms(True, warn_only=True)

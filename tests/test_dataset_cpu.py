@@ -37,3 +37,56 @@ def test_npz_schema_roundtrip_and_flow_rekeying(tmp_path):
         for i1 in range(4):
             if i0 != i1:
                 assert torch.equal(t[f'flow_{i0}{i1}'], torch.from_numpy(fl[f'flow_{perm[i0]}{perm[i1]}']))
+
+
+class _FakeH5(dict):
+    """stand-in for h5py.File(path, 'r'): a mapping name -> array, usable as a context manager (h5py is not in the image;
+    the converter takes the opener as an argument)"""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def test_reference_hdf5_layout_converts_to_the_npz_schema(tmp_path):
+    """scripts/convert_hdf5.py / data/convert.py: a dataset root in the REFERENCE's layout (settings.pkl, %08d/frames.hdf5,
+    flow.hdf5, single_frame_disp.hdf5: data/create_syn_data.py:245-255,327-337, data/presave_disp.py:116-117) becomes a root
+    TrackNpzDataset loads, value for value."""
+    import pickle
+    from depthinspace_amd import synth
+    from depthinspace_amd.data import convert, dataset as D
+    st = synth.make_settings(32, 24)
+    src, dst = tmp_path / 'ref', tmp_path / 'npz'
+    src.mkdir()
+    with open(src / 'settings.pkl', 'wb') as f:
+        pickle.dump({'imsize': st.imsize, 'pattern': st.pattern, 'baseline': st.baseline, 'K': st.K}, f)
+    store = {}
+    for i in range(2):
+        b = synth.make_batch(st, 1, 4, seed=40 + i, with_primary=True)
+        d = src / f'{i:08d}'
+        d.mkdir()
+        im = b['im0'][0]
+        store[str(d / 'frames.hdf5')] = _FakeH5(im=im, ambient=b['ambient0'][0], grad=np.zeros_like(im), disp=b['disp0'][0],
+                                                R=b['R'][0], t=b['t'][0], sgm_disp=b['disp0'][0] + 1)
+        store[str(d / 'flow.hdf5')] = _FakeH5({k: v[0] for k, v in b.items() if k.startswith('flow_')})
+        store[str(d / 'single_frame_disp.hdf5')] = _FakeH5(disp=b['primary_disp'][0])
+        for k in store:
+            open(k, 'wb').close()   # the converter looks for the files
+    n = convert.convert_dataset(str(src), str(dst), open_h5=lambda p: store[p], log=lambda s: None)
+    assert n == 2
+    s2 = D.load_settings(str(dst))
+    assert s2.imsize == st.imsize and np.array_equal(s2.K, st.K) and np.array_equal(s2.pattern, st.pattern)
+    paths = [str(dst / f'{i:08d}') for i in range(2)]
+    ds = D.TrackNpzDataset(str(dst), paths, 4, train=False, load_flow_data=True, load_primary_data=True, data_type='real')
+    s = ds[1]
+    b = synth.make_batch(st, 1, 4, seed=41, with_primary=True)
+    for k in ('im0', 'ambient0', 'disp0', 'R', 't', 'primary_disp', 'flow_30'):
+        assert torch.equal(s[k], torch.from_numpy(b[k][0])), k
+    assert torch.equal(s['sgm_disp'], torch.from_numpy(b['disp0'][0] + 1))
+    # a track without frames.hdf5 is an error, not a silent skip
+    import pytest
+    (src / 'broken').mkdir()
+    with pytest.raises(FileNotFoundError):
+        convert.convert_track(str(src / 'broken'), str(dst / 'broken'), open_h5=lambda p: store[p])

@@ -169,3 +169,50 @@ def test_rank_sharded_batches_differ():
     assert b0['im0'].shape == b1['im0'].shape == (1, 4, 1, 32, 32)
     assert float(np.abs(b0['R'] - b1['R']).max()) > 0
     assert float(np.abs(b0['im0'] - b1['im0']).max()) > 0
+
+
+def _metric_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from depthinspace_amd.co import metric
+        m = metric.MultipleMetric(metric.DistanceMetric(vec_length=1),
+                                  metric.OutlierFractionMetric(vec_length=1, thresholds=[0.1, 0.5, 1]))
+        if rank == 0:  # rank 1's test shard is EMPTY (fewer test tracks than ranks): it must still join the collectives
+            g = torch.Generator().manual_seed(3)
+            m.add(torch.randn(50, 1, generator=g), torch.zeros(50, 1))
+            m.add(torch.randn(30, 1, generator=g), torch.zeros(30, 1))
+        q.put((rank, m.get()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_metrics_merge_with_an_empty_rank_gloo_world2():
+    """callback_test_stop on a rank that never added a sample used to raise (torch.cat([]), counts None) while
+    its peers blocked in all_gather: every rank must return the metrics of the whole set."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metric_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from depthinspace_amd.co import metric
+    g = torch.Generator().manual_seed(3)
+    d = torch.cat([torch.randn(50, 1, generator=g), torch.randn(30, 1, generator=g)])
+    ref = metric.MultipleMetric(metric.DistanceMetric(vec_length=1),
+                                metric.OutlierFractionMetric(vec_length=1, thresholds=[0.1, 0.5, 1]))
+    ref.add(d, torch.zeros(80, 1))
+    want = ref.get()
+    for r in range(world):
+        assert res[r].keys() == want.keys()
+        for k in want:
+            assert abs(res[r][k] - want[k]) < 1e-12, (r, k)
+    # nothing anywhere: NaNs, not an exception
+    e = metric.MultipleMetric(metric.DistanceMetric(vec_length=1), metric.OutlierFractionMetric(vec_length=1, thresholds=[1]))
+    assert all(np.isnan(v) for v in e.get().values())

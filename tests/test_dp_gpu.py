@@ -169,7 +169,7 @@ def test_two_rank_train_step(arch, tmp_path):
         # reduced gradient == sum of the ranks' own gradients (float atomics in two scatter kernels: tolerance, not bits; measured
         # <= 3e-7).  The two ranks of this test TIME-SHARE one GPU: under that sharing (never with one process per GPU) an
         # evaluation of the DIS-MF step occasionally comes out ~1e-4..1e-3 off - the GroupNorm sums of one 1x1-conv launch lose
-        # the contribution of 16 lanes (scripts/dbg_scaled_stats2.py) - so the bar is the MEDIAN of the steps,
+        # the contribution of 16 lanes (scripts/diag/dbg_scaled_stats2.py) - so the bar is the MEDIAN of the steps,
         # with a loose bound on every step.
         errs = sorted(res[r][f'grad_err{step}'] for step in range(NSTEPS))
         assert errs[NSTEPS // 2] < 1e-5, (r, errs, res[r])

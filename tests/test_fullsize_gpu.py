@@ -117,6 +117,65 @@ def test_mf_forward_fullsize_matches_oracle():
     assert l1 < 1e-4, (l1, mx)
 
 
+def test_mf_step_fullsize_matches_oracle():
+    """BASELINE config 3's BACKWARD at its own image size: one free-running DIS-MF training step (copy_data + LCN, FuseNet
+    forward, all loss terms, backward into the flat gradient buffer) at 512x432, bs=1 (4 frames: the CSR lists, the Conv3D
+    scatter, the GroupNorm slabs and the weight-gradient slab reduces all see 221 184-pixel maps), against the CPU oracle's
+    step on the same inputs (reference model/multi_frame_worker.py:103-175, train_val.py:55-56).  The oracle runs on the HIP
+    path's neighbour sets, which test_mf_forward_fullsize_matches_oracle ties to the reference's selection.  Bars: ordered
+    loss terms rtol 2e-4, every parameter gradient within 1e-3 of its largest entry, disparity L1 < 1e-4."""
+    import argparse
+    from depthinspace_amd import synth
+    from depthinspace_amd.model import multi_frame_networks, multi_frame_worker
+    from depthinspace_amd.trainer import FlatAdam
+    settings = synth.make_settings(H, W)
+    batch = synth.make_batch(settings, 1, 4, seed=33)
+    params = O.init_params(O.mf_param_shapes(), seed=5)
+    net = multi_frame_networks.FuseNet((H, W), settings.K, settings.baseline)
+    net.load_state_dict({k: v.detach() for k, v in params.items()})
+    net = net.cuda()
+    args = argparse.Namespace(use_pseudo_gt=False, lcn_radius=5, track_length=4, data_type='synthetic',
+                              architecture='multi_frame', epochs=1, warmup_epochs=150, train_batch_size=1, max_disp=128)
+    w = multi_frame_worker.Worker(args, settings=settings)
+    w.build_losses()
+    w.current_epoch = 0     # epoch < 2: the L1 warm-up term is part of the step
+    opt = FlatAdam(net.parameters(), lr=1e-4)
+    p0 = opt.flat_p.clone()
+    errs, out = w.train_step(net, opt, {k: torch.from_numpy(v) for k, v in batch.items()})
+    torch.cuda.synchronize()
+    sets = [net.last_knn_index[k].cpu() for k in range(2)]
+    ctx = O.StepContext(settings)
+    O.CONV3D_FORCE = {'core': sets[0].long(), 'quarter': sets[1].long()}
+    try:
+        ref = O.train_step(ctx, 'multi_frame', {k: v.detach().clone().requires_grad_(True) for k, v in params.items()},
+                           {k: torch.from_numpy(v) for k, v in batch.items()}, epoch=0)
+    finally:
+        O.CONV3D_FORCE = None
+    l1 = float((out.detach().cpu() - ref['out'].detach()).abs().mean())
+    assert l1 < 1e-4, l1
+    vals = np.array([float(e.detach()) for e in errs])
+    rvals = np.array([float(v.detach()) for v in ref['vals']])
+    assert len(vals) == len(rvals)
+    np.testing.assert_allclose(vals, rvals, rtol=2e-4, atol=2e-6)
+    rows = []
+    for k, p in net.named_parameters():
+        g = ref['grads'][k]
+        if g is None:
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        rows.append((float((p.grad.cpu() - g).abs().max()) / (float(g.abs().max()) + 1e-30), k))
+    rows.sort(reverse=True)
+    print('full-size DIS-MF step vs oracle: disp L1 %.2e, loss terms max rel %.2e, worst gradients:' %
+          (l1, float(np.max(np.abs(vals - rvals) / (np.abs(rvals) + 1e-12)))), rows[:4])
+    assert rows[0][0] < 1e-3, rows[:4]
+    # the optimiser ran: every parameter with a clearly non-zero gradient moved by lr in the direction of -g
+    moved = (opt.flat_p - p0)
+    g = opt.flat_g
+    sure = g.abs() > 1e-3 * float(g.abs().max())
+    assert bool(sure.any()) and bool(torch.all(torch.sign(moved[sure]) == -torch.sign(g[sure])))
+    assert float((moved[sure].abs() - 1e-4).abs().max()) < 2e-7
+
+
 def test_dispnets_fullsize_matches_oracle():
     """Whole DispNetS / DispDecoder at 512x432 (2 images), forward and every parameter gradient, vs the CPU oracle.  At this
     size crop_like trims (W: 432,216,108,54,27,14,7,4: upconv outputs 28->27 and 8->7), which the reference-generated golden

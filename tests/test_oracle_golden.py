@@ -63,21 +63,28 @@ def test_conv3d(G, stride):
     assert float((f.grad - ref).abs().max()) < 1e-5 * float(ref.abs().max()) + 1e-7
 
 
-@pytest.mark.parametrize('name', ['mf_64_bs1', 'mf_64_bs2_rnd', 'sf_64_bs1'])
+@pytest.mark.parametrize('name', ['mf_64_bs1', 'mf_64_bs2_rnd', 'sf_64_bs1', 'mf_64_real_sgm', 'sf_64_real_sgm'])
 def test_step_golden(golden_dir, name):
     """(i)-(v) of SURVEY.md section 8(c): data after copy_data, outputs, ordered loss terms, gradients, Adam."""
     Gs = np.load(os.path.join(golden_dir, name + '.npz'))
     arch = str(Gs['arch'])
     H, W, bs = int(Gs['H']), int(Gs['W']), int(Gs['bs'])
-    settings = synth.make_settings(H, W)
+    settings = synth.make_settings(H, W, pattern=str(Gs['pattern']))
     mk = synth.make_random_batch if int(Gs['random_batch']) else synth.make_batch
     batch = mk(settings, bs, 4, seed=int(Gs['bseed']), with_pseudo_gt=bool(int(Gs['use_pseudo_gt'])))
+    real_sgm = 'real_sgm' in Gs.files   # `real` data in the warm-up epochs: SGM disparities + the reference's recorded draws
+    if real_sgm:
+        batch['sgm_disp'] = Gs['sgm_disp']
+        for k in range(4):
+            if f'sgm_noise{k}' in Gs.files:
+                batch[f'_sgm_noise{k}'] = Gs[f'sgm_noise{k}']
     shapes = O.mf_param_shapes() if arch == 'multi_frame' else O.sf_param_shapes()
     params = O.init_params(shapes, seed=int(Gs['pseed']))
     ctx = O.StepContext(settings)
     st = {'step': 0, 'm': {}, 'v': {}}
     res = O.train_step(ctx, arch, params, {k: t(v) for k, v in batch.items()}, adam_state=st, epoch=int(Gs['epoch']),
-                       use_pseudo_gt=bool(int(Gs['use_pseudo_gt'])))
+                       use_pseudo_gt=bool(int(Gs['use_pseudo_gt'])), data_type='real' if real_sgm else 'synthetic')
+    assert len(res['vals']) == len(Gs['vals'])
     outs = res['out'] if isinstance(res['out'], (list, tuple)) else [res['out']]
     for i, o in enumerate(outs):
         assert float((o.detach() - t(Gs[f'out{i}'])).abs().max()) < 1e-5

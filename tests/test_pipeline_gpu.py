@@ -144,13 +144,23 @@ def test_resume_from_reference_checkpoint(golden_dir):
     np.testing.assert_allclose(np.array([float(e.detach()) for e in errs]), G['step2_vals'], rtol=2e-4, atol=2e-6)
     assert float((out.detach().cpu() - torch.from_numpy(G['step2_out0'])).abs().mean()) < 1e-4
     named = dict(net.named_parameters())
-    n = 0
+    n, checked = 0, 0
+    # second moments after the step (exp_avg_sq of the flat buffer, per parameter): where sqrt(v_hat) is well above eps the
+    # update lr * m_hat / (sqrt(v_hat) + eps) is determined by the carried-over moments and the new gradient, so the
+    # parameters must equal the reference's to fp32 rounding; entries with a ~0 second moment may differ by up to 2 lr
+    v_of = {id(p): opt.exp_avg_sq[o:o + p.numel()].view(p.shape) for p, o in zip(opt.params, opt.offsets)}
     for k in G.files:
         if k.startswith('step2_new:') and k[10:] in named:
-            # two Adam steps of |lr| each: a sign flip of a ~0 gradient moves a weight by at most 2 lr
-            assert float((named[k[10:]].detach().cpu() - torch.from_numpy(G[k])).abs().max()) <= 2.1e-4, k
+            p = named[k[10:]]
+            d = (p.detach().cpu() - torch.from_numpy(G[k])).abs()
+            rv = (v_of[id(p)] / (1.0 - 0.999 ** 2)).sqrt().cpu()
+            sure = rv > max(0.05 * float(rv.max()), 1e-6)   # (gradient error <= 2e-4 of the largest entry moves the ratio by < 1e-2)
+            checked += int(sure.sum())
+            if bool(sure.any()):
+                assert float(d[sure].max()) <= 1e-6, (k, float(d[sure].max()))
+            assert float(d.max()) <= 2.1e-4, k
             n += 1
-    assert n > 100
+    assert n > 100 and checked > 1000, (n, checked)
 
 
 def test_device_augmentation_distributions():

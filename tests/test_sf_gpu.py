@@ -169,17 +169,19 @@ def test_dispnets_matches_oracle(H, W):
     print('DispNetS', H, W, 'worst grad rel err', worst)
 
 
-def make_args(bs, use_pseudo_gt):
-    return argparse.Namespace(use_pseudo_gt=use_pseudo_gt, lcn_radius=5, track_length=4, data_type='synthetic',
+def make_args(bs, use_pseudo_gt, data_type='synthetic'):
+    return argparse.Namespace(use_pseudo_gt=use_pseudo_gt, lcn_radius=5, track_length=4, data_type=data_type,
                               architecture='single_frame', epochs=1, warmup_epochs=150, train_batch_size=bs,
                               max_disp=128)
 
 
-@pytest.mark.parametrize('name', ['sf_64_bs1', 'sf_128_bs1_pgt', 'sf_128x108_bs1', 'sf_128_real_pgt'])
+@pytest.mark.parametrize('name', ['sf_64_bs1', 'sf_128_bs1_pgt', 'sf_128x108_bs1', 'sf_128_real_pgt', 'sf_64_real_sgm'])
 def test_sf_step_matches_reference(golden_dir, name):
     """whole DIS-SF / DIS-FTSF step vs fixtures generated by the imported reference.  sf_128x108_bs1: widths
     108,54,27,14,7,4,2,1 - crop_like (reference model/networks.py:242-263) trims 28->27, 8->7 and 2->1 exactly as at
-    512x432.  sf_128_real_pgt: BASELINE config 5 (real pattern, K_processed, baseline 0.0246, pseudo-GT terms)."""
+    512x432.  sf_128_real_pgt: BASELINE config 5 (real pattern, K_processed, baseline 0.0246, pseudo-GT terms).
+    sf_64_real_sgm: `real` data in the warm-up epochs: four SGM terms, one per output scale, each with the noise the
+    reference drew for it (model/single_frame_worker.py:158-163)."""
     from depthinspace_amd import synth
     from depthinspace_amd.model import networks, single_frame_worker
     from depthinspace_amd.trainer import FlatAdam
@@ -188,8 +190,13 @@ def test_sf_step_matches_reference(golden_dir, name):
     settings = synth.make_settings(H, W, pattern=str(G['pattern']))
     batch = synth.make_batch(settings, bs, 4, seed=int(G['bseed']), with_pseudo_gt=pgt, scene=str(G['scene']),
                              motion=float(G['motion']))
+    real_sgm = 'real_sgm' in G.files
+    if real_sgm:
+        batch['sgm_disp'] = G['sgm_disp']
+        for k in range(4):
+            batch[f'_sgm_noise{k}'] = G[f'sgm_noise{k}']
     params = O.init_params(O.sf_param_shapes(), seed=int(G['pseed']))
-    w = single_frame_worker.Worker(make_args(bs, pgt), settings=settings)
+    w = single_frame_worker.Worker(make_args(bs, pgt, 'real' if real_sgm else 'synthetic'), settings=settings)
     w.build_losses()
     w.current_epoch = int(G['epoch'])
     net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=w.imsizes)
@@ -221,13 +228,23 @@ def test_sf_step_matches_reference(golden_dir, name):
         if 'grad:' + k in G.files:
             err = float((g.cpu() - torch.from_numpy(G['grad:' + k])).abs().max()) / scale
             worst = max(worst, err)
-            assert err < 5e-3, (k, err)
-    # (v) parameters after one Adam step, where stored
+            assert err < 2e-3, (k, err)
+    # (v) parameters after one Adam step, where stored: equal to fp32 rounding wherever the reference gradient is well away
+    # from 0 (the first Adam step is lr * g / (|g| + eps)); a ~0 gradient may flip its sign: at most 2 lr there
+    checked = 0
     for k in keys:
         if 'new:' + k in G.files:
             new_ref = torch.from_numpy(G['new:' + k])
-            assert float((named[k].detach().cpu() - new_ref).abs().max()) <= 2.1e-4, k
-    print(name, 'worst grad rel err', worst)
+            d = (named[k].detach().cpu() - new_ref).abs()
+            if 'grad:' + k in G.files:
+                g_ref = torch.from_numpy(G['grad:' + k]).abs()
+                sure = g_ref > max(1e-3 * float(g_ref.max()), 1e-6)
+                checked += int(sure.sum())
+                if bool(sure.any()):
+                    assert float(d[sure].max()) <= 1e-6, (k, float(d[sure].max()))
+            assert float(d.max()) <= 2.1e-4, k
+    assert checked > 1000, checked
+    print(name, 'worst grad rel err', worst, 'post-Adam entries checked to 1e-6:', checked)
 
 
 def test_act_bwd_and_copy_on_channel_ranges():

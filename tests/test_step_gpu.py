@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 from oracle import dis_oracle as O
 
 
-def make_args(arch, bs):
-    return argparse.Namespace(use_pseudo_gt=False, lcn_radius=5, track_length=4, data_type='synthetic',
+def make_args(arch, bs, data_type='synthetic'):
+    return argparse.Namespace(use_pseudo_gt=False, lcn_radius=5, track_length=4, data_type=data_type,
                               architecture=arch, epochs=1, warmup_epochs=150, train_batch_size=bs, max_disp=128)
 
 
@@ -27,6 +27,13 @@ def golden_batch(G):
     else:
         batch = synth.make_batch(settings, bs, 4, seed=int(G['bseed']), with_pseudo_gt=pgt, scene=str(G['scene']),
                                  motion=float(G['motion']))
+    if 'real_sgm' in G.files:
+        # `real` data during the warm-up epochs: the SGM disparities and the noise the REFERENCE drew inside its loss
+        # expression (recorded by oracle/make_golden.py, already scaled by 1.5) travel with the batch
+        batch['sgm_disp'] = G['sgm_disp']
+        for k in range(4):
+            if f'sgm_noise{k}' in G.files:
+                batch[f'_sgm_noise{k}'] = G[f'sgm_noise{k}']
     return settings, batch
 
 
@@ -42,7 +49,8 @@ def run_hip_step(G, force_reference_knn=False):
     net = net.cuda()
     if force_reference_knn:  # diagnostic only: no test uses it (the HIP selection IS the reference's, see below)
         net.knn_index_override = (torch.from_numpy(G['knn_idx_core']).cuda(), torch.from_numpy(G['knn_idx_quarter']).cuda())
-    w = multi_frame_worker.Worker(make_args('multi_frame', bs), settings=settings)
+    w = multi_frame_worker.Worker(make_args('multi_frame', bs, 'real' if 'real_sgm' in G.files else 'synthetic'),
+                                  settings=settings)
     w.build_losses()
     w.current_epoch = int(G['epoch'])
     opt = FlatAdam(net.parameters(), lr=1e-4)
@@ -51,7 +59,9 @@ def run_hip_step(G, force_reference_knn=False):
     return net, opt, errs, out
 
 
-MF_GOLDENS = ['mf_64_bs1', 'mf_64_bs2_rnd', 'mf_128_bs1', 'mf_128_bumps']
+# mf_64_real_sgm: `real` data, epoch < warmup_epochs - the step carries the SGM warm-up term (reference
+# model/multi_frame_worker.py:168-173) with the reference's own noise draw
+MF_GOLDENS = ['mf_64_bs1', 'mf_64_bs2_rnd', 'mf_128_bs1', 'mf_128_bumps', 'mf_64_real_sgm']
 
 
 def test_mf_step_with_deterministic_conv3d_gradient(golden_dir):
@@ -113,13 +123,23 @@ def test_mf_step_matches_reference(golden_dir, name):
         if 'grad:' + k in G.files:
             err = float((g.cpu() - torch.from_numpy(G['grad:' + k])).abs().max()) / scale
             worst = max(worst, err)
-            assert err < 5e-3, (k, err)
+            assert err < 1e-3, (k, err)   # measured <= 2e-4
     # (v) parameters after one Adam step, where stored
+    checked = 0
     for k in keys:
         if 'new:' + k in G.files:
             new_ref = torch.from_numpy(G['new:' + k])
-            # Adam's first step moves every weight by ~lr*sign(g); sign flips of ~0 gradients allow 2*lr
-            assert float((named[k].detach().cpu() - new_ref).abs().max()) <= 2.1e-4, k
-    print(name, 'disp L1', l1, 'max', mx, 'worst grad rel err', worst)
+            d = (named[k].detach().cpu() - new_ref).abs()
+            # Adam's first step moves every weight by lr * g / (|g| + eps): where the reference gradient is well away from 0
+            # the step is determined (its sensitivity to a gradient error dg is lr * eps / g^2 * dg), so the parameters must
+            # agree to fp32 rounding; only entries with a ~0 gradient may differ, by at most 2 lr (a sign flip)
+            g_ref = torch.from_numpy(G['grad:' + k]).abs()
+            sure = g_ref > max(1e-3 * float(g_ref.max()), 1e-6)
+            checked += int(sure.sum())
+            if bool(sure.any()):
+                assert float(d[sure].max()) <= 1e-6, (k, float(d[sure].max()))
+            assert float(d.max()) <= 2.1e-4, k
+    assert checked > 1000, checked
+    print(name, 'disp L1', l1, 'max', mx, 'worst grad rel err', worst, 'post-Adam entries checked to 1e-6:', checked)
 
 
