@@ -60,7 +60,7 @@ def conv_flops(n, ho, wo, cin, cout, k):
     return 2.0 * n * ho * wo * cin * cout * k * k
 
 
-def cpu_baseline(arch='multi_frame', timed_steps=3):
+def cpu_baseline(arch='multi_frame', timed_steps=3, knn_sets=None):
     """Oracle training step on the host cores: 1 warm-up + `timed_steps` timed steps (Adam state carried along), bs=1
     (one 4-frame track), full resolution.  The bounded sample of BASELINE.md section 3; reported, never the target."""
     from depthinspace_amd import synth
@@ -88,6 +88,19 @@ def cpu_baseline(arch='multi_frame', timed_steps=3):
         torch.set_num_threads(nthr)
     dt = sum(times[1:]) / timed_steps
     tag = 'DIS-MF' if arch == 'multi_frame' else 'DIS-SF'
+    if knn_sets is not None and arch == 'multi_frame':
+        # (untimed) the oracle forward once more from the initial parameters, on the HIP path's Conv3D neighbour sets: the
+        # oracle's own top-9-of-36 depends on how THIS host's BLAS rounds a K = 3 product at exact key ties, which is not
+        # the rounding of the host the reference fixtures were generated on; the HIP selection is
+        # pinned to the reference's by tests/test_step_gpu.py and tests/test_fullsize_gpu.py
+        p0 = O.init_params(O.mf_param_shapes(), seed=0)
+        O.CONV3D_FORCE = {'core': knn_sets[0].long(), 'quarter': knn_sets[1].long()}
+        try:
+            with torch.no_grad():
+                data = O.copy_data(ctx, tb)
+                first['out_forced'] = O.mf_net_forward(ctx, p0, data, O.read_optical_flow(data, TL)).detach().clone()
+        finally:
+            O.CONV3D_FORCE = None
     return {'value': TL / dt, 'unit': 'frames/s', 'cores': want, 'kind': 'port',
             'sample': f'CPU oracle training step, {tag} bs=1 (one 4-frame track) 512x432 fp32: 1 warm-up ({times[0]:.1f} s) + '
                       f'{timed_steps} timed steps (mean {dt:.1f} s), torch threads={want} of os.cpu_count()={os.cpu_count()}'}, first
@@ -444,12 +457,17 @@ def main():
         # BASELINE metric, second half ("disp L1 vs ref"): the HIP forward on the oracle's bs=1 inputs and initial parameters
         # against the disparity of the oracle's first (warm-up) step; north-star bar 1e-4 px for the fp32 path
         hip_out, hip_vals, hip_sets = hip_first_step(args.arch, settings, dev, args.dtype)
-        cpu, first = cpu_baseline(args.arch)
-        d = (hip_out.reshape(-1) - first['out'].float().reshape(-1)).abs()
+        cpu, first = cpu_baseline(args.arch, knn_sets=hip_sets)
+        d_free = (hip_out.reshape(-1) - first['out'].float().reshape(-1)).abs()
+        d = (hip_out.reshape(-1) - first['out_forced'].float().reshape(-1)).abs() if 'out_forced' in first else d_free
         l1_ref = {'value': float(d.mean()), 'max': float(d.max()), 'unit': 'px', 'bar': 1e-4 if args.dtype == 'f32' else 0.05,
-                  'loss_terms_max_abs_diff': max(abs(a - b) for a, b in zip(hip_vals, first['vals'])),
+                  'vs_free_running_oracle_on_this_host': {'value': float(d_free.mean()), 'max': float(d_free.max())},
+                  'loss_terms_max_abs_diff_free_running': max(abs(a - b) for a, b in zip(hip_vals, first['vals'])),
                   'sample': 'bs=1 (one 4-frame track, batch seed 1234, init_params(seed=0)), 512x432: free-running HIP forward vs '
-                            'the free-running CPU oracle of cpu_baseline on this host'}
+                            'the CPU oracle' + (' evaluated on the HIP path\'s Conv3D neighbour sets (`value`; those sets are '
+                            'pinned to the reference\'s torch.topk output by the parity tests) and vs the oracle free-running '
+                            'on this host, whose own top-k breaks exact key ties by this host\'s BLAS rounding'
+                            if 'out_forced' in first else ' of cpu_baseline on this host')}
 
     if rank == 0:
         frames = world * args.bs * TL * args.steps

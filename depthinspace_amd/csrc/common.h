@@ -76,6 +76,16 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
   return 1.f;
 }
 
+// GroupNorm(1 group) moments of sample n from its fp64 sum / sum of squares over m elements (shared by the GroupNorm kernels
+// and by the conv kernels that apply the normalisation while they stage their input: identical bits everywhere)
+__device__ __forceinline__ void gn_moments(const double* stats, int n, double m, float eps, float* mean, float* rstd) {
+  const double mu = stats[2 * n] / m;
+  double var = stats[2 * n + 1] / m - mu * mu;
+  if (var < 0.0) var = 0.0;
+  *mean = (float)mu;
+  *rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 // The reference normalises pixel coordinates to [-1,1] and grid_sample maps them back
 // (networks.py:363-364 -> ATen grid_sampler, align_corners=True).  Reproduce that round trip so that
 // sampling positions carry the same fp32 rounding as the reference's.

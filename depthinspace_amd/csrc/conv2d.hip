@@ -48,6 +48,13 @@ struct ConvArgs {
   // entries that exist
   int ldx, ldy, cx, cy, x_sub, y_sub, nbias;
   int wtap0, wtap_step;  // tap-row instances (1 x 7 window of a 7x7 weight): see the weight prologue
+  // bf16x3 kernel, INGN instances: x is the PRE-GroupNorm tensor (output of the producing conv + activation); the affine map
+  // of GroupNorm(1 group) - per sample rstd * gamma_c, beta_c - rstd * gamma_c * mean - is applied while the halo is staged,
+  // the zero padding stays zero.  gn_stats (n, 2) fp64 sum / sum of squares, as dis_gn_apply takes them.
+  const double* gn_stats;
+  const float* gn_gamma;
+  const float* gn_beta;
+  float gn_eps;
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -608,11 +615,16 @@ extern "C" int dis_debug_bx_stamps(unsigned long long* host) {
 // consecutive output channels of one pixel and stores a float4.
 // INACT != 0 (input-gradient launches of a conv that had an activation): x is the gradient wrt the activation's OUTPUT
 // and a.xact that output; the halo is staged as x * act'(xact), which replaces a separate pass over the tensor.
-template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool GEN = false, int KHT = 3, int KWT = 3>
+// INGN: x is a conv output whose GroupNorm has NOT been applied in memory: the halo is staged as x * scale_c + shift_c of its
+// sample (the arithmetic of gn_apply_kernel, bit for bit), pixels outside the image stay zero.  Replaces a dis_gn_apply pass
+// (read + write of the whole tensor) between a conv -> act -> GroupNorm -> conv pair (reference ResNetBlock, multi_frame_networks.py:514-542).
+template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool GEN = false, int KHT = 3, int KWT = 3,
+          bool INGN = false>
 __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
   using C = BxCfg<CIN, COUT, KHT, KWT>;
   constexpr int BX_IC = C::IC;
   static_assert(!GEN || (!STATS && INACT == 0), "slice form: plain convolution / input gradient");
+  static_assert(!INGN || (!GEN && INACT == 0 && 512 % C::CV == 0), "GroupNorm on load: dense forward instances");
   static_assert(GEN || (KHT == 3 && KWT == 3), "tap rows are a slice-launch form");
   const int ldx = GEN ? a.ldx : CIN, ldy = GEN ? a.ldy : COUT;  // floats per pixel
   constexpr int PS = C::PS, NT = C::NT, KS = C::KS, NLOAD = C::NLOAD, NPIECE = C::NPIECE, CV = C::CV;
@@ -669,12 +681,35 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
       pre2[it] = __builtin_bit_cast(
           float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.xact + (pf_x - a.x), pf_bytes), off, 0, 0));
   };
-  auto stage = [&]() {
+  // INGN: this thread's 4 channels are the same for all its items (512 % CV == 0)
+  float4 gn_g = make_float4(0.f, 0.f, 0.f, 0.f), gn_b = gn_g, gn_sc = gn_g, gn_sh = gn_g;
+  int gn_n = -1;
+  if (INGN) {
+    gn_g = *(const float4*)(a.gn_gamma + ((int)threadIdx.x % CV) * 4);
+    gn_b = *(const float4*)(a.gn_beta + ((int)threadIdx.x % CV) * 4);
+  }
+  auto stage = [&](int n_cur) {
+    if (INGN && n_cur != gn_n) {  // (block-uniform) a new sample: its scale / shift
+      gn_n = n_cur;
+      float mean, rstd;
+      gn_moments(a.gn_stats, n_cur, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
+      gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
+      gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the halo loads (one unconditional wait, not one per divergent item)
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
       if ((int)threadIdx.x + it * 512 < C::NITEMS) {
         float4 v = pre[it];
+        if (INGN) {
+          // (pf_iy0 / pf_ix0 still describe the tile being staged: pf_setup of the next one runs after this)
+          const int iy = pf_iy0 + (it_rc[it] & 0xffff), ix = pf_ix0 + (it_rc[it] >> 16);
+          const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+          v.x = ok ? v.x * gn_sc.x + gn_sh.x : 0.f;
+          v.y = ok ? v.y * gn_sc.y + gn_sh.y : 0.f;
+          v.z = ok ? v.z * gn_sc.z + gn_sh.z : 0.f;
+          v.w = ok ? v.w * gn_sc.w + gn_sh.w : 0.f;
+        }
         if (INACT) {
           const float4 q = pre2[it];
           v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
@@ -845,7 +880,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     BX_T(0)
     __syncthreads();  // every wave has finished reading the previous halo tile
     BX_T(1)
-    stage();
+    stage(cn);
     BX_T(2)
     __syncthreads();
     BX_T(3)
@@ -1022,9 +1057,11 @@ template <int CIN, int COUT>
 static hipError_t bx_launch(const ConvArgs& a, bool stats, int inact, long grid, hipStream_t stream) {
   using C = BxCfg<CIN, COUT>;
   const int variant = (a.act * 2 + a.accum) * 2 + (stats ? 1 : 0);
-  static bool attr_set[12 + 4] = {};
+  const bool ingn = a.gn_stats != nullptr;
+  static bool attr_set[12 + 4 + 4] = {};
   auto launch = [&](auto kern) -> hipError_t {
-    bool& set = attr_set[inact ? 12 + (inact - 1) * 2 + a.accum : variant];
+    bool& set = attr_set[ingn ? 16 + (a.act == DIS_ACT_SELU ? 2 : 0) + (stats ? 1 : 0)
+                              : (inact ? 12 + (inact - 1) * 2 + a.accum : variant)];
     if (!set) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
       if (e != hipSuccess) return e;
@@ -1033,6 +1070,18 @@ static hipError_t bx_launch(const ConvArgs& a, bool stats, int inact, long grid,
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
     return hipSuccess;
   };
+  if (ingn) {  // GroupNorm applied on load: the consumer convs of the conv -> act -> GroupNorm -> conv chains (forward only)
+    if constexpr (CIN == COUT) {
+      if (inact || a.accum || (a.act != DIS_ACT_NONE && a.act != DIS_ACT_SELU)) return hipErrorInvalidValue;
+      if (a.act == DIS_ACT_SELU)
+        return stats ? launch(conv_bf16x3_kernel<CIN, COUT, DIS_ACT_SELU, false, true, 0, false, 3, 3, true>)
+                     : launch(conv_bf16x3_kernel<CIN, COUT, DIS_ACT_SELU, false, false, 0, false, 3, 3, true>);
+      return stats ? launch(conv_bf16x3_kernel<CIN, COUT, DIS_ACT_NONE, false, true, 0, false, 3, 3, true>)
+                   : launch(conv_bf16x3_kernel<CIN, COUT, DIS_ACT_NONE, false, false, 0, false, 3, 3, true>);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (inact) {  // input gradient with the activation gradient fused into the staging: no epilogue activation, no statistics
     if (a.act != DIS_ACT_NONE || stats) return hipErrorInvalidValue;
     if (inact == DIS_ACT_SELU)
@@ -1078,9 +1127,15 @@ extern "C" int dis_conv2d_pack_weights_bf16x3(const float* w_oihw, void* packed,
   return DIS_OK;
 }
 
+struct GnIn {  // GroupNorm applied to x on load (ConvArgs::gn_stats ...); stats == nullptr: none
+  const double* stats = nullptr;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float eps = 0.f;
+};
 static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o, int w_i, int w_rs, const float* bias, float* y,
                               double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad,
-                              int act, void* stream, const float* xact = nullptr, int inact = 0) {
+                              int act, void* stream, const float* xact = nullptr, int inact = 0, GnIn gn = GnIn()) {
   if (!x || !w || !y) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0 || pad < 0) return DIS_ERR_BAD_SHAPE;
   if (!bx_shape_ok(cin, cout, k, stride)) return DIS_ERR_UNSUPPORTED;
@@ -1099,6 +1154,10 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
   a.w_i = w_i;
   a.w_rs = w_rs;
   a.xact = xact;
+  a.gn_stats = gn.stats; a.gn_gamma = gn.gamma; a.gn_beta = gn.beta; a.gn_eps = gn.eps;
+  if (gn.stats && (!gn.gamma || !gn.beta)) return DIS_ERR_NULL;
+  if (gn.stats && (cin != cout || inact || (act & DIS_CONV_ACCUM) || ((act & 0xff) != DIS_ACT_NONE && (act & 0xff) != DIS_ACT_SELU)))
+    return DIS_ERR_UNSUPPORTED;
   if (inact < 0 || inact > DIS_ACT_RELU || (inact && !xact)) return DIS_ERR_UNSUPPORTED;
   if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
   // the kernel addresses x and y per sample through buffer descriptors with 31-bit byte offsets
@@ -1139,6 +1198,23 @@ extern "C" int dis_conv2d_fwd_bf16x3_oihw(const float* x, const float* w_oihw, i
   if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
   return launch_conv_bf16x3(x, w_oihw, mode, w_o, w_i, w_row_stride, bias, y, stats, n, hin, win, cin, cout, k, stride,
                             pad, act, stream);
+}
+/* dis_conv2d_fwd_bf16x3_oihw(mode 0) of GroupNorm(x): x is the PRE-normalisation tensor, gn_stats (n, 2) its fp64 per-sample
+ * sum / sum of squares, gn_gamma / gn_beta (cin) the GroupNorm(1 group) parameters.  y = act(conv(gn(x)) + bias), equal bit for
+ * bit to dis_gn_apply followed by the plain call; the normalised tensor never exists in memory.  cin == cout, no accumulate. */
+extern "C" int dis_conv2d_fwd_bf16x3_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta,
+                                        float gn_eps, const float* w_oihw, int w_o, int w_i, int w_row_stride,
+                                        const float* bias, float* y, double* stats, int n, int hin, int win, int cin,
+                                        int cout, int k, int stride, int pad, int act, void* stream) {
+  if (!gn_stats || !gn_gamma || !gn_beta) return DIS_ERR_NULL;
+  if (w_o <= 0 || w_i <= 0 || w_o > 32 || w_i > 32) return DIS_ERR_UNSUPPORTED;
+  if (cout != w_o || cin != w_i) return DIS_ERR_BAD_SHAPE;
+  if (w_row_stride == 0) w_row_stride = w_i * 9;
+  if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
+  GnIn gn;
+  gn.stats = gn_stats; gn.gamma = gn_gamma; gn.beta = gn_beta; gn.eps = gn_eps;
+  return launch_conv_bf16x3(x, w_oihw, 0, w_o, w_i, w_row_stride, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act,
+                            stream, nullptr, 0, gn);
 }
 /* Input gradient of a 3x3 stride-1 convolution that was followed by an activation, with the activation's gradient fused
  * in: gx (+)= conv_T(gy * act'(y), w) where y (same shape as gy) is the activation's output.  Replaces dis_act_bwd +
@@ -1205,6 +1281,7 @@ int dis_bx_slices_run(int dgrad, const float* x, int ldx, int xoff, int cin, int
       a.accum = first ? 0 : 1;
       if (!first) a.bias = nullptr;
       a.xscale = nullptr; a.yscale = nullptr; a.xact = nullptr;
+      a.gn_stats = nullptr; a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_eps = 0.f;
       a.ldx = ldx; a.ldy = ldy;
       a.cx = cin - 32 * cb < 32 ? cin - 32 * cb : 32;
       a.cy = cout - 32 * gb < 32 ? cout - 32 * gb : 32;
@@ -1293,6 +1370,11 @@ struct WgArgs {
   // ldx / ldg floats, the layer's channels start at xoff / goff and there are cx / cg of them; blockIdx.y = gb * npx + cb
   // selects x channels [32 cb, 32 cb + 32) and gy channels [32 gb, 32 gb + 32)
   int ldx, xoff, cx, ldg, goff, cg, npx;
+  // bf16x3 kernel, INGN instances: x is staged as GroupNorm(x) (see ConvArgs::gn_stats)
+  const double* gn_stats;
+  const float* gn_gamma;
+  const float* gn_beta;
+  float gn_eps;
 };
 
 template <int CIN, int COUT, int KH, int KW, int S>
@@ -1621,13 +1703,18 @@ __device__ __forceinline__ s16x8 tr_read8(const unsigned short* p0, const unsign
   return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int CIN, int COUT, int INACT = 0, bool GEN = false, int K = 3, int S = 1, int TR = 8, int KH = K, bool BF = false>
+// INGN: x is staged as GroupNorm(x) (the consumer conv of a conv -> act -> GroupNorm -> conv chain: its input was never
+// written in normalised form, see conv_bf16x3_kernel); padding pixels stay zero.
+template <int CIN, int COUT, int INACT = 0, bool GEN = false, int K = 3, int S = 1, int TR = 8, int KH = K, bool BF = false,
+          bool INGN = false>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   // BF: x and gy hold bf16 values (a.x / a.gy point at 16-bit elements; ldx / xoff / ldg / goff count elements): one plane,
   // one product per MAC, no split - the bf16 activation storage mode of DispNetS (conv_bf16.hip)
   constexpr int NP = BF ? 1 : 3, CPI = BF ? 8 : 4, ES = BF ? 2 : 4;
   static_assert(!BF || (GEN && INACT == 0), "bf16 inputs: slice-pair form only");
+  static_assert(!INGN || (!GEN && !BF), "GroupNorm on load: the FuseNet form");
   using C = WxCfg<CIN, COUT, K, S, TR, KH, NP, CPI>;
+  static_assert(!INGN || 256 % C::CVX == 0, "a thread keeps its 4 channels over its items");
   const int ky0 = KH < K ? (int)blockIdx.z * KH : 0;  // first tap row of this workgroup (7x7: two groups of 4 rows)
   constexpr int WX_IC = C::IC;
   static_assert(GEN || (K == 3 && S == 1 && TR == 8), "the FuseNet form");
@@ -1674,9 +1761,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
     ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * ldg + gc0 + vv * CPI) * ES;
   }
   const unsigned x_bytes = (unsigned)a.hin * a.win * (ldx * (unsigned)ES), g_bytes = (unsigned)a.hout * a.wout * (ldg * (unsigned)ES);
+  // INGN: origin and sample of the tile whose items are in flight (stage() runs before the next prefetch), this thread's
+  // GroupNorm parameters and the scale / shift of the current sample
+  int st_iy0 = 0, st_ix0 = 0, st_n = -1, gn_n = -1;
+  float4 gn_g = make_float4(0.f, 0.f, 0.f, 0.f), gn_b = gn_g, gn_sc = gn_g, gn_sh = gn_g;
+  if (INGN) {
+    gn_g = *(const float4*)(a.gn_gamma + ((int)threadIdx.x % C::CVX) * 4);
+    gn_b = *(const float4*)(a.gn_beta + ((int)threadIdx.x % C::CVX) * 4);
+  }
   auto prefetch = [&](int tile) __attribute__((always_inline)) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * (TR * S) - a.pad + ky0, ix0 = tx * (16 * S) - a.pad;
+    if (INGN) st_iy0 = iy0, st_ix0 = ix0, st_n = n;
     const char* xb = (const char*)a.x + (long)n * a.hin * a.win * ldx * ES;
     const int xoff0 = (iy0 * a.win + ix0) * (ldx * ES);
 #pragma unroll
@@ -1713,11 +1809,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
     *(uint2*)(p + 2 * plane) = make_uint2(a3, b3);
   };
   auto stage = [&]() __attribute__((always_inline)) {
+    if (INGN && st_n != gn_n) {  // (block-uniform) a new sample
+      gn_n = st_n;
+      float mean, rstd;
+      gn_moments(a.gn_stats, st_n, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
+      gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
+      gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one unconditional wait for the prefetched tile
 #pragma unroll
     for (int it = 0; it < NLX; ++it) {
       const int idx = (int)threadIdx.x + it * 256;
-      if (idx < C::NIX) put3(xl + (idx / C::CVX) * PSX + (idx % C::CVX) * CPI, prex[it], CIN);
+      if (idx < C::NIX) {
+        float4 v = prex[it];
+        if (INGN) {
+          const int iy = st_iy0 + (ix_rc[it] & 0xffff), ix = st_ix0 + (ix_rc[it] >> 16);
+          const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+          v.x = ok ? v.x * gn_sc.x + gn_sh.x : 0.f;
+          v.y = ok ? v.y * gn_sc.y + gn_sh.y : 0.f;
+          v.z = ok ? v.z * gn_sc.z + gn_sh.z : 0.f;
+          v.w = ok ? v.w * gn_sc.w + gn_sh.w : 0.f;
+        }
+        put3(xl + (idx / C::CVX) * PSX + (idx % C::CVX) * CPI, v, CIN);
+      }
     }
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
@@ -1840,7 +1954,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
   }
 }
 
-template <int CIN, int COUT, int INACT = 0>
+template <int CIN, int COUT, int INACT = 0, bool INGN = false>
 static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hipStream_t s) {
   using C = WgCfg<CIN, COUT, 3, 3, 1>;
   using X = WxCfg<CIN, COUT>;
@@ -1850,7 +1964,7 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
     return DIS_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_bf16x3_kernel<CIN, COUT, INACT>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_bf16x3_kernel<CIN, COUT, INACT, false, 3, 1, 8, 3, false, INGN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, X::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -1863,7 +1977,8 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
   const long elems = C::PART;
   float* tmp = a.part + (long)WG_WORKERS * elems;
   a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
-  hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<CIN, COUT, INACT>), dim3((unsigned)workers), dim3(256), X::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<CIN, COUT, INACT, false, 3, 1, 8, 3, false, INGN>), dim3((unsigned)workers),
+                     dim3(256), X::LDS_BYTES, s, a);
   const long total = (long)C::MROWS * COUT;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(64 * WG_RW), 0, s,
                      (const float*)a.part, gw, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, COUT, cin_real, C::PART,
@@ -2023,7 +2138,7 @@ extern "C" long dis_conv2d_wgrad_workspace(int cin, int cout, int k, int stride)
 // same contract as dis_conv2d_wgrad (and the same workspace size) for cin = cout = 32, k = 3, stride 1
 static int wgrad_bf16x3_entry(const float* x, const float* gy, const float* gact, int inact, float* grad_w, float* grad_b,
                               float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k,
-                              int stride, int pad, void* stream) {
+                              int stride, int pad, void* stream, GnIn gn = GnIn()) {
   if (!x || !gy || !grad_w || !workspace) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0) return DIS_ERR_BAD_SHAPE;
   if (!bx_shape_ok(cin_pad, cout, k, stride) || cin_real <= 0 || cin_real > cin_pad) return DIS_ERR_UNSUPPORTED;
@@ -2035,7 +2150,16 @@ static int wgrad_bf16x3_entry(const float* x, const float* gy, const float* gact
   a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
   a.xscale = nullptr;
   a.gact = gact;
+  a.gn_stats = gn.stats; a.gn_gamma = gn.gamma; a.gn_beta = gn.beta; a.gn_eps = gn.eps;
   hipStream_t s = (hipStream_t)stream;
+  if (gn.stats) {  // x = GroupNorm(x) on load: the square shapes of the conv -> act -> GroupNorm -> conv chains
+    if (!gn.gamma || !gn.beta) return DIS_ERR_NULL;
+    if (cin_pad != cout || cin_real != cin_pad) return DIS_ERR_UNSUPPORTED;
+    // (the consumers' own activation gradient arrives folded into gy: GroupNorm's backward emits the pre-activation gradient)
+    if (inact != 0) return DIS_ERR_UNSUPPORTED;
+    if (cout == 32) return launch_wgrad_bf16x3<32, 32, 0, true>(a, grad_w, grad_b, cin_real, s);
+    return launch_wgrad_bf16x3<16, 16, 0, true>(a, grad_w, grad_b, cin_real, s);
+  }
 #define WX_DISPATCH(CI, CO)                                                                                      \
   if (cin_pad == CI && cout == CO) {                                                                             \
     if (inact == DIS_ACT_SELU) return launch_wgrad_bf16x3<CI, CO, DIS_ACT_SELU>(a, grad_w, grad_b, cin_real, s); \
@@ -2060,6 +2184,19 @@ extern "C" int dis_conv2d_wgrad_bf16x3_act(const float* x, const float* gy, cons
   if (!y || act == DIS_ACT_NONE) return DIS_ERR_UNSUPPORTED;
   return wgrad_bf16x3_entry(x, gy, y, act, grad_w, grad_b, workspace, n, hin, win, cin_pad, cin_real, cout, k, stride, pad,
                             stream);
+}
+
+/* dis_conv2d_wgrad_bf16x3 with x = GroupNorm(x) applied on load (see dis_conv2d_fwd_bf16x3_gn); gy is the gradient wrt the
+ * conv's pre-activation output.  cin_pad == cin_real == cout in {16, 32}. */
+extern "C" int dis_conv2d_wgrad_bf16x3_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta,
+                                          float gn_eps, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
+                                          int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,
+                                          void* stream) {
+  if (!gn_stats || !gn_gamma || !gn_beta) return DIS_ERR_NULL;
+  GnIn gn;
+  gn.stats = gn_stats; gn.gamma = gn_gamma; gn.beta = gn_beta; gn.eps = gn_eps;
+  return wgrad_bf16x3_entry(x, gy, nullptr, 0, grad_w, grad_b, workspace, n, hin, win, cin_pad, cin_real, cout, k, stride, pad,
+                            stream, gn);
 }
 
 extern "C" int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace,

@@ -218,13 +218,6 @@ extern "C" int dis_gn_stats(const float* x, double* stats, int n, long per_sampl
 
 #define GN_MAXC 128
 
-__device__ __forceinline__ void gn_moments(const double* stats, int n, double m, float eps, float* mean, float* rstd) {
-  const double mu = stats[2 * n] / m;
-  double var = stats[2 * n + 1] / m - mu * mu;
-  if (var < 0.0) var = 0.0;
-  *mean = (float)mu;
-  *rstd = (float)(1.0 / sqrt(var + (double)eps));
-}
 
 // y = act(x*scale_c + shift_c (+ residual)),  scale_c = rstd*gamma_c, shift_c = beta_c - scale_c*mean
 // Non-temporal loads / stores for the GroupNorm passes (bit 0: forward apply, 1 / 2: backward apply loads / store, 3: backward

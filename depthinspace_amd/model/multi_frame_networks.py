@@ -91,8 +91,13 @@ class ResNetBlock(torch.nn.Module):
     def forward(self, x):
         j = ops.GradJoin() if x.requires_grad else None  # x feeds conv1 and the residual: one shared gradient buffer
         o, st = ops.conv2d(x, self.conv1.weight, self.conv1.bias, 1, 1, SELU, want_stats=True, gy_is_pre=True, join=j)
-        o = ops.group_norm(o, self.bn1.weight, self.bn1.bias, stats=st, in_act=SELU)
-        o, st = ops.conv2d(o, self.conv2.weight, self.conv2.bias, 1, 1, NONE, want_stats=True)
+        if ops.gn_fusable(o.shape[-1], self.conv2.weight.shape[0], 3, 1):
+            # bn1 is applied by conv2 while it stages its input: GN1(...) is never written
+            o, st = ops.conv2d_gn_in(o, st, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.conv2.bias, 1, NONE,
+                                     want_stats=True, in_act=SELU)
+        else:
+            o = ops.group_norm(o, self.bn1.weight, self.bn1.bias, stats=st, in_act=SELU)
+            o, st = ops.conv2d(o, self.conv2.weight, self.conv2.bias, 1, 1, NONE, want_stats=True)
         return ops.group_norm(o, self.bn2.weight, self.bn2.bias, stats=st, residual=x, act=SELU, join=j)
 
 
@@ -143,6 +148,17 @@ class Block2D3D(TimedModule):
                            join=join)
         return ops.group_norm(o, slots[gn_idx].weight, slots[gn_idx].bias, stats=st, in_act=act)
 
+    @staticmethod
+    def _conv_gn_pair(x, s1, s2, stride1, join=None):
+        """GN(SELU(conv_s2(GN(SELU(conv_s1(x)))))) (reference :338-345: two Conv-SELU-GroupNorm stages): the first GroupNorm is
+        applied by the second conv while it stages its input (ops.conv2d_gn_in), the second one is written"""
+        if not ops.gn_fusable(s1[1].weight.shape[0], s2[1].weight.shape[0], s2[1].weight.shape[2], 1):
+            return Block2D3D._conv_gn(Block2D3D._conv_gn(x, s1, 3, stride1, 1, SELU, join), s2, 3, 1, 1, SELU)
+        o, st = ops.conv2d(x, s1[1].weight, s1[1].bias, stride1, 1, SELU, want_stats=True, gy_is_pre=True, join=join)
+        o, st = ops.conv2d_gn_in(o, st, s1[3].weight, s1[3].bias, s2[1].weight, s2[1].bias, 1, SELU, want_stats=True,
+                                 gy_is_pre=True, in_act=SELU)
+        return ops.group_norm(o, s2[3].weight, s2[3].bias, stats=st, in_act=SELU)
+
     def tforward(self, feat, geom, geom_q, flows, flows_q, idx=None, idx_q=None, csr=None, csr_q=None, wgt=None):
         """feat (tl,bs,h,w,C) nhwc.  geom/geom_q: core / quarter geometry; flows/flows_q: (tl*tl,bs,.,.,2);
         idx/idx_q: neighbour sets of the two Conv3D layers (shared by all blocks: they depend on geometry only)."""
@@ -165,10 +181,8 @@ class Block2D3D(TimedModule):
         o, st = ops.conv2d_scaled_in(wf.view(N, h, w, tl * C), wgt, self.conv_mf[1].weight, self.conv_mf[1].bias, 1, 0,
                                      want_stats=True, join=j_wf)
         mf = ops.group_norm(o, self.conv_mf[2].weight, self.conv_mf[2].bias, stats=st)
-        a = self._conv_gn(mf, self.conv1_1, 3, 1, 1, SELU, j_mf)
-        a = self._conv_gn(a, self.conv1_2, 3, 1, 1, SELU)
-        b = self._conv_gn(mf, self.conv2_1, 3, 2, 1, SELU, j_mf)
-        b = self._conv_gn(b, self.conv2_2, 3, 1, 1, SELU)
+        a = self._conv_gn_pair(mf, self.conv1_1, self.conv1_2, 1, j_mf)
+        b = self._conv_gn_pair(mf, self.conv2_1, self.conv2_2, 2, j_mf)
         b = ops.resize_nhwc(b, (2 * b.shape[1], 2 * b.shape[2]), True)
         c = ops.resize_nhwc(o3d2.view(N, hq, wq, C), (2 * hq, 2 * wq), True)
         # conv over cat(a, b, c) as three accumulating 32->32 launches: the 96-channel tensor never exists

@@ -680,6 +680,87 @@ def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, nee
     return _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre, join)
 
 
+GN_FUSE = _os.environ.get('DIS_GN_FUSE', '1') != '0'
+
+
+def gn_fusable(cin, cout, k, stride):
+    """conv2d_gn_in exists for the bf16x3 square shapes (3x3, stride 1, 16 -> 16 / 32 -> 32)"""
+    return GN_FUSE and BF16X3 and cin == cout and cin in (16, 32) and k == 3 and stride == 1
+
+
+class _Conv2dGnIn(torch.autograd.Function):
+    """y = act(conv3x3(GroupNorm(x)) + bias) where the GroupNorm (1 group; its statistics `gn_stats` come from the epilogue of
+    the conv that produced x) is applied by the conv kernels while they stage x: the normalised tensor is never written or
+    read (reference: the conv -> SELU -> GroupNorm -> conv chains of ResNetBlock / Block2D3D, model/multi_frame_networks.py
+    :338-345,:514-542).  One autograd node for the pair GroupNorm + conv: its backward runs the conv's input gradient, the
+    GroupNorm backward (which hands the producer of x its PRE-activation gradient when `in_act` is that producer's
+    activation) and the conv's weight gradient with the same on-load normalisation."""
+
+    @staticmethod
+    def forward(ctx, x, gn_stats, gamma, beta, weight, bias, pad, act, want_stats, gy_is_pre, eps, in_act):
+        x, weight = _c(x), _c(weight)
+        _chk(x, gamma, beta, weight, bias)
+        n, h, w, cin = x.shape
+        cout, _, k, _ = weight.shape
+        assert gn_fusable(cin, cout, k, 1) and weight.shape[1] == cin
+        ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+        y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+        stats = _zeros_d(2 * n, x.device) if want_stats else None
+        lib.call('dis_conv2d_fwd_bf16x3_gn', x, gn_stats, gamma, beta, float(eps), weight, cout, cin, weight.stride(0), bias, y,
+                 stats, n, h, w, cin, cout, k, 1, pad, act)
+        if gy_is_pre:
+            act = ACT_NONE
+        ctx.save_for_backward(x, gn_stats, gamma, weight, y if act != ACT_NONE else None)
+        ctx.cfg = (pad, act, bias is not None, float(eps), in_act)
+        ctx.bias_ref, ctx.beta_ref = bias, beta
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, gy, _gstats):
+        x, gn_stats, gamma, weight, y = ctx.saved_tensors
+        pad, act, has_bias, eps, in_act = ctx.cfg
+        n, h, w, cin = x.shape
+        cout, _, k, _ = weight.shape
+        gy = _c(gy)
+        if act != ACT_NONE:   # (not the case in the networks here: the consumers are followed by a GroupNorm themselves)
+            gpre = torch.empty_like(gy)
+            lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
+        else:
+            gpre = gy
+        # gradient wrt the normalised tensor, then through the GroupNorm to the producer's (pre-activation) output
+        gnorm = torch.empty_like(x)
+        _conv_fwd_any(gpre, weight, cin, 1, None, gnorm, None, n, gpre.shape[1], gpre.shape[2], cout, cin, k, 1, k - 1 - pad,
+                      ACT_NONE)
+        gx = torch.empty_like(x)
+        gg, gg_ret = _sink(gamma)
+        gbt, gbt_ret = _sink(ctx.beta_ref)
+        hw = h * w
+        wtot = lib.fn('dis_gn_bwd_workspace')(n, cin)
+        ws = torch.empty(wtot, dtype=torch.float64, device=x.device)
+        nred2 = wtot // (2 + 2 * cin) * 2
+        lib.call('dis_gn_apply_bwd', gnorm, None, x, gn_stats, gamma, gx, None, gg, gbt, ws[:nred2], ws[nred2:], n, hw, cin,
+                 ACT_NONE, eps, in_act)
+        gw, gw_ret = _sink(weight)
+        gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
+        wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin, cout, k, 1)
+        wws = torch.empty(wsz, dtype=torch.float32, device=x.device)
+        lib.call('dis_conv2d_wgrad_bf16x3_gn', x, gn_stats, gamma, ctx.beta_ref, eps, gpre, gw, gb, wws, n, h, w, cin, cin, cout,
+                 k, 1, pad)
+        _sinks_written()
+        return gx, None, gg_ret, gbt_ret, gw_ret, gb_ret, None, None, None, None, None, None
+
+
+def conv2d_gn_in(x, gn_stats, gamma, beta, weight, bias, pad=1, act=ACT_NONE, want_stats=False, gy_is_pre=False, eps=1e-5,
+                 in_act=ACT_NONE):
+    """conv2d(group_norm(x, gamma, beta, stats=gn_stats, in_act=in_act), weight, bias, 1, pad, act, ...) with the
+    normalisation applied on load.  Returns (y, stats|None).  Shapes: see gn_fusable()."""
+    return _Conv2dGnIn.apply(x, gn_stats, gamma, beta, weight, bias, pad, act, want_stats, gy_is_pre, eps, in_act)
+
+
 class _Conv2dMulti(torch.autograd.Function):
     """Conv2d (stride 1) over the channel concatenation of several nhwc tensors WITHOUT materialising the
     concatenation: one launch per source with the matching slice of the weight, the later launches accumulate into

@@ -260,6 +260,21 @@ int dis_conv2d_wgrad_bf16x3_act(const float* x, const float* gy, const float* y,
 int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
                      int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,
                      void* stream);
+/* GroupNorm applied ON LOAD by the consuming convolution (round 3).  The reference chains Conv2d -> SELU -> GroupNorm(1, C) ->
+ * Conv2d (ResNetBlock model/multi_frame_networks.py:514-542; Block2D3D conv1_1 -> conv1_2, conv2_1 -> conv2_2 :338-345) and
+ * writes the normalised tensor between them; here x is the PRE-normalisation tensor and the consumer stages
+ * x * (rstd * gamma_c) + (beta_c - rstd * gamma_c * mean) per sample (gn_stats (n, 2): fp64 sum / sum of squares as
+ * dis_conv2d_fwd leaves them; gn_gamma / gn_beta (cin)), padding stays zero: bit for bit dis_gn_apply followed by
+ * dis_conv2d_fwd_bf16x3_oihw / dis_conv2d_wgrad_bf16x3, without the read + write of the normalised tensor.
+ * 3x3, stride 1, cin == cout in {16, 32}, w_oihw (w_o, w_i, 3, 3) dense or a row-strided slice; act NONE / SELU. */
+int dis_conv2d_fwd_bf16x3_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta,
+                             float gn_eps, const float* w_oihw, int w_o, int w_i, int w_row_stride, const float* bias,
+                             float* y, double* stats, int n, int hin, int win, int cin, int cout, int k, int stride,
+                             int pad, int act, void* stream);
+int dis_conv2d_wgrad_bf16x3_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta,
+                               float gn_eps, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
+                               int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,
+                               void* stream);
 /* Input gradient of a k=4, stride=2, pad=1 convolution (transposed convolution) as four 2x2 phase convolutions on
  * the matrix cores.  w_oihw is the unpacked weight (cout,cin,4,4).  workspace: 16*cin*cout floats.
  * gx: (n,hin,win,cin) overwritten, or added to when `accumulate` != 0. */

@@ -130,6 +130,56 @@ def test_group_norm(c, act, res):
         assert relerr(nchw(rd.grad), rr.grad) < 1e-6
 
 
+@pytest.mark.parametrize('c', [16, 32])
+@pytest.mark.parametrize('act', [0, 1])
+@pytest.mark.parametrize('n,h,w', [(3, 37, 29), (2, 64, 48)])
+def test_conv_with_group_norm_on_load_equals_the_two_pass_form(c, act, n, h, w):
+    """ops.conv2d_gn_in (GroupNorm applied by the consuming conv while it stages its input: the normalised tensor never
+    exists) against the two-pass form it replaces, group_norm -> conv2d, on the same values: outputs, statistics and EVERY
+    gradient (input of the pair, GroupNorm scale / shift, conv weight / bias) must be bit-identical - the staging computes
+    x * (rstd * gamma) + (beta - rstd * gamma * mean) exactly as gn_apply does, padding stays zero (ragged 37 x 29 tiles
+    included).  And both against torch (reference chain: model/multi_frame_networks.py:338-345,514-542)."""
+    from depthinspace_amd import ops, lib
+    assert ops.gn_fusable(c, c, 3, 1)
+    g = torch.Generator().manual_seed(100 * c + act + h)
+    x = torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3
+    gam = 1 + 0.2 * torch.randn(c, generator=g)
+    bet = 0.2 * torch.randn(c, generator=g)
+    wt = torch.randn(c, c, 3, 3, generator=g) / (3 * c ** 0.5)
+    b = 0.1 * torch.randn(c, generator=g)
+    go = torch.randn(n, c, h, w, generator=g)
+    # producer: x = SELU(pre); the pair's input gradient is handed back as the PRE-activation gradient (in_act)
+    res = []
+    for fused in (False, True):
+        xd = F.selu(nhwc(x).cuda()).contiguous().requires_grad_(True)
+        gd, bd, wd, bbd = [t.cuda().requires_grad_(True) for t in (gam, bet, wt, b)]
+        st = torch.zeros(2 * n, dtype=torch.float64, device='cuda')
+        lib.call('dis_gn_stats', xd.detach(), st, n, h * w * c)
+        if fused:
+            y, yst = ops.conv2d_gn_in(xd, st, gd, bd, wd, bbd, 1, act, want_stats=True, gy_is_pre=False, in_act=ops.ACT_SELU)
+        else:
+            nrm = ops.group_norm(xd, gd, bd, stats=st, in_act=ops.ACT_SELU)
+            y, yst = ops.conv2d(nrm, wd, bbd, 1, 1, act, want_stats=True)
+        y.backward(nhwc(go).cuda())
+        res.append((y.detach(), yst.clone(), xd.grad, gd.grad, bd.grad, wd.grad, bbd.grad))
+    for a_, b_, name in zip(res[0], res[1], ('y', 'stats', 'gx', 'ggamma', 'gbeta', 'gw', 'gb')):
+        assert torch.equal(a_, b_), (name, float((a_ - b_).abs().max()))
+    # torch on the host
+    xr = F.selu(nchw(nhwc(x))).detach().requires_grad_(True)
+    gr, br, wr, bbr = [t.clone().requires_grad_(True) for t in (gam, bet, wt, b)]
+    yr = F.conv2d(F.group_norm(xr, 1, gr, br), wr, bbr, padding=1)
+    if act:
+        yr = F.selu(yr)
+    yr.backward(go)
+    y, _, gx, gg, gb_, gw, gbb = res[1]
+    assert relerr(nchw(y), yr) < 5e-6
+    # gx is the gradient wrt the producer's PRE-activation: torch's gradient wrt xr times SELU'(xr)
+    sel = torch.where(xr.detach() > 0, torch.full_like(xr, 1.0507009873554805), xr.detach() + 1.0507009873554805 * 1.6732632423543772)
+    assert relerr(nchw(gx), xr.grad * sel) < 5e-5
+    assert relerr(gg, gr.grad) < 5e-5 and relerr(gb_, br.grad) < 5e-5
+    assert relerr(gw, wr.grad) < 5e-5 and relerr(gbb, bbr.grad) < 5e-5
+
+
 @pytest.mark.parametrize('ac', [True, False])
 @pytest.mark.parametrize('hin,win,ho,wo', [(8, 10, 16, 20), (9, 7, 18, 14), (16, 20, 8, 10), (5, 6, 13, 11)])
 def test_resize(ac, hin, win, ho, wo):
