@@ -696,19 +696,27 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
       gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
       gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
     }
+    // (wave-uniform) the whole halo lies inside the image: no padding masks
+    const bool gn_interior = INGN && pf_iy0 >= 0 && pf_ix0 >= 0 && pf_iy0 + C::IR <= a.hin && pf_ix0 + C::IC <= a.win;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the halo loads (one unconditional wait, not one per divergent item)
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
       if ((int)threadIdx.x + it * 512 < C::NITEMS) {
         float4 v = pre[it];
         if (INGN) {
-          // (pf_iy0 / pf_ix0 still describe the tile being staged: pf_setup of the next one runs after this)
-          const int iy = pf_iy0 + (it_rc[it] & 0xffff), ix = pf_ix0 + (it_rc[it] >> 16);
-          const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
-          v.x = ok ? v.x * gn_sc.x + gn_sh.x : 0.f;
-          v.y = ok ? v.y * gn_sc.y + gn_sh.y : 0.f;
-          v.z = ok ? v.z * gn_sc.z + gn_sh.z : 0.f;
-          v.w = ok ? v.w * gn_sc.w + gn_sh.w : 0.f;
+          // (pf_iy0 / pf_ix0 still describe the tile being staged: pf_setup of the next one runs after this.)  Pixels
+          // outside the image were loaded as zeros and must stay zero: their shift is dropped (0 * scale + 0).  Packed fp32
+          // multiply / add (two roundings, as gn_apply_kernel computes it).
+          f32x2 sh_lo = {gn_sh.x, gn_sh.y}, sh_hi = {gn_sh.z, gn_sh.w};
+          if (!gn_interior) {
+            const int iy = pf_iy0 + (it_rc[it] & 0xffff), ix = pf_ix0 + (it_rc[it] >> 16);
+            const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+            sh_lo = ok ? sh_lo : (f32x2){0.f, 0.f};
+            sh_hi = ok ? sh_hi : (f32x2){0.f, 0.f};
+          }
+          const f32x2 lo = (f32x2){v.x, v.y} * (f32x2){gn_sc.x, gn_sc.y} + sh_lo;
+          const f32x2 hi = (f32x2){v.z, v.w} * (f32x2){gn_sc.z, gn_sc.w} + sh_hi;
+          v = make_float4(lo[0], lo[1], hi[0], hi[1]);
         }
         if (INACT) {
           const float4 q = pre2[it];
@@ -1816,19 +1824,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
       gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
       gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
     }
+    const bool gn_interior = INGN && st_iy0 >= 0 && st_ix0 >= 0 && st_iy0 + C::IR <= a.hin && st_ix0 + C::IC <= a.win;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): one unconditional wait for the prefetched tile
 #pragma unroll
     for (int it = 0; it < NLX; ++it) {
       const int idx = (int)threadIdx.x + it * 256;
       if (idx < C::NIX) {
         float4 v = prex[it];
-        if (INGN) {
-          const int iy = st_iy0 + (ix_rc[it] & 0xffff), ix = st_ix0 + (ix_rc[it] >> 16);
-          const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
-          v.x = ok ? v.x * gn_sc.x + gn_sh.x : 0.f;
-          v.y = ok ? v.y * gn_sc.y + gn_sh.y : 0.f;
-          v.z = ok ? v.z * gn_sc.z + gn_sh.z : 0.f;
-          v.w = ok ? v.w * gn_sc.w + gn_sh.w : 0.f;
+        if (INGN) {  // (as in conv_bf16x3_kernel::stage)
+          f32x2 sh_lo = {gn_sh.x, gn_sh.y}, sh_hi = {gn_sh.z, gn_sh.w};
+          if (!gn_interior) {
+            const int iy = st_iy0 + (ix_rc[it] & 0xffff), ix = st_ix0 + (ix_rc[it] >> 16);
+            const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+            sh_lo = ok ? sh_lo : (f32x2){0.f, 0.f};
+            sh_hi = ok ? sh_hi : (f32x2){0.f, 0.f};
+          }
+          const f32x2 lo = (f32x2){v.x, v.y} * (f32x2){gn_sc.x, gn_sc.y} + sh_lo;
+          const f32x2 hi = (f32x2){v.z, v.w} * (f32x2){gn_sc.z, gn_sc.w} + sh_hi;
+          v = make_float4(lo[0], lo[1], hi[0], hi[1]);
         }
         put3(xl + (idx / C::CVX) * PSX + (idx % C::CVX) * CPI, v, CIN);
       }
