@@ -17,45 +17,10 @@
 //
 // The same kernel computes stride-1 input gradients (flipped/transposed weights) and, with a 2x2 tap
 // set and interleaved output addressing, the four phases of the stride-2 transposed convolution.
-#include "common.h"
+#include "conv_args.h"
 #include <stdlib.h>
 #include <type_traits>
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvArgs {
-  const float* x;
-  const float* w;     // packed
-  const float* bias;  // may be null
-  float* y;
-  double* stats;  // may be null: (n,2)
-  int n, hin, win;
-  int hv, wv;          // virtual output grid the tiles run over
-  int pad_y, pad_x;
-  int hf, wf;          // full output tensor dims
-  int osy, ooy, osx, oox;  // output pixel = (vy*osy+ooy, vx*osx+oox)
-  int act;
-  int accum;  // epilogue adds the previous contents of y (before the activation): y = act(y_old + conv + bias)
-  const float* xscale;  // optional (n,hin,win,NCHUNK): input pixel x chunk multiplier applied when the halo is staged
-  const float* yscale;  // optional (n,hf,wf,COUT/32): output pixel x 32-channel-group multiplier (before bias/accum)
-  int wmode;  // bf16x3 kernel only: -1 = w is packed; 0 / 1 = w is OIHW fp32, split in the kernel (forward / input gradient)
-  int w_o, w_i;  // ... and its leading dims
-  int w_rs;      // ... and the floats between its rows (w_i * 9 if dense; larger for a slice w[:, a:b] of a wider weight)
-  const float* xact;  // bf16x3 kernel, INACT instances: activation OUTPUT at x's positions; x is multiplied by act'(xact)
-  // bf16x3 kernel, GEN instances (32-channel slices of wider tensors, dis_convg_run): x / y point at the slice's first
-  // channel, a pixel occupies ldx / ldy floats, cx / cy channels of the slice exist (the rest load zeros / are not
-  // stored), x_sub / y_sub = floats between the tensor's start and the slice's (for the buffer range), nbias = bias
-  // entries that exist
-  int ldx, ldy, cx, cy, x_sub, y_sub, nbias;
-  int wtap0, wtap_step;  // tap-row instances (1 x 7 window of a 7x7 weight): see the weight prologue
-  // bf16x3 kernel, INGN instances: x is the PRE-GroupNorm tensor (output of the producing conv + activation); the affine map
-  // of GroupNorm(1 group) - per sample rstd * gamma_c, beta_c - rstd * gamma_c * mean - is applied while the halo is staged,
-  // the zero padding stays zero.  gn_stats (n, 2) fp64 sum / sum of squares, as dis_gn_apply takes them.
-  const double* gn_stats;
-  const float* gn_gamma;
-  const float* gn_beta;
-  float gn_eps;
-};
 
 template <int CIN, int COUT, int KH, int KW, int S>
 struct ConvCfg {
@@ -767,14 +732,26 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
         *(uint4*)(wl + (((ks * 3 + p) * 4 + g) * COUT + co) * 8) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
     }
   } else if (a.wmode < 0) {
-    for (int i = threadIdx.x; i < C::W_U16 / 8; i += 512) ((uint4*)wl)[i] = ((const uint4*)a.w)[i];
+    // (packed planes: <= 7 uint4 per thread, all requested before the first is stored - see dis_copy_w_rows)
+    constexpr int NWV = (C::W_U16 / 8 + 511) / 512;
+    uint4 wv[NWV];
+#pragma unroll
+    for (int k = 0; k < NWV; ++k) {
+      const int i = (int)threadIdx.x + k * 512;
+      wv[k] = i < C::W_U16 / 8 ? ((const uint4*)a.w)[i] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < NWV; ++k) {
+      const int i = (int)threadIdx.x + k * 512;
+      if (i < C::W_U16 / 8) ((uint4*)wl)[i] = wv[k];
+    }
   } else {
     // OIHW fp32 weights: split here instead of in a launch of their own.  Coalesced copy into the (still unused) halo
     // region, rows padded by one float so that the gather below is conflict-free, then every thread builds
     // (k-step, lane group, cout) units of 3 x 8 bf16.
     float* ws = (float*)xl;
-    const int row = a.w_i * 9, nw = a.w_o * row;
-    for (int i = threadIdx.x; i < nw; i += 512) ws[(i / row) * (row + 1) + i % row] = a.w[(i / row) * a.w_rs + i % row];
+    const int row = a.w_i * 9;
+    dis_copy_w_rows(a.w, a.w_o, row, a.w_rs, ws);  // (all loads in flight at once)
     __syncthreads();
     for (int u = threadIdx.x; u < KS * 4 * COUT; u += 512) {
       const int co = u % COUT, g = (u / COUT) & 3, ks = u / (4 * COUT);
@@ -1180,6 +1157,14 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
   if (grid >= 8) grid -= grid % 8;
   if (grid < 1) grid = 1;
   hipError_t le;
+  if (dis_f2_enabled() && wmode >= 0) {  // two-term fp16 split (conv_f16x2.hip); no instance for this configuration: fall through
+    le = dis_f2_conv_launch(a, cin, cout, stats != nullptr, inact, grid, (hipStream_t)stream);
+    if (le == hipSuccess) {
+      DIS_CHECK_LAUNCH();
+      return DIS_OK;
+    }
+    if (le != hipErrorInvalidValue) return (int)le;
+  }
   if (cin == 32 && cout == 32) le = bx_launch<32, 32>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
   else if (cin == 16 && cout == 16) le = bx_launch<16, 16>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
   else if (cin == 16 && cout == 32) le = bx_launch<16, 32>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
@@ -1366,24 +1351,6 @@ struct WgCfg {
   static constexpr int PART = MB * 16 * COUT;      // floats per partial slab
 };
 
-struct WgArgs {
-  const float* x;
-  const float* gy;
-  float* part;   // [worker][chunk][split][PART]
-  float* bpart;  // [worker][COUT] bias partial sums (written by chunk 0 / split 0 workgroups), may be null
-  int n, hin, win, hout, wout, pad;
-  const float* xscale;  // optional (n,hin,win,NCHUNK) multiplier of x (see ConvArgs::xscale)
-  const float* gact;    // bf16x3 kernel, INACT instances: activation OUTPUT at gy's positions; gy is multiplied by act'(gact)
-  // bf16x3 kernel, GEN instance (channel-slice pairs of a wide layer, dis_convg_wgrad): a pixel of x / gy occupies
-  // ldx / ldg floats, the layer's channels start at xoff / goff and there are cx / cg of them; blockIdx.y = gb * npx + cb
-  // selects x channels [32 cb, 32 cb + 32) and gy channels [32 gb, 32 gb + 32)
-  int ldx, xoff, cx, ldg, goff, cg, npx;
-  // bf16x3 kernel, INGN instances: x is staged as GroupNorm(x) (see ConvArgs::gn_stats)
-  const double* gn_stats;
-  const float* gn_gamma;
-  const float* gn_beta;
-  float gn_eps;
-};
 
 template <int CIN, int COUT, int KH, int KW, int S>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
@@ -1990,8 +1957,12 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
   const long elems = C::PART;
   float* tmp = a.part + (long)WG_WORKERS * elems;
   a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
-  hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<CIN, COUT, INACT, false, 3, 1, 8, 3, false, INGN>), dim3((unsigned)workers),
-                     dim3(256), X::LDS_BYTES, s, a);
+  // two-term fp16 split (conv_f16x2.hip; same slab layout), else the three-term kernel
+  hipError_t le = dis_f2_enabled() ? dis_f2_wgrad_launch(a, CIN, COUT, INACT, workers, s) : hipErrorInvalidValue;
+  if (le != hipSuccess && le != hipErrorInvalidValue) return (int)le;
+  if (le != hipSuccess)
+    hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<CIN, COUT, INACT, false, 3, 1, 8, 3, false, INGN>), dim3((unsigned)workers),
+                       dim3(256), X::LDS_BYTES, s, a);
   const long total = (long)C::MROWS * COUT;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(64 * WG_RW), 0, s,
                      (const float*)a.part, gw, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, COUT, cin_real, C::PART,

@@ -1,0 +1,936 @@
+// fp32 convolution on the fp16 matrix cores with TWO-term operands ("f16x2"): the 3x3 stride-1 convolutions of FuseNet with 16 / 32
+// channels on either side (forward, input gradient, weight gradient), the same launches conv2d.hip's bf16x3 kernels serve.
+//
+//   x * 2^s = h1 + h2,  h1 = fp16(x * 2^s), h2 = fp16(x * 2^s - h1)        (11 + 11 significant bits)
+//   a * b  ~= a1 b1 + a1 b2 + a2 b1                                        (3 products on v_mfma_f32_16x16x32_f16, fp32 accumulate)
+//
+// Each fp16 x fp16 product is exact in fp32.  What is dropped - a2 b2 and the third-order remainders of the operands - is
+// <= 2^-21 of |a b| (typically 2^-23): operands of 22 bits instead of fp32's 24, measured end to end at the level of the fp32
+// summation-order noise of the CPU reference itself (scripts/diag/emul_f16x2.py).  Against the three-term
+// bf16 split of conv2d.hip (6 products, >= 24 bits) this is HALF the matrix work, 2 operand planes instead of 3 in LDS and
+// two thirds of the fragment reads.  fp16 has 5 exponent bits, so every operand block is scaled by a power of two first:
+//   * weights: one scale per launch (largest |w| -> [2^14, 2^15)), found in the prologue that splits them into LDS;
+//   * pixels: one scale per halo tile.  Every wave reduces the values it is about to stage to a maximum (DPP), the eight
+//     maxima are exchanged through LDS across the barrier that already separates two tiles, and the tile is split with
+//     2^(14 - exponent of its maximum).  Entries far below the tile's maximum lose RELATIVE precision (they reach the fp16
+//     subnormals 2^-39 below it) but their ABSOLUTE error stays 2^-24 * 2^-15 of the maximum: nothing a dot product can see.
+//   * the accumulators are multiplied by 2^-(sx + sw) (exact) when a finished tile is handed to the deferred epilogue; the
+//     bias joins there.
+// DIS_CONV_SPLIT=bf16x3 keeps every launch on the three-term kernels.
+#include "conv_args.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+#ifndef F2_VALU_PER_GAP
+#define F2_VALU_PER_GAP 6
+#endif
+#define F2_TR 16
+#define F2_TC 16
+
+// 1: two-term fp16 split (default), 0: three-term bf16 split; DIS_CONV_SPLIT=bf16x3 / f16x2 sets the start value
+static int g_f2_mode = -1;
+bool dis_f2_enabled() {
+  if (g_f2_mode < 0) g_f2_mode = (getenv("DIS_CONV_SPLIT") && getenv("DIS_CONV_SPLIT")[0] == 'b') ? 0 : 1;
+  return g_f2_mode == 1;
+}
+extern "C" int dis_set_conv_split(int mode) {
+  if (mode != 0 && mode != 1) return DIS_ERR_UNSUPPORTED;
+  g_f2_mode = mode;
+  return DIS_OK;
+}
+extern "C" int dis_get_conv_split(void) { return dis_f2_enabled() ? 1 : 0; }
+
+template <int CIN, int COUT>
+struct F2Cfg {
+  static constexpr int IR = F2_TR + 2, IC = F2_TC + 2;  // halo tile
+  static constexpr int CV = CIN / 4;                      // float4s per pixel
+  static constexpr int NP = 2;                            // planes
+  // LDS pixel stride (16-bit units): payload NP * CIN, padded to 2 (mod 4) sixteen-byte units - the stride at which the four
+  // NON-contiguous 16-lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS table) hit disjoint banks (see BxCfg::PS)
+  static constexpr int PS = CIN == 32 ? 80 : 48;
+  static constexpr int NT = COUT / 16;
+  static constexpr int KS = CIN == 32 ? 9 : 5;  // k-steps: a tap (32 channels) or a pair of taps (16 + 16)
+  static constexpr int W_U16 = KS * NP * 4 * COUT * 8;  // packed[kstep][plane][lg][co][8]
+  static constexpr int X_U16 = IR * IC * PS;
+  static constexpr int LDS_BYTES = W_U16 * 2 + X_U16 * 2 + 64 + 64;  // + stats reduction (8 doubles) + wave maxima (2 x 8 floats)
+  static constexpr int NITEMS = IR * IC * CV;
+  static constexpr int NLOAD = (NITEMS + 511) / 512;
+  static constexpr int NPIECE = 2 * NT;
+  static constexpr int piece_ks(int i) { return KS == 9 ? 2 * i + 1 : i + 1; }
+  static constexpr int load_ks(int i) { return KS == 9 ? 2 * (i / 2) : i; }
+};
+
+// same tap / channel -> k-slot map as conv2d.hip's bx_weight
+template <int CIN, int COUT>
+__device__ __forceinline__ float f2_weight(const float* w, int stride_row, int mode, int wo, int wi, int ks, int lg, int j, int co) {
+  const int tap = CIN == 32 ? ks : 2 * ks + (lg >> 1);
+  const int c = CIN == 32 ? 8 * lg + j : 8 * (lg & 1) + j;
+  if (tap > 8) return 0.f;
+  if (mode == 0) return (co < wo && c < wi) ? w[co * stride_row + c * 9 + tap] : 0.f;
+  return (c < wo && co < wi) ? w[c * stride_row + co * 9 + (8 - tap)] : 0.f;
+}
+
+// two fp32 values (already scaled) -> two packed fp16 pairs: h1 = RN(v), h2 = RN(v - h1)
+__device__ __forceinline__ void f2_split_pair(float x, float y, unsigned& p1, unsigned& p2) {
+  const f32x2 v = {x, y};
+  const f16x2_t h1 = __builtin_convertvector(v, f16x2_t);
+  const f32x2 r = v - __builtin_convertvector(h1, f32x2);
+  const f16x2_t h2 = __builtin_convertvector(r, f16x2_t);
+  p1 = __builtin_bit_cast(unsigned, h1);
+  p2 = __builtin_bit_cast(unsigned, h2);
+}
+
+// maximum of a non-negative value over the wave (DPP row operations, no LDS traffic); valid in every lane's return value
+__device__ __forceinline__ float f2_wave_max(float m) {
+  int v = __float_as_int(m);  // non-negative floats order like their bit patterns
+#define F2_DPP(ctrl, rmask) v = max(v, __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, true))
+  F2_DPP(0xB1, 0xf);   // quad_perm [1,0,3,2]
+  F2_DPP(0x4E, 0xf);   // quad_perm [2,3,0,1]
+  F2_DPP(0x124, 0xf);  // row_ror:4
+  F2_DPP(0x128, 0xf);  // row_ror:8   -> every lane holds its row's maximum
+  F2_DPP(0x142, 0xa);  // row_bcast:15 into rows 1, 3
+  F2_DPP(0x143, 0xc);  // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's maximum
+#undef F2_DPP
+  return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
+
+// power-of-two scale exponent that brings a block's largest magnitude into [2^14, 2^15) (fp16's largest binade is 2^15);
+// clamped so that the product of two scales and its inverse stay representable in fp32
+__device__ __forceinline__ int f2_scale_exp(float m) {
+  int e = 14 - __builtin_amdgcn_frexp_expf(m) + 1;  // frexp: m = f * 2^e, f in [0.5, 1)  ->  m in [2^(e-1), 2^e)
+  e = m > 0.f ? e : 0;
+  return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / input gradient.  Structure of conv2d.hip's conv_bf16x3_kernel (8 waves = 16 x 16 output pixels, weights resident in
+// LDS, halo of tile t+1 fetched into registers and the epilogue of tile t-1 run from a register copy during the MFMA loop of
+// tile t, tap loop one basic block with an explicit issue order), with two operand planes and three products per k-step.
+// INACT / INGN as there: x staged as x * act'(xact) / as GroupNorm(x).
+// ------------------------------------------------------------------------------------------------
+// Diagnostic build only (make stamp, scripts/stamp_bf16x3.py f16x2): per-wave s_memtime sums of the kernel's phases
+#ifdef BX_STAMP
+__device__ unsigned long long f2_stamps[256 * 8 * 8];
+#define F2_T(k)                                                   \
+  {                                                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    st_[k] += now_ - last_;                                       \
+    last_ = now_;                                                 \
+  }
+extern "C" int dis_debug_f2_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(f2_stamps), sizeof(f2_stamps));
+}
+#else
+#define F2_T(k)
+#endif
+
+template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool INGN = false>
+__global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
+  using C = F2Cfg<CIN, COUT>;
+#ifdef BX_STAMP
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
+  constexpr int IC = C::IC, PS = C::PS, NT = C::NT, KS = C::KS, NLOAD = C::NLOAD, NPIECE = C::NPIECE, CV = C::CV, NP = C::NP;
+  static_assert(!INGN || (INACT == 0 && 512 % CV == 0), "GroupNorm on load: forward instances");
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  unsigned short* wl = smem16;
+  unsigned short* xl = smem16 + C::W_U16;
+  double* red = (double*)(smem16 + C::W_U16 + C::X_U16);
+  float* mxs = (float*)(smem16 + C::W_U16 + C::X_U16 + 32);  // [parity][wave]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int tiles_x = (a.wv + F2_TC - 1) / F2_TC, tiles_y = (a.hv + F2_TR - 1) / F2_TR;
+  const int ntiles = a.n * tiles_y * tiles_x;
+  const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
+  const int xcd = blockIdx.x % nxcd, rank = blockIdx.x / nxcd, per = gridDim.x / nxcd;
+  const int t_lo = (int)((long)ntiles * xcd / nxcd), t_hi = (int)((long)ntiles * (xcd + 1) / nxcd);
+  const int d_tx = per % tiles_x, d_ty = (per / tiles_x) % tiles_y, d_n = per / (tiles_x * tiles_y);
+
+  float4 pre[NLOAD], pre2[INACT ? NLOAD : 1];
+  int it_rc[NLOAD], it_off[NLOAD];
+#pragma unroll
+  for (int it = 0; it < NLOAD; ++it) {
+    const int idx = (int)threadIdx.x + it * 512;
+    const int vv = idx % CV, pix = idx / CV;
+    const int r = pix / IC, c = pix % IC;
+    it_rc[it] = idx < C::NITEMS ? (r | (c << 16)) : 0x4000;
+    it_off[it] = ((r * a.win + c) * CIN + vv * 4) * 4;
+  }
+  const unsigned x_bytes = (unsigned)a.hin * a.win * (CIN * 4u);
+  const unsigned y_bytes = (unsigned)a.hf * a.wf * (COUT * 4u);
+  const float* pf_x = a.x;
+  unsigned pf_bytes = 0;
+  int pf_iy0 = 0, pf_ix0 = 0, pf_off0 = 0;
+  auto pf_setup = [&](int n, int ty, int tx, bool live) {
+    pf_iy0 = ty * F2_TR - a.pad_y;
+    pf_ix0 = tx * F2_TC - a.pad_x;
+    pf_off0 = (pf_iy0 * a.win + pf_ix0) * (CIN * 4);
+    pf_x = a.x + (long)n * a.hin * a.win * CIN;
+    pf_bytes = live ? x_bytes : 0u;
+  };
+  auto pf_issue = [&](int it) {
+    const int iy = pf_iy0 + (it_rc[it] & 0xffff), ix = pf_ix0 + (it_rc[it] >> 16);
+    const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+    const unsigned off = ok ? (unsigned)(pf_off0 + it_off[it]) : BX_OOB;
+    pre[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(pf_x, pf_bytes), off, 0, 0));
+    if (INACT)
+      pre2[it] = __builtin_bit_cast(
+          float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.xact + (pf_x - a.x), pf_bytes), off, 0, 0));
+  };
+  float4 gn_g = make_float4(0.f, 0.f, 0.f, 0.f), gn_b = gn_g, gn_sc = gn_g, gn_sh = gn_g;
+  int gn_n = -1;
+  if (INGN) {
+    gn_g = *(const float4*)(a.gn_gamma + ((int)threadIdx.x % CV) * 4);
+    gn_b = *(const float4*)(a.gn_beta + ((int)threadIdx.x % CV) * 4);
+  }
+  // (1) BEFORE the barrier between two tiles: the final fp32 values of the halo items in flight (activation gradient / GroupNorm
+  // applied) and this wave's largest magnitude, left in LDS for the other waves
+  auto prep = [&](int n_cur, int parity) {
+    if (INGN && n_cur != gn_n) {
+      gn_n = n_cur;
+      float mean, rstd;
+      gn_moments(a.gn_stats, n_cur, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
+      gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
+      gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
+    }
+    const bool gn_interior = INGN && pf_iy0 >= 0 && pf_ix0 >= 0 && pf_iy0 + C::IR <= a.hin && pf_ix0 + C::IC <= a.win;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    float m = 0.f;
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      float4 v = pre[it];
+      if (INGN) {
+        f32x2 sh_lo = {gn_sh.x, gn_sh.y}, sh_hi = {gn_sh.z, gn_sh.w};
+        if (!gn_interior) {
+          const int iy = pf_iy0 + (it_rc[it] & 0xffff), ix = pf_ix0 + (it_rc[it] >> 16);
+          const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+          sh_lo = ok ? sh_lo : (f32x2){0.f, 0.f};
+          sh_hi = ok ? sh_hi : (f32x2){0.f, 0.f};
+        }
+        const f32x2 lo = (f32x2){v.x, v.y} * (f32x2){gn_sc.x, gn_sc.y} + sh_lo;
+        const f32x2 hi = (f32x2){v.z, v.w} * (f32x2){gn_sc.z, gn_sc.w} + sh_hi;
+        v = make_float4(lo[0], lo[1], hi[0], hi[1]);
+      }
+      if (INACT) {
+        const float4 q = pre2[it];
+        v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
+        v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
+      }
+      pre[it] = v;
+      // (items past the end of the halo - last round only - are not staged and do not count)
+      const float mv = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+      m = ((int)threadIdx.x + it * 512 < C::NITEMS) ? fmaxf(m, mv) : m;
+    }
+    m = f2_wave_max(m);
+    if (lane == 0) mxs[parity * 8 + wave] = m;
+  };
+  // (2) AFTER it: the tile's scale from the eight maxima, split, LDS write.  Returns the scale's exponent.
+  auto stage = [&](int parity) -> int {
+    const float4 m0 = *(const float4*)(mxs + parity * 8), m1 = *(const float4*)(mxs + parity * 8 + 4);
+    const float m = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+    const int se = f2_scale_exp(m);
+    const float sc = __builtin_ldexpf(1.f, se);
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) {
+      if ((int)threadIdx.x + it * 512 < C::NITEMS) {
+        const float4 v = pre[it];
+        unsigned a1, a2, b1, b2;
+        f2_split_pair(v.x * sc, v.y * sc, a1, a2);
+        f2_split_pair(v.z * sc, v.w * sc, b1, b2);
+        const int idx = (int)threadIdx.x + it * 512;
+        unsigned short* p = xl + (idx / CV) * PS + (idx % CV) * 4;
+        *(uint2*)(p) = make_uint2(a1, b1);
+        *(uint2*)(p + CIN) = make_uint2(a2, b2);
+      }
+    }
+    return se;
+  };
+
+  int tile = t_lo + rank;
+  int cn = 0, cty = 0, ctx = 0;
+  if (tile < t_hi) {
+    ctx = tile % tiles_x, cty = (tile / tiles_x) % tiles_y, cn = tile / (tiles_x * tiles_y);
+    pf_setup(cn, cty, ctx, true);
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) pf_issue(it);  // in flight while the weights are split
+  }
+  // ---- weights: OIHW fp32 -> scaled fp16 planes in fragment order.  Coalesced copy into the (still unused) halo region, rows
+  // padded by one float, largest magnitude over the block, then (k-step, lane group, cout) units of 2 x 8 fp16.
+  int sw_e = 0;
+  {
+    float* ws = (float*)xl;
+    const int row = a.w_i * 9;
+    float m = dis_copy_w_rows(a.w, a.w_o, row, a.w_rs, ws);
+    m = f2_wave_max(m);
+    if (lane == 0) mxs[wave] = m;
+    __syncthreads();
+    const float4 m0 = *(const float4*)(mxs), m1 = *(const float4*)(mxs + 4);
+    sw_e = f2_scale_exp(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))));
+    const float sw = __builtin_ldexpf(1.f, sw_e);
+    for (int u = threadIdx.x; u < KS * 4 * COUT; u += 512) {
+      const int co = u % COUT, g = (u / COUT) & 3, ks = u / (4 * COUT);
+      unsigned pl[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v0 = f2_weight<CIN, COUT>(ws, row + 1, a.wmode, a.w_o, a.w_i, ks, g, 2 * j, co);
+        const float v1 = f2_weight<CIN, COUT>(ws, row + 1, a.wmode, a.w_o, a.w_i, ks, g, 2 * j + 1, co);
+        f2_split_pair(v0 * sw, v1 * sw, pl[0][j], pl[1][j]);
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        *(uint4*)(wl + (((ks * NP + p) * 4 + g) * COUT + co) * 8) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
+    }
+    __syncthreads();  // the maxima slots and `ws` are free again before the first tile's prep / stage
+  }
+
+  f32x4 acc[2][NT], outv[2][NT];
+  float4 prevy[NPIECE];
+  double s1 = 0.0, s2 = 0.0;
+  float t1 = 0.f, t2 = 0.f;
+  int stat_n = -1;
+  float4 bias_v[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    bias_v[nt] = a.bias ? *(const float4*)(a.bias + nt * 16 + lg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int yrow = a.osy * a.wf * (COUT * 4);
+  const int y_lane = ((wave * 2 * a.osy * a.wf + li * a.osx) * COUT + lg * 4) * 4;
+
+  const float* prev_y = a.y;
+  unsigned prev_off[2] = {BX_OOB, BX_OOB};
+  int prev_n = -1;
+  auto stats_flush = [&]() {
+    const double r1 = block_sum_d(s1, red);
+    const double r2 = block_sum_d(s2, red);
+    if (threadIdx.x == 0) {
+      atomic_add_d(a.stats + 2 * stat_n, r1);
+      atomic_add_d(a.stats + 2 * stat_n + 1, r2);
+    }
+    s1 = 0.0;
+    s2 = 0.0;
+  };
+  auto stats_sample = [&]() {
+    if (STATS && prev_n >= 0 && prev_n != stat_n) {
+      if (stat_n >= 0) stats_flush();
+      stat_n = prev_n;
+    }
+  };
+  auto epi_load = [&](const float* yb, const unsigned (&off)[2]) {
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i)
+      prevy[i] = __builtin_bit_cast(
+          float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(yb, y_bytes), off[i / NT] + (i % NT) * 64, 0, 0));
+  };
+  auto epi_piece = [&](int i) {
+    const int mt = i / NT, nt = i % NT;
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = outv[mt][nt][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (ACT == DIS_ACT_SELU) {
+        const float e = __builtin_amdgcn_exp2f(fminf(o[r], 0.f) * 1.44269504088896340736f);
+        o[r] = SELU_SCALE_F * fmaxf(o[r], 0.f) + (SELU_SCALE_F * SELU_ALPHA_F) * (e - 1.f);
+      } else if (ACT == DIS_ACT_RELU) {
+        o[r] = fmaxf(o[r], 0.f);
+      }
+    }
+    const bool live = prev_off[mt] != BX_OOB;
+    u32x4 ov;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ov[r] = __float_as_uint(o[r]);
+    __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(prev_y, y_bytes), prev_off[mt] + nt * 64, 0, 0);
+    if (STATS) {
+      const float q1 = (o[0] + o[1]) + (o[2] + o[3]);
+      const float q2 = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+      t1 += live ? q1 : 0.f;
+      t2 += live ? q2 : 0.f;
+    }
+  };
+
+  const int xa_lane = (wave * 2 * IC + li) * PS + (CIN == 32 ? lg * 8 : (lg & 1) * 8);
+  const bool hi_tap = (lg >> 1) != 0;
+  int parity = 0;
+
+  while (tile < t_hi) {
+    const int vy0 = cty * F2_TR + wave * 2, vx0 = ctx * F2_TC + li;
+    const int tile_yoff = ((cty * F2_TR * a.osy + a.ooy) * a.wf + ctx * F2_TC * a.osx + a.oox) * (COUT * 4) + y_lane;
+    const float* cur_y = a.y + (long)cn * a.hf * a.wf * COUT;
+    unsigned cur_off[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) cur_off[mt] = (vx0 < a.wv && vy0 + mt < a.hv) ? (unsigned)(tile_yoff + mt * yrow) : BX_OOB;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    stats_sample();
+    F2_T(0)
+    prep(cn, parity);
+    F2_T(1)
+    __syncthreads();  // every wave has finished reading the previous halo tile, and has left its maximum
+    F2_T(2)
+    const int sx_e = stage(parity);
+    F2_T(3)
+    __syncthreads();
+    F2_T(4)
+    parity ^= 1;
+    const int ntile = tile + per;
+    int ntx = ctx + d_tx, nty = cty + d_ty, nn = cn + d_n;
+    if (ntx >= tiles_x) ntx -= tiles_x, ++nty;
+    if (nty >= tiles_y) nty -= tiles_y, ++nn;
+    pf_setup(nn, nty, ntx, ntile < t_hi);
+    t1 = 0.f;
+    t2 = 0.f;
+
+    auto ride = [&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      if (ACCUM && ks == 0) epi_load(cur_y, cur_off);
+#pragma unroll
+      for (int it = 0; it < NLOAD; ++it)
+        if (C::load_ks(it) == ks) pf_issue(it);
+#pragma unroll
+      for (int i = 0; i < NPIECE; ++i)
+        if (C::piece_ks(i) == ks) epi_piece(i);
+    };
+    auto pattern = [&](auto nrc) {
+      constexpr int NM = 6 * NT, NR = decltype(nrc)::value;
+#pragma unroll
+      for (int g = 0; g < NM; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        if (g < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        // (an MFMA holds the pipe for 16 cycles and the SIMD's other wave issues one in between: up to ~6 VALU of this wave
+        // fit behind each of its own MFMAs; with 3 - the bf16x3 kernel's figure, twice the MFMAs per k-step - the epilogue
+        // VALU that did not fit was issued after the k-step's last MFMA, exposed)
+        __builtin_amdgcn_sched_group_barrier(0x002, F2_VALU_PER_GAP, 0);
+        if (g == (NR < NM ? NR : NM - 1)) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // the k-step's halo loads
+      }
+      __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // the k-step's store
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // products (pixel plane, weight plane), smallest terms first
+    constexpr int PA[3] = {1, 0, 0};
+    constexpr int PB[3] = {0, 1, 0};
+    if constexpr (CIN == 32) {
+      s16x8 R[2][4][NP];     // [kx parity][halo row][plane]
+      s16x8 fb[2][NP][NT];   // [buffer][plane][nt]
+      auto load_row = [&](int kx, int j) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) R[kx & 1][j][p] = *(const s16x8*)(xl + xa_lane + (j * IC + kx) * PS + p * CIN);
+      };
+      auto load_w = [&](int ks, s16x8 (&B)[NP][NT]) {
+#ifdef F2_EXP_NOW  // timing experiment (wrong results): no weight-fragment reads after the first tap
+        if (ks > 1) return;
+#endif
+        const int wt = (ks % 3) * 3 + ks / 3;  // the weights are packed tap-major (ky * 3 + kx); the loop walks kx outer
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) B[p][nt] = *(const s16x8*)(wl + (((wt * NP + p) * 4 + lg) * COUT + nt * 16 + li) * 8);
+      };
+      load_row(0, 0);
+      load_row(0, 1);
+      load_w(0, fb[0]);
+      auto step = [&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        constexpr int kx = ks / 3, ky = ks % 3, nkx = (ks + 1) / 3, nky = (ks + 1) % 3;
+        if (ks + 1 < KS) {
+          if (nky == 0) {
+            load_row(nkx, 0);
+            load_row(nkx, 1);
+          } else {
+            load_row(nkx, nky + 1);
+          }
+          load_w(ks + 1, fb[(ks + 1) & 1]);
+        }
+        ride(ksc);
+        constexpr int b = ks & 1;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fb[b][PB[q]][nt]),
+                                                                  __builtin_bit_cast(f16x8_t, R[kx & 1][ky + mt][PA[q]]),
+                                                                  acc[mt][nt], 0, 0, 0);
+        pattern(std::integral_constant<int, (ks + 1 < KS ? (nky == 0 ? 2 * NP : NP) + NP * NT : 0)>{});
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+    } else {
+      s16x8 fa[2][NP][2], fb[2][NP][NT];
+      auto load_frag = [&](int ks, s16x8 (&A)[NP][2], s16x8 (&B)[NP][NT]) {
+        const int t0 = 2 * ks, t1_ = 2 * ks + 1 > 8 ? 8 : 2 * ks + 1;
+        const int xoff = hi_tap ? ((t1_ / 3) * IC + t1_ % 3) * PS : ((t0 / 3) * IC + t0 % 3) * PS;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) A[p][mt] = *(const s16x8*)(xl + xa_lane + xoff + mt * IC * PS + p * CIN);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) B[p][nt] = *(const s16x8*)(wl + (((ks * NP + p) * 4 + lg) * COUT + nt * 16 + li) * 8);
+        }
+      };
+      load_frag(0, fa[0], fb[0]);
+      auto step = [&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        if (ks + 1 < KS) load_frag(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+        ride(ksc);
+        constexpr int b = ks & 1;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fb[b][PB[q]][nt]),
+                                                                  __builtin_bit_cast(f16x8_t, fa[b][PA[q]][mt]),
+                                                                  acc[mt][nt], 0, 0, 0);
+        pattern(std::integral_constant<int, (ks + 1 < KS ? NP * (2 + NT) : 0)>{});
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{});
+    }
+    s1 += (double)t1;
+    s2 += (double)t2;
+    F2_T(5)
+
+    // hand the finished tile over to the deferred epilogue: undo the two scales (exact), add the bias
+    const float desc = __builtin_ldexpf(1.f, -(sx_e + sw_e));
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      prev_off[mt] = cur_off[mt];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 bv = {bias_v[nt].x, bias_v[nt].y, bias_v[nt].z, bias_v[nt].w};
+        outv[mt][nt] = acc[mt][nt] * desc + bv;
+        if (ACCUM) {
+          const float4 q = prevy[mt * NT + nt];
+          outv[mt][nt] += (f32x4){q.x, q.y, q.z, q.w};
+        }
+      }
+    }
+    prev_y = cur_y;
+    prev_n = cn;
+    cn = nn, cty = nty, ctx = ntx;
+    tile = ntile;
+    F2_T(6)
+  }
+  stats_sample();
+  t1 = 0.f;
+  t2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) epi_piece(i);
+  s1 += (double)t1;
+  s2 += (double)t2;
+  if (STATS && stat_n >= 0) stats_flush();
+#ifdef BX_STAMP
+  F2_T(7)
+  if (lane == 0 && blockIdx.x < 256)
+    for (int k = 0; k < 8; ++k) f2_stamps[(blockIdx.x * 8 + wave) * 8 + k] = st_[k];
+#endif
+}
+
+template <int CIN, int COUT>
+static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid, hipStream_t stream) {
+  using C = F2Cfg<CIN, COUT>;
+  static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
+  const bool ingn = a.gn_stats != nullptr;
+  static bool attr_set[16] = {};
+  auto launch = [&](auto kern, int slot) -> hipError_t {
+    if (!attr_set[slot]) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+      if (e != hipSuccess) return e;
+      attr_set[slot] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
+    return hipSuccess;
+  };
+  if (a.act != DIS_ACT_NONE && a.act != DIS_ACT_SELU) return hipErrorInvalidValue;
+  const bool selu = a.act == DIS_ACT_SELU;
+  if (ingn) {
+    if constexpr (CIN == COUT) {
+      if (inact || a.accum) return hipErrorInvalidValue;
+      if (selu)
+        return stats ? launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_SELU, false, true, 0, true>, 12)
+                     : launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_SELU, false, false, 0, true>, 13);
+      return stats ? launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, true, 0, true>, 14)
+                   : launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, 0, true>, 15);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
+  if (inact) {
+    if (inact != DIS_ACT_SELU || selu || stats) return hipErrorInvalidValue;
+    return a.accum ? launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, true, false, DIS_ACT_SELU>, 8)
+                   : launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, DIS_ACT_SELU>, 9);
+  }
+  switch ((selu ? 4 : 0) + (a.accum ? 2 : 0) + (stats ? 1 : 0)) {
+    case 0: return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false>, 0);
+    case 1: return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, true>, 1);
+    case 2: return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, true, false>, 2);
+    case 3: return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, true, true>, 3);
+    case 4: return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_SELU, false, false>, 4);
+    case 5: return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_SELU, false, true>, 5);
+    case 6: return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_SELU, true, false>, 6);
+    default: return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_SELU, true, true>, 7);
+  }
+}
+
+hipError_t dis_f2_conv_launch(const ConvArgs& a, int cin, int cout, bool stats, int inact, long grid, hipStream_t stream) {
+  if (a.wmode < 0) return hipErrorInvalidValue;  // pre-packed bf16 planes: the bf16x3 kernel's format
+  if (cin == 32 && cout == 32) return f2_launch<32, 32>(a, stats, inact, grid, stream);
+  if (cin == 16 && cout == 16) return f2_launch<16, 16>(a, stats, inact, grid, stream);
+  if (cin == 16 && cout == 32) return f2_launch<16, 32>(a, stats, inact, grid, stream);
+  if (cin == 32 && cout == 16) return f2_launch<32, 16>(a, stats, inact, grid, stream);
+  return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient.  Structure of conv2d.hip's conv_wgrad_bf16x3_kernel<CIN, COUT> (4 waves, 8 x 16 output pixels per tile, both
+// operands fetched with the transposing read ds_read_b64_tr_b16, the (9 CIN / 16) x (COUT / 16) accumulator tiles split
+// statically over the waves and kept in registers across ALL tiles of a workgroup, 2 workgroups per CU), two planes, three
+// products.  The contraction runs over pixels, i.e. over tiles, so the block scales of x and gy must not change under the
+// accumulators: each is a RUNNING scale that only ever shrinks (when a tile brings a larger magnitude than any before it), and
+// the accumulators are multiplied by the (exact, power-of-two) ratio at that moment.  Later tiles with smaller values then
+// carry the coarser scale: their absolute error is bounded by 2^-24 x 2^-15 of the largest magnitude seen, which is what a sum
+// over all pixels can resolve anyway.  The slab is written as acc * 2^-(sx + sg).
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+struct F2WxCfg {
+  static constexpr int NP = 2, K = 3, TR = 8;
+  static constexpr int ps_for(int payload_u16) {  // see WxCfg::ps_for (conflict-free transposing reads)
+    int ps = (payload_u16 + 7) / 8 * 8;
+    while (((ps / 2) % 16) != 8) ps += 8;
+    return ps;
+  }
+  static constexpr int PSX = ps_for(NP * CIN), PSG = ps_for(NP * COUT);
+  static constexpr int CVX = CIN / 4, CVG = COUT / 4;
+  static constexpr int IR = TR - 1 + K, IC = 15 + K;
+  static constexpr int X_U16 = IR * IC * PSX, G_U16 = TR * 16 * PSG;
+  static constexpr int LDS_BYTES = (X_U16 + G_U16) * 2 + 1024 * 4 + 64;  // + bias partials + wave maxima [parity][x|g][wave]
+  static constexpr int NIX = IR * IC * CVX, NLX = (NIX + 255) / 256;
+  static constexpr int NLG = TR * 16 * CVG / 256;
+  static constexpr int KSN = TR / 2;
+  static constexpr int MB = K * K * CIN / 16, NB = COUT / 16, T = MB * NB, TW = (T + 3) / 4;
+};
+
+typedef short f2_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x8 f2_tr_read8(const unsigned short* p0, const unsigned short* p1) {
+  const f2_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) f2_s16x4*)p0);
+  const f2_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) f2_s16x4*)p1);
+  return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void f2_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    f2_static_for<I + 1, N>(f);
+  }
+}
+
+template <int CIN, int COUT, int INACT = 0, bool INGN = false>
+__global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
+  using C = F2WxCfg<CIN, COUT>;
+  constexpr int NP = C::NP, K = C::K, TR = C::TR, WX_IC = C::IC;
+  constexpr int PSX = C::PSX, PSG = C::PSG, NLX = C::NLX, NLG = C::NLG, NB = C::NB, TW = C::TW;
+  static_assert(!INGN || 256 % C::CVX == 0, "a thread keeps its 4 channels over its items");
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  unsigned short* xl = smem16;
+  unsigned short* gl = smem16 + C::X_U16;
+  float* bred = (float*)(smem16 + C::X_U16 + C::G_U16);
+  float* mxs = bred + 1024;  // [parity][x | g][wave]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lg = lane >> 4, l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3;
+  const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + TR - 1) / TR;
+  const int ntiles = a.n * tiles_y * tiles_x;
+
+  f32x4 acc[TW];
+#pragma unroll
+  for (int j = 0; j < TW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  float4 prex[NLX], preg[NLG], preg2[INACT ? NLG : 1];
+  int ix_rc[NLX], ix_off[NLX], ig_rc[NLG], ig_off[NLG];
+#pragma unroll
+  for (int it = 0; it < NLX; ++it) {
+    const int idx = (int)threadIdx.x + it * 256;
+    const int vv = idx % C::CVX, pix = idx / C::CVX;
+    const int r = pix / WX_IC, c = pix % WX_IC;
+    ix_rc[it] = idx < C::NIX ? (r | (c << 16)) : 0x4000;
+    ix_off[it] = ((r * a.win + c) * CIN + vv * 4) * 4;
+  }
+#pragma unroll
+  for (int it = 0; it < NLG; ++it) {
+    const int idx = threadIdx.x + it * 256;
+    const int vv = idx % C::CVG, pix = idx / C::CVG;
+    ig_rc[it] = (pix >> 4) | ((pix & 15) << 16);
+    ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * COUT + vv * 4) * 4;
+  }
+  const unsigned x_bytes = (unsigned)a.hin * a.win * (CIN * 4u), g_bytes = (unsigned)a.hout * a.wout * (COUT * 4u);
+  int st_iy0 = 0, st_ix0 = 0, st_n = -1, gn_n = -1;
+  float4 gn_g = make_float4(0.f, 0.f, 0.f, 0.f), gn_b = gn_g, gn_sc = gn_g, gn_sh = gn_g;
+  if (INGN) {
+    gn_g = *(const float4*)(a.gn_gamma + ((int)threadIdx.x % C::CVX) * 4);
+    gn_b = *(const float4*)(a.gn_beta + ((int)threadIdx.x % C::CVX) * 4);
+  }
+  auto prefetch = [&](int tile) __attribute__((always_inline)) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int iy0 = ty * TR - a.pad, ix0 = tx * 16 - a.pad;
+    st_iy0 = iy0, st_ix0 = ix0, st_n = n;
+    const char* xb = (const char*)a.x + (long)n * a.hin * a.win * CIN * 4;
+    const int xoff0 = (iy0 * a.win + ix0) * (CIN * 4);
+#pragma unroll
+    for (int it = 0; it < NLX; ++it) {
+      const int iy = iy0 + (ix_rc[it] & 0xffff), ix = ix0 + (ix_rc[it] >> 16);
+      const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+      prex[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                bx_rsrc(xb, x_bytes), ok ? (unsigned)(xoff0 + ix_off[it]) : BX_OOB, 0, 0));
+    }
+    const char* gb = (const char*)a.gy + (long)n * a.hout * a.wout * COUT * 4;
+    const int goff0 = (ty * TR * a.wout + tx * 16) * (COUT * 4);
+#pragma unroll
+    for (int it = 0; it < NLG; ++it) {
+      const int oy = ty * TR + (ig_rc[it] & 0xffff), ox = tx * 16 + (ig_rc[it] >> 16);
+      const bool ok = oy < a.hout && ox < a.wout;
+      preg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                bx_rsrc(gb, g_bytes), ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
+      if (INACT)
+        preg2[it] = __builtin_bit_cast(
+            float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc((const char*)a.gact + (gb - (const char*)a.gy), g_bytes),
+                                                          ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
+    }
+  };
+  // (1) before the barrier: final fp32 values of the items in flight, this wave's two maxima into LDS
+  auto prep = [&](int parity) __attribute__((always_inline)) {
+    if (INGN && st_n != gn_n) {
+      gn_n = st_n;
+      float mean, rstd;
+      gn_moments(a.gn_stats, st_n, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
+      gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
+      gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
+    }
+    const bool gn_interior = INGN && st_iy0 >= 0 && st_ix0 >= 0 && st_iy0 + C::IR <= a.hin && st_ix0 + C::IC <= a.win;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    float mx = 0.f, mg = 0.f;
+#pragma unroll
+    for (int it = 0; it < NLX; ++it) {
+      float4 v = prex[it];
+      if (INGN) {
+        f32x2 sh_lo = {gn_sh.x, gn_sh.y}, sh_hi = {gn_sh.z, gn_sh.w};
+        if (!gn_interior) {
+          const int iy = st_iy0 + (ix_rc[it] & 0xffff), ix = st_ix0 + (ix_rc[it] >> 16);
+          const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+          sh_lo = ok ? sh_lo : (f32x2){0.f, 0.f};
+          sh_hi = ok ? sh_hi : (f32x2){0.f, 0.f};
+        }
+        const f32x2 lo = (f32x2){v.x, v.y} * (f32x2){gn_sc.x, gn_sc.y} + sh_lo;
+        const f32x2 hi = (f32x2){v.z, v.w} * (f32x2){gn_sc.z, gn_sc.w} + sh_hi;
+        v = make_float4(lo[0], lo[1], hi[0], hi[1]);
+        prex[it] = v;
+      }
+      const float mv = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+      mx = ((int)threadIdx.x + it * 256 < C::NIX) ? fmaxf(mx, mv) : mx;
+    }
+#pragma unroll
+    for (int it = 0; it < NLG; ++it) {
+      float4 v = preg[it];
+      if (INACT) {
+        const float4 q = preg2[it];
+        v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
+        v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
+        preg[it] = v;
+      }
+      bsum.x += v.x, bsum.y += v.y, bsum.z += v.z, bsum.w += v.w;
+      mg = fmaxf(mg, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    mx = f2_wave_max(mx);
+    mg = f2_wave_max(mg);
+    if (lane == 0) {
+      mxs[parity * 8 + wave] = mx;
+      mxs[parity * 8 + 4 + wave] = mg;
+    }
+  };
+  int sx_e = 60, sg_e = 60;  // running scale exponents (the clamp's upper end: any real tile lowers them)
+  // (2) after it: running scales (accumulators follow), split, LDS write
+  auto stage = [&](int parity) __attribute__((always_inline)) {
+    const float4 m0 = *(const float4*)(mxs + parity * 8), m1 = *(const float4*)(mxs + parity * 8 + 4);
+    const int ex = f2_scale_exp(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)));
+    const int eg = f2_scale_exp(fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+    const int nx = ex < sx_e ? ex : sx_e, ng = eg < sg_e ? eg : sg_e;
+    if (nx != sx_e || ng != sg_e) {  // (block-uniform, rare) a larger magnitude than any before: the accumulators follow
+      const float r = __builtin_ldexpf(1.f, (nx - sx_e) + (ng - sg_e));
+#pragma unroll
+      for (int j = 0; j < TW; ++j) acc[j] *= r;
+      sx_e = nx;
+      sg_e = ng;
+    }
+    const float scx = __builtin_ldexpf(1.f, sx_e), scg = __builtin_ldexpf(1.f, sg_e);
+#pragma unroll
+    for (int it = 0; it < NLX; ++it) {
+      const int idx = (int)threadIdx.x + it * 256;
+      if (idx < C::NIX) {
+        const float4 v = prex[it];
+        unsigned a1, a2, b1, b2;
+        f2_split_pair(v.x * scx, v.y * scx, a1, a2);
+        f2_split_pair(v.z * scx, v.w * scx, b1, b2);
+        unsigned short* p = xl + (idx / C::CVX) * PSX + (idx % C::CVX) * 4;
+        *(uint2*)(p) = make_uint2(a1, b1);
+        *(uint2*)(p + CIN) = make_uint2(a2, b2);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NLG; ++it) {
+      const int idx = threadIdx.x + it * 256;
+      const float4 v = preg[it];
+      unsigned a1, a2, b1, b2;
+      f2_split_pair(v.x * scg, v.y * scg, a1, a2);
+      f2_split_pair(v.z * scg, v.w * scg, b1, b2);
+      unsigned short* p = gl + (idx / C::CVG) * PSG + (idx % C::CVG) * 4;
+      *(uint2*)(p) = make_uint2(a1, b1);
+      *(uint2*)(p + COUT) = make_uint2(a2, b2);
+    }
+  };
+
+  if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+  auto run = [&](auto wc) __attribute__((always_inline)) {
+    constexpr int W = decltype(wc)::value, T0 = TW * W, T1 = (T0 + TW < C::T) ? T0 + TW : C::T;
+    constexpr int NTW = T1 > T0 ? T1 - T0 : 0;
+    constexpr int MB0 = T0 / NB, NG = NTW ? (T1 - 1) / NB - MB0 + 1 : 0;
+    constexpr int NU = C::KSN * NG, NGD = NG ? NG : 1;
+    auto load_fb = [&](int ks, s16x8 (&F)[NP][NB]) __attribute__((always_inline)) {
+      const unsigned short* gq = gl + (2 * ks * 16 + 4 * lg + tq) * PSG + tp * 4;
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) F[p][nb] = f2_tr_read8(gq + p * COUT + nb * 16, gq + 16 * PSG + p * COUT + nb * 16);
+    };
+    auto load_fa = [&](int ks, int mb, s16x8 (&F)[NP]) __attribute__((always_inline)) {
+      const int tap = CIN == 32 ? mb >> 1 : mb, half = CIN == 32 ? mb & 1 : 0, ky = tap / K, kx = tap - K * ky;
+      const unsigned short* xq = xl + ((2 * ks + ky) * WX_IC + (4 * lg + tq) + kx) * PSX + half * 16 + tp * 4;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) F[p] = f2_tr_read8(xq + p * CIN, xq + WX_IC * PSX + p * CIN);
+    };
+    int parity = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      prep(parity);
+      __syncthreads();
+      stage(parity);
+      __syncthreads();
+      parity ^= 1;
+      if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+      if (NTW > 0) {
+        s16x8 fa[2][NP], fb[2][NP][NB];
+        load_fb(0, fb[0]);
+        load_fa(0, MB0, fa[0]);
+        f2_static_for<0, NU>([&](auto uc) __attribute__((always_inline)) {
+          constexpr int u = decltype(uc)::value;
+          constexpr int ks = u / NGD, gi = u % NGD, mb = MB0 + gi;
+          int nread = 0;
+          if (u + 1 < NU) {
+            const int ks2 = (u + 1) / NGD, gi2 = (u + 1) % NGD;
+            if (gi2 == 0) load_fb(ks2, fb[ks2 & 1]), nread += 2 * NP * NB;
+            load_fa(ks2, MB0 + gi2, fa[(u + 1) & 1]);
+            nread += 2 * NP;
+          }
+          constexpr int PA[3] = {1, 0, 0};
+          constexpr int PB[3] = {0, 1, 0};
+          int nm = 0;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int t = NB * mb + nb;
+            if (t >= T0 && t < T1) {
+#pragma unroll
+              for (int q = 0; q < 3; ++q)
+                acc[t - T0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa[u & 1][PA[q]]),
+                                                                     __builtin_bit_cast(f16x8_t, fb[ks & 1][PB[q]][nb]),
+                                                                     acc[t - T0], 0, 0, 0);
+              nm += 3;
+            }
+          }
+          const int per = nm ? (nread + nm - 1) / nm : 0;
+#pragma unroll
+          for (int g = 0; g < 6; ++g)
+            if (g < nm) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (per == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              else if (per == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              else if (per == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+              else if (per >= 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    }
+    // partial slab of this workgroup: [m = mb*16 + row][co], scales undone
+    const float desc = __builtin_ldexpf(1.f, -(sx_e + sg_e));
+    float* out = a.part + (long)blockIdx.x * (C::MB * 16 * COUT);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int t = T0 + j, mb = t / NB, nb = t % NB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(mb * 16 + lg * 4 + r) * COUT + nb * 16 + l16] = acc[j][r] * desc;
+    }
+  };
+  switch (wave) {
+    case 0: run(std::integral_constant<int, 0>{}); break;
+    case 1: run(std::integral_constant<int, 1>{}); break;
+    case 2: run(std::integral_constant<int, 2>{}); break;
+    default: run(std::integral_constant<int, 3>{}); break;
+  }
+  if (a.bpart) {
+    __syncthreads();
+    const int vv = threadIdx.x % C::CVG, row = threadIdx.x / C::CVG;
+    bred[row * COUT + vv * 4 + 0] = bsum.x;
+    bred[row * COUT + vv * 4 + 1] = bsum.y;
+    bred[row * COUT + vv * 4 + 2] = bsum.z;
+    bred[row * COUT + vv * 4 + 3] = bsum.w;
+    __syncthreads();
+    if (threadIdx.x < COUT) {
+      float sum = 0.f;
+      for (int r = 0; r < 256 / C::CVG; ++r) sum += bred[r * COUT + threadIdx.x];
+      a.bpart[(long)blockIdx.x * COUT + threadIdx.x] = sum;
+    }
+  }
+}
+
+template <int CIN, int COUT>
+static hipError_t f2_wgrad_launch(const WgArgs& a, int inact, long workers, hipStream_t stream) {
+  using C = F2WxCfg<CIN, COUT>;
+  static_assert(2 * C::LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+  const bool ingn = a.gn_stats != nullptr;
+  static bool attr_set[3] = {};
+  auto launch = [&](auto kern, int slot) -> hipError_t {
+    if (!attr_set[slot]) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+      if (e != hipSuccess) return e;
+      attr_set[slot] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)workers), dim3(256), C::LDS_BYTES, stream, a);
+    return hipSuccess;
+  };
+  if (ingn) {
+    if constexpr (CIN == COUT) {
+      if (inact) return hipErrorInvalidValue;
+      return launch(conv_wgrad_f16x2_kernel<CIN, COUT, 0, true>, 2);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
+  if (inact == DIS_ACT_SELU) return launch(conv_wgrad_f16x2_kernel<CIN, COUT, DIS_ACT_SELU>, 1);
+  if (inact == 0) return launch(conv_wgrad_f16x2_kernel<CIN, COUT, 0>, 0);
+  return hipErrorInvalidValue;
+}
+
+hipError_t dis_f2_wgrad_launch(const WgArgs& a, int cin, int cout, int inact, long workers, hipStream_t stream) {
+  if (a.xscale) return hipErrorInvalidValue;
+  if (cin == 32 && cout == 32) return f2_wgrad_launch<32, 32>(a, inact, workers, stream);
+  if (cin == 16 && cout == 16) return f2_wgrad_launch<16, 16>(a, inact, workers, stream);
+  if (cin == 16 && cout == 32) return f2_wgrad_launch<16, 32>(a, inact, workers, stream);
+  if (cin == 32 && cout == 16) return f2_wgrad_launch<32, 16>(a, inact, workers, stream);
+  return hipErrorInvalidValue;
+}

@@ -55,6 +55,8 @@ SIGS = {
     'dis_conv2d_pack_bf16x3_size': 'ii',
     'dis_conv2d_dgrad_bf16x3_act': 'ppipiiipiiiiiiip',
     'dis_conv2d_wgrad_bf16x3_act': 'pppipppiiiiiiiiip',
+    'dis_set_conv_split': 'i',
+    'dis_get_conv_split': '',
     'dis_conv2d_fwd_bf16x3_gn': 'ppppfpiiipppiiiiiiiiip',
     'dis_conv2d_wgrad_bf16x3_gn': 'ppppfppppiiiiiiiiip',
     'dis_conv2d_fwd_scaled': 'ppppppp' + 'iiiiiiiii' + 'p',

@@ -260,6 +260,11 @@ int dis_conv2d_wgrad_bf16x3_act(const float* x, const float* gy, const float* y,
 int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
                      int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,
                      void* stream);
+/* Operand split of the dis_conv2d_*_bf16x3* entry points that take fp32 weights (round 3): 1 = two fp16 terms, 3 products per
+ * MAC (22-bit operands, power-of-two block scaling; default), 0 = three bf16 terms, 6 products (>= 24 bits).  Process-wide;
+ * DIS_CONV_SPLIT=bf16x3 | f16x2 sets the initial value.  Same arguments, layouts and workspaces either way. */
+int dis_set_conv_split(int mode);
+int dis_get_conv_split(void);
 /* GroupNorm applied ON LOAD by the consuming convolution (round 3).  The reference chains Conv2d -> SELU -> GroupNorm(1, C) ->
  * Conv2d (ResNetBlock model/multi_frame_networks.py:514-542; Block2D3D conv1_1 -> conv1_2, conv2_1 -> conv2_2 :338-345) and
  * writes the normalised tensor between them; here x is the PRE-normalisation tensor and the consumer stages

@@ -21,13 +21,23 @@ P = ctypes.c_void_p
 L.dis_conv2d_pack_weights_bf16x3(P(wt.data_ptr()), P(pk.data_ptr()), 32, 32, 3, 0, P(0))
 
 
+F2 = len(sys.argv) > 4 and sys.argv[4] == 'f16x2'   # python scripts/stamp_bf16x3.py n h w f16x2: the two-term fp16 kernel
+
+
 def run(act, stats):
+    if F2:
+        return L.dis_conv2d_fwd_bf16x3_oihw(P(x.data_ptr()), P(wt.data_ptr()), 0, 32, 32, 0, P(b.data_ptr()), P(y.data_ptr()),
+                                            P(st.data_ptr() if stats else 0), n, h, w, 32, 32, 3, 1, 1, act, P(0))
     return L.dis_conv2d_fwd_bf16x3(P(x.data_ptr()), P(pk.data_ptr()), P(b.data_ptr()), P(y.data_ptr()),
                                    P(st.data_ptr() if stats else 0), n, h, w, 32, 32, 3, 1, 1, act, P(0))
 
 
 names = ['tile setup (first: weight copy)', 'barrier A (skew)', 'stage (wait halo+split+ds_write)', 'barrier B',
          'next-tile coordinates', 'MFMA loop + halo issue + deferred epilogue', 'hand-over', 'last epilogue + stats']
+if F2:
+    names = ['tile setup (first: weight split)', 'prep (wait halo, values, wave max)', 'barrier A (skew)',
+             'stage (scale + split + ds_write)', 'barrier B', 'MFMA loop + halo issue + deferred epilogue',
+             'hand-over (descale + bias)', 'last epilogue + stats']
 for act, stats, label in ((1, True, 'fwd: SELU + GN stats'), (0, False, 'dgrad: no act, no stats'),
                           (0x100, False, 'dgrad accumulating into y')):
     for _ in range(200):  # hold the clock where a training step holds it
@@ -37,7 +47,7 @@ for act, stats, label in ((1, True, 'fwd: SELU + GN stats'), (0, False, 'dgrad: 
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(act, stats); e1.record()
     torch.cuda.synchronize()
-    assert L.dis_debug_bx_stamps(buf.ctypes.data_as(P)) == 0
+    assert (L.dis_debug_f2_stamps if F2 else L.dis_debug_bx_stamps)(buf.ctypes.data_as(P)) == 0
     s = buf.reshape(256, 8, 8).astype(np.float64)
     tiles = n * ((h + 15) // 16) * ((w + 15) // 16)
     per_cu = tiles / float(os.environ.get('BX_GRID', 256))
