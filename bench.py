@@ -353,9 +353,20 @@ def main():
             # (the product path hands the OIHW weights to the kernel: same int args behind `mode, w_o, w_i, w_row_stride`; the 32 -> 32 instance)
             sel += [(ia[4:], ms) for name, ia, ms in rec
                     if name == 'dis_conv2d_fwd_bf16x3_oihw' and ia[7:11] == (32, 32, 3, 1)]
-            kname = ('conv_bf16x3_kernel (fp32 conv as 6 bf16 products per MAC on v_mfma_f32_16x16x32_bf16, fp32 '
-                     'accumulate; TFLOP/s are fp32-equivalent algorithmic flops)')
-            peak, peak_note = PEAK_BF16_MFMA_TFLOPS / 6.0, 'bf16 MFMA dense peak (2500 TFLOP/s) / 6 products per fp32 MAC'
+            # ... and the GroupNorm-on-load form of the same kernel: int args (w_o, w_i, w_row_stride, n, hin, win, cin, cout, k, ...)
+            sel += [(ia[3:], ms) for name, ia, ms in rec
+                    if name == 'dis_conv2d_fwd_bf16x3_gn' and ia[6:10] == (32, 32, 3, 1)]
+            f2 = lib.fn('dis_get_conv_split')() == 1
+            nprod = 3 if f2 else 6
+            if f2:
+                kname = ('conv_f16x2_kernel (fp32 conv as 3 fp16 products per MAC on v_mfma_f32_16x16x32_f16: two-term operand '
+                         'split with power-of-two block scaling, fp32 accumulate; TFLOP/s are fp32-equivalent algorithmic flops; '
+                         'the 32 -> 32 3x3 launches incl. the GroupNorm-on-load form)')
+            else:
+                kname = ('conv_bf16x3_kernel (fp32 conv as 6 bf16 products per MAC on v_mfma_f32_16x16x32_bf16, fp32 '
+                         'accumulate; TFLOP/s are fp32-equivalent algorithmic flops)')
+            peak = PEAK_BF16_MFMA_TFLOPS / nprod
+            peak_note = f'bf16 / fp16 MFMA dense peak (2500 TFLOP/s) / {nprod} products per fp32 MAC'
             if not sel:  # DIS_CONV_BF16X3=0: the fp32-MFMA kernel
                 sel = [(ia, ms) for name, ia, ms in rec if name == 'dis_conv2d_fwd' and ia[3:7] == (32, 32, 3, 1)]
                 kname = 'conv_fwd_kernel<32,32,3,3,1> (fp32 MFMA 16x16x4)'
@@ -483,8 +494,13 @@ def main():
                        'global_batch': world * args.bs, 'parallelism': f'dp{world}', 'hip_graph': bool(use_graph),
                        'backend': (args.backend if world > 1 else None),
                        'conv_arithmetic': (('fp32 results everywhere; the 3x3 stride-1 convs with 16 / 32 channels (fwd, '
-                                            'dgrad, wgrad) run as bf16x3 (3-way bf16 operand split, 6 products, fp32 '
-                                            'accumulate: error vs fp64 <= the exact-fp32 MFMA kernel, '
+                                            'dgrad, wgrad) run as ' +
+                                            ('f16x2 (two-term fp16 operand split with power-of-two block scaling, 3 products, '
+                                             'fp32 accumulate: 22-bit operands, error vs fp64 < 1e-6 of the largest entry; '
+                                             'DIS_CONV_SPLIT=bf16x3 selects the three-term bf16 split, 6 products, >= 24 bits; '
+                                             if lib.fn('dis_get_conv_split')() == 1 else
+                                             'bf16x3 (3-way bf16 operand split, 6 products, fp32 accumulate: error vs fp64 <= '
+                                             'the exact-fp32 MFMA kernel; ') +
                                             'tests/test_net_ops_gpu.py), all other convs on v_mfma_f32_16x16x4_f32' if mf else
                                             'fp32 results everywhere; forward / input-gradient convs with >= 32 input '
                                             'channels run as bf16x3 (3-way bf16 operand split, 6 products, fp32 accumulate), '

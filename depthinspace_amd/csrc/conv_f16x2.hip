@@ -97,6 +97,19 @@ __device__ __forceinline__ float f2_wave_max(float m) {
   return __int_as_float(__builtin_amdgcn_readlane(v, 63));
 }
 
+// sum of a double over the wave (DPP row operations on the two halves, no LDS traffic); valid in lane 63
+__device__ __forceinline__ double f2_wave_sum_d(double v) {
+#define F2_DPPD(ctrl, rmask)                                                                              \
+  {                                                                                                       \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, true);             \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, true);             \
+    v += __hiloint2double(hi, lo);                                                                        \
+  }
+  F2_DPPD(0xB1, 0xf) F2_DPPD(0x4E, 0xf) F2_DPPD(0x124, 0xf) F2_DPPD(0x128, 0xf) F2_DPPD(0x142, 0xa) F2_DPPD(0x143, 0xc)
+#undef F2_DPPD
+  return v;
+}
+
 // power-of-two scale exponent that brings a block's largest magnitude into [2^14, 2^15) (fp16's largest binade is 2^15);
 // clamped so that the product of two scales and its inverse stay representable in fp32
 __device__ __forceinline__ int f2_scale_exp(float m) {
@@ -268,6 +281,11 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     float m = dis_copy_w_rows(a.w, a.w_o, row, a.w_rs, ws);
     m = f2_wave_max(m);
     if (lane == 0) mxs[wave] = m;
+    if (threadIdx.x == 0) {  // statistics accumulators (stats_flush)
+      red[0] = 0.0;
+      red[1] = 0.0;
+      *(unsigned*)(red + 2) = 0u;
+    }
     __syncthreads();
     const float4 m0 = *(const float4*)(mxs), m1 = *(const float4*)(mxs + 4);
     sw_e = f2_scale_exp(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))));
@@ -289,6 +307,10 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   }
 
   f32x4 acc[2][NT], outv[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) outv[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};  // (the first tile's ride has no finished tile: 0 * livef)
   float4 prevy[NPIECE];
   double s1 = 0.0, s2 = 0.0;
   float t1 = 0.f, t2 = 0.f;
@@ -303,12 +325,26 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   const float* prev_y = a.y;
   unsigned prev_off[2] = {BX_OOB, BX_OOB};
   int prev_n = -1;
+  // GroupNorm statistics leave through ONE fp64 atomic pair per workgroup and sample, without a block-wide barrier: every
+  // wave adds its sums (DPP reduction) to two LDS accumulators and counts itself in; the wave that finds the count complete
+  // moves the totals to memory and clears the slots (the next flush is at least one tile - two barriers - away).  The two
+  // block_sum_d of the bf16x3 kernel cost 4 barriers and 24 LDS shuffles per flush: ~9 us per launch at 2 - 3 flushes per
+  // workgroup (scripts/diag/conv_fixed_cost.py).
   auto stats_flush = [&]() {
-    const double r1 = block_sum_d(s1, red);
-    const double r2 = block_sum_d(s2, red);
-    if (threadIdx.x == 0) {
-      atomic_add_d(a.stats + 2 * stat_n, r1);
-      atomic_add_d(a.stats + 2 * stat_n + 1, r2);
+    const double r1 = f2_wave_sum_d(s1), r2 = f2_wave_sum_d(s2);
+    if (lane == 63) {
+      __hip_atomic_fetch_add(red, r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(red + 1, r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned arrived = __hip_atomic_fetch_add((unsigned*)(red + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (arrived == 7u) {  // (LDS operations of a wave complete in order: the other waves' sums are in)
+        const double q1 = __hip_atomic_load(red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const double q2 = __hip_atomic_load(red + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        atomic_add_d(a.stats + 2 * stat_n, q1);
+        atomic_add_d(a.stats + 2 * stat_n + 1, q2);
+        red[0] = 0.0;
+        red[1] = 0.0;
+        *(unsigned*)(red + 2) = 0u;
+      }
     }
     s1 = 0.0;
     s2 = 0.0;
@@ -325,30 +361,32 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       prevy[i] = __builtin_bit_cast(
           float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(yb, y_bytes), off[i / NT] + (i % NT) * 64, 0, 0));
   };
+  float livef[2] = {0.f, 0.f};  // 1 for the deferred tile's pixels of this lane that exist (statistics)
   auto epi_piece = [&](int i) {
     const int mt = i / NT, nt = i % NT;
-    float o[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = outv[mt][nt][r];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (ACT == DIS_ACT_SELU) {
-        const float e = __builtin_amdgcn_exp2f(fminf(o[r], 0.f) * 1.44269504088896340736f);
-        o[r] = SELU_SCALE_F * fmaxf(o[r], 0.f) + (SELU_SCALE_F * SELU_ALPHA_F) * (e - 1.f);
-      } else if (ACT == DIS_ACT_RELU) {
-        o[r] = fmaxf(o[r], 0.f);
-      }
+    f32x2 lo = {outv[mt][nt][0], outv[mt][nt][1]}, hi = {outv[mt][nt][2], outv[mt][nt][3]};
+    if (ACT == DIS_ACT_SELU) {
+      // scale * max(x, 0) + scale * alpha * (exp(min(x, 0)) - 1), branch-free (for x > 0 the second term is sa * 1 - sa = 0
+      // exactly), as two packed fused multiply-adds per pair: 5.5 issue slots per element instead of 9
+      constexpr float L2E = 1.44269504088896340736f, SA = SELU_SCALE_F * SELU_ALPHA_F;
+      const f32x2 nlo = (f32x2){fminf(lo[0], 0.f), fminf(lo[1], 0.f)} * (f32x2){L2E, L2E};
+      const f32x2 nhi = (f32x2){fminf(hi[0], 0.f), fminf(hi[1], 0.f)} * (f32x2){L2E, L2E};
+      const f32x2 elo = {__builtin_amdgcn_exp2f(nlo[0]), __builtin_amdgcn_exp2f(nlo[1])};
+      const f32x2 ehi = {__builtin_amdgcn_exp2f(nhi[0]), __builtin_amdgcn_exp2f(nhi[1])};
+      const f32x2 tlo = __builtin_elementwise_fma((f32x2){SA, SA}, elo, (f32x2){-SA, -SA});
+      const f32x2 thi = __builtin_elementwise_fma((f32x2){SA, SA}, ehi, (f32x2){-SA, -SA});
+      lo = __builtin_elementwise_fma((f32x2){SELU_SCALE_F, SELU_SCALE_F}, (f32x2){fmaxf(lo[0], 0.f), fmaxf(lo[1], 0.f)}, tlo);
+      hi = __builtin_elementwise_fma((f32x2){SELU_SCALE_F, SELU_SCALE_F}, (f32x2){fmaxf(hi[0], 0.f), fmaxf(hi[1], 0.f)}, thi);
+    } else if (ACT == DIS_ACT_RELU) {
+      lo = (f32x2){fmaxf(lo[0], 0.f), fmaxf(lo[1], 0.f)};
+      hi = (f32x2){fmaxf(hi[0], 0.f), fmaxf(hi[1], 0.f)};
     }
-    const bool live = prev_off[mt] != BX_OOB;
-    u32x4 ov;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ov[r] = __float_as_uint(o[r]);
+    const u32x4 ov = {__float_as_uint(lo[0]), __float_as_uint(lo[1]), __float_as_uint(hi[0]), __float_as_uint(hi[1])};
     __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(prev_y, y_bytes), prev_off[mt] + nt * 64, 0, 0);
     if (STATS) {
-      const float q1 = (o[0] + o[1]) + (o[2] + o[3]);
-      const float q2 = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
-      t1 += live ? q1 : 0.f;
-      t2 += live ? q2 : 0.f;
+      const f32x2 sm = lo + hi, sq = lo * lo + hi * hi;
+      t1 = __builtin_fmaf(livef[mt], sm[0] + sm[1], t1);
+      t2 = __builtin_fmaf(livef[mt], sq[0] + sq[1], t2);
     }
   };
 
@@ -504,6 +542,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       prev_off[mt] = cur_off[mt];
+      livef[mt] = cur_off[mt] != BX_OOB ? 1.f : 0.f;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const f32x4 bv = {bias_v[nt].x, bias_v[nt].y, bias_v[nt].z, bias_v[nt].w};
