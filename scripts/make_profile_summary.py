@@ -20,7 +20,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = 'conv_bf16x3_kernel<32, 32,'  # every <ACT, ACCUM, STATS> instance of the 32 -> 32 kernel (bench.py's roofline)
+# every <ACT, ACCUM, STATS, ...> instance of the 32 -> 32 kernel (bench.py's roofline): the two-term fp16 kernel (default since
+# round 3), else the three-term bf16 kernel
+DOMINANTS = ('conv_f16x2_kernel<32, 32,', 'conv_bf16x3_kernel<32, 32,')
 
 
 def main(tag):
@@ -73,12 +75,16 @@ def main(tag):
                 'HBM columns: PMC passes of one eager step (`scripts/prof_round.sh`), FETCH_SIZE doubled as '
                 'MI355X_MICROARCH.md prescribes for gfx950; wait/active columns are fractions of SQ_WAVE_CYCLES.\n\n')
         f.write('\n'.join(lines) + '\n')
-    fam = [m for k, m in mem.items() if DOMINANT in k]
+    fam, DOMINANT = [], DOMINANTS[0]
+    for DOMINANT in DOMINANTS:
+        fam = [m for k, m in mem.items() if DOMINANT in k]
+        if fam:
+            break
     if fam:
         calls = sum(int(m['Calls']) for m in fam)
         rd = sum(float(m['FETCH_SIZE']) * 2 * 1024 * int(m['Calls']) for m in fam) / calls
         wr = sum(float(m['WRITE_SIZE']) * 1024 * int(m['Calls']) for m in fam) / calls
-        json.dump({'kernel': 'conv_bf16x3_kernel<32, 32, ACT, ACCUM, STATS> (all instances, launch-weighted)',
+        json.dump({'kernel': DOMINANT + ' ACT, ACCUM, STATS, ...> (all instances, launch-weighted)',
                    'hbm_bytes_per_launch': rd + wr, 'read_bytes': rd, 'write_bytes': wr,
                    'launches_averaged': calls,
                    'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over one eager step; '
