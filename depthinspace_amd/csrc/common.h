@@ -30,15 +30,37 @@ static inline int dis_red_grid(long work_items, int block) {
   return (int)g;
 }
 
+// Wave-wide sums with DPP row operations (no LDS traffic, fixed summation order): quad swaps, row rotations, then the
+// row_bcast steps; lane 63 holds the total, which is broadcast - the result is valid in EVERY lane.
+#define DIS_DPP_STEPS(STEP) STEP(0xB1, 0xf) STEP(0x4E, 0xf) STEP(0x124, 0xf) STEP(0x128, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef DIS_WAVE_SUM_SHFL
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
+#else
+#define DIS_STEP_F(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, true));
+  DIS_DPP_STEPS(DIS_STEP_F)
+#undef DIS_STEP_F
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+#endif
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
+#ifdef DIS_WAVE_SUM_SHFL
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
+#else
+#define DIS_STEP_D(ctrl, rmask)                                                                 \
+  {                                                                                             \
+    const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, true);  \
+    const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, true);  \
+    v += __hiloint2double(hi_, lo_);                                                            \
+  }
+  DIS_DPP_STEPS(DIS_STEP_D)
+#undef DIS_STEP_D
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+#endif
 }
 
 // Block-wide sum of a double; result valid in thread 0.  `sm` needs blockDim.x/64 doubles.
@@ -54,6 +76,8 @@ __device__ __forceinline__ double block_sum_d(double v, double* sm) {
   return r;
 }
 
+// (fire-and-forget: a returning atomic + wait was tried against the sharing anomaly of round 2 and changed nothing - the
+// anomaly was a packed-fp32 hazard, see the Makefile)
 __device__ __forceinline__ void atomic_add_d(double* p, double v) { atomicAdd(p, v); }
 
 #define SELU_ALPHA_F 1.6732632423543772848170429916717f

@@ -56,6 +56,18 @@ __host__ __device__ inline long packed_w_offset(int tap, int c, int co, int cin,
   return ((((long)(tap * nchunk + chunk) * 4 + g) * nq + q) * cout + co) * e + ee;
 }
 
+// Sum of squares of the outputs (GroupNorm statistics): a fused multiply-add per value.  Written as `t1 += v; t2 += v * v` the
+// compiler packs the two accumulators into one register pair and emits v_mul_f32 v[n+1], v, v ; v_pk_add_f32 acc[0:1], acc[0:1],
+// v[n:n+1] - and that sequence LOSES one half's addend in lanes 48..63 of a wave in ~17 % of the launches once other processes
+// time-share the GPU (never alone): scripts/diag/share_repro.hip isolates it (per-thread sums dumped: every deviating thread is in
+// lanes 48..63, one of its two sums short by exactly one term, outputs bit-identical), and with this form the count is 0 of
+// 8000.  DESIGN.md section 4.  (-DDIS_STATS_PK_ORIG restores the old form for the reproducer.)
+#ifdef DIS_STATS_PK_ORIG
+#define DIS_T2_ACC(t2, v) t2 += (v) * (v)
+#else
+#define DIS_T2_ACC(t2, v) t2 = __builtin_fmaf(v, v, t2)
+#endif
+
 template <int CIN, int COUT, int KH, int KW, int S>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   using C = ConvCfg<CIN, COUT, KH, KW, S>;
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
               const float v = act_apply(pre_v, ACT);
               *yp = v;
               t1 += v;
-              t2 += v * v;
+              DIS_T2_ACC(t2, v);
             }
       } else {
 #pragma unroll
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                 const float v = act_apply(pre_v, ACT);
                 *yp = v;
                 t1 += v;
-                t2 += v * v;
+                DIS_T2_ACC(t2, v);
               }
             }
       }
@@ -292,11 +304,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     tile += per;
   }
   if (a.stats && stat_n >= 0) {
+#ifdef DIS_STATS_DUMP  // diagnostic build (scripts/diag/share_repro.hip): every thread's sums, behind the n x 2 statistics
+    a.stats[2 * a.n + 2 * (blockIdx.x * 256 + threadIdx.x)] = s1;
+    a.stats[2 * a.n + 2 * (blockIdx.x * 256 + threadIdx.x) + 1] = s2;
+#endif
     const double r1 = block_sum_d(s1, red);
     const double r2 = block_sum_d(s2, red);
     if (threadIdx.x == 0) {
       atomic_add_d(a.stats + 2 * stat_n, r1);
       atomic_add_d(a.stats + 2 * stat_n + 1, r2);
+#ifdef DIS_STATS_DUMP
+      a.stats[2 * a.n + 2 * 256 * gridDim.x + 2 * blockIdx.x] = r1;
+      a.stats[2 * a.n + 2 * 256 * gridDim.x + 2 * blockIdx.x + 1] = r2;
+#endif
     }
   }
 }

@@ -167,13 +167,12 @@ def test_two_rank_train_step(arch, tmp_path):
         for k_, v_ in sorted(res[r].items()):
             print(f'rank {r} {k_}: {v_}')
         # reduced gradient == sum of the ranks' own gradients (float atomics in two scatter kernels: tolerance, not bits; measured
-        # <= 3e-7).  The two ranks of this test TIME-SHARE one GPU: under that sharing (never with one process per GPU) an
-        # evaluation of the DIS-MF step occasionally comes out ~1e-4..1e-3 off - the GroupNorm sums of one 1x1-conv launch lose
-        # the contribution of 16 lanes (scripts/diag/dbg_scaled_stats2.py) - so the bar is the MEDIAN of the steps,
-        # with a loose bound on every step.
-        errs = sorted(res[r][f'grad_err{step}'] for step in range(NSTEPS))
-        assert errs[NSTEPS // 2] < 1e-5, (r, errs, res[r])
-        assert errs[-1] < 2e-2, (r, errs, res[r])
+        # <= 3e-7), on EVERY step.  The two ranks of this test time-share one GPU; in round 2 that sharing made an evaluation of
+        # the DIS-MF step come out 1e-4..1e-3 off once in ~10 steps and the bar here was a median.  Round 3 found the cause - a
+        # compiler-formed v_pk_add_f32 losing one half's addend in lanes 48..63 under contention (scripts/diag/share_repro.hip,
+        # DESIGN.md section 4) - and the library is now built without packed fp32 instructions: the per-step bar is back.
+        errs = [res[r][f'grad_err{step}'] for step in range(NSTEPS)]
+        assert max(errs) < 1e-5, (r, errs, res[r])
         # step 0 learns the notification pattern; from step 1 on (almost) every bucket is in flight before backward returns
         assert res[r]['early'][0] == 0 and all(e >= res[r]['nbuckets'] - 1 for e in res[r]['early'][1:]), res[r]
         assert res[r]['replicas_equal'] and res[r]['steps'] == NSTEPS
