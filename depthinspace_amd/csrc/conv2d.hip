@@ -1137,6 +1137,8 @@ struct GnIn {  // GroupNorm applied to x on load (ConvArgs::gn_stats ...); stats
   const float* gamma = nullptr;
   const float* beta = nullptr;
   float eps = 0.f;
+  const float* ab_x = nullptr;  // ConvArgs::ab_x / ab_out (f16x2 kernel only)
+  double* ab_out = nullptr;
 };
 static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o, int w_i, int w_rs, const float* bias, float* y,
                               double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad,
@@ -1160,6 +1162,8 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
   a.w_rs = w_rs;
   a.xact = xact;
   a.gn_stats = gn.stats; a.gn_gamma = gn.gamma; a.gn_beta = gn.beta; a.gn_eps = gn.eps;
+  a.ab_x = gn.ab_x; a.ab_out = gn.ab_out; a.ab_slots = num_cus();
+  if (gn.ab_out && !(dis_f2_enabled() && wmode >= 0)) return DIS_ERR_UNSUPPORTED;  // (the two-term kernel's epilogue)
   if (gn.stats && (!gn.gamma || !gn.beta)) return DIS_ERR_NULL;
   if (gn.stats && (cin != cout || inact || (act & DIS_CONV_ACCUM) || ((act & 0xff) != DIS_ACT_NONE && (act & 0xff) != DIS_ACT_SELU)))
     return DIS_ERR_UNSUPPORTED;
@@ -1185,6 +1189,7 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
     }
     if (le != hipErrorInvalidValue) return (int)le;
   }
+  if (gn.ab_out) return DIS_ERR_UNSUPPORTED;
   if (cin == 32 && cout == 32) le = bx_launch<32, 32>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
   else if (cin == 16 && cout == 16) le = bx_launch<16, 16>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
   else if (cin == 16 && cout == 32) le = bx_launch<16, 32>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
@@ -1228,6 +1233,24 @@ extern "C" int dis_conv2d_fwd_bf16x3_gn(const float* x, const double* gn_stats, 
   gn.stats = gn_stats; gn.gamma = gn_gamma; gn.beta = gn_beta; gn.eps = gn_eps;
   return launch_conv_bf16x3(x, w_oihw, 0, w_o, w_i, w_row_stride, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act,
                             stream, nullptr, 0, gn);
+}
+/* Input gradient of the conv of dis_conv2d_fwd_bf16x3_gn, g = conv_T(gy, w), which ALSO leaves what the GroupNorm backward needs
+ * besides g: per (sample, channel) the sums of g and of g * x over the pixels (x = gn_x, the GroupNorm's input, shaped like g),
+ * one fp64 slot per workgroup: ab_out (n, dis_conv2d_gnsums_slots(), 2, cin) doubles, ZEROED by the caller.  Replaces the
+ * reduce pass of dis_gn_apply_bwd (a read of g and x).  Two-term fp16 kernels only (DIS_ERR_UNSUPPORTED otherwise: the caller keeps
+ * the two-pass form). */
+extern "C" long dis_conv2d_gnsums_slots(void) { return num_cus(); }
+extern "C" int dis_conv2d_dgrad_bf16x3_gnsums(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g,
+                                              const float* gn_x, double* ab_out, int n, int hin, int win, int cin, int cout,
+                                              int pad, void* stream) {
+  if (!gn_x || !ab_out) return DIS_ERR_NULL;
+  if (w_o <= 0 || w_i <= 0 || w_o > 32 || w_i > 32 || cin != w_o || cout != w_i || cin != cout) return DIS_ERR_BAD_SHAPE;
+  if (w_row_stride == 0) w_row_stride = w_i * 9;
+  if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
+  GnIn gn;
+  gn.ab_x = gn_x; gn.ab_out = ab_out;
+  return launch_conv_bf16x3(gy, w_oihw, 1, w_o, w_i, w_row_stride, nullptr, g, nullptr, n, hin, win, cin, cout, 3, 1, pad, 0, stream,
+                            nullptr, 0, gn);
 }
 /* Input gradient of a 3x3 stride-1 convolution that was followed by an activation, with the activation's gradient fused
  * in: gx (+)= conv_T(gy * act'(y), w) where y (same shape as gy) is the activation's output.  Replaces dis_act_bwd +
@@ -1295,6 +1318,7 @@ int dis_bx_slices_run(int dgrad, const float* x, int ldx, int xoff, int cin, int
       if (!first) a.bias = nullptr;
       a.xscale = nullptr; a.yscale = nullptr; a.xact = nullptr;
       a.gn_stats = nullptr; a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_eps = 0.f;
+      a.ab_x = nullptr; a.ab_out = nullptr; a.ab_slots = 0;
       a.ldx = ldx; a.ldy = ldy;
       a.cx = cin - 32 * cb < 32 ? cin - 32 * cb : 32;
       a.cy = cout - 32 * gb < 32 ? cout - 32 * gb : 32;

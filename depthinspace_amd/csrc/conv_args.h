@@ -36,6 +36,13 @@ struct ConvArgs {
   const float* gn_gamma;
   const float* gn_beta;
   float gn_eps;
+  // f16x2 kernel, EPIAB instance (input gradient of the conv that consumes a GroupNorm output, conv2d_gn_in): besides the
+  // gradient g it writes, the epilogue sums g and g * x per (sample, channel), x = the GroupNorm's INPUT at the same positions
+  // (ab_x, shaped like y); every workgroup leaves its sums of a sample in its own slot ab_out[(sample * ab_slots + block) * 2 C ..]
+  // (fp64: C sums of g, C sums of g * x; the buffer arrives zeroed).  These are all the GroupNorm backward needs besides g.
+  const float* ab_x;
+  double* ab_out;
+  int ab_slots;  // slots per sample in ab_out (>= gridDim.x)
 };
 
 struct WgArgs {

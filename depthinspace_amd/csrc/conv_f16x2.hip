@@ -55,7 +55,8 @@ struct F2Cfg {
   static constexpr int KS = CIN == 32 ? 9 : 5;  // k-steps: a tap (32 channels) or a pair of taps (16 + 16)
   static constexpr int W_U16 = KS * NP * 4 * COUT * 8;  // packed[kstep][plane][lg][co][8]
   static constexpr int X_U16 = IR * IC * PS;
-  static constexpr int LDS_BYTES = W_U16 * 2 + X_U16 * 2 + 64 + 64;  // + stats reduction (8 doubles) + wave maxima (2 x 8 floats)
+  // + stats reduction (8 doubles) + wave maxima (2 x 8 floats) + per-wave channel sums of the EPIAB form (8 x 2 COUT floats)
+  static constexpr int LDS_BYTES = W_U16 * 2 + X_U16 * 2 + 64 + 64 + 8 * 2 * COUT * 4;
   static constexpr int NITEMS = IR * IC * CV;
   static constexpr int NLOAD = (NITEMS + 511) / 512;
   static constexpr int NPIECE = 2 * NT;
@@ -140,9 +141,10 @@ extern "C" int dis_debug_f2_stamps(unsigned long long* host) {
 #define F2_T(k)
 #endif
 
-template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool INGN = false>
+template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool INGN = false, bool EPIAB = false>
 __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   using C = F2Cfg<CIN, COUT>;
+  static_assert(!EPIAB || (!STATS && ACT == DIS_ACT_NONE && 2 * COUT <= 64), "channel sums: plain input-gradient instances");
 #ifdef BX_STAMP
   unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_amdgcn_s_memtime();
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   unsigned short* xl = smem16 + C::W_U16;
   double* red = (double*)(smem16 + C::W_U16 + C::X_U16);
   float* mxs = (float*)(smem16 + C::W_U16 + C::X_U16 + 32);  // [parity][wave]
+  float* abw = (float*)(smem16 + C::W_U16 + C::X_U16 + 64);  // EPIAB: [wave][2 COUT]
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       red[0] = 0.0;
       red[1] = 0.0;
       *(unsigned*)(red + 2) = 0u;
+      *(unsigned*)(red + 3) = 0u;  // (ab_flush)
     }
     __syncthreads();
     const float4 m0 = *(const float4*)(mxs), m1 = *(const float4*)(mxs + 4);
@@ -312,6 +316,15 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) outv[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};  // (the first tile's ride has no finished tile: 0 * livef)
   float4 prevy[NPIECE];
+  float4 prevx[EPIAB ? NPIECE : 1], epix[EPIAB ? NPIECE : 1];  // EPIAB: the GroupNorm input at this / the deferred tile's outputs
+  float sA[NT][4], sB[NT][4];                                   // ... and this lane's sums of g, g * x for the current sample
+  int ab_n = -1;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sA[nt][r] = sB[nt][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (EPIAB ? NPIECE : 1); ++i) epix[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   double s1 = 0.0, s2 = 0.0;
   float t1 = 0.f, t2 = 0.f;
   int stat_n = -1;
@@ -355,6 +368,51 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       stat_n = prev_n;
     }
   };
+  // EPIAB: a sample's channel sums leave the workgroup: row reduction over the 16 pixel lanes (DPP), per-wave slots in LDS, the
+  // wave that arrives last adds the eight slots in a fixed order and stores the workgroup's slot of ab_out (no atomics)
+  auto ab_flush = [&]() {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float va = sA[nt][r], vb = sB[nt][r];
+#define F2_ROW(ctrl)                                                                                       \
+  va += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(va), ctrl, 0xf, 0xf, true)); \
+  vb += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(vb), ctrl, 0xf, 0xf, true));
+        F2_ROW(0xB1) F2_ROW(0x4E) F2_ROW(0x124) F2_ROW(0x128)
+#undef F2_ROW
+        if (li == 0) {
+          abw[wave * 2 * COUT + nt * 16 + lg * 4 + r] = va;
+          abw[wave * 2 * COUT + COUT + nt * 16 + lg * 4 + r] = vb;
+        }
+        sA[nt][r] = 0.f;
+        sB[nt][r] = 0.f;
+      }
+    unsigned arrived = 0;
+    if (lane == 0) arrived = __hip_atomic_fetch_add((unsigned*)(red + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived == 7u) {  // (a wave's LDS operations complete in order: the other waves' slots are written)
+      if (lane < 2 * COUT) {
+        double t = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) t += (double)abw[wv * 2 * COUT + lane];
+        a.ab_out[((long)ab_n * a.ab_slots + blockIdx.x) * (2 * COUT) + lane] = t;
+      }
+      if (lane == 0) *(unsigned*)(red + 3) = 0u;
+    }
+  };
+  auto ab_sample = [&]() {
+    if (EPIAB && prev_n >= 0 && prev_n != ab_n) {
+      if (ab_n >= 0) ab_flush();
+      ab_n = prev_n;
+    }
+  };
+  auto abx_load = [&](const float* xb, const unsigned (&off)[2]) {
+#pragma unroll
+    for (int i = 0; i < (EPIAB ? NPIECE : 0); ++i)
+      prevx[i] = __builtin_bit_cast(
+          float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(xb, y_bytes), off[i / NT] + (i % NT) * 64, 0, 0));
+  };
   auto epi_load = [&](const float* yb, const unsigned (&off)[2]) {
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i)
@@ -388,6 +446,13 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       t1 = __builtin_fmaf(livef[mt], sm[0] + sm[1], t1);
       t2 = __builtin_fmaf(livef[mt], sq[0] + sq[1], t2);
     }
+    if (EPIAB) {
+      const float4 xv = epix[i];
+      const float g0 = lo[0] * livef[mt], g1 = lo[1] * livef[mt], g2 = hi[0] * livef[mt], g3 = hi[1] * livef[mt];
+      sA[nt][0] += g0, sA[nt][1] += g1, sA[nt][2] += g2, sA[nt][3] += g3;
+      sB[nt][0] = __builtin_fmaf(g0, xv.x, sB[nt][0]), sB[nt][1] = __builtin_fmaf(g1, xv.y, sB[nt][1]);
+      sB[nt][2] = __builtin_fmaf(g2, xv.z, sB[nt][2]), sB[nt][3] = __builtin_fmaf(g3, xv.w, sB[nt][3]);
+    }
   };
 
   const int xa_lane = (wave * 2 * IC + li) * PS + (CIN == 32 ? lg * 8 : (lg & 1) * 8);
@@ -406,6 +471,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     stats_sample();
+    ab_sample();
     F2_T(0)
     prep(cn, parity);
     F2_T(1)
@@ -427,6 +493,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     auto ride = [&](auto ksc) {
       constexpr int ks = decltype(ksc)::value;
       if (ACCUM && ks == 0) epi_load(cur_y, cur_off);
+      if (EPIAB && ks == 0) abx_load(a.ab_x + (cur_y - a.y), cur_off);
 #pragma unroll
       for (int it = 0; it < NLOAD; ++it)
         if (C::load_ks(it) == ks) pf_issue(it);
@@ -553,6 +620,8 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
         }
       }
     }
+#pragma unroll
+    for (int i = 0; i < (EPIAB ? NPIECE : 0); ++i) epix[i] = prevx[i];
     prev_y = cur_y;
     prev_n = cn;
     cn = nn, cty = nty, ctx = ntx;
@@ -560,6 +629,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     F2_T(6)
   }
   stats_sample();
+  ab_sample();
   t1 = 0.f;
   t2 = 0.f;
 #pragma unroll
@@ -567,6 +637,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   s1 += (double)t1;
   s2 += (double)t2;
   if (STATS && stat_n >= 0) stats_flush();
+  if (EPIAB && ab_n >= 0) ab_flush();
 #ifdef BX_STAMP
   F2_T(7)
   if (lane == 0 && blockIdx.x < 256)
@@ -591,6 +662,14 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
   };
   if (a.act != DIS_ACT_NONE && a.act != DIS_ACT_SELU) return hipErrorInvalidValue;
   const bool selu = a.act == DIS_ACT_SELU;
+  if (a.ab_out) {  // input gradient + per-(sample, channel) sums for the GroupNorm backward
+    if constexpr (CIN == COUT) {
+      if (ingn || inact || a.accum || selu || stats || !a.ab_x) return hipErrorInvalidValue;
+      return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, 0, false, true>, 10);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (ingn) {
     if constexpr (CIN == COUT) {
       if (inact || a.accum) return hipErrorInvalidValue;

@@ -439,6 +439,121 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// GroupNorm backward from per-(sample, channel) sums (round 3).  With A_c = sum_p g, B_c = sum_p g x over a sample's pixels
+// (left by the epilogue of the kernel that produced g: dis_conv2d_dgrad_bf16x3_gnsums) everything else follows:
+//   dbeta_c = A_c, dgamma_c = rstd (B_c - mean A_c), a1 = sum_c gamma_c A_c / M, a2 = sum_c gamma_c dgamma_c / M,
+//   gx = act'(x) rstd (g gamma_c - a1 - xhat a2) = act'(x) (g k1_c + x kx + k0),  k1_c = rstd gamma_c, kx = -rstd^2 a2,
+//   k0 = rstd^2 a2 mean - rstd a1
+// so the backward is ONE elementwise pass (read g, x; write gx) instead of a reduce pass and an apply pass.
+// ------------------------------------------------------------------------------------------------
+// grid n: block b writes coef[b][0..c) = k1_c, coef[b][c] = kx, coef[b][c + 1] = k0 and the sample's dgamma_c / dbeta_c (fp64) behind
+// the coefficients of all samples (pg); the apply kernel's first block adds those over the samples.  Fixed orders: deterministic.
+__global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__ ab, int slots, const double* __restrict__ stats,
+                                                      const float* __restrict__ gamma, float* __restrict__ coef,
+                                                      double* __restrict__ pg, long hw, int c, float eps) {
+  __shared__ double sA[GN_MAXC], sB[GN_MAXC], part[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const double m = (double)hw * c;
+  {  // A_c, B_c of this sample: 4 threads per value, each a quarter of the slots, 8 loads in flight
+    const int j = t & 63, q = t >> 6;  // (2 c <= 64 values)
+    double v = 0.0;
+    if (j < 2 * c) {
+      const double* p = ab + (long)b * slots * (2 * c) + j;
+      int s_ = q;
+      for (; s_ + 28 < slots; s_ += 32) {
+        double u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = p[(long)(s_ + 4 * k) * (2 * c)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += u[k];
+      }
+      for (; s_ < slots; s_ += 4) v += p[(long)s_ * (2 * c)];
+    }
+    part[t] = v;
+    __syncthreads();
+    if (t < 2 * c) {
+      const double tot = (part[t] + part[t + 64]) + (part[t + 128] + part[t + 192]);
+      if (t < c) sA[t] = tot;
+      else sB[t - c] = tot;
+    }
+    __syncthreads();
+  }
+  float mean, rstd;
+  gn_moments(stats, b, m, eps, &mean, &rstd);
+  if (t < c) {
+    coef[(long)b * (c + 2) + t] = rstd * gamma[t];
+    pg[(long)b * 2 * c + t] = (double)rstd * (sB[t] - (double)mean * sA[t]);
+    pg[(long)b * 2 * c + c + t] = sA[t];
+  }
+  if (t == 0) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < c; ++k) {
+      const double dg = (double)rstd * (sB[k] - (double)mean * sA[k]);
+      s1 += (double)gamma[k] * sA[k];
+      s2 += (double)gamma[k] * dg;
+    }
+    const float a1 = (float)(s1 / m), a2 = (float)(s2 / m);
+    coef[(long)b * (c + 2) + c] = -(rstd * rstd) * a2;
+    coef[(long)b * (c + 2) + c + 1] = (rstd * rstd) * a2 * mean - rstd * a1;
+  }
+}
+__global__ void gn_apply_coef_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ coef,
+                                     float* __restrict__ gx, long hw, int c, int in_act, int nt, const double* __restrict__ pg,
+                                     float* __restrict__ gg, float* __restrict__ gb) {
+  __shared__ float k1[GN_MAXC], kk[2];
+  const int n = blockIdx.y;
+  if (blockIdx.x == 0 && n == 0 && (int)threadIdx.x < 2 * c) {  // dgamma / dbeta: the samples' parts, in order
+    double v = 0.0;
+    for (int sn = 0; sn < (int)gridDim.y; ++sn) v += pg[(long)sn * 2 * c + threadIdx.x];
+    if ((int)threadIdx.x < c) gg[threadIdx.x] = (float)v;
+    else gb[threadIdx.x - c] = (float)v;
+  }
+  if (threadIdx.x < c) k1[threadIdx.x] = coef[(long)n * (c + 2) + threadIdx.x];
+  if (threadIdx.x < 2) kk[threadIdx.x] = coef[(long)n * (c + 2) + c + threadIdx.x];
+  __syncthreads();
+  const float kx = kk[0], k0 = kk[1];
+  const int cg = c >> 2;
+  const long per4 = hw * cg;
+  const float4* gp = (const float4*)(g + (long)n * hw * c);
+  const float4* xp = (const float4*)(x + (long)n * hw * c);
+  float4* op = (float4*)(gx + (long)n * hw * c);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per4; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cg) * 4;
+    const float4 gv = gn_ld4(gp + i, nt & 2), xv = gn_ld4(xp + i, nt & 2);
+    float4 o;
+    o.x = __builtin_fmaf(gv.x, k1[ch], __builtin_fmaf(xv.x, kx, k0));
+    o.y = __builtin_fmaf(gv.y, k1[ch + 1], __builtin_fmaf(xv.y, kx, k0));
+    o.z = __builtin_fmaf(gv.z, k1[ch + 2], __builtin_fmaf(xv.z, kx, k0));
+    o.w = __builtin_fmaf(gv.w, k1[ch + 3], __builtin_fmaf(xv.w, kx, k0));
+    if (in_act != DIS_ACT_NONE) {
+      o.x *= act_grad_from_out(xv.x, in_act); o.y *= act_grad_from_out(xv.y, in_act);
+      o.z *= act_grad_from_out(xv.z, in_act); o.w *= act_grad_from_out(xv.w, in_act);
+    }
+    gn_st4(op + i, o, nt & 4);
+  }
+}
+/* GroupNorm(1 group) backward from the sums dis_conv2d_dgrad_bf16x3_gnsums left: g (n, hw, c) the gradient wrt the GroupNorm's
+ * output, x its input, stats (n, 2) the forward statistics, ab (n, slots, 2, c) doubles.  Writes gx (the gradient wrt x, times
+ * act'(x) when x is the output of the activation in_act of the producing conv), grad_gamma, grad_beta (c).
+ * coef: workspace of n * (c + 2) floats followed by n * 2 c doubles (n * (c + 2) + 4 n c + 2 floats in all: 8-byte alignment). */
+extern "C" int dis_gn_bwd_from_sums(const float* g, const float* x, const double* stats, const float* gamma, const double* ab,
+                                    int slots, float* gx, float* grad_gamma, float* grad_beta, float* coef, int n, long hw, int c,
+                                    float eps, int in_act, void* stream) {
+  if (!g || !x || !stats || !gamma || !ab || !gx || !grad_gamma || !grad_beta || !coef) return DIS_ERR_NULL;
+  if (n <= 0 || hw <= 0 || c <= 0 || slots <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c % 4 != 0 || 2 * c > 64) return DIS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  double* pg = (double*)(((uintptr_t)(coef + (long)n * (c + 2)) + 7) & ~(uintptr_t)7);
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(n), dim3(256), 0, s, ab, slots, stats, gamma, coef, pg, hw, c, eps);
+  int gxg = dis_ew_grid(hw * (c / 4), 256);
+  if (gxg > 512) gxg = 512;
+  hipLaunchKernelGGL(gn_apply_coef_kernel, dim3(gxg, n), dim3(256), 0, s, g, x, (const float*)coef, gx, hw, c, in_act,
+                     gn_nt_flags(), (const double*)pg, grad_gamma, grad_beta);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 extern "C" long dis_gn_bwd_workspace(int n, int c) { return (n > 0 && c > 0) ? (long)n * GN_BWD_BLOCKS_MAX * (2 + 2 * c) : -1; }
 
 // Samples per reduce / apply launch pair.  Measured and rejected (round 2): running the two passes over sample GROUPS small

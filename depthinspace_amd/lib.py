@@ -58,6 +58,9 @@ SIGS = {
     'dis_set_conv_split': 'i',
     'dis_get_conv_split': '',
     'dis_conv2d_fwd_bf16x3_gn': 'ppppfpiiipppiiiiiiiiip',
+    'dis_conv2d_gnsums_slots': '',
+    'dis_conv2d_dgrad_bf16x3_gnsums': 'ppiiipppiiiiiip',
+    'dis_gn_bwd_from_sums': 'pppppippppilifip',
     'dis_conv2d_wgrad_bf16x3_gn': 'ppppfppppiiiiiiiiip',
     'dis_conv2d_fwd_scaled': 'ppppppp' + 'iiiiiiiii' + 'p',
     'dis_conv2d_wgrad_scaled': 'pppppp' + 'iiiiiiiii' + 'p',
@@ -110,7 +113,7 @@ SIGS = {
     'dis_adam_step': 'pppplfddfifp',
     'dis_adam_step_dev': 'pppplfddfpfp',
 }
-_RET_LONG = {'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
+_RET_LONG = {'dis_conv2d_gnsums_slots', 'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
              'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_act_bwd_ld_bias_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_conv3d_knn_bwd_stage', 'dis_conv3d_csr_workspace', 'dis_gather_csr_workspace',
              'dis_conv2d_pack_bf16x3_size', 'dis_disp_head_bwd_workspace'}
 

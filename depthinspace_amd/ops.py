@@ -681,6 +681,7 @@ def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, nee
 
 
 GN_FUSE = _os.environ.get('DIS_GN_FUSE', '1') != '0'
+GN_SUMS = _os.environ.get('DIS_GN_SUMS', '1') != '0'   # GroupNorm backward from the sums of the input-gradient epilogue
 
 
 def gn_fusable(cin, cout, k, stride):
@@ -733,17 +734,27 @@ class _Conv2dGnIn(torch.autograd.Function):
             gpre = gy
         # gradient wrt the normalised tensor, then through the GroupNorm to the producer's (pre-activation) output
         gnorm = torch.empty_like(x)
-        _conv_fwd_any(gpre, weight, cin, 1, None, gnorm, None, n, gpre.shape[1], gpre.shape[2], cout, cin, k, 1, k - 1 - pad,
-                      ACT_NONE)
         gx = torch.empty_like(x)
         gg, gg_ret = _sink(gamma)
         gbt, gbt_ret = _sink(ctx.beta_ref)
         hw = h * w
-        wtot = lib.fn('dis_gn_bwd_workspace')(n, cin)
-        ws = torch.empty(wtot, dtype=torch.float64, device=x.device)
-        nred2 = wtot // (2 + 2 * cin) * 2
-        lib.call('dis_gn_apply_bwd', gnorm, None, x, gn_stats, gamma, gx, None, gg, gbt, ws[:nred2], ws[nred2:], n, hw, cin,
-                 ACT_NONE, eps, in_act)
+        if GN_SUMS and lib.fn('dis_get_conv_split')() == 1:
+            # the input-gradient launch leaves the per-(sample, channel) sums of g and g * x in its epilogue: the GroupNorm
+            # backward is then ONE elementwise pass (no reduce pass over g and x)
+            slots = lib.fn('dis_conv2d_gnsums_slots')()
+            ab = torch.zeros(n * slots * 2 * cin, dtype=torch.float64, device=x.device)
+            lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, weight, cout, cin, weight.stride(0), gnorm, x, ab, n, gpre.shape[1],
+                     gpre.shape[2], cout, cin, k - 1 - pad)
+            coef = torch.empty(n * (cin + 2) + 4 * n * cin + 2, dtype=torch.float32, device=x.device)
+            lib.call('dis_gn_bwd_from_sums', gnorm, x, gn_stats, gamma, ab, slots, gx, gg, gbt, coef, n, hw, cin, eps, in_act)
+        else:
+            _conv_fwd_any(gpre, weight, cin, 1, None, gnorm, None, n, gpre.shape[1], gpre.shape[2], cout, cin, k, 1, k - 1 - pad,
+                          ACT_NONE)
+            wtot = lib.fn('dis_gn_bwd_workspace')(n, cin)
+            ws = torch.empty(wtot, dtype=torch.float64, device=x.device)
+            nred2 = wtot // (2 + 2 * cin) * 2
+            lib.call('dis_gn_apply_bwd', gnorm, None, x, gn_stats, gamma, gx, None, gg, gbt, ws[:nred2], ws[nred2:], n, hw, cin,
+                     ACT_NONE, eps, in_act)
         gw, gw_ret = _sink(weight)
         gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
         wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin, cout, k, 1)

@@ -276,6 +276,19 @@ int dis_conv2d_fwd_bf16x3_gn(const float* x, const double* gn_stats, const float
                              float gn_eps, const float* w_oihw, int w_o, int w_i, int w_row_stride, const float* bias,
                              float* y, double* stats, int n, int hin, int win, int cin, int cout, int k, int stride,
                              int pad, int act, void* stream);
+/* ... and its backward without the GroupNorm reduce pass: the input gradient g = conv_T(gy, w) of that conv also leaves, per
+ * (sample, channel), the sums of g and of g * x over the pixels (x = gn_x: the GroupNorm's input, shaped like g) - one fp64 slot per
+ * workgroup, ab_out (n, dis_conv2d_gnsums_slots(), 2, cin), ZEROED by the caller - and dis_gn_bwd_from_sums turns g, x and the sums
+ * into the gradient wrt x (times act'(x) for in_act != 0), grad_gamma and grad_beta in ONE elementwise pass (reference backward of
+ * torch.nn.GroupNorm(1, C), model/multi_frame_networks.py:338-345).  coef: n * (c + 2) + 4 n c + 2 floats of workspace.  Two-term fp16
+ * kernels only: DIS_ERR_UNSUPPORTED under dis_set_conv_split(0) (dis_gn_apply_bwd remains the general form). */
+long dis_conv2d_gnsums_slots(void);
+int dis_conv2d_dgrad_bf16x3_gnsums(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g,
+                                   const float* gn_x, double* ab_out, int n, int hin, int win, int cin, int cout, int pad,
+                                   void* stream);
+int dis_gn_bwd_from_sums(const float* g, const float* x, const double* stats, const float* gamma, const double* ab, int slots,
+                         float* gx, float* grad_gamma, float* grad_beta, float* coef, int n, long hw, int c, float eps,
+                         int in_act, void* stream);
 int dis_conv2d_wgrad_bf16x3_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta,
                                float gn_eps, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
                                int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,

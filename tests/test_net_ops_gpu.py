@@ -163,7 +163,12 @@ def test_conv_with_group_norm_on_load_equals_the_two_pass_form(c, act, n, h, w):
         y.backward(nhwc(go).cuda())
         res.append((y.detach(), yst.clone(), xd.grad, gd.grad, bd.grad, wd.grad, bbd.grad))
     for a_, b_, name in zip(res[0], res[1], ('y', 'stats', 'gx', 'ggamma', 'gbeta', 'gw', 'gb')):
-        assert torch.equal(a_, b_), (name, float((a_ - b_).abs().max()))
+        if name in ('gx', 'ggamma', 'gbeta') and ops.GN_SUMS:
+            # the fused pair's GroupNorm backward works from the per-(sample, channel) sums of its input-gradient epilogue
+            # (dis_gn_bwd_from_sums): the same quantities, factored differently - equal to rounding, not bit for bit
+            assert relerr(a_, b_) < 2e-5, (name, relerr(a_, b_))
+        else:
+            assert torch.equal(a_, b_), (name, float((a_ - b_).abs().max()))
     # torch on the host
     xr = F.selu(nchw(nhwc(x))).detach().requires_grad_(True)
     gr, br, wr, bbr = [t.clone().requires_grad_(True) for t in (gam, bet, wt, b)]
