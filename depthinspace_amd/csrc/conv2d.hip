@@ -1137,8 +1137,9 @@ struct GnIn {  // GroupNorm applied to x on load (ConvArgs::gn_stats ...); stats
   const float* gamma = nullptr;
   const float* beta = nullptr;
   float eps = 0.f;
-  const float* ab_x = nullptr;  // ConvArgs::ab_x / ab_out (f16x2 kernel only)
+  const float* ab_x = nullptr;  // ConvArgs::ab_x / ab_out / ab_act_y (f16x2 kernel only)
   double* ab_out = nullptr;
+  const float* ab_act_y = nullptr;
 };
 static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o, int w_i, int w_rs, const float* bias, float* y,
                               double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad,
@@ -1162,7 +1163,7 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
   a.w_rs = w_rs;
   a.xact = xact;
   a.gn_stats = gn.stats; a.gn_gamma = gn.gamma; a.gn_beta = gn.beta; a.gn_eps = gn.eps;
-  a.ab_x = gn.ab_x; a.ab_out = gn.ab_out; a.ab_slots = num_cus();
+  a.ab_x = gn.ab_x; a.ab_out = gn.ab_out; a.ab_slots = num_cus(); a.ab_act_y = gn.ab_act_y;
   if (gn.ab_out && !(dis_f2_enabled() && wmode >= 0)) return DIS_ERR_UNSUPPORTED;  // (the two-term kernel's epilogue)
   if (gn.stats && (!gn.gamma || !gn.beta)) return DIS_ERR_NULL;
   if (gn.stats && (cin != cout || inact || (act & DIS_CONV_ACCUM) || ((act & 0xff) != DIS_ACT_NONE && (act & 0xff) != DIS_ACT_SELU)))
@@ -1252,6 +1253,21 @@ extern "C" int dis_conv2d_dgrad_bf16x3_gnsums(const float* gy, const float* w_oi
   return launch_conv_bf16x3(gy, w_oihw, 1, w_o, w_i, w_row_stride, nullptr, g, nullptr, n, hin, win, cin, cout, 3, 1, pad, 0, stream,
                             nullptr, 0, gn);
 }
+/* The ResNetBlock-chain form: g = (g + conv_T(gy, w)) * selu'(act_y) in place (g arrives holding the residual branch's gradient;
+ * act_y = the block input = output of the previous block's SELU(GroupNorm(.) + residual)), plus the sums of g and g * gn_x (gn_x =
+ * that GroupNorm's input) as above: g is then BOTH the previous block's residual gradient and the input of dis_gn_bwd_from_sums. */
+extern "C" int dis_conv2d_dgrad_bf16x3_gnsums_res(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride,
+                                                  float* g, const float* act_y, const float* gn_x, double* ab_out, int n, int hin,
+                                                  int win, int cin, int cout, int pad, void* stream) {
+  if (!gn_x || !ab_out || !act_y) return DIS_ERR_NULL;
+  if (w_o <= 0 || w_i <= 0 || w_o > 32 || w_i > 32 || cin != w_o || cout != w_i || cin != cout) return DIS_ERR_BAD_SHAPE;
+  if (w_row_stride == 0) w_row_stride = w_i * 9;
+  if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
+  GnIn gn;
+  gn.ab_x = gn_x; gn.ab_out = ab_out; gn.ab_act_y = act_y;
+  return launch_conv_bf16x3(gy, w_oihw, 1, w_o, w_i, w_row_stride, nullptr, g, nullptr, n, hin, win, cin, cout, 3, 1, pad,
+                            DIS_CONV_ACCUM, stream, nullptr, 0, gn);
+}
 /* Input gradient of a 3x3 stride-1 convolution that was followed by an activation, with the activation's gradient fused
  * in: gx (+)= conv_T(gy * act'(y), w) where y (same shape as gy) is the activation's output.  Replaces dis_act_bwd +
  * dis_conv2d_fwd_bf16x3_oihw(mode 1).  w_oihw (w_o, w_i, 3, 3) is the forward convolution's weight: gy has w_o channels,
@@ -1318,7 +1334,7 @@ int dis_bx_slices_run(int dgrad, const float* x, int ldx, int xoff, int cin, int
       if (!first) a.bias = nullptr;
       a.xscale = nullptr; a.yscale = nullptr; a.xact = nullptr;
       a.gn_stats = nullptr; a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_eps = 0.f;
-      a.ab_x = nullptr; a.ab_out = nullptr; a.ab_slots = 0;
+      a.ab_x = nullptr; a.ab_out = nullptr; a.ab_slots = 0; a.ab_act_y = nullptr;
       a.ldx = ldx; a.ldy = ldy;
       a.cx = cin - 32 * cb < 32 ? cin - 32 * cb : 32;
       a.cy = cout - 32 * gb < 32 ? cout - 32 * gb : 32;

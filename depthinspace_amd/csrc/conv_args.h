@@ -43,6 +43,9 @@ struct ConvArgs {
   const float* ab_x;
   double* ab_out;
   int ab_slots;  // slots per sample in ab_out (>= gridDim.x)
+  // ... EPIACT form (the accumulating input gradient whose result is the gradient wrt the OUTPUT of act(GroupNorm(.) + residual),
+  // ResNetBlock chains): the finished value is multiplied by act'(ab_act_y) before it is stored and summed (ab_act_y: that output)
+  const float* ab_act_y;
 };
 
 struct WgArgs {

@@ -141,10 +141,11 @@ extern "C" int dis_debug_f2_stamps(unsigned long long* host) {
 #define F2_T(k)
 #endif
 
-template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool INGN = false, bool EPIAB = false>
+template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool INGN = false, bool EPIAB = false, int EPIACT = 0>
 __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   using C = F2Cfg<CIN, COUT>;
   static_assert(!EPIAB || (!STATS && ACT == DIS_ACT_NONE && 2 * COUT <= 64), "channel sums: plain input-gradient instances");
+  static_assert(EPIACT == 0 || EPIAB, "activation gradient at the output: only with the channel sums");
 #ifdef BX_STAMP
   unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_amdgcn_s_memtime();
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     for (int nt = 0; nt < NT; ++nt) outv[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};  // (the first tile's ride has no finished tile: 0 * livef)
   float4 prevy[NPIECE];
   float4 prevx[EPIAB ? NPIECE : 1], epix[EPIAB ? NPIECE : 1];  // EPIAB: the GroupNorm input at this / the deferred tile's outputs
+  float4 prevyv[EPIACT ? NPIECE : 1];                           // EPIACT: the activation output at this tile's outputs
   float sA[NT][4], sB[NT][4];                                   // ... and this lane's sums of g, g * x for the current sample
   int ab_n = -1;
 #pragma unroll
@@ -407,11 +409,15 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       ab_n = prev_n;
     }
   };
-  auto abx_load = [&](const float* xb, const unsigned (&off)[2]) {
+  auto abx_load = [&](const float* xb, const float* yvb, const unsigned (&off)[2]) {
 #pragma unroll
-    for (int i = 0; i < (EPIAB ? NPIECE : 0); ++i)
+    for (int i = 0; i < (EPIAB ? NPIECE : 0); ++i) {
       prevx[i] = __builtin_bit_cast(
           float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(xb, y_bytes), off[i / NT] + (i % NT) * 64, 0, 0));
+      if (EPIACT)
+        prevyv[i] = __builtin_bit_cast(
+            float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(yvb, y_bytes), off[i / NT] + (i % NT) * 64, 0, 0));
+    }
   };
   auto epi_load = [&](const float* yb, const unsigned (&off)[2]) {
 #pragma unroll
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     auto ride = [&](auto ksc) {
       constexpr int ks = decltype(ksc)::value;
       if (ACCUM && ks == 0) epi_load(cur_y, cur_off);
-      if (EPIAB && ks == 0) abx_load(a.ab_x + (cur_y - a.y), cur_off);
+      if (EPIAB && ks == 0) abx_load(a.ab_x + (cur_y - a.y), EPIACT ? a.ab_act_y + (cur_y - a.y) : nullptr, cur_off);
 #pragma unroll
       for (int it = 0; it < NLOAD; ++it)
         if (C::load_ks(it) == ks) pf_issue(it);
@@ -618,6 +624,11 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
           const float4 q = prevy[mt * NT + nt];
           outv[mt][nt] += (f32x4){q.x, q.y, q.z, q.w};
         }
+        if (EPIACT) {  // gradient wrt the pre-activation value: what is stored, and what the channel sums are sums of
+          const float4 q = prevyv[mt * NT + nt];
+          outv[mt][nt] *= (f32x4){act_grad_from_out(q.x, EPIACT), act_grad_from_out(q.y, EPIACT), act_grad_from_out(q.z, EPIACT),
+                                  act_grad_from_out(q.w, EPIACT)};
+        }
       }
     }
 #pragma unroll
@@ -664,7 +675,12 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
   const bool selu = a.act == DIS_ACT_SELU;
   if (a.ab_out) {  // input gradient + per-(sample, channel) sums for the GroupNorm backward
     if constexpr (CIN == COUT) {
-      if (ingn || inact || a.accum || selu || stats || !a.ab_x) return hipErrorInvalidValue;
+      if (ingn || inact || selu || stats || !a.ab_x) return hipErrorInvalidValue;
+      if (a.ab_act_y) {  // accumulating form whose result passes through SELU' (ResNetBlock chains)
+        if (!a.accum) return hipErrorInvalidValue;
+        return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, true, false, 0, false, true, DIS_ACT_SELU>, 11);
+      }
+      if (a.accum) return hipErrorInvalidValue;
       return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, 0, false, true>, 10);
     } else {
       return hipErrorInvalidValue;

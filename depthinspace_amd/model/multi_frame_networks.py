@@ -90,7 +90,10 @@ class ResNetBlock(torch.nn.Module):
 
     def forward(self, x):
         j = ops.GradJoin() if x.requires_grad else None  # x feeds conv1 and the residual: one shared gradient buffer
-        o, st = ops.conv2d(x, self.conv1.weight, self.conv1.bias, 1, 1, SELU, want_stats=True, gy_is_pre=True, join=j)
+        # (x may be the previous ResNetBlock's SELU(GroupNorm(.) + residual): conv1's input-gradient launch then also serves
+        # that GroupNorm's backward, ops._Conv2d.backward)
+        o, st = ops.conv2d(x, self.conv1.weight, self.conv1.bias, 1, 1, SELU, want_stats=True, gy_is_pre=True, join=j,
+                           gnres=getattr(x, '_gn_res_src', None) if j is not None else None)
         if ops.gn_fusable(o.shape[-1], self.conv2.weight.shape[0], 3, 1):
             # bn1 is applied by conv2 while it stages its input: GN1(...) is never written
             o, st = ops.conv2d_gn_in(o, st, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.conv2.bias, 1, NONE,

@@ -36,7 +36,15 @@ _ARENA = {}
 _ARENA_DOUBLES = 1 << 16
 
 
+# gradient tensors whose producer already left the GroupNorm-backward sums (see _Conv2d.backward / _GroupNorm.backward):
+# data_ptr -> (ab, slots)
+_GN_PRE = {}
+
+
 def begin_step(dev):
+    if _GN_PRE:   # a gradient that was handed on pre-multiplied was never picked up by its GroupNorm: the step would be wrong
+        _GN_PRE.clear()
+        raise RuntimeError('ops: a pre-reduced GroupNorm gradient of the previous backward pass was not consumed')
     dev = torch.device(dev)
     a = _ARENA.get(dev)
     if a is None:
@@ -602,9 +610,10 @@ def _bx_shape(cin, cout, k, stride):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre=False, join=None):
+    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre=False, join=None, gnres=None):
         x, weight = _c(x), _c(weight)
         _chk(x, weight, bias)
+        ctx.gnres = gnres
         n, hin, win, cin_pad = x.shape
         cout, cin, k, _ = weight.shape
         ho = (hin + 2 * pad - k) // stride + 1
@@ -644,9 +653,21 @@ class _Conv2d(torch.autograd.Function):
             join = ctx.join
             second = join is not None and join.buf is not None
             gx = join.take(x.shape) if second else torch.empty_like(x)
+            gnres = ctx.gnres
             if fuse_act:
                 lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, weight, cout, cin, weight.stride(0), gx, n, gy.shape[1],
                          gy.shape[2], cout, cin, k - 1 - pad, 1 if second else 0)
+            elif (gnres is not None and second and GN_SUMS and _bx_shape(cin_pad, cout, k, stride) and cin == cout and
+                  tuple(gnres[0].shape) == tuple(x.shape) and lib.fn('dis_get_conv_split')() == 1):
+                # x is out = SELU(GroupNorm(x2) + res) of the previous ResNetBlock, and gx - which arrives holding this block's
+                # residual-branch gradient - becomes the complete gradient wrt out here.  The epilogue turns it into the gradient
+                # wrt the pre-activation value (times SELU'(x)) and leaves the GroupNorm-backward sums: that GroupNorm's backward
+                # then needs neither its reduce pass nor a residual-gradient write (_GroupNorm.backward looks the buffer up)
+                slots = lib.fn('dis_conv2d_gnsums_slots')()
+                ab = torch.zeros(n * slots * 2 * cin, dtype=torch.float64, device=x.device)
+                lib.call('dis_conv2d_dgrad_bf16x3_gnsums_res', gpre, weight, cout, cin, weight.stride(0), gx, x, gnres[0], ab, n,
+                         gpre.shape[1], gpre.shape[2], cout, cin, k - 1 - pad)
+                _GN_PRE[gx.data_ptr()] = (ab, slots)
             elif stride == 1:
                 _conv_fwd_any(gpre, weight, cin, 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cin, k, 1,
                               k - 1 - pad, ACT_NONE | (CONV_ACCUM if second else 0))
@@ -668,16 +689,16 @@ class _Conv2d(torch.autograd.Function):
         else:
             _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
         _sinks_written()
-        return gx, gw_ret, gb_ret, None, None, None, None, None, None, None
+        return gx, gw_ret, gb_ret, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, need_dgrad=True, gy_is_pre=False,
-           join=None):
+           join=None, gnres=None):
     """x nhwc (n,h,w,cin_pad>=cin); weight OIHW.  Returns (y, stats|None).
     gy_is_pre: the only consumer of y is group_norm(..., in_act=act), whose backward already multiplies by act'(y);
     the incoming gradient is then taken as the pre-activation gradient.
     join: GradJoin shared with the other consumer of x (see GradJoin)."""
-    return _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre, join)
+    return _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre, join, gnres)
 
 
 GN_FUSE = _os.environ.get('DIS_GN_FUSE', '1') != '0'
@@ -1453,9 +1474,24 @@ class _GroupNorm(torch.autograd.Function):
         n, hw, c, act, eps, has_res, in_act = ctx.cfg
         gy = _c(gy)
         gx = torch.empty_like(x)
-        gres = torch.empty_like(x) if has_res else None
         gg, gg_ret = _sink(gamma)
         gb, gb_ret = _sink(ctx.beta_ref)
+        pre = _GN_PRE.pop(gy.data_ptr(), None)
+        if pre is not None and has_res and act == ACT_SELU and in_act == ACT_NONE:
+            # gy already IS the gradient wrt the pre-activation value (the producing input-gradient launch multiplied by
+            # SELU'(y) and left the channel sums): it doubles as the residual gradient, and one elementwise pass gives gx
+            ab, slots = pre
+            coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=x.device)
+            lib.call('dis_gn_bwd_from_sums', gy, x, stats, gamma, ab, slots, gx, gg, gb, coef, n, hw, c, eps, ACT_NONE)
+            gres = gy.view(x.shape)
+            if ctx.join is not None:
+                if ctx.join.buf is None:
+                    gres = ctx.join.first(gres)
+                else:
+                    gres = ctx.join.take(gres.shape).add_(gres)
+            _sinks_written()
+            return gx, None, gg_ret, gb_ret, gres, None, None, None, None
+        gres = torch.empty_like(x) if has_res else None
         wtot = lib.fn('dis_gn_bwd_workspace')(n, c)
         ws = torch.empty(wtot, dtype=torch.float64, device=x.device)
         nred2 = wtot // (2 + 2 * c) * 2  # (n * blocks-per-sample-max) pairs of per-block sums, then the parameter partials
@@ -1474,7 +1510,10 @@ def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5
     """GroupNorm(1 group) over all but the first dim of an nhwc tensor; y = act(gn(x) (+ residual)).
     in_act: x is the output of that activation (conv2d(..., act, gy_is_pre=True)); the backward then returns the
     gradient wrt the producer's pre-activation output."""
-    return _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act, join)
+    y = _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act, join)
+    if residual is not None and act == ACT_SELU and in_act == ACT_NONE:
+        y._gn_res_src = (x,)   # (a ResNetBlock that takes y as its input hands this to its first conv: conv2d(gnres=...))
+    return y
 
 
 # --------------------------------------------------------------------------------------------------

@@ -286,6 +286,14 @@ long dis_conv2d_gnsums_slots(void);
 int dis_conv2d_dgrad_bf16x3_gnsums(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g,
                                    const float* gn_x, double* ab_out, int n, int hin, int win, int cin, int cout, int pad,
                                    void* stream);
+/* The same for the residual pattern out = SELU(GroupNorm(x2) + res) whose gradient arrives through the NEXT ResNetBlock's first conv
+ * (reference model/multi_frame_networks.py:514-542): that conv's accumulating input-gradient launch computes, in place,
+ * g = (g + conv_T(gy, w)) * selu'(act_y) (g arrives holding the next block's residual-branch gradient, act_y = out) and the sums of
+ * g and g * gn_x (gn_x = x2); g then is the residual gradient of THIS block and, with dis_gn_bwd_from_sums(in_act = 0), gives the
+ * gradient wrt x2 - no reduce pass, no separate residual-gradient write. */
+int dis_conv2d_dgrad_bf16x3_gnsums_res(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g,
+                                       const float* act_y, const float* gn_x, double* ab_out, int n, int hin, int win, int cin,
+                                       int cout, int pad, void* stream);
 int dis_gn_bwd_from_sums(const float* g, const float* x, const double* stats, const float* gamma, const double* ab, int slots,
                          float* gx, float* grad_gamma, float* grad_beta, float* coef, int n, long hw, int c, float eps,
                          int in_act, void* stream);
