@@ -1268,6 +1268,21 @@ extern "C" int dis_conv2d_dgrad_bf16x3_gnsums_res(const float* gy, const float* 
   return launch_conv_bf16x3(gy, w_oihw, 1, w_o, w_i, w_row_stride, nullptr, g, nullptr, n, hin, win, cin, cout, 3, 1, pad,
                             DIS_CONV_ACCUM, stream, nullptr, 0, gn);
 }
+/* ... and for a conv that had an activation of its own behind such a block (final_conv: 32 -> 16 + SELU behind ref_res3):
+ * g = conv_T(gy * selu'(y), w) * selu'(act_y), written (not accumulated), plus the sums.  cin = 16 (gy), cout = 32 (g). */
+extern "C" int dis_conv2d_dgrad_bf16x3_act_gnsums_res(const float* gy, const float* y, const float* w_oihw, int w_o, int w_i,
+                                                      int w_row_stride, float* g, const float* act_y, const float* gn_x,
+                                                      double* ab_out, int n, int hin, int win, int cin, int cout, int pad,
+                                                      void* stream) {
+  if (!y || !gn_x || !ab_out || !act_y) return DIS_ERR_NULL;
+  if (w_o != 16 || w_i != 32 || cin != w_o || cout != w_i) return DIS_ERR_UNSUPPORTED;
+  if (w_row_stride == 0) w_row_stride = w_i * 9;
+  if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
+  GnIn gn;
+  gn.ab_x = gn_x; gn.ab_out = ab_out; gn.ab_act_y = act_y;
+  return launch_conv_bf16x3(gy, w_oihw, 1, w_o, w_i, w_row_stride, nullptr, g, nullptr, n, hin, win, cin, cout, 3, 1, pad, 0, stream,
+                            y, DIS_ACT_SELU, gn);
+}
 /* Input gradient of a 3x3 stride-1 convolution that was followed by an activation, with the activation's gradient fused
  * in: gx (+)= conv_T(gy * act'(y), w) where y (same shape as gy) is the activation's output.  Replaces dis_act_bwd +
  * dis_conv2d_fwd_bf16x3_oihw(mode 1).  w_oihw (w_o, w_i, 3, 3) is the forward convolution's weight: gy has w_o channels,

@@ -661,7 +661,7 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
   using C = F2Cfg<CIN, COUT>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
   const bool ingn = a.gn_stats != nullptr;
-  static bool attr_set[16] = {};
+  static bool attr_set[17] = {};
   auto launch = [&](auto kern, int slot) -> hipError_t {
     if (!attr_set[slot]) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -673,6 +673,14 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
   };
   if (a.act != DIS_ACT_NONE && a.act != DIS_ACT_SELU) return hipErrorInvalidValue;
   const bool selu = a.act == DIS_ACT_SELU;
+  if (a.ab_out && inact) {  // ... of a conv that had an activation itself and whose INPUT was SELU(GroupNorm(.) + residual)
+    if constexpr (CIN == 16 && COUT == 32) {  // (final_conv behind ref_res3: reference model/multi_frame_networks.py:262-266)
+      if (ingn || selu || stats || a.accum || inact != DIS_ACT_SELU || !a.ab_x || !a.ab_act_y) return hipErrorInvalidValue;
+      return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, DIS_ACT_SELU, false, true, DIS_ACT_SELU>, 16);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (a.ab_out) {  // input gradient + per-(sample, channel) sums for the GroupNorm backward
     if constexpr (CIN == COUT) {
       if (ingn || inact || selu || stats || !a.ab_x) return hipErrorInvalidValue;

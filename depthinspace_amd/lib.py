@@ -61,6 +61,7 @@ SIGS = {
     'dis_conv2d_gnsums_slots': '',
     'dis_conv2d_dgrad_bf16x3_gnsums': 'ppiiipppiiiiiip',
     'dis_conv2d_dgrad_bf16x3_gnsums_res': 'ppiiippppiiiiiip',
+    'dis_conv2d_dgrad_bf16x3_act_gnsums_res': 'pppiiippppiiiiiip',
     'dis_gn_bwd_from_sums': 'pppppippppilifip',
     'dis_conv2d_wgrad_bf16x3_gn': 'ppppfppppiiiiiiiiip',
     'dis_conv2d_fwd_scaled': 'ppppppp' + 'iiiiiiiii' + 'p',

@@ -259,7 +259,9 @@ class FuseNet(TimedModule):
         up = ops.resize_nhwc(feat, (H, W), True)
         x = ops.conv2d_multi((up, a), self.ref_conv[1].weight, self.ref_conv[1].bias, 1, SELU)[0]
         x = self.ref_res3(self.ref_res2(self.ref_res1(x)))
-        x = ops.conv2d(x, self.final_conv[1].weight, self.final_conv[1].bias, 1, 1, SELU)[0]
+        # (x = ref_res3's SELU(GroupNorm(.) + residual) and final_conv is its only consumer: gnres, see ResNetBlock.forward)
+        x = ops.conv2d(x, self.final_conv[1].weight, self.final_conv[1].bias, 1, 1, SELU,
+                       gnres=getattr(x, '_gn_res_src', None) if x.requires_grad else None)[0]
         return ops.disp_head(x, self.predict_disp[0].weight, self.predict_disp[0].bias, float(self.max_disp), 3.0)
 
     def tforward(self, ir, amb, d, depth, R, t, flow):

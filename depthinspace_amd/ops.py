@@ -654,7 +654,15 @@ class _Conv2d(torch.autograd.Function):
             second = join is not None and join.buf is not None
             gx = join.take(x.shape) if second else torch.empty_like(x)
             gnres = ctx.gnres
-            if fuse_act:
+            if (fuse_act and gnres is not None and join is None and act == ACT_SELU and GN_SUMS and (cout, cin) == (16, 32) and
+                    tuple(gnres[0].shape) == tuple(x.shape) and lib.fn('dis_get_conv_split')() == 1):
+                # (final_conv: x = SELU(GroupNorm(.) + res) of ref_res3 and this conv is its only consumer - as below)
+                slots = lib.fn('dis_conv2d_gnsums_slots')()
+                ab = torch.zeros(n * slots * 2 * cin, dtype=torch.float64, device=x.device)
+                lib.call('dis_conv2d_dgrad_bf16x3_act_gnsums_res', gy, y, weight, cout, cin, weight.stride(0), gx, x, gnres[0], ab,
+                         n, gy.shape[1], gy.shape[2], cout, cin, k - 1 - pad)
+                _GN_PRE[gx.data_ptr()] = (ab, slots)
+            elif fuse_act:
                 lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, weight, cout, cin, weight.stride(0), gx, n, gy.shape[1],
                          gy.shape[2], cout, cin, k - 1 - pad, 1 if second else 0)
             elif (gnres is not None and second and GN_SUMS and _bx_shape(cin_pad, cout, k, stride) and cin == cout and

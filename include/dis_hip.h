@@ -294,6 +294,11 @@ int dis_conv2d_dgrad_bf16x3_gnsums(const float* gy, const float* w_oihw, int w_o
 int dis_conv2d_dgrad_bf16x3_gnsums_res(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g,
                                        const float* act_y, const float* gn_x, double* ab_out, int n, int hin, int win, int cin,
                                        int cout, int pad, void* stream);
+/* ... and when the consumer of `out` is a conv with an activation of its own (final_conv, 32 -> 16 + SELU, :262-266):
+ * g = conv_T(gy * selu'(y), w) * selu'(act_y), written; cin = 16 (gy / y channels), cout = 32. */
+int dis_conv2d_dgrad_bf16x3_act_gnsums_res(const float* gy, const float* y, const float* w_oihw, int w_o, int w_i,
+                                           int w_row_stride, float* g, const float* act_y, const float* gn_x, double* ab_out,
+                                           int n, int hin, int win, int cin, int cout, int pad, void* stream);
 int dis_gn_bwd_from_sums(const float* g, const float* x, const double* stats, const float* gamma, const double* ab, int slots,
                          float* gx, float* grad_gamma, float* grad_beta, float* coef, int n, long hw, int c, float eps,
                          int in_act, void* stream);
