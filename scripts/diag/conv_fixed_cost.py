@@ -11,7 +11,7 @@ wt = (torch.randn(32, 32, 3, 3) * 0.05).cuda()
 b = torch.randn(32).cuda()
 for split in (1, 0):
     lib.fn('dis_set_conv_split')(split)
-    for act, stats, label in ((1, True, 'SELU+stats'), (0, False, 'plain')):
+    for act, stats, label in ((1, True, 'SELU+stats'), (1, False, 'SELU only '), (0, True, 'stats only'), (0, False, 'plain     ')):
         pts = []
         for n in (8, 16, 32, 64):
             x = torch.randn(n, h, w, 32, device='cuda')
