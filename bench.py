@@ -188,6 +188,9 @@ def main():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to exercise the '
                          'multi-rank code path on a box with fewer GPUs than ranks)')
+    ap.add_argument('--with-sf', action='store_true',
+                    help='also run BASELINE config 2 (DIS-SF bs=8, bf16 activation storage) and config 2 in fp32 as child processes '
+                         'after this run and embed their lines as `extra_dis_sf` (N = 1 only)')
     ap.add_argument('--epoch', type=int, default=2, help='training epoch the step models (epoch<2 adds the L1 warm-up term)')
     args = ap.parse_args()
     if args.bs is None:
@@ -480,6 +483,23 @@ def main():
                             'on this host, whose own top-k breaks exact key ties by this host\'s BLAS rounding'
                             if 'out_forced' in first else ' of cpu_baseline on this host')}
 
+    extra_sf = None
+    if rank == 0 and world == 1 and args.with_sf and mf:
+        # fresh child processes (their own GPU context), after everything of this run has been measured
+        import subprocess
+        torch.cuda.synchronize()
+        extra_sf = {}
+        for tag, extra in (('bf16_activation_storage', ['--dtype', 'bf16']), ('fp32', [])):
+            cmd = [sys.executable, os.path.abspath(__file__), '--arch', 'single_frame', '--steps', str(max(5, args.steps // 2)),
+                   '--warmup', '3', '--no-cpu-baseline'] + extra
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            try:
+                d = json.loads(out.stdout.strip().splitlines()[-1])
+                extra_sf[tag] = {'metric': d['metric'], 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'],
+                                 'dtype': d['dtype'], 'roofline_frac': (d.get('roofline') or {}).get('frac'),
+                                 'command': 'python bench.py --arch single_frame' + (' --dtype bf16' if extra else '')}
+            except Exception as e:   # the headline line must not depend on the extra legs
+                extra_sf[tag] = {'error': f'{type(e).__name__}: {e}', 'rc': out.returncode}
     if rank == 0:
         frames = world * args.bs * TL * args.steps
         res = {
@@ -517,6 +537,7 @@ def main():
             'multi_gpu_measured': ('this line' if world > 1 and args.backend == 'nccl' else
                                    'unmeasured (no SCALE record with N > 1 exists yet)' if world == 1 else
                                    'gloo plumbing run, not a measurement'),
+            'extra_dis_sf': extra_sf,
             'loss_terms': losses,
             'eager_launch_frames_per_s': eager_fps, 'adam_steps_taken': adam_steps, 'step_mode': stepper.mode,
             'kernel_ms_one_eager_step': kernel_ms,
