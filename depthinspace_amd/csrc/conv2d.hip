@@ -1259,7 +1259,7 @@ extern "C" int dis_conv2d_dgrad_bf16x3_gnsums(const float* gy, const float* w_oi
 extern "C" int dis_conv2d_dgrad_bf16x3_gnsums_res(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride,
                                                   float* g, const float* act_y, const float* gn_x, double* ab_out, int n, int hin,
                                                   int win, int cin, int cout, int pad, void* stream) {
-  if (!gn_x || !ab_out || !act_y) return DIS_ERR_NULL;
+  if (!gn_x || !ab_out) return DIS_ERR_NULL;  // (act_y == NULL: no activation between the GroupNorm and this conv)
   if (w_o <= 0 || w_i <= 0 || w_o > 32 || w_i > 32 || cin != w_o || cout != w_i || cin != cout) return DIS_ERR_BAD_SHAPE;
   if (w_row_stride == 0) w_row_stride = w_i * 9;
   if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;

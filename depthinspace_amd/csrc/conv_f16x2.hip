@@ -661,7 +661,7 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
   using C = F2Cfg<CIN, COUT>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
   const bool ingn = a.gn_stats != nullptr;
-  static bool attr_set[17] = {};
+  static bool attr_set[18] = {};
   auto launch = [&](auto kern, int slot) -> hipError_t {
     if (!attr_set[slot]) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -688,7 +688,8 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
         if (!a.accum) return hipErrorInvalidValue;
         return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, true, false, 0, false, true, DIS_ACT_SELU>, 11);
       }
-      if (a.accum) return hipErrorInvalidValue;
+      if (a.accum)  // accumulating form without an activation behind the GroupNorm (a GroupNorm output with two consumers)
+        return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, true, false, 0, false, true, 0>, 17);
       return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, 0, false, true>, 10);
     } else {
       return hipErrorInvalidValue;

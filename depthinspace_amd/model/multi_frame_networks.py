@@ -152,12 +152,13 @@ class Block2D3D(TimedModule):
         return ops.group_norm(o, slots[gn_idx].weight, slots[gn_idx].bias, stats=st, in_act=act)
 
     @staticmethod
-    def _conv_gn_pair(x, s1, s2, stride1, join=None):
+    def _conv_gn_pair(x, s1, s2, stride1, join=None, gnres=None):
         """GN(SELU(conv_s2(GN(SELU(conv_s1(x)))))) (reference :338-345: two Conv-SELU-GroupNorm stages): the first GroupNorm is
         applied by the second conv while it stages its input (ops.conv2d_gn_in), the second one is written"""
         if not ops.gn_fusable(s1[1].weight.shape[0], s2[1].weight.shape[0], s2[1].weight.shape[2], 1):
             return Block2D3D._conv_gn(Block2D3D._conv_gn(x, s1, 3, stride1, 1, SELU, join), s2, 3, 1, 1, SELU)
-        o, st = ops.conv2d(x, s1[1].weight, s1[1].bias, stride1, 1, SELU, want_stats=True, gy_is_pre=True, join=join)
+        o, st = ops.conv2d(x, s1[1].weight, s1[1].bias, stride1, 1, SELU, want_stats=True, gy_is_pre=True, join=join,
+                           gnres=gnres)
         o, st = ops.conv2d_gn_in(o, st, s1[3].weight, s1[3].bias, s2[1].weight, s2[1].bias, 1, SELU, want_stats=True,
                                  gy_is_pre=True, in_act=SELU)
         return ops.group_norm(o, s2[3].weight, s2[3].bias, stats=st, in_act=SELU)
@@ -184,7 +185,9 @@ class Block2D3D(TimedModule):
         o, st = ops.conv2d_scaled_in(wf.view(N, h, w, tl * C), wgt, self.conv_mf[1].weight, self.conv_mf[1].bias, 1, 0,
                                      want_stats=True, join=j_wf)
         mf = ops.group_norm(o, self.conv_mf[2].weight, self.conv_mf[2].bias, stats=st)
-        a = self._conv_gn_pair(mf, self.conv1_1, self.conv1_2, 1, j_mf)
+        # (mf = GroupNorm(conv_mf(.)) has two consumers; the a-branch's backward runs second: conv1_1's accumulating input-gradient
+        # launch completes the gradient wrt mf and leaves the sums for that GroupNorm's backward)
+        a = self._conv_gn_pair(mf, self.conv1_1, self.conv1_2, 1, j_mf, gnres=getattr(mf, '_gn_plain_src', None) if grad else None)
         b = self._conv_gn_pair(mf, self.conv2_1, self.conv2_2, 2, j_mf)
         b = ops.resize_nhwc(b, (2 * b.shape[1], 2 * b.shape[2]), True)
         c = ops.resize_nhwc(o3d2.view(N, hq, wq, C), (2 * hq, 2 * wq), True)

@@ -666,15 +666,16 @@ class _Conv2d(torch.autograd.Function):
                 lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, weight, cout, cin, weight.stride(0), gx, n, gy.shape[1],
                          gy.shape[2], cout, cin, k - 1 - pad, 1 if second else 0)
             elif (gnres is not None and second and GN_SUMS and _bx_shape(cin_pad, cout, k, stride) and cin == cout and
-                  tuple(gnres[0].shape) == tuple(x.shape) and lib.fn('dis_get_conv_split')() == 1):
+                  tuple(gnres[0].shape) == tuple(x.shape) and lib.fn('dis_get_conv_split')() == 1 and gpre is gy):
                 # x is out = SELU(GroupNorm(x2) + res) of the previous ResNetBlock, and gx - which arrives holding this block's
                 # residual-branch gradient - becomes the complete gradient wrt out here.  The epilogue turns it into the gradient
                 # wrt the pre-activation value (times SELU'(x)) and leaves the GroupNorm-backward sums: that GroupNorm's backward
                 # then needs neither its reduce pass nor a residual-gradient write (_GroupNorm.backward looks the buffer up)
                 slots = lib.fn('dis_conv2d_gnsums_slots')()
                 ab = torch.zeros(n * slots * 2 * cin, dtype=torch.float64, device=x.device)
-                lib.call('dis_conv2d_dgrad_bf16x3_gnsums_res', gpre, weight, cout, cin, weight.stride(0), gx, x, gnres[0], ab, n,
-                         gpre.shape[1], gpre.shape[2], cout, cin, k - 1 - pad)
+                # (gnres = (x2,): x = SELU(GroupNorm(x2) + res); gnres = (x2, None): x = GroupNorm(x2) with two consumers, no SELU)
+                lib.call('dis_conv2d_dgrad_bf16x3_gnsums_res', gpre, weight, cout, cin, weight.stride(0), gx,
+                         x if len(gnres) == 1 else None, gnres[0], ab, n, gpre.shape[1], gpre.shape[2], cout, cin, k - 1 - pad)
                 _GN_PRE[gx.data_ptr()] = (ab, slots)
             elif stride == 1:
                 _conv_fwd_any(gpre, weight, cin, 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cin, k, 1,
@@ -1485,6 +1486,13 @@ class _GroupNorm(torch.autograd.Function):
         gg, gg_ret = _sink(gamma)
         gb, gb_ret = _sink(ctx.beta_ref)
         pre = _GN_PRE.pop(gy.data_ptr(), None)
+        if pre is not None and not has_res and act == ACT_NONE:
+            # (a plain GroupNorm output with two consumers: the consumer whose backward ran second left the sums of the complete g)
+            ab, slots = pre
+            coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=x.device)
+            lib.call('dis_gn_bwd_from_sums', gy, x, stats, gamma, ab, slots, gx, gg, gb, coef, n, hw, c, eps, in_act)
+            _sinks_written()
+            return gx, None, gg_ret, gb_ret, None, None, None, None, None
         if pre is not None and has_res and act == ACT_SELU and in_act == ACT_NONE:
             # gy already IS the gradient wrt the pre-activation value (the producing input-gradient launch multiplied by
             # SELU'(y) and left the channel sums): it doubles as the residual gradient, and one elementwise pass gives gx
@@ -1514,6 +1522,10 @@ class _GroupNorm(torch.autograd.Function):
         return gx, None, gg_ret, gb_ret, gres, None, None, None, None
 
 
+def c_ok(x):
+    return x.shape[-1] in (16, 32)
+
+
 def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5, in_act=ACT_NONE, join=None):
     """GroupNorm(1 group) over all but the first dim of an nhwc tensor; y = act(gn(x) (+ residual)).
     in_act: x is the output of that activation (conv2d(..., act, gy_is_pre=True)); the backward then returns the
@@ -1521,6 +1533,8 @@ def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5
     y = _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act, join)
     if residual is not None and act == ACT_SELU and in_act == ACT_NONE:
         y._gn_res_src = (x,)   # (a ResNetBlock that takes y as its input hands this to its first conv: conv2d(gnres=...))
+    elif residual is None and act == ACT_NONE and c_ok(x):
+        y._gn_plain_src = (x, None)   # (two-consumer form: Block2D3D hands it to the consumer whose backward runs second)
     return y
 
 

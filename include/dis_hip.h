@@ -290,7 +290,8 @@ int dis_conv2d_dgrad_bf16x3_gnsums(const float* gy, const float* w_oihw, int w_o
  * (reference model/multi_frame_networks.py:514-542): that conv's accumulating input-gradient launch computes, in place,
  * g = (g + conv_T(gy, w)) * selu'(act_y) (g arrives holding the next block's residual-branch gradient, act_y = out) and the sums of
  * g and g * gn_x (gn_x = x2); g then is the residual gradient of THIS block and, with dis_gn_bwd_from_sums(in_act = 0), gives the
- * gradient wrt x2 - no reduce pass, no separate residual-gradient write. */
+ * gradient wrt x2 - no reduce pass, no separate residual-gradient write.  act_y == NULL: a plain GroupNorm output with TWO consumers
+ * (Block2D3D's conv_mf GroupNorm, :338-345): g = g + conv_T(gy, w) in place, the sums of g and g * gn_x as above. */
 int dis_conv2d_dgrad_bf16x3_gnsums_res(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g,
                                        const float* act_y, const float* gn_x, double* ab_out, int n, int hin, int win, int cin,
                                        int cout, int pad, void* stream);
