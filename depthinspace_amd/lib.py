@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdis_hip.so')
+# (DIS_HIP_LIB: another build of the same library, for A/B measurements of build flags)
+LIB_PATH = os.environ.get('DIS_HIP_LIB') or os.path.join(_HERE, 'libdis_hip.so')
 
 # signature strings: p = pointer (device or host), i = int, l = long, f = float, d = double; the return type is int
 # unless listed in _RET_LONG.  Keep in sync with include/dis_hip.h (tests/test_abi.py checks the symbol set).
