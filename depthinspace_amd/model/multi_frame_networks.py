@@ -152,7 +152,7 @@ class Block2D3D(TimedModule):
         return ops.group_norm(o, slots[gn_idx].weight, slots[gn_idx].bias, stats=st, in_act=act)
 
     @staticmethod
-    def _conv_gn_pair(x, s1, s2, stride1, join=None, gnres=None):
+    def _conv_gn_pair(x, s1, s2, stride1, join=None, gnres=None, apply_last=True):
         """GN(SELU(conv_s2(GN(SELU(conv_s1(x)))))) (reference :338-345: two Conv-SELU-GroupNorm stages): the first GroupNorm is
         applied by the second conv while it stages its input (ops.conv2d_gn_in), the second one is written"""
         if not ops.gn_fusable(s1[1].weight.shape[0], s2[1].weight.shape[0], s2[1].weight.shape[2], 1):
@@ -161,6 +161,8 @@ class Block2D3D(TimedModule):
                            gnres=gnres)
         o, st = ops.conv2d_gn_in(o, st, s1[3].weight, s1[3].bias, s2[1].weight, s2[1].bias, 1, SELU, want_stats=True,
                                  gy_is_pre=True, in_act=SELU)
+        if not apply_last:   # the caller applies the second GroupNorm on load as well (conv_fuse): (pre-normalisation tensor, stats)
+            return o, st
         return ops.group_norm(o, s2[3].weight, s2[3].bias, stats=st, in_act=SELU)
 
     def tforward(self, feat, geom, geom_q, flows, flows_q, idx=None, idx_q=None, csr=None, csr_q=None, wgt=None):
@@ -187,12 +189,19 @@ class Block2D3D(TimedModule):
         mf = ops.group_norm(o, self.conv_mf[2].weight, self.conv_mf[2].bias, stats=st)
         # (mf = GroupNorm(conv_mf(.)) has two consumers; the a-branch's backward runs second: conv1_1's accumulating input-gradient
         # launch completes the gradient wrt mf and leaves the sums for that GroupNorm's backward)
-        a = self._conv_gn_pair(mf, self.conv1_1, self.conv1_2, 1, j_mf, gnres=getattr(mf, '_gn_plain_src', None) if grad else None)
+        fuse_a = ops.gn_fusable(C, C, 3, 1)   # conv_fuse applies conv1_2's GroupNorm on load (its first input slice)
+        a = self._conv_gn_pair(mf, self.conv1_1, self.conv1_2, 1, j_mf, gnres=getattr(mf, '_gn_plain_src', None) if grad else None,
+                               apply_last=not fuse_a)
         b = self._conv_gn_pair(mf, self.conv2_1, self.conv2_2, 2, j_mf)
         b = ops.resize_nhwc(b, (2 * b.shape[1], 2 * b.shape[2]), True)
         c = ops.resize_nhwc(o3d2.view(N, hq, wq, C), (2 * hq, 2 * wq), True)
         # conv over cat(a, b, c) as three accumulating 32->32 launches: the 96-channel tensor never exists
-        f, st = ops.conv2d_multi((a, b, c), self.conv_fuse[1].weight, self.conv_fuse[1].bias, 1, NONE, want_stats=True)
+        if fuse_a:
+            a, st_a = a
+            f, st = ops.conv2d_multi((a, b, c), self.conv_fuse[1].weight, self.conv_fuse[1].bias, 1, NONE, want_stats=True,
+                                     gn0=(st_a, self.conv1_2[3].weight, self.conv1_2[3].bias, 1e-5, SELU))
+        else:
+            f, st = ops.conv2d_multi((a, b, c), self.conv_fuse[1].weight, self.conv_fuse[1].bias, 1, NONE, want_stats=True)
         out = ops.group_norm(f, self.conv_fuse[2].weight, self.conv_fuse[2].bias, stats=st,
                              residual=feat.view(N, h, w, C), act=SELU, join=j_feat)
         return out.view(tl, bs, h, w, C)

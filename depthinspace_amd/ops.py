@@ -806,10 +806,12 @@ class _Conv2dMulti(torch.autograd.Function):
     """Conv2d (stride 1) over the channel concatenation of several nhwc tensors WITHOUT materialising the
     concatenation: one launch per source with the matching slice of the weight, the later launches accumulate into
     y (DIS_CONV_ACCUM); bias enters with the first launch, the activation and the GroupNorm statistics with the last.
-    The backward produces one input gradient per source directly (no split copies)."""
+    The backward produces one input gradient per source directly (no split copies).
+    gn_*: the FIRST source is the input of a GroupNorm that is applied on load (see _Conv2dGnIn): xs[0] is the pre-normalisation
+    tensor, gn_meta = (eps, in_act); its GroupNorm backward runs inside this node (sums in the input-gradient epilogue)."""
 
     @staticmethod
-    def forward(ctx, weight, bias, pad, act, want_stats, gy_is_pre, *xs):
+    def forward(ctx, weight, bias, pad, act, want_stats, gy_is_pre, gn_stats, gn_gamma, gn_beta, gn_meta, *xs):
         xs = [_c(x) for x in xs]
         weight = _c(weight)
         _chk(weight, bias, *xs)
@@ -825,14 +827,19 @@ class _Conv2dMulti(torch.autograd.Function):
             last = i == len(xs) - 1
             wi = weight[:, off:off + cs[i]]  # a view: no copy
             a = (act if last else ACT_NONE) | (CONV_ACCUM if i > 0 else 0)
-            _conv_fwd_any(x, wi, cs[i], 0, bias if i == 0 else None, y, stats if last else None, n, h, w, cs[i], cout, k, 1,
-                          pad, a)
+            if i == 0 and gn_meta is not None:
+                assert gn_fusable(cs[0], cout, k, 1) and len(xs) > 1
+                lib.call('dis_conv2d_fwd_bf16x3_gn', x, gn_stats, gn_gamma, gn_beta, float(gn_meta[0]), wi, cout, cs[0],
+                         wi.stride(0), bias, y, None, n, h, w, cs[0], cout, k, 1, pad, ACT_NONE)
+            else:
+                _conv_fwd_any(x, wi, cs[i], 0, bias if i == 0 else None, y, stats if last else None, n, h, w, cs[i], cout, k, 1,
+                              pad, a)
             off += cs[i]
         if gy_is_pre:
             act = ACT_NONE
-        ctx.save_for_backward(weight, y if act != ACT_NONE else None, *xs)
-        ctx.cfg = (pad, act, bias is not None, cs)
-        ctx.bias_ref = bias
+        ctx.save_for_backward(weight, y if act != ACT_NONE else None, gn_stats, gn_gamma, *xs)
+        ctx.cfg = (pad, act, bias is not None, cs, gn_meta)
+        ctx.bias_ref, ctx.beta_ref = bias, gn_beta
         if want_stats:
             ctx.mark_non_differentiable(stats)
             ctx.set_materialize_grads(False)  # no zero tensor for the statistics' (non-existent) gradient
@@ -841,13 +848,14 @@ class _Conv2dMulti(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gstats):
-        weight, y = ctx.saved_tensors[:2]
-        xs = ctx.saved_tensors[2:]
-        pad, act, has_bias, cs = ctx.cfg
+        weight, y, gn_stats, gn_gamma = ctx.saved_tensors[:4]
+        xs = ctx.saved_tensors[4:]
+        pad, act, has_bias, cs, gn_meta = ctx.cfg
         cout, cin, k, _ = weight.shape
         n, h, w, _ = xs[0].shape
         gy = _c(gy)
         fuse_act = act != ACT_NONE and all(_bx_shape(c_, cout, k, 1) for c_ in cs)  # see _Conv2d.backward
+        assert gn_meta is None or act == ACT_NONE
         if act != ACT_NONE and not fuse_act:
             gpre = torch.empty_like(gy)
             lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
@@ -855,14 +863,38 @@ class _Conv2dMulti(torch.autograd.Function):
             gpre = gy
         gw, gw_ret = _sink(weight)
         gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
+        gg_ret = gbt_ret = None
         gxs = []
         off = 0
         for i, x in enumerate(xs):
             wi = weight[:, off:off + cs[i]]  # a view: no copy
+            gn0 = i == 0 and gn_meta is not None
             gx = None
-            if ctx.needs_input_grad[6 + i]:
+            if ctx.needs_input_grad[10 + i]:
                 gx = torch.empty_like(x)
-                if fuse_act:
+                if gn0:
+                    # gradient wrt the normalised tensor, then through the GroupNorm (as _Conv2dGnIn.backward)
+                    eps, in_act = gn_meta
+                    gnorm = torch.empty_like(x)
+                    gg, gg_ret = _sink(gn_gamma)
+                    gbt, gbt_ret = _sink(ctx.beta_ref)
+                    if GN_SUMS and lib.fn('dis_get_conv_split')() == 1:
+                        slots = lib.fn('dis_conv2d_gnsums_slots')()
+                        ab = torch.zeros(n * slots * 2 * cs[0], dtype=torch.float64, device=x.device)
+                        lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, wi, cout, cs[0], wi.stride(0), gnorm, x, ab, n,
+                                 gpre.shape[1], gpre.shape[2], cout, cs[0], k - 1 - pad)
+                        coef = torch.empty(n * (cs[0] + 2) + 4 * n * cs[0] + 2, dtype=torch.float32, device=x.device)
+                        lib.call('dis_gn_bwd_from_sums', gnorm, x, gn_stats, gn_gamma, ab, slots, gx, gg, gbt, coef, n, h * w, cs[0],
+                                 float(eps), in_act)
+                    else:
+                        _conv_fwd_any(gpre, wi, cs[0], 1, None, gnorm, None, n, gpre.shape[1], gpre.shape[2], cout, cs[0], k, 1,
+                                      k - 1 - pad, ACT_NONE)
+                        wtot = lib.fn('dis_gn_bwd_workspace')(n, cs[0])
+                        wsd = torch.empty(wtot, dtype=torch.float64, device=x.device)
+                        nred2 = wtot // (2 + 2 * cs[0]) * 2
+                        lib.call('dis_gn_apply_bwd', gnorm, None, x, gn_stats, gn_gamma, gx, None, gg, gbt, wsd[:nred2], wsd[nred2:],
+                                 n, h * w, cs[0], ACT_NONE, float(eps), in_act)
+                elif fuse_act:
                     lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, wi, cout, cs[i], wi.stride(0), gx, n, gy.shape[1],
                              gy.shape[2], cout, cs[i], k - 1 - pad, 0)
                 else:
@@ -875,19 +907,25 @@ class _Conv2dMulti(torch.autograd.Function):
                 raise lib.DisHipError(f'conv2d_multi wgrad: unsupported shape cin={cs[i]} cout={cout} k={k}')
             ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
             gbi = gb if (i == 0 and has_bias) else None
-            if fuse_act:
+            if gn0:
+                lib.call('dis_conv2d_wgrad_bf16x3_gn', x, gn_stats, gn_gamma, ctx.beta_ref, float(gn_meta[0]), gpre, gwi, gbi, ws, n,
+                         h, w, cs[0], cs[0], cout, k, 1, pad)
+            elif fuse_act:
                 lib.call('dis_conv2d_wgrad_bf16x3_act', x, gy, y, act, gwi, gbi, ws, n, h, w, cs[i], cs[i], cout, k, 1, pad)
             else:
                 _conv_wgrad_any(x, gpre, gwi, gbi, ws, n, h, w, cs[i], cs[i], cout, k, 1, pad)
             gw[:, off:off + cs[i]].copy_(gwi)  # small strided memory move into the (flat) weight-gradient slice
             off += cs[i]
         _sinks_written()
-        return (gw_ret, gb_ret, None, None, None, None) + tuple(gxs)
+        return (gw_ret, gb_ret, None, None, None, None, None, gg_ret, gbt_ret, None) + tuple(gxs)
 
 
-def conv2d_multi(xs, weight, bias, pad=0, act=ACT_NONE, want_stats=False, gy_is_pre=False):
-    """conv2d(cat(xs, channel dim), weight) without the cat.  Returns (y, stats|None)."""
-    return _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, *xs)
+def conv2d_multi(xs, weight, bias, pad=0, act=ACT_NONE, want_stats=False, gy_is_pre=False, gn0=None):
+    """conv2d(cat(xs, channel dim), weight) without the cat.  Returns (y, stats|None).
+    gn0 = (stats, gamma, beta, eps, in_act): xs[0] is the INPUT of a GroupNorm(1 group) that is applied on load (conv2d_gn_in)."""
+    if gn0 is not None:
+        return _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, gn0[0], gn0[1], gn0[2], (gn0[3], gn0[4]), *xs)
+    return _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, None, None, None, None, *xs)
 
 
 class _Conv2dScaledIn(torch.autograd.Function):
