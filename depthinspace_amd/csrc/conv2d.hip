@@ -1402,15 +1402,19 @@ int dis_bx_slices_run(int dgrad, const float* x, int ldx, int xoff, int cin, int
 // ------------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int KH, int KW, int S>
 struct WgCfg {
-  static constexpr int CINB = (CIN % 32 == 0) ? 32 : ((CIN % 16 == 0) ? 16 : 4);
+  // channels per workgroup.  The 128 -> 32 1x1 conv of Block2D3D (conv_mf) takes all 128 at once: with 32-channel chunks as
+  // separate workgroups gy was read once per chunk (828 MB per launch against 566 MB algorithmic, round-2 profile)
+  static constexpr bool WIDE1X1 = CIN == 128 && KH == 1 && KW == 1 && S == 1;
+  static constexpr int CINB = WIDE1X1 ? 128 : ((CIN % 32 == 0) ? 32 : ((CIN % 16 == 0) ? 16 : 4));
   static constexpr int NCHUNK = CIN / CINB;
+  static constexpr int SG = CIN >= 32 ? CIN / 32 : 1;  // 32-channel groups of x: the granularity of WgArgs::xscale
   static constexpr bool KYSPLIT = (KH * KW * CINB * COUT) > 160 * 64;  // accumulator registers > 160
   static constexpr int KHB = KYSPLIT ? 1 : KH;     // tap rows handled per block
   static constexpr int NSPLIT = KYSPLIT ? KH : 1;
   static constexpr int MROWS = KHB * KW * CINB;
   static constexpr int MB = (MROWS + 15) / 16;
   static constexpr int NB = COUT / 16;
-  static constexpr int TROWS = (S == 1) ? 8 : 4;
+  static constexpr int TROWS = (S == 1 && !WIDE1X1) ? 8 : 4;  // (WIDE1X1: 64 pixels x 144 floats = 37 KB, 3 workgroups per CU)
   static constexpr int RPW = TROWS / 4;            // tile rows per wave
   static constexpr int STEPS = RPW * 4;            // MFMA k-steps per wave per tile (16 px per row / 4)
   static constexpr int IN_ROWS = (TROWS - 1) * S + KHB;
@@ -1484,7 +1488,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
         if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) {
           v = *(const float4*)(xb + ((long)iy * a.win + ix) * CIN + vv * 4);
           if (a.xscale) {
-            const float sc = a.xscale[(((long)n * a.hin + iy) * a.win + ix) * C::NCHUNK + chunk];
+            const float sc = a.xscale[(((long)n * a.hin + iy) * a.win + ix) * C::SG + chunk * (C::CINB / 32) + (vv * 4) / 32];
             v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
           }
         }
