@@ -130,6 +130,34 @@ def test_group_norm(c, act, res):
         assert relerr(nchw(rd.grad), rr.grad) < 1e-6
 
 
+@pytest.mark.parametrize('n,h,w', [(3, 19, 23), (2, 32, 48)])
+def test_conv1x1_scaled_input_matches_torch(n, h, w):
+    """ops.conv2d_scaled_in: the 128 -> 32 1x1 conv over the four mask-weighted slots of Block2D3D (conv_mf, reference
+    model/multi_frame_networks.py:406-411: `wf * (mask / mean(mask))` then Conv2d(4C, C, 1)), multiplier per (pixel, 32-channel slot)
+    applied inside the kernels: output, statistics, input gradient, weight and bias gradient (the weight gradient takes all 128
+    channels in one workgroup since round 3) against torch on the host; ragged tiles."""
+    from depthinspace_amd import ops
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x = torch.randn(n, h, w, 128, generator=g)
+    sc = torch.rand(n, h, w, 4, generator=g) * 2
+    wt = torch.randn(32, 128, 1, 1, generator=g) / 128 ** 0.5
+    b = torch.randn(32, generator=g) * 0.1
+    go = torch.randn(n, h, w, 32, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xs = (xr.view(n, h, w, 4, 32) * sc.unsqueeze(-1)).view(n, h, w, 128)
+    yr = F.conv2d(xs.permute(0, 3, 1, 2), wr, br).permute(0, 2, 3, 1)
+    yr.backward(go)
+    xd, wd, bd = x.cuda().requires_grad_(True), wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yd, st = ops.conv2d_scaled_in(xd, sc.cuda(), wd, bd, 1, 0, want_stats=True)
+    yd.backward(go.cuda())
+    assert relerr(yd, yr) < 2e-6
+    s_ref = torch.stack([yr.double().sum(dim=(1, 2, 3)), (yr.double() ** 2).sum(dim=(1, 2, 3))], dim=1).reshape(-1)
+    assert torch.allclose(st.cpu(), s_ref.detach(), rtol=1e-6, atol=1e-4)
+    assert relerr(xd.grad, xr.grad) < 5e-6
+    assert relerr(wd.grad, wr.grad) < 5e-6
+    assert relerr(bd.grad, br.grad) < 5e-6
+
+
 @pytest.mark.parametrize('c', [16, 32])
 @pytest.mark.parametrize('act', [0, 1])
 @pytest.mark.parametrize('n,h,w', [(3, 37, 29), (2, 64, 48)])
