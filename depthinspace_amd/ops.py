@@ -1682,6 +1682,15 @@ def mask_weight_slots(wf, geom, join=None):
 # frames/s) - the scatter is 9 whole 128-byte rows per output pixel, which L2 atomics handle at the rate of the plain traffic
 # the staged form needs.
 CONV3D_CSR = _os.environ.get('DIS_CONV3D_CSR', '0') == '1'
+# DIS_CONV3D_BWD: which backward Conv3D runs.
+#   det (default)  class-ordered plain read-modify-write of the feature-gradient rows (dis_conv3d_knn_bwd_det): bitwise
+#                  reproducible, no index structure; the forward keeps its aggregate (128 B per output pixel) for it
+#   agg            the same kernel in one launch with the float-atomic scatter (dis_conv3d_knn_bwd_agg)
+#   atomic         round 1-2's kernel (recomputes the aggregate; float atomics), csr with DIS_CONV3D_CSR=1
+CONV3D_BWD = _os.environ.get('DIS_CONV3D_BWD', 'det')
+if CONV3D_CSR:
+    CONV3D_BWD = 'atomic'
+assert CONV3D_BWD in ('det', 'agg', 'atomic')
 
 
 def conv3d_select(geom, stride, with_csr=False):
@@ -1724,8 +1733,10 @@ class _Conv3dKnn(torch.autograd.Function):
         wo = (wd + 2 - 3) // stride + 1
         assert idx.dtype == torch.uint8 and tuple(idx.shape) == (tl, bs, ho, wo, 9) and idx.is_contiguous()
         y = torch.empty((tl, bs, ho, wo, c), dtype=torch.float32, device=wf.device)
-        lib.call('dis_conv3d_knn_fwd', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, tl, bs, h, wd, stride)
-        ctx.save_for_backward(geom, wf, d1w, d1b, d2w, d2b, w, idx, y)
+        keep_agg = CONV3D_BWD != 'atomic' and any(ctx.needs_input_grad)
+        agg = torch.empty_like(y) if keep_agg else None
+        lib.call('dis_conv3d_knn_fwd_agg', geom, wf, d1w, d1b, d2w, d2b, w, idx, y, agg, tl, bs, h, wd, stride)
+        ctx.save_for_backward(geom, wf, d1w, d1b, d2w, d2b, w, idx, y, agg)
         ctx.stride = stride
         ctx.join = join
         ctx.c3csr = getattr(idx, 'c3csr', None)
@@ -1733,12 +1744,26 @@ class _Conv3dKnn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        geom, wf, d1w, d1b, d2w, d2b, w, idx, y = ctx.saved_tensors
+        geom, wf, d1w, d1b, d2w, d2b, w, idx, y, agg = ctx.saved_tensors
         tl, bs, h, wd, s, c = wf.shape
         join = ctx.join
         second = join is not None and join.buf is not None
         sunk = _sink_block((w, d1w, d1b, d2w, d2b))  # the kernel's parameter-gradient block IS the flat buffer's order
         gp = sunk if sunk is not None else torch.empty(1632, dtype=torch.float32, device=wf.device)
+        if agg is not None:
+            # class-ordered read-modify-write (det) / one launch with float atomics (agg): both ADD to the rows
+            gwf = join.take(wf.shape) if second else torch.zeros_like(wf)
+            acc = torch.empty(lib.fn('dis_conv3d_knn_bwd_det_workspace')(tl, bs, h, wd, ctx.stride), dtype=torch.float32,
+                              device=wf.device)
+            lib.call('dis_conv3d_knn_bwd_det' if CONV3D_BWD == 'det' else 'dis_conv3d_knn_bwd_agg', geom, wf, d1w, d1b, d2w, d2b, w,
+                     idx, y, agg, _c(gy), gwf, gp, acc, tl, bs, h, wd, ctx.stride)
+            if join is not None and not second:
+                gwf = join.first(gwf)
+            _sinks_written()
+            if sunk is not None:
+                return (None, gwf, None, None, None, None, None, None, None, None)
+            return (None, gwf, gp[1024:1072].view(16, 3), gp[1072:1088], gp[1088:1600].view(32, 16), gp[1600:1632],
+                    gp[0:1024].view(32, 32), None, None, None)
         acc = torch.empty(lib.fn('dis_conv3d_knn_bwd_workspace')(), dtype=torch.float32, device=wf.device)
         if ctx.c3csr is not None:
             # deterministic form: per-entry gradient rows staged, then summed per source row in list order

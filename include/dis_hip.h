@@ -386,6 +386,11 @@ int dis_conv3d_knn_select(const float* geom, unsigned char* idx_out, int tl, int
 int dis_conv3d_knn_fwd(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
                        const float* dense2_w, const float* dense2_b, const float* w, const unsigned char* idx,
                        float* y, int tl, int bs, int h, int wd, int stride, void* stream);
+/* The forward that also keeps agg (tl,bs,ho,wo,32), the weighted feature sums in front of the 32x32 mix, for
+ * dis_conv3d_knn_bwd_det (agg may be NULL: dis_conv3d_knn_fwd). */
+int dis_conv3d_knn_fwd_agg(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
+                           const float* dense2_w, const float* dense2_b, const float* w, const unsigned char* idx,
+                           float* y, float* agg, int tl, int bs, int h, int wd, int stride, void* stream);
 /* gy: gradient wrt y (post-SELU).  grad_wf (zeroed) scatter-added (float atomics, 128-B rows).  gparams:
  * 32*32+16*3+16+32*16+32 floats overwritten in that order (w, dense1_w, dense1_b, dense2_w, dense2_b: the order of
  * the module's parameters()).
@@ -408,6 +413,23 @@ int dis_conv3d_knn_bwd_csr(const float* geom, const float* wf, const float* dens
                            const float* y, const float* gy, float* grad_wf, float* gparams, float* workspace,
                            const int* csr, float* stage, int accumulate, int tl, int bs, int h, int wd, int stride,
                            void* stream);
+
+/* The backward of Conv3D (reference :469-512 under autograd) with a DETERMINISTIC feature gradient and no index structure:
+ * the output pixels are processed in 9 (stride 1) / 4 (stride 2) classes of pixels with pairwise disjoint 3x3 windows, one
+ * launch per class, so the rows of grad_wf are updated with plain read-modify-writes in a fixed order.  grad_wf is ADDED to
+ * (zero it, or hand in the gradient another consumer of wf has written).  agg: from dis_conv3d_knn_fwd_agg.  gparams as above.
+ * workspace: dis_conv3d_knn_bwd_det_workspace(...) floats. */
+long dis_conv3d_knn_bwd_det_workspace(int tl, int bs, int h, int wd, int stride);
+int dis_conv3d_knn_bwd_det(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
+                           const float* dense2_w, const float* dense2_b, const float* w, const unsigned char* idx,
+                           const float* y, const float* agg, const float* gy, float* grad_wf, float* gparams,
+                           float* workspace, int tl, int bs, int h, int wd, int stride, void* stream);
+/* The same kernel in one launch over all pixels with the float-atomic scatter (not reproducible bit for bit); same arguments
+ * and workspace. */
+int dis_conv3d_knn_bwd_agg(const float* geom, const float* wf, const float* dense1_w, const float* dense1_b,
+                           const float* dense2_w, const float* dense2_b, const float* w, const unsigned char* idx,
+                           const float* y, const float* agg, const float* gy, float* grad_wf, float* gparams,
+                           float* workspace, int tl, int bs, int h, int wd, int stride, void* stream);
 
 /* ---------------------------------------------------------------- general convolution family (DIS-SF) */
 

@@ -1,9 +1,10 @@
 """Run-to-run variance of one training step (SURVEY.md section 5 asks for it: the reference's scatter kernels are atomic and its
 results move from run to run).  The same DIS-MF / DIS-SF step is evaluated several times from identical parameters and inputs.
 The forward side (index selection, disparities) is required to repeat to 1e-5 px (in practice bit for bit: its only
-order-dependent sums are fp64); the losses are summed through fp64 atomics and are required to repeat to 1e-6 relative; the gradients pass through the float
-scatters that are left (geo-loss backward warp; Conv3D feature gradient) and are required to repeat to 1e-5 of the gradient's
-largest entry - two orders below the tolerance of the parity tests that read them."""
+order-dependent sums are fp64); the losses are summed through fp64 atomics and are required to repeat to 1e-6 relative; the
+gradients pass through the one float scatter that is left (the geo-loss backward warp; the Conv3D feature gradient is
+class-ordered and reproducible since round 3, tests/test_net_ops_gpu.py::test_conv3d_class_ordered_backward) and are required to
+repeat to 1e-5 of the gradient's largest entry - two orders below the tolerance of the parity tests that read them."""
 import argparse
 
 import numpy as np

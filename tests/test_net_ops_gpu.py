@@ -434,6 +434,49 @@ def test_conv3d_csr_feature_gradient(golden_dir, stride):
     assert all(np.all(np.diff(ents[offs[d]:offs[d + 1]]) > 0) for d in np.flatnonzero(np.diff(offs) > 1)[:2000])
 
 
+@pytest.mark.parametrize('stride', [1, 2])
+def test_conv3d_class_ordered_backward(golden_dir, stride):
+    """dis_conv3d_knn_bwd_det (the default backward: class-ordered plain read-modify-write, aggregate read back from the forward)
+    equals round 1-2's float-atomic kernel to rounding - feature gradient added on top of a base and all parameter gradients -,
+    repeats bit for bit, and so does its one-launch float-atomic form up to the atomics' order."""
+    from depthinspace_amd import ops
+    G = np.load(os.path.join(golden_dir, 'ops.npz'))
+    xyz, feat, mask = [torch.from_numpy(G[k]) for k in ('c3_xyz', 'c3_feat', 'c3_mask')]
+    tl, bs, C, h, w = feat.shape
+    p = O.init_params({k: v for k, v in O.mf_param_shapes().items() if k.startswith('blocks.0.conv3d_1')}, seed=5)
+    pd = {k[len('blocks.0.conv3d_1.'):]: v.detach().cuda() for k, v in p.items()}
+    g = torch.Generator().manual_seed(3)
+    geom1 = torch.cat([xyz, mask], dim=2).permute(1, 3, 4, 0, 2)
+    geom = geom1.unsqueeze(0).expand(tl, -1, -1, -1, -1, -1).contiguous().cuda()
+    wf = torch.randn(tl, bs, h, w, tl, C, generator=g).cuda()
+    idx = ops.conv3d_select(geom, stride)
+    ho, wo = idx.shape[2:4]
+    y, agg, y0 = [torch.empty((tl, bs, ho, wo, C), device='cuda') for _ in range(3)]
+    args = (geom, wf, pd['dense1.0.weight'], pd['dense1.0.bias'], pd['dense2.0.weight'], pd['dense2.0.bias'], pd['w'], idx)
+    ops.lib.call('dis_conv3d_knn_fwd_agg', *args, y, agg, tl, bs, h, w, stride)
+    ops.lib.call('dis_conv3d_knn_fwd', *args, y0, tl, bs, h, w, stride)
+    assert torch.equal(y, y0)
+    gy = torch.randn(y.shape, generator=g).cuda()
+    base = torch.randn(wf.shape, generator=g).cuda()
+    acc = torch.empty(ops.lib.fn('dis_conv3d_knn_bwd_workspace')(), device='cuda')
+    accd = torch.empty(ops.lib.fn('dis_conv3d_knn_bwd_det_workspace')(tl, bs, h, w, stride), device='cuda')
+    g_at, gp_at = base.clone(), torch.empty(1632, device='cuda')
+    ops.lib.call('dis_conv3d_knn_bwd', *args, y, gy, g_at, gp_at, acc, tl, bs, h, w, stride)
+    outs = []
+    for rep in range(2):
+        g_d, gp_d = base.clone(), torch.empty(1632, device='cuda')
+        ops.lib.call('dis_conv3d_knn_bwd_det', *args, y, agg, gy, g_d, gp_d, accd, tl, bs, h, w, stride)
+        outs.append((g_d, gp_d))
+    g_a, gp_a = base.clone(), torch.empty(1632, device='cuda')
+    ops.lib.call('dis_conv3d_knn_bwd_agg', *args, y, agg, gy, g_a, gp_a, accd, tl, bs, h, w, stride)
+    scale = float((g_at - base).abs().max())
+    assert scale > 0
+    for g_x, gp_x in (outs[0], (g_a, gp_a)):
+        assert float((g_x - g_at).abs().max()) < 2e-6 * scale
+        assert relerr(gp_x, gp_at) < 2e-6
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # bitwise reproducible
+
+
 def test_disp_head():
     from depthinspace_amd import ops
     g = torch.Generator().manual_seed(2)
