@@ -56,12 +56,18 @@ struct F2Cfg {
   static constexpr int W_U16 = KS * NP * 4 * COUT * 8;  // packed[kstep][plane][lg][co][8]
   static constexpr int X_U16 = IR * IC * PS;
   // + stats reduction (8 doubles) + wave maxima (2 x 8 floats) + per-wave channel sums of the EPIAB form (8 x 2 COUT floats)
-  static constexpr int LDS_BYTES = W_U16 * 2 + X_U16 * 2 + 64 + 64 + 8 * 2 * COUT * 4;
+  static constexpr int NXB = 2;  // halo buffers: tile t+1 is split and written while the matrix loop of tile t reads the other one
+  static constexpr int LDS_BYTES = W_U16 * 2 + NXB * X_U16 * 2 + 64 + 64 + 8 * 2 * COUT * 4;
   static constexpr int NITEMS = IR * IC * CV;
   static constexpr int NLOAD = (NITEMS + 511) / 512;
   static constexpr int NPIECE = 2 * NT;
   static constexpr int piece_ks(int i) { return KS == 9 ? 2 * i + 1 : i + 1; }
   static constexpr int load_ks(int i) { return KS == 9 ? 2 * (i / 2) : i; }
+  static constexpr int nload_at(int ks) {  // halo items staged (and refilled) at k-step ks
+    int c = 0;
+    for (int i = 0; i < NLOAD; ++i) c += load_ks(i) == ks ? 1 : 0;
+    return c;
+  }
 };
 
 // same tap / channel -> k-slot map as conv2d.hip's bx_weight
@@ -79,6 +85,16 @@ __device__ __forceinline__ void f2_split_pair(float x, float y, unsigned& p1, un
   const f32x2 v = {x, y};
   const f16x2_t h1 = __builtin_convertvector(v, f16x2_t);
   const f32x2 r = v - __builtin_convertvector(h1, f32x2);
+  const f16x2_t h2 = __builtin_convertvector(r, f16x2_t);
+  p1 = __builtin_bit_cast(unsigned, h1);
+  p2 = __builtin_bit_cast(unsigned, h2);
+}
+// the same for x * sc, y * sc with sc a power of two (the products are exact): the remainder x * sc - h1 as ONE mixed-precision
+// fused multiply-add per value (v_fma_mix_f32 reads h1's halves in place) instead of multiply, convert back, subtract
+__device__ __forceinline__ void f2_split_pair_scaled(float x, float y, float sc, unsigned& p1, unsigned& p2) {
+  const f32x2 v = {x * sc, y * sc};
+  const f16x2_t h1 = __builtin_convertvector(v, f16x2_t);
+  const f32x2 r = {__builtin_fmaf(x, sc, -(float)h1[0]), __builtin_fmaf(y, sc, -(float)h1[1])};
   const f16x2_t h2 = __builtin_convertvector(r, f16x2_t);
   p1 = __builtin_bit_cast(unsigned, h1);
   p2 = __builtin_bit_cast(unsigned, h2);
@@ -155,9 +171,9 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   unsigned short* wl = smem16;
   unsigned short* xl = smem16 + C::W_U16;
-  double* red = (double*)(smem16 + C::W_U16 + C::X_U16);
-  float* mxs = (float*)(smem16 + C::W_U16 + C::X_U16 + 32);  // [parity][wave]
-  float* abw = (float*)(smem16 + C::W_U16 + C::X_U16 + 64);  // EPIAB: [wave][2 COUT]
+  double* red = (double*)(smem16 + C::W_U16 + C::NXB * C::X_U16);
+  float* mxs = (float*)(smem16 + C::W_U16 + C::NXB * C::X_U16 + 32);  // [parity][wave]
+  float* abw = (float*)(smem16 + C::W_U16 + C::NXB * C::X_U16 + 64);  // EPIAB: [wave][2 COUT]
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -175,7 +191,8 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     const int idx = (int)threadIdx.x + it * 512;
     const int vv = idx % CV, pix = idx / CV;
     const int r = pix / IC, c = pix % IC;
-    it_rc[it] = idx < C::NITEMS ? (r | (c << 16)) : 0x4000;
+    (void)r;
+    it_rc[it] = idx < C::NITEMS ? c : 0x40000000;  // (halo column; items past the end of the halo: never in range)
     it_off[it] = ((r * a.win + c) * CIN + vv * 4) * 4;
   }
   const unsigned x_bytes = (unsigned)a.hin * a.win * (CIN * 4u);
@@ -191,9 +208,10 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     pf_bytes = live ? x_bytes : 0u;
   };
   auto pf_issue = [&](int it) {
-    const int iy = pf_iy0 + (it_rc[it] & 0xffff), ix = pf_ix0 + (it_rc[it] >> 16);
-    const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
-    const unsigned off = ok ? (unsigned)(pf_off0 + it_off[it]) : BX_OOB;
+    // rows above / below the sample leave the sample's buffer range by themselves (the offset wraps below 0 or passes its
+    // end): only the column needs a test - 4 vector instructions per item, the loop is vector-issue-bound
+    const int ix = pf_ix0 + it_rc[it];
+    const unsigned off = (unsigned)ix < (unsigned)a.win ? (unsigned)(pf_off0 + it_off[it]) : BX_OOB;
     pre[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(pf_x, pf_bytes), off, 0, 0));
     if (INACT)
       pre2[it] = __builtin_bit_cast(
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       if (INGN) {
         f32x2 sh_lo = {gn_sh.x, gn_sh.y}, sh_hi = {gn_sh.z, gn_sh.w};
         if (!gn_interior) {
-          const int iy = pf_iy0 + (it_rc[it] & 0xffff), ix = pf_ix0 + (it_rc[it] >> 16);
+          const int iy = pf_iy0 + ((int)threadIdx.x + it * 512) / (CV * IC), ix = pf_ix0 + it_rc[it];
           const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
           sh_lo = ok ? sh_lo : (f32x2){0.f, 0.f};
           sh_hi = ok ? sh_hi : (f32x2){0.f, 0.f};
@@ -238,34 +256,36 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
         v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
         v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
       }
+      // (items past the end of the halo - last round only - were loaded out of range, zeros, and are not staged; under GroupNorm
+      //  on load they would carry the shift into the tile's maximum)
+      if (INGN && (it + 1) * 512 > C::NITEMS && (int)threadIdx.x + it * 512 >= C::NITEMS) v = make_float4(0.f, 0.f, 0.f, 0.f);
       pre[it] = v;
-      // (items past the end of the halo - last round only - are not staged and do not count)
-      const float mv = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-      m = ((int)threadIdx.x + it * 512 < C::NITEMS) ? fmaxf(m, mv) : m;
+      m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.x)), fabsf(v.y));   // -> v_max3_f32 with |.| modifiers
+      m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.z)), fabsf(v.w));
     }
     m = f2_wave_max(m);
     if (lane == 0) mxs[parity * 8 + wave] = m;
   };
-  // (2) AFTER it: the tile's scale from the eight maxima, split, LDS write.  Returns the scale's exponent.
-  auto stage = [&](int parity) -> int {
+  // (2) AFTER it: the tile's scale from the eight maxima (returns its exponent) ...
+  auto tile_scale = [&](int parity) -> int {
     const float4 m0 = *(const float4*)(mxs + parity * 8), m1 = *(const float4*)(mxs + parity * 8 + 4);
     const float m = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
-    const int se = f2_scale_exp(m);
-    const float sc = __builtin_ldexpf(1.f, se);
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
-      if ((int)threadIdx.x + it * 512 < C::NITEMS) {
-        const float4 v = pre[it];
-        unsigned a1, a2, b1, b2;
-        f2_split_pair(v.x * sc, v.y * sc, a1, a2);
-        f2_split_pair(v.z * sc, v.w * sc, b1, b2);
-        const int idx = (int)threadIdx.x + it * 512;
-        unsigned short* p = xl + (idx / CV) * PS + (idx % CV) * 4;
-        *(uint2*)(p) = make_uint2(a1, b1);
-        *(uint2*)(p + CIN) = make_uint2(a2, b2);
-      }
+    return f2_scale_exp(m);
+  };
+  // ... and, item by item, scale, split, LDS write into halo buffer xb.  For every tile but a workgroup's first these ride in
+  // the matrix loop of the tile before (the even k-steps; the deferred epilogue has the odd ones), each item followed by the
+  // load that refills its registers with the tile after.
+  auto stage_item = [&](int it, float sc, unsigned short* xb) {
+    if ((int)threadIdx.x + it * 512 < C::NITEMS) {
+      const float4 v = pre[it];
+      unsigned a1, a2, b1, b2;
+      f2_split_pair_scaled(v.x, v.y, sc, a1, a2);
+      f2_split_pair_scaled(v.z, v.w, sc, b1, b2);
+      const int idx = (int)threadIdx.x + it * 512;
+      unsigned short* p = xb + (idx / CV) * PS + (idx % CV) * 4;
+      *(uint2*)(p) = make_uint2(a1, b1);
+      *(uint2*)(p + CIN) = make_uint2(a2, b2);
     }
-    return se;
   };
 
   int tile = t_lo + rank;
@@ -463,7 +483,29 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 
   const int xa_lane = (wave * 2 * IC + li) * PS + (CIN == 32 ? lg * 8 : (lg & 1) * 8);
   const bool hi_tap = (lg >> 1) != 0;
-  int parity = 0;
+  int parity = 0, buf = 0, sx_e = 0;
+  auto advance = [&](int& n_, int& ty_, int& tx_) {
+    tx_ += d_tx, ty_ += d_ty, n_ += d_n;
+    if (tx_ >= tiles_x) tx_ -= tiles_x, ++ty_;
+    if (ty_ >= tiles_y) ty_ -= tiles_y, ++n_;
+  };
+  int n1 = cn, ty1 = cty, tx1 = ctx;   // the tile after the current one
+  if (tile < t_hi) {
+    // the workgroup's first tile: staged here, nothing to hide it behind
+    prep(cn, parity);
+    __syncthreads();
+    sx_e = tile_scale(parity);
+    {
+      const float sc = __builtin_ldexpf(1.f, sx_e);
+#pragma unroll
+      for (int it = 0; it < NLOAD; ++it) stage_item(it, sc, xl);
+    }
+    parity ^= 1;
+    advance(n1, ty1, tx1);
+    pf_setup(n1, ty1, tx1, tile + per < t_hi);
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) pf_issue(it);
+  }
 
   while (tile < t_hi) {
     const int vy0 = cty * F2_TR + wave * 2, vx0 = ctx * F2_TC + li;
@@ -479,20 +521,23 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     stats_sample();
     ab_sample();
     F2_T(0)
-    prep(cn, parity);
+    // the NEXT tile's items (in flight since the previous matrix loop; zeros when there is no next tile): final values, maxima
+    prep(n1, parity);
     F2_T(1)
-    __syncthreads();  // every wave has finished reading the previous halo tile, and has left its maximum
-    F2_T(2)
-    const int sx_e = stage(parity);
-    F2_T(3)
+    // ONE barrier per tile: every wave has finished reading the other halo buffer (the previous tile), this tile's buffer is
+    // completely written, the maxima of the next tile are visible
     __syncthreads();
-    F2_T(4)
+    F2_T(2)
+    const int sx_n = tile_scale(parity);
+    const float sc_n = __builtin_ldexpf(1.f, sx_n);
     parity ^= 1;
-    const int ntile = tile + per;
-    int ntx = ctx + d_tx, nty = cty + d_ty, nn = cn + d_n;
-    if (ntx >= tiles_x) ntx -= tiles_x, ++nty;
-    if (nty >= tiles_y) nty -= tiles_y, ++nn;
-    pf_setup(nn, nty, ntx, ntile < t_hi);
+    const unsigned short* xc = xl + buf * C::X_U16;        // this tile's halo
+    unsigned short* xn = xl + (buf ^ 1) * C::X_U16;        // the next tile's
+    int n2 = n1, ty2 = ty1, tx2 = tx1;
+    advance(n2, ty2, tx2);
+    pf_setup(n2, ty2, tx2, tile + 2 * per < t_hi);
+    F2_T(3)
+    F2_T(4)
     t1 = 0.f;
     t2 = 0.f;
 
@@ -502,13 +547,19 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       if (EPIAB && ks == 0) abx_load(a.ab_x + (cur_y - a.y), EPIACT ? a.ab_act_y + (cur_y - a.y) : nullptr, cur_off);
 #pragma unroll
       for (int it = 0; it < NLOAD; ++it)
+        if (C::load_ks(it) == ks) stage_item(it, sc_n, xn);
+#pragma unroll
+      for (int it = 0; it < NLOAD; ++it)
         if (C::load_ks(it) == ks) pf_issue(it);
 #pragma unroll
       for (int i = 0; i < NPIECE; ++i)
         if (C::piece_ks(i) == ks) epi_piece(i);
     };
-    auto pattern = [&](auto nrc) {
-      constexpr int NM = 6 * NT, NR = decltype(nrc)::value;
+    auto pattern = [&](auto nrc, auto ksc) {
+      constexpr int NM = 6 * NT, NR = decltype(nrc)::value, ks = decltype(ksc)::value;
+      constexpr int NIT = C::nload_at(ks), NSW = 2 * NIT, NLD = NIT * (INACT ? 2 : 1);
+      constexpr int NEARLY = ks == 0 ? (ACCUM ? NPIECE : 0) + (EPIAB ? NPIECE * (EPIACT ? 2 : 1) : 0) : 0;
+      static_assert(NSW <= NM, "one LDS write per matrix instruction gap");
 #pragma unroll
       for (int g = 0; g < NM; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
@@ -517,7 +568,9 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
         // fit behind each of its own MFMAs; with 3 - the bf16x3 kernel's figure, twice the MFMAs per k-step - the epilogue
         // VALU that did not fit was issued after the k-step's last MFMA, exposed)
         __builtin_amdgcn_sched_group_barrier(0x002, F2_VALU_PER_GAP, 0);
-        if (g == (NR < NM ? NR : NM - 1)) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // the k-step's halo loads
+        if (NEARLY && g == (NR < NM ? NR : NM - 1)) __builtin_amdgcn_sched_group_barrier(0x020, NEARLY, 0);  // epilogue operands
+        if (NSW && g >= NM - NSW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // the next tile's split items -> LDS
+        if (NLD && g == NM - 1) __builtin_amdgcn_sched_group_barrier(0x020, NLD, 0);  // ... and the loads that refill them
       }
       __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);  // the k-step's store
       __builtin_amdgcn_sched_barrier(0);
@@ -530,7 +583,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       s16x8 fb[2][NP][NT];   // [buffer][plane][nt]
       auto load_row = [&](int kx, int j) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) R[kx & 1][j][p] = *(const s16x8*)(xl + xa_lane + (j * IC + kx) * PS + p * CIN);
+        for (int p = 0; p < NP; ++p) R[kx & 1][j][p] = *(const s16x8*)(xc + xa_lane + (j * IC + kx) * PS + p * CIN);
       };
       auto load_w = [&](int ks, s16x8 (&B)[NP][NT]) {
 #ifdef F2_EXP_NOW  // timing experiment (wrong results): no weight-fragment reads after the first tap
@@ -568,7 +621,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fb[b][PB[q]][nt]),
                                                                   __builtin_bit_cast(f16x8_t, R[kx & 1][ky + mt][PA[q]]),
                                                                   acc[mt][nt], 0, 0, 0);
-        pattern(std::integral_constant<int, (ks + 1 < KS ? (nky == 0 ? 2 * NP : NP) + NP * NT : 0)>{});
+        pattern(std::integral_constant<int, (ks + 1 < KS ? (nky == 0 ? 2 * NP : NP) + NP * NT : 0)>{}, ksc);
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
       step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
@@ -581,7 +634,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) A[p][mt] = *(const s16x8*)(xl + xa_lane + xoff + mt * IC * PS + p * CIN);
+          for (int mt = 0; mt < 2; ++mt) A[p][mt] = *(const s16x8*)(xc + xa_lane + xoff + mt * IC * PS + p * CIN);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) B[p][nt] = *(const s16x8*)(wl + (((ks * NP + p) * 4 + lg) * COUT + nt * 16 + li) * 8);
         }
@@ -601,7 +654,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fb[b][PB[q]][nt]),
                                                                   __builtin_bit_cast(f16x8_t, fa[b][PA[q]][mt]),
                                                                   acc[mt][nt], 0, 0, 0);
-        pattern(std::integral_constant<int, (ks + 1 < KS ? NP * (2 + NT) : 0)>{});
+        pattern(std::integral_constant<int, (ks + 1 < KS ? NP * (2 + NT) : 0)>{}, ksc);
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
       step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{});
@@ -635,8 +688,11 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     for (int i = 0; i < (EPIAB ? NPIECE : 0); ++i) epix[i] = prevx[i];
     prev_y = cur_y;
     prev_n = cn;
-    cn = nn, cty = nty, ctx = ntx;
-    tile = ntile;
+    cn = n1, cty = ty1, ctx = tx1;
+    n1 = n2, ty1 = ty2, tx1 = tx2;
+    tile += per;
+    sx_e = sx_n;
+    buf ^= 1;
     F2_T(6)
   }
   stats_sample();
@@ -804,7 +860,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
     const int idx = (int)threadIdx.x + it * 256;
     const int vv = idx % C::CVX, pix = idx / C::CVX;
     const int r = pix / WX_IC, c = pix % WX_IC;
-    ix_rc[it] = idx < C::NIX ? (r | (c << 16)) : 0x4000;
+    ix_rc[it] = idx < C::NIX ? (r | (c << 16)) : 0x40000000;  // (items past the end of the halo: column never in range)
     ix_off[it] = ((r * a.win + c) * CIN + vv * 4) * 4;
   }
 #pragma unroll
@@ -829,8 +885,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
     const int xoff0 = (iy0 * a.win + ix0) * (CIN * 4);
 #pragma unroll
     for (int it = 0; it < NLX; ++it) {
-      const int iy = iy0 + (ix_rc[it] & 0xffff), ix = ix0 + (ix_rc[it] >> 16);
-      const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+      // (rows above / below the sample leave the sample's buffer range by themselves: only the column is tested)
+      const int ix = ix0 + (ix_rc[it] >> 16);
+      const bool ok = (unsigned)ix < (unsigned)a.win;
       prex[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(xb, x_bytes), ok ? (unsigned)(xoff0 + ix_off[it]) : BX_OOB, 0, 0));
     }
@@ -838,8 +895,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
     const int goff0 = (ty * TR * a.wout + tx * 16) * (COUT * 4);
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
-      const int oy = ty * TR + (ig_rc[it] & 0xffff), ox = tx * 16 + (ig_rc[it] >> 16);
-      const bool ok = oy < a.hout && ox < a.wout;
+      const int ox = tx * 16 + (ig_rc[it] >> 16);
+      const bool ok = ox < a.wout;   // (rows below the sample: past the end of its buffer range)
       preg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(gb, g_bytes), ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
       if (INACT)
@@ -876,8 +933,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
         v = make_float4(lo[0], lo[1], hi[0], hi[1]);
         prex[it] = v;
       }
-      const float mv = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-      mx = ((int)threadIdx.x + it * 256 < C::NIX) ? fmaxf(mx, mv) : mx;
+      const float mv = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)), fabsf(v.w));
+      mx = (!INGN || (it + 1) * 256 <= C::NIX || (int)threadIdx.x + it * 256 < C::NIX) ? fmaxf(mx, mv) : mx;  // (not loaded: zeros)
     }
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
@@ -889,7 +946,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
         preg[it] = v;
       }
       bsum.x += v.x, bsum.y += v.y, bsum.z += v.z, bsum.w += v.w;
-      mg = fmaxf(mg, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      mg = __builtin_fmaxf(__builtin_fmaxf(mg, fabsf(v.x)), fabsf(v.y));
+      mg = __builtin_fmaxf(__builtin_fmaxf(mg, fabsf(v.z)), fabsf(v.w));
     }
     mx = f2_wave_max(mx);
     mg = f2_wave_max(mg);
@@ -919,8 +977,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
       if (idx < C::NIX) {
         const float4 v = prex[it];
         unsigned a1, a2, b1, b2;
-        f2_split_pair(v.x * scx, v.y * scx, a1, a2);
-        f2_split_pair(v.z * scx, v.w * scx, b1, b2);
+        f2_split_pair_scaled(v.x, v.y, scx, a1, a2);
+        f2_split_pair_scaled(v.z, v.w, scx, b1, b2);
         unsigned short* p = xl + (idx / C::CVX) * PSX + (idx % C::CVX) * 4;
         *(uint2*)(p) = make_uint2(a1, b1);
         *(uint2*)(p + CIN) = make_uint2(a2, b2);
@@ -931,8 +989,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
       const int idx = threadIdx.x + it * 256;
       const float4 v = preg[it];
       unsigned a1, a2, b1, b2;
-      f2_split_pair(v.x * scg, v.y * scg, a1, a2);
-      f2_split_pair(v.z * scg, v.w * scg, b1, b2);
+      f2_split_pair_scaled(v.x, v.y, scg, a1, a2);
+      f2_split_pair_scaled(v.z, v.w, scg, b1, b2);
       unsigned short* p = gl + (idx / C::CVG) * PSG + (idx % C::CVG) * 4;
       *(uint2*)(p) = make_uint2(a1, b1);
       *(uint2*)(p + COUT) = make_uint2(a2, b2);
