@@ -296,25 +296,46 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) pf_issue(it);  // in flight while the weights are split
   }
-  // ---- weights: OIHW fp32 -> scaled fp16 planes in fragment order.  Coalesced copy into the (still unused) halo region, rows
-  // padded by one float, largest magnitude over the block, then (k-step, lane group, cout) units of 2 x 8 fp16.
-  int sw_e = 0;
+  // ---- weights: OIHW fp32 -> scaled fp16 planes in fragment order.  Coalesced copy into the second (still unused) halo buffer,
+  // rows padded by one float, largest magnitude over the block, then (k-step, lane group, cout) units of 2 x 8 fp16.  The
+  // workgroup's FIRST tile is staged in between (nothing to hide it behind), so that the loads of its second tile are in flight
+  // while the weights are split: one barrier for weights + first tile, the next one is the first loop iteration's.
+  int sw_e = 0, parity = 0, buf = 0, sx_e = 0;
+  auto advance = [&](int& n_, int& ty_, int& tx_) {
+    tx_ += d_tx, ty_ += d_ty, n_ += d_n;
+    if (tx_ >= tiles_x) tx_ -= tiles_x, ++ty_;
+    if (ty_ >= tiles_y) ty_ -= tiles_y, ++n_;
+  };
+  int n1 = cn, ty1 = cty, tx1 = ctx;   // the tile after the current one
   {
-    float* ws = (float*)xl;
+    float* ws = (float*)(xl + C::X_U16);
+    float* wmx = (float*)(red + 4);   // the weights' eight wave maxima (their own slots: mxs is the tiles')
     const int row = a.w_i * 9;
     float m = dis_copy_w_rows(a.w, a.w_o, row, a.w_rs, ws);
     m = f2_wave_max(m);
-    if (lane == 0) mxs[wave] = m;
+    if (lane == 0) wmx[wave] = m;
     if (threadIdx.x == 0) {  // statistics accumulators (stats_flush)
       red[0] = 0.0;
       red[1] = 0.0;
       *(unsigned*)(red + 2) = 0u;
       *(unsigned*)(red + 3) = 0u;  // (ab_flush)
     }
+    if (tile < t_hi) prep(cn, parity);
     __syncthreads();
-    const float4 m0 = *(const float4*)(mxs), m1 = *(const float4*)(mxs + 4);
+    const float4 m0 = *(const float4*)(wmx), m1 = *(const float4*)(wmx + 4);
     sw_e = f2_scale_exp(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))));
     const float sw = __builtin_ldexpf(1.f, sw_e);
+    if (tile < t_hi) {
+      sx_e = tile_scale(parity);
+      const float sc = __builtin_ldexpf(1.f, sx_e);
+#pragma unroll
+      for (int it = 0; it < NLOAD; ++it) stage_item(it, sc, xl);
+      advance(n1, ty1, tx1);
+      pf_setup(n1, ty1, tx1, tile + per < t_hi);
+#pragma unroll
+      for (int it = 0; it < NLOAD; ++it) pf_issue(it);
+    }
+    parity ^= 1;
     for (int u = threadIdx.x; u < KS * 4 * COUT; u += 512) {
       const int co = u % COUT, g = (u / COUT) & 3, ks = u / (4 * COUT);
       unsigned pl[2][4];
@@ -328,7 +349,8 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       for (int p = 0; p < NP; ++p)
         *(uint4*)(wl + (((ks * NP + p) * 4 + g) * COUT + co) * 8) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
     }
-    __syncthreads();  // the maxima slots and `ws` are free again before the first tile's prep / stage
+    // (no barrier here: the first loop iteration's publishes the weight planes and the first halo buffer, and by then every
+    //  wave has finished reading `ws` - the second halo buffer is first written after that barrier)
   }
 
   f32x4 acc[2][NT], outv[2][NT];
@@ -483,30 +505,6 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 
   const int xa_lane = (wave * 2 * IC + li) * PS + (CIN == 32 ? lg * 8 : (lg & 1) * 8);
   const bool hi_tap = (lg >> 1) != 0;
-  int parity = 0, buf = 0, sx_e = 0;
-  auto advance = [&](int& n_, int& ty_, int& tx_) {
-    tx_ += d_tx, ty_ += d_ty, n_ += d_n;
-    if (tx_ >= tiles_x) tx_ -= tiles_x, ++ty_;
-    if (ty_ >= tiles_y) ty_ -= tiles_y, ++n_;
-  };
-  int n1 = cn, ty1 = cty, tx1 = ctx;   // the tile after the current one
-  if (tile < t_hi) {
-    // the workgroup's first tile: staged here, nothing to hide it behind
-    prep(cn, parity);
-    __syncthreads();
-    sx_e = tile_scale(parity);
-    {
-      const float sc = __builtin_ldexpf(1.f, sx_e);
-#pragma unroll
-      for (int it = 0; it < NLOAD; ++it) stage_item(it, sc, xl);
-    }
-    parity ^= 1;
-    advance(n1, ty1, tx1);
-    pf_setup(n1, ty1, tx1, tile + per < t_hi);
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) pf_issue(it);
-  }
-
   while (tile < t_hi) {
     const int vy0 = cty * F2_TR + wave * 2, vx0 = ctx * F2_TC + li;
     const int tile_yoff = ((cty * F2_TR * a.osy + a.ooy) * a.wf + ctx * F2_TC * a.osx + a.oox) * (COUT * 4) + y_lane;
