@@ -33,7 +33,7 @@ def _c(t):
 # A slice is handed out at most once between two clears; without begin_step (tests, inference) the arena simply runs
 # out and plain torch.zeros takes over.
 _ARENA = {}
-_ARENA_DOUBLES = 1 << 16
+_ARENA_DOUBLES = 1 << 23   # 64 MiB: the per-workgroup channel-sum slots of the GroupNorm backward are 2 MiB per launch, ~30 per step
 
 
 # gradient tensors whose producer already left the GroupNorm-backward sums (see _Conv2d.backward / _GroupNorm.backward):
@@ -48,10 +48,11 @@ def begin_step(dev):
     dev = torch.device(dev)
     a = _ARENA.get(dev)
     if a is None:
-        a = _ARENA[dev] = [torch.zeros(_ARENA_DOUBLES, dtype=torch.float64, device=dev), 0]
-    else:
-        a[0].zero_()
+        a = _ARENA[dev] = [torch.zeros(_ARENA_DOUBLES, dtype=torch.float64, device=dev), 0, 0]
+    elif a[2] > 0:
+        a[0][:a[2]].zero_()   # only what was handed out since the last clear (the rest is still zero)
     a[1] = 0
+    a[2] = 0
 
 
 def _zeros_d(n, dev):
@@ -59,6 +60,7 @@ def _zeros_d(n, dev):
     if a is not None and a[1] + n <= _ARENA_DOUBLES:
         v = a[0][a[1]:a[1] + n]
         a[1] += (n + 1) // 2 * 2
+        a[2] = max(a[2], a[1])
         return v
     return torch.zeros(n, dtype=torch.float64, device=dev)
 
@@ -658,7 +660,7 @@ class _Conv2d(torch.autograd.Function):
                     tuple(gnres[0].shape) == tuple(x.shape) and lib.fn('dis_get_conv_split')() == 1):
                 # (final_conv: x = SELU(GroupNorm(.) + res) of ref_res3 and this conv is its only consumer - as below)
                 slots = lib.fn('dis_conv2d_gnsums_slots')()
-                ab = torch.zeros(n * slots * 2 * cin, dtype=torch.float64, device=x.device)
+                ab = _zeros_d(n * slots * 2 * cin, x.device)
                 lib.call('dis_conv2d_dgrad_bf16x3_act_gnsums_res', gy, y, weight, cout, cin, weight.stride(0), gx, x, gnres[0], ab,
                          n, gy.shape[1], gy.shape[2], cout, cin, k - 1 - pad)
                 _GN_PRE[gx.data_ptr()] = (ab, slots)
@@ -672,7 +674,7 @@ class _Conv2d(torch.autograd.Function):
                 # wrt the pre-activation value (times SELU'(x)) and leaves the GroupNorm-backward sums: that GroupNorm's backward
                 # then needs neither its reduce pass nor a residual-gradient write (_GroupNorm.backward looks the buffer up)
                 slots = lib.fn('dis_conv2d_gnsums_slots')()
-                ab = torch.zeros(n * slots * 2 * cin, dtype=torch.float64, device=x.device)
+                ab = _zeros_d(n * slots * 2 * cin, x.device)
                 # (gnres = (x2,): x = SELU(GroupNorm(x2) + res); gnres = (x2, None): x = GroupNorm(x2) with two consumers, no SELU)
                 lib.call('dis_conv2d_dgrad_bf16x3_gnsums_res', gpre, weight, cout, cin, weight.stride(0), gx,
                          x if len(gnres) == 1 else None, gnres[0], ab, n, gpre.shape[1], gpre.shape[2], cout, cin, k - 1 - pad)
@@ -772,7 +774,7 @@ class _Conv2dGnIn(torch.autograd.Function):
             # the input-gradient launch leaves the per-(sample, channel) sums of g and g * x in its epilogue: the GroupNorm
             # backward is then ONE elementwise pass (no reduce pass over g and x)
             slots = lib.fn('dis_conv2d_gnsums_slots')()
-            ab = torch.zeros(n * slots * 2 * cin, dtype=torch.float64, device=x.device)
+            ab = _zeros_d(n * slots * 2 * cin, x.device)
             lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, weight, cout, cin, weight.stride(0), gnorm, x, ab, n, gpre.shape[1],
                      gpre.shape[2], cout, cin, k - 1 - pad)
             coef = torch.empty(n * (cin + 2) + 4 * n * cin + 2, dtype=torch.float32, device=x.device)
@@ -880,7 +882,7 @@ class _Conv2dMulti(torch.autograd.Function):
                     gbt, gbt_ret = _sink(ctx.beta_ref)
                     if GN_SUMS and lib.fn('dis_get_conv_split')() == 1:
                         slots = lib.fn('dis_conv2d_gnsums_slots')()
-                        ab = torch.zeros(n * slots * 2 * cs[0], dtype=torch.float64, device=x.device)
+                        ab = _zeros_d(n * slots * 2 * cs[0], x.device)
                         lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, wi, cout, cs[0], wi.stride(0), gnorm, x, ab, n,
                                  gpre.shape[1], gpre.shape[2], cout, cs[0], k - 1 - pad)
                         coef = torch.empty(n * (cs[0] + 2) + 4 * n * cs[0] + 2, dtype=torch.float32, device=x.device)
