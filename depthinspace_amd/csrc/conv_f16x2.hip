@@ -57,7 +57,7 @@ struct F2Cfg {
   static constexpr int X_U16 = IR * IC * PS;
   // + stats reduction (8 doubles) + wave maxima (2 x 8 floats) + per-wave channel sums of the EPIAB form (8 x 2 COUT floats)
   static constexpr int NXB = 2;  // halo buffers: tile t+1 is split and written while the matrix loop of tile t reads the other one
-  static constexpr int LDS_BYTES = W_U16 * 2 + NXB * X_U16 * 2 + 64 + 64 + 8 * 2 * COUT * 4;
+  static constexpr int LDS_BYTES = W_U16 * 2 + NXB * X_U16 * 2 + 64 + 64 + 8 * 2 * COUT * 4 + 16 + 2 * CIN;  // (+ a write pad)
   static constexpr int NITEMS = IR * IC * CV;
   static constexpr int NLOAD = (NITEMS + 511) / 512;
   static constexpr int NPIECE = 2 * NT;
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   double* red = (double*)(smem16 + C::W_U16 + C::NXB * C::X_U16);
   float* mxs = (float*)(smem16 + C::W_U16 + C::NXB * C::X_U16 + 32);  // [parity][wave]
   float* abw = (float*)(smem16 + C::W_U16 + C::NXB * C::X_U16 + 64);  // EPIAB: [wave][2 COUT]
+  unsigned short* pad16 = smem16 + C::W_U16 + C::NXB * C::X_U16 + 64 + 8 * 2 * COUT * 2 + CIN;  // target of idle threads' LDS writes
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -276,16 +277,16 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   // the matrix loop of the tile before (the even k-steps; the deferred epilogue has the odd ones), each item followed by the
   // load that refills its registers with the tile after.
   auto stage_item = [&](int it, float sc, unsigned short* xb) {
-    if ((int)threadIdx.x + it * 512 < C::NITEMS) {
-      const float4 v = pre[it];
-      unsigned a1, a2, b1, b2;
-      f2_split_pair_scaled(v.x, v.y, sc, a1, a2);
-      f2_split_pair_scaled(v.z, v.w, sc, b1, b2);
-      const int idx = (int)threadIdx.x + it * 512;
-      unsigned short* p = xb + (idx / CV) * PS + (idx % CV) * 4;
-      *(uint2*)(p) = make_uint2(a1, b1);
-      *(uint2*)(p + CIN) = make_uint2(a2, b2);
-    }
+    const float4 v = pre[it];
+    unsigned a1, a2, b1, b2;
+    f2_split_pair_scaled(v.x, v.y, sc, a1, a2);
+    f2_split_pair_scaled(v.z, v.w, sc, b1, b2);
+    const int idx = (int)threadIdx.x + it * 512;
+    unsigned short* p = xb + (idx / CV) * PS + (idx % CV) * 4;
+    // (the last round is partial: its idle threads write a pad - a select instead of a branch, the tap loop stays one basic block)
+    if ((it + 1) * 512 > C::NITEMS) p = idx < C::NITEMS ? p : pad16 - CIN;
+    *(uint2*)(p) = make_uint2(a1, b1);
+    *(uint2*)(p + CIN) = make_uint2(a2, b2);
   };
 
   int tile = t_lo + rank;
