@@ -696,6 +696,12 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   }
   stats_sample();
   ab_sample();
+  // A flush above (the last tile belongs to another sample than the sums so far) and the final flush below must not overlap: the
+  // flushes are barrier-free - LDS slots, an arrival counter that the last wave clears - and inside the loop the tile barrier
+  // separates two of them.  Without this barrier a fast wave's second flush rewrote its slot and bumped the counter while the
+  // last wave of the first was still adding the slots up: sums of the wrong sample, and a final count that never completes
+  // (seen only when wave timing shifts, e.g. two processes sharing the GPU: scripts/diag/share_gnin.py).
+  if (STATS || EPIAB) __syncthreads();
   t1 = 0.f;
   t2 = 0.f;
 #pragma unroll

@@ -4,6 +4,7 @@ Each Function allocates outputs/workspaces with torch (the caller owns all memor
 kernels on the current stream through `lib.call`, and wires the hand-written backward kernels.
 No ATen compute op is used for the arithmetic of the step; torch is memory + autograd tape only.
 """
+import os as _os_env
 import torch
 from . import lib
 
@@ -33,7 +34,7 @@ def _c(t):
 # A slice is handed out at most once between two clears; without begin_step (tests, inference) the arena simply runs
 # out and plain torch.zeros takes over.
 _ARENA = {}
-_ARENA_DOUBLES = 1 << 23   # 64 MiB: the per-workgroup channel-sum slots of the GroupNorm backward are 2 MiB per launch, ~30 per step
+_ARENA_DOUBLES = int(_os_env.environ.get('DIS_ARENA_DOUBLES', 1 << 23))   # 64 MiB: the per-workgroup channel-sum slots of the GroupNorm backward are 2 MiB per launch, ~30 per step
 
 
 # gradient tensors whose producer already left the GroupNorm-backward sums (see _Conv2d.backward / _GroupNorm.backward):
@@ -656,7 +657,7 @@ class _Conv2d(torch.autograd.Function):
             second = join is not None and join.buf is not None
             gx = join.take(x.shape) if second else torch.empty_like(x)
             gnres = ctx.gnres
-            if (fuse_act and gnres is not None and join is None and act == ACT_SELU and GN_SUMS and (cout, cin) == (16, 32) and
+            if (fuse_act and gnres is not None and join is None and act == ACT_SELU and (GN_SUMS & 1) and (cout, cin) == (16, 32) and
                     tuple(gnres[0].shape) == tuple(x.shape) and lib.fn('dis_get_conv_split')() == 1):
                 # (final_conv: x = SELU(GroupNorm(.) + res) of ref_res3 and this conv is its only consumer - as below)
                 slots = lib.fn('dis_conv2d_gnsums_slots')()
@@ -667,7 +668,7 @@ class _Conv2d(torch.autograd.Function):
             elif fuse_act:
                 lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, weight, cout, cin, weight.stride(0), gx, n, gy.shape[1],
                          gy.shape[2], cout, cin, k - 1 - pad, 1 if second else 0)
-            elif (gnres is not None and second and GN_SUMS and _bx_shape(cin_pad, cout, k, stride) and cin == cout and
+            elif (gnres is not None and second and (GN_SUMS & 2) and _bx_shape(cin_pad, cout, k, stride) and cin == cout and
                   tuple(gnres[0].shape) == tuple(x.shape) and lib.fn('dis_get_conv_split')() == 1 and gpre is gy):
                 # x is out = SELU(GroupNorm(x2) + res) of the previous ResNetBlock, and gx - which arrives holding this block's
                 # residual-branch gradient - becomes the complete gradient wrt out here.  The epilogue turns it into the gradient
@@ -713,7 +714,9 @@ def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, nee
 
 
 GN_FUSE = _os.environ.get('DIS_GN_FUSE', '1') != '0'
-GN_SUMS = _os.environ.get('DIS_GN_SUMS', '1') != '0'   # GroupNorm backward from the sums of the input-gradient epilogue
+# GroupNorm backward from the sums of the input-gradient epilogue.  DIS_GN_SUMS=0 disables it; as a bit mask (diagnostics) it selects
+# the forms: 1 final_conv (activation + residual), 2 residual / two-consumer, 4 GroupNorm-on-load pairs, 8 conv_fuse's first slice
+GN_SUMS = int(_os.environ.get('DIS_GN_SUMS', '15'))
 
 
 def gn_fusable(cin, cout, k, stride):
@@ -770,7 +773,7 @@ class _Conv2dGnIn(torch.autograd.Function):
         gg, gg_ret = _sink(gamma)
         gbt, gbt_ret = _sink(ctx.beta_ref)
         hw = h * w
-        if GN_SUMS and lib.fn('dis_get_conv_split')() == 1:
+        if (GN_SUMS & 4) and lib.fn('dis_get_conv_split')() == 1:
             # the input-gradient launch leaves the per-(sample, channel) sums of g and g * x in its epilogue: the GroupNorm
             # backward is then ONE elementwise pass (no reduce pass over g and x)
             slots = lib.fn('dis_conv2d_gnsums_slots')()
@@ -880,7 +883,7 @@ class _Conv2dMulti(torch.autograd.Function):
                     gnorm = torch.empty_like(x)
                     gg, gg_ret = _sink(gn_gamma)
                     gbt, gbt_ret = _sink(ctx.beta_ref)
-                    if GN_SUMS and lib.fn('dis_get_conv_split')() == 1:
+                    if (GN_SUMS & 4) and lib.fn('dis_get_conv_split')() == 1:
                         slots = lib.fn('dis_conv2d_gnsums_slots')()
                         ab = _zeros_d(n * slots * 2 * cs[0], x.device)
                         lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, wi, cout, cs[0], wi.stride(0), gnorm, x, ab, n,

@@ -434,6 +434,44 @@ def test_conv3d_csr_feature_gradient(golden_dir, stride):
     assert all(np.all(np.diff(ents[offs[d]:offs[d + 1]]) > 0) for d in np.flatnonzero(np.diff(offs) > 1)[:2000])
 
 
+def test_gn_sums_epilogue_repeats_bitwise():
+    """The channel sums an input-gradient launch leaves for the GroupNorm backward (fixed summation orders, no atomics) and what
+    dis_gn_bwd_from_sums makes of them repeat bit for bit - at a shape with few tiles per workgroup, where a workgroup's last
+    tile often belongs to another sample than its sums so far: two barrier-free flushes then follow each other at the end of
+    the kernel, and before the barrier between them was added they raced (wrong / missing sums whenever wave timing shifted;
+    found with two processes sharing the GPU, scripts/diag/share_gnin.py)."""
+    from depthinspace_amd import ops
+    if ops.lib.fn('dis_get_conv_split')() != 1:
+        pytest.skip('channel sums: f16x2 kernels')
+    g = torch.Generator().manual_seed(11)
+    n, h, w, c = 16, 128, 108, 32
+    x = torch.randn(n, h, w, c, generator=g).cuda()
+    wt = (torch.randn(c, c, 3, 3, generator=g) * 0.05).cuda()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.1).cuda()
+    gy = torch.randn(n, h, w, c, generator=g).cuda()
+    st = torch.stack([x.double().sum(dim=(1, 2, 3)), (x.double() ** 2).sum(dim=(1, 2, 3))], 1).reshape(-1).contiguous()
+    slots = ops.lib.fn('dis_conv2d_gnsums_slots')()
+    first = None
+    for rep in range(12):
+        gnorm, gx = torch.empty_like(x), torch.empty_like(x)
+        gg, gb = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+        ab = torch.zeros(n * slots * 2 * c, dtype=torch.float64, device='cuda')
+        ops.lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gy, wt, c, c, wt.stride(0), gnorm, x, ab, n, h, w, c, c, 1)
+        coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device='cuda')
+        ops.lib.call('dis_gn_bwd_from_sums', gnorm, x, st, gamma, ab, slots, gx, gg, gb, coef, n, h * w, c, 1e-5, ops.ACT_SELU)
+        cur = (ab, gx, gg, gb)
+        if first is None:
+            first = tuple(t.clone() for t in cur)
+            # the sums are the sums: against a plain reduction of the kernel's own gradient output
+            ref_a = gnorm.double().sum(dim=(1, 2))
+            ref_b = (gnorm.double() * x.double()).sum(dim=(1, 2))
+            got = ab.view(n, slots, 2, c).sum(dim=1)
+            assert float((got[:, 0] - ref_a).abs().max()) < 1e-6 * float(ref_a.abs().max())
+            assert float((got[:, 1] - ref_b).abs().max()) < 1e-6 * float(ref_b.abs().max())
+        else:
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(cur, first)), rep
+
+
 @pytest.mark.parametrize('stride', [1, 2])
 def test_conv3d_class_ordered_backward(golden_dir, stride):
     """dis_conv3d_knn_bwd_det (the default backward: class-ordered plain read-modify-write, aggregate read back from the forward)
