@@ -747,13 +747,34 @@ __global__ void geo_loss_fwd_kernel(const float* __restrict__ depth0, const floa
     s_diff += (double)(diff * m);
     s_mask += (double)m;
   }
+  // per-block partial sums to the block's slot behind acc[0..1] (summed in a fixed order by geo_finalize_kernel): two same-address
+  // fp64 atomics per block serialise at ~10 ns each, which capped the grid at 512 blocks (8 waves per CU) for a kernel that is
+  // bound by the latency of its dependent gathers - 48 us per launch at 512 blocks with atomics, ~25 us at 1024 blocks with slots
   double r0 = block_sum_d(s_diff, sm);
   double r1 = block_sum_d(s_mask, sm);
   if (threadIdx.x == 0) {
-    atomic_add_d(acc, r0);
-    atomic_add_d(acc + 1, r1);
+    acc[2 + 2 * blockIdx.x] = r0;
+    acc[3 + 2 * blockIdx.x] = r1;
   }
 }
+#define GEO_BLOCKS 1024
+__global__ __launch_bounds__(256) void geo_finalize_kernel(double* __restrict__ acc, float* __restrict__ out, int nblocks,
+                                                           double eps_den) {
+  __shared__ double sm[8];
+  double a = 0.0, b = 0.0;
+  for (int k = threadIdx.x; k < nblocks; k += 256) {
+    a += acc[2 + 2 * k];
+    b += acc[3 + 2 * k];
+  }
+  a = block_sum_d(a, sm);
+  b = block_sum_d(b, sm);
+  if (threadIdx.x == 0) {
+    acc[0] = a;
+    acc[1] = b;
+    out[0] = (float)((float)a / ((float)b + (float)eps_den));
+  }
+}
+extern "C" long dis_geo_loss_acc_doubles(void) { return 2 + 2 * GEO_BLOCKS; }
 
 __global__ void geo_loss_bwd_kernel(const float* __restrict__ depth0, const float* __restrict__ depth1,
                                     const float* __restrict__ flow0, const float* __restrict__ R0,
@@ -816,9 +837,11 @@ extern "C" int dis_geo_loss_fwd(const float* depth0, const float* depth1, const 
   GeoCam cam;
   fill_cam(cam, K_host, Kinv_host);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(geo_loss_fwd_kernel, dim3(dis_red_grid((long)bs * h * w, 256)), dim3(256), 0, s, depth0, depth1,
+  long gl = ((long)bs * h * w + 255) / 256;
+  const int grid = (int)(gl > GEO_BLOCKS ? GEO_BLOCKS : gl);
+  hipLaunchKernelGGL(geo_loss_fwd_kernel, dim3(grid), dim3(256), 0, s, depth0, depth1,
                      flow0, flow1, amb0, amb1, primary_depth1, R0, t0, R1, t1, cam, clampv, mask_out, acc, bs, h, w);
-  hipLaunchKernelGGL(ratio_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)acc, out, 1e-8);
+  hipLaunchKernelGGL(geo_finalize_kernel, dim3(1), dim3(256), 0, s, acc, out, grid, 1e-8);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

@@ -446,7 +446,7 @@ class _GeoLossDir(torch.autograd.Function):
         _chk(depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1)
         bs, _, h, w = depth0.shape
         mask = torch.empty_like(depth0)
-        acc = _zeros_d(2, depth0.device)
+        acc = torch.empty(lib.fn('dis_geo_loss_acc_doubles')(), dtype=torch.float64, device=depth0.device)  # sums + block slots
         out = torch.empty((), dtype=torch.float32, device=depth0.device)
         lib.call('dis_geo_loss_fwd', depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1, K, Kinv,
                  float(clamp), mask, acc, out, bs, h, w)

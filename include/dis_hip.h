@@ -107,8 +107,10 @@ int dis_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* gra
  *   single-frame reference model/networks.py:619-655  (clamp > 0: diff clamped to [0,clamp])
  * depth0, depth1, amb0, amb1, primary_depth1: (bs,1,h,w); flow0, flow1: (bs,2,h,w) pixel units;
  * R0,R1: (bs,3,3); t0,t1: (bs,3) device pointers; K: 9 floats, Kinv: 9 floats (host values, by pointer to host).
- * mask_out: (bs,1,h,w) {0,1} loss mask (saved for backward); acc: 2 zeroed doubles {sum(diff*mask), sum(mask)};
- * out: 1 float = acc0/(acc1+1e-8). */
+ * mask_out: (bs,1,h,w) {0,1} loss mask (saved for backward); acc: dis_geo_loss_acc_doubles() doubles of scratch (no zeroing):
+ * acc[0], acc[1] = {sum(diff*mask), sum(mask)} after the call (dis_geo_loss_bwd reads them), behind them the per-block partial
+ * sums they are formed from in a fixed order; out: 1 float = acc0/(acc1+1e-8). */
+long dis_geo_loss_acc_doubles(void);
 int dis_geo_loss_fwd(const float* depth0, const float* depth1, const float* flow0, const float* flow1,
                      const float* amb0, const float* amb1, const float* primary_depth1, const float* R0,
                      const float* t0, const float* R1, const float* t1, const float* K_host,
