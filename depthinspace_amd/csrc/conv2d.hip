@@ -1471,6 +1471,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   constexpr int NIX = C::IN_ROWS * C::IN_COLS * C::NV, NLX = (NIX + 255) / 256;
   constexpr int NIG = C::TROWS * 16 * (COUT / 4), NLG = (NIG + 255) / 256;
   float4 prex[NLX], preg[NLG];
+  float presc[NLX];
+#pragma unroll
+  for (int it = 0; it < NLX; ++it) presc[it] = 1.f;
   // (loads stay under their bounds branches here: the unconditional/clamped form that helps conv_fwd_kernel made
   //  hipcc park the prefetched values in AGPRs right behind each load in this register-bound kernel: 114 -> 77 TFLOP/s)
   auto prefetch = [&](int tile) {
@@ -1487,10 +1490,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
         const int iy = iy0 + r, ix = ix0 + c;
         if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) {
           v = *(const float4*)(xb + ((long)iy * a.win + ix) * CIN + vv * 4);
-          if (a.xscale) {
-            const float sc = a.xscale[(((long)n * a.hin + iy) * a.win + ix) * C::SG + chunk * (C::CINB / 32) + (vv * 4) / 32];
-            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-          }
+          // (the scale is applied in stage(): multiplying here made every item wait for its two loads in turn - the prefetch
+          //  was not one: 224 us per launch of the 128 -> 32 1x1 weight gradient at 2.5 TB/s)
+          if (a.xscale)
+            presc[it] = a.xscale[(((long)n * a.hin + iy) * a.win + ix) * C::SG + chunk * (C::CINB / 32) + (vv * 4) / 32];
         }
       }
       prex[it] = v;
@@ -1513,7 +1516,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int it = 0; it < NLX; ++it) {
       const int idx = threadIdx.x + it * 256;
-      if (idx < NIX) *(float4*)(xl + (idx / C::NV) * C::CS + (idx % C::NV) * 4) = prex[it];
+      if (idx < NIX) {
+        float4 v = prex[it];
+        if (a.xscale) v.x *= presc[it], v.y *= presc[it], v.z *= presc[it], v.w *= presc[it];
+        *(float4*)(xl + (idx / C::NV) * C::CS + (idx % C::NV) * 4) = v;
+      }
     }
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
