@@ -30,6 +30,14 @@ def run(h, w, stride, reps=10, modes=('atomic', 'agg', 'det', 'det2')):
     y0 = torch.empty_like(y)
     ops.lib.call('dis_conv3d_knn_fwd', *args, y0, tl, bs, h, w, stride)
     assert torch.equal(y, y0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.lib.call('dis_conv3d_knn_fwd_agg', *args, y, agg, tl, bs, h, w, stride)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f'h={h} w={w} stride={stride} forward (+ aggregate kept): {e0.elapsed_time(e1) / reps:.3f} ms per call', flush=True)
     gy = torch.randn(y.shape, device='cuda', generator=g)
     acc = torch.empty(ops.lib.fn('dis_conv3d_knn_bwd_workspace')(), device='cuda')
     accd = torch.empty(ops.lib.fn('dis_conv3d_knn_bwd_det_workspace')(tl, bs, h, w, stride), device='cuda')
