@@ -789,7 +789,6 @@ __global__ __launch_bounds__(256, C3D_WPE) void conv3d_bwd2_kernel(const float4*
   C3S(1)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* X = L.X[wave];
-  float* H = L.H[wave];
   float4* D = L.D[wave];
   int* R = L.R[wave];
 
