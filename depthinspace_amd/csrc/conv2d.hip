@@ -150,6 +150,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   int tile = t_lo + rank;
   if (tile < t_hi) prefetch(tile, 0);
   f32x4 acc[C::MT][C::NT];
+  constexpr bool YS = COUT == 128;   // four 32-channel groups: the multipliers of a pixel are one float4, fetched a matrix loop ahead
+  float4 ysc[C::MT][4];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ysc[mt][r] = make_float4(1.f, 1.f, 1.f, 1.f);
   double s1 = 0.0, s2 = 0.0;
   int stat_n = -1;
   float bias_v[C::NT];
@@ -170,6 +176,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       // issue the next halo tile's loads now; they land while the MFMAs below run
       if (chunk + 1 < C::NCHUNK) prefetch(tile, chunk + 1);
       else if (tile + per < t_hi) prefetch(tile + per, 0);
+      // ... and this tile's output multipliers (loaded in the epilogue, right in front of their use, every tile waited for them)
+      if (YS && a.yscale && chunk == C::NCHUNK - 1) {
+        const int tx_ = tile % tiles_x, ty_ = (tile / tiles_x) % tiles_y, n_ = tile / (tiles_x * tiles_y);
+        const int vy_ = ty_ * C::TROWS + wave * C::MT, vx_ = tx_ * C::TCOLS + lg * 4;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int oy = min(vy_ + mt, a.hv - 1) * a.osy + a.ooy, ox = min(vx_ + r, a.wv - 1) * a.osx + a.oox;
+            ysc[mt][r] = *(const float4*)(a.yscale + (((long)n_ * a.hf + oy) * a.wf + ox) * 4);
+          }
+      }
 
       // software-pipelined fragment reads: the LDS reads of step s+1 are issued before the MFMAs of step s
       constexpr int NS = KH * KW * C::NQ;
@@ -245,10 +263,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int oy = min(vy0 + mt, a.hv - 1) * a.osy + a.ooy, ox = min(vx0 + r, a.wv - 1) * a.osx + a.oox;
-          const float* sp = a.yscale + (((long)n * a.hf + oy) * a.wf + ox) * NG;
+          if (YS) {
+            const float sv[4] = {ysc[mt][r].x, ysc[mt][r].y, ysc[mt][r].z, ysc[mt][r].w};
 #pragma unroll
-          for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt][r] *= sp[nt >> 1];
+            for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt][r] *= sv[(nt >> 1) & 3];
+          } else {
+            const int oy = min(vy0 + mt, a.hv - 1) * a.osy + a.ooy, ox = min(vx0 + r, a.wv - 1) * a.osx + a.oox;
+            const float* sp = a.yscale + (((long)n * a.hf + oy) * a.wf + ox) * NG;
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt][r] *= sp[nt >> 1];
+          }
         }
     }
     auto emit = [&](auto actc, auto accc) {
