@@ -1654,6 +1654,17 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
       const float* p = part + ((long)chunk * nsplit + split) * partsz + (long)m * cout + co;
       const int lo = (int)((long)workers * wv / WG_RW), hi = (int)((long)workers * (wv + 1) / WG_RW);
       int k = lo;
+      // (the wave's whole range - 32 slabs at 512 workers - in flight at once: with 8 per round the launch was four dependent
+      //  memory round trips long, 8.7 us, and there are 56 of these launches in a DIS-MF step)
+      for (; k + 31 < hi; k += 32) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = p[(long)(k + u) * elems];
+#pragma unroll
+        for (int u = 0; u < 32; u += 8)
+          s += (((double)v[u] + (double)v[u + 1]) + ((double)v[u + 2] + (double)v[u + 3])) +
+               (((double)v[u + 4] + (double)v[u + 5]) + ((double)v[u + 6] + (double)v[u + 7]));
+      }
       for (; k + 7 < hi; k += 8) {
         float v[8];
 #pragma unroll
@@ -1684,9 +1695,21 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     __syncthreads();
     red[threadIdx.x] = s;
     __syncthreads();
+    // (two levels, fixed order: 128 threads add 8 sub-sums each, then 8 threads add 16 - a single 128-term loop in 8 threads was
+    //  ~6 us of dependent LDS reads at the end of every launch with a bias)
+    double t8 = 0.0;
+    if (threadIdx.x < 128) {
+      const int c = threadIdx.x & 7, g = threadIdx.x >> 3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t8 += red[(g * 8 + j) * 8 + c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) red[threadIdx.x] = t8;
+    __syncthreads();
     if (threadIdx.x < 8) {
       double t = 0.0;
-      for (int k = 0; k < 128; ++k) t += red[k * 8 + threadIdx.x];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g * 8 + threadIdx.x];
       gb[co] = (float)t;
     }
   }
