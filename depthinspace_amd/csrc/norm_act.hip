@@ -449,31 +449,35 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
 // ------------------------------------------------------------------------------------------------
 // grid n: block b writes coef[b][0..c) = k1_c, coef[b][c] = kx, coef[b][c + 1] = k0 and the sample's dgamma_c / dbeta_c (fp64) behind
 // the coefficients of all samples (pg); the apply kernel's first block adds those over the samples.  Fixed orders: deterministic.
-__global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__ ab, int slots, const double* __restrict__ stats,
-                                                      const float* __restrict__ gamma, float* __restrict__ coef,
-                                                      double* __restrict__ pg, long hw, int c, float eps) {
-  __shared__ double sA[GN_MAXC], sB[GN_MAXC], part[256];
+#define GN_COEF_T 1024
+__global__ __launch_bounds__(GN_COEF_T) void gn_coef_kernel(const double* __restrict__ ab, int slots, const double* __restrict__ stats,
+                                                            const float* __restrict__ gamma, float* __restrict__ coef,
+                                                            double* __restrict__ pg, long hw, int c, float eps) {
+  __shared__ double sA[GN_MAXC], sB[GN_MAXC], part[GN_COEF_T];
   const int b = blockIdx.x, t = threadIdx.x;
   const double m = (double)hw * c;
-  {  // A_c, B_c of this sample: 4 threads per value, each a quarter of the slots, 8 loads in flight
+  {  // A_c, B_c of this sample: 16 threads per value, each a sixteenth of the slots with all of its loads in flight (256 slots:
+     // one round; with 4 threads per value and 8 loads per round the launch was eight dependent round trips, 9 us, 30 per step)
     const int j = t & 63, q = t >> 6;  // (2 c <= 64 values)
     double v = 0.0;
     if (j < 2 * c) {
       const double* p = ab + (long)b * slots * (2 * c) + j;
       int s_ = q;
-      for (; s_ + 28 < slots; s_ += 32) {
-        double u[8];
+      for (; s_ + 15 * 16 < slots; s_ += 256) {
+        double u[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) u[k] = p[(long)(s_ + 4 * k) * (2 * c)];
+        for (int k = 0; k < 16; ++k) u[k] = p[(long)(s_ + 16 * k) * (2 * c)];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v += u[k];
+        for (int k = 0; k < 16; ++k) v += u[k];
       }
-      for (; s_ < slots; s_ += 4) v += p[(long)s_ * (2 * c)];
+      for (; s_ < slots; s_ += 16) v += p[(long)s_ * (2 * c)];
     }
     part[t] = v;
     __syncthreads();
     if (t < 2 * c) {
-      const double tot = (part[t] + part[t + 64]) + (part[t + 128] + part[t + 192]);
+      double tot = 0.0;
+#pragma unroll
+      for (int q2 = 0; q2 < 16; ++q2) tot += part[t + 64 * q2];
       if (t < c) sA[t] = tot;
       else sB[t - c] = tot;
     }
@@ -486,16 +490,20 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__
     pg[(long)b * 2 * c + t] = (double)rstd * (sB[t] - (double)mean * sA[t]);
     pg[(long)b * 2 * c + c + t] = sA[t];
   }
-  if (t == 0) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < c; ++k) {
-      const double dg = (double)rstd * (sB[k] - (double)mean * sA[k]);
-      s1 += (double)gamma[k] * sA[k];
-      s2 += (double)gamma[k] * dg;
+  if (t < 64) {   // (c <= 64: one wave, fixed-order DPP sums instead of a serial loop over the channels in one thread)
+    double p1 = 0.0, p2 = 0.0;
+    if (t < c) {
+      const double gk = (double)gamma[t];
+      const double dg = (double)rstd * (sB[t] - (double)mean * sA[t]);
+      p1 = gk * sA[t];
+      p2 = gk * dg;
     }
+    const double s1 = wave_sum_d(p1), s2 = wave_sum_d(p2);
     const float a1 = (float)(s1 / m), a2 = (float)(s2 / m);
-    coef[(long)b * (c + 2) + c] = -(rstd * rstd) * a2;
-    coef[(long)b * (c + 2) + c + 1] = (rstd * rstd) * a2 * mean - rstd * a1;
+    if (t == 0) {
+      coef[(long)b * (c + 2) + c] = -(rstd * rstd) * a2;
+      coef[(long)b * (c + 2) + c + 1] = (rstd * rstd) * a2 * mean - rstd * a1;
+    }
   }
 }
 __global__ void gn_apply_coef_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ coef,
@@ -545,7 +553,7 @@ extern "C" int dis_gn_bwd_from_sums(const float* g, const float* x, const double
   if (c % 4 != 0 || 2 * c > 64) return DIS_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   double* pg = (double*)(((uintptr_t)(coef + (long)n * (c + 2)) + 7) & ~(uintptr_t)7);
-  hipLaunchKernelGGL(gn_coef_kernel, dim3(n), dim3(256), 0, s, ab, slots, stats, gamma, coef, pg, hw, c, eps);
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(n), dim3(GN_COEF_T), 0, s, ab, slots, stats, gamma, coef, pg, hw, c, eps);
   int gxg = dis_ew_grid(hw * (c / 4), 256);
   if (gxg > 512) gxg = 512;
   hipLaunchKernelGGL(gn_apply_coef_kernel, dim3(gxg, n), dim3(256), 0, s, g, x, (const float*)coef, gx, hw, c, in_act,
