@@ -1,6 +1,19 @@
 // Fused Adam over a flat fp32 parameter buffer (torch.optim.Adam defaults, reference train_val.py:55-56).
 #include "common.h"
 
+const char* g_dis_last_kernel = nullptr;
+// diagnostics: kernel family of the most recent conv dispatch of this process ("" if none since the last clear)
+extern "C" int dis_last_kernel(char* name, int cap, int clear) {
+  if (!name) return DIS_ERR_NULL;
+  if (cap <= 0) return DIS_ERR_BAD_SHAPE;
+  const char* r = g_dis_last_kernel ? g_dis_last_kernel : "";
+  int i = 0;
+  for (; i < cap - 1 && r[i]; ++i) name[i] = r[i];
+  name[i] = 0;
+  if (clear) g_dis_last_kernel = nullptr;
+  return DIS_OK;
+}
+
 // omb1 / omb2 = (1 - beta) evaluated in double precision on the host and rounded once, as torch.optim.Adam's python floats
 // are (1.f - 0.999f in fp32 is off by 1.3e-5 relative).
 __global__ void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,

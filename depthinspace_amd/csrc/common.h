@@ -12,6 +12,11 @@
     if (e__ != hipSuccess) return (int)e__;      \
   } while (0)
 
+// Diagnostics only (bench.py's per-call timing labels a call by the kernel family that served it): the conv dispatchers leave
+// the name of the kernel template they launched here; dis_last_kernel() hands it out.  Never read by any compute path.
+extern const char* g_dis_last_kernel;
+#define DIS_TAG(name) (g_dis_last_kernel = (name))
+
 static inline int dis_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // grid size for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8, never more than needed
 static inline int dis_ew_grid(long work_items, int block) {

@@ -424,6 +424,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
   if (grid > ntiles) grid = ntiles;
   if (grid >= 8) grid -= grid % 8;
   if (grid < 1) grid = 1;
+  DIS_TAG("conv_fwd_kernel (fp32 MFMA)");
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, s, a);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
@@ -1096,6 +1097,7 @@ static hipError_t bx_launch(const ConvArgs& a, bool stats, int inact, long grid,
       if (e != hipSuccess) return e;
       set = true;
     }
+    DIS_TAG(CIN == 32 && COUT == 32 ? "conv_bf16x3_kernel<32,32>" : CIN == 16 && COUT == 16 ? "conv_bf16x3_kernel<16,16>" : CIN == 16 ? "conv_bf16x3_kernel<16,32>" : "conv_bf16x3_kernel<32,16>");
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
     return hipSuccess;
   };
@@ -1398,6 +1400,7 @@ int dis_bx_slices_run(int dgrad, const float* x, int ldx, int xoff, int cin, int
           if (e != hipSuccess) return e;
           attr_set[slot] = true;
         }
+        DIS_TAG("conv_bf16x3_kernel<32,32,GEN> slices");
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, a);
         return hipSuccess;
       };
@@ -1748,6 +1751,7 @@ static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_
   const long elems = (long)C::NCHUNK * C::NSPLIT * C::PART;
   float* tmp = a.part + (long)WG_WORKERS * elems;
   a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
+  DIS_TAG("conv_wgrad_kernel (fp32 MFMA)");
   hipLaunchKernelGGL(kern, dim3((unsigned)workers, C::NCHUNK, C::NSPLIT), dim3(256), C::LDS_BYTES, s, a);
   const long total = (long)C::NCHUNK * C::NSPLIT * C::MROWS * COUT;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(64 * WG_RW), 0, s,
@@ -2093,6 +2097,7 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
   // two-term fp16 split (conv_f16x2.hip; same slab layout), else the three-term kernel
   hipError_t le = dis_f2_enabled() ? dis_f2_wgrad_launch(a, CIN, COUT, INACT, workers, s) : hipErrorInvalidValue;
   if (le != hipSuccess && le != hipErrorInvalidValue) return (int)le;
+  if (le != hipSuccess) DIS_TAG(CIN == 32 && COUT == 32 ? "conv_wgrad_bf16x3_kernel<32,32>" : "conv_wgrad_bf16x3_kernel<16|32,16|32>");
   if (le != hipSuccess)
     hipLaunchKernelGGL((conv_wgrad_bf16x3_kernel<CIN, COUT, INACT, false, 3, 1, 8, 3, false, INGN>), dim3((unsigned)workers),
                        dim3(256), X::LDS_BYTES, s, a);
@@ -2176,6 +2181,7 @@ static int wgrad_pairs_launch(WgArgs a, float* grad_w, int cX_w, int cG_w, int n
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  DIS_TAG(BF ? "conv_wgrad_bf16x3_kernel<BF> slice pairs" : "conv_wgrad_bf16x3_kernel slice pairs");
   hipLaunchKernelGGL(kern, dim3((unsigned)wpp, (unsigned)(a.npx * ngb), NGRP), dim3(256), XC::LDS_BYTES, s, a);
   const long total = (long)NGRP * a.npx * ngb * KH * K * 32 * COB;
   hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)a.part,

@@ -710,6 +710,7 @@ static int cb_bn(int cout) { return cout > 32 ? 64 : (cout > 16 ? 32 : 16); }
 
 template <bool XB, bool YB>
 static void cb_launch(const GenArgsB& a, int bn, long grid, hipStream_t s) {
+  DIS_TAG("convb_fwd_kernel (bf16 streaming)");
   if (bn == 64) hipLaunchKernelGGL((convb_fwd_kernel<64, XB, YB>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else if (bn == 32) hipLaunchKernelGGL((convb_fwd_kernel<32, XB, YB>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((convb_fwd_kernel<16, XB, YB>), dim3((unsigned)grid), dim3(256), 0, s, a);
@@ -776,6 +777,7 @@ static int cbh_launch3(const GenArgsB& a, long grid, long lds, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
+  DIS_TAG("convb_halo_kernel (bf16 LDS halo)");
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, s, a);
   return DIS_OK;
 }
@@ -848,6 +850,7 @@ static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t
   if (grid > 2147483647L) return DIS_ERR_BAD_SHAPE;
   static const bool no128 = getenv("DIS_CONVB_128") && getenv("DIS_CONVB_128")[0] == '0';
   if (x_bf16 && a.cin >= 128 && bn >= 32 && !no128) {  // deep layers: 128-channel stages
+    DIS_TAG("convb_fwd128_kernel (bf16 streaming, 128-channel stages)");
     if (bn == 64 && y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<64, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
     else if (bn == 64) hipLaunchKernelGGL((convb_fwd128_kernel<64, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
     else if (y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<32, true>), dim3((unsigned)grid), dim3(256), 0, s, a);

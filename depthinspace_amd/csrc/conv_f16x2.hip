@@ -729,6 +729,7 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
       if (e != hipSuccess) return e;
       attr_set[slot] = true;
     }
+    DIS_TAG(CIN == 32 && COUT == 32 ? "conv_f16x2_kernel<32,32>" : CIN == 16 && COUT == 16 ? "conv_f16x2_kernel<16,16>" : CIN == 16 ? "conv_f16x2_kernel<16,32>" : "conv_f16x2_kernel<32,16>");
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
     return hipSuccess;
   };
@@ -1116,6 +1117,7 @@ static hipError_t f2_wgrad_launch(const WgArgs& a, int inact, long workers, hipS
       if (e != hipSuccess) return e;
       attr_set[slot] = true;
     }
+    DIS_TAG(CIN == 32 && COUT == 32 ? "conv_wgrad_f16x2_kernel<32,32>" : CIN == 16 && COUT == 16 ? "conv_wgrad_f16x2_kernel<16,16>" : CIN == 16 ? "conv_wgrad_f16x2_kernel<16,32>" : "conv_wgrad_f16x2_kernel<32,16>");
     hipLaunchKernelGGL(kern, dim3((unsigned)workers), dim3(256), C::LDS_BYTES, stream, a);
     return hipSuccess;
   };

@@ -436,6 +436,7 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
     const long M3 = (long)a.n * a.hv * a.wv;
     const long grid3 = ((M3 + CG_BM - 1) / CG_BM) * a.nblk;
     if (grid3 > 2147483647L) return DIS_ERR_BAD_SHAPE;
+    DIS_TAG("convg3_fwd_kernel (bf16x3 streaming)");
     if (bn == 64) hipLaunchKernelGGL(convg3_fwd_kernel<64>, dim3((unsigned)grid3), dim3(256), 0, s, a);
     else if (bn == 32) hipLaunchKernelGGL(convg3_fwd_kernel<32>, dim3((unsigned)grid3), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(convg3_fwd_kernel<16>, dim3((unsigned)grid3), dim3(256), 0, s, a);
@@ -457,6 +458,7 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
   const long M = (long)a.n * a.hv * a.wv;
   const long grid = ((M + CG_BM - 1) / CG_BM) * a.nblk;
   if (grid > 2147483647L) return DIS_ERR_BAD_SHAPE;
+  DIS_TAG("convg_fwd_kernel (fp32 MFMA streaming)");
   if (bn == 64) hipLaunchKernelGGL(convg_fwd_kernel<64>, dim3((unsigned)grid), dim3(256), 0, s, a);
   else if (bn == 32) hipLaunchKernelGGL(convg_fwd_kernel<32>, dim3((unsigned)grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(convg_fwd_kernel<16>, dim3((unsigned)grid), dim3(256), 0, s, a);
@@ -779,6 +781,7 @@ extern "C" int dis_convg_wgrad(const float* X, int ldX, int xoff, int hX, int wX
   a.cXp = a.nxb * 32 * mtw;
   a.cGp = a.ngb * 32 * ntw;
   const dim3 grid((unsigned)(k * k * a.nxb * a.ngb), (unsigned)nsplit);
+  DIS_TAG("convg_wgrad_kernel (fp32 MFMA streaming)");
   if (mtw == 2 && ntw == 2) hipLaunchKernelGGL((convg_wgrad_kernel<2, 2>), grid, dim3(256), 0, s, a);
   else if (mtw == 2) hipLaunchKernelGGL((convg_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, a);
   else if (ntw == 2) hipLaunchKernelGGL((convg_wgrad_kernel<1, 2>), grid, dim3(256), 0, s, a);

@@ -58,6 +58,7 @@ SIGS = {
     'dis_conv2d_wgrad_bf16x3_act': 'pppipppiiiiiiiiip',
     'dis_set_conv_split': 'i',
     'dis_get_conv_split': '',
+    'dis_last_kernel': 'pii',
     'dis_conv2d_fwd_bf16x3_gn': 'ppppfpiiipppiiiiiiiiip',
     'dis_conv2d_gnsums_slots': '',
     'dis_conv2d_dgrad_bf16x3_gnsums': 'ppiiipppiiiiiip',
@@ -172,19 +173,23 @@ _ERR = {-1: 'bad shape', -2: 'unsupported configuration', -3: 'null pointer'}
 
 # optional per-call HIP-event timing (bench.py roofline leg): list of (name, int-args, start_event, end_event)
 _profile = None
+_tagbuf = ctypes.create_string_buffer(96)
 
 
 def profile_start():
     global _profile
     _profile = []
+    fn('dis_last_kernel')(ctypes.cast(_tagbuf, ctypes.c_void_p), len(_tagbuf), 1)
 
 
 def profile_stop():
-    """-> list of (name, int_args_tuple, milliseconds); synchronises the device."""
+    """-> list of (name, int_args_tuple, milliseconds, kernel_tag, n_tensor_args); synchronises the device.  kernel_tag: the
+    kernel family the conv dispatchers report through dis_last_kernel ('' for the other entry points); n_tensor_args: how many
+    of the call's pointer arguments were not NULL (optional operands change a launch's algorithmic bytes)."""
     global _profile
     rec, _profile = _profile, None
     torch.cuda.synchronize()
-    return [(n, a, e0.elapsed_time(e1)) for (n, a, e0, e1) in rec]
+    return [(n, a, e0.elapsed_time(e1), t, k) for (n, a, e0, e1, t, k) in rec]
 
 
 def call(name, *args):
@@ -209,7 +214,12 @@ def call(name, *args):
         e0.record()
         rc = f(*conv)
         e1.record()
-        _profile.append((name, tuple(a for a in args if isinstance(a, int)), e0, e1))
+        # the kernel family that served the call (conv dispatchers only): `*_bf16x3*` entry points run the two-term fp16 kernels
+        # by default, and bench.py selects / labels launches by what actually ran
+        fn('dis_last_kernel')(ctypes.cast(_tagbuf, ctypes.c_void_p), len(_tagbuf), 1)
+        tag = _tagbuf.value.decode()
+        _profile.append((name, tuple(a for a in args if isinstance(a, int)), e0, e1, tag,
+                         sum(1 for a in args if isinstance(a, torch.Tensor))))
     else:
         rc = f(*conv)
     if rc != 0:

@@ -13,8 +13,13 @@
  * Conventions
  *  - plain C symbols, raw DEVICE pointers, sizes as int, no torch types.
  *  - the caller owns every buffer (inputs, outputs, workspaces); the library never allocates,
- *    frees or synchronises, and keeps no state.  All calls are asynchronous on `stream`
- *    (a hipStream_t passed as void*), graph-capturable and re-entrant.
+ *    frees or synchronises.  All calls are asynchronous on `stream` (a hipStream_t passed as
+ *    void*) and graph-capturable.  Process-wide state is limited to: (1) the operand split of the
+ *    `*_bf16x3*` entry points (dis_set_conv_split / DIS_CONV_SPLIT: the entry points keep their
+ *    round-1 names, the arithmetic they run is two-term fp16 by default, three-term bf16 on request
+ *    - dis_get_conv_split() tells which); (2) one-time hipFuncSetAttribute flags per kernel;
+ *    (3) the diagnostic tag of dis_last_kernel().  None of it is per-call data: calls from several
+ *    host threads on different streams are safe as long as no thread changes the split meanwhile.
  *  - return value: 0 on success, DIS_ERR_* (<0) on a rejected argument, or the positive hipError_t
  *    of a failed launch.  Nothing throws across the boundary.
  *  - "planar" tensors are (N,C,H,W) contiguous fp32 (the reference layout, used for the 1-3 channel
@@ -267,6 +272,12 @@ int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, float* grad
  * DIS_CONV_SPLIT=bf16x3 | f16x2 sets the initial value.  Same arguments, layouts and workspaces either way. */
 int dis_set_conv_split(int mode);
 int dis_get_conv_split(void);
+/* Diagnostics: writes the name of the kernel template family the most recent convolution entry point of this process launched
+ * ("conv_f16x2_kernel<32,32>", "conv_bf16x3_kernel<32,32>", "conv_fwd_kernel (fp32 MFMA)", ...; "" if none since the last call
+ * with clear != 0) into the HOST buffer `name` of `cap` bytes, NUL-terminated.  bench.py labels its per-call HIP-event times
+ * with it, so that a `*_bf16x3*` call served by the two-term fp16 kernel is reported as such.  Not thread-safe, never read by a
+ * compute path. */
+int dis_last_kernel(char* name, int cap, int clear);
 /* GroupNorm applied ON LOAD by the consuming convolution (round 3).  The reference chains Conv2d -> SELU -> GroupNorm(1, C) ->
  * Conv2d (ResNetBlock model/multi_frame_networks.py:514-542; Block2D3D conv1_1 -> conv1_2, conv2_1 -> conv2_2 :338-345) and
  * writes the normalised tensor between them; here x is the PRE-normalisation tensor and the consumer stages

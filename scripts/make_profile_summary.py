@@ -80,13 +80,21 @@ def main(tag):
         fam = [m for k, m in mem.items() if DOMINANT in k]
         if fam:
             break
+    # whole-step HBM traffic of the PMC passes: sum over ALL kernels of (2 x FETCH_SIZE + WRITE_SIZE) x calls, per step (the
+    # once-per-step Adam counter kernel counts the steps of the PMC run)
+    adv_m = [m for k, m in mem.items() if k.startswith('adam_advance_kernel')]
+    pmc_steps = int(adv_m[0]['Calls']) if adv_m else 4
+    step_bytes = sum((float(m['FETCH_SIZE']) * 2 + float(m['WRITE_SIZE'])) * 1024 * int(m['Calls']) for m in mem.values()
+                     if m['FETCH_SIZE'] not in ('', 'nan') and m['WRITE_SIZE'] not in ('', 'nan')) / pmc_steps
+    step_us = sum(float(m['AvgUs']) * int(m['Calls']) for m in mem.values()) / pmc_steps
     if fam:
         calls = sum(int(m['Calls']) for m in fam)
         rd = sum(float(m['FETCH_SIZE']) * 2 * 1024 * int(m['Calls']) for m in fam) / calls
         wr = sum(float(m['WRITE_SIZE']) * 1024 * int(m['Calls']) for m in fam) / calls
         json.dump({'kernel': DOMINANT + ' ACT, ACCUM, STATS, ...> (all instances, launch-weighted)',
                    'hbm_bytes_per_launch': rd + wr, 'read_bytes': rd, 'write_bytes': wr,
-                   'launches_averaged': calls,
+                   'launches_averaged': calls, 'launches_per_step': calls / pmc_steps,
+                   'step_hbm_bytes': step_bytes, 'step_kernel_ms_under_pmc': step_us / 1e3, 'pmc_steps': pmc_steps,
                    'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over one eager step; '
                              'FETCH_SIZE (KB) doubled (gfx950 counts 64 B per 128-B request), WRITE_SIZE (KB) as read',
                    'source': f'profiles/{tag}_pmc_mem.csv'}, open(os.path.join(dst, 'roofline_traffic.json'), 'w'), indent=1)

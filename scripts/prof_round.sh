@@ -7,11 +7,11 @@ OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /root/repo
 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-python bench.py --arch single_frame --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_sf.json 2> $OUT/bench_sf.err
-python bench.py --arch single_frame --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_sf_bf16.json 2> $OUT/bench_sf_bf16.err
+python bench.py --arch single_frame --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs > $OUT/bench_sf.json 2> $OUT/bench_sf.err
+python bench.py --arch single_frame --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs > $OUT/bench_sf_bf16.json 2> $OUT/bench_sf_bf16.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o run -- python3 /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/bench_prof.err
-ARGS="/root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o run -- python3 /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs > $OUT/bench_prof.json 2> $OUT/bench_prof.err
+ARGS="/root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-extra-legs"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/sq -o sq \
   --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES \
   -- python3 $ARGS > $OUT/sq.json 2> $OUT/sq.err

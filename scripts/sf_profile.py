@@ -22,7 +22,8 @@ lib.profile_start()
 worker.train_step(net, opt, batch)
 rec = lib.profile_stop()
 agg = {}
-for name, ia, ms in rec:
+for name, ia, ms, tag, _ in rec:
+    name = name + ("@" + tag if tag else "")
     k = (name, ia)
     agg.setdefault(k, [0, 0.0]); agg[k][0] += 1; agg[k][1] += ms
 tot = sum(v[1] for v in agg.values())
