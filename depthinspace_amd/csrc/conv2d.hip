@@ -702,7 +702,7 @@ __global__ __launch_bounds__(512) void conv_bf16x3_kernel(ConvArgs a) {
     if (INGN && n_cur != gn_n) {  // (block-uniform) a new sample: its scale / shift
       gn_n = n_cur;
       float mean, rstd;
-      gn_moments(a.gn_stats, n_cur, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
+      gn_moments(a.gn_stats, n_cur < a.n ? n_cur : a.n - 1, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
       gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
       gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
     }
@@ -1924,7 +1924,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16x3_kernel(WgArgs a) {
     if (INGN && st_n != gn_n) {  // (block-uniform) a new sample
       gn_n = st_n;
       float mean, rstd;
-      gn_moments(a.gn_stats, st_n, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
+      gn_moments(a.gn_stats, st_n < a.n ? st_n : a.n - 1, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
       gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
       gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
     }

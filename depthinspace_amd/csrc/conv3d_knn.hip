@@ -1111,6 +1111,10 @@ static int c3_bwd2_run(bool det, const float* geom, const float* wf, const float
   int rc = c3_dims(&d, tl, bs, h, wd, stride);
   if (rc != DIS_OK) return rc;
   if ((long)tl * bs * h * wd * C3_TL >= (1L << 31)) return DIS_ERR_BAD_SHAPE;  // (row indices are ints)
+  // wf / grad_wf are addressed through ONE buffer descriptor each, 32-bit byte offsets, and BX_OOB (2 GiB) is the offset that
+  // drops a lane: past 2 GiB the drop offset would land INSIDE the tensor (padded candidates would load real rows and, in the
+  // class-ordered form, store into one).  Same bound as the conv launchers; the caller's alternative is dis_conv3d_knn_bwd.
+  if ((long)tl * bs * h * wd * C3_TL * C3_C * 4L >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   C3Params P{dense1_w, dense1_b, dense2_w, dense2_b, w};
   int grids[9], tot;

@@ -230,7 +230,8 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     if (INGN && n_cur != gn_n) {
       gn_n = n_cur;
       float mean, rstd;
-      gn_moments(a.gn_stats, n_cur, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
+      // (after a workgroup's last tile the look-ahead sample index can pass the batch: its values are never used, the read is clamped)
+      gn_moments(a.gn_stats, n_cur < a.n ? n_cur : a.n - 1, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
       gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
       gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
     }
@@ -393,8 +394,10 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     if (lane == 63) {
       __hip_atomic_fetch_add(red, r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_fetch_add(red + 1, r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const unsigned arrived = __hip_atomic_fetch_add((unsigned*)(red + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (arrived == 7u) {  // (LDS operations of a wave complete in order: the other waves' sums are in)
+      // acq_rel at workgroup scope: this wave's two sums are ordered before its count, and the wave that completes the count sees
+      // every other wave's (the hardware completes a wave's LDS operations in order; the ordering is spelled out for the compiler)
+      const unsigned arrived = __hip_atomic_fetch_add((unsigned*)(red + 2), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (arrived == 7u) {
         const double q1 = __hip_atomic_load(red, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const double q2 = __hip_atomic_load(red + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         atomic_add_d(a.stats + 2 * stat_n, q1);
@@ -434,9 +437,14 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
         sB[nt][r] = 0.f;
       }
     unsigned arrived = 0;
+    // release: the abw[] slot stores above (plain stores of other lanes of this wave) are ordered before the count; acquire:
+    // the last arriver's slot reads below are ordered after it.  The fences cover the whole wave's accesses, the atomic is
+    // lane 0's.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) arrived = __hip_atomic_fetch_add((unsigned*)(red + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     arrived = __builtin_amdgcn_readfirstlane(arrived);
-    if (arrived == 7u) {  // (a wave's LDS operations complete in order: the other waves' slots are written)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (arrived == 7u) {
       if (lane < 2 * COUT) {
         double t = 0.0;
 #pragma unroll
@@ -916,7 +924,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
     if (INGN && st_n != gn_n) {
       gn_n = st_n;
       float mean, rstd;
-      gn_moments(a.gn_stats, st_n, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
+      gn_moments(a.gn_stats, st_n < a.n ? st_n : a.n - 1, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
       gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
       gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
     }

@@ -883,7 +883,7 @@ class _Conv2dMulti(torch.autograd.Function):
                     gnorm = torch.empty_like(x)
                     gg, gg_ret = _sink(gn_gamma)
                     gbt, gbt_ret = _sink(ctx.beta_ref)
-                    if (GN_SUMS & 4) and lib.fn('dis_get_conv_split')() == 1:
+                    if (GN_SUMS & 8) and lib.fn('dis_get_conv_split')() == 1:
                         slots = lib.fn('dis_conv2d_gnsums_slots')()
                         ab = _zeros_d(n * slots * 2 * cs[0], x.device)
                         lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, wi, cout, cs[0], wi.stride(0), gnorm, x, ab, n,
@@ -1550,6 +1550,11 @@ class _GroupNorm(torch.autograd.Function):
                     gres = ctx.join.take(gres.shape).add_(gres)
             _sinks_written()
             return gx, None, gg_ret, gb_ret, gres, None, None, None, None
+        if pre is not None:
+            # the producer has ALREADY turned gy into the pre-activation gradient and formed its channel sums: the generic
+            # two-pass form below would apply act' a second time.  No networks here reach this; a new caller must not do so silently.
+            raise RuntimeError(f'group_norm backward: channel sums were registered for this gradient but no from-sums form matches '
+                               f'(residual={has_res}, act={act}, in_act={in_act})')
         gres = torch.empty_like(x) if has_res else None
         wtot = lib.fn('dis_gn_bwd_workspace')(n, c)
         ws = torch.empty(wtot, dtype=torch.float64, device=x.device)

@@ -176,6 +176,9 @@ def run_step_case(ref, arch, size, bs, pseed, bseed, epoch=0, use_pseudo_gt=Fals
         sgm_draws.append(r.detach().clone())
         return r
     torch.randn = _rec_randn
+    # the reference's draw comes from torch's GLOBAL generator (no seed anywhere in its loss): seed it here, per case, so that a
+    # regeneration reproduces the committed fixture bit for bit (the recorded draws travel as inputs either way)
+    torch.manual_seed(1000 + bseed)
     try:
         vals = w.loss_forward(out, True, flow)
     finally:
@@ -474,37 +477,46 @@ def op_goldens(ref):
     return fx, rep
 
 
+CASES = [
+    ('mf_64_bs1', dict(arch='multi_frame', size=(64, 64), bs=1, pseed=11, bseed=1234, epoch=0, full_grads=True)),
+    ('mf_64_bs2_rnd', dict(arch='multi_frame', size=(64, 64), bs=2, pseed=12, bseed=99, epoch=2, random_batch=True,
+                           save_ckpt=True)),
+    ('mf_128_bs1', dict(arch='multi_frame', size=(128, 128), bs=1, pseed=13, bseed=1234, epoch=2)),
+    ('sf_64_bs1', dict(arch='single_frame', size=(64, 64), bs=1, pseed=21, bseed=1234)),
+    ('sf_128_bs1_pgt', dict(arch='single_frame', size=(128, 128), bs=1, pseed=22, bseed=1234, use_pseudo_gt=True)),
+    # crop_like trims here (reference model/networks.py:242-263): W 108 -> 54 -> 27 -> 14 -> 7 -> 4 -> 2 -> 1, so upconv
+    # outputs 28 -> 27 and 8 -> 7 (and 2 -> 1 at the deepest level) are cut exactly as at 512x432
+    ('sf_128x108_bs1', dict(arch='single_frame', size=(128, 108), bs=1, pseed=23, bseed=77)),
+    # non-degenerate scene: non-planar surface, 1.5x camera motion (few exactly tied top-k keys)
+    ('mf_128_bumps', dict(arch='multi_frame', size=(128, 128), bs=1, pseed=14, bseed=4321, epoch=2, scene='bumps',
+                          motion=1.5)),
+    # BASELINE config 5: DIS-FTSF (pseudo-GT) on the real pattern, K_processed, baseline 0.0246
+    ('sf_128_real_pgt', dict(arch='single_frame', size=(128, 128), bs=1, pseed=24, bseed=555, use_pseudo_gt=True,
+                             pattern='real')),
+    # `real` data during the warm-up epochs: the masked-L1 SGM term with the reference's own noise draws recorded
+    # (model/multi_frame_worker.py:168-173: one draw; model/single_frame_worker.py:158-163: one per output scale)
+    ('mf_64_real_sgm', dict(arch='multi_frame', size=(64, 64), bs=1, pseed=15, bseed=808, epoch=2, pattern='real',
+                            real_sgm=True)),
+    ('sf_64_real_sgm', dict(arch='single_frame', size=(64, 64), bs=1, pseed=25, bseed=809, epoch=2, pattern='real',
+                            real_sgm=True)),
+]
+
+
 def main():
+    global GOLD
+    only = sys.argv[1:]
+    if '--out' in only:   # write somewhere else than tests/golden (tests/test_oracle_golden.py regenerates cases into a tmp dir)
+        i = only.index('--out')
+        GOLD = only[i + 1]
+        only = only[:i] + only[i + 2:]
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = import_reference()
-    fx, rep = op_goldens(ref)
-    np.savez_compressed(os.path.join(GOLD, 'ops.npz'), **fx)
-    cases = [
-        ('mf_64_bs1', dict(arch='multi_frame', size=(64, 64), bs=1, pseed=11, bseed=1234, epoch=0, full_grads=True)),
-        ('mf_64_bs2_rnd', dict(arch='multi_frame', size=(64, 64), bs=2, pseed=12, bseed=99, epoch=2, random_batch=True,
-                               save_ckpt=True)),
-        ('mf_128_bs1', dict(arch='multi_frame', size=(128, 128), bs=1, pseed=13, bseed=1234, epoch=2)),
-        ('sf_64_bs1', dict(arch='single_frame', size=(64, 64), bs=1, pseed=21, bseed=1234)),
-        ('sf_128_bs1_pgt', dict(arch='single_frame', size=(128, 128), bs=1, pseed=22, bseed=1234, use_pseudo_gt=True)),
-        # crop_like trims here (reference model/networks.py:242-263): W 108 -> 54 -> 27 -> 14 -> 7 -> 4 -> 2 -> 1, so upconv
-        # outputs 28 -> 27 and 8 -> 7 (and 2 -> 1 at the deepest level) are cut exactly as at 512x432
-        ('sf_128x108_bs1', dict(arch='single_frame', size=(128, 108), bs=1, pseed=23, bseed=77)),
-        # non-degenerate scene: non-planar surface, 1.5x camera motion (few exactly tied top-k keys)
-        ('mf_128_bumps', dict(arch='multi_frame', size=(128, 128), bs=1, pseed=14, bseed=4321, epoch=2, scene='bumps',
-                              motion=1.5)),
-        # BASELINE config 5: DIS-FTSF (pseudo-GT) on the real pattern, K_processed, baseline 0.0246
-        ('sf_128_real_pgt', dict(arch='single_frame', size=(128, 128), bs=1, pseed=24, bseed=555, use_pseudo_gt=True,
-                                 pattern='real')),
-        # `real` data during the warm-up epochs: the masked-L1 SGM term with the reference's own noise draws recorded
-        # (model/multi_frame_worker.py:168-173: one draw; model/single_frame_worker.py:158-163: one per output scale)
-        ('mf_64_real_sgm', dict(arch='multi_frame', size=(64, 64), bs=1, pseed=15, bseed=808, epoch=2, pattern='real',
-                                real_sgm=True)),
-        ('sf_64_real_sgm', dict(arch='single_frame', size=(64, 64), bs=1, pseed=25, bseed=809, epoch=2, pattern='real',
-                                real_sgm=True)),
-    ]
-    only = sys.argv[1:]
+    if not only or 'ops' in only:
+        fx, rep = op_goldens(ref)
+        np.savez_compressed(os.path.join(GOLD, 'ops.npz'), **fx)
+    cases = CASES
     for name, kw in cases:
         if only and name not in only:
             continue

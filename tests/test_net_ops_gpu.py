@@ -661,6 +661,87 @@ def test_conv_bf16x3_is_fp32_accurate(h, w, cin, cout, cin_real):
         assert e2 < 1e-6, res
 
 
+@pytest.mark.parametrize('case', ['outlier_pixel', 'tiny_tiles', 'dominant_weight'])
+@pytest.mark.parametrize('cin,cout', [(32, 32), (16, 16)])
+def test_conv_f16x2_dynamic_range(case, cin, cout):
+    """The two-term fp16 split scales every halo TILE (and the weights of a launch) by a power of two, because fp16 has 5 exponent
+    bits.  Inputs that stress that block scaling, against fp64, beside the three-term bf16 kernel (8 exponent bits, no scaling)
+    on the same inputs; bar = 4 x the bf16x3 kernel's error (+ 2e-7 of the normalising magnitude):
+      outlier_pixel   one pixel of 1e4 among O(1) values: the tile's scale is set by the outlier; errors are measured over ALL
+                      outputs (of the largest entry) and over the outputs that do not see the outlier (of THEIR largest entry);
+      tiny_tiles      a 32 x 32 corner of 1e-6 values beside O(1) tiles: the all-tiny tile (its halo included) must keep full
+                      relative accuracy (own scale); a tile whose halo touches the O(1) region is scaled by that region - its tiny
+                      entries keep an ABSOLUTE error of 2^-39 of the tile maximum (asserted: 1e-9 of the largest output), the
+                      local relative figure is printed;
+      dominant_weight one weight 1e3 x the rest: one weight scale per launch.
+    Forward, input gradient (the same kernel on gy) and weight gradient (running scales over the tiles)."""
+    from depthinspace_amd import lib
+    from tests.conftest import conv_split
+    g = torch.Generator().manual_seed(cin * 10 + cout + len(case))
+    n, h, w = 2, 48, 64
+    x = torch.randn(n, h, w, cin, generator=g)
+    gy = torch.randn(n, h, w, cout, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.06
+    keep = torch.ones(n, h, w, dtype=torch.bool)     # outputs judged by the local metric
+    if case == 'outlier_pixel':
+        x[0, 20, 21, :] = 1e4
+        gy[1, 7, 40, 3] = 1e4
+        keep[0, 19:22, 20:23] = False
+    elif case == 'tiny_tiles':
+        x[:, :32, :32, :] *= 1e-6
+        gy[:, :32, :32, :] *= 1e-6
+    else:
+        wt[5, 3, 1, 1] = 60.0
+    x, gy, wt = x.cuda(), gy.cuda(), wt.cuda()
+    b = torch.randn(cout, generator=g).cuda() * (1e-6 if case == 'tiny_tiles' else 1.0)
+    xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    wr = wt.double().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b.double().cpu(), padding=1)
+    yr.backward(gy.permute(0, 3, 1, 2).double().cpu())
+    yr, gxr, gwr = yr.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1), wr.grad
+    out = {}
+    for tag in ('bf16x3', 'f16x2'):
+        with conv_split(tag):
+            y = torch.empty(n, h, w, cout, device='cuda')
+            gx = torch.zeros_like(x)
+            gw = torch.empty_like(wt)
+            gb = torch.empty(cout, device='cuda')
+            ws = torch.empty(lib.fn('dis_conv2d_wgrad_workspace')(cin, cout, 3, 1), device='cuda')
+            lib.call('dis_conv2d_fwd_bf16x3_oihw', x, wt, 0, cout, cin, 0, b, y, None, n, h, w, cin, cout, 3, 1, 1, 0)
+            lib.call('dis_conv2d_fwd_bf16x3_oihw', gy, wt, 1, cout, cin, 0, None, gx, None, n, h, w, cout, cin, 3, 1, 1, 0)
+            lib.call('dis_conv2d_wgrad_bf16x3', x, gy, gw, gb, ws, n, h, w, cin, cin, cout, 3, 1, 1)
+            out[tag] = (y.double().cpu(), gx.double().cpu(), gw.double().cpu())
+
+    def err(a, ref, sel=None):
+        d, r = (a - ref).abs(), ref.abs()
+        if sel is not None:
+            d, r = d[sel], r[sel]
+        return float(d.max() / (r.max() + 1e-300))
+    for name, i, ref in (('y', 0, yr), ('gx', 1, gxr), ('gw', 2, gwr)):
+        e3, e2 = err(out['bf16x3'][i], ref), err(out['f16x2'][i], ref)
+        print(f'{case} {cin}->{cout} {name}: of the largest entry: bf16x3 {e3:.2e}  f16x2 {e2:.2e}')
+        assert e2 < 4 * e3 + 2e-7, (case, name, e3, e2)
+    if case == 'outlier_pixel':
+        e3, e2 = err(out['bf16x3'][0], yr, keep), err(out['f16x2'][0], yr, keep)
+        print(f'  outputs that do not see the outlier (same tile included): bf16x3 {e3:.2e}  f16x2 {e2:.2e}')
+        assert e2 < 4 * e3 + 2e-7, (e3, e2)
+    if case == 'tiny_tiles':
+        own = torch.zeros(n, h, w, dtype=torch.bool)
+        own[:, :15, :15] = True       # tile (0, 0) minus the row / column whose taps reach halo row / column 16 (still tiny here)
+        mixed = torch.zeros(n, h, w, dtype=torch.bool)
+        mixed[:, 16:31, :31] = True   # tiny outputs of tiles whose halo (row 32) lies in the O(1) region
+        mixed[:, :31, 16:31] = True
+        for name, i, ref in (('y', 0, yr), ('gx', 1, gxr)):
+            e3, e2 = err(out['bf16x3'][i], ref, own), err(out['f16x2'][i], ref, own)
+            print(f'  {name}, all-tiny tile, of ITS largest entry: bf16x3 {e3:.2e}  f16x2 {e2:.2e}')
+            assert e2 < 4 * e3 + 2e-7, (name, e3, e2)
+            m3, m2 = err(out['bf16x3'][i], ref, mixed), err(out['f16x2'][i], ref, mixed)
+            a2 = float((out['f16x2'][i] - ref).abs()[mixed].max() / ref.abs().max())
+            print(f'  {name}, tiny outputs of tiles scaled by an O(1) halo: local relative error bf16x3 {m3:.2e}  f16x2 {m2:.2e}; '
+                  f'absolute, of the largest output: {a2:.2e}')
+            assert a2 < 1e-9, a2
+
+
 @pytest.mark.parametrize('h,w,pad', [(27, 45, 1), (16, 16, 1), (8, 19, 0), (33, 64, 2)])
 @pytest.mark.parametrize('act', [0, 1, 2])
 @pytest.mark.parametrize('cin,cout', [(32, 32), (16, 16), (16, 32), (32, 16)])

@@ -121,3 +121,35 @@ def test_geometry_against_numpy_convention():
     assert np.allclose(uv[0].numpy(), uvd[:, :2] / uvd[:, 2:3], atol=2e-3)
     # exact rigid flow of the synthetic scene agrees with the projection
     assert np.allclose(b['flow_01'][0, 0, 0].reshape(-1), uvd[:, 0] / uvd[:, 2] - u.reshape(-1), atol=2e-3)
+
+
+STEP_FIXTURES = ['mf_64_bs1', 'mf_64_bs2_rnd', 'mf_128_bs1', 'mf_128_bumps', 'mf_64_real_sgm', 'sf_64_bs1', 'sf_128_bs1_pgt',
+                 'sf_128x108_bs1', 'sf_128_real_pgt', 'sf_64_real_sgm']
+
+
+def test_committed_fixtures_are_what_the_generator_writes(golden_dir):
+    """Every step fixture carries the generator's current field set (`torch_threads`: ATen picks its CPU rounding chains by
+    thread count for a few ops, so index-class parity is parity with the 8-thread reference run) ..."""
+    for name in STEP_FIXTURES:
+        Gs = np.load(os.path.join(golden_dir, name + '.npz'))
+        assert 'torch_threads' in Gs.files and int(Gs['torch_threads']) == 8, name
+
+
+def test_fixtures_regenerate_bit_for_bit(golden_dir, tmp_path):
+    """... and regenerating them from the imported reference (a child process: the import recipe monkey-patches torch) reproduces
+    the committed files array for array, the `real`-data SGM fixtures included: the reference draws their noise from torch's
+    global generator, which the generator script seeds per case.  Needs /root/reference (this container only; the GPU box skips)."""
+    import subprocess
+    import sys
+    if not os.path.isdir('/root/reference/model'):
+        pytest.skip('reference checkout not present')
+    names = ['sf_64_real_sgm', 'mf_64_real_sgm', 'sf_64_bs1', 'mf_64_bs1']
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'oracle', 'make_golden.py'), '--out', str(tmp_path)] + names,
+                       capture_output=True, text=True, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for name in names:
+        new, old = np.load(os.path.join(str(tmp_path), name + '.npz')), np.load(os.path.join(golden_dir, name + '.npz'))
+        assert sorted(new.files) == sorted(old.files), name
+        for k in old.files:
+            assert np.array_equal(new[k], old[k]), (name, k)
