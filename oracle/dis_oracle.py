@@ -401,7 +401,7 @@ def conv3d_knn(p, name, xyz, feat, mask, stride, tl=4, neighbors=9, return_index
         idx = CONV3D_FORCE['core' if stride == 2 else 'quarter'][target].reshape(-1, neighbors, 1).long()
     if CONV3D_TAP is not None:
         CONV3D_TAP.append({'name': name, 'target': target, 'idx': idx.view(*bhw, neighbors).clone(),
-                           'key': key.view(*bhw, 9 * tl).clone()})
+                           'key': key.view(*bhw, 9 * tl).clone(), 'plane_absmax': float(plane.abs().max())})
     nb_xyz = torch.gather(local, 1, idx.expand(-1, -1, 3))
     nb_feat = torch.gather(Fe, 1, idx.expand(-1, -1, Fe.shape[-1]))
     h1 = F.selu(F.linear(nb_xyz, p[name + '.dense1.0.weight'], p[name + '.dense1.0.bias']))
