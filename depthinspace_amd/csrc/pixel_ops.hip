@@ -3,6 +3,7 @@
 // All are HBM-bandwidth-bound stencil/gather kernels: coalesced row-major access, LDS halo tiles for the
 // windowed ones, wavefront-shuffle + fp64-atomic reductions for the scalar losses.
 #include "common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // LCN  (reference model/networks.py:663-689)
@@ -84,6 +85,10 @@ extern "C" int dis_lcn_fwd(const float* x, float* out_lcn, float* out_std, int n
 // Both go through ONE v_rsq_f32 (1 ulp; q >= eps > 0): the kernels are bound by exactly this arithmetic (81 taps x 2
 // soft signs per pixel), and an IEEE sqrt + an IEEE division per soft sign cost ~4x as many instructions.
 __device__ __forceinline__ float census_rsq(float d, float eps) { return __builtin_amdgcn_rsqf(d * d + eps); }
+// ... with the argument as ONE fused multiply-add (the multi-estimate kernels: tolerance-checked, every VALU slot counts)
+__device__ __forceinline__ float census_rsq_fma(float d, float eps) { return __builtin_amdgcn_rsqf(__builtin_fmaf(d, d, eps)); }
+// sign(x) in {-1, 0, 1} as two VALU instructions (|x| >= 1e-30 or 0: differences of O(1) values)
+__device__ __forceinline__ float census_sign(float x) { return __builtin_amdgcn_fmed3f(x * 1e30f, -1.f, 1.f); }
 // h(a) - h(b) given the two reciprocal roots (the 0.5 (1 + .) parts cancel)
 __device__ __forceinline__ float census_hdiff(float a, float ra, float b, float rb) { return 0.5f * (a * ra - b * rb); }
 __device__ __forceinline__ float census_dh_r(float r, float eps) { return (0.5f * eps) * (r * r * r); }
@@ -257,6 +262,287 @@ extern "C" int dis_photometric_bwd(const float* es, const float* ta, const float
     case 2: hipLaunchKernelGGL(photometric_bwd_kernel<2>, grid, blk, 0, s, es, ta, grad_out, grad_es, c, h, w, block, eps); break;
     default: hipLaunchKernelGGL(photometric_bwd_kernel<3>, grid, blk, 0, s, es, ta, grad_out, grad_es, c, h, w, block, eps); break;
   }
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// census window loss of S estimates against ONE target in one launch (DIS-SF: the four output scales are all compared with the
+// same LCN image, reference model/single_frame_worker.py:110-118 -> model/networks.py:372 -> ext_functions.py:156-183).
+// The soft sign of the TARGET differences, h(ta_nb - ta_c), is the same for every estimate: evaluated once per tap instead of
+// once per estimate (5 reciprocal square roots per tap for S = 4 instead of 8; the kernels are bound by exactly this
+// arithmetic).  9 x 9 window; 2 pixels per lane, a tap row of both is 10 consecutive LDS values (5 ds_read_b64 instead of 18
+// ds_read_b32); the factor 0.5 of h is applied once at the end (a power of two: every partial sum scales exactly), so the
+// results equal S calls of dis_photometric_fwd / dis_photometric_bwd bit for bit.
+// ------------------------------------------------------------------------------------------------
+#define PM_TX 64
+#define PM_TY 8
+#define PM_P 4
+#define PM_TW (PM_TX + 2 * PM_P)
+#define PM_TH (PM_TY + 2 * PM_P)
+
+template <int TYPE, int S>
+__global__ __launch_bounds__(256, 4) void census_fwd_multi_kernel(const float* __restrict__ es, const float* __restrict__ ta,
+                                                               float* __restrict__ out, long sstride, int h, int w, float eps) {
+  __shared__ __attribute__((aligned(16))) float tl[(S + 1) * PM_TH * PM_TW];  // [estimate 0..S-1, target][row][col]
+  const int n = blockIdx.z, x0 = blockIdx.x * PM_TX, y0 = blockIdx.y * PM_TY;
+  const long ibase = (long)n * h * w;
+  for (int i = threadIdx.x; i < PM_TH * PM_TW; i += 256) {
+    const int ty = i / PM_TW, tx = i - ty * PM_TW;
+    const int gy = min(max(y0 + ty - PM_P, 0), h - 1), gx = min(max(x0 + tx - PM_P, 0), w - 1);  // replicate pad
+    const long o = ibase + (long)gy * w + gx;
+    float v[S + 1];
+#pragma unroll
+    for (int k = 0; k < S; ++k) v[k] = es[k * sstride + o];
+    v[S] = ta[o];
+#pragma unroll
+    for (int k = 0; k <= S; ++k) tl[k * (PM_TH * PM_TW) + i] = v[k];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  const float* tt = tl + S * (PM_TH * PM_TW);
+  float tc[2], ec[S][2], acc[S][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    tc[j] = tt[(ly + PM_P) * PM_TW + 2 * lx + j + PM_P];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+      ec[k][j] = tl[k * (PM_TH * PM_TW) + (ly + PM_P) * PM_TW + 2 * lx + j + PM_P];
+      acc[k][j] = 0.f;
+    }
+  }
+#pragma unroll 1
+  for (int dy = 0; dy < 9; ++dy) {
+    const int ro = (ly + dy) * PM_TW + 2 * lx;
+    float tr[10], tq[2][9];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const float2 v = *(const float2*)(tt + ro + 2 * q);
+      tr[2 * q] = v.x;
+      tr[2 * q + 1] = v.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int dx = 0; dx < 9; ++dx) {
+        const float dt = tr[j + dx] - tc[j];
+        tq[j][dx] = dt * census_rsq_fma(dt, eps);
+      }
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+      float er[10];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const float2 v = *(const float2*)(tl + k * (PM_TH * PM_TW) + ro + 2 * q);
+        er[2 * q] = v.x;
+        er[2 * q + 1] = v.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int dx = 0; dx < 9; ++dx) {
+          const float de = er[j + dx] - ec[k][j];
+          const float v = __builtin_fmaf(de, census_rsq_fma(de, eps), -tq[j][dx]);   // 2 (h(de) - h(dt)): 4 VALU + 1 v_rsq per tap
+          acc[k][j] = (TYPE == 2) ? __builtin_fmaf(v, v, acc[k][j]) : acc[k][j] + fabsf(v);
+        }
+      // (keep the next estimate's row reads behind this estimate's arithmetic: hoisting all S rows costs 40 registers and spills)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int py = y0 + ly;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int px = x0 + 2 * lx + j;
+    if (px < w && py < h) {
+#pragma unroll
+      for (int k = 0; k < S; ++k)
+        out[k * sstride + ibase + (long)py * w + px] = (acc[k][j] * (TYPE == 2 ? 0.25f : 0.5f)) / 81.f;
+    }
+  }
+}
+
+// census_sad backward, rare path (see census_bwd_multi_kernel): corrections of the S sums for one tap row of one pixel
+template <int S>
+__device__ __noinline__ float4 census_fix_row(const float* tl, int img, int ro, int cidx, int tw, float tk, float eps, int border,
+                                              int px, int py, int dy, int h, int w) {
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* tt = tl + S * img;
+#pragma unroll 1
+  for (int q = 0; q < 9 * S; ++q) {
+    const int k = q / 9, dx = q - 9 * k;
+    const float e = tl[k * img + ro + dx], t = tt[ro + dx], g = tl[(S + 1 + k) * img + ro + dx];
+    const float ekk = tl[k * img + cidx], gkk = tl[(S + 1 + k) * img + cidx];
+    const float des = ekk - e, dta = tk - t;
+    const float re = census_rsq_fma(des, eps);
+    const float v2 = __builtin_fmaf(des, re, -(dta * census_rsq_fma(dta, eps)));   // exactly the main path's value
+    if (fabsf(v2) < 2e-5f && (des != 0.f || dta != 0.f)) {
+      const float dx_ = census_h_exact(des, eps) - census_h_exact(dta, eps);
+      const float s0 = census_sign(v2), s1 = dx_ > 0.f ? 1.f : (dx_ < 0.f ? -1.f : 0.f);
+      float m = 1.f;
+      if (border) m = (float)(clamp_mult(py + dy - PM_P, py, PM_P, h) * clamp_mult(px + dx - PM_P, px, PM_P, w));
+      const float v = (m * g + gkk) * ((s1 - s0) * (re * re * re));   // (the caller's sum is scaled by 0.5 eps at the end)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) c[kk] += (kk == k) ? v : 0.f;
+    }
+  }
+  return make_float4(c[0], c[1], c[2], c[3]);
+}
+
+// Backward: ONE pixel per lane (32 x 8 tile).  The two-pixel form of the forward kernel needs ~164 registers here (3 waves per
+// SIMD) and ran slower than four single-estimate launches: the kernel is bound by VALU issue only while enough waves hide the
+// LDS and v_rsq latencies (measured: 2.1 ms for 4 estimates against 4 x 0.385 ms).
+#define PB_TX 32
+#ifndef PB_WPE
+#define PB_WPE 6       // waves per SIMD the register allocation aims at
+#endif
+#ifndef PB_DY_UNROLL
+#define PB_DY_UNROLL 1  // tap rows per trip of the row loop
+#endif
+#define PB_STR_(x) #x
+#define PB_STR(x) PB_STR_(x)
+#define PB_TW (PB_TX + 2 * PM_P)
+template <int TYPE, int S>
+__global__ __launch_bounds__(256, PB_WPE) void census_bwd_multi_kernel(const float* __restrict__ es, const float* __restrict__ ta,
+                                                               const float* __restrict__ gout, float* __restrict__ ges,
+                                                               long sstride, int h, int w, float eps) {
+  // [estimate 0..S-1][row][col], [target], [grad_out / 81 of estimate 0..S-1 (0 where no window centre exists)]
+  constexpr int IMG = PM_TH * PB_TW;
+  __shared__ float tl[(2 * S + 1) * IMG];
+  const int n = blockIdx.z, x0 = blockIdx.x * PB_TX, y0 = blockIdx.y * PM_TY;
+  const long ibase = (long)n * h * w;
+  const float inv = 1.f / 81.f;
+  for (int i = threadIdx.x; i < IMG; i += 256) {
+    const int ty = i / PB_TW, tx = i - ty * PB_TW;
+    const int ry = y0 + ty - PM_P, rx = x0 + tx - PM_P;
+    const int gy = min(max(ry, 0), h - 1), gx = min(max(rx, 0), w - 1);
+    const long o = ibase + (long)gy * w + gx;
+    const bool in = ry >= 0 && ry < h && rx >= 0 && rx < w;
+    float v[2 * S + 1];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+      v[k] = es[k * sstride + o];
+      v[S + 1 + k] = gout[k * sstride + o];
+    }
+    v[S] = ta[o];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+      tl[k * IMG + i] = v[k];
+      tl[(S + 1 + k) * IMG + i] = in ? v[S + 1 + k] * inv : 0.f;
+    }
+    tl[S * IMG + i] = v[S];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  const float* tt = tl + S * IMG;
+  const int px = x0 + lx, py = y0 + ly;
+  const int cidx = (ly + PM_P) * PB_TW + lx + PM_P;
+  const float tk = tt[cidx];
+  float ek[S], gk[S], acc[S];
+#pragma unroll
+  for (int k = 0; k < S; ++k) {
+    ek[k] = tl[k * IMG + cidx];
+    gk[k] = tl[(S + 1 + k) * IMG + cidx];
+    acc[k] = 0.f;
+  }
+  const bool interior = px > 0 && px < w - 1 && py > 0 && py < h - 1;
+  auto rows = [&](auto border_c) {
+    constexpr bool BORDER = decltype(border_c)::value;
+_Pragma(PB_STR(unroll PB_DY_UNROLL))
+    for (int dy = 0; dy < 9; ++dy) {
+      const int ro = (ly + dy) * PB_TW + lx;
+      float tq[9], mult[BORDER ? 9 : 1];
+#pragma unroll
+      for (int dx = 0; dx < 9; ++dx) {
+        const float dta = tk - tt[ro + dx];
+        tq[dx] = dta * census_rsq_fma(dta, eps);
+      }
+      if (BORDER) {  // (pixels on the image border: replicate-pad multiplicities of the window centres)
+        const int my = clamp_mult(py + dy - PM_P, py, PM_P, h);
+#pragma unroll
+        for (int dx = 0; dx < 9; ++dx) mult[dx] = (float)(my * clamp_mult(px + dx - PM_P, px, PM_P, w));
+      }
+      unsigned mnd = 0xffffffffu;   // smallest NON-ZERO |difference| of the row (all estimates), as (float bits << 1) - 1
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        // role (a) neighbour of the window centre at this tap, role (b) centre of its own window: one evaluation serves both
+        // (see photometric_bwd_kernel).  Branch-free main path; the sign of a near-zero difference (rare) is re-evaluated in the
+        // reference's own operation order afterwards, for the whole tap row.
+#pragma unroll
+        for (int dx = 0; dx < 9; ++dx) {
+          // per tap: 10 VALU + 1 v_rsq.  v = 2 (h(des) - h(dta)); the constant 0.5 eps of h' (and the 0.5 of h for census_mse)
+          // multiplies the finished sum; sign(v) through a clamp, not compares and selects
+          const float des = ek[k] - tl[k * IMG + ro + dx];
+          const float re = census_rsq_fma(des, eps);
+          const float v = __builtin_fmaf(des, re, -tq[dx]);
+          mnd = min(mnd, (__float_as_uint(v) << 1) - 1u);   // 2 |v| as bits, exact zeros (centre tap, flat regions) -> largest
+          const float sg = (TYPE == 2) ? v : census_sign(v);
+          const float g = tl[(S + 1 + k) * IMG + ro + dx];
+          const float wgt = BORDER ? __builtin_fmaf(mult[BORDER ? dx : 0], g, gk[k]) : g + gk[k];
+          acc[k] = __builtin_fmaf(wgt, sg * (re * re * re), acc[k]);
+        }
+      }
+      if (TYPE == 3 && mnd < (__float_as_uint(2e-5f) << 1) - 1u) {   // (0 < |h(des) - h(dta)| < 1e-5)
+        // (rare: ~1e-5 of the taps) the SIGN of a near-zero difference is the reference's, evaluated in its own operation order
+        // (IEEE sqrt and division): an out-of-line function that re-reads the row from LDS and returns the corrections of the
+        // sums.  Inlined, its loop cost the main path its registers (543 spills at 6 waves per SIMD).
+        const float4 c = census_fix_row<S>(tl, IMG, ro, cidx, PB_TW, tk, eps, BORDER ? 1 : 0, px, py, dy, h, w);
+        acc[0] += c.x;
+        if (S > 1) acc[S > 1 ? 1 : 0] += c.y;
+        if (S > 2) acc[S > 2 ? 2 : 0] += c.z;
+        if (S > 3) acc[S > 3 ? 3 : 0] += c.w;
+      }
+    }
+  };
+  if (interior) rows(std::false_type{});   // (divergent only in the tiles on the image border)
+  else rows(std::true_type{});
+  if (px < w && py < h) {
+#pragma unroll
+    for (int k = 0; k < S; ++k) ges[k * sstride + ibase + (long)py * w + px] = acc[k] * (0.5f * eps);
+  }
+}
+
+template <int TYPE>
+static void census_fwd_multi_launch(int s, dim3 grid, hipStream_t st, const float* es, const float* ta, float* out, long ss, int h,
+                                    int w, float eps) {
+  switch (s) {
+    case 1: hipLaunchKernelGGL((census_fwd_multi_kernel<TYPE, 1>), grid, dim3(256), 0, st, es, ta, out, ss, h, w, eps); break;
+    case 2: hipLaunchKernelGGL((census_fwd_multi_kernel<TYPE, 2>), grid, dim3(256), 0, st, es, ta, out, ss, h, w, eps); break;
+    case 3: hipLaunchKernelGGL((census_fwd_multi_kernel<TYPE, 3>), grid, dim3(256), 0, st, es, ta, out, ss, h, w, eps); break;
+    default: hipLaunchKernelGGL((census_fwd_multi_kernel<TYPE, 4>), grid, dim3(256), 0, st, es, ta, out, ss, h, w, eps); break;
+  }
+}
+template <int TYPE>
+static void census_bwd_multi_launch(int s, dim3 grid, hipStream_t st, const float* es, const float* ta, const float* go, float* ge,
+                                    long ss, int h, int w, float eps) {
+  switch (s) {
+    case 1: hipLaunchKernelGGL((census_bwd_multi_kernel<TYPE, 1>), grid, dim3(256), 0, st, es, ta, go, ge, ss, h, w, eps); break;
+    case 2: hipLaunchKernelGGL((census_bwd_multi_kernel<TYPE, 2>), grid, dim3(256), 0, st, es, ta, go, ge, ss, h, w, eps); break;
+    case 3: hipLaunchKernelGGL((census_bwd_multi_kernel<TYPE, 3>), grid, dim3(256), 0, st, es, ta, go, ge, ss, h, w, eps); break;
+    default: hipLaunchKernelGGL((census_bwd_multi_kernel<TYPE, 4>), grid, dim3(256), 0, st, es, ta, go, ge, ss, h, w, eps); break;
+  }
+}
+
+extern "C" int dis_photometric_fwd_multi(const float* es, const float* ta, float* out, int s, int n, int h, int w, int block,
+                                         int type, float eps, void* stream) {
+  if (!es || !ta || !out) return DIS_ERR_NULL;
+  if (s <= 0 || n <= 0 || h <= 0 || w <= 0) return DIS_ERR_BAD_SHAPE;
+  if (s > 4 || block != 9 || (type != 2 && type != 3) || n > 65535) return DIS_ERR_UNSUPPORTED;
+  const dim3 grid(dis_cdiv(w, PM_TX), dis_cdiv(h, PM_TY), n);
+  const long ss = (long)n * h * w;
+  if (type == 2) census_fwd_multi_launch<2>(s, grid, (hipStream_t)stream, es, ta, out, ss, h, w, eps);
+  else census_fwd_multi_launch<3>(s, grid, (hipStream_t)stream, es, ta, out, ss, h, w, eps);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_photometric_bwd_multi(const float* es, const float* ta, const float* grad_out, float* grad_es, int s, int n,
+                                         int h, int w, int block, int type, float eps, void* stream) {
+  if (!es || !ta || !grad_out || !grad_es) return DIS_ERR_NULL;
+  if (s <= 0 || n <= 0 || h <= 0 || w <= 0) return DIS_ERR_BAD_SHAPE;
+  if (s > 4 || block != 9 || (type != 2 && type != 3) || n > 65535) return DIS_ERR_UNSUPPORTED;
+  const dim3 grid(dis_cdiv(w, PB_TX), dis_cdiv(h, PM_TY), n);
+  const long ss = (long)n * h * w;
+  if (type == 2) census_bwd_multi_launch<2>(s, grid, (hipStream_t)stream, es, ta, grad_out, grad_es, ss, h, w, eps);
+  else census_bwd_multi_launch<3>(s, grid, (hipStream_t)stream, es, ta, grad_out, grad_es, ss, h, w, eps);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

@@ -19,6 +19,8 @@ SIGS = {
     'dis_lcn_fwd': 'pppiiiifp',
     'dis_photometric_fwd': 'pppiiiiiifp',
     'dis_photometric_bwd': 'ppppiiiiiifp',
+    'dis_photometric_fwd_multi': 'pppiiiiiifp',
+    'dis_photometric_bwd_multi': 'ppppiiiiiifp',
     'dis_pattern_warp_fwd': 'pppiiip',
     'dis_pattern_warp_bwd': 'ppppiiip',
     'dis_weighted_mean_fwd': 'pppplp',

@@ -44,9 +44,9 @@ class Worker(multi_frame_worker.Worker):
         std = self.data['std0']
         std = std.view(-1, *std.shape[2:])
         im_lcn = im[:, 0:1, ...].contiguous()
-        for s, o in zip(itertools.count(), out):
-            o = o.view(-1, *o.shape[2:])
-            val, _ = self.ph_losses[0](o, im_lcn, std)
+        # (one launch for all scales: the census terms of the image are shared, networks.RectifiedPatternSimilarityLoss.forward_multi)
+        ph = self.ph_losses[0].forward_multi([o.view(-1, *o.shape[2:]) for o in out], im_lcn, std)
+        for s, val in zip(itertools.count(), ph):
             vals.append(val / (2 ** s))
         # smoothness on scale 0
         amb0 = self.data['ambient0']

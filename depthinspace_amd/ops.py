@@ -271,6 +271,42 @@ def photometric(es, ta, block_size, type, eps):
     return _Photometric.apply(es, ta, block_size, type, eps)
 
 
+class _PhotometricMulti(torch.autograd.Function):
+    """census window loss of S stacked estimates (S, n, 1, h, w) against one target (n, 1, h, w) in one launch
+    (dis_photometric_fwd_multi): the target's soft signs are evaluated once for all S."""
+
+    @staticmethod
+    def forward(ctx, es, ta, block_size, type, eps):
+        es, ta = _c(es), _c(ta)
+        _chk(es, ta)
+        s, n, c, h, w = es.shape
+        assert c == 1 and tuple(ta.shape) == (n, 1, h, w)
+        out = torch.empty_like(es)
+        lib.call('dis_photometric_fwd_multi', es, ta, out, s, n, h, w, int(block_size), int(type), float(eps))
+        ctx.save_for_backward(es, ta)
+        ctx.cfg = (int(block_size), int(type), float(eps))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        es, ta = ctx.saved_tensors
+        block, type, eps = ctx.cfg
+        s, n, _, h, w = es.shape
+        ges = torch.empty_like(es)
+        lib.call('dis_photometric_bwd_multi', es, ta, _c(grad_out), ges, s, n, h, w, block, type, eps)
+        return ges, None, None, None, None
+
+
+def photometric_multi_ok(n_estimates, channels, block_size, type):
+    return 1 <= n_estimates <= 4 and channels == 1 and int(block_size) == 9 and int(type) in (2, 3)
+
+
+def photometric_multi(es_list, ta, block_size, type, eps):
+    """[photometric(es, ta, ...) for es in es_list] in one launch (census types, 9 x 9, one channel, <= 4 estimates)."""
+    out = _PhotometricMulti.apply(torch.stack([_c(e) for e in es_list], 0), ta, block_size, type, eps)
+    return list(out.unbind(0))
+
+
 # --------------------------------------------------------------------------------------------------
 # pattern projection
 # --------------------------------------------------------------------------------------------------

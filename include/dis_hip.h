@@ -64,6 +64,15 @@ int dis_photometric_fwd(const float* es, const float* ta, float* out, int n, int
 /* replaces photometric_loss_backward (reference model/ext_functions.py:137,139): gradient wrt `es` only. */
 int dis_photometric_bwd(const float* es, const float* ta, const float* grad_out, float* grad_es, int n, int c,
                         int h, int w, int block, int type, float eps, void* stream);
+/* The census forms (type 2 / 3, 9 x 9 window, one channel) for S <= 4 estimates against ONE target in a single launch: DIS-SF
+ * compares its four output scales with the same LCN image (reference model/single_frame_worker.py:110-118), and the soft sign of the
+ * target differences is the same for all of them.  es, out, grad_out, grad_es: (s, n, 1, h, w) stacked; ta (n, 1, h, w).
+ * Equal to s calls of dis_photometric_fwd / _bwd to rounding.  Other types / windows: DIS_ERR_UNSUPPORTED. */
+int dis_photometric_fwd_multi(const float* es, const float* ta, float* out, int s, int n, int h, int w, int block, int type,
+                              float eps, void* stream);
+int dis_photometric_bwd_multi(const float* es, const float* ta, const float* grad_out, float* grad_es, int s, int n, int h,
+                              int w, int block, int type, float eps, void* stream);
+
 
 /* Pattern projection of RectifiedPatternSimilarityLoss, reference model/networks.py:358-367:
  * proj[n,y,x] = bilinear(pattern, x - disp[n,y,x], y), align_corners=True, padding 'border'.

@@ -72,6 +72,38 @@ def test_photometric_ragged_sizes():
         close(e2.grad, e1.grad, 2e-6, 2e-5, what=f'bwd {n,c,h,w}')
 
 
+@pytest.mark.parametrize('type_id', [2, 3])
+@pytest.mark.parametrize('s_n_h_w', [(4, 2, 40, 70), (1, 1, 9, 9), (3, 1, 8, 130), (2, 3, 33, 41), (4, 1, 64, 64)])
+def test_photometric_multi_equals_per_estimate_calls(type_id, s_n_h_w):
+    """dis_photometric_fwd_multi / _bwd_multi (S estimates against one target, the target's census terms shared): equal to S
+    calls of the single-estimate kernels to rounding (fused multiply-adds; the rare near-zero-difference sign path corrects the
+    sum instead of branching inside it); ragged tiles, images smaller than the window, borders; and against the oracle."""
+    from depthinspace_amd import ops
+    s, n, h, w = s_n_h_w
+    g = torch.Generator().manual_seed(s * 1000 + n * 100 + h + w + type_id)
+    ta = torch.randn(n, 1, h, w, generator=g)
+    es = [torch.randn(n, 1, h, w, generator=g) for _ in range(s)]
+    es[0][:, :, : h // 2] = ta[:, :, : h // 2]            # exact zeros of h(des) - h(dta): the sign path of census_sad
+    go = [torch.rand(n, 1, h, w, generator=g) for _ in range(s)]
+    assert ops.photometric_multi_ok(s, 1, 9, type_id)
+    e_m = [e.cuda().requires_grad_(True) for e in es]
+    outs = ops.photometric_multi(e_m, ta.cuda(), 9, type_id, 0.5)
+    sum((o * g_.cuda()).sum() for o, g_ in zip(outs, go)).backward()
+    name = {2: 'census_mse', 3: 'census_sad'}[type_id]
+    for k in range(s):
+        e1 = es[k].cuda().requires_grad_(True)
+        y1 = ops.photometric(e1, ta.cuda(), 9, type_id, 0.5)
+        y1.backward(go[k].cuda())
+        close(outs[k], y1, 1e-7, 2e-6, what=f'fwd vs single {k}')   # (fused multiply-adds in the multi kernels: rounding level)
+        close(e_m[k].grad, e1.grad, 1e-7, 1e-6, what=f'bwd vs single {k}')
+        eo = es[k].clone().requires_grad_(True)
+        yo = O.photometric(eo, ta, 9, name, 0.5)
+        yo.backward(go[k])
+        close(outs[k], yo, 1e-5, 1e-5, what=f'fwd vs oracle {k}')
+        if k > 0:   # (estimate 0 has exact ties, where |.|' is a convention: the HIP kernels follow the reference's autograd, checked above against the single kernel)
+            close(e_m[k].grad, eo.grad, 2e-6, 2e-5, what=f'bwd vs oracle {k}')
+
+
 def test_photometric_rejects_bad_args():
     from depthinspace_amd import ops, lib
     x = torch.zeros(1, 1, 8, 8).cuda()
