@@ -96,6 +96,67 @@ __device__ __forceinline__ float dis_copy_w_rows(const float* w, int w_o, int ro
   return m;
 }
 
+// ------------------------------------------------------------------------------------------------
+// two-term fp16 split ("f16x2": conv_f16x2.hip, conv_gen.hip): x * 2^s = h1 + h2, 11 + 11 significant bits
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+// two fp32 values (already scaled) -> two packed fp16 pairs: h1 = RN(v), h2 = RN(v - h1)
+__device__ __forceinline__ void f2_split_pair(float x, float y, unsigned& p1, unsigned& p2) {
+  const f32x2 v = {x, y};
+  const f16x2_t h1 = __builtin_convertvector(v, f16x2_t);
+  const f32x2 r = v - __builtin_convertvector(h1, f32x2);
+  const f16x2_t h2 = __builtin_convertvector(r, f16x2_t);
+  p1 = __builtin_bit_cast(unsigned, h1);
+  p2 = __builtin_bit_cast(unsigned, h2);
+}
+// the same for x * sc, y * sc with sc a power of two (the products are exact): the remainder x * sc - h1 as ONE mixed-precision
+// fused multiply-add per value (v_fma_mix_f32 reads h1's halves in place) instead of multiply, convert back, subtract
+__device__ __forceinline__ void f2_split_pair_scaled(float x, float y, float sc, unsigned& p1, unsigned& p2) {
+  const f32x2 v = {x * sc, y * sc};
+  const f16x2_t h1 = __builtin_convertvector(v, f16x2_t);
+  const f32x2 r = {__builtin_fmaf(x, sc, -(float)h1[0]), __builtin_fmaf(y, sc, -(float)h1[1])};
+  const f16x2_t h2 = __builtin_convertvector(r, f16x2_t);
+  p1 = __builtin_bit_cast(unsigned, h1);
+  p2 = __builtin_bit_cast(unsigned, h2);
+}
+
+// maximum of a non-negative value over the wave (DPP row operations, no LDS traffic); valid in every lane's return value
+__device__ __forceinline__ float f2_wave_max(float m) {
+  int v = __float_as_int(m);  // non-negative floats order like their bit patterns
+#define F2_DPP(ctrl, rmask) v = max(v, __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, true))
+  F2_DPP(0xB1, 0xf);   // quad_perm [1,0,3,2]
+  F2_DPP(0x4E, 0xf);   // quad_perm [2,3,0,1]
+  F2_DPP(0x124, 0xf);  // row_ror:4
+  F2_DPP(0x128, 0xf);  // row_ror:8   -> every lane holds its row's maximum
+  F2_DPP(0x142, 0xa);  // row_bcast:15 into rows 1, 3
+  F2_DPP(0x143, 0xc);  // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's maximum
+#undef F2_DPP
+  return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
+
+// sum of a double over the wave (DPP row operations on the two halves, no LDS traffic); valid in lane 63
+__device__ __forceinline__ double f2_wave_sum_d(double v) {
+#define F2_DPPD(ctrl, rmask)                                                                              \
+  {                                                                                                       \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, true);             \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, true);             \
+    v += __hiloint2double(hi, lo);                                                                        \
+  }
+  F2_DPPD(0xB1, 0xf) F2_DPPD(0x4E, 0xf) F2_DPPD(0x124, 0xf) F2_DPPD(0x128, 0xf) F2_DPPD(0x142, 0xa) F2_DPPD(0x143, 0xc)
+#undef F2_DPPD
+  return v;
+}
+
+// power-of-two scale exponent that brings a block's largest magnitude into [2^14, 2^15) (fp16's largest binade is 2^15);
+// clamped so that the product of two scales and its inverse stay representable in fp32
+__device__ __forceinline__ int f2_scale_exp(float m) {
+  int e = 14 - __builtin_amdgcn_frexp_expf(m) + 1;  // frexp: m = f * 2^e, f in [0.5, 1)  ->  m in [2^(e-1), 2^e)
+  e = m > 0.f ? e : 0;
+  return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
+
 // fp16x2 kernels (conv_f16x2.hip): launched from conv2d.hip's dispatchers.  Return hipErrorInvalidValue when no instance
 // exists for the configuration (the caller then takes the bf16x3 kernel).
 hipError_t dis_f2_conv_launch(const ConvArgs& a, int cin, int cout, bool stats, int inact, long grid, hipStream_t stream);

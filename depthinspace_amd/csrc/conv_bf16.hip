@@ -706,7 +706,11 @@ __global__ void convb_pack_halo_kernel(PackArgsH a) {
   }
 }
 
-static int cb_bn(int cout) { return cout > 32 ? 64 : (cout > 16 ? 32 : 16); }
+static int cb_bn(int cout) {
+  static const int cap = getenv("DIS_CONVB_BN") ? atoi(getenv("DIS_CONVB_BN")) : 64;   // (experiments: narrower cout blocks)
+  const int bn = cout > 32 ? 64 : (cout > 16 ? 32 : 16);
+  return bn > cap ? cap : bn;
+}
 
 template <bool XB, bool YB>
 static void cb_launch(const GenArgsB& a, int bn, long grid, hipStream_t s) {

@@ -19,7 +19,7 @@
 //   weight-gradient kernel  dW[tap][xc][gc] = sum_pixels X[pixel+tap][xc] * G[pixel][gc]
 //     tile (one tap) x TX x-channels x TG g-channels per workgroup, k = 32 pixels per step, split-K over
 //     pixel ranges into partial slabs that a second kernel sums in a fixed order (deterministic).
-#include "common.h"
+#include "conv_args.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -46,6 +46,8 @@ struct GenArgs {
   // fp32 kernel, 4-channel inputs (DispNetS conv1: 2 -> 32, 7x7): a 16-wide k-chunk is FOUR TAPS x 4 channels instead of
   // one tap's 4 channels + 12 zeros; ntaps then counts tap groups and ntaps_real the taps
   int tpack, ntaps_real;
+  // two-term fp16 streaming kernel (convg2_fwd_kernel): block-scale workspace of this call, see CG2_WS below; null otherwise
+  const float* f2ws;
 };
 
 template <int BN>
@@ -412,6 +414,280 @@ __global__ __launch_bounds__(256, 2) void convg3_fwd_kernel(GenArgs a) {
   else emit(std::integral_constant<int, DIS_ACT_NONE>{});
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same streaming implicit GEMM with TWO-term fp16 operands ("f16x2", conv_f16x2.hip: x * 2^s = h1 + h2, 3 products per MAC
+// on v_mfma_f32_16x16x32_f16 - half the matrix work of the three-term bf16 form above, two operand planes instead of three).
+// fp16's 5 exponent bits need block scaling by powers of two (exact).  Here the blocks are
+//   * the WEIGHT tensor of the call (one scale, found by convg2_absmax_kernel, applied by the packing launch), and
+//   * every SAMPLE of x (one scale per image: the rows of the GEMM are output pixels, and all taps of an output pixel read its own
+//     image, so the scale is constant along K and is undone per output row in the epilogue - no running scales, no rescaling of
+//     accumulators).  A streaming kernel has no halo tile to take a maximum over; the per-sample maxima come from one
+//     launch in front of the packing launch (x was just written by the producing layer: the read is served by the Infinity
+//     Cache for all but the full-resolution maps).
+// Values within 2^18 of their image's largest magnitude keep 22 significant bits; smaller ones keep an ABSOLUTE error of 2^-39
+// of that magnitude (tests/test_sf_gpu.py: against fp64, beside the three-term kernel, incl. an image with a 1e4 outlier).
+// DIS_CONV_SPLIT=bf16x3 / dis_set_conv_split(0) keeps every launch on convg3_fwd_kernel.
+// Workspace (CG2_WS floats at the end of the call's first packing slice):
+//   [0, n * CG2_XB)        partial maxima of |x| per sample     (convg2_absmax_kernel)
+//   [CG2_WOFF, +CG2_WB)    partial maxima of |w|
+//   [CG2_EOFF, +n] ints    scale exponent per sample; [CG2_EOFF + CG2_NMAX] the weights'   (convg2_pack_kernel, block 0 / all)
+// ------------------------------------------------------------------------------------------------
+#define CG2_PS 80    // LDS pixel stride in 16-bit units (2 planes x 32 channels + 16 pad: 2 (mod 4) sixteen-byte units, see F2Cfg::PS)
+#define CG2_XB 8     // partial maxima per sample
+#define CG2_WB 256   // partial maxima of the weights (a 1024 x 512 x 3 x 3 weight is 4.7 M values: 64 blocks took longer than the conv)
+#define CG2_NMAX 224 // samples per call
+#define CG2_WOFF (CG2_NMAX * CG2_XB)
+#define CG2_EOFF (CG2_WOFF + CG2_WB)
+#define CG2_WS 2560  // >= CG2_EOFF + CG2_NMAX + 1, a multiple of 256
+
+__global__ __launch_bounds__(256) void convg2_absmax_kernel(const float* __restrict__ x, int n, long hw, int ldx, int xoff, int cin,
+                                                            const float* __restrict__ w, long wcount, float* __restrict__ ws) {
+  __shared__ float sm[4];
+  float m = 0.f;
+  int slot;
+  if ((int)blockIdx.x < n * CG2_XB) {
+    const int nn = blockIdx.x / CG2_XB, q = blockIdx.x % CG2_XB;
+    const long p_lo = hw * q / CG2_XB, p_hi = hw * (q + 1) / CG2_XB;
+    const int cv = cin >> 2;
+    const float* xb = x + ((long)nn * hw) * ldx + xoff;
+    for (long i = p_lo * cv + threadIdx.x; i < p_hi * cv; i += 256) {
+      const long p = i / cv;
+      const int c = (int)(i - p * cv);
+      const float4 v = *(const float4*)(xb + p * ldx + c * 4);
+      m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    slot = blockIdx.x;
+  } else {
+    const int q = blockIdx.x - n * CG2_XB;
+    for (long i = wcount * q / CG2_WB + threadIdx.x; i < wcount * (q + 1) / CG2_WB; i += 256) m = fmaxf(m, fabsf(w[i]));
+    slot = CG2_WOFF + q;
+  }
+  m = f2_wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[slot] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+struct Pack2Args {
+  const float* w;
+  unsigned short* packed;  // [tap][chunk][nblk][plane][lg][bn][8]
+  int ntaps, nchunk, nblk, bn, ci_real, co_real;
+  long s_ci, s_co;
+  short tsrc[CG_MAXTAPS];
+  float* ws;   // CG2_WS block-scale workspace
+  int n;       // > 0: block 0 also turns the per-sample partial maxima into exponents (first packing launch of the call)
+};
+__global__ __launch_bounds__(256) void convg2_pack_kernel(Pack2Args a) {
+  __shared__ int s_ew;
+  if (threadIdx.x < 64) {
+    float m = 0.f;
+#pragma unroll
+    for (int q = 0; q < CG2_WB / 64; ++q) m = fmaxf(m, a.ws[CG2_WOFF + q * 64 + threadIdx.x]);
+    m = f2_wave_max(m);
+    if (threadIdx.x == 0) {
+      s_ew = f2_scale_exp(m);
+      if (blockIdx.x == 0) ((int*)a.ws)[CG2_EOFF + CG2_NMAX] = s_ew;
+    }
+  }
+  if (blockIdx.x == 0 && a.n > 0) {
+    for (int nn = threadIdx.x; nn < a.n; nn += 256) {
+      float m = 0.f;
+#pragma unroll
+      for (int q = 0; q < CG2_XB; ++q) m = fmaxf(m, a.ws[nn * CG2_XB + q]);
+      ((int*)a.ws)[CG2_EOFF + nn] = f2_scale_exp(m);
+    }
+  }
+  __syncthreads();
+  const float sw = __builtin_ldexpf(1.f, s_ew);
+  const long total = (long)a.ntaps * a.nchunk * a.nblk * 4 * a.bn * 4;   // pairs of consecutive channels
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 3) * 2;
+    long r = i >> 2;
+    const int col = (int)(r % a.bn);
+    r /= a.bn;
+    const int lg = (int)(r & 3);
+    r >>= 2;
+    const int nb = (int)(r % a.nblk);
+    r /= a.nblk;
+    const int chunk = (int)(r % a.nchunk);
+    const int tap = (int)(r / a.nchunk);
+    const int ci = chunk * CG3_CK + lg * 8 + j, co = nb * a.bn + col;
+    float v0 = 0.f, v1 = 0.f;
+    if (co < a.co_real) {
+      if (ci < a.ci_real) v0 = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
+      if (ci + 1 < a.ci_real) v1 = a.w[(ci + 1) * a.s_ci + co * a.s_co + a.tsrc[tap]];
+    }
+    unsigned p1, p2;
+    f2_split_pair(v0 * sw, v1 * sw, p1, p2);
+    const long plane = 4L * a.bn * 8;
+    const long base = (((long)(tap * a.nchunk + chunk) * a.nblk + nb) * 2) * plane + ((long)lg * a.bn + col) * 8 + j;
+    *(unsigned*)(a.packed + base) = p1;
+    *(unsigned*)(a.packed + base + plane) = p2;
+  }
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void convg2_fwd_kernel(GenArgs a) {
+  constexpr int NT = BN / 16;
+  constexpr int NBQ = (2 * 4 * BN + 255) / 256;                   // 16-byte vectors of the B tile per thread
+  constexpr int A_U16 = CG_BM * CG2_PS, B_U16 = NBQ * 256 * 8;    // per buffer (B padded to whole rounds of the block)
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (A_U16 + B_U16)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int M = a.n * a.hv * a.wv;
+  const int nb = blockIdx.x % a.nblk, m0 = (blockIdx.x / a.nblk) * CG_BM;
+  const int* sexp = (const int*)a.f2ws + CG2_EOFF;
+
+  // loader role: thread owns channel group pq (4 channels) of pixels p0 + 32 j of the tile
+  const int pq = tid & 7, p0 = tid >> 3;
+  long pbase[4];
+  int piy[4], pix[4];
+  bool pval[4];
+  float psc[4];   // 2^(scale exponent of the row's image)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + p0 + j * 32;
+    pval[j] = m < M;
+    const int mm = pval[j] ? m : 0;
+    const int vx = mm % a.wv, t = mm / a.wv, vy = t % a.hv, nn = t / a.hv;
+    pbase[j] = (long)nn * a.hin * a.win;
+    piy[j] = vy * a.S;
+    pix[j] = vx * a.S;
+    psc[j] = __builtin_ldexpf(1.f, sexp[nn]);
+  }
+  // ring of three register sets, as convg3_fwd_kernel
+  float4 ra[3][4];
+  u32x4 rb[3][NBQ];
+  const u32x4* wq = (const u32x4*)a.w;
+  const int nk = a.ntaps * a.nchunk;
+  int ptap = 0, pchunk = 0, pnext = 0;  // cursor of the next k-step to request
+  auto prefetch = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    if (pnext >= nk) return;
+    const int dy = a.tdy[ptap], dx = a.tdx[ptap];
+    const int c = pchunk * CG3_CK + pq * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iy = piy[j] + dy, ix = pix[j] + dx;
+      const bool ok = pval[j] && c < a.cin && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+      const unsigned off = ok ? (unsigned)(((pbase[j] + (long)iy * a.win + ix) * a.ldx + a.xoff + c) * 4) : BX_OOB;
+      ra[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.x, a.x_bytes), off, 0, 0));
+    }
+    const long wb = ((long)(ptap * a.nchunk + pchunk) * a.nblk + nb) * (2 * 4 * BN);
+#pragma unroll
+    for (int q = 0; q < NBQ; ++q) rb[set][q] = wq[wb + min(tid + q * 256, 2 * 4 * BN - 1)];
+    ++pnext;
+    if (++pchunk == a.nchunk) {
+      pchunk = 0;
+      ++ptap;
+    }
+  };
+  auto stage = [&](auto setc, int buf) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    unsigned short* A = smem + buf * (A_U16 + B_U16);
+    unsigned short* B = A + A_U16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = ra[set][j];
+      unsigned a1, a2, b1, b2;
+      f2_split_pair_scaled(v.x, v.y, psc[j], a1, a2);
+      f2_split_pair_scaled(v.z, v.w, psc[j], b1, b2);
+      unsigned short* p = A + (p0 + j * 32) * CG2_PS + pq * 4;
+      *(uint2*)(p) = make_uint2(a1, b1);
+      *(uint2*)(p + 32) = make_uint2(a2, b2);
+    }
+#pragma unroll
+    for (int q = 0; q < NBQ; ++q) ((u32x4*)B)[tid + q * 256] = rb[set][q];  // (B is padded to NBQ * 256 vectors)
+  };
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  prefetch(S0{});
+  prefetch(S1{});
+  prefetch(S2{});
+  stage(S0{}, 0);
+  __syncthreads();
+  auto body = [&](int s, auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    prefetch(setc);
+    const unsigned short* A = smem + (s & 1) * (A_U16 + B_U16);
+    const unsigned short* B = A + A_U16;
+    s16x8 fa[2][2], fb[2][NT];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        fa[p][mt] = *(const s16x8*)(A + (wave * 32 + mt * 16 + li) * CG2_PS + p * 32 + lg * 8);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[p][nt] = *(const s16x8*)(B + ((p * 4 + lg) * BN + nt * 16 + li) * 8);
+    }
+    // smallest terms first: x2 w1, x1 w2, x1 w1
+    constexpr int PA[3] = {1, 0, 0};
+    constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa[PA[q]][mt]),
+                                                              __builtin_bit_cast(f16x8_t, fb[PB[q]][nt]), acc[mt][nt], 0, 0,
+                                                              0);
+    stage(std::integral_constant<int, (set + 1) % 3>{}, (s + 1) & 1);
+    constexpr int NM = 6 * NT;
+#pragma unroll
+    for (int g = 0; g < NM; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, (80 + NM - 1) / NM + 1, 0);  // its share of the split VALU
+      if (NM >= 12 ? g % 2 == 1 : true) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+    }
+    __syncthreads();
+  };
+  for (int ks = 0; ks < nk; ks += 3) {
+    body(ks, S0{});
+    if (ks + 1 < nk) body(ks + 1, S1{});
+    if (ks + 2 < nk) body(ks + 2, S2{});
+  }
+
+  // epilogue: undo the two block scales per output row (exact), then bias + activation, masked store of the real output channels
+  const int ew = sexp[CG2_NMAX];
+  float bias_v[NT];
+  bool cok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = nb * BN + nt * 16 + li;
+    cok[nt] = co < a.cout;
+    bias_v[nt] = (a.bias && cok[nt]) ? a.bias[co] : 0.f;
+  }
+  auto emit = [&](auto actc) {
+    constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wave * 32 + mt * 16 + lg * 4 + r;
+        if (m >= M) continue;
+        const int vx = m % a.wv, t = m / a.wv, vy = t % a.hv, nn = t / a.hv;
+        const float desc = __builtin_ldexpf(1.f, -(sexp[nn] + ew));
+        float* yp = a.y + (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff +
+                    nb * BN + li;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if (cok[nt]) yp[nt * 16] = act_apply(acc[mt][nt][r] * desc + bias_v[nt], ACT);
+      }
+    }
+  };
+  if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{});
+  else if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{});
+  else emit(std::integral_constant<int, DIS_ACT_NONE>{});
+}
+
 static int cg_bn(int cout) { return cout > 32 ? 64 : (cout > 16 ? 32 : 16); }
 
 // one launch of the forward-like kernel (packs its weights first)
@@ -423,6 +699,27 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
   a.nblk = (a.cout + bn - 1) / bn;
   static const bool use3 = !(getenv("DIS_CONV_BF16X3") && getenv("DIS_CONV_BF16X3")[0] == '0');
   const long xb3 = (long)a.n * a.hin * a.win * a.ldx * 4;  // the bf16x3 kernel addresses x with 31-bit byte offsets
+  if (use3 && a.f2ws && a.cin >= CG3_CK && xb3 < 0x7fff0000L) {  // two-term fp16 form (default): see convg2_fwd_kernel
+    a.x_bytes = (unsigned)xb3;
+    a.nchunk = (a.cin + CG3_CK - 1) / CG3_CK;
+    Pack2Args p2;
+    p2.w = w_raw; p2.packed = (unsigned short*)wpack; p2.ntaps = a.ntaps; p2.nchunk = a.nchunk; p2.nblk = a.nblk;
+    p2.bn = bn; p2.ci_real = ci_real; p2.co_real = co_real; p2.s_ci = s_ci; p2.s_co = s_co;
+    for (int t = 0; t < a.ntaps; ++t) p2.tsrc[t] = tsrc[t];
+    p2.ws = const_cast<float*>(a.f2ws); p2.n = a.n;   // (every phase recomputes the same exponents: idempotent)
+    const long ptotal2 = (long)a.ntaps * a.nchunk * a.nblk * 4 * bn * 4;
+    hipLaunchKernelGGL(convg2_pack_kernel, dim3(dis_ew_grid(ptotal2, 256)), dim3(256), 0, s, p2);
+    a.w = wpack;
+    const long M2 = (long)a.n * a.hv * a.wv;
+    const long grid2 = ((M2 + CG_BM - 1) / CG_BM) * a.nblk;
+    if (grid2 > 2147483647L) return DIS_ERR_BAD_SHAPE;
+    DIS_TAG("convg2_fwd_kernel (f16x2 streaming)");
+    if (bn == 64) hipLaunchKernelGGL(convg2_fwd_kernel<64>, dim3((unsigned)grid2), dim3(256), 0, s, a);
+    else if (bn == 32) hipLaunchKernelGGL(convg2_fwd_kernel<32>, dim3((unsigned)grid2), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(convg2_fwd_kernel<16>, dim3((unsigned)grid2), dim3(256), 0, s, a);
+    DIS_CHECK_LAUNCH();
+    return DIS_OK;
+  }
   if (use3 && a.cin >= CG3_CK && xb3 < 0x7fff0000L) {  // bf16x3 form: 32-channel k-steps, weights pre-split
     a.x_bytes = (unsigned)xb3;
     a.nchunk = (a.cin + CG3_CK - 1) / CG3_CK;
@@ -472,7 +769,7 @@ extern "C" long dis_convg_pack_workspace(int cin, int cout, int k) {
   const long nblk = (cout + bn - 1) / bn, nchunk = (cin + CG_CK - 1) / CG_CK, nchunk3 = (cin + CG3_CK - 1) / CG3_CK;
   const long f32 = (long)k * k * nchunk * nblk * 16 * bn;        // fp32 fragment image
   const long b3 = (long)k * k * nchunk3 * nblk * (3 * 4 * 8 / 2) * bn;  // 3 bf16 planes (16-bit words / 2 = floats)
-  return f32 > b3 ? f32 : b3;
+  return (f32 > b3 ? f32 : b3) + CG2_WS;   // (+ the block-scale workspace of the two-term fp16 form, at the end of the first slice)
 }
 
 static int floordiv2(int v) { return (v >= 0) ? v / 2 : -((-v + 1) / 2); }
@@ -506,6 +803,14 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
   a.hf = hout; a.wf = wout; a.ldy = ldy; a.yoff = yoff; a.cout = cout; a.act = act;
   short tsrc[CG_MAXTAPS];
   const long kk = (long)k * k;
+  a.f2ws = nullptr;
+  if (dis_f2_enabled() && cin >= CG3_CK && n <= CG2_NMAX) {
+    // two-term fp16 form: block maxima of this call's x (per sample) and weights, one launch in front of the packing launch(es)
+    float* f2ws = wpack + dis_convg_pack_workspace(cin, cout, k) - CG2_WS;
+    hipLaunchKernelGGL(convg2_absmax_kernel, dim3(n * CG2_XB + CG2_WB), dim3(256), 0, s, x, n, (long)hin * win, ldx, xoff, cin, w,
+                       (long)cin_w * cout_w * kk, f2ws);
+    a.f2ws = f2ws;
+  }
   if (mode == DIS_CONVG_CONV || mode == DIS_CONVG_TCONV_DGRAD) {
     // direct form: out[vy][vx] = sum_taps in[vy*S + ky - pad][vx*S + kx - pad] * W
     if (mode == DIS_CONVG_CONV) {

@@ -71,6 +71,57 @@ def test_convg_conv_fwd_bwd(cin, cin_mem, cout, k, stride, h, w):
     assert relerr(bd.grad, br.grad) < 5e-5
 
 
+@pytest.mark.parametrize('case', ['randn', 'outlier_pixel', 'tiny_image', 'dominant_weight'])
+@pytest.mark.parametrize('cin,cout,k,stride,h,w', [(64, 64, 5, 1, 22, 20), (256, 512, 3, 2, 16, 14), (128, 64, 3, 1, 24, 27)])
+def test_convg_f16x2_streaming_is_fp32_accurate(case, cin, cout, k, stride, h, w):
+    """The streaming convolutions of DispNetS with >= 32 input channels on the two-term fp16 split (convg2_fwd_kernel: 3 products,
+    one power-of-two scale per IMAGE of x and one for the weights) against fp64, beside the three-term bf16 kernel (6 products, no
+    scaling) on the same inputs; forward and input gradient (the same kernel in its transposed mode).  Bar: 4 x the bf16x3
+    kernel's error + 2e-7, of the largest entry - overall, and PER IMAGE (each image has its own scale):
+      outlier_pixel   one pixel of 1e4 in image 0: that image's scale is set by the outlier (its other outputs keep an absolute
+                      error of 2^-39 of it), image 1 is untouched;
+      tiny_image      image 1 is 1e-6 x image 0: its own scale, full relative accuracy;
+      dominant_weight one weight 1e3 x the rest."""
+    from depthinspace_amd import ops
+    from tests.conftest import conv_split
+    g = torch.Generator().manual_seed(cin + cout + k + len(case))
+    n, pad = 2, (k - 1) // 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    if case == 'outlier_pixel':
+        x[0, :, h // 2, w // 3] = 1e4
+    elif case == 'tiny_image':
+        x[1] *= 1e-6
+    elif case == 'dominant_weight':
+        wt[3, 5, k // 2, k // 2] *= 1e3
+    b = torch.randn(cout, generator=g) * (0.1 if case != 'tiny_image' else 0.0)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    y = F.conv2d(xr, wr, b.double(), stride=stride, padding=pad)
+    go = torch.randn(y.shape, generator=g)
+    if case == 'tiny_image':
+        go[1] *= 1e-6
+    y.backward(go.double())
+    out = {}
+    for tag in ('bf16x3', 'f16x2'):
+        with conv_split(tag):
+            xd = nhwc(x).cuda().requires_grad_(True)
+            wd, bd = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+            yd = ops.convg(xd, wd, bd, stride, pad, ops.ACT_NONE)
+            yd.backward(nhwc(go).cuda())
+            out[tag] = (nchw(yd).detach().double().cpu(), nchw(xd.grad).double().cpu())
+
+    def err(a, ref):
+        return float((a - ref).abs().max() / (ref.abs().max() + 1e-300))
+    for name, i, ref in (('y', 0, y.detach()), ('gx', 1, xr.grad)):
+        e3, e2 = err(out['bf16x3'][i], ref), err(out['f16x2'][i], ref)
+        per3 = [err(out['bf16x3'][i][q], ref[q]) for q in range(n)]
+        per2 = [err(out['f16x2'][i][q], ref[q]) for q in range(n)]
+        print(f'{case} {cin}->{cout} k{k} s{stride} {name}: bf16x3 {e3:.2e} {per3}  f16x2 {e2:.2e} {per2}')
+        assert e2 < 4 * e3 + 2e-7, (case, name, e3, e2)
+        for q in range(n):
+            assert per2[q] < 4 * per3[q] + 2e-7, (case, name, q, per3[q], per2[q])
+
+
 # cin, cout, hin, win, hout, wout (crop_like target)
 TCONV_SHAPES = [
     (512, 512, 4, 4, 8, 7),     # upconv7 at 512x432: 8x8 cropped to 8x7
