@@ -1404,7 +1404,11 @@ int dis_bx_slices_run(int dgrad, const float* x, int ldx, int xoff, int cin, int
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, a);
         return hipSuccess;
       };
-      hipError_t le;
+      hipError_t le = hipErrorInvalidValue;
+      // two-term fp16 split (conv_f16x2.hip, default): the 3 x 3 slices; the 7 x 7 tap rows stay on the three-term kernel
+      if (k == 3 && dis_f2_enabled()) le = dis_f2_conv_gen_launch(a, grid, stream);
+      if (le == hipSuccess) continue;
+      if (le != hipErrorInvalidValue) return (int)le;
       if (k == 7) {
         if (variant == 0) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_NONE, false, false, 0, true, 1, 7>);
         else if (variant == 1) le = launch(conv_bf16x3_kernel<32, 32, DIS_ACT_NONE, true, false, 0, true, 1, 7>);

@@ -161,4 +161,5 @@ __device__ __forceinline__ int f2_scale_exp(float m) {
 // exists for the configuration (the caller then takes the bf16x3 kernel).
 hipError_t dis_f2_conv_launch(const ConvArgs& a, int cin, int cout, bool stats, int inact, long grid, hipStream_t stream);
 hipError_t dis_f2_wgrad_launch(const WgArgs& a, int cin, int cout, int inact, long workers, hipStream_t stream);
+hipError_t dis_f2_conv_gen_launch(const ConvArgs& a, long grid, hipStream_t stream);  // 32 x 32 channel slices (DispNetS)
 bool dis_f2_enabled();

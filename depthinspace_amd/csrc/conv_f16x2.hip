@@ -99,9 +99,15 @@ extern "C" int dis_debug_f2_stamps(unsigned long long* host) {
 #define F2_T(k)
 #endif
 
-template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool INGN = false, bool EPIAB = false, int EPIACT = 0>
+// GEN: channel-slice form (DispNetS layers as 32 x 32 slices of wider tensors, conv2d.hip dis_bx_slices_run): x / y point at the
+// slice's first channel, a pixel occupies a.ldx / a.ldy floats, a.cx / a.cy channels of the slice exist (the rest load zeros /
+// are not stored), a.nbias bias entries exist; ACT may be ReLU.
+template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool INGN = false, bool EPIAB = false, int EPIACT = 0,
+          bool GEN = false>
 __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   using C = F2Cfg<CIN, COUT>;
+  static_assert(!GEN || (!STATS && INACT == 0 && !INGN && !EPIAB && CIN == 32 && COUT == 32), "slice form: plain convolution / input gradient");
+  const int ldx = GEN ? a.ldx : CIN, ldy = GEN ? a.ldy : COUT;  // floats per pixel
   static_assert(!EPIAB || (!STATS && ACT == DIS_ACT_NONE && 2 * COUT <= 64), "channel sums: plain input-gradient instances");
   static_assert(EPIACT == 0 || EPIAB, "activation gradient at the output: only with the channel sums");
 #ifdef BX_STAMP
@@ -135,19 +141,20 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     const int vv = idx % CV, pix = idx / CV;
     const int r = pix / IC, c = pix % IC;
     (void)r;
-    it_rc[it] = idx < C::NITEMS ? c : 0x40000000;  // (halo column; items past the end of the halo: never in range)
-    it_off[it] = ((r * a.win + c) * CIN + vv * 4) * 4;
+    // (halo column; items past the end of the halo - and, GEN, channels the slice does not have - are never in range: zeros)
+    it_rc[it] = (idx < C::NITEMS && (!GEN || vv * 4 < a.cx)) ? c : 0x40000000;
+    it_off[it] = ((r * a.win + c) * ldx + vv * 4) * 4;
   }
-  const unsigned x_bytes = (unsigned)a.hin * a.win * (CIN * 4u);
-  const unsigned y_bytes = (unsigned)a.hf * a.wf * (COUT * 4u);
+  const unsigned x_bytes = GEN ? ((unsigned)a.hin * a.win * ldx - a.x_sub) * 4u : (unsigned)a.hin * a.win * (CIN * 4u);
+  const unsigned y_bytes = GEN ? ((unsigned)a.hf * a.wf * ldy - a.y_sub) * 4u : (unsigned)a.hf * a.wf * (COUT * 4u);
   const float* pf_x = a.x;
   unsigned pf_bytes = 0;
   int pf_iy0 = 0, pf_ix0 = 0, pf_off0 = 0;
   auto pf_setup = [&](int n, int ty, int tx, bool live) {
     pf_iy0 = ty * F2_TR - a.pad_y;
     pf_ix0 = tx * F2_TC - a.pad_x;
-    pf_off0 = (pf_iy0 * a.win + pf_ix0) * (CIN * 4);
-    pf_x = a.x + (long)n * a.hin * a.win * CIN;
+    pf_off0 = (pf_iy0 * a.win + pf_ix0) * (ldx * 4);
+    pf_x = a.x + (long)n * a.hin * a.win * ldx;
     pf_bytes = live ? x_bytes : 0u;
   };
   auto pf_issue = [&](int it) {
@@ -317,11 +324,15 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   float t1 = 0.f, t2 = 0.f;
   int stat_n = -1;
   float4 bias_v[NT];
+  unsigned ymask[NT];  // GEN: 0 where this lane's 4 output channels of block nt exist in the slice, else the drop-this-store offset
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-    bias_v[nt] = a.bias ? *(const float4*)(a.bias + nt * 16 + lg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int yrow = a.osy * a.wf * (COUT * 4);
-  const int y_lane = ((wave * 2 * a.osy * a.wf + li * a.osx) * COUT + lg * 4) * 4;
+  for (int nt = 0; nt < NT; ++nt) {
+    bias_v[nt] = (a.bias && (!GEN || nt * 16 + lg * 4 < a.nbias)) ? *(const float4*)(a.bias + nt * 16 + lg * 4)
+                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    ymask[nt] = (!GEN || nt * 16 + lg * 4 < a.cy) ? 0u : BX_OOB;
+  }
+  const int yrow = a.osy * a.wf * (ldy * 4);
+  const int y_lane = ((wave * 2 * a.osy * a.wf + li * a.osx) * ldy + lg * 4) * 4;
 
   const float* prev_y = a.y;
   unsigned prev_off[2] = {BX_OOB, BX_OOB};
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       hi = (f32x2){fmaxf(hi[0], 0.f), fmaxf(hi[1], 0.f)};
     }
     const u32x4 ov = {__float_as_uint(lo[0]), __float_as_uint(lo[1]), __float_as_uint(hi[0]), __float_as_uint(hi[1])};
-    __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(prev_y, y_bytes), prev_off[mt] + nt * 64, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(prev_y, y_bytes), GEN ? ((prev_off[mt] + nt * 64) | ymask[nt]) : prev_off[mt] + nt * 64, 0, 0);
     if (STATS) {
       const f32x2 sm = lo + hi, sq = lo * lo + hi * hi;
       t1 = __builtin_fmaf(livef[mt], sm[0] + sm[1], t1);
@@ -458,8 +469,8 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   const bool hi_tap = (lg >> 1) != 0;
   while (tile < t_hi) {
     const int vy0 = cty * F2_TR + wave * 2, vx0 = ctx * F2_TC + li;
-    const int tile_yoff = ((cty * F2_TR * a.osy + a.ooy) * a.wf + ctx * F2_TC * a.osx + a.oox) * (COUT * 4) + y_lane;
-    const float* cur_y = a.y + (long)cn * a.hf * a.wf * COUT;
+    const int tile_yoff = ((cty * F2_TR * a.osy + a.ooy) * a.wf + ctx * F2_TC * a.osx + a.oox) * (ldy * 4) + y_lane;
+    const float* cur_y = a.y + (long)cn * a.hf * a.wf * ldy;
     unsigned cur_off[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) cur_off[mt] = (vx0 < a.wv && vy0 + mt < a.hv) ? (unsigned)(tile_yoff + mt * yrow) : BX_OOB;
@@ -734,6 +745,28 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
     case 6: return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_SELU, true, false>, 6);
     default: return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_SELU, true, true>, 7);
   }
+}
+
+// channel-slice form (conv2d.hip dis_bx_slices_run): 32 x 32 slices, act NONE / ReLU, writing or accumulating
+hipError_t dis_f2_conv_gen_launch(const ConvArgs& a, long grid, hipStream_t stream) {
+  using C = F2Cfg<32, 32>;
+  if (a.wmode < 0 || (a.act != DIS_ACT_NONE && a.act != DIS_ACT_RELU)) return hipErrorInvalidValue;
+  static bool attr_set[4] = {};
+  const int slot = (a.act == DIS_ACT_RELU ? 2 : 0) + (a.accum ? 1 : 0);
+  auto launch = [&](auto kern) -> hipError_t {
+    if (!attr_set[slot]) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+      if (e != hipSuccess) return e;
+      attr_set[slot] = true;
+    }
+    DIS_TAG("conv_f16x2_kernel<32,32,GEN> slices");
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
+    return hipSuccess;
+  };
+  if (slot == 0) return launch(conv_f16x2_kernel<32, 32, DIS_ACT_NONE, false, false, 0, false, false, 0, true>);
+  if (slot == 1) return launch(conv_f16x2_kernel<32, 32, DIS_ACT_NONE, true, false, 0, false, false, 0, true>);
+  if (slot == 2) return launch(conv_f16x2_kernel<32, 32, DIS_ACT_RELU, false, false, 0, false, false, 0, true>);
+  return launch(conv_f16x2_kernel<32, 32, DIS_ACT_RELU, true, false, 0, false, false, 0, true>);
 }
 
 hipError_t dis_f2_conv_launch(const ConvArgs& a, int cin, int cout, bool stats, int inact, long grid, hipStream_t stream) {
