@@ -2185,8 +2185,15 @@ static int wgrad_pairs_launch(WgArgs a, float* grad_w, int cX_w, int cG_w, int n
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  DIS_TAG(BF ? "conv_wgrad_bf16x3_kernel<BF> slice pairs" : "conv_wgrad_bf16x3_kernel slice pairs");
-  hipLaunchKernelGGL(kern, dim3((unsigned)wpp, (unsigned)(a.npx * ngb), NGRP), dim3(256), XC::LDS_BYTES, s, a);
+  // two-term fp16 split (conv_f16x2.hip, default): the fp32 3 x 3 stride-1 pairs; same slab layout, same reduce launch
+  hipError_t le = hipErrorInvalidValue;
+  if (!BF && K == 3 && S == 1 && KH == 3 && dis_f2_enabled())
+    le = dis_f2_wgrad_pairs_launch(a, COB, (unsigned)wpp, (unsigned)(a.npx * ngb), s);
+  if (le != hipSuccess && le != hipErrorInvalidValue) return (int)le;
+  if (le != hipSuccess) {
+    DIS_TAG(BF ? "conv_wgrad_bf16x3_kernel<BF> slice pairs" : "conv_wgrad_bf16x3_kernel slice pairs");
+    hipLaunchKernelGGL(kern, dim3((unsigned)wpp, (unsigned)(a.npx * ngb), NGRP), dim3(256), XC::LDS_BYTES, s, a);
+  }
   const long total = (long)NGRP * a.npx * ngb * KH * K * 32 * COB;
   hipLaunchKernelGGL(wgrad_pairs_reduce_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, (const float*)a.part,
                      grad_w, wpp, a.npx, a.npx * ngb, cX_w, cG_w, K, KH, COB);

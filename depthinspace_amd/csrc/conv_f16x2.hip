@@ -821,9 +821,16 @@ __device__ __forceinline__ void f2_static_for(F&& f) {
   }
 }
 
-template <int CIN, int COUT, int INACT = 0, bool INGN = false>
+// GEN: channel-slice PAIRS of a wide layer (DispNetS, conv2d.hip dis_wgrad_pairs_run: 3 x 3, stride 1): blockIdx.y = gb * npx + cb
+// selects x channels [32 cb, 32 cb + 32) and gy channels [COUT gb, + COUT) of pixels that occupy a.ldx / a.ldg floats; channels
+// past the layer's last one load zeros; one slab per (pair, worker).
+template <int CIN, int COUT, int INACT = 0, bool INGN = false, bool GEN = false>
 __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
   using C = F2WxCfg<CIN, COUT>;
+  static_assert(!GEN || (CIN == 32 && INACT == 0 && !INGN), "slice-pair form");
+  const int ldx = GEN ? a.ldx : CIN, ldg = GEN ? a.ldg : COUT;
+  const int cb = GEN ? (int)blockIdx.y % a.npx : 0, gbk = GEN ? (int)blockIdx.y / a.npx : 0;
+  const int xc0 = GEN ? a.xoff + 32 * cb : 0, gc0 = GEN ? a.goff + COUT * gbk : 0;
   constexpr int NP = C::NP, K = C::K, TR = C::TR, WX_IC = C::IC;
   constexpr int PSX = C::PSX, PSG = C::PSG, NLX = C::NLX, NLG = C::NLG, NB = C::NB, TW = C::TW;
   static_assert(!INGN || 256 % C::CVX == 0, "a thread keeps its 4 channels over its items");
@@ -849,17 +856,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
     const int idx = (int)threadIdx.x + it * 256;
     const int vv = idx % C::CVX, pix = idx / C::CVX;
     const int r = pix / WX_IC, c = pix % WX_IC;
-    ix_rc[it] = idx < C::NIX ? (r | (c << 16)) : 0x40000000;  // (items past the end of the halo: column never in range)
-    ix_off[it] = ((r * a.win + c) * CIN + vv * 4) * 4;
+    // (items past the end of the halo - and, GEN, channels past the layer's last one: column never in range, zeros)
+    ix_rc[it] = (idx < C::NIX && (!GEN || 32 * cb + vv * 4 < a.cx)) ? (r | (c << 16)) : 0x40000000;
+    ix_off[it] = ((r * a.win + c) * ldx + xc0 + vv * 4) * 4;
   }
 #pragma unroll
   for (int it = 0; it < NLG; ++it) {
     const int idx = threadIdx.x + it * 256;
     const int vv = idx % C::CVG, pix = idx / C::CVG;
-    ig_rc[it] = (pix >> 4) | ((pix & 15) << 16);
-    ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * COUT + vv * 4) * 4;
+    ig_rc[it] = (!GEN || COUT * gbk + vv * 4 < a.cg) ? ((pix >> 4) | ((pix & 15) << 16)) : 0x40000000;
+    ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * ldg + gc0 + vv * 4) * 4;
   }
-  const unsigned x_bytes = (unsigned)a.hin * a.win * (CIN * 4u), g_bytes = (unsigned)a.hout * a.wout * (COUT * 4u);
+  const unsigned x_bytes = (unsigned)a.hin * a.win * (ldx * 4u), g_bytes = (unsigned)a.hout * a.wout * (ldg * 4u);
   int st_iy0 = 0, st_ix0 = 0, st_n = -1, gn_n = -1;
   float4 gn_g = make_float4(0.f, 0.f, 0.f, 0.f), gn_b = gn_g, gn_sc = gn_g, gn_sh = gn_g;
   if (INGN) {
@@ -870,8 +878,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * TR - a.pad, ix0 = tx * 16 - a.pad;
     st_iy0 = iy0, st_ix0 = ix0, st_n = n;
-    const char* xb = (const char*)a.x + (long)n * a.hin * a.win * CIN * 4;
-    const int xoff0 = (iy0 * a.win + ix0) * (CIN * 4);
+    const char* xb = (const char*)a.x + (long)n * a.hin * a.win * ldx * 4;
+    const int xoff0 = (iy0 * a.win + ix0) * (ldx * 4);
 #pragma unroll
     for (int it = 0; it < NLX; ++it) {
       // (rows above / below the sample leave the sample's buffer range by themselves: only the column is tested)
@@ -880,8 +888,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
       prex[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(xb, x_bytes), ok ? (unsigned)(xoff0 + ix_off[it]) : BX_OOB, 0, 0));
     }
-    const char* gb = (const char*)a.gy + (long)n * a.hout * a.wout * COUT * 4;
-    const int goff0 = (ty * TR * a.wout + tx * 16) * (COUT * 4);
+    const char* gb = (const char*)a.gy + (long)n * a.hout * a.wout * ldg * 4;
+    const int goff0 = (ty * TR * a.wout + tx * 16) * (ldg * 4);
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
       const int ox = tx * 16 + (ig_rc[it] >> 16);
@@ -1058,7 +1066,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
     }
     // partial slab of this workgroup: [m = mb*16 + row][co], scales undone
     const float desc = __builtin_ldexpf(1.f, -(sx_e + sg_e));
-    float* out = a.part + (long)blockIdx.x * (C::MB * 16 * COUT);
+    float* out = a.part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (C::MB * 16 * COUT);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       const int t = T0 + j, mb = t / NB, nb = t % NB;
@@ -1114,6 +1122,24 @@ static hipError_t f2_wgrad_launch(const WgArgs& a, int inact, long workers, hipS
   }
   if (inact == DIS_ACT_SELU) return launch(conv_wgrad_f16x2_kernel<CIN, COUT, DIS_ACT_SELU>, 1);
   if (inact == 0) return launch(conv_wgrad_f16x2_kernel<CIN, COUT, 0>, 0);
+  return hipErrorInvalidValue;
+}
+
+// slice-pair form (conv2d.hip wgrad_pairs_launch, 3 x 3 stride 1): grid = (workers per pair, pairs); cob = gy channels per pair
+hipError_t dis_f2_wgrad_pairs_launch(const WgArgs& a, int cob, unsigned workers, unsigned pairs, hipStream_t stream) {
+  static bool attr_set[2] = {};
+  auto launch = [&](auto kern, int lds, int slot) -> hipError_t {
+    if (!attr_set[slot]) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+      attr_set[slot] = true;
+    }
+    DIS_TAG("conv_wgrad_f16x2_kernel slice pairs");
+    hipLaunchKernelGGL(kern, dim3(workers, pairs), dim3(256), lds, stream, a);
+    return hipSuccess;
+  };
+  if (cob == 32) return launch(conv_wgrad_f16x2_kernel<32, 32, 0, false, true>, F2WxCfg<32, 32>::LDS_BYTES, 0);
+  if (cob == 16) return launch(conv_wgrad_f16x2_kernel<32, 16, 0, false, true>, F2WxCfg<32, 16>::LDS_BYTES, 1);
   return hipErrorInvalidValue;
 }
 
