@@ -1726,7 +1726,7 @@ static inline int wgrad_reduce_grid(long total, bool bias) {
   if (g > 1024) g = 1024;
   return (bias && g < 16) ? 16 : (int)g;  // the bias part needs cout/8 <= 16 blocks
 }
-#define WG_WORKERS 512
+#define WG_WORKERS 768
 
 template <int CIN, int COUT, int KH, int KW, int S>
 static long wgrad_ws(void) {
@@ -2092,7 +2092,7 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
   }
   const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + 7) / 8;
   const long ntiles = (long)a.n * tiles_y * tiles_x;
-  long workers = 2L * num_cus();
+  long workers = (dis_f2_enabled() ? (long)dis_f2_wgrad_wpc() : 2L) * num_cus();
   if (workers > WG_WORKERS) workers = WG_WORKERS;
   if (workers > ntiles) workers = ntiles;
   const long elems = C::PART;

@@ -800,13 +800,19 @@ struct F2WxCfg {
   static constexpr int CVX = CIN / 4, CVG = COUT / 4;
   static constexpr int IR = TR - 1 + K, IC = 15 + K;
   static constexpr int X_U16 = IR * IC * PSX, G_U16 = TR * 16 * PSG;
-  static constexpr int LDS_BYTES = (X_U16 + G_U16) * 2 + 1024 * 4 + 64;  // + bias partials + wave maxima [parity][x|g][wave]
+  // + wave maxima [parity][x|g][wave]; the bias partials (1024 floats, end of the kernel only) alias the x halo
+  static constexpr int LDS_BYTES = (X_U16 + G_U16) * 2 + 64;
+  static_assert(X_U16 * 2 >= 1024 * 4, "bias partials alias the x halo");
   static constexpr int NIX = IR * IC * CVX, NLX = (NIX + 255) / 256;
   static constexpr int NLG = TR * 16 * CVG / 256;
   static constexpr int KSN = TR / 2;
   static constexpr int MB = K * K * CIN / 16, NB = COUT / 16, T = MB * NB, TW = (T + 3) / 4;
 };
 
+#ifndef F2W_WPC
+#define F2W_WPC 2   // workgroups per CU (= waves per SIMD) the weight-gradient kernel is built for
+#endif
+int dis_f2_wgrad_wpc() { return F2W_WPC; }
 typedef short f2_s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ s16x8 f2_tr_read8(const unsigned short* p0, const unsigned short* p1) {
   const f2_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) f2_s16x4*)p0);
@@ -825,7 +831,7 @@ __device__ __forceinline__ void f2_static_for(F&& f) {
 // selects x channels [32 cb, 32 cb + 32) and gy channels [COUT gb, + COUT) of pixels that occupy a.ldx / a.ldg floats; channels
 // past the layer's last one load zeros; one slab per (pair, worker).
 template <int CIN, int COUT, int INACT = 0, bool INGN = false, bool GEN = false>
-__global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
+__global__ __launch_bounds__(256, F2W_WPC) void conv_wgrad_f16x2_kernel(WgArgs a) {
   using C = F2WxCfg<CIN, COUT>;
   static_assert(!GEN || (CIN == 32 && INACT == 0 && !INGN), "slice-pair form");
   const int ldx = GEN ? a.ldx : CIN, ldg = GEN ? a.ldg : COUT;
@@ -837,8 +843,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   unsigned short* xl = smem16;
   unsigned short* gl = smem16 + C::X_U16;
-  float* bred = (float*)(smem16 + C::X_U16 + C::G_U16);
-  float* mxs = bred + 1024;  // [parity][x | g][wave]
+  float* bred = (float*)smem16;                                   // (after the last tile: aliases the x halo)
+  float* mxs = (float*)(smem16 + C::X_U16 + C::G_U16);  // [parity][x | g][wave]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lg = lane >> 4, l16 = lane & 15, tq = l16 >> 2, tp = l16 & 3;
   const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + TR - 1) / TR;
@@ -1099,7 +1105,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f16x2_kernel(WgArgs a) {
 template <int CIN, int COUT>
 static hipError_t f2_wgrad_launch(const WgArgs& a, int inact, long workers, hipStream_t stream) {
   using C = F2WxCfg<CIN, COUT>;
-  static_assert(2 * C::LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+  static_assert(F2W_WPC * C::LDS_BYTES <= 160 * 1024, "workgroups per CU");
   const bool ingn = a.gn_stats != nullptr;
   static bool attr_set[3] = {};
   auto launch = [&](auto kern, int slot) -> hipError_t {

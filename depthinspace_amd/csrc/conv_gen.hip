@@ -48,6 +48,12 @@ struct GenArgs {
   int tpack, ntaps_real;
   // two-term fp16 streaming kernel (convg2_fwd_kernel): block-scale workspace of this call, see CG2_WS below; null otherwise
   const float* f2ws;
+  // ... split-K (small maps: fewer workgroups than CUs, each with hundreds of dependent k-steps): blockIdx.y = split takes the
+  // k-steps [nk * split / ksplit, nk * (split + 1) / ksplit) and leaves its raw sums in skpart[split][m][nblk * BN]; the
+  // reduce launch adds the splits in a fixed order, then bias + activation.  ksplit = 1: the kernel writes y itself.
+  int ksplit;
+  float* skpart;
+  long skcap;   // floats available at skpart
 };
 
 template <int BN>
@@ -558,8 +564,9 @@ __global__ __launch_bounds__(256, 2) void convg2_fwd_kernel(GenArgs a) {
   float4 ra[3][4];
   u32x4 rb[3][NBQ];
   const u32x4* wq = (const u32x4*)a.w;
-  const int nk = a.ntaps * a.nchunk;
-  int ptap = 0, pchunk = 0, pnext = 0;  // cursor of the next k-step to request
+  const int nk_all = a.ntaps * a.nchunk;
+  const int k0 = (int)((long)nk_all * blockIdx.y / a.ksplit), nk = (int)((long)nk_all * (blockIdx.y + 1) / a.ksplit);
+  int ptap = k0 / a.nchunk, pchunk = k0 % a.nchunk, pnext = k0;  // cursor of the next k-step to request
   auto prefetch = [&](auto setc) __attribute__((always_inline)) {
     constexpr int set = decltype(setc)::value;
     if (pnext >= nk) return;
@@ -649,10 +656,10 @@ __global__ __launch_bounds__(256, 2) void convg2_fwd_kernel(GenArgs a) {
     }
     __syncthreads();
   };
-  for (int ks = 0; ks < nk; ks += 3) {
-    body(ks, S0{});
-    if (ks + 1 < nk) body(ks + 1, S1{});
-    if (ks + 2 < nk) body(ks + 2, S2{});
+  for (int ks = k0; ks < nk; ks += 3) {   // (the LDS buffer parity follows the trip count, not the k-step index)
+    body(ks - k0, S0{});
+    if (ks + 1 < nk) body(ks - k0 + 1, S1{});
+    if (ks + 2 < nk) body(ks - k0 + 2, S2{});
   }
 
   // epilogue: undo the two block scales per output row (exact), then bias + activation, masked store of the real output channels
@@ -675,6 +682,12 @@ __global__ __launch_bounds__(256, 2) void convg2_fwd_kernel(GenArgs a) {
         if (m >= M) continue;
         const int vx = m % a.wv, t = m / a.wv, vy = t % a.hv, nn = t / a.hv;
         const float desc = __builtin_ldexpf(1.f, -(sexp[nn] + ew));
+        if (a.ksplit > 1) {   // split-K: this split's raw sums (block-uniform branch); bias and activation in the reduce launch
+          float* pp = a.skpart + ((long)blockIdx.y * M + m) * (a.nblk * BN) + nb * BN + li;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) pp[nt * 16] = acc[mt][nt][r] * desc;
+          continue;
+        }
         float* yp = a.y + (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff +
                     nb * BN + li;
 #pragma unroll
@@ -688,8 +701,38 @@ __global__ __launch_bounds__(256, 2) void convg2_fwd_kernel(GenArgs a) {
   else emit(std::integral_constant<int, DIS_ACT_NONE>{});
 }
 
+// split-K reduce of convg2_fwd_kernel: y[m][co] = act(sum over the splits (fixed order) + bias); one thread = 4 output channels
+__global__ __launch_bounds__(256) void convg2_splitk_reduce_kernel(GenArgs a, int coutp) {
+  const int M = a.n * a.hv * a.wv;
+  const int cq = (a.cout + 3) >> 2;
+  const long total = (long)M * cq;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / cq), co = (int)(i - (long)m * cq) * 4;
+    float4 sum = *(const float4*)(a.skpart + (long)m * coutp + co);
+    for (int sp = 1; sp < a.ksplit; ++sp) {
+      const float4 v = *(const float4*)(a.skpart + ((long)sp * M + m) * coutp + co);
+      sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+    }
+    const int vx = m % a.wv, t = m / a.wv, vy = t % a.hv, nn = t / a.hv;
+    float* yp = a.y + (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff + co;
+    const float s4[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (co + e < a.cout) yp[e] = act_apply(s4[e] + (a.bias ? a.bias[co + e] : 0.f), a.act);
+  }
+}
+
 static int cg_bn(int cout) { return cout > 32 ? 64 : (cout > 16 ? 32 : 16); }
 
+// split-K factor of the two-term streaming kernel: only when the launch has fewer workgroups than the device has CUs and a long
+// chain of k-steps; aims at ~2 workgroups per CU, at least 12 k-steps per split, at most 8 splits
+static int cg2_ksplit(long wgs, int nk) {
+  if (wgs >= 256 || nk < 48) return 1;
+  long ks = (512 + wgs - 1) / wgs;
+  if (ks > 8) ks = 8;
+  while (ks > 1 && nk / ks < 12) --ks;
+  return (int)ks;
+}
 // one launch of the forward-like kernel (packs its weights first)
 static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int co_real, long s_ci, long s_co,
                   const short* tsrc, hipStream_t s) {
@@ -713,10 +756,19 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
     const long M2 = (long)a.n * a.hv * a.wv;
     const long grid2 = ((M2 + CG_BM - 1) / CG_BM) * a.nblk;
     if (grid2 > 2147483647L) return DIS_ERR_BAD_SHAPE;
-    DIS_TAG("convg2_fwd_kernel (f16x2 streaming)");
-    if (bn == 64) hipLaunchKernelGGL(convg2_fwd_kernel<64>, dim3((unsigned)grid2), dim3(256), 0, s, a);
-    else if (bn == 32) hipLaunchKernelGGL(convg2_fwd_kernel<32>, dim3((unsigned)grid2), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(convg2_fwd_kernel<16>, dim3((unsigned)grid2), dim3(256), 0, s, a);
+    // split-K for the small maps (see GenArgs::ksplit): enough workgroups to fill the device twice, >= 12 k-steps per split
+    const int nk2 = a.ntaps * a.nchunk, coutp = a.nblk * bn;
+    int ksplit = cg2_ksplit(grid2, nk2);
+    while (ksplit > 1 && (long)ksplit * M2 * coutp > a.skcap) --ksplit;
+    if (!a.skpart) ksplit = 1;
+    a.ksplit = ksplit;
+    DIS_TAG(ksplit > 1 ? "convg2_fwd_kernel (f16x2 streaming, split-K)" : "convg2_fwd_kernel (f16x2 streaming)");
+    const dim3 g2((unsigned)grid2, (unsigned)ksplit);
+    if (bn == 64) hipLaunchKernelGGL(convg2_fwd_kernel<64>, g2, dim3(256), 0, s, a);
+    else if (bn == 32) hipLaunchKernelGGL(convg2_fwd_kernel<32>, g2, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(convg2_fwd_kernel<16>, g2, dim3(256), 0, s, a);
+    if (ksplit > 1)
+      hipLaunchKernelGGL(convg2_splitk_reduce_kernel, dim3(dis_ew_grid(M2 * ((a.cout + 3) / 4), 256)), dim3(256), 0, s, a, coutp);
     DIS_CHECK_LAUNCH();
     return DIS_OK;
   }
@@ -763,6 +815,36 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
   return DIS_OK;
 }
 
+// floats of split-K partial sums dis_convg_run may need BEHIND its packing slices (0: none); wpack must hold
+// dis_convg_pack_workspace() x phases + this many floats (phases = 4 for the stride-2 input-gradient / transposed modes)
+extern "C" long dis_convg_splitk_workspace(int mode, int n, int hin, int win, int hout, int wout, int cin, int cout, int k,
+                                           int stride, int pad) {
+  if (n <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || cin <= 0 || cout <= 0 || k <= 0 || k * k > CG_MAXTAPS || pad < 0)
+    return -1;
+  if (cin < CG3_CK || n > CG2_NMAX) return 0;
+  const int bn = cg_bn(cout);
+  const long nblk = (cout + bn - 1) / bn, nchunk = (cin + CG3_CK - 1) / CG3_CK;
+  auto need = [&](long hv, long wv, int ntaps) -> long {
+    const long M = (long)n * hv * wv;
+    if (M <= 0 || ntaps <= 0) return 0;
+    const int ks = cg2_ksplit(((M + CG_BM - 1) / CG_BM) * nblk, (int)(ntaps * nchunk));
+    return ks > 1 ? (long)ks * M * nblk * bn : 0;
+  };
+  const bool phased = (mode == DIS_CONVG_CONV_DGRAD || mode == DIS_CONVG_TCONV) && stride == 2;
+  if (!phased) return need(hout, wout, k * k);
+  long best = 0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      int nt = 0;
+      for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx)
+          if (!((py + pad - ky) & 1) && !((px + pad - kx) & 1)) ++nt;
+      const long v = need((hout - py + 1) / 2, (wout - px + 1) / 2, nt);
+      best = v > best ? v : best;
+    }
+  return best;
+}
+
 extern "C" long dis_convg_pack_workspace(int cin, int cout, int k) {
   if (cin <= 0 || cout <= 0 || k <= 0 || k * k > CG_MAXTAPS) return -1;
   const int bn = cg_bn(cout);
@@ -803,8 +885,12 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
   a.hf = hout; a.wf = wout; a.ldy = ldy; a.yoff = yoff; a.cout = cout; a.act = act;
   short tsrc[CG_MAXTAPS];
   const long kk = (long)k * k;
-  a.f2ws = nullptr;
+  a.f2ws = nullptr; a.ksplit = 1; a.skpart = nullptr; a.skcap = 0;
   if (dis_f2_enabled() && cin >= CG3_CK && n <= CG2_NMAX) {
+    // (split-K partial sums: behind the packing slices, dis_convg_splitk_workspace floats)
+    const int phases = ((mode == DIS_CONVG_CONV_DGRAD || mode == DIS_CONVG_TCONV) && stride == 2) ? 4 : 1;
+    a.skcap = dis_convg_splitk_workspace(mode, n, hin, win, hout, wout, cin, cout, k, stride, pad);
+    a.skpart = a.skcap > 0 ? wpack + dis_convg_pack_workspace(cin, cout, k) * phases : nullptr;
     // two-term fp16 form: block maxima of this call's x (per sample) and weights, one launch in front of the packing launch(es)
     float* f2ws = wpack + dis_convg_pack_workspace(cin, cout, k) - CG2_WS;
     hipLaunchKernelGGL(convg2_absmax_kernel, dim3(n * CG2_XB + CG2_WB), dim3(256), 0, s, x, n, (long)hin * win, ldx, xoff, cin, w,

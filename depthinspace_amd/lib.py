@@ -103,6 +103,7 @@ SIGS = {
     'dis_conv3d_csr_workspace': 'iiiii',
     'dis_conv3d_csr_build': 'ppiiiiip',
     'dis_convg_pack_workspace': 'iii',
+    'dis_convg_splitk_workspace': 'iiiiiiiiiii',
     'dis_convg_run': 'ipiipppiip' + 'iiiiiiiiiiiii' + 'p',
     'dis_convg_wgrad_workspace': 'iiiiii',
     'dis_convg_wgrad': 'piiiiiipiiiiiipp' + 'iiiip',
@@ -124,7 +125,7 @@ SIGS = {
     'dis_adam_step': 'pppplfddfifp',
     'dis_adam_step_dev': 'pppplfddfpfp',
 }
-_RET_LONG = {'dis_conv2d_gnsums_slots', 'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
+_RET_LONG = {'dis_convg_splitk_workspace', 'dis_conv2d_gnsums_slots', 'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
              'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_act_bwd_ld_bias_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_geo_loss_acc_doubles', 'dis_conv3d_knn_bwd_det_workspace', 'dis_conv3d_knn_bwd_stage', 'dis_conv3d_csr_workspace', 'dis_gather_csr_workspace',
              'dis_conv2d_pack_bf16x3_size', 'dis_disp_head_bwd_workspace'}
 

@@ -1159,7 +1159,8 @@ def _convg_run(mode, x, w, bias, y, n, hin, win, cin, cin_w, hout, wout, cout, c
     if per < 0:
         raise lib.DisHipError(f'convg: unsupported shape cin={cin} cout={cout} k={k}')
     phases = 4 if (mode in (CONVG_CONV_DGRAD, CONVG_TCONV) and stride == 2) else 1
-    wp = torch.empty(per * phases, dtype=torch.float32, device=x.device)
+    sk = lib.fn('dis_convg_splitk_workspace')(mode, n, hin, win, hout, wout, cin, cout, k, stride, pad)   # (small maps: split-K partials)
+    wp = torch.empty(per * phases + max(sk, 0), dtype=torch.float32, device=x.device)
     lib.call('dis_convg_run', mode, x, _ld(x), 0, w, bias, y, _ld(y), 0, wp, n, hin, win, cin, cin_w, hout,
              wout, cout, cout_w, k, stride, pad, act)
 

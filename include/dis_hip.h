@@ -470,14 +470,20 @@ int dis_conv3d_knn_bwd_agg(const float* geom, const float* wf, const float* dens
  *   DIS_CONVG_TCONV_DGRAD x := gradient wrt the (cropped) transposed-conv output; y := gradient wrt its input;
  *                         w is the transposed conv's weight [cout_w][cin_w][k][k]
  * wpack: workspace of dis_convg_pack_workspace(cin,cout,k) floats (x4 for the two phase-decomposed cases:
- * CONV_DGRAD and TCONV with stride 2).
+ * CONV_DGRAD and TCONV with stride 2) PLUS dis_convg_splitk_workspace(...) floats (round 4; 0 for most calls: partial sums of
+ * the split-K form small maps take under the two-term fp16 split).
  * Routing (same results, same contract): 3x3 (and 7x7, one launch per tap row) stride-1 CONV / CONV_DGRAD calls with
- * <= 10 32x32 channel-slice launches and >= 400k pixels run on the halo-resident bf16x3 kernel; everything else streams. */
+ * <= 10 32x32 channel-slice launches and >= 400k pixels run on the halo-resident kernels; everything else streams.
+ * Arithmetic (dis_set_conv_split, default 1): layers with >= 32 input channels multiply two-term fp16 operands (3 products per
+ * MAC, fp32 accumulate; one power-of-two scale per image of x - per halo tile in the slice launches - and one per weight
+ * tensor); dis_set_conv_split(0) selects the three-term bf16 split (6 products, >= 24-bit operands) everywhere. */
 #define DIS_CONVG_CONV 0
 #define DIS_CONVG_CONV_DGRAD 1
 #define DIS_CONVG_TCONV 2
 #define DIS_CONVG_TCONV_DGRAD 3
 long dis_convg_pack_workspace(int cin, int cout, int k);
+long dis_convg_splitk_workspace(int mode, int n, int hin, int win, int hout, int wout, int cin, int cout, int k, int stride,
+                                int pad);
 int dis_convg_run(int mode, const float* x, int ldx, int xoff, const float* w, const float* bias, float* y, int ldy,
                   int yoff, float* wpack, int n, int hin, int win, int cin, int cin_w, int hout, int wout, int cout,
                   int cout_w, int k, int stride, int pad, int act, void* stream);
