@@ -51,6 +51,12 @@ struct GenArgsB {
   int dy0, dx0, HR, HC, PS, TP, nks, GT, tiles_x, tiles_y;
   int trh;         // tile rows: 8 (2 per wave) or 16 (4 per wave)
   int res, wsz16;  // weights of a cout block resident in LDS (all chunks); 16-bit words of the weight region in front of the halo
+  // convb_fwd128_kernel, split-K (small maps: fewer workgroups than CUs, each with a long chain of dependent stages):
+  // blockIdx.y = split takes the stages [nk * split / ksplit, nk * (split + 1) / ksplit) and leaves its raw fp32 sums in
+  // skpart[split][m][nblk * BN]; convb_splitk_reduce_kernel adds the splits in a fixed order, then bias + activation + store
+  int ksplit;
+  float* skpart;
+  long skcap;  // floats available at skpart
 };
 
 template <int BN, bool XB, bool YB>
@@ -236,12 +242,13 @@ __global__ __launch_bounds__(256) void convb_fwd128_kernel(GenArgsB a) {
     pix[j] = vx * a.S;
   }
   const int nst = (a.nchunk + 3) >> 2;  // stages per tap
-  const int nk = a.ntaps * nst;
+  const int nk_all = a.ntaps * nst;
+  const int k0 = (int)((long)nk_all * blockIdx.y / a.ksplit), nk = (int)((long)nk_all * (blockIdx.y + 1) / a.ksplit);
   u32x4 ra[2][2][4], rb[2][4];
   const u32x4* wq = (const u32x4*)a.w;
   const int bvec = 4 * BN;            // 16-byte vectors of one 32-channel weight block
   const bool wload = tid < bvec;
-  int ptap = 0, pst = 0, pnext = 0;
+  int ptap = k0 / nst, pst = k0 % nst, pnext = k0;
   auto prefetch = [&](auto setc) __attribute__((always_inline)) {
     constexpr int set = decltype(setc)::value;
     if (pnext >= nk) return;
@@ -312,9 +319,21 @@ __global__ __launch_bounds__(256) void convb_fwd128_kernel(GenArgsB a) {
                                                                __builtin_bit_cast(bf16x8, fa[mt]), acc[mt][nt], 0, 0, 0);
     }
   };
-  for (int ks = 0; ks < nk; ks += 2) {
+  for (int ks = k0; ks < nk; ks += 2) {
     body(S0{});
     if (ks + 1 < nk) body(S1{});
+  }
+  if (a.ksplit > 1) {  // split-K: this split's raw sums; bias, activation and the store in the reduce launch
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = m0 + wave * 32 + mt * 16 + li;
+      if (m >= M) continue;
+      float* pp = a.skpart + ((long)blockIdx.y * M + m) * (a.nblk * BN) + nb * BN + lg * 4;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        *(float4*)(pp + nt * 16) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+    }
+    return;
   }
   auto emit = [&](auto actc) {
     constexpr int ACT = decltype(actc)::value;
@@ -349,6 +368,41 @@ __global__ __launch_bounds__(256) void convb_fwd128_kernel(GenArgsB a) {
   if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{});
   else if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{});
   else emit(std::integral_constant<int, DIS_ACT_NONE>{});
+}
+
+// split-K reduce of convb_fwd128_kernel: y[m][co] = act(sum over the splits (fixed order) + bias); one thread = 4 output channels
+template <bool YB>
+__global__ __launch_bounds__(256) void convb_splitk_reduce_kernel(GenArgsB a, int coutp) {
+  const int M = a.n * a.hv * a.wv;
+  const int cq = (a.cout + 3) >> 2;
+  const long total = (long)M * cq;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / cq), co = (int)(i - (long)m * cq) * 4;
+    float4 sum = *(const float4*)(a.skpart + (long)m * coutp + co);
+    for (int sp = 1; sp < a.ksplit; ++sp) {
+      const float4 v = *(const float4*)(a.skpart + ((long)sp * M + m) * coutp + co);
+      sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+    }
+    const int vx = m % a.wv, t = m / a.wv, vy = t % a.hv, nn = t / a.hv;
+    const long pe = (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff + co;
+    const float s4[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (co + e >= a.cout) continue;
+      const float o = act_apply(s4[e] + (a.bias ? a.bias[co + e] : 0.f), a.act);
+      if (YB) ((bf16_t*)a.y)[pe + e] = (bf16_t)(cb_pack2(o, 0.f) & 0xffffu);
+      else ((float*)a.y)[pe + e] = o;
+    }
+  }
+}
+// split-K factor: only when the launch has fewer workgroups than the device has CUs and a long chain of stages; aims at ~2
+// workgroups per CU, at least 6 stages (of 128 channels) per split, at most 8 splits
+static int cb_ksplit(long wgs, int nk) {
+  if (wgs >= 256 || nk < 24) return 1;
+  long ks = (512 + wgs - 1) / wgs;
+  if (ks > 8) ks = 8;
+  while (ks > 1 && nk / ks < 6) --ks;
+  return (int)ks;
 }
 
 // packed[tap][chunk][nb][lg][col][j] = bf16(W(tap, ci = chunk*32 + lg*8 + j, co = nb*BN + col))
@@ -854,11 +908,22 @@ static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t
   if (grid > 2147483647L) return DIS_ERR_BAD_SHAPE;
   static const bool no128 = getenv("DIS_CONVB_128") && getenv("DIS_CONVB_128")[0] == '0';
   if (x_bf16 && a.cin >= 128 && bn >= 32 && !no128) {  // deep layers: 128-channel stages
-    DIS_TAG("convb_fwd128_kernel (bf16 streaming, 128-channel stages)");
-    if (bn == 64 && y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<64, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else if (bn == 64) hipLaunchKernelGGL((convb_fwd128_kernel<64, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else if (y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<32, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((convb_fwd128_kernel<32, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    const int nk128 = a.ntaps * ((a.nchunk + 3) >> 2), coutp = a.nblk * bn;
+    int ksplit = a.skpart ? cb_ksplit(grid, nk128) : 1;
+    while (ksplit > 1 && (long)ksplit * M * coutp > a.skcap) --ksplit;
+    a.ksplit = ksplit;
+    DIS_TAG(ksplit > 1 ? "convb_fwd128_kernel (bf16 streaming, 128-channel stages, split-K)"
+                       : "convb_fwd128_kernel (bf16 streaming, 128-channel stages)");
+    const dim3 g((unsigned)grid, (unsigned)ksplit);
+    if (bn == 64 && y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<64, true>), g, dim3(256), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((convb_fwd128_kernel<64, false>), g, dim3(256), 0, s, a);
+    else if (y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<32, true>), g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((convb_fwd128_kernel<32, false>), g, dim3(256), 0, s, a);
+    if (ksplit > 1) {
+      const int rg = dis_ew_grid(M * ((a.cout + 3) / 4), 256);
+      if (y_bf16) hipLaunchKernelGGL((convb_splitk_reduce_kernel<true>), dim3(rg), dim3(256), 0, s, a, coutp);
+      else hipLaunchKernelGGL((convb_splitk_reduce_kernel<false>), dim3(rg), dim3(256), 0, s, a, coutp);
+    }
     DIS_CHECK_LAUNCH();
     return DIS_OK;
   }
@@ -868,6 +933,35 @@ static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t
   else cb_launch<false, false>(a, bn, grid, s);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
+}
+
+// floats of split-K partial sums dis_convb_run may need BEHIND its four packing slices (0: none)
+extern "C" long dis_convb_splitk_workspace(int mode, int x_bf16, int n, int hin, int win, int hout, int wout, int cin, int cout,
+                                           int k, int stride, int pad) {
+  if (n <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || cin <= 0 || cout <= 0 || k <= 0 || k * k > CB_MAXTAPS || pad < 0)
+    return -1;
+  const int bn = cb_bn(cout);
+  if (!x_bf16 || cin < 128 || bn < 32) return 0;
+  const long nblk = (cout + bn - 1) / bn, nst = ((cin + CB_CK - 1) / CB_CK + 3) / 4;
+  auto need = [&](long hv, long wv, int ntaps) -> long {
+    const long M = (long)n * hv * wv;
+    if (M <= 0 || ntaps <= 0) return 0;
+    const int ks = cb_ksplit(((M + CB_BM - 1) / CB_BM) * nblk, (int)(ntaps * nst));
+    return ks > 1 ? (long)ks * M * nblk * bn : 0;
+  };
+  const bool phased = (mode == DIS_CONVG_CONV_DGRAD || mode == DIS_CONVG_TCONV) && stride == 2;
+  if (!phased) return need(hout, wout, k * k);
+  long best = 0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      int nt = 0;
+      for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx)
+          if (!((py + pad - ky) & 1) && !((px + pad - kx) & 1)) ++nt;
+      const long v = need((hout - py + 1) / 2, (wout - px + 1) / 2, nt);
+      best = v > best ? v : best;
+    }
+  return best;
 }
 
 // workspace in 16-bit words for ONE phase
@@ -905,6 +999,10 @@ extern "C" int dis_convb_run(int mode, const void* x, int x_bf16, int ldx, int x
   short tsrc[CB_MAXTAPS];
   const long kk = (long)k * k;
   bf16_t* wp = (bf16_t*)wpack;
+  // (split-K partial sums of the small maps: behind the four packing slices)
+  a.ksplit = 1;
+  a.skcap = dis_convb_splitk_workspace(mode, x_bf16, n, hin, win, hout, wout, cin, cout, k, stride, pad);
+  a.skpart = a.skcap > 0 ? (float*)(wp + 4 * dis_convb_pack_workspace(cin, cout, k)) : nullptr;
   if (mode == DIS_CONVG_CONV || mode == DIS_CONVG_TCONV_DGRAD) {
     if (mode == DIS_CONVG_CONV) {
       if (hout != (hin + 2 * pad - k) / stride + 1 || wout != (win + 2 * pad - k) / stride + 1) return DIS_ERR_BAD_SHAPE;

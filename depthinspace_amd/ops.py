@@ -1368,7 +1368,8 @@ def _convb_run(mode, x, w, bias, y, n, hin, win, cin, cin_w, hout, wout, cout, c
     per = lib.fn('dis_convb_pack_workspace')(cin, cout, k)
     if per < 0:
         raise lib.DisHipError(f'convb: unsupported shape cin={cin} cout={cout} k={k}')
-    wp = torch.empty(per * 4, dtype=torch.int16, device=x.device)
+    sk = lib.fn('dis_convb_splitk_workspace')(mode, _isbf(x), n, hin, win, hout, wout, cin, cout, k, stride, pad)   # floats
+    wp = torch.empty(per * 4 + 2 * max(sk, 0), dtype=torch.int16, device=x.device)
     ldy = y.stride(2) if y.dim() == 4 else 1
     lib.call('dis_convb_run', mode, x, _isbf(x), _ld(x), 0, w, bias, y, _isbf(y), ldy, 0, wp, n, hin, win, cin, cin_w,
              hout, wout, cout, cout_w, k, stride, pad, act)

@@ -516,8 +516,12 @@ int dis_sigmoid_affine_bwd(const float* y, const float* gy, float* gpre4, float 
  * fp32.  Same modes / argument meaning as dis_convg_run and dis_convg_wgrad (reference model/networks.py:170-295:
  * Conv2d k7/k5/k3 s1/s2 + ReLU, ConvTranspose2d(k3,s2,p1,op1) + crop_like), with a storage flag per tensor
  * (x_bf16 / y_bf16 / g_bf16: 1 = bf16, 0 = fp32) and ld / channel offsets counted in ELEMENTS of the tensor's own
- * type (bf16: multiples of 8, fp32: multiples of 4).  dis_convb_pack_workspace counts 16-bit words per phase (x4). */
+ * type (bf16: multiples of 8, fp32: multiples of 4).  dis_convb_pack_workspace counts 16-bit words per phase (x4);
+ * wpack holds 4 x that many words PLUS dis_convb_splitk_workspace(...) floats (round 4; 0 for most calls: partial sums of the
+ * split-K form the small maps of the deep layers take). */
 long dis_convb_pack_workspace(int cin, int cout, int k);
+long dis_convb_splitk_workspace(int mode, int x_bf16, int n, int hin, int win, int hout, int wout, int cin, int cout, int k,
+                                int stride, int pad);
 int dis_convb_run(int mode, const void* x, int x_bf16, int ldx, int xoff, const float* w, const float* bias, void* y,
                   int y_bf16, int ldy, int yoff, void* wpack, int n, int hin, int win, int cin, int cin_w, int hout,
                   int wout, int cout, int cout_w, int k, int stride, int pad, int act, void* stream);
