@@ -600,6 +600,13 @@ def main():
                            lambda ia: 12.0 * ia[0] * ia[2] * ia[3], '12 B per pixel (VALU-bound: 81 taps x rsqrt)'))
         hbm.append(hbm_row('photometric_bwd', ('dis_photometric_bwd',),
                            lambda ia: 16.0 * ia[0] * ia[2] * ia[3], '16 B per pixel (VALU-bound)'))
+        # the round-4 census kernels: int args (s, n, h, w, block, type); s estimates share one target image
+        hbm.append(hbm_row('census_fwd_multi (census 9x9, s estimates against one image)', ('dis_photometric_fwd_multi',),
+                           lambda ia: (8.0 * ia[0] + 4.0) * ia[1] * ia[2] * ia[3],
+                           '8 B per pixel and estimate + 4 B per pixel for the shared image (VALU-bound: 81 taps x (s + 1) rsqrt)'))
+        hbm.append(hbm_row('census_bwd_multi', ('dis_photometric_bwd_multi',),
+                           lambda ia: (12.0 * ia[0] + 4.0) * ia[1] * ia[2] * ia[3],
+                           '12 B per pixel and estimate + 4 B per pixel for the shared image (VALU-bound)'))
         hbm.append(hbm_row('lcn_fwd', ('dis_lcn_fwd',), lambda ia: 12.0 * ia[0] * ia[1] * ia[2], '12 B per pixel'))
         hbm = [r for r in hbm if r is not None]
         top = sorted(per.items(), key=lambda kv: -kv[1][1])[:12]

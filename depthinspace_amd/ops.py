@@ -267,7 +267,15 @@ class _Photometric(torch.autograd.Function):
         return ges, None, None, None, None
 
 
+# DIS_PHOTO_SINGLE_VIA_MULTI=0: a single estimate stays on the general kernels (diagnostics)
+PHOTO_SINGLE_VIA_MULTI = _os_env.environ.get('DIS_PHOTO_SINGLE_VIA_MULTI', '1') != '0'
+
+
 def photometric(es, ta, block_size, type, eps):
+    # the census forms at the reference's window (9 x 9, one channel) run the round-4 kernels (csrc/pixel_ops.hip
+    # census_*_multi_kernel with one estimate: fused multiply-adds, sign by clamp); everything else the general kernels
+    if PHOTO_SINGLE_VIA_MULTI and es.dim() == 4 and photometric_multi_ok(1, es.shape[1], block_size, type):
+        return _PhotometricMulti.apply(es.unsqueeze(0), ta, block_size, type, eps)[0]
     return _Photometric.apply(es, ta, block_size, type, eps)
 
 

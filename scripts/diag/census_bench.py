@@ -38,6 +38,17 @@ def single_bwd():
         lib.call('dis_photometric_bwd', es[k], ta, go[k], ge[k], n, 1, h, w, 9, 3, 0.5)
 
 
+def multi1_fwd():
+    for k in range(S):
+        lib.call('dis_photometric_fwd_multi', es[k], ta, out[k], 1, n, h, w, 9, 3, 0.5)
+
+
+def multi1_bwd():
+    for k in range(S):
+        lib.call('dis_photometric_bwd_multi', es[k], ta, go[k], ge[k], 1, n, h, w, 9, 3, 0.5)
+
+
+print('4 x multi with ONE estimate: fwd %.3f ms, bwd %.3f ms' % (timeit(multi1_fwd), timeit(multi1_bwd)))
 print(os.environ.get('DIS_HIP_LIB', 'default'),
       'fwd 4 x single %.3f ms, multi %.3f ms;  bwd 4 x single %.3f ms, multi %.3f ms' % (
           timeit(single_fwd), timeit(lambda: lib.call('dis_photometric_fwd_multi', es, ta, out, S, n, h, w, 9, 3, 0.5)),

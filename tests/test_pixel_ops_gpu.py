@@ -92,7 +92,7 @@ def test_photometric_multi_equals_per_estimate_calls(type_id, s_n_h_w):
     name = {2: 'census_mse', 3: 'census_sad'}[type_id]
     for k in range(s):
         e1 = es[k].cuda().requires_grad_(True)
-        y1 = ops.photometric(e1, ta.cuda(), 9, type_id, 0.5)
+        y1 = ops._Photometric.apply(e1, ta.cuda(), 9, type_id, 0.5)   # (the general single-estimate kernels)
         y1.backward(go[k].cuda())
         close(outs[k], y1, 1e-7, 2e-6, what=f'fwd vs single {k}')   # (fused multiply-adds in the multi kernels: rounding level)
         close(e_m[k].grad, e1.grad, 1e-7, 1e-6, what=f'bwd vs single {k}')
