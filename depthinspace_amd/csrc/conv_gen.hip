@@ -439,12 +439,12 @@ __global__ __launch_bounds__(256, 2) void convg3_fwd_kernel(GenArgs a) {
 //   [CG2_EOFF, +n] ints    scale exponent per sample; [CG2_EOFF + CG2_NMAX] the weights'   (convg2_pack_kernel, block 0 / all)
 // ------------------------------------------------------------------------------------------------
 #define CG2_PS 80    // LDS pixel stride in 16-bit units (2 planes x 32 channels + 16 pad: 2 (mod 4) sixteen-byte units, see F2Cfg::PS)
-#define CG2_XB 8     // partial maxima per sample
+#define CG2_XB 32    // partial maxima per sample (8 left a 3.5 MB image to one workgroup: 31 us per call, 1.5 ms of a DIS-SF step)
 #define CG2_WB 256   // partial maxima of the weights (a 1024 x 512 x 3 x 3 weight is 4.7 M values: 64 blocks took longer than the conv)
 #define CG2_NMAX 224 // samples per call
 #define CG2_WOFF (CG2_NMAX * CG2_XB)
 #define CG2_EOFF (CG2_WOFF + CG2_WB)
-#define CG2_WS 2560  // >= CG2_EOFF + CG2_NMAX + 1, a multiple of 256
+#define CG2_WS 7936  // >= CG2_EOFF + CG2_NMAX + 1, a multiple of 256
 
 __global__ __launch_bounds__(256) void convg2_absmax_kernel(const float* __restrict__ x, int n, long hw, int ldx, int xoff, int cin,
                                                             const float* __restrict__ w, long wcount, float* __restrict__ ws) {
@@ -456,7 +456,20 @@ __global__ __launch_bounds__(256) void convg2_absmax_kernel(const float* __restr
     const long p_lo = hw * q / CG2_XB, p_hi = hw * (q + 1) / CG2_XB;
     const int cv = cin >> 2;
     const float* xb = x + ((long)nn * hw) * ldx + xoff;
-    for (long i = p_lo * cv + threadIdx.x; i < p_hi * cv; i += 256) {
+    const long i_hi = p_hi * cv;
+    long i = p_lo * cv + threadIdx.x;
+    for (; i + 768 < i_hi; i += 1024) {   // four independent loads in flight per thread
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long q = i + u * 256, p = q / cv;
+        v[u] = *(const float4*)(xb + p * ldx + (int)(q - p * cv) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        m = fmaxf(fmaxf(fmaxf(m, fabsf(v[u].x)), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
+    for (; i < i_hi; i += 256) {
       const long p = i / cv;
       const int c = (int)(i - p * cv);
       const float4 v = *(const float4*)(xb + p * ldx + c * 4);
