@@ -812,8 +812,8 @@ static bool cb_halo_plan(GenArgsB& a, int bn) {
   const long wall = (long)a.nchunk * a.nks * 4 * bn * 16, hal = (long)a.HR * a.HC * a.PS * 2;
   a.res = (256 + wall + hal <= 75 * 1024) ? 1 : 0;  // (two resident workgroups per CU at least: one alone cannot hide its LDS latency)
   a.wsz16 = (int)((a.res ? wall : 2L * a.GT * 4 * bn * 16) / 2);
-  static const bool t16res = getenv("DIS_CONVB_T16RES") && getenv("DIS_CONVB_T16RES")[0] == '1';   // (experiment: 16-row tiles for resident weights too)
-  if ((!a.res || (t16res && a.hv >= 128)) && a.hv >= 32) {
+  // (16-row tiles for the resident-weight layers as well: measured neutral, 5.51 vs 5.56 ms over the 33 halo launches of a step)
+  if (!a.res && a.hv >= 32) {
     // streaming weights: 16 x 16 tiles when the larger halo still leaves two workgroups per CU and 12 prefetch items per thread
     const int hr16 = 15 * a.S + (dy1 - dy0) + 1;
     const long hal16 = (long)hr16 * a.HC * a.PS * 2;
