@@ -760,6 +760,119 @@ __global__ void convb_pack_halo_kernel(PackArgsH a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One packing launch per STEP instead of one per call (round 4).  The packed weights of a call depend on the weights alone, which
+// change once per step (Adam): dis_convb_pack_record() makes every packing launch of the following calls also leave its descriptor
+// in a HOST array; the caller keeps the calls' wpack buffers alive, uploads the array once, and from then on runs
+// dis_convb_pack_batch() at the start of a step and dis_convb_run(mode | DIS_CONVB_PREPACKED) for the calls (~100 launches of
+// 5 - 7 us each become one).  The record is process-global host state, like dis_last_kernel: not thread-safe.
+// ------------------------------------------------------------------------------------------------
+struct PackDesc {
+  int kind;  // 0: streaming layout (convb_pack_kernel), 1: halo layout (convb_pack_halo_kernel)
+  int blk0;  // first workgroup of this descriptor in the batch launch (set when the record is stopped); nblk workgroups
+  int nblk, pad_;
+  PackArgsH a;  // (a superset of PackArgsB: tp / nks are the halo layout's)
+};
+static PackDesc* g_pack_rec = nullptr;
+static int g_pack_cap = 0, g_pack_n = 0;
+static void cb_pack_note(int kind, const PackArgsH& a) {
+  if (!g_pack_rec) return;
+  if (g_pack_n < g_pack_cap) {
+    g_pack_rec[g_pack_n].kind = kind;
+    g_pack_rec[g_pack_n].blk0 = g_pack_rec[g_pack_n].nblk = g_pack_rec[g_pack_n].pad_ = 0;
+    g_pack_rec[g_pack_n].a = a;
+  }
+  ++g_pack_n;  // (past the capacity: the caller sees count > capacity and does not use the record)
+}
+#define CB_PACK_EPB 4096  // packed values per workgroup (a descriptor gets ceil(total / CB_PACK_EPB) workgroups, at most 512)
+static long cb_pack_total(const PackDesc& d) {
+  return d.kind == 0 ? (long)d.a.ntaps * d.a.nchunk * d.a.nblk * 4 * d.a.bn * 8 : (long)d.a.nchunk * d.a.nblk * d.a.nks * 4 * d.a.bn * 8;
+}
+__global__ __launch_bounds__(256) void convb_pack_batch_kernel(const PackDesc* __restrict__ descs, int count) {
+  int lo = 0, hi = count - 1;  // the descriptor this workgroup belongs to: last one with blk0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk0 <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const PackDesc& d = descs[lo];
+  const PackArgsH& a = d.a;
+  const long first = (long)((int)blockIdx.x - d.blk0) * 256 + threadIdx.x, stride = (long)d.nblk * 256;
+  if (d.kind == 0) {
+    const long total = (long)a.ntaps * a.nchunk * a.nblk * 4 * a.bn * 8;
+    for (long i = first; i < total; i += stride) {
+      const int j = (int)(i & 7);
+      long r = i >> 3;
+      const int col = (int)(r % a.bn);
+      r /= a.bn;
+      const int lg = (int)(r & 3);
+      r >>= 2;
+      const int nb = (int)(r % a.nblk);
+      r /= a.nblk;
+      const int chunk = (int)(r % a.nchunk);
+      const int tap = (int)(r / a.nchunk);
+      const int ci = chunk * CB_CK + lg * 8 + j, co = nb * a.bn + col;
+      float v = 0.f;
+      if (ci < a.ci_real && co < a.co_real) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
+      a.packed[i] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
+    }
+  } else {
+    const long total = (long)a.nchunk * a.nblk * a.nks * 4 * a.bn * 8;
+    const int gpt = 4 / a.tp;
+    for (long i = first; i < total; i += stride) {
+      const int j = (int)(i & 7);
+      long r = i >> 3;
+      const int col = (int)(r % a.bn);
+      r /= a.bn;
+      const int lg = (int)(r & 3);
+      r >>= 2;
+      const int ks = (int)(r % a.nks);
+      r /= a.nks;
+      const int nb = (int)(r % a.nblk);
+      const int chunk = (int)(r / a.nblk);
+      const int tap = ks * a.tp + lg / gpt;
+      const int ci = chunk * CB_CK + (lg % gpt) * 8 + j, co = nb * a.bn + col;
+      float v = 0.f;
+      if (tap < a.ntaps && ci < a.ci_real && co < a.co_real) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
+      a.packed[i] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
+    }
+  }
+}
+extern "C" long dis_convb_pack_desc_bytes(void) { return (long)sizeof(PackDesc); }
+extern "C" int dis_convb_pack_record(void* host_descs, int capacity, int* count_out) {
+  if (host_descs) {  // start: descriptors of the following packing launches go to host_descs[0 .. capacity)
+    if (capacity <= 0) return DIS_ERR_BAD_SHAPE;
+    g_pack_rec = (PackDesc*)host_descs;
+    g_pack_cap = capacity;
+    g_pack_n = 0;
+    return DIS_OK;
+  }
+  if (!count_out) return DIS_ERR_NULL;  // stop: how many launches were seen (> capacity: the record is incomplete)
+  count_out[0] = g_pack_n;
+  // ... and the batch launch's plan: workgroups in proportion to the packed size; count_out[1] = workgroups in all
+  long blk = 0;
+  if (g_pack_rec && g_pack_n <= g_pack_cap)
+    for (int i = 0; i < g_pack_n; ++i) {
+      long nb = (cb_pack_total(g_pack_rec[i]) + CB_PACK_EPB - 1) / CB_PACK_EPB;
+      nb = nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+      g_pack_rec[i].blk0 = (int)blk;
+      g_pack_rec[i].nblk = (int)nb;
+      blk += nb;
+    }
+  count_out[1] = (int)blk;
+  g_pack_rec = nullptr;
+  g_pack_cap = g_pack_n = 0;
+  return DIS_OK;
+}
+extern "C" int dis_convb_pack_batch(const void* dev_descs, int count, int workgroups, void* stream) {
+  if (!dev_descs) return DIS_ERR_NULL;
+  if (count <= 0 || workgroups < count) return DIS_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(convb_pack_batch_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream,
+                     (const PackDesc*)dev_descs, count);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 static int cb_bn(int cout) {
   static const int cap = getenv("DIS_CONVB_BN") ? atoi(getenv("DIS_CONVB_BN")) : 64;   // (experiments: narrower cout blocks)
   const int bn = cout > 32 ? 64 : (cout > 16 ? 32 : 16);
@@ -864,7 +977,10 @@ static int cb_run_halo(GenArgsB a, int x_bf16, int y_bf16, int bn, const float* 
   p.ci_real = ci_real; p.co_real = co_real; p.tp = a.TP; p.nks = a.nks; p.s_ci = s_ci; p.s_co = s_co;
   for (int t = 0; t < a.ntaps; ++t) p.tsrc[t] = tsrc[t];
   const long ptotal = (long)a.nchunk * a.nblk * a.nks * 4 * bn * 8;
-  hipLaunchKernelGGL(convb_pack_halo_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
+  if (w_raw) {  // (null: the call runs on weights dis_convb_pack_batch has packed)
+    hipLaunchKernelGGL(convb_pack_halo_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
+    cb_pack_note(1, p);
+  }
   a.w = wpack;
   const long units = (long)a.n * a.tiles_y * a.tiles_x * a.nblk;
   if (units > 2147483647L) return DIS_ERR_BAD_SHAPE;
@@ -903,7 +1019,14 @@ static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t
   p.ci_real = ci_real; p.co_real = co_real; p.s_ci = s_ci; p.s_co = s_co;
   for (int t = 0; t < a.ntaps; ++t) p.tsrc[t] = tsrc[t];
   const long ptotal = (long)a.ntaps * a.nchunk * a.nblk * 4 * bn * 8;
-  hipLaunchKernelGGL(convb_pack_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
+  if (w_raw) {
+    hipLaunchKernelGGL(convb_pack_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
+    PackArgsH ph;
+    ph.w = p.w; ph.packed = p.packed; ph.ntaps = p.ntaps; ph.nchunk = p.nchunk; ph.nblk = p.nblk; ph.bn = p.bn;
+    ph.ci_real = p.ci_real; ph.co_real = p.co_real; ph.tp = 1; ph.nks = p.ntaps; ph.s_ci = p.s_ci; ph.s_co = p.s_co;
+    for (int t = 0; t < a.ntaps; ++t) ph.tsrc[t] = p.tsrc[t];
+    cb_pack_note(0, ph);
+  }
   a.w = wpack;
   const long grid = ((M + CB_BM - 1) / CB_BM) * a.nblk;
   if (grid > 2147483647L) return DIS_ERR_BAD_SHAPE;
@@ -982,7 +1105,10 @@ extern "C" int dis_convb_run(int mode, const void* x, int x_bf16, int ldx, int x
                              void* y, int y_bf16, int ldy, int yoff, void* wpack, int n, int hin, int win, int cin,
                              int cin_w, int hout, int wout, int cout, int cout_w, int k, int stride, int pad, int act,
                              void* stream) {
-  if (!x || !w || !y || !wpack) return DIS_ERR_NULL;
+  const bool prepacked = (mode & DIS_CONVB_PREPACKED) != 0;  // wpack already holds this call's packed weights (dis_convb_pack_batch)
+  mode &= ~DIS_CONVB_PREPACKED;
+  if (!x || (!w && !prepacked) || !y || !wpack) return DIS_ERR_NULL;
+  if (prepacked) w = nullptr;
   if (n <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || cin <= 0 || cout <= 0 || cin_w <= 0 || cout_w <= 0 ||
       k <= 0 || pad < 0)
     return DIS_ERR_BAD_SHAPE;

@@ -114,6 +114,9 @@ SIGS = {
     'dis_augment': 'pppppppiiip',
     'dis_convb_pack_workspace': 'iii',
     'dis_convb_splitk_workspace': 'iiiiiiiiiiii',
+    'dis_convb_pack_desc_bytes': '',
+    'dis_convb_pack_record': 'pip',
+    'dis_convb_pack_batch': 'piip',
     'dis_convb_run': 'ipiiipppiiip' + 'iiiiiiiiiiiii' + 'p',
     'dis_convb_wgrad_workspace': 'iiiiii',
     'dis_convb_wgrad': 'piiiiiiipiiiiiiipp' + 'iiiip',
@@ -126,7 +129,7 @@ SIGS = {
     'dis_adam_step': 'pppplfddfifp',
     'dis_adam_step_dev': 'pppplfddfpfp',
 }
-_RET_LONG = {'dis_convg_splitk_workspace', 'dis_convb_splitk_workspace', 'dis_conv2d_gnsums_slots', 'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
+_RET_LONG = {'dis_convb_pack_desc_bytes', 'dis_convg_splitk_workspace', 'dis_convb_splitk_workspace', 'dis_conv2d_gnsums_slots', 'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
              'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_act_bwd_ld_bias_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_geo_loss_acc_doubles', 'dis_conv3d_knn_bwd_det_workspace', 'dis_conv3d_knn_bwd_stage', 'dis_conv3d_csr_workspace', 'dis_gather_csr_workspace',
              'dis_conv2d_pack_bf16x3_size', 'dis_disp_head_bwd_workspace'}
 

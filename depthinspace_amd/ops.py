@@ -54,6 +54,71 @@ def begin_step(dev):
         a[0][:a[2]].zero_()   # only what was handed out since the last clear (the rest is still zero)
     a[1] = 0
     a[2] = 0
+    _PackBatch.begin_step(dev)
+
+
+class _PackBatch(object):
+    """One weight-packing launch per training step for the bf16 DispNetS path (dis_convb_pack_record / dis_convb_pack_batch).
+    Every dis_convb_run call packs its fp32 weights into its `wpack` workspace first (~100 launches of 5 - 7 us per step).  The packed
+    form depends on the weights alone, and those change once per step, so: the call sites keep PERSISTENT workspaces (keyed by
+    weight address and call geometry); the first begin_step() outside a graph capture starts a record, the next one stops it, uploads
+    the descriptors and from then on every begin_step() (FlatAdam.zero_grad, i.e. in front of the forward pass) packs ALL recorded
+    calls in one launch; the calls then pass DIS_CONVB_PREPACKED.  Calls that were not in the record (another network, inference
+    without begin_step) keep packing for themselves.  DIS_PACK_BATCH=0 disables it."""
+    enabled = _os_env.environ.get('DIS_PACK_BATCH', '1') != '0'
+    CAP = 1024
+    cache = {}        # key -> [wpack tensor, in_table]
+    state = 'idle'    # idle -> recording -> ready
+    used = None       # keys seen while recording
+    host = None
+    table = None
+    count = 0
+    blocks = 0
+    step = 0
+    packed_step = -1  # the step whose begin_step ran the batch launch
+
+    @classmethod
+    def begin_step(cls, dev):
+        cls.step += 1
+        if not cls.enabled:
+            return
+        capturing = torch.cuda.is_current_stream_capturing()
+        if cls.state == 'recording' and not capturing:
+            import ctypes
+            cnt = (ctypes.c_int * 2)(0, 0)
+            rc = lib.fn('dis_convb_pack_record')(None, 0, ctypes.cast(cnt, ctypes.c_void_p))
+            n, cls.blocks = cnt[0], cnt[1]
+            if rc == 0 and 0 < n <= cls.CAP:
+                nbytes = n * lib.fn('dis_convb_pack_desc_bytes')()
+                cls.table = torch.frombuffer(bytearray(cls.host.raw[:nbytes]), dtype=torch.uint8).to(dev)
+                cls.count = n
+                for k in cls.used:
+                    cls.cache[k][1] = True
+                cls.state = 'ready'
+            else:
+                cls.state = 'idle' if n == 0 else 'off'   # (no bf16 convolution ran / more calls than the table holds)
+            cls.used = None
+        if cls.state == 'ready':
+            lib.call('dis_convb_pack_batch', cls.table, cls.count, cls.blocks)
+            cls.packed_step = cls.step
+        elif cls.state == 'idle' and not capturing:
+            import ctypes
+            if cls.host is None:
+                cls.host = ctypes.create_string_buffer(cls.CAP * lib.fn('dis_convb_pack_desc_bytes')())
+            if lib.fn('dis_convb_pack_record')(ctypes.cast(cls.host, ctypes.c_void_p), cls.CAP, None) == 0:
+                cls.state, cls.used = 'recording', set()
+
+    @classmethod
+    def workspace(cls, key, words, dev):
+        """-> (wpack tensor, prepacked): the call's persistent workspace and whether this step's batch launch has filled it"""
+        if not cls.enabled:
+            return torch.empty(words, dtype=torch.int16, device=dev), False
+        ent = cls.cache.get(key)
+        if ent is None or ent[0].numel() != words or ent[0].device != dev:
+            ent = cls.cache[key] = [torch.empty(words, dtype=torch.int16, device=dev), False]
+        if cls.state == 'recording' and cls.used is not None:
+            cls.used.add(key)
+        return ent[0], (ent[1] and cls.state == 'ready' and cls.packed_step == cls.step)
 
 
 def _zeros_d(n, dev):
@@ -1372,15 +1437,19 @@ def _chk_act(*ts):
             raise RuntimeError('expected a dense nhwc tensor or a channel range of one (bf16: channels in multiples of 8)')
 
 
+CONVB_PREPACKED = 0x100   # include/dis_hip.h DIS_CONVB_PREPACKED
+
+
 def _convb_run(mode, x, w, bias, y, n, hin, win, cin, cin_w, hout, wout, cout, cout_w, k, stride, pad, act):
     per = lib.fn('dis_convb_pack_workspace')(cin, cout, k)
     if per < 0:
         raise lib.DisHipError(f'convb: unsupported shape cin={cin} cout={cout} k={k}')
     sk = lib.fn('dis_convb_splitk_workspace')(mode, _isbf(x), n, hin, win, hout, wout, cin, cout, k, stride, pad)   # floats
-    wp = torch.empty(per * 4 + 2 * max(sk, 0), dtype=torch.int16, device=x.device)
+    key = (w.data_ptr(), mode, _isbf(x), _isbf(y), n, hin, win, cin, cin_w, hout, wout, cout, cout_w, k, stride, pad)
+    wp, prepacked = _PackBatch.workspace(key, per * 4 + 2 * max(sk, 0), x.device)
     ldy = y.stride(2) if y.dim() == 4 else 1
-    lib.call('dis_convb_run', mode, x, _isbf(x), _ld(x), 0, w, bias, y, _isbf(y), ldy, 0, wp, n, hin, win, cin, cin_w,
-             hout, wout, cout, cout_w, k, stride, pad, act)
+    lib.call('dis_convb_run', mode | (CONVB_PREPACKED if prepacked else 0), x, _isbf(x), _ld(x), 0, w, bias, y, _isbf(y), ldy, 0,
+             wp, n, hin, win, cin, cin_w, hout, wout, cout, cout_w, k, stride, pad, act)
 
 
 def _convb_wgrad(X, hX, wX, cX, cX_w, G, hG, wG, cG, cG_w, gw, n, k, stride, pad):
@@ -1857,9 +1926,11 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, lr=1e-4, beta1=0.9, b
         raise RuntimeError('adam_step_dev: state must be a 4-element int32 CUDA(HIP) tensor')
     lib.call('dis_adam_step_dev', param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(beta1), float(beta2),
              float(eps), state, float(grad_scale))
+    _PackBatch.packed_step = -1   # the parameters moved: what this step's batch launch packed is stale (inference before the next step packs per call)
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     _chk(param, grad, exp_avg, exp_avg_sq)
+    _PackBatch.packed_step = -1
     lib.call('dis_adam_step', param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(beta1), float(beta2),
              float(eps), int(step), float(grad_scale))

@@ -522,6 +522,20 @@ int dis_sigmoid_affine_bwd(const float* y, const float* gy, float* gpre4, float 
 long dis_convb_pack_workspace(int cin, int cout, int k);
 long dis_convb_splitk_workspace(int mode, int x_bf16, int n, int hin, int win, int hout, int wout, int cin, int cout, int k,
                                 int stride, int pad);
+/* One packing launch per step (round 4).  A call's packed weights depend on its weights alone, which change once per step:
+ *   dis_convb_pack_record(host_descs, capacity, NULL)  every packing launch of the dis_convb_run calls that follow also leaves a
+ *                                                      descriptor (dis_convb_pack_desc_bytes() bytes) in the HOST array;
+ *   dis_convb_pack_record(NULL, 0, out)                stops; out[0] = descriptors seen (> capacity: the record is incomplete,
+ *                                                      do not use it), out[1] = workgroups of the batch launch (its plan is
+ *                                                      written into the descriptors: upload them AFTER the stop);
+ *   dis_convb_pack_batch(dev_descs, count, workgroups, stream)  packs all recorded calls' weights (into the wpack buffers they were
+ *                                                      recorded with: the caller keeps those alive and unchanged) in ONE launch;
+ *   dis_convb_run(mode | DIS_CONVB_PREPACKED, ...)     runs a recorded call on its packed weights (w may be NULL).
+ * The record is process-global host state (like dis_last_kernel), not thread-safe. */
+#define DIS_CONVB_PREPACKED 0x100
+long dis_convb_pack_desc_bytes(void);
+int dis_convb_pack_record(void* host_descs, int capacity, int* count_out);
+int dis_convb_pack_batch(const void* dev_descs, int count, int workgroups, void* stream);
 int dis_convb_run(int mode, const void* x, int x_bf16, int ldx, int xoff, const float* w, const float* bias, void* y,
                   int y_bf16, int ldy, int yoff, void* wpack, int n, int hin, int win, int cin, int cin_w, int hout,
                   int wout, int cout, int cout_w, int k, int stride, int pad, int act, void* stream);

@@ -209,3 +209,52 @@ def test_worker_trains_and_evaluates_in_bf16():
             d = out[0] if isinstance(out, (list, tuple)) else out
             assert d.dtype == torch.float32 and bool(torch.isfinite(d).all())
     np.testing.assert_allclose(losses['bf16'], losses['f32'], rtol=0.03, atol=2e-4)
+
+
+def test_batched_weight_packing_equals_per_call_packing():
+    """One packing launch per step (ops._PackBatch: dis_convb_pack_record / dis_convb_pack_batch / DIS_CONVB_PREPACKED) must be
+    invisible: three training steps of DIS-SF with bf16 activation storage at 64 x 56 with it (record in step 1, batch launch from
+    step 2 on) and without it give the same parameters (to the run-to-run noise of the step's float atomics; weights that are one
+    Adam step stale would be 1e-3 off), and an inference forward after the optimizer step packs for itself (the batch launch's
+    weights are stale by then)."""
+    import argparse
+    from depthinspace_amd import synth, ops
+    from depthinspace_amd.model import single_frame_worker, networks
+    from depthinspace_amd.trainer import FlatAdam
+    H, W = 64, 56
+    settings = synth.make_settings(H, W)
+    batch = {k: torch.from_numpy(v) for k, v in synth.make_batch(settings, 2, 4, seed=5).items()}
+
+    def run(enabled):
+        PB = ops._PackBatch
+        PB.enabled, PB.cache, PB.state, PB.used, PB.table, PB.count, PB.packed_step = enabled, {}, 'idle', None, None, 0, -1
+        args = argparse.Namespace(use_pseudo_gt=False, lcn_radius=5, track_length=4, data_type='synthetic',
+                                  architecture='single_frame', epochs=1, warmup_epochs=150, train_batch_size=2, max_disp=128)
+        worker = single_frame_worker.Worker(args, settings=settings, train_device='cuda:0')
+        torch.manual_seed(3)
+        net = networks.DispDecoder(channels_in=2, max_disp=128, imsizes=worker.imsizes, act_dtype=torch.bfloat16).cuda()
+        worker.build_losses(device=torch.device('cuda', 0))
+        worker.current_epoch = 2
+        worker.device_aug = False   # (no random augmentation: the two runs see the same images)
+        np.random.seed(0)
+        opt = FlatAdam(net.parameters(), lr=1e-3)
+        states = []
+        for _ in range(3):
+            worker.train_step(net, opt, batch)
+            states.append(PB.state)
+        with torch.no_grad():
+            worker.copy_data(batch, device=torch.device('cuda', 0), requires_grad=False, train=False)
+            out = worker.net_forward(net, worker.read_optical_flow(train=False))
+        torch.cuda.synchronize()
+        o = out[0] if isinstance(out, (list, tuple)) else out
+        return opt.flat_p.clone(), o.detach().float().clone(), states
+
+    try:
+        p1, o1, st1 = run(True)
+        assert st1 == ['recording', 'ready', 'ready'], st1
+        p0, o0, st0 = run(False)
+    finally:
+        PB = ops._PackBatch
+        PB.enabled, PB.cache, PB.state, PB.used, PB.table, PB.count, PB.packed_step = True, {}, 'idle', None, None, 0, -1
+    assert float((p1 - p0).abs().max()) < 2e-5, float((p1 - p0).abs().max())
+    assert float((o1 - o0).abs().max()) < 2e-3 * float(o0.abs().max()), float((o1 - o0).abs().max())
