@@ -54,6 +54,9 @@ struct GenArgs {
   int ksplit;
   float* skpart;
   long skcap;   // floats available at skpart
+  // two-term fp16 halo kernel (convh2_kernel): first tap offsets, halo extent, LDS pixel stride (16-bit words), taps per k-step,
+  // channels per plane, k-steps, k-steps per weight group, tile grid, tile rows, resident weights, 16-bit words of the weight region
+  int dy0, dx0, HR, HC, PS, TP, PL, nks, GT, tiles_x, tiles_y, trh, res, wsz16;
 };
 
 template <int BN>
@@ -735,6 +738,478 @@ __global__ __launch_bounds__(256) void convg2_splitk_reduce_kernel(GenArgs a, in
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Halo form of the two-term fp16 convolution, for the large maps of DispNetS (round 4; the structure of conv_bf16.hip's
+// convb_halo_kernel with fp32 tensors and two operand planes).  The streaming kernel above gathers - and SPLITS - the A tile of
+// every tap from global memory: a pixel is fetched through L2 and split k*k times, and a layer with few taps per output (the
+// four parity classes of a transposed convolution: 1 - 4 taps) is a chain of three dependent memory round trips per 128 pixels.
+// Here the input halo of an 8 x 16 (or 16 x 16) tile of virtual output positions is fetched ONCE per 32-channel chunk, split
+// once into [pixel][plane][channel] fp16 and every tap reads its MFMA operand from LDS at its own offset; the weights (packed
+// [chunk][cout block][k-step][plane][lane group][cout][8], pre-scaled) stay resident in LDS when a cout block's share fits
+// beside the halo, otherwise they stream in groups of GT k-steps double-buffered through registers.
+//   k-step = TP taps x 32/TP channels (TP = 2 for <= 16 input channels)
+//   wave w = tile rows MT w .. MT w + MT - 1 x 16 columns; lane (li, lg): column li, k-slice lg; 3 MFMAs per operand pair
+//   block scales: one per image (the exponents convg2_absmax_kernel / the packing launch leave in f2ws) and one for the weights
+// Persistent workgroups, XCD-contiguous shares of the (tile, cout block) units; the halo of the next stage (two stages with
+// resident weights) is in flight in registers - 16-byte items, NH per thread - while the current stage's MFMAs run.
+// ------------------------------------------------------------------------------------------------
+#define CH2_TC 16
+#define CH2_GVEC 1024  // 16-byte vectors of one weight group (16 KB): 4 per thread
+template <int BN, int NH, int MT, bool RES>
+__global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
+  constexpr int NT = BN / 16, TRH = 4 * MT, NSET = RES ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned short hsm[];
+  int* toff = (int*)hsm;                       // 64 ints
+  const int bsz = a.GT * 2 * 4 * BN * 8;       // 16-bit words of one weight buffer
+  unsigned short* Bb = hsm + 128;
+  unsigned short* halo = Bb + a.wsz16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int PS = a.PS, HC = a.HC, PL = a.PL, ipp = PL >> 2;   // items (4 channels) per pixel
+  const int* sexp = (const int*)a.f2ws + CG2_EOFF;
+  const int ntile = a.n * a.tiles_y * a.tiles_x;
+  auto unit_nb = [&](int uu) { return RES ? uu / ntile : uu % a.nblk; };
+  auto unit_tile = [&](int uu) { return RES ? uu % ntile : uu / a.nblk; };
+  if (tid < 64) {
+    int o = 0;
+    if (tid < a.ntaps) o = ((a.tdy[tid] - a.dy0) * HC + (a.tdx[tid] - a.dx0)) * PS;
+    toff[tid] = o;
+  }
+  const int units = ntile * a.nblk;
+  const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
+  const int xcd = blockIdx.x % nxcd, rank = blockIdx.x / nxcd, per = gridDim.x / nxcd;
+  const int u_hi = (int)((long)units * (xcd + 1) / nxcd);
+  int u = (int)((long)units * xcd / nxcd) + rank;
+  if (u >= u_hi) return;
+
+  const int gpt = 4 / a.TP;  // lane groups per tap
+  const int lgq = lg / gpt, cg = lg - lgq * gpt;
+  const int a_lane = (wave * MT * a.S * HC + li * a.S) * PS + cg * 8;
+  const int rowstep = a.S * HC * PS;
+  const u32x4* wq = (const u32x4*)a.w;
+  const int ngrp = (a.nks + a.GT - 1) / a.GT;
+  u32x4 rb[4];
+  auto pref_b = [&](int nb, int c, int g) __attribute__((always_inline)) {
+    const long base = ((long)(c * a.nblk + nb) * a.nks + g * a.GT) * (8 * BN);
+    const int cnt = min(a.GT, a.nks - g * a.GT) * (8 * BN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      rb[i] = wq[base + (idx < cnt ? idx : 0)];
+    }
+  };
+  // halo items of this thread: (row, column) inside the halo, first channel, LDS offset (fixed for the whole launch)
+  const int nitems = a.HR * HC * ipp;
+  int it_rc[NH], it_cg[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int i = tid + j * 256;
+    const int p = i / ipp, cgi = i - p * ipp;
+    const int r = p / HC, cc = p - r * HC;
+    it_rc[j] = i < nitems ? (r | (cc << 16)) : 0x4000;  // (past the end: a row outside every image)
+    it_cg[j] = cgi * 4 | ((p * PS + cgi * 4) << 8);
+  }
+  u32x4 pre[NSET][NH];
+  float psc[NSET];   // 2^(scale exponent) of the image the register set's stage belongs to
+  auto halo_issue = [&](int uu, int c, auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    int t = unit_tile(uu);
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y, nn = t / a.tiles_y;
+    const int iy0 = ty * TRH * a.S + a.dy0, ix0 = tx * CH2_TC * a.S + a.dx0;
+    const long sbase = (long)nn * a.hin * a.win;
+    psc[set] = __builtin_ldexpf(1.f, sexp[nn]);
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int iy = iy0 + (it_rc[j] & 0xffff), ix = ix0 + (it_rc[j] >> 16);
+      const int ch = c * CG3_CK + (it_cg[j] & 0xff);
+      const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win && ch < a.cin;
+      const long e = (sbase + (long)iy * a.win + ix) * a.ldx + a.xoff + ch;
+      pre[set][j] = __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.x, a.x_bytes), ok ? (unsigned)(e * 4) : BX_OOB, 0, 0);
+    }
+  };
+  auto halo_write = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    const float sc = psc[set];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      if (tid + j * 256 < nitems) {
+        const u32x4 v = pre[set][j];
+        unsigned a1, a2, b1, b2;
+        f2_split_pair_scaled(__uint_as_float(v[0]), __uint_as_float(v[1]), sc, a1, a2);
+        f2_split_pair_scaled(__uint_as_float(v[2]), __uint_as_float(v[3]), sc, b1, b2);
+        unsigned short* q = halo + (it_cg[j] >> 8);
+        *(uint2*)q = make_uint2(a1, b1);
+        *(uint2*)(q + PL) = make_uint2(a2, b2);
+      }
+    }
+  };
+
+  f32x4 acc[MT][NT], bias_v[NT];
+  int bias_nb = -1;
+  // k-steps [0, kn) of a weight block B ([k-step][plane][lg][BN][8]) whose tap offsets start at tq; software-pipelined by hand:
+  // the operands of k-step kk+1 are requested before the MFMAs of kk issue
+  auto ksteps = [&](const unsigned short* B, const int* tq, int kn) __attribute__((always_inline)) {
+    const unsigned short* bl = B + (lg * BN + li) * 8;
+    auto frag = [&](int kk, int to, s16x8 (&fa)[2][MT], s16x8 (&fb)[2][NT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa[p][mt] = *(const s16x8*)(halo + a_lane + mt * rowstep + to + p * PL);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fb[p][nt] = *(const s16x8*)(bl + ((kk * 2 + p) * 4 * BN + nt * 16) * 8);
+      }
+    };
+    auto mac = [&](const s16x8 (&fa)[2][MT], const s16x8 (&fb)[2][NT]) __attribute__((always_inline)) {
+      // smallest terms first: x2 w1, x1 w2, x1 w1
+      constexpr int PA[3] = {1, 0, 0};
+      constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fb[PB[q]][nt]),
+                                                                __builtin_bit_cast(f16x8_t, fa[PA[q]][mt]), acc[mt][nt], 0, 0, 0);
+    };
+    s16x8 fa0[2][MT], fb0[2][NT], fa1[2][MT], fb1[2][NT];
+    int to0 = tq[0], to1 = kn > 1 ? tq[a.TP] : 0;
+    frag(0, to0, fa0, fb0);
+    for (int kk = 0; kk < kn; kk += 2) {
+      if (kk + 1 < kn) frag(kk + 1, to1, fa1, fb1);
+      to0 = kk + 2 < kn ? tq[(kk + 2) * a.TP] : 0;
+      mac(fa0, fb0);
+      if (kk + 1 < kn) {
+        if (kk + 2 < kn) frag(kk + 2, to0, fa0, fb0);
+        to1 = kk + 3 < kn ? tq[(kk + 3) * a.TP] : 0;
+        mac(fa1, fb1);
+      }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, NSET - 1>;
+  auto load_bias = [&](int nb) __attribute__((always_inline)) {
+    if (nb == bias_nb) return;
+    bias_nb = nb;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = nb * BN + nt * 16 + lg * 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < a.cout) bv[r] = a.bias[co + r];
+      }
+      bias_v[nt] = bv;
+    }
+  };
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  const int ew = sexp[CG2_NMAX];
+  // epilogue: lane (li, lg) holds couts nb*BN + nt*16 + lg*4 + {0..3} of position (ty*TRH + wave*MT + mt, tx*16 + li); the two
+  // block scales are undone first (exact: powers of two)
+  auto epilogue = [&](int uu, int nb) __attribute__((always_inline)) {
+    int t = unit_tile(uu);
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y, nn = t / a.tiles_y;
+    const float desc = __builtin_ldexpf(1.f, -(sexp[nn] + ew));
+    auto emit = [&](auto actc) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int vy = ty * TRH + wave * MT + mt, vx = tx * CH2_TC + li;
+        if (vy >= a.hv || vx >= a.wv) continue;
+        const long pe = (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = nb * BN + nt * 16 + lg * 4;
+          if (co >= a.cout) continue;
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[mt][nt][r] * desc + bias_v[nt][r], ACT);
+          if (co + 4 <= a.cout && ((pe + co) & 3) == 0) {
+            *(float4*)(a.y + pe + co) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+            for (int r = 0; r < 4 && co + r < a.cout; ++r) a.y[pe + co + r] = o[r];
+          }
+        }
+      }
+    };
+    if (a.act == DIS_ACT_RELU) emit(std::integral_constant<int, DIS_ACT_RELU>{});
+    else if (a.act == DIS_ACT_SELU) emit(std::integral_constant<int, DIS_ACT_SELU>{});
+    else emit(std::integral_constant<int, DIS_ACT_NONE>{});
+  };
+
+  if constexpr (RES) {
+    // Resident weights.  The walk is a flat sequence of stages (unit, chunk); the halos of the next TWO stages are in flight
+    // (register sets alternate): a stage of a narrow high-resolution layer is far shorter than a memory round trip.
+    int u1 = u, c1 = 0, u2 = u, c2 = 0;  // cursors of the stages held by the register sets after the current one
+    auto advance = [&](int& uu, int& cc) __attribute__((always_inline)) {
+      if (cc + 1 < a.nchunk) ++cc;
+      else uu += per, cc = 0;
+    };
+    int c0 = 0;
+    halo_issue(u, 0, S0{});
+    advance(u1, c1);
+    if (u1 < u_hi) halo_issue(u1, c1, S1{});
+    u2 = u1, c2 = c1;
+    advance(u2, c2);
+    int wres_nb = -1;
+    auto stage = [&](auto setc) __attribute__((always_inline)) {
+      const int nb = unit_nb(u);
+      if (c0 == 0) {
+        load_bias(nb);
+        zero_acc();
+      }
+      if (nb != wres_nb) {  // (block-uniform) this cout block's weights, all chunks: once per workgroup and block
+        __syncthreads();
+        const int nv = a.nks * 8 * BN;
+        for (int c = 0; c < a.nchunk; ++c)
+          for (int i = tid; i < nv; i += 256) ((u32x4*)Bb)[c * nv + i] = wq[(long)(c * a.nblk + nb) * nv + i];
+        wres_nb = nb;
+      }
+      __syncthreads();  // every wave is done with the previous stage's halo
+      halo_write(setc);
+      __syncthreads();
+      if (u2 < u_hi) halo_issue(u2, c2, setc);  // the set just consumed takes the stage after next
+      ksteps(Bb + (long)c0 * a.nks * 8 * BN * 8, toff + lgq, a.nks);
+      if (c0 + 1 == a.nchunk) epilogue(u, nb);
+      u = u1, c0 = c1;
+      u1 = u2, c1 = c2;
+      advance(u2, c2);
+    };
+    while (true) {
+      stage(S0{});
+      if (u >= u_hi) break;
+      stage(S1{});
+      if (u >= u_hi) break;
+    }
+  } else {
+    // streaming weights: groups of GT k-steps double-buffered through registers, one stage of halo look-ahead
+    halo_issue(u, 0, S0{});
+    pref_b(unit_nb(u), 0, 0);
+    int flat = 0;
+    while (true) {
+      const int nb = unit_nb(u);
+      const int un = u + per;  // this workgroup's next unit
+      load_bias(nb);
+      zero_acc();
+      for (int c = 0; c < a.nchunk; ++c) {
+        __syncthreads();  // every wave is done with the previous stage's halo
+        halo_write(S0{});
+        for (int g = 0; g < ngrp; ++g) {
+          unsigned short* B = Bb + (flat & 1) * bsz;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < a.GT * 8 * BN) ((u32x4*)B)[idx] = rb[i];
+          }
+          __syncthreads();
+          if (g == 0) {  // next stage's halo
+            if (c + 1 < a.nchunk) halo_issue(u, c + 1, S0{});
+            else if (un < u_hi) halo_issue(un, 0, S0{});
+          }
+          if (g + 1 < ngrp) pref_b(nb, c, g + 1);
+          else if (c + 1 < a.nchunk) pref_b(nb, c + 1, 0);
+          else if (un < u_hi) pref_b(unit_nb(un), 0, 0);
+          ksteps(B, toff + g * a.GT * a.TP + lgq, min(a.GT, a.nks - g * a.GT));
+          ++flat;
+        }
+      }
+      epilogue(u, nb);
+      if (un >= u_hi) break;
+      u = un;
+    }
+  }
+}
+
+// packed[chunk][nb][k-step][plane][lg][col][j] = plane of 2^ew W(tap, ci, co = nb*BN + col), (tap, ci) = (k-step*TP + lg / (4/TP),
+// chunk*32 + (lg % (4/TP))*8 + j); taps past the last one and channels past ci_real hold zeros.  Block 0 also turns the
+// per-sample partial maxima into exponents (as convg2_pack_kernel).
+struct PackH2Args {
+  const float* w;
+  unsigned short* packed;
+  int ntaps, nchunk, nblk, bn, ci_real, co_real, tp, nks;
+  long s_ci, s_co;
+  short tsrc[CG_MAXTAPS];
+  float* ws;
+  int n;
+};
+__global__ __launch_bounds__(256) void convh2_pack_kernel(PackH2Args a) {
+  __shared__ int s_ew;
+  if (threadIdx.x < 64) {
+    float m = 0.f;
+#pragma unroll
+    for (int q = 0; q < CG2_WB / 64; ++q) m = fmaxf(m, a.ws[CG2_WOFF + q * 64 + threadIdx.x]);
+    m = f2_wave_max(m);
+    if (threadIdx.x == 0) {
+      s_ew = f2_scale_exp(m);
+      if (blockIdx.x == 0) ((int*)a.ws)[CG2_EOFF + CG2_NMAX] = s_ew;
+    }
+  }
+  if (blockIdx.x == 0 && a.n > 0) {
+    for (int nn = threadIdx.x; nn < a.n; nn += 256) {
+      float m = 0.f;
+#pragma unroll
+      for (int q = 0; q < CG2_XB; ++q) m = fmaxf(m, a.ws[nn * CG2_XB + q]);
+      ((int*)a.ws)[CG2_EOFF + nn] = f2_scale_exp(m);
+    }
+  }
+  __syncthreads();
+  const float sw = __builtin_ldexpf(1.f, s_ew);
+  const int gpt = 4 / a.tp;
+  const long total = (long)a.nchunk * a.nblk * a.nks * 4 * a.bn * 4;   // pairs of consecutive channels
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 3) * 2;
+    long r = i >> 2;
+    const int col = (int)(r % a.bn);
+    r /= a.bn;
+    const int lg = (int)(r & 3);
+    r >>= 2;
+    const int ks = (int)(r % a.nks);
+    r /= a.nks;
+    const int nb = (int)(r % a.nblk);
+    const int chunk = (int)(r / a.nblk);
+    const int tap = ks * a.tp + lg / gpt;
+    const int ci = chunk * CG3_CK + (lg % gpt) * 8 + j, co = nb * a.bn + col;
+    float v0 = 0.f, v1 = 0.f;
+    if (tap < a.ntaps && co < a.co_real) {
+      if (ci < a.ci_real) v0 = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
+      if (ci + 1 < a.ci_real) v1 = a.w[(ci + 1) * a.s_ci + co * a.s_co + a.tsrc[tap]];
+    }
+    unsigned p1, p2;
+    f2_split_pair(v0 * sw, v1 * sw, p1, p2);
+    const long plane = 4L * a.bn * 8;
+    const long base = ((((long)chunk * a.nblk + nb) * a.nks + ks) * 2) * plane + ((long)lg * a.bn + col) * 8 + j;
+    *(unsigned*)(a.packed + base) = p1;
+    *(unsigned*)(a.packed + base + plane) = p2;
+  }
+}
+
+static int ch2_num_cus() {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  return ncu;
+}
+static long ch2_lds(const GenArgs& a) { return 256 + 2L * a.wsz16 + (long)a.HR * a.HC * a.PS * 2; }
+#define CH2_LDS_MAX (156 * 1024)
+// halo form: worth it when the map is large (tile quantisation wastes small maps; their layers are weight-bound anyway) and the
+// halo + weight buffers fit LDS.  Fills the halo fields of a.
+static bool ch2_plan(GenArgs& a, int bn) {
+  // DIS_CONVG_HALO_MIN: smallest virtual output grid (pixels) that takes this form; read per call (host-side, ~100 ns) so that
+  // the tests can run one layer both ways in one process.  0 pixels never qualify; a huge value keeps every call streaming.
+  const char* mh = getenv("DIS_CONVG_HALO_MIN");
+  const long min_hw = mh ? atol(mh) : 1024;
+  if ((long)a.hv * a.wv < min_hw || a.ntaps > CG_MAXTAPS) return false;
+  int dy0 = a.tdy[0], dy1 = a.tdy[0], dx0 = a.tdx[0], dx1 = a.tdx[0];
+  for (int t = 1; t < a.ntaps; ++t) {
+    dy0 = a.tdy[t] < dy0 ? a.tdy[t] : dy0; dy1 = a.tdy[t] > dy1 ? a.tdy[t] : dy1;
+    dx0 = a.tdx[t] < dx0 ? a.tdx[t] : dx0; dx1 = a.tdx[t] > dx1 ? a.tdx[t] : dx1;
+  }
+  a.dy0 = dy0; a.dx0 = dx0;
+  a.TP = a.cin <= 16 ? 2 : 1;
+  a.PL = 32 / a.TP;
+  a.PS = a.TP == 1 ? 80 : 48;   // 2 planes + pad: 2 (mod 4) sixteen-byte units (F2Cfg::PS)
+  a.nks = (a.ntaps + a.TP - 1) / a.TP;
+  if (a.nks * a.TP > 64) return false;
+  a.GT = CH2_GVEC / (8 * bn);
+  if (a.GT > a.nks) a.GT = a.nks;
+  a.HC = (CH2_TC - 1) * a.S + (dx1 - dx0) + 1;
+  a.tiles_x = (a.wv + CH2_TC - 1) / CH2_TC;
+  const long ipp = a.PL / 4;
+  auto rows = [&](int trh) { return (trh - 1) * a.S + (dy1 - dy0) + 1; };
+  // a cout block's weights (all chunks) stay in LDS when they fit next to the halo of an 8-row tile with two workgroups per CU
+  const long wall = (long)a.nchunk * a.nks * 8 * bn * 16;
+  const long hal8 = (long)rows(8) * a.HC * a.PS * 2, items8 = (long)rows(8) * a.HC * ipp;
+  a.trh = 8;
+  a.HR = rows(8);
+  if (256 + wall + hal8 <= 78 * 1024 && items8 <= 8 * 256) {
+    a.res = 1;
+    a.wsz16 = (int)(wall / 2);
+  } else {
+    a.res = 0;
+    a.wsz16 = (int)((2L * a.GT * 8 * bn * 16) / 2);
+    const long hal16 = (long)rows(16) * a.HC * a.PS * 2, items16 = (long)rows(16) * a.HC * ipp;
+    static const bool no16 = getenv("DIS_CONVG_T16") && getenv("DIS_CONVG_T16")[0] == '0';
+    if (!no16 && a.hv >= 32 && 256 + 2L * a.wsz16 + hal16 <= CH2_LDS_MAX && items16 <= 20 * 256) {
+      a.trh = 16;
+      a.HR = rows(16);
+    } else if (items8 > 20 * 256) {
+      return false;
+    }
+  }
+  a.tiles_y = (a.hv + a.trh - 1) / a.trh;
+  return ch2_lds(a) <= CH2_LDS_MAX;
+}
+template <int BN, int NH, int MT, bool RES>
+static int ch2_launch3(const GenArgs& a, long grid, long lds, hipStream_t s) {
+  static bool attr = false;
+  auto kern = convh2_kernel<BN, NH, MT, RES>;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH2_LDS_MAX);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  DIS_TAG(RES ? "convh2_kernel (f16x2 LDS halo, resident weights)" : "convh2_kernel (f16x2 LDS halo)");
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, s, a);
+  return DIS_OK;
+}
+template <int BN>
+static int ch2_launch(const GenArgs& a, int nh, long grid, long lds, hipStream_t s) {
+  if (a.res) {
+    if (nh <= 4) return ch2_launch3<BN, 4, 2, true>(a, grid, lds, s);
+    return ch2_launch3<BN, 8, 2, true>(a, grid, lds, s);
+  }
+  if (a.trh == 16) {
+    if (nh <= 8) return ch2_launch3<BN, 8, 4, false>(a, grid, lds, s);
+    if (nh <= 14) return ch2_launch3<BN, 14, 4, false>(a, grid, lds, s);
+    return ch2_launch3<BN, 20, 4, false>(a, grid, lds, s);
+  }
+  if (nh <= 8) return ch2_launch3<BN, 8, 2, false>(a, grid, lds, s);
+  if (nh <= 14) return ch2_launch3<BN, 14, 2, false>(a, grid, lds, s);
+  return ch2_launch3<BN, 20, 2, false>(a, grid, lds, s);
+}
+static int ch2_run(GenArgs a, int bn, const float* w_raw, float* wpack, int ci_real, int co_real, long s_ci, long s_co,
+                   const short* tsrc, hipStream_t s) {
+  PackH2Args p;
+  p.w = w_raw; p.packed = (unsigned short*)wpack; p.ntaps = a.ntaps; p.nchunk = a.nchunk; p.nblk = a.nblk; p.bn = bn;
+  p.ci_real = ci_real; p.co_real = co_real; p.tp = a.TP; p.nks = a.nks; p.s_ci = s_ci; p.s_co = s_co;
+  for (int t = 0; t < a.ntaps; ++t) p.tsrc[t] = tsrc[t];
+  p.ws = const_cast<float*>(a.f2ws); p.n = a.n;
+  const long ptotal = (long)a.nchunk * a.nblk * a.nks * 4 * bn * 4;
+  hipLaunchKernelGGL(convh2_pack_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
+  a.w = wpack;
+  const long units = (long)a.n * a.tiles_y * a.tiles_x * a.nblk;
+  if (units > 2147483647L) return DIS_ERR_BAD_SHAPE;
+  const long lds = ch2_lds(a);
+  // persistent grid: as many workgroups as stay resident (LDS-bound, at most 4 per CU), a multiple of the 8 XCDs
+  long wpc = (160L * 1024) / lds;
+  wpc = wpc > 4 ? 4 : (wpc < 1 ? 1 : wpc);
+  long grid = wpc * ch2_num_cus();
+  if (grid > units) grid = units;
+  if (grid >= 8) grid -= grid % 8;
+  const int nh = (int)(((long)a.HR * a.HC * (a.PL / 4) + 255) / 256);
+  int rc;
+  if (bn == 64) rc = ch2_launch<64>(a, nh, grid, lds, s);
+  else if (bn == 32) rc = ch2_launch<32>(a, nh, grid, lds, s);
+  else rc = ch2_launch<16>(a, nh, grid, lds, s);
+  if (rc != DIS_OK) return rc;
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 static int cg_bn(int cout) { return cout > 32 ? 64 : (cout > 16 ? 32 : 16); }
 
 // split-K factor of the two-term streaming kernel: only when the launch has fewer workgroups than the device has CUs and a long
@@ -758,6 +1233,7 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
   if (use3 && a.f2ws && a.cin >= CG3_CK && xb3 < 0x7fff0000L) {  // two-term fp16 form (default): see convg2_fwd_kernel
     a.x_bytes = (unsigned)xb3;
     a.nchunk = (a.cin + CG3_CK - 1) / CG3_CK;
+    if (ch2_plan(a, bn)) return ch2_run(a, bn, w_raw, wpack, ci_real, co_real, s_ci, s_co, tsrc, s);   // large maps: LDS halo form
     Pack2Args p2;
     p2.w = w_raw; p2.packed = (unsigned short*)wpack; p2.ntaps = a.ntaps; p2.nchunk = a.nchunk; p2.nblk = a.nblk;
     p2.bn = bn; p2.ci_real = ci_real; p2.co_real = co_real; p2.s_ci = s_ci; p2.s_co = s_co;
@@ -888,7 +1364,10 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
   if ((cin & 3) || (xoff & 3) || (ldx & 3) || xoff + cin > ldx || yoff + cout > ldy || cin_w > cin || cout_w > cout)
     return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if ((mode == DIS_CONVG_CONV || mode == DIS_CONVG_CONV_DGRAD) && hin == hout && win == wout &&
+  // (7x7 layers: the two-term halo kernel runs all 49 taps in one launch; the tap rows of the resident-weight kernel - seven
+  // accumulating launches, each a pass over x and two over y - stay the three-term path's form)
+  const bool halo7 = k == 7 && dis_f2_enabled() && cin >= CG3_CK && n <= CG2_NMAX && !getenv("DIS_CONVG_NO_HALO7");
+  if ((mode == DIS_CONVG_CONV || mode == DIS_CONVG_CONV_DGRAD) && hin == hout && win == wout && !halo7 &&
       dis_bx_slices_ok(n, hin, win, cin, cout, ldx, ldy, xoff, yoff, k, stride, pad, act))
     return dis_bx_slices_run(mode == DIS_CONVG_CONV_DGRAD, x, ldx, xoff, cin, cin_w, w, bias, y, ldy, yoff, cout, cout_w,
                              n, hin, win, k, act, s);

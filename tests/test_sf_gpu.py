@@ -122,6 +122,101 @@ def test_convg_f16x2_streaming_is_fp32_accurate(case, cin, cout, k, stride, h, w
             assert per2[q] < 4 * per3[q] + 2e-7, (case, name, q, per3[q], per2[q])
 
 
+class halo_min(object):
+    """context manager: DIS_CONVG_HALO_MIN for a block (the smallest output grid, in pixels, whose fp32 streaming convolutions
+    take the LDS-halo form convh2_kernel; the library reads it per call)"""
+
+    def __init__(self, v):
+        self.v = str(v)
+
+    def __enter__(self):
+        self.prev = os.environ.get('DIS_CONVG_HALO_MIN')
+        os.environ['DIS_CONVG_HALO_MIN'] = self.v
+
+    def __exit__(self, *a):
+        if self.prev is None:
+            os.environ.pop('DIS_CONVG_HALO_MIN', None)
+        else:
+            os.environ['DIS_CONVG_HALO_MIN'] = self.prev
+        return False
+
+
+def _kernels_of(fn_):
+    """run fn_ under lib's per-call recorder -> (result, set of kernel tags the dis_convg_run calls reported)"""
+    from depthinspace_amd import lib
+    lib.profile_start()
+    out = fn_()
+    rec = lib.profile_stop()
+    return out, {t for (name, _, _, t, _) in rec if name == 'dis_convg_run'}
+
+
+# kind, cin, cin_mem, cout, k, stride, h, w (conv: input size; tconv: input size, output = 2h-? x 2w-? given below)
+HALO_SHAPES = [
+    ('conv', 32, 32, 32, 7, 1, 37, 41),     # conv1.2: 49 taps, streaming weight groups, 16-row tiles, ragged edges
+    ('conv', 32, 32, 64, 5, 2, 45, 38),     # conv2.0: stride 2 (large halo)
+    ('conv', 64, 64, 64, 5, 1, 33, 35),     # conv2.2: two 32-channel chunks
+    ('conv', 64, 64, 128, 3, 2, 40, 36),    # conv3.0: two cout blocks
+    ('conv', 129, 132, 64, 3, 2, 34, 33),   # a padded concat buffer (zero weights beyond channel 129), 5 chunks
+    ('conv', 64, 64, 4, 5, 1, 36, 40),      # a partial cout block (4 of 16)
+    ('tconv', 32, 32, 16, 3, 2, 33, 38),    # upconv1: 4 parity classes of 1 - 4 taps, resident weights
+    ('tconv', 64, 64, 32, 3, 2, 32, 35),    # upconv2 with a crop
+    ('tconv', 128, 128, 64, 3, 2, 35, 32),
+]
+
+
+@pytest.mark.parametrize('kind,cin,cin_mem,cout,k,stride,h,w', HALO_SHAPES)
+def test_convg_f16x2_halo_form(kind, cin, cin_mem, cout, k, stride, h, w):
+    """convh2_kernel (two-term fp16, input halo staged in LDS once per tile and 32-channel chunk) against fp64 and beside the
+    streaming kernel convg2_fwd_kernel on the same inputs: forward and input gradient (which runs the same kernel in its other
+    mode: stride-2 input gradients and transposed convolutions as four parity classes).  Both forms split the operands the same
+    way (one scale per image, one for the weights), so their errors against fp64 are of one size: bar 3 x streaming + 2e-7."""
+    from depthinspace_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + k + h)
+    n, pad = 3, (k - 1) // 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    x[1] *= 37.0    # (images with different scales)
+    b = torch.randn(cout, generator=g) * 0.1
+    if kind == 'conv':
+        wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        xr = x.double().requires_grad_(True)
+        y = F.conv2d(xr, wt.double(), b.double(), stride=stride, padding=pad)
+    else:
+        wt = torch.randn(cin, cout, 3, 3, generator=g) / (cin * 9) ** 0.5
+        xr = x.double().requires_grad_(True)
+        hout, wout = 2 * h - (h % 2), 2 * w - 1   # crop_like targets: one with, one without a cropped row
+        y = F.conv_transpose2d(xr, wt.double(), b.double(), stride=2, padding=1, output_padding=1)[:, :, :hout, :wout]
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go.double())
+    xp = torch.zeros(n, h, w, cin_mem)
+    xp[..., :cin] = nhwc(x)
+
+    def run():
+        xd = xp.cuda().requires_grad_(True)
+        wd, bd = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        if kind == 'conv':
+            yd = ops.convg(xd, wd, bd, stride, pad, ops.ACT_NONE)
+        else:
+            yd = ops.convg_transposed(xd, wd, bd, (y.shape[2], y.shape[3]), 1, ops.ACT_NONE)
+        yd.backward(nhwc(go).cuda())
+        return nchw(yd).detach().double().cpu(), nchw(xd.grad[..., :cin]).double().cpu(), wd.grad.double().cpu()
+    with halo_min(1):
+        halo, tags_h = _kernels_of(run)
+    with halo_min(1 << 40):
+        stream, tags_s = _kernels_of(run)
+    assert any('convh2_kernel' in t for t in tags_h), tags_h
+    assert not any('convh2_kernel' in t for t in tags_s), tags_s
+
+    def err(a, ref):
+        return float((a - ref).abs().max() / (ref.abs().max() + 1e-300))
+    for name, i, ref in (('y', 0, y.detach()), ('gx', 1, xr.grad)):
+        eh, es = err(halo[i], ref), err(stream[i], ref)
+        print(f'{kind} {cin}->{cout} k{k} s{stride} {name}: halo {eh:.2e} streaming {es:.2e}  kernels {sorted(tags_h)}')
+        assert eh < 3 * es + 2e-7, (name, eh, es)
+        for q in range(n):
+            assert err(halo[i][q], ref[q]) < 3 * err(stream[i][q], ref[q]) + 2e-7, (name, q)
+    assert err(halo[2], stream[2]) < 1e-6   # (the weight gradient does not depend on the form)
+
+
 # cin, cout, hin, win, hout, wout (crop_like target)
 TCONV_SHAPES = [
     (512, 512, 4, 4, 8, 7),     # upconv7 at 512x432: 8x8 cropped to 8x7
