@@ -57,6 +57,14 @@ struct GenArgs {
   // two-term fp16 halo kernel (convh2_kernel): first tap offsets, halo extent, LDS pixel stride (16-bit words), taps per k-step,
   // channels per plane, k-steps, k-steps per weight group, tile grid, tile rows, resident weights, 16-bit words of the weight region
   int dy0, dx0, HR, HC, PS, TP, PL, nks, GT, tiles_x, tiles_y, trh, res, wsz16;
+  // ... output phases of one launch: 1, or the 4 parity classes of a stride-2 transposed form (input gradient of a stride-2
+  // convolution, ConvTranspose2d forward) sharing one halo: phase p owns the k-steps [ph_k0[p], ph_k0[p] + ph_kn[p]) of the tap
+  // list and writes output pixel (2 vy + ph_oy[p], 2 vx + ph_ox[p]) (one phase: (vy osy + ooy, vx osx + oox) as above);
+  // streamed weight groups never straddle phases: group g = k-steps [grp_k0[g], + grp_kn[g]), phase p owns groups
+  // [ph_g0[p], ph_g0[p] + ph_ng[p])
+  int nph, ngrp, kc;   // kc: column walk (taps ordered dx-major, dy ascending; a weight group = one column of kc taps), 0: generic
+  unsigned char ph_k0[4], ph_kn[4], ph_oy[4], ph_ox[4], ph_g0[4], ph_ng[4];
+  unsigned char grp_k0[32], grp_kn[32];
 };
 
 template <int BN>
@@ -756,9 +764,17 @@ __global__ __launch_bounds__(256) void convg2_splitk_reduce_kernel(GenArgs a, in
 // ------------------------------------------------------------------------------------------------
 #define CH2_TC 16
 #define CH2_GVEC 1024  // 16-byte vectors of one weight group (16 KB): 4 per thread
-template <int BN, int NH, int MT, bool RES>
+// KC > 0 (streamed weights, stride 1, one phase, a full KC x KC window - the 7 x 7 and 5 x 5 layers): the tap list is ordered
+// column by column (dx outer, dy ascending) and a weight group is one column.  A wave's MT output rows read the halo rows
+// r + ky .. r + ky + MT - 1 for tap row ky, so a column needs only the MT + KC - 1 row fragments r .. r + MT + KC - 2, each read
+// ONCE and kept in registers while ky slides down (one new row per k-step instead of MT): with the generic tap walk a k-step is
+// 2 (MT + NT) ds_read_b128 per wave for 3 MT NT MFMAs, which keeps the LDS port as busy as the matrix unit (MT 4, NT 2: 12 reads
+// per 24 MFMAs, the 7 x 7 layer ran at 27 % of the matrix rate); here it is 2 (1 + NT).
+template <int BN, int NH, int MT, bool RES, int PH, int KC = 0>
 __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
+  static_assert(KC == 0 || (!RES && PH == 1), "column walk: streamed weights, one phase");
   constexpr int NT = BN / 16, TRH = 4 * MT, NSET = RES ? 2 : 1;
+  constexpr int NRB = KC > 0 ? (KC * 8 * BN + 255) / 256 : 4;   // 16-byte vectors of a weight group per thread
   extern __shared__ __attribute__((aligned(16))) unsigned short hsm[];
   int* toff = (int*)hsm;                       // 64 ints
   const int bsz = a.GT * 2 * 4 * BN * 8;       // 16-bit words of one weight buffer
@@ -787,13 +803,12 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
   const int a_lane = (wave * MT * a.S * HC + li * a.S) * PS + cg * 8;
   const int rowstep = a.S * HC * PS;
   const u32x4* wq = (const u32x4*)a.w;
-  const int ngrp = (a.nks + a.GT - 1) / a.GT;
-  u32x4 rb[4];
+  u32x4 rb[NRB];
   auto pref_b = [&](int nb, int c, int g) __attribute__((always_inline)) {
-    const long base = ((long)(c * a.nblk + nb) * a.nks + g * a.GT) * (8 * BN);
-    const int cnt = min(a.GT, a.nks - g * a.GT) * (8 * BN);
+    const long base = ((long)(c * a.nblk + nb) * a.nks + a.grp_k0[g]) * (8 * BN);
+    const int cnt = a.grp_kn[g] * (8 * BN);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NRB; ++i) {
       const int idx = tid + i * 256;
       rb[i] = wq[base + (idx < cnt ? idx : 0)];
     }
@@ -846,11 +861,16 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
     }
   };
 
-  f32x4 acc[MT][NT], bias_v[NT];
+  f32x4 acc[PH][MT][NT], bias_v[NT];
+  // SACC: the two cross terms (x2 w1, x1 w2 - 2^-11 of the main product) accumulate in registers of their own and join the main
+  // sums in the epilogue: a third of the additions into the large running sum, whose fp32 rounding is this kernel's error
+  // (7 x 7, 32 -> 32 against fp64: largest error 1.0e-6 -> 5.0e-7 of the largest output, mean 6.3e-8 -> 3.7e-8; scripts/diag/halo_err_map.py)
+  constexpr bool SACC = (PH == 1) && MT * NT <= 8;   // (16 tiles per wave: 64 more registers would spill)
+  f32x4 accs[SACC ? MT : 1][SACC ? NT : 1];
   int bias_nb = -1;
-  // k-steps [0, kn) of a weight block B ([k-step][plane][lg][BN][8]) whose tap offsets start at tq; software-pipelined by hand:
-  // the operands of k-step kk+1 are requested before the MFMAs of kk issue
-  auto ksteps = [&](const unsigned short* B, const int* tq, int kn) __attribute__((always_inline)) {
+  // k-steps [0, kn) of a weight block B ([k-step][plane][lg][BN][8]) whose tap offsets start at tq, into one phase's accumulators;
+  // software-pipelined by hand: the operands of k-step kk+1 are requested before the MFMAs of kk issue
+  auto ksteps = [&](const unsigned short* B, const int* tq, int kn, f32x4 (&acc)[MT][NT]) __attribute__((always_inline)) {
     const unsigned short* bl = B + (lg * BN + li) * 8;
     auto frag = [&](int kk, int to, s16x8 (&fa)[2][MT], s16x8 (&fb)[2][NT]) __attribute__((always_inline)) {
 #pragma unroll
@@ -870,9 +890,11 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fb[PB[q]][nt]),
-                                                                __builtin_bit_cast(f16x8_t, fa[PA[q]][mt]), acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt) {
+            f32x4& d = (SACC && q < 2) ? accs[SACC ? mt : 0][SACC ? nt : 0] : acc[mt][nt];
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fb[PB[q]][nt]),
+                                                      __builtin_bit_cast(f16x8_t, fa[PA[q]][mt]), d, 0, 0, 0);
+          }
     };
     s16x8 fa0[2][MT], fb0[2][NT], fa1[2][MT], fb1[2][NT];
     int to0 = tq[0], to1 = kn > 1 ? tq[a.TP] : 0;
@@ -886,6 +908,55 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
         to1 = kk + 3 < kn ? tq[(kk + 3) * a.TP] : 0;
         mac(fa1, fb1);
       }
+    }
+  };
+  // one column of KC taps (weights B: [ky][plane][lg][BN][8]; `to` = halo offset of the column's first tap): sliding window of row
+  // fragments.  Rn: the first MT rows of the NEXT column (offset to_next), requested during the last k-steps of this one.
+  constexpr int KCC = KC > 0 ? KC : 1;
+  s16x8 Rn[MT][2];
+  auto col_rows = [&](int to) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) Rn[j][p] = *(const s16x8*)(halo + a_lane + j * rowstep + to + p * PL);
+  };
+  auto kcolumn = [&](const unsigned short* B, int to, int to_next, bool has_next, f32x4 (&acc)[MT][NT]) __attribute__((always_inline)) {
+    const unsigned short* bl = B + (lg * BN + li) * 8;
+    s16x8 R[MT + KCC - 1][2];
+    s16x8 fb[2][2][NT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) R[j][p] = Rn[j][p];
+    auto load_fb = [&](int ky, s16x8 (&f)[2][NT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) f[p][nt] = *(const s16x8*)(bl + ((ky * 2 + p) * 4 * BN + nt * 16) * 8);
+    };
+    load_fb(0, fb[0]);
+    constexpr int PA[3] = {1, 0, 0};
+    constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int ky = 0; ky < KCC; ++ky) {
+      if (ky + 1 < KCC) {
+        // the row that enters the window at the next k-step, and its weights
+#pragma unroll
+        for (int p = 0; p < 2; ++p) R[ky + MT][p] = *(const s16x8*)(halo + a_lane + (ky + MT) * rowstep + to + p * PL);
+        load_fb(ky + 1, fb[(ky + 1) & 1]);
+      } else if (has_next) {
+        col_rows(to_next);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            f32x4& d = (SACC && q < 2) ? accs[SACC ? mt : 0][SACC ? nt : 0] : acc[mt][nt];
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fb[ky & 1][PB[q]][nt]),
+                                                      __builtin_bit_cast(f16x8_t, R[ky + mt][PA[q]]), d, 0, 0, 0);
+          }
     }
   };
   using S0 = std::integral_constant<int, 0>;
@@ -907,9 +978,17 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
   };
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int ph = 0; ph < PH; ++ph)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[ph][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (SACC) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) accs[SACC ? mt : 0][SACC ? nt : 0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
   };
   const int ew = sexp[CG2_NMAX];
   // epilogue: lane (li, lg) holds couts nb*BN + nt*16 + lg*4 + {0..3} of position (ty*TRH + wave*MT + mt, tx*16 + li); the two
@@ -926,18 +1005,26 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
       for (int mt = 0; mt < MT; ++mt) {
         const int vy = ty * TRH + wave * MT + mt, vx = tx * CH2_TC + li;
         if (vy >= a.hv || vx >= a.wv) continue;
-        const long pe = (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int co = nb * BN + nt * 16 + lg * 4;
-          if (co >= a.cout) continue;
-          float o[4];
+        for (int ph = 0; ph < PH; ++ph) {
+          const int oy = vy * a.osy + a.ph_oy[ph], ox = vx * a.osx + a.ph_ox[ph];
+          if (PH > 1 && (oy >= a.hf || ox >= a.wf)) continue;   // (the classes of an odd output size differ by one row / column)
+          const long pe = (((long)nn * a.hf + oy) * a.wf + ox) * a.ldy + a.yoff;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[mt][nt][r] * desc + bias_v[nt][r], ACT);
-          if (co + 4 <= a.cout && ((pe + co) & 3) == 0) {
-            *(float4*)(a.y + pe + co) = make_float4(o[0], o[1], o[2], o[3]);
-          } else {
-            for (int r = 0; r < 4 && co + r < a.cout; ++r) a.y[pe + co + r] = o[r];
+          for (int nt = 0; nt < NT; ++nt) {
+            const int co = nb * BN + nt * 16 + lg * 4;
+            if (co >= a.cout) continue;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float sum = SACC ? acc[ph][mt][nt][r] + accs[SACC ? mt : 0][SACC ? nt : 0][r] : acc[ph][mt][nt][r];
+              o[r] = act_apply(sum * desc + bias_v[nt][r], ACT);
+            }
+            if (co + 4 <= a.cout && ((pe + co) & 3) == 0) {
+              *(float4*)(a.y + pe + co) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+              for (int r = 0; r < 4 && co + r < a.cout; ++r) a.y[pe + co + r] = o[r];
+            }
           }
         }
       }
@@ -979,7 +1066,9 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
       halo_write(setc);
       __syncthreads();
       if (u2 < u_hi) halo_issue(u2, c2, setc);  // the set just consumed takes the stage after next
-      ksteps(Bb + (long)c0 * a.nks * 8 * BN * 8, toff + lgq, a.nks);
+#pragma unroll
+      for (int ph = 0; ph < PH; ++ph)
+        ksteps(Bb + ((long)c0 * a.nks + a.ph_k0[ph]) * (8 * BN * 8), toff + a.ph_k0[ph] * a.TP + lgq, a.ph_kn[ph], acc[ph]);
       if (c0 + 1 == a.nchunk) epilogue(u, nb);
       u = u1, c0 = c1;
       u1 = u2, c1 = c2;
@@ -1004,23 +1093,32 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
       for (int c = 0; c < a.nchunk; ++c) {
         __syncthreads();  // every wave is done with the previous stage's halo
         halo_write(S0{});
-        for (int g = 0; g < ngrp; ++g) {
-          unsigned short* B = Bb + (flat & 1) * bsz;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < a.GT * 8 * BN) ((u32x4*)B)[idx] = rb[i];
+        for (int ph = 0; ph < PH; ++ph) {
+          const int g_lo = a.ph_g0[ph], g_hi = g_lo + a.ph_ng[ph];
+          for (int g = g_lo; g < g_hi; ++g) {
+            unsigned short* B = Bb + (flat & 1) * bsz;
+#pragma unroll
+            for (int i = 0; i < NRB; ++i) {
+              const int idx = tid + i * 256;
+              if (idx < a.GT * 8 * BN) ((u32x4*)B)[idx] = rb[i];
+            }
+            __syncthreads();
+            if (g == 0) {  // next stage's halo
+              if (c + 1 < a.nchunk) halo_issue(u, c + 1, S0{});
+              else if (un < u_hi) halo_issue(un, 0, S0{});
+            }
+            if (g + 1 < a.ngrp) pref_b(nb, c, g + 1);
+            else if (c + 1 < a.nchunk) pref_b(nb, c + 1, 0);
+            else if (un < u_hi) pref_b(unit_nb(un), 0, 0);
+            if constexpr (KC > 0) {
+              if (g == 0) col_rows(toff[0]);   // (the first column of a stage: its rows were not requested by a predecessor)
+              kcolumn(B, toff[g * KC], g + 1 < a.ngrp ? toff[(g + 1) * KC] : 0, g + 1 < a.ngrp, acc[ph]);
+            } else {
+              ksteps(B, toff + a.grp_k0[g] * a.TP + lgq, a.grp_kn[g], acc[ph]);
+            }
+            ++flat;
           }
-          __syncthreads();
-          if (g == 0) {  // next stage's halo
-            if (c + 1 < a.nchunk) halo_issue(u, c + 1, S0{});
-            else if (un < u_hi) halo_issue(un, 0, S0{});
-          }
-          if (g + 1 < ngrp) pref_b(nb, c, g + 1);
-          else if (c + 1 < a.nchunk) pref_b(nb, c + 1, 0);
-          else if (un < u_hi) pref_b(unit_nb(un), 0, 0);
-          ksteps(B, toff + g * a.GT * a.TP + lgq, min(a.GT, a.nks - g * a.GT));
-          ++flat;
         }
       }
       epilogue(u, nb);
@@ -1120,6 +1218,11 @@ static bool ch2_plan(GenArgs& a, int bn) {
   }
   a.dy0 = dy0; a.dx0 = dx0;
   a.TP = a.cin <= 16 ? 2 : 1;
+  if (a.nph > 1 && a.TP != 1) return false;   // (a k-step of two taps could straddle two phases)
+  if (a.nph == 1) {
+    a.ph_k0[0] = 0; a.ph_kn[0] = (unsigned char)((a.ntaps + a.TP - 1) / a.TP);
+    a.ph_oy[0] = (unsigned char)a.ooy; a.ph_ox[0] = (unsigned char)a.oox;
+  }
   a.PL = 32 / a.TP;
   a.PS = a.TP == 1 ? 80 : 48;   // 2 planes + pad: 2 (mod 4) sixteen-byte units (F2Cfg::PS)
   a.nks = (a.ntaps + a.TP - 1) / a.TP;
@@ -1143,34 +1246,85 @@ static bool ch2_plan(GenArgs& a, int bn) {
     a.wsz16 = (int)((2L * a.GT * 8 * bn * 16) / 2);
     const long hal16 = (long)rows(16) * a.HC * a.PS * 2, items16 = (long)rows(16) * a.HC * ipp;
     static const bool no16 = getenv("DIS_CONVG_T16") && getenv("DIS_CONVG_T16")[0] == '0';
-    if (!no16 && a.hv >= 32 && 256 + 2L * a.wsz16 + hal16 <= CH2_LDS_MAX && items16 <= 20 * 256) {
+    if (!no16 && a.nph == 1 && a.hv >= 32 && 256 + 2L * a.wsz16 + hal16 <= CH2_LDS_MAX && items16 <= 20 * 256) {
       a.trh = 16;
       a.HR = rows(16);
     } else if (items8 > 20 * 256) {
       return false;
     }
   }
+  // column walk (see convh2_kernel, KC): a full K x K stride-1 window, 16-row tiles, the instances that exist
+  a.kc = 0;
+  {
+    const int K = dy1 - dy0 + 1;
+    static const bool nokc = getenv("DIS_CONVG_KC") && getenv("DIS_CONVG_KC")[0] == '0';
+    if (!nokc && a.nph == 1 && a.S == 1 && a.TP == 1 && !a.res && a.trh == 16 && dx1 - dx0 + 1 == K && a.ntaps == K * K &&
+        ((K == 7 && bn == 32) || (K == 5 && bn == 64))) {
+      const long wsz = 2L * K * 8 * bn * 16 / 2;   // two buffers of one column
+      if (256 + 2 * wsz + (long)a.HR * a.HC * a.PS * 2 <= CH2_LDS_MAX) {
+        a.kc = K;
+        a.GT = K;
+        a.wsz16 = (int)wsz;
+      }
+    }
+  }
   a.tiles_y = (a.hv + a.trh - 1) / a.trh;
+  // weight groups (streamed form): GT k-steps each, cut at the phase boundaries
+  int ng = 0;
+  for (int ph = 0; ph < a.nph; ++ph) {
+    a.ph_g0[ph] = (unsigned char)ng;
+    for (int k0 = 0; k0 < a.ph_kn[ph]; k0 += a.GT) {
+      if (ng >= 32) return false;
+      a.grp_k0[ng] = (unsigned char)(a.ph_k0[ph] + k0);
+      a.grp_kn[ng] = (unsigned char)(a.ph_kn[ph] - k0 < a.GT ? a.ph_kn[ph] - k0 : a.GT);
+      ++ng;
+    }
+    a.ph_ng[ph] = (unsigned char)(ng - a.ph_g0[ph]);
+  }
+  a.ngrp = ng;
+  // four phases in one launch pay when their weights are resident or the cout block is wide (measured, DispNetS bs=8 x 4 frames:
+  // 32 -> 16 at 512 x 432 resident 0.61 -> 0.31 ms; 128 -> 64 streamed 0.21 -> 0.19 ms; but 64 -> 32 streamed 0.24 -> 0.28 ms and
+  // the 5 x 5 input gradient 64 -> 32 0.30 -> 0.40 ms: per phase most of their launches keep resident weights)
+  if (a.nph > 1 && !a.res && bn < 64) return false;
   return ch2_lds(a) <= CH2_LDS_MAX;
 }
-template <int BN, int NH, int MT, bool RES>
+template <int BN, int NH, int MT, bool RES, int PH = 1, int KC = 0>
 static int ch2_launch3(const GenArgs& a, long grid, long lds, hipStream_t s) {
   static bool attr = false;
-  auto kern = convh2_kernel<BN, NH, MT, RES>;
+  auto kern = convh2_kernel<BN, NH, MT, RES, PH, KC>;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH2_LDS_MAX);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  DIS_TAG(RES ? "convh2_kernel (f16x2 LDS halo, resident weights)" : "convh2_kernel (f16x2 LDS halo)");
+  DIS_TAG(KC > 0 ? "convh2_kernel (f16x2 LDS halo, column walk)" : PH > 1 ? (RES ? "convh2_kernel (f16x2 LDS halo, 4 phases, resident weights)" : "convh2_kernel (f16x2 LDS halo, 4 phases)")
+                 : (RES ? "convh2_kernel (f16x2 LDS halo, resident weights)" : "convh2_kernel (f16x2 LDS halo)"));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, s, a);
   return DIS_OK;
 }
 template <int BN>
 static int ch2_launch(const GenArgs& a, int nh, long grid, long lds, hipStream_t s) {
+  if (a.nph == 4) {
+    if (a.res) {
+      if (nh <= 4) return ch2_launch3<BN, 4, 2, true, 4>(a, grid, lds, s);
+      return ch2_launch3<BN, 8, 2, true, 4>(a, grid, lds, s);
+    }
+    if (nh <= 8) return ch2_launch3<BN, 8, 2, false, 4>(a, grid, lds, s);
+    if (nh <= 14) return ch2_launch3<BN, 14, 2, false, 4>(a, grid, lds, s);
+    return ch2_launch3<BN, 20, 2, false, 4>(a, grid, lds, s);
+  }
   if (a.res) {
     if (nh <= 4) return ch2_launch3<BN, 4, 2, true>(a, grid, lds, s);
     return ch2_launch3<BN, 8, 2, true>(a, grid, lds, s);
+  }
+  if (a.kc > 0) {
+    if constexpr (BN == 32) {
+      if (a.kc == 7 && nh <= 16) return ch2_launch3<32, 16, 4, false, 1, 7>(a, grid, lds, s);
+    }
+    if constexpr (BN == 64) {
+      if (a.kc == 5 && nh <= 14) return ch2_launch3<64, 14, 4, false, 1, 5>(a, grid, lds, s);
+    }
+    return DIS_ERR_UNSUPPORTED;
   }
   if (a.trh == 16) {
     if (nh <= 8) return ch2_launch3<BN, 8, 4, false>(a, grid, lds, s);
@@ -1187,6 +1341,15 @@ static int ch2_run(GenArgs a, int bn, const float* w_raw, float* wpack, int ci_r
   p.w = w_raw; p.packed = (unsigned short*)wpack; p.ntaps = a.ntaps; p.nchunk = a.nchunk; p.nblk = a.nblk; p.bn = bn;
   p.ci_real = ci_real; p.co_real = co_real; p.tp = a.TP; p.nks = a.nks; p.s_ci = s_ci; p.s_co = s_co;
   for (int t = 0; t < a.ntaps; ++t) p.tsrc[t] = tsrc[t];
+  if (a.kc > 0) {
+    // column walk: taps ordered by (dx, dy) ascending - slot (dx - dx0) * kc + (dy - dy0); the window is full (ch2_plan)
+    short ty[CG_MAXTAPS], tx[CG_MAXTAPS];
+    for (int t = 0; t < a.ntaps; ++t) {
+      const int slot = (a.tdx[t] - a.dx0) * a.kc + (a.tdy[t] - a.dy0);
+      ty[slot] = a.tdy[t]; tx[slot] = a.tdx[t]; p.tsrc[slot] = tsrc[t];
+    }
+    for (int t = 0; t < a.ntaps; ++t) a.tdy[t] = ty[t], a.tdx[t] = tx[t];
+  }
   p.ws = const_cast<float*>(a.f2ws); p.n = a.n;
   const long ptotal = (long)a.nchunk * a.nblk * a.nks * 4 * bn * 4;
   hipLaunchKernelGGL(convh2_pack_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
@@ -1223,7 +1386,7 @@ static int cg2_ksplit(long wgs, int nk) {
 }
 // one launch of the forward-like kernel (packs its weights first)
 static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int co_real, long s_ci, long s_co,
-                  const short* tsrc, hipStream_t s) {
+                  const short* tsrc, hipStream_t s, bool halo_only = false) {
   if (a.ntaps <= 0) return DIS_OK;  // empty phase
   if ((long)a.n * a.hv * a.wv <= 0) return DIS_OK;
   const int bn = cg_bn(a.cout);
@@ -1234,6 +1397,7 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
     a.x_bytes = (unsigned)xb3;
     a.nchunk = (a.cin + CG3_CK - 1) / CG3_CK;
     if (ch2_plan(a, bn)) return ch2_run(a, bn, w_raw, wpack, ci_real, co_real, s_ci, s_co, tsrc, s);   // large maps: LDS halo form
+    if (halo_only) return DIS_ERR_UNSUPPORTED;   // (the caller falls back to one launch per phase)
     Pack2Args p2;
     p2.w = w_raw; p2.packed = (unsigned short*)wpack; p2.ntaps = a.ntaps; p2.nchunk = a.nchunk; p2.nblk = a.nblk;
     p2.bn = bn; p2.ci_real = ci_real; p2.co_real = co_real; p2.s_ci = s_ci; p2.s_co = s_co;
@@ -1261,6 +1425,7 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
     DIS_CHECK_LAUNCH();
     return DIS_OK;
   }
+  if (halo_only) return DIS_ERR_UNSUPPORTED;
   if (use3 && a.cin >= CG3_CK && xb3 < 0x7fff0000L) {  // bf16x3 form: 32-channel k-steps, weights pre-split
     a.x_bytes = (unsigned)xb3;
     a.nchunk = (a.cin + CG3_CK - 1) / CG3_CK;
@@ -1377,7 +1542,7 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
   a.hf = hout; a.wf = wout; a.ldy = ldy; a.yoff = yoff; a.cout = cout; a.act = act;
   short tsrc[CG_MAXTAPS];
   const long kk = (long)k * k;
-  a.f2ws = nullptr; a.ksplit = 1; a.skpart = nullptr; a.skcap = 0;
+  a.f2ws = nullptr; a.ksplit = 1; a.skpart = nullptr; a.skcap = 0; a.nph = 1;
   if (dis_f2_enabled() && cin >= CG3_CK && n <= CG2_NMAX) {
     // (split-K partial sums: behind the packing slices, dis_convg_splitk_workspace floats)
     const int phases = ((mode == DIS_CONVG_CONV_DGRAD || mode == DIS_CONVG_TCONV) && stride == 2) ? 4 : 1;
@@ -1425,6 +1590,37 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
     return cg_run(a, w, wpack, cin_w, cout_w, s_ci, s_co, tsrc, s);
   }
   const long pstride = dis_convg_pack_workspace(cin, cout, k);  // every phase packs into its own slice
+  if (a.f2ws && k * k <= 255 && !getenv("DIS_CONVG_NO_FUSED_PHASES")) {
+    // the four parity classes in ONE launch of the halo kernel (they read the same input tile): taps listed class by class
+    GenArgs b = a;
+    b.hv = (hout + 1) / 2; b.wv = (wout + 1) / 2; b.S = 1;
+    b.osy = 2; b.ooy = 0; b.osx = 2; b.oox = 0;
+    b.nph = 4;
+    int nt = 0;
+    bool ok = true;
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        const int ph = py * 2 + px, t0 = nt;
+        for (int ky = 0; ky < k; ++ky) {
+          if ((py + pad - ky) & 1) continue;
+          for (int kx = 0; kx < k; ++kx) {
+            if ((px + pad - kx) & 1) continue;
+            b.tdy[nt] = (short)floordiv2(py + pad - ky);
+            b.tdx[nt] = (short)floordiv2(px + pad - kx);
+            tsrc[nt] = (short)(ky * k + kx);
+            ++nt;
+          }
+        }
+        b.ph_k0[ph] = (unsigned char)t0; b.ph_kn[ph] = (unsigned char)(nt - t0);
+        b.ph_oy[ph] = (unsigned char)py; b.ph_ox[ph] = (unsigned char)px;
+        ok = ok && nt > t0;
+      }
+    b.ntaps = nt;
+    if (ok) {
+      const int rc = cg_run(b, w, wpack, cin_w, cout_w, s_ci, s_co, tsrc, s, true);
+      if (rc != DIS_ERR_UNSUPPORTED) return rc;
+    }
+  }
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       GenArgs b = a;
