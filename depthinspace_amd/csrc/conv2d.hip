@@ -2185,10 +2185,11 @@ static int wgrad_pairs_launch(WgArgs a, float* grad_w, int cX_w, int cG_w, int n
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  // two-term fp16 split (conv_f16x2.hip, default): the fp32 3 x 3 stride-1 pairs; same slab layout, same reduce launch
+  // two-term fp16 split (conv_f16x2.hip, default) for the fp32 pairs; same slab layout, same reduce launch
   hipError_t le = hipErrorInvalidValue;
-  if (!BF && K == 3 && S == 1 && KH == 3 && dis_f2_enabled())
-    le = dis_f2_wgrad_pairs_launch(a, COB, (unsigned)wpp, (unsigned)(a.npx * ngb), s);
+  static const bool f2_all = !getenv("DIS_F2_WGRAD_3X3_ONLY");
+  if (!BF && dis_f2_enabled() && (f2_all || (K == 3 && S == 1)))
+    le = dis_f2_wgrad_pairs_launch(a, COB, (unsigned)wpp, (unsigned)(a.npx * ngb), K, S, KH, s);
   if (le != hipSuccess && le != hipErrorInvalidValue) return (int)le;
   if (le != hipSuccess) {
     DIS_TAG(BF ? "conv_wgrad_bf16x3_kernel<BF> slice pairs" : "conv_wgrad_bf16x3_kernel slice pairs");

@@ -162,6 +162,7 @@ __device__ __forceinline__ int f2_scale_exp(float m) {
 hipError_t dis_f2_conv_launch(const ConvArgs& a, int cin, int cout, bool stats, int inact, long grid, hipStream_t stream);
 hipError_t dis_f2_wgrad_launch(const WgArgs& a, int cin, int cout, int inact, long workers, hipStream_t stream);
 hipError_t dis_f2_conv_gen_launch(const ConvArgs& a, long grid, hipStream_t stream);  // 32 x 32 channel slices (DispNetS)
-hipError_t dis_f2_wgrad_pairs_launch(const WgArgs& a, int cob, unsigned workers, unsigned pairs, hipStream_t stream);
+hipError_t dis_f2_wgrad_pairs_launch(const WgArgs& a, int cob, unsigned workers, unsigned pairs, int k, int stride, int kh,
+                                     hipStream_t stream);
 bool dis_f2_enabled();
 int dis_f2_wgrad_wpc();   // workgroups per CU the two-term weight-gradient kernel is built for

@@ -788,17 +788,20 @@ hipError_t dis_f2_conv_launch(const ConvArgs& a, int cin, int cout, bool stats, 
 // carry the coarser scale: their absolute error is bounded by 2^-24 x 2^-15 of the largest magnitude seen, which is what a sum
 // over all pixels can resolve anyway.  The slab is written as acc * 2^-(sx + sg).
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT>
+// K x K taps, stride S, TR x 16 output pixels per tile, KH of the K tap rows per workgroup (blockIdx.z selects the group): the
+// FuseNet instances are K = 3, S = 1, TR = 8; the slice-pair instances of DispNetS also use 5 x 5 / 7 x 7 taps and stride 2
+// (the geometry of conv2d.hip's WxCfg).
+template <int CIN, int COUT, int K_ = 3, int S_ = 1, int TR_ = 8, int KH_ = K_>
 struct F2WxCfg {
-  static constexpr int NP = 2, K = 3, TR = 8;
-  static constexpr int ps_for(int payload_u16) {  // see WxCfg::ps_for (conflict-free transposing reads)
+  static constexpr int NP = 2, K = K_, S = S_, TR = TR_, KH = KH_;
+  static constexpr int ps_for(int payload_u16, int step) {  // see WxCfg::ps_for (conflict-free transposing reads)
     int ps = (payload_u16 + 7) / 8 * 8;
-    while (((ps / 2) % 16) != 8) ps += 8;
+    while (((step * (ps / 2)) % 16) != 8) ps += 8;
     return ps;
   }
-  static constexpr int PSX = ps_for(NP * CIN), PSG = ps_for(NP * COUT);
+  static constexpr int PSX = ps_for(NP * CIN, S), PSG = ps_for(NP * COUT, 1);
   static constexpr int CVX = CIN / 4, CVG = COUT / 4;
-  static constexpr int IR = TR - 1 + K, IC = 15 + K;
+  static constexpr int IR = (TR - 1) * S + KH, IC = 15 * S + K;
   static constexpr int X_U16 = IR * IC * PSX, G_U16 = TR * 16 * PSG;
   // + wave maxima [parity][x|g][wave]; the bias partials (1024 floats, end of the kernel only) alias the x halo
   static constexpr int LDS_BYTES = (X_U16 + G_U16) * 2 + 64;
@@ -806,7 +809,8 @@ struct F2WxCfg {
   static constexpr int NIX = IR * IC * CVX, NLX = (NIX + 255) / 256;
   static constexpr int NLG = TR * 16 * CVG / 256;
   static constexpr int KSN = TR / 2;
-  static constexpr int MB = K * K * CIN / 16, NB = COUT / 16, T = MB * NB, TW = (T + 3) / 4;
+  static constexpr int MB = KH * K * CIN / 16, NB = COUT / 16, T = MB * NB, TW = (T + 3) / 4;
+  static_assert(TR % 2 == 0 && (TR * 16 * CVG) % 256 == 0, "tile geometry");
 };
 
 #ifndef F2W_WPC
@@ -830,10 +834,13 @@ __device__ __forceinline__ void f2_static_for(F&& f) {
 // GEN: channel-slice PAIRS of a wide layer (DispNetS, conv2d.hip dis_wgrad_pairs_run: 3 x 3, stride 1): blockIdx.y = gb * npx + cb
 // selects x channels [32 cb, 32 cb + 32) and gy channels [COUT gb, + COUT) of pixels that occupy a.ldx / a.ldg floats; channels
 // past the layer's last one load zeros; one slab per (pair, worker).
-template <int CIN, int COUT, int INACT = 0, bool INGN = false, bool GEN = false>
-__global__ __launch_bounds__(256, F2W_WPC) void conv_wgrad_f16x2_kernel(WgArgs a) {
-  using C = F2WxCfg<CIN, COUT>;
+template <int CIN, int COUT, int INACT = 0, bool INGN = false, bool GEN = false, int K_ = 3, int S_ = 1, int TR_ = 8, int KH_ = K_>
+__global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_wgrad_f16x2_kernel(WgArgs a) {
+  using C = F2WxCfg<CIN, COUT, K_, S_, TR_, KH_>;
   static_assert(!GEN || (CIN == 32 && INACT == 0 && !INGN), "slice-pair form");
+  static_assert(GEN || (K_ == 3 && S_ == 1 && TR_ == 8 && KH_ == 3), "the FuseNet form");
+  constexpr int S = S_, KH = KH_;
+  const int ky0 = KH < K_ ? (int)blockIdx.z * KH : 0;  // first tap row of this workgroup (7x7: two groups of 4 rows)
   const int ldx = GEN ? a.ldx : CIN, ldg = GEN ? a.ldg : COUT;
   const int cb = GEN ? (int)blockIdx.y % a.npx : 0, gbk = GEN ? (int)blockIdx.y / a.npx : 0;
   const int xc0 = GEN ? a.xoff + 32 * cb : 0, gc0 = GEN ? a.goff + COUT * gbk : 0;
@@ -882,7 +889,7 @@ __global__ __launch_bounds__(256, F2W_WPC) void conv_wgrad_f16x2_kernel(WgArgs a
   }
   auto prefetch = [&](int tile) __attribute__((always_inline)) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-    const int iy0 = ty * TR - a.pad, ix0 = tx * 16 - a.pad;
+    const int iy0 = ty * (TR * S) - a.pad + ky0, ix0 = tx * (16 * S) - a.pad;
     st_iy0 = iy0, st_ix0 = ix0, st_n = n;
     const char* xb = (const char*)a.x + (long)n * a.hin * a.win * ldx * 4;
     const int xoff0 = (iy0 * a.win + ix0) * (ldx * 4);
@@ -1015,9 +1022,9 @@ __global__ __launch_bounds__(256, F2W_WPC) void conv_wgrad_f16x2_kernel(WgArgs a
     };
     auto load_fa = [&](int ks, int mb, s16x8 (&F)[NP]) __attribute__((always_inline)) {
       const int tap = CIN == 32 ? mb >> 1 : mb, half = CIN == 32 ? mb & 1 : 0, ky = tap / K, kx = tap - K * ky;
-      const unsigned short* xq = xl + ((2 * ks + ky) * WX_IC + (4 * lg + tq) + kx) * PSX + half * 16 + tp * 4;
+      const unsigned short* xq = xl + ((2 * ks * S + ky) * WX_IC + (4 * lg + tq) * S + kx) * PSX + half * 16 + tp * 4;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) F[p] = f2_tr_read8(xq + p * CIN, xq + WX_IC * PSX + p * CIN);
+      for (int p = 0; p < NP; ++p) F[p] = f2_tr_read8(xq + p * CIN, xq + S * WX_IC * PSX + p * CIN);
     };
     int parity = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -1072,7 +1079,7 @@ __global__ __launch_bounds__(256, F2W_WPC) void conv_wgrad_f16x2_kernel(WgArgs a
     }
     // partial slab of this workgroup: [m = mb*16 + row][co], scales undone
     const float desc = __builtin_ldexpf(1.f, -(sx_e + sg_e));
-    float* out = a.part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (C::MB * 16 * COUT);
+    float* out = a.part + (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (C::MB * 16 * COUT);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       const int t = T0 + j, mb = t / NB, nb = t % NB;
@@ -1131,21 +1138,36 @@ static hipError_t f2_wgrad_launch(const WgArgs& a, int inact, long workers, hipS
   return hipErrorInvalidValue;
 }
 
-// slice-pair form (conv2d.hip wgrad_pairs_launch, 3 x 3 stride 1): grid = (workers per pair, pairs); cob = gy channels per pair
-hipError_t dis_f2_wgrad_pairs_launch(const WgArgs& a, int cob, unsigned workers, unsigned pairs, hipStream_t stream) {
-  static bool attr_set[2] = {};
-  auto launch = [&](auto kern, int lds, int slot) -> hipError_t {
+// slice-pair form (conv2d.hip wgrad_pairs_launch): grid = (workers per pair, pairs, tap-row groups); cob = gy channels per pair;
+// (k, stride, kh) as conv2d.hip instantiates the three-term kernel: 3x3 / 5x5 at stride 1 and 2, 7x7 in two groups of 4 tap rows
+hipError_t dis_f2_wgrad_pairs_launch(const WgArgs& a, int cob, unsigned workers, unsigned pairs, int k, int stride, int kh,
+                                     hipStream_t stream) {
+  static bool attr_set[6] = {};
+  auto launch = [&](auto kern, int lds, int slot, unsigned ngrp) -> hipError_t {
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (!attr_set[slot]) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return e;
       attr_set[slot] = true;
     }
     DIS_TAG("conv_wgrad_f16x2_kernel slice pairs");
-    hipLaunchKernelGGL(kern, dim3(workers, pairs), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(workers, pairs, ngrp), dim3(256), lds, stream, a);
     return hipSuccess;
   };
-  if (cob == 32) return launch(conv_wgrad_f16x2_kernel<32, 32, 0, false, true>, F2WxCfg<32, 32>::LDS_BYTES, 0);
-  if (cob == 16) return launch(conv_wgrad_f16x2_kernel<32, 16, 0, false, true>, F2WxCfg<32, 16>::LDS_BYTES, 1);
+  if (k == 3 && stride == 1 && kh == 3) {
+    if (cob == 32) return launch(conv_wgrad_f16x2_kernel<32, 32, 0, false, true>, F2WxCfg<32, 32>::LDS_BYTES, 0, 1);
+    if (cob == 16) return launch(conv_wgrad_f16x2_kernel<32, 16, 0, false, true>, F2WxCfg<32, 16>::LDS_BYTES, 1, 1);
+    return hipErrorInvalidValue;
+  }
+  if (cob != 32) return hipErrorInvalidValue;
+  if (k == 5 && stride == 1 && kh == 5)
+    return launch(conv_wgrad_f16x2_kernel<32, 32, 0, false, true, 5, 1, 8, 5>, F2WxCfg<32, 32, 5, 1, 8, 5>::LDS_BYTES, 2, 1);
+  if (k == 3 && stride == 2 && kh == 3)
+    return launch(conv_wgrad_f16x2_kernel<32, 32, 0, false, true, 3, 2, 4, 3>, F2WxCfg<32, 32, 3, 2, 4, 3>::LDS_BYTES, 3, 1);
+  if (k == 5 && stride == 2 && kh == 5)
+    return launch(conv_wgrad_f16x2_kernel<32, 32, 0, false, true, 5, 2, 4, 5>, F2WxCfg<32, 32, 5, 2, 4, 5>::LDS_BYTES, 4, 1);
+  if (k == 7 && stride == 1 && kh == 4)
+    return launch(conv_wgrad_f16x2_kernel<32, 32, 0, false, true, 7, 1, 8, 4>, F2WxCfg<32, 32, 7, 1, 8, 4>::LDS_BYTES, 5, 2);
   return hipErrorInvalidValue;
 }
 
