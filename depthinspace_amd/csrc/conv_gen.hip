@@ -1532,7 +1532,7 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
   // (7x7 layers: the two-term halo kernel runs all 49 taps in one launch; the tap rows of the resident-weight kernel - seven
   // accumulating launches, each a pass over x and two over y - stay the three-term path's form)
   const bool halo7 = k == 7 && dis_f2_enabled() && cin >= CG3_CK && n <= CG2_NMAX && !getenv("DIS_CONVG_NO_HALO7");
-  if ((mode == DIS_CONVG_CONV || mode == DIS_CONVG_CONV_DGRAD) && hin == hout && win == wout && !halo7 &&
+  if ((mode == DIS_CONVG_CONV || mode == DIS_CONVG_CONV_DGRAD) && hin == hout && win == wout && !halo7 && !getenv("DIS_CONVG_NO_SLICES") &&
       dis_bx_slices_ok(n, hin, win, cin, cout, ldx, ldy, xoff, yoff, k, stride, pad, act))
     return dis_bx_slices_run(mode == DIS_CONVG_CONV_DGRAD, x, ldx, xoff, cin, cin_w, w, bias, y, ldy, yoff, cout, cout_w,
                              n, hin, win, k, act, s);

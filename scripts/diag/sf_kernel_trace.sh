@@ -4,7 +4,7 @@
 OUT=/root/repo/gpurun_out/$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o run -- python3 /root/repo/scripts/sf_profile.py 8 > $OUT/calls.txt 2> $OUT/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o run -- python3 /root/repo/scripts/sf_profile.py 8 $2 > $OUT/calls.txt 2> $OUT/err.txt
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 out = sys.argv[1]
@@ -16,7 +16,7 @@ n = len(rows) // 3
 with open(out + '/dispatches.txt', 'w') as g:
     for r in rows[-n:]:
         name = r['Kernel_Name']
-        if not any(k in name for k in ('convh2', 'convg', 'conv_f16x2', 'conv_bf16x3', 'conv_wgrad')):
+        if not any(k in name for k in ('convh2', 'convg', 'convb', 'conv_f16x2', 'conv_bf16x3', 'conv_wgrad')):
             continue
         us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
         g.write(f"{us:9.1f} us  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>9} wg {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?')):>4} lds {r.get('LDS_Block_Size','?'):>7} vgpr {r.get('VGPR_Count','?'):>4}+{r.get('Accum_VGPR_Count','?'):<4}  {name[:150]}\n")
