@@ -50,6 +50,7 @@ struct GenArgsB {
   // weight group, tile grid
   int dy0, dx0, HR, HC, PS, TP, nks, GT, tiles_x, tiles_y;
   int trh;         // tile rows: 8 (2 per wave) or 16 (4 per wave)
+  int kc;          // column walk: taps ordered dx-major / dy ascending, a weight group = one column of kc taps (0: generic walk)
   int res, wsz16;  // weights of a cout block resident in LDS (all chunks); 16-bit words of the weight region in front of the halo
   // convb_fwd128_kernel, split-K (small maps: fewer workgroups than CUs, each with a long chain of dependent stages):
   // blockIdx.y = split takes the stages [nk * split / ksplit, nk * (split + 1) / ksplit) and leaves its raw fp32 sums in
@@ -452,9 +453,14 @@ __global__ void convb_pack_kernel(PackArgsB a) {
 // while the current stage's MFMAs run; pixels outside the image / channels past cin get an out-of-range buffer offset (zeros).
 // MT = output rows per wave: 2 (8 x 16 tiles), or 4 (16 x 16 tiles: twice the MFMAs per streamed weight group and a smaller halo
 // overhead - the layers whose weights do not stay resident, 7x7 / 5x5 taps)
-template <int BN, bool XB, bool YB, int NH, int MT>
+// KC > 0 (round 4; streamed weights, stride 1, a full KC x KC window: the 7 x 7 and 5 x 5 layers): the column walk of
+// conv_gen.hip's convh2_kernel - taps ordered column by column, a weight group = one column, the MT + KC - 1 row fragments of a
+// column read once and kept in registers while ky slides down: 1 + NT ds_read_b128 per k-step instead of MT + NT for MT NT MFMAs
+// (MT 4, NT 2: six reads per eight MFMAs had the LDS port 1.5 x as busy as the matrix unit).
+template <int BN, bool XB, bool YB, int NH, int MT, int KC = 0>
 __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
   constexpr int NT = BN / 16, TRH = 4 * MT;
+  constexpr int NRB = KC > 0 ? (KC * 4 * BN + 255) / 256 : 4;   // 16-byte vectors of a weight group per thread
   extern __shared__ __attribute__((aligned(16))) unsigned short hsm[];
   int* toff = (int*)hsm;                     // 64 ints
   const int bsz = a.GT * 4 * BN * 8;         // 16-bit words of one weight buffer
@@ -487,12 +493,12 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
   const int rowstep = a.S * HC * PS;
   const u32x4* wq = (const u32x4*)a.w;  // packed [chunk][nb][kstep][lg][BN][8]
   const int ngrp = (a.nks + a.GT - 1) / a.GT;
-  u32x4 rb[4];
+  u32x4 rb[NRB];
   auto pref_b = [&](int nb, int c, int g) __attribute__((always_inline)) {
     const long base = ((long)(c * a.nblk + nb) * a.nks + g * a.GT) * (4 * BN);
     const int cnt = min(a.GT, a.nks - g * a.GT) * (4 * BN);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NRB; ++i) {
       const int idx = tid + i * 256;
       rb[i] = wq[base + (idx < cnt ? idx : 0)];
     }
@@ -581,6 +587,41 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
         to1 = kk + 3 < kn ? tq[(kk + 3) * a.TP] : 0;
         mac(fa1, fb1);
       }
+    }
+  };
+  // one column of KC taps (weights B: [ky][lg][BN][8]; `to` = halo offset of the column's first tap): sliding window of row fragments.
+  // Rn: the first MT rows of the NEXT column (offset to_next), requested during the last k-step of this one.
+  constexpr int KCC = KC > 0 ? KC : 1;
+  s16x8 Rn[MT];
+  auto col_rows = [&](int to) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j) Rn[j] = *(const s16x8*)(halo + a_lane + j * rowstep + to);
+  };
+  auto kcolumn = [&](const unsigned short* B, int to, int to_next, bool has_next) __attribute__((always_inline)) {
+    const unsigned short* bl = B + (lg * BN + li) * 8;
+    s16x8 R[MT + KCC - 1];
+    s16x8 fb[2][NT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) R[j] = Rn[j];
+    auto load_fb = [&](int ky, s16x8 (&f)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) f[nt] = *(const s16x8*)(bl + (ky * 4 * BN + nt * 16) * 8);
+    };
+    load_fb(0, fb[0]);
+#pragma unroll
+    for (int ky = 0; ky < KCC; ++ky) {
+      if (ky + 1 < KCC) {
+        R[ky + MT] = *(const s16x8*)(halo + a_lane + (ky + MT) * rowstep + to);
+        load_fb(ky + 1, fb[(ky + 1) & 1]);
+      } else if (has_next) {
+        col_rows(to_next);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ky & 1][nt]),
+                                                               __builtin_bit_cast(bf16x8, R[ky + mt]), acc[mt][nt], 0, 0, 0);
     }
   };
   using S0 = std::integral_constant<int, 0>;
@@ -707,7 +748,7 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
       for (int g = 0; g < ngrp; ++g) {
         unsigned short* B = Bb + (flat & 1) * bsz;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NRB; ++i) {
           const int idx = tid + i * 256;
           if (idx < a.GT * 4 * BN) ((u32x4*)B)[idx] = rb[i];
         }
@@ -719,7 +760,12 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
         if (g + 1 < ngrp) pref_b(nb, c, g + 1);
         else if (c + 1 < a.nchunk) pref_b(nb, c + 1, 0);
         else if (un < u_hi) pref_b(unit_nb(un), 0, 0);
-        ksteps(B, toff + g * a.GT * a.TP + lgq, min(a.GT, a.nks - g * a.GT));
+        if constexpr (KC > 0) {
+          if (g == 0) col_rows(toff[0]);   // (the first column of a stage: its rows were not requested by a predecessor)
+          kcolumn(B, toff[g * KC], g + 1 < ngrp ? toff[(g + 1) * KC] : 0, g + 1 < ngrp);
+        } else {
+          ksteps(B, toff + g * a.GT * a.TP + lgq, min(a.GT, a.nks - g * a.GT));
+        }
         ++flat;
       }
     }
@@ -937,19 +983,34 @@ static bool cb_halo_plan(GenArgsB& a, int bn) {
       a.tiles_y = (a.hv + 15) / 16;
     }
   }
+  // column walk (convb_halo_kernel, KC): a full K x K stride-1 window on 16-row tiles, the instances that exist
+  a.kc = 0;
+  {
+    const int K = dy1 - dy0 + 1;
+    static const bool nokc = getenv("DIS_CONVB_KC") && getenv("DIS_CONVB_KC")[0] == '0';
+    if (!nokc && a.S == 1 && a.TP == 1 && !a.res && a.trh == 16 && dx1 - dx0 + 1 == K && a.ntaps == K * K &&
+        ((K == 7 && bn == 32) || (K == 5 && bn == 64))) {
+      const long wsz = 2L * K * 4 * bn * 16 / 2;   // two buffers of one column (16-bit words)
+      if (256 + 2 * wsz + (long)a.HR * a.HC * a.PS * 2 <= 150 * 1024) {
+        a.kc = K;
+        a.GT = K;
+        a.wsz16 = (int)wsz;
+      }
+    }
+  }
   return cb_halo_lds(a, bn) <= 150 * 1024;
 }
 static long cb_halo_lds(const GenArgsB& a, int bn) { return 256 + 2L * a.wsz16 + (long)a.HR * a.HC * a.PS * 2; }
-template <int BN, bool XB, bool YB, int NH, int MT>
+template <int BN, bool XB, bool YB, int NH, int MT, int KC = 0>
 static int cbh_launch3(const GenArgsB& a, long grid, long lds, hipStream_t s) {
   static bool attr = false;
-  auto kern = convb_halo_kernel<BN, XB, YB, NH, MT>;
+  auto kern = convb_halo_kernel<BN, XB, YB, NH, MT, KC>;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  DIS_TAG("convb_halo_kernel (bf16 LDS halo)");
+  DIS_TAG(KC > 0 ? "convb_halo_kernel (bf16 LDS halo, column walk)" : "convb_halo_kernel (bf16 LDS halo)");
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, s, a);
   return DIS_OK;
 }
@@ -966,16 +1027,38 @@ static int cbh_launch1(const GenArgsB& a, int nh, long grid, long lds, hipStream
 }
 template <bool XB, bool YB>
 static int cbh_launch(const GenArgsB& a, int bn, int nh, long grid, long lds, hipStream_t s) {
+  if (a.kc > 0) {   // (cb_halo_plan grants the column walk to bf16 -> bf16 layers of these two shapes only)
+    if constexpr (XB && YB) {
+      if (a.kc == 7 && bn == 32 && nh <= 8) return cbh_launch3<32, true, true, 8, 4, 7>(a, grid, lds, s);
+      if (a.kc == 5 && bn == 64 && nh <= 8) return cbh_launch3<64, true, true, 8, 4, 5>(a, grid, lds, s);
+    }
+    return DIS_ERR_UNSUPPORTED;
+  }
   if (bn == 64) return cbh_launch1<64, XB, YB>(a, nh, grid, lds, s);
   if (bn == 32) return cbh_launch1<32, XB, YB>(a, nh, grid, lds, s);
   return cbh_launch1<16, XB, YB>(a, nh, grid, lds, s);
 }
 static int cb_run_halo(GenArgsB a, int x_bf16, int y_bf16, int bn, const float* w_raw, bf16_t* wpack, int ci_real,
                        int co_real, long s_ci, long s_co, const short* tsrc, hipStream_t s) {
+  if (a.kc > 0 && !(x_bf16 && y_bf16)) {   // (no instance: the generic walk with its own group size)
+    a.kc = 0;
+    a.GT = CBH_GVEC / (4 * bn);
+    if (a.GT > a.nks) a.GT = a.nks;
+    a.wsz16 = (int)((2L * a.GT * 4 * bn * 16) / 2);
+  }
   PackArgsH p;
   p.w = w_raw; p.packed = wpack; p.ntaps = a.ntaps; p.nchunk = a.nchunk; p.nblk = a.nblk; p.bn = bn;
   p.ci_real = ci_real; p.co_real = co_real; p.tp = a.TP; p.nks = a.nks; p.s_ci = s_ci; p.s_co = s_co;
   for (int t = 0; t < a.ntaps; ++t) p.tsrc[t] = tsrc[t];
+  if (a.kc > 0) {
+    // column walk: taps ordered by (dx, dy) ascending - slot (dx - dx0) * kc + (dy - dy0); the window is full (cb_halo_plan)
+    short ty[CB_MAXTAPS], tx[CB_MAXTAPS];
+    for (int t = 0; t < a.ntaps; ++t) {
+      const int slot = (a.tdx[t] - a.dx0) * a.kc + (a.tdy[t] - a.dy0);
+      ty[slot] = a.tdy[t]; tx[slot] = a.tdx[t]; p.tsrc[slot] = tsrc[t];
+    }
+    for (int t = 0; t < a.ntaps; ++t) a.tdy[t] = ty[t], a.tdx[t] = tx[t];
+  }
   const long ptotal = (long)a.nchunk * a.nblk * a.nks * 4 * bn * 8;
   if (w_raw) {  // (null: the call runs on weights dis_convb_pack_batch has packed)
     hipLaunchKernelGGL(convb_pack_halo_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
