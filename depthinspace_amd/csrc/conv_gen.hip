@@ -556,18 +556,28 @@ __global__ __launch_bounds__(256) void convg2_pack_kernel(Pack2Args a) {
   }
 }
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void convg2_fwd_kernel(GenArgs a) {
-  constexpr int NT = BN / 16;
-  constexpr int NBQ = (2 * 4 * BN + 255) / 256;                   // 16-byte vectors of the B tile per thread
-  constexpr int A_U16 = CG_BM * CG2_PS, B_U16 = NBQ * 256 * 8;    // per buffer (B padded to whole rounds of the block)
-  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (A_U16 + B_U16)];
+// NW waves per workgroup = 32 NW output pixels x BN couts: 4 x 64 (128-pixel tiles, two workgroups per CU) for most layers;
+// 8 x 128 for the deep ones (>= 128 channels on both sides), whose bound is the operand traffic from L2 / Infinity Cache - a
+// 128 x 64 tile moves 24 KB per k-step for 128 x 64 x 32 MACs, a 256 x 128 tile 48 KB for four times as many.
+template <int BN, int NW = 4>
+struct Cg2Cfg {
+  static constexpr int NTHR = 64 * NW, BM = 32 * NW;
+  static constexpr int NBQ = (2 * 4 * BN + NTHR - 1) / NTHR;           // 16-byte vectors of the B tile per thread
+  static constexpr int A_U16 = BM * CG2_PS, B_U16 = NBQ * NTHR * 8;    // per buffer (B padded to whole rounds of the block)
+  static constexpr int LDS_BYTES = 2 * (A_U16 + B_U16) * 2;
+};
+template <int BN, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void convg2_fwd_kernel(GenArgs a) {
+  using CF = Cg2Cfg<BN, NW>;
+  constexpr int NT = BN / 16, NTHR = CF::NTHR, BM = CF::BM, PSTEP = NTHR / 8;   // PSTEP: pixels one loader pass covers
+  constexpr int NBQ = CF::NBQ, A_U16 = CF::A_U16, B_U16 = CF::B_U16;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int M = a.n * a.hv * a.wv;
-  const int nb = blockIdx.x % a.nblk, m0 = (blockIdx.x / a.nblk) * CG_BM;
+  const int nb = blockIdx.x % a.nblk, m0 = (blockIdx.x / a.nblk) * BM;
   const int* sexp = (const int*)a.f2ws + CG2_EOFF;
 
-  // loader role: thread owns channel group pq (4 channels) of pixels p0 + 32 j of the tile
+  // loader role: thread owns channel group pq (4 channels) of pixels p0 + PSTEP j of the tile
   const int pq = tid & 7, p0 = tid >> 3;
   long pbase[4];
   int piy[4], pix[4];
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void convg2_fwd_kernel(GenArgs a) {
   float psc[4];   // 2^(scale exponent of the row's image)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int m = m0 + p0 + j * 32;
+    const int m = m0 + p0 + j * PSTEP;
     pval[j] = m < M;
     const int mm = pval[j] ? m : 0;
     const int vx = mm % a.wv, t = mm / a.wv, vy = t % a.hv, nn = t / a.hv;
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void convg2_fwd_kernel(GenArgs a) {
     }
     const long wb = ((long)(ptap * a.nchunk + pchunk) * a.nblk + nb) * (2 * 4 * BN);
 #pragma unroll
-    for (int q = 0; q < NBQ; ++q) rb[set][q] = wq[wb + min(tid + q * 256, 2 * 4 * BN - 1)];
+    for (int q = 0; q < NBQ; ++q) rb[set][q] = wq[wb + min(tid + q * NTHR, 2 * 4 * BN - 1)];
     ++pnext;
     if (++pchunk == a.nchunk) {
       pchunk = 0;
@@ -622,12 +632,12 @@ __global__ __launch_bounds__(256, 2) void convg2_fwd_kernel(GenArgs a) {
       unsigned a1, a2, b1, b2;
       f2_split_pair_scaled(v.x, v.y, psc[j], a1, a2);
       f2_split_pair_scaled(v.z, v.w, psc[j], b1, b2);
-      unsigned short* p = A + (p0 + j * 32) * CG2_PS + pq * 4;
+      unsigned short* p = A + (p0 + j * PSTEP) * CG2_PS + pq * 4;
       *(uint2*)(p) = make_uint2(a1, b1);
       *(uint2*)(p + 32) = make_uint2(a2, b2);
     }
 #pragma unroll
-    for (int q = 0; q < NBQ; ++q) ((u32x4*)B)[tid + q * 256] = rb[set][q];  // (B is padded to NBQ * 256 vectors)
+    for (int q = 0; q < NBQ; ++q) ((u32x4*)B)[tid + q * NTHR] = rb[set][q];  // (B is padded to NBQ * 256 vectors)
   };
 
   f32x4 acc[2][NT];
@@ -1377,6 +1387,11 @@ static int cg_bn(int cout) { return cout > 32 ? 64 : (cout > 16 ? 32 : 16); }
 
 // split-K factor of the two-term streaming kernel: only when the launch has fewer workgroups than the device has CUs and a long
 // chain of k-steps; aims at ~2 workgroups per CU, at least 12 k-steps per split, at most 8 splits
+// 256 x 128 tiles (convg2_fwd_kernel<128, 8>): both channel counts >= 128 and the cout a multiple of 128
+static bool cg2_big(int cin, int cout) {
+  static const bool off = getenv("DIS_CONVG_BIG") && getenv("DIS_CONVG_BIG")[0] == '0';
+  return !off && cin >= 128 && cout >= 128 && cout % 128 == 0;
+}
 static int cg2_ksplit(long wgs, int nk) {
   if (wgs >= 256 || nk < 48) return 1;
   long ks = (512 + wgs - 1) / wgs;
@@ -1384,12 +1399,20 @@ static int cg2_ksplit(long wgs, int nk) {
   while (ks > 1 && nk / ks < 12) --ks;
   return (int)ks;
 }
+// ... and enough of them: a launch of M output positions and nk k-steps takes the large tiles when they still make ~3/4 of a
+// workgroup per CU (with split-K).  The parity classes of the small stride-2 maps (M = 7 k, 16 - 64 k-steps) do not: 56 workgroups
+// of 256 x 128 ran 0.19 -> 0.23 ms.
+static bool cg2_big_for(int cin, int cout, long M, int nk) {
+  if (!cg2_big(cin, cout)) return false;
+  const long wgs = ((M + 255) / 256) * (cout / 128);
+  return wgs * cg2_ksplit(wgs, nk) >= 192;
+}
 // one launch of the forward-like kernel (packs its weights first)
 static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int co_real, long s_ci, long s_co,
                   const short* tsrc, hipStream_t s, bool halo_only = false) {
   if (a.ntaps <= 0) return DIS_OK;  // empty phase
   if ((long)a.n * a.hv * a.wv <= 0) return DIS_OK;
-  const int bn = cg_bn(a.cout);
+  const int bn = cg_bn(a.cout), bn0 = bn;
   a.nblk = (a.cout + bn - 1) / bn;
   static const bool use3 = !(getenv("DIS_CONV_BF16X3") && getenv("DIS_CONV_BF16X3")[0] == '0');
   const long xb3 = (long)a.n * a.hin * a.win * a.ldx * 4;  // the bf16x3 kernel addresses x with 31-bit byte offsets
@@ -1398,6 +1421,9 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
     a.nchunk = (a.cin + CG3_CK - 1) / CG3_CK;
     if (ch2_plan(a, bn)) return ch2_run(a, bn, w_raw, wpack, ci_real, co_real, s_ci, s_co, tsrc, s);   // large maps: LDS halo form
     if (halo_only) return DIS_ERR_UNSUPPORTED;   // (the caller falls back to one launch per phase)
+    const bool big = cg2_big_for(a.cin, a.cout, (long)a.n * a.hv * a.wv, a.ntaps * a.nchunk);   // deep layers: 256 x 128 tiles
+    const int bn = big ? 128 : bn0;
+    a.nblk = (a.cout + bn - 1) / bn;
     Pack2Args p2;
     p2.w = w_raw; p2.packed = (unsigned short*)wpack; p2.ntaps = a.ntaps; p2.nchunk = a.nchunk; p2.nblk = a.nblk;
     p2.bn = bn; p2.ci_real = ci_real; p2.co_real = co_real; p2.s_ci = s_ci; p2.s_co = s_co;
@@ -1407,7 +1433,8 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
     hipLaunchKernelGGL(convg2_pack_kernel, dim3(dis_ew_grid(ptotal2, 256)), dim3(256), 0, s, p2);
     a.w = wpack;
     const long M2 = (long)a.n * a.hv * a.wv;
-    const long grid2 = ((M2 + CG_BM - 1) / CG_BM) * a.nblk;
+    const int bm2 = big ? 256 : CG_BM;
+    const long grid2 = ((M2 + bm2 - 1) / bm2) * a.nblk;
     if (grid2 > 2147483647L) return DIS_ERR_BAD_SHAPE;
     // split-K for the small maps (see GenArgs::ksplit): enough workgroups to fill the device twice, >= 12 k-steps per split
     const int nk2 = a.ntaps * a.nchunk, coutp = a.nblk * bn;
@@ -1417,9 +1444,20 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
     a.ksplit = ksplit;
     DIS_TAG(ksplit > 1 ? "convg2_fwd_kernel (f16x2 streaming, split-K)" : "convg2_fwd_kernel (f16x2 streaming)");
     const dim3 g2((unsigned)grid2, (unsigned)ksplit);
-    if (bn == 64) hipLaunchKernelGGL(convg2_fwd_kernel<64>, g2, dim3(256), 0, s, a);
-    else if (bn == 32) hipLaunchKernelGGL(convg2_fwd_kernel<32>, g2, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(convg2_fwd_kernel<16>, g2, dim3(256), 0, s, a);
+    if (big) {
+      static bool attr = false;
+      if (!attr) {
+        constexpr int lds_attr = Cg2Cfg<128, 8>::LDS_BYTES;
+        hipError_t e = hipFuncSetAttribute((const void*)convg2_fwd_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+      }
+      DIS_TAG(ksplit > 1 ? "convg2_fwd_kernel (f16x2 streaming, 256 x 128 tiles, split-K)" : "convg2_fwd_kernel (f16x2 streaming, 256 x 128 tiles)");
+      constexpr int lds_big = Cg2Cfg<128, 8>::LDS_BYTES;
+      hipLaunchKernelGGL((convg2_fwd_kernel<128, 8>), g2, dim3(512), lds_big, s, a);
+    } else if (bn == 64) hipLaunchKernelGGL((convg2_fwd_kernel<64>), g2, dim3(256), Cg2Cfg<64>::LDS_BYTES, s, a);
+    else if (bn == 32) hipLaunchKernelGGL((convg2_fwd_kernel<32>), g2, dim3(256), Cg2Cfg<32>::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((convg2_fwd_kernel<16>), g2, dim3(256), Cg2Cfg<16>::LDS_BYTES, s, a);
     if (ksplit > 1)
       hipLaunchKernelGGL(convg2_splitk_reduce_kernel, dim3(dis_ew_grid(M2 * ((a.cout + 3) / 4), 256)), dim3(256), 0, s, a, coutp);
     DIS_CHECK_LAUNCH();
@@ -1476,12 +1514,14 @@ extern "C" long dis_convg_splitk_workspace(int mode, int n, int hin, int win, in
   if (n <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || cin <= 0 || cout <= 0 || k <= 0 || k * k > CG_MAXTAPS || pad < 0)
     return -1;
   if (cin < CG3_CK || n > CG2_NMAX) return 0;
-  const int bn = cg_bn(cout);
-  const long nblk = (cout + bn - 1) / bn, nchunk = (cin + CG3_CK - 1) / CG3_CK;
+  const long nchunk = (cin + CG3_CK - 1) / CG3_CK;
   auto need = [&](long hv, long wv, int ntaps) -> long {
     const long M = (long)n * hv * wv;
     if (M <= 0 || ntaps <= 0) return 0;
-    const int ks = cg2_ksplit(((M + CG_BM - 1) / CG_BM) * nblk, (int)(ntaps * nchunk));
+    const bool big = cg2_big_for(cin, cout, M, (int)(ntaps * nchunk));   // (the tile cg_run will pick for this launch)
+    const int bn = big ? 128 : cg_bn(cout), bm = big ? 256 : CG_BM;
+    const long nblk = (cout + bn - 1) / bn;
+    const int ks = cg2_ksplit(((M + bm - 1) / bm) * nblk, (int)(ntaps * nchunk));
     return ks > 1 ? (long)ks * M * nblk * bn : 0;
   };
   const bool phased = (mode == DIS_CONVG_CONV_DGRAD || mode == DIS_CONVG_TCONV) && stride == 2;
