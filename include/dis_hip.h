@@ -472,8 +472,12 @@ int dis_conv3d_knn_bwd_agg(const float* geom, const float* wf, const float* dens
  * wpack: workspace of dis_convg_pack_workspace(cin,cout,k) floats (x4 for the two phase-decomposed cases:
  * CONV_DGRAD and TCONV with stride 2) PLUS dis_convg_splitk_workspace(...) floats (round 4; 0 for most calls: partial sums of
  * the split-K form small maps take under the two-term fp16 split).
- * Routing (same results, same contract): 3x3 (and 7x7, one launch per tap row) stride-1 CONV / CONV_DGRAD calls with
- * <= 10 32x32 channel-slice launches and >= 400k pixels run on the halo-resident kernels; everything else streams.
+ * Routing (same results, same contract): 3x3 stride-1 CONV / CONV_DGRAD calls with <= 10 32x32 channel-slice launches and
+ * >= 400k pixels run on the halo-resident kernels (7x7 too, one launch per tap row, under the three-term split); with >= 32 input
+ * channels and a virtual output grid of >= 1024 positions (DIS_CONVG_HALO_MIN) the call takes the LDS-halo form convh2_kernel
+ * (round 4: the input halo of a tile staged once per 32-channel chunk, all taps from LDS; the four parity phases of the stride-2
+ * transposed forms in one launch when their weights stay resident); everything else streams (256 x 128 tiles for >= 128 channels
+ * on both sides).
  * Arithmetic (dis_set_conv_split, default 1): layers with >= 32 input channels multiply two-term fp16 operands (3 products per
  * MAC, fp32 accumulate; one power-of-two scale per image of x - per halo tile in the slice launches - and one per weight
  * tensor); dis_set_conv_split(0) selects the three-term bf16 split (6 products, >= 24-bit operands) everywhere. */
@@ -493,8 +497,9 @@ int dis_convg_run(int mode, const float* x, int ldx, int xoff, const float* w, c
  *   conv:            X = layer input,              G = gradient wrt the pre-activation output  -> (cout,cin,k,k)
  *   transposed conv: X = gradient wrt its output,  G = layer input                             -> (cin,cout,k,k)
  * workspace: dis_convg_wgrad_workspace(n,hG,wG,cX,cG,k) floats.
- * Routing: k in {3,5} with stride in {1,2} and k = 7 with stride 1, cX >= 16, cG >= 32 run as 32x32 channel-slice pairs of the one-pass bf16x3
- * kernel (x and G staged once for all taps); other shapes on the fp32 split-K kernel (one pass per tap). */
+ * Routing: k in {3,5} with stride in {1,2} and k = 7 with stride 1, cX >= 16, cG >= 32 run as 32x32 channel-slice pairs of the one-pass
+ * halo kernels (x and G staged once for all taps; two-term fp16 operands by default, the three-term bf16 split under
+ * dis_set_conv_split(0)); other shapes on the fp32 split-K kernel (one pass per tap). */
 long dis_convg_wgrad_workspace(int n, int hG, int wG, int cX, int cG, int k);
 int dis_convg_wgrad(const float* X, int ldX, int xoff, int hX, int wX, int cX, int cX_w, const float* G, int ldG,
                     int goff, int hG, int wG, int cG, int cG_w, float* grad_w, float* workspace, int n, int k,
