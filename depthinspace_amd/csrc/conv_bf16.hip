@@ -50,6 +50,8 @@ struct GenArgsB {
   // weight group, tile grid
   int dy0, dx0, HR, HC, PS, TP, nks, GT, tiles_x, tiles_y;
   int trh;         // tile rows: 8 (2 per wave) or 16 (4 per wave)
+  int nph;         // output phases of one launch: 1, or the 4 parity classes of a stride-2 transposed form (see convb_halo_kernel, PH)
+  unsigned char ph_k0[4], ph_kn[4], ph_oy[4], ph_ox[4];
   int kc;          // column walk: taps ordered dx-major / dy ascending, a weight group = one column of kc taps (0: generic walk)
   int res, wsz16;  // weights of a cout block resident in LDS (all chunks); 16-bit words of the weight region in front of the halo
   // convb_fwd128_kernel, split-K (small maps: fewer workgroups than CUs, each with a long chain of dependent stages):
@@ -457,8 +459,12 @@ __global__ void convb_pack_kernel(PackArgsB a) {
 // conv_gen.hip's convh2_kernel - taps ordered column by column, a weight group = one column, the MT + KC - 1 row fragments of a
 // column read once and kept in registers while ky slides down: 1 + NT ds_read_b128 per k-step instead of MT + NT for MT NT MFMAs
 // (MT 4, NT 2: six reads per eight MFMAs had the LDS port 1.5 x as busy as the matrix unit).
-template <int BN, bool XB, bool YB, int NH, int MT, int KC = 0>
+// PH = 4 (round 4; resident weights): the four parity classes of a stride-2 transposed form in ONE launch, as convh2_kernel - they
+// read the same input tile, so one halo serves four accumulator sets; class p owns the k-steps [ph_k0[p], + ph_kn[p]) of the tap
+// list and writes output pixel (2 vy + ph_oy[p], 2 vx + ph_ox[p]).
+template <int BN, bool XB, bool YB, int NH, int MT, int KC = 0, int PH = 1>
 __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
+  static_assert(PH == 1 || KC == 0, "column walk: one phase");
   constexpr int NT = BN / 16, TRH = 4 * MT;
   constexpr int NRB = KC > 0 ? (KC * 4 * BN + 255) / 256 : 4;   // 16-byte vectors of a weight group per thread
   extern __shared__ __attribute__((aligned(16))) unsigned short hsm[];
@@ -554,12 +560,13 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
     }
   };
 
-  f32x4 acc[MT][NT], bias_v[NT];
+  f32x4 accp[PH][MT][NT], bias_v[NT];
+  f32x4 (&acc)[MT][NT] = accp[0];   // (one phase: the only set)
   int bias_nb = -1;
   // k-steps [0, kn) of a weight block B ([kstep][lg][BN][8]) whose tap offsets start at tq: software-pipelined by hand (a
   // runtime trip count: the compiler does not) - the operands of k-step kk+1 are requested before the MFMAs of kk issue, its
   // tap offset one step earlier still
-  auto ksteps = [&](const unsigned short* B, const int* tq, int kn) __attribute__((always_inline)) {
+  auto ksteps = [&](const unsigned short* B, const int* tq, int kn, f32x4 (&acc)[MT][NT]) __attribute__((always_inline)) {
     const unsigned short* bl = B + (lg * BN + li) * 8;
     auto frag = [&](int kk, int to, s16x8 (&fa)[MT], s16x8 (&fb)[NT]) __attribute__((always_inline)) {
 #pragma unroll
@@ -644,9 +651,11 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
   };
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int ph = 0; ph < PH; ++ph)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) accp[ph][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
   // epilogue: lane (li, lg) holds couts nb*BN + nt*16 + lg*4 + {0..3} of position (ty*8 + wave*2 + mt, tx*16 + li)
   auto epilogue = [&](int uu, int nb) __attribute__((always_inline)) {
@@ -660,21 +669,26 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
       for (int mt = 0; mt < MT; ++mt) {
         const int vy = ty * TRH + wave * MT + mt, vx = tx * CBH_TC + li;
         if (vy >= a.hv || vx >= a.wv) continue;
-        const long pe = (((long)nn * a.hf + (vy * a.osy + a.ooy)) * a.wf + (vx * a.osx + a.oox)) * a.ldy + a.yoff;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int co = nb * BN + nt * 16 + lg * 4;
-          if (co >= a.cout) continue;
-          float o[4];
+        for (int ph = 0; ph < PH; ++ph) {
+          const int oy = vy * a.osy + (PH > 1 ? (int)a.ph_oy[ph] : a.ooy), ox = vx * a.osx + (PH > 1 ? (int)a.ph_ox[ph] : a.oox);
+          if (PH > 1 && (oy >= a.hf || ox >= a.wf)) continue;   // (the classes of an odd output size differ by one row / column)
+          const long pe = (((long)nn * a.hf + oy) * a.wf + ox) * a.ldy + a.yoff;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[mt][nt][r] + bias_v[nt][r], ACT);
-          if (co + 4 <= a.cout) {
-            if (YB) *(uint2*)((bf16_t*)a.y + pe + co) = make_uint2(cb_pack2(o[0], o[1]), cb_pack2(o[2], o[3]));
-            else *(float4*)((float*)a.y + pe + co) = make_float4(o[0], o[1], o[2], o[3]);
-          } else {
-            for (int r = 0; r < 4 && co + r < a.cout; ++r) {
-              if (YB) ((bf16_t*)a.y)[pe + co + r] = (bf16_t)(cb_pack2(o[r], 0.f) & 0xffffu);
-              else ((float*)a.y)[pe + co + r] = o[r];
+          for (int nt = 0; nt < NT; ++nt) {
+            const int co = nb * BN + nt * 16 + lg * 4;
+            if (co >= a.cout) continue;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = act_apply(accp[ph][mt][nt][r] + bias_v[nt][r], ACT);
+            if (co + 4 <= a.cout) {
+              if (YB) *(uint2*)((bf16_t*)a.y + pe + co) = make_uint2(cb_pack2(o[0], o[1]), cb_pack2(o[2], o[3]));
+              else *(float4*)((float*)a.y + pe + co) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+              for (int r = 0; r < 4 && co + r < a.cout; ++r) {
+                if (YB) ((bf16_t*)a.y)[pe + co + r] = (bf16_t)(cb_pack2(o[r], 0.f) & 0xffffu);
+                else ((float*)a.y)[pe + co + r] = o[r];
+              }
             }
           }
         }
@@ -718,7 +732,13 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
       halo_write(setc);
       __syncthreads();
       if (u2 < u_hi) halo_issue(u2, c2, setc);  // the set just consumed takes the stage after next
-      ksteps(Bb + (long)c0 * a.nks * 4 * BN * 8, toff + lgq, a.nks);
+      if constexpr (PH > 1) {
+#pragma unroll
+        for (int ph = 0; ph < PH; ++ph)
+          ksteps(Bb + ((long)c0 * a.nks + a.ph_k0[ph]) * (4 * BN * 8), toff + a.ph_k0[ph] * a.TP + lgq, a.ph_kn[ph], accp[ph]);
+      } else {
+        ksteps(Bb + (long)c0 * a.nks * 4 * BN * 8, toff + lgq, a.nks, acc);
+      }
       if (c0 + 1 == a.nchunk) epilogue(u, nb);
       u = u1, c0 = c1;
       u1 = u2, c1 = c2;
@@ -764,7 +784,7 @@ __global__ __launch_bounds__(256) void convb_halo_kernel(GenArgsB a) {
           if (g == 0) col_rows(toff[0]);   // (the first column of a stage: its rows were not requested by a predecessor)
           kcolumn(B, toff[g * KC], g + 1 < ngrp ? toff[(g + 1) * KC] : 0, g + 1 < ngrp);
         } else {
-          ksteps(B, toff + g * a.GT * a.TP + lgq, min(a.GT, a.nks - g * a.GT));
+          ksteps(B, toff + g * a.GT * a.TP + lgq, min(a.GT, a.nks - g * a.GT), acc);
         }
         ++flat;
       }
@@ -972,6 +992,7 @@ static bool cb_halo_plan(GenArgsB& a, int bn) {
   a.res = (256 + wall + hal <= 75 * 1024) ? 1 : 0;  // (two resident workgroups per CU at least: one alone cannot hide its LDS latency)
   a.wsz16 = (int)((a.res ? wall : 2L * a.GT * 4 * bn * 16) / 2);
   // (16-row tiles for the resident-weight layers as well: measured neutral, 5.51 vs 5.56 ms over the 33 halo launches of a step)
+  if (a.nph > 1 && (!a.res || a.TP != 1)) return false;   // (four phases in one launch: resident weights only)
   if (!a.res && a.hv >= 32) {
     // streaming weights: 16 x 16 tiles when the larger halo still leaves two workgroups per CU and 12 prefetch items per thread
     const int hr16 = 15 * a.S + (dy1 - dy0) + 1;
@@ -988,7 +1009,7 @@ static bool cb_halo_plan(GenArgsB& a, int bn) {
   {
     const int K = dy1 - dy0 + 1;
     static const bool nokc = getenv("DIS_CONVB_KC") && getenv("DIS_CONVB_KC")[0] == '0';
-    if (!nokc && a.S == 1 && a.TP == 1 && !a.res && a.trh == 16 && dx1 - dx0 + 1 == K && a.ntaps == K * K &&
+    if (!nokc && a.nph == 1 && a.S == 1 && a.TP == 1 && !a.res && a.trh == 16 && dx1 - dx0 + 1 == K && a.ntaps == K * K &&
         ((K == 7 && bn == 32) || (K == 5 && bn == 64))) {
       const long wsz = 2L * K * 4 * bn * 16 / 2;   // two buffers of one column (16-bit words)
       if (256 + 2 * wsz + (long)a.HR * a.HC * a.PS * 2 <= 150 * 1024) {
@@ -1001,16 +1022,16 @@ static bool cb_halo_plan(GenArgsB& a, int bn) {
   return cb_halo_lds(a, bn) <= 150 * 1024;
 }
 static long cb_halo_lds(const GenArgsB& a, int bn) { return 256 + 2L * a.wsz16 + (long)a.HR * a.HC * a.PS * 2; }
-template <int BN, bool XB, bool YB, int NH, int MT, int KC = 0>
+template <int BN, bool XB, bool YB, int NH, int MT, int KC = 0, int PH = 1>
 static int cbh_launch3(const GenArgsB& a, long grid, long lds, hipStream_t s) {
   static bool attr = false;
-  auto kern = convb_halo_kernel<BN, XB, YB, NH, MT, KC>;
+  auto kern = convb_halo_kernel<BN, XB, YB, NH, MT, KC, PH>;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  DIS_TAG(KC > 0 ? "convb_halo_kernel (bf16 LDS halo, column walk)" : "convb_halo_kernel (bf16 LDS halo)");
+  DIS_TAG(KC > 0 ? "convb_halo_kernel (bf16 LDS halo, column walk)" : PH > 1 ? "convb_halo_kernel (bf16 LDS halo, 4 phases)" : "convb_halo_kernel (bf16 LDS halo)");
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, s, a);
   return DIS_OK;
 }
@@ -1027,6 +1048,14 @@ static int cbh_launch1(const GenArgsB& a, int nh, long grid, long lds, hipStream
 }
 template <bool XB, bool YB>
 static int cbh_launch(const GenArgsB& a, int bn, int nh, long grid, long lds, hipStream_t s) {
+  if (a.nph == 4) {   // (bf16 -> bf16 layers, 8-row tiles, resident weights)
+    if constexpr (XB && YB) {
+      if (bn == 64 && nh <= 4) return cbh_launch3<64, true, true, 4, 2, 0, 4>(a, grid, lds, s);
+      if (bn == 32 && nh <= 4) return cbh_launch3<32, true, true, 4, 2, 0, 4>(a, grid, lds, s);
+      if (bn == 16 && nh <= 4) return cbh_launch3<16, true, true, 4, 2, 0, 4>(a, grid, lds, s);
+    }
+    return DIS_ERR_UNSUPPORTED;
+  }
   if (a.kc > 0) {   // (cb_halo_plan grants the column walk to bf16 -> bf16 layers of these two shapes only)
     if constexpr (XB && YB) {
       if (a.kc == 7 && bn == 32 && nh <= 8) return cbh_launch3<32, true, true, 8, 4, 7>(a, grid, lds, s);
@@ -1086,7 +1115,7 @@ static int cb_run_halo(GenArgsB a, int x_bf16, int y_bf16, int bn, const float* 
 }
 
 static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t* wpack, int ci_real, int co_real, long s_ci,
-                  long s_co, const short* tsrc, hipStream_t s) {
+                  long s_co, const short* tsrc, hipStream_t s, bool halo_only = false) {
   if (a.ntaps <= 0) return DIS_OK;
   const long M = (long)a.n * a.hv * a.wv;
   if (M <= 0) return DIS_OK;
@@ -1096,6 +1125,11 @@ static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t
   if (xb >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;  // 31-bit byte offsets of the buffer descriptor
   a.x_bytes = (unsigned)xb;
   a.nchunk = (a.cin + CB_CK - 1) / CB_CK;
+  if (halo_only) {   // (four phases in one launch: bf16 tensors on both sides, a plan with resident weights and <= 4 halo items)
+    if (!(x_bf16 && y_bf16) || !cb_halo_plan(a, bn)) return DIS_ERR_UNSUPPORTED;
+    if ((long)a.HR * a.HC * ((a.PS - 8) / 8) > 4 * 256) return DIS_ERR_UNSUPPORTED;
+    return cb_run_halo(a, x_bf16, y_bf16, bn, w_raw, wpack, ci_real, co_real, s_ci, s_co, tsrc, s);
+  }
   if (cb_halo_plan(a, bn)) return cb_run_halo(a, x_bf16, y_bf16, bn, w_raw, wpack, ci_real, co_real, s_ci, s_co, tsrc, s);
   PackArgsB p;
   p.w = w_raw; p.packed = wpack; p.ntaps = a.ntaps; p.nchunk = a.nchunk; p.nblk = a.nblk; p.bn = bn;
@@ -1211,6 +1245,7 @@ extern "C" int dis_convb_run(int mode, const void* x, int x_bf16, int ldx, int x
   bf16_t* wp = (bf16_t*)wpack;
   // (split-K partial sums of the small maps: behind the four packing slices)
   a.ksplit = 1;
+  a.nph = 1;
   a.skcap = dis_convb_splitk_workspace(mode, x_bf16, n, hin, win, hout, wout, cin, cout, k, stride, pad);
   a.skpart = a.skcap > 0 ? (float*)(wp + 4 * dis_convb_pack_workspace(cin, cout, k)) : nullptr;
   if (mode == DIS_CONVG_CONV || mode == DIS_CONVG_TCONV_DGRAD) {
@@ -1242,6 +1277,38 @@ extern "C" int dis_convb_run(int mode, const void* x, int x_bf16, int ldx, int x
     return cb_run(a, x_bf16, y_bf16, w, wp, cin_w, cout_w, s_ci, s_co, tsrc, s);
   }
   const long pstride = dis_convb_pack_workspace(cin, cout, k);
+  static const bool nofuse = getenv("DIS_CONVB_NO_FUSED_PHASES") != nullptr;
+  if (!nofuse && k * k <= 255) {
+    // the four parity classes in ONE launch of the halo kernel (they read the same input tile): taps listed class by class
+    GenArgsB b = a;
+    b.hv = (hout + 1) / 2; b.wv = (wout + 1) / 2; b.S = 1;
+    b.osy = 2; b.ooy = 0; b.osx = 2; b.oox = 0;
+    b.nph = 4;
+    int nt = 0;
+    bool ok = true;
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        const int ph = py * 2 + px, t0 = nt;
+        for (int ky = 0; ky < k; ++ky) {
+          if ((py + pad - ky) & 1) continue;
+          for (int kx = 0; kx < k; ++kx) {
+            if ((px + pad - kx) & 1) continue;
+            b.tdy[nt] = (short)cb_floordiv2(py + pad - ky);
+            b.tdx[nt] = (short)cb_floordiv2(px + pad - kx);
+            tsrc[nt] = (short)(ky * k + kx);
+            ++nt;
+          }
+        }
+        b.ph_k0[ph] = (unsigned char)t0; b.ph_kn[ph] = (unsigned char)(nt - t0);
+        b.ph_oy[ph] = (unsigned char)py; b.ph_ox[ph] = (unsigned char)px;
+        ok = ok && nt > t0;
+      }
+    b.ntaps = nt;
+    if (ok) {
+      const int rc = cb_run(b, x_bf16, y_bf16, w, wp, cin_w, cout_w, s_ci, s_co, tsrc, s, true);
+      if (rc != DIS_ERR_UNSUPPORTED) return rc;
+    }
+  }
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       GenArgsB b = a;
