@@ -217,6 +217,45 @@ def test_convg_f16x2_halo_form(kind, cin, cin_mem, cout, k, stride, h, w):
     assert err(halo[2], stream[2]) < 1e-6   # (the weight gradient does not depend on the form)
 
 
+@pytest.mark.parametrize('cin,cout,stride,h,w', [(128, 512, 1, 80, 84), (256, 128, 1, 160, 164), (256, 256, 2, 180, 176)])
+def test_convg_f16x2_large_tiles(cin, cout, stride, h, w):
+    """convg2_fwd_kernel<128, 8> (eight waves on a 256-pixel x 128-cout tile: the deep layers of DispNetS at bench scale, where the
+    launch still fills the device) against fp64, beside the three-term kernel on its 128 x 64 tiles: forward and input gradient.
+    The maps here are large enough for the large tile and are kept out of the halo form (DIS_CONVG_HALO_MIN)."""
+    from depthinspace_amd import ops
+    from tests.conftest import conv_split
+    g = torch.Generator().manual_seed(cin + cout + h)
+    n, k, pad = 2, 3, 1
+    x = torch.randn(n, cin, h, w, generator=g)
+    x[1] *= 0.01
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xr = x.double().requires_grad_(True)
+    y = F.conv2d(xr, wt.double(), b.double(), stride=stride, padding=pad)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go.double())
+    out, tags = {}, {}
+    for tag in ('bf16x3', 'f16x2'):
+        with conv_split(tag), halo_min(1 << 40):
+            def run():
+                xd = nhwc(x).cuda().requires_grad_(True)
+                wd, bd = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+                yd = ops.convg(xd, wd, bd, stride, pad, ops.ACT_NONE)
+                yd.backward(nhwc(go).cuda())
+                return nchw(yd).detach().double().cpu(), nchw(xd.grad).double().cpu()
+            out[tag], tags[tag] = _kernels_of(run)
+    assert any('256 x 128 tiles' in t for t in tags['f16x2']), tags['f16x2']
+
+    def err(a, ref):
+        return float((a - ref).abs().max() / (ref.abs().max() + 1e-300))
+    for name, i, ref in (('y', 0, y.detach()), ('gx', 1, xr.grad)):
+        e3, e2 = err(out['bf16x3'][i], ref), err(out['f16x2'][i], ref)
+        print(f'{cin}->{cout} s{stride} {name}: bf16x3 {e3:.2e} f16x2 (large tiles) {e2:.2e}  kernels {sorted(tags["f16x2"])}')
+        assert e2 < 4 * e3 + 2e-7, (name, e3, e2)
+        for q in range(n):
+            assert err(out['f16x2'][i][q], ref[q]) < 4 * err(out['bf16x3'][i][q], ref[q]) + 2e-7, (name, q)
+
+
 # cin, cout, hin, win, hout, wout (crop_like target)
 TCONV_SHAPES = [
     (512, 512, 4, 4, 8, 7),     # upconv7 at 512x432: 8x8 cropped to 8x7
