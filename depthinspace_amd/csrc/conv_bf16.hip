@@ -219,24 +219,34 @@ __global__ __launch_bounds__(256, 2) void convb_fwd_kernel(GenArgsB a) {
 // multiplied from a single LDS buffer.  Weights: the packed layout of convb_pack_kernel (sub-step s of a stage = 32-channel
 // chunk 4 stage + s).  x and y bf16.
 #define CB_AS4 136  // LDS pixel stride of the 128-channel A tile (16-bit units): 128 + 8 (16 consecutive pixels: 16 distinct slots)
-template <int BN, bool YB>
-__global__ __launch_bounds__(256) void convb_fwd128_kernel(GenArgsB a) {
-  constexpr int NT = BN / 16;
-  constexpr int A_U16 = CB_BM * CB_AS4, B_U16 = 4 * (4 * BN * 8);
-  __shared__ __attribute__((aligned(16))) unsigned short smem[A_U16 + B_U16];
+// NW waves = 32 NW pixels x BN couts per workgroup: 4 x 64 by default; 8 x 128 (round 4, as conv_gen.hip's convg2_fwd_kernel<128, 8>)
+// for layers with >= 128 channels on both sides whose launch still fills the device - twice the MACs per operand byte from L2.
+template <int BN, int NW = 4>
+struct Cb128Cfg {
+  static constexpr int NTHR = 64 * NW, BM = 32 * NW;
+  static constexpr int A_U16 = BM * CB_AS4, B_U16 = 4 * (4 * BN * 8);
+  static constexpr int LDS_BYTES = (A_U16 + B_U16) * 2;
+  static_assert(4 * BN <= NTHR, "one 16-byte vector of a 32-channel weight block per thread");
+};
+template <int BN, bool YB, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void convb_fwd128_kernel(GenArgsB a) {
+  using CF = Cb128Cfg<BN, NW>;
+  constexpr int NT = BN / 16, BM = CF::BM, PSTEP = CF::NTHR / 4;   // PSTEP: pixels one loader pass covers
+  constexpr int A_U16 = CF::A_U16;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* A = smem;
   unsigned short* B = smem + A_U16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int M = a.n * a.hv * a.wv;
-  const int nb = blockIdx.x % a.nblk, m0 = (blockIdx.x / a.nblk) * CB_BM;
-  // loader role: channel group pq (8 channels of every 32-channel sub-step) of pixels p0 and p0 + 64
+  const int nb = blockIdx.x % a.nblk, m0 = (blockIdx.x / a.nblk) * BM;
+  // loader role: channel group pq (8 channels of every 32-channel sub-step) of pixels p0 and p0 + PSTEP
   const int pq = tid & 3, p0 = tid >> 2;
   long pbase[2];
   int piy[2], pix[2];
   bool pval[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int m = m0 + p0 + j * 64;
+    const int m = m0 + p0 + j * PSTEP;
     pval[j] = m < M;
     const int mm = pval[j] ? m : 0;
     const int vx = mm % a.wv, t = mm / a.wv, vy = t % a.hv, nn = t / a.hv;
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(256) void convb_fwd128_kernel(GenArgsB a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) *(u32x4*)(A + (p0 + j * 64) * CB_AS4 + s * 32 + pq * 8) = ra[set][j][s];
+      for (int s = 0; s < 4; ++s) *(u32x4*)(A + (p0 + j * PSTEP) * CB_AS4 + s * 32 + pq * 8) = ra[set][j][s];
     if (wload) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) ((u32x4*)B)[s * bvec + tid] = rb[set][s];
@@ -408,6 +418,18 @@ static int cb_ksplit(long wgs, int nk) {
   return (int)ks;
 }
 
+// 256 x 128 tiles of convb_fwd128_kernel: bf16 input, >= 128 channels on both sides, cout a multiple of 128, and a launch that
+// makes ~3/4 of a workgroup per CU WITHOUT split-K (M output positions).  Measured (DispNetS bs=8 x 4 frames): the 32 x 27 maps
+// gain (256 -> 512: 0.142 -> 0.116 ms, 256 -> 256: 0.078 -> 0.065 ms), the 16 x 14 maps, which need split-K to fill the device
+// with the large tile, lose (1024 -> 512: 0.144 -> 0.153 ms, 512 -> 1024: 0.079 -> 0.097 ms) - unlike the fp32 twin, whose
+// operand bytes per MAC are twice these.
+static bool cb_big_for(int x_bf16, int cin, int cout, long M, int nk) {
+  static const bool off = getenv("DIS_CONVB_BIG") && getenv("DIS_CONVB_BIG")[0] == '0';
+  static const bool no128 = getenv("DIS_CONVB_128") && getenv("DIS_CONVB_128")[0] == '0';
+  (void)nk;
+  if (off || no128 || !x_bf16 || cin < 128 || cout < 128 || cout % 128) return false;
+  return ((M + 255) / 256) * (cout / 128) >= 192;
+}
 // packed[tap][chunk][nb][lg][col][j] = bf16(W(tap, ci = chunk*32 + lg*8 + j, co = nb*BN + col))
 struct PackArgsB {
   const float* w;
@@ -1119,7 +1141,7 @@ static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t
   if (a.ntaps <= 0) return DIS_OK;
   const long M = (long)a.n * a.hv * a.wv;
   if (M <= 0) return DIS_OK;
-  const int bn = cb_bn(a.cout);
+  int bn = cb_bn(a.cout);
   a.nblk = (a.cout + bn - 1) / bn;
   const long xb = (long)a.n * a.hin * a.win * a.ldx * (x_bf16 ? 2 : 4);
   if (xb >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;  // 31-bit byte offsets of the buffer descriptor
@@ -1131,6 +1153,13 @@ static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t
     return cb_run_halo(a, x_bf16, y_bf16, bn, w_raw, wpack, ci_real, co_real, s_ci, s_co, tsrc, s);
   }
   if (cb_halo_plan(a, bn)) return cb_run_halo(a, x_bf16, y_bf16, bn, w_raw, wpack, ci_real, co_real, s_ci, s_co, tsrc, s);
+  const bool big = cb_big_for(x_bf16, a.cin, a.cout, M, a.ntaps * ((a.nchunk + 3) >> 2));   // deep layers: 256 x 128 tiles
+  const int bn0 = bn;
+  (void)bn0;
+  if (big) {
+    bn = 128;
+    a.nblk = (a.cout + bn - 1) / bn;
+  }
   PackArgsB p;
   p.w = w_raw; p.packed = wpack; p.ntaps = a.ntaps; p.nchunk = a.nchunk; p.nblk = a.nblk; p.bn = bn;
   p.ci_real = ci_real; p.co_real = co_real; p.s_ci = s_ci; p.s_co = s_co;
@@ -1145,7 +1174,7 @@ static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t
     cb_pack_note(0, ph);
   }
   a.w = wpack;
-  const long grid = ((M + CB_BM - 1) / CB_BM) * a.nblk;
+  const long grid = ((M + (big ? 256 : CB_BM) - 1) / (big ? 256 : CB_BM)) * a.nblk;
   if (grid > 2147483647L) return DIS_ERR_BAD_SHAPE;
   static const bool no128 = getenv("DIS_CONVB_128") && getenv("DIS_CONVB_128")[0] == '0';
   if (x_bf16 && a.cin >= 128 && bn >= 32 && !no128) {  // deep layers: 128-channel stages
@@ -1156,10 +1185,23 @@ static int cb_run(GenArgsB a, int x_bf16, int y_bf16, const float* w_raw, bf16_t
     DIS_TAG(ksplit > 1 ? "convb_fwd128_kernel (bf16 streaming, 128-channel stages, split-K)"
                        : "convb_fwd128_kernel (bf16 streaming, 128-channel stages)");
     const dim3 g((unsigned)grid, (unsigned)ksplit);
-    if (bn == 64 && y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<64, true>), g, dim3(256), 0, s, a);
-    else if (bn == 64) hipLaunchKernelGGL((convb_fwd128_kernel<64, false>), g, dim3(256), 0, s, a);
-    else if (y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<32, true>), g, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((convb_fwd128_kernel<32, false>), g, dim3(256), 0, s, a);
+    constexpr int lds64 = Cb128Cfg<64>::LDS_BYTES, lds32 = Cb128Cfg<32>::LDS_BYTES, ldsbig = Cb128Cfg<128, 8>::LDS_BYTES;
+    if (big) {
+      static bool attr[2] = {false, false};
+      if (!attr[y_bf16 ? 1 : 0]) {
+        hipError_t e = y_bf16 ? hipFuncSetAttribute((const void*)convb_fwd128_kernel<128, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsbig)
+                              : hipFuncSetAttribute((const void*)convb_fwd128_kernel<128, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsbig);
+        if (e != hipSuccess) return (int)e;
+        attr[y_bf16 ? 1 : 0] = true;
+      }
+      DIS_TAG(ksplit > 1 ? "convb_fwd128_kernel (bf16 streaming, 128-channel stages, 256 x 128 tiles, split-K)"
+                         : "convb_fwd128_kernel (bf16 streaming, 128-channel stages, 256 x 128 tiles)");
+      if (y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<128, true, 8>), g, dim3(512), ldsbig, s, a);
+      else hipLaunchKernelGGL((convb_fwd128_kernel<128, false, 8>), g, dim3(512), ldsbig, s, a);
+    } else if (bn == 64 && y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<64, true>), g, dim3(256), lds64, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((convb_fwd128_kernel<64, false>), g, dim3(256), lds64, s, a);
+    else if (y_bf16) hipLaunchKernelGGL((convb_fwd128_kernel<32, true>), g, dim3(256), lds32, s, a);
+    else hipLaunchKernelGGL((convb_fwd128_kernel<32, false>), g, dim3(256), lds32, s, a);
     if (ksplit > 1) {
       const int rg = dis_ew_grid(M * ((a.cout + 3) / 4), 256);
       if (y_bf16) hipLaunchKernelGGL((convb_splitk_reduce_kernel<true>), dim3(rg), dim3(256), 0, s, a, coutp);
@@ -1181,13 +1223,16 @@ extern "C" long dis_convb_splitk_workspace(int mode, int x_bf16, int n, int hin,
                                            int k, int stride, int pad) {
   if (n <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || cin <= 0 || cout <= 0 || k <= 0 || k * k > CB_MAXTAPS || pad < 0)
     return -1;
-  const int bn = cb_bn(cout);
-  if (!x_bf16 || cin < 128 || bn < 32) return 0;
-  const long nblk = (cout + bn - 1) / bn, nst = ((cin + CB_CK - 1) / CB_CK + 3) / 4;
+  const int bn0 = cb_bn(cout);
+  if (!x_bf16 || cin < 128 || bn0 < 32) return 0;
+  const long nst = ((cin + CB_CK - 1) / CB_CK + 3) / 4;
   auto need = [&](long hv, long wv, int ntaps) -> long {
     const long M = (long)n * hv * wv;
     if (M <= 0 || ntaps <= 0) return 0;
-    const int ks = cb_ksplit(((M + CB_BM - 1) / CB_BM) * nblk, (int)(ntaps * nst));
+    const bool big = cb_big_for(x_bf16, cin, cout, M, (int)(ntaps * nst));   // (the tile cb_run will pick for this launch)
+    const int bn = big ? 128 : bn0, bm = big ? 256 : CB_BM;
+    const long nblk = (cout + bn - 1) / bn;
+    const int ks = cb_ksplit(((M + bm - 1) / bm) * nblk, (int)(ntaps * nst));
     return ks > 1 ? (long)ks * M * nblk * bn : 0;
   };
   const bool phased = (mode == DIS_CONVG_CONV_DGRAD || mode == DIS_CONVG_TCONV) && stride == 2;

@@ -50,6 +50,7 @@ CASES = [
     (64, 64, 64, 5, 1, False, 33, 37, False),    # two chunks
     (129, 136, 64, 3, 1, False, 34, 38, False),  # five chunks, the last one 8 channels wide
     (64, 64, 32, 3, 2, True, 36, 34, False),     # transposed conv and its input gradient: four tap-parity phases
+    (512, 512, 512, 3, 1, False, 32, 27, False),  # a deep layer on a small map (< 1024 positions): streaming, 128-channel stages, split-K
 ]
 
 
@@ -99,6 +100,35 @@ def test_convb_matches_exact_arithmetic(cin_w, cin_mem, cout, k, stride, transpo
         assert float((gx - xr.grad).abs().max()) < 1.5 * 2 ** -8 * float(xr.grad.abs().max()) + 4e-3 * float(xr.grad.abs().max())
         if cin_mem > cin_w:
             assert float(xd.grad.float()[..., cin_w:].abs().max()) == 0.0
+
+
+def test_convb_large_tiles():
+    """convb_fwd128_kernel<128, ., 8> (eight waves on a 256-pixel x 128-cout tile: deep layers whose launch fills the device without
+    split-K - at bench scale the 32 x 27 maps) against the exact-arithmetic reference of test_convb_matches_exact_arithmetic:
+    8 images of 32 x 27, 128 -> 1024 channels; forward, input gradient (1024 -> 128 runs the small tile: cout 128 x 27 tiles) and
+    weight gradient; the forward launch must report the large tile."""
+    from depthinspace_amd import ops, lib
+    g = torch.Generator().manual_seed(21)
+    n, cin, cout, h, w = 8, 128, 1024, 32, 27
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = bfr(x).clone().requires_grad_(True), bfr(wt).clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.relu(F.conv2d(xr, wr, br, padding=1))
+    go = bfr(torch.randn(y.shape, generator=g))
+    y.backward(go)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(BF).cuda().requires_grad_(True)
+    wd, bd = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    lib.profile_start()
+    yd = ops.convg(xd, wd, bd, 1, 1, ops.ACT_RELU, dtype=BF)
+    tags = {t for (name, _, _, t, _) in lib.profile_stop() if name == 'dis_convb_run'}
+    assert tags and all('256 x 128 tiles' in t for t in tags), tags
+    scale = float(y.abs().max())
+    assert float((yd.float().cpu().permute(0, 3, 1, 2) - y.detach()).abs().max()) <= 1.2 * 2 ** -8 * scale
+    yd.backward(go.permute(0, 2, 3, 1).contiguous().to(BF).cuda())
+    assert float((wd.grad.cpu() - wr.grad).abs().max()) < 4e-3 * float(wr.grad.abs().max())
+    gx = xd.grad.float().cpu().permute(0, 3, 1, 2)
+    assert float((gx - xr.grad).abs().max()) < (1.5 * 2 ** -8 + 4e-3) * float(xr.grad.abs().max())
 
 
 @pytest.mark.parametrize('H,W', [(64, 56), (128, 108)])
