@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
   const int ntile = a.n * a.tiles_y * a.tiles_x;
   auto unit_nb = [&](int uu) { return RES ? uu / ntile : uu % a.nblk; };
   auto unit_tile = [&](int uu) { return RES ? uu % ntile : uu / a.nblk; };
-  if (tid < 64) {
+  if (tid < 56) {   // (toff[56 .. 63] are the wave-maximum slots, written by other waves before the first barrier)
     int o = 0;
     if (tid < a.ntaps) o = ((a.tdy[tid] - a.dy0) * HC + (a.tdx[tid] - a.dx0)) * PS;
     toff[tid] = o;
@@ -835,7 +835,25 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
     it_cg[j] = cgi * 4 | ((p * PS + cgi * 4) << 8);
   }
   u32x4 pre[NSET][NH];
-  float psc[NSET];   // 2^(scale exponent) of the image the register set's stage belongs to
+  // Block scale of x: one per halo stage (tile x 32-channel chunk), found in the kernel - no pass over x in front of the launch.
+  // The stage's largest magnitude is taken before the barrier that ends the previous stage (thread maxima -> wave maxima by DPP ->
+  // four LDS slots); the contraction runs over chunks, so within a unit the scale is a RUNNING one that only ever shrinks, and the
+  // accumulators are multiplied by the (exact, power-of-two) ratio when a chunk brings a larger magnitude than those before it
+  // (as conv_wgrad_f16x2_kernel does over tiles).  Finer than the per-image scale of the streaming kernel.
+  float* mxs = (float*)(toff + 56);   // [parity][wave]  (the tap offsets use toff[0 .. 48])
+  int mpar = 0, s_run = 0;
+  auto prep = [&](auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {   // (items past the halo's end and pixels outside the image were loaded as zeros)
+      const u32x4 v = pre[set][j];
+      m = fmaxf(fmaxf(m, fabsf(__uint_as_float(v[0]))), fabsf(__uint_as_float(v[1])));
+      m = fmaxf(fmaxf(m, fabsf(__uint_as_float(v[2]))), fabsf(__uint_as_float(v[3])));
+    }
+    m = f2_wave_max(m);
+    if (lane == 0) mxs[mpar * 4 + wave] = m;
+  };
   auto halo_issue = [&](int uu, int c, auto setc) __attribute__((always_inline)) {
     constexpr int set = decltype(setc)::value;
     int t = unit_tile(uu);
@@ -844,7 +862,6 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
     const int ty = t % a.tiles_y, nn = t / a.tiles_y;
     const int iy0 = ty * TRH * a.S + a.dy0, ix0 = tx * CH2_TC * a.S + a.dx0;
     const long sbase = (long)nn * a.hin * a.win;
-    psc[set] = __builtin_ldexpf(1.f, sexp[nn]);
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
       const int iy = iy0 + (it_rc[j] & 0xffff), ix = ix0 + (it_rc[j] >> 16);
@@ -854,9 +871,8 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
       pre[set][j] = __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.x, a.x_bytes), ok ? (unsigned)(e * 4) : BX_OOB, 0, 0);
     }
   };
-  auto halo_write = [&](auto setc) __attribute__((always_inline)) {
+  auto halo_write = [&](auto setc, float sc) __attribute__((always_inline)) {
     constexpr int set = decltype(setc)::value;
-    const float sc = psc[set];
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
       if (tid + j * 256 < nitems) {
@@ -1000,6 +1016,31 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
         for (int mt = 0; mt < MT; ++mt) accs[SACC ? mt : 0][SACC ? nt : 0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
+  // after the barrier: the stage's scale exponent from the four wave maxima; `first`: the unit's first chunk (fresh accumulators)
+  auto stage_scale = [&](bool first) __attribute__((always_inline)) -> float {
+    const float4 mv = *(const float4*)(mxs + mpar * 4);
+    mpar ^= 1;
+    const int e = f2_scale_exp(fmaxf(fmaxf(mv.x, mv.y), fmaxf(mv.z, mv.w)));
+    if (first) {
+      s_run = e;
+    } else if (e < s_run) {   // (block-uniform, rare) a larger magnitude than the chunks before it: the accumulators follow
+      const float r = __builtin_ldexpf(1.f, e - s_run);
+#pragma unroll
+      for (int ph = 0; ph < PH; ++ph)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[ph][mt][nt] *= r;
+      if (SACC) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) accs[SACC ? mt : 0][SACC ? nt : 0] *= r;
+      }
+      s_run = e;
+    }
+    return __builtin_ldexpf(1.f, s_run);
+  };
   const int ew = sexp[CG2_NMAX];
   // epilogue: lane (li, lg) holds couts nb*BN + nt*16 + lg*4 + {0..3} of position (ty*TRH + wave*MT + mt, tx*16 + li); the two
   // block scales are undone first (exact: powers of two)
@@ -1008,7 +1049,7 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y, nn = t / a.tiles_y;
-    const float desc = __builtin_ldexpf(1.f, -(sexp[nn] + ew));
+    const float desc = __builtin_ldexpf(1.f, -(s_run + ew));   // (the unit's final running scale and the weights')
     auto emit = [&](auto actc) __attribute__((always_inline)) {
       constexpr int ACT = decltype(actc)::value;
 #pragma unroll
@@ -1065,6 +1106,7 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
         load_bias(nb);
         zero_acc();
       }
+      prep(setc);
       if (nb != wres_nb) {  // (block-uniform) this cout block's weights, all chunks: once per workgroup and block
         __syncthreads();
         const int nv = a.nks * 8 * BN;
@@ -1072,8 +1114,8 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
           for (int i = tid; i < nv; i += 256) ((u32x4*)Bb)[c * nv + i] = wq[(long)(c * a.nblk + nb) * nv + i];
         wres_nb = nb;
       }
-      __syncthreads();  // every wave is done with the previous stage's halo
-      halo_write(setc);
+      __syncthreads();  // every wave is done with the previous stage's halo; the stage's wave maxima are visible
+      halo_write(setc, stage_scale(c0 == 0));
       __syncthreads();
       if (u2 < u_hi) halo_issue(u2, c2, setc);  // the set just consumed takes the stage after next
 #pragma unroll
@@ -1101,8 +1143,9 @@ __global__ __launch_bounds__(256) void convh2_kernel(GenArgs a) {
       load_bias(nb);
       zero_acc();
       for (int c = 0; c < a.nchunk; ++c) {
-        __syncthreads();  // every wave is done with the previous stage's halo
-        halo_write(S0{});
+        prep(S0{});
+        __syncthreads();  // every wave is done with the previous stage's halo; the stage's wave maxima are visible
+        halo_write(S0{}, stage_scale(c == 0));
 #pragma unroll
         for (int ph = 0; ph < PH; ++ph) {
           const int g_lo = a.ph_g0[ph], g_hi = g_lo + a.ph_ng[ph];
@@ -1360,7 +1403,7 @@ static int ch2_run(GenArgs a, int bn, const float* w_raw, float* wpack, int ci_r
     }
     for (int t = 0; t < a.ntaps; ++t) a.tdy[t] = ty[t], a.tdx[t] = tx[t];
   }
-  p.ws = const_cast<float*>(a.f2ws); p.n = a.n;
+  p.ws = const_cast<float*>(a.f2ws); p.n = 0;   // (no per-image exponents: the halo kernel scales x per tile)
   const long ptotal = (long)a.nchunk * a.nblk * a.nks * 4 * bn * 4;
   hipLaunchKernelGGL(convh2_pack_kernel, dim3(dis_ew_grid(ptotal, 256)), dim3(256), 0, s, p);
   a.w = wpack;
@@ -1383,6 +1426,25 @@ static int ch2_run(GenArgs a, int bn, const float* w_raw, float* wpack, int ci_r
   return DIS_OK;
 }
 
+// Block maxima of a dis_convg_run call under the two-term split, launched when the first kernel that needs them is chosen: the
+// halo form scales x per tile by itself and needs the weights' maximum only (256 blocks); the streaming form also needs the
+// per-image maxima of x (a pass over x).
+struct F2Maxima {
+  const float* x; int n; long hw; int ldx, xoff, cin;
+  const float* w; long wcount;
+  float* ws;
+  bool w_done, x_done;
+};
+static void f2_maxima(F2Maxima* m, bool need_x, hipStream_t s) {
+  if (!m || !m->ws) return;
+  if (need_x ? m->x_done : m->w_done) return;
+  // (n = 0: the weight blocks only; a full launch recomputes the weights' maximum too - idempotent)
+  const int n = need_x ? m->n : 0;
+  hipLaunchKernelGGL(convg2_absmax_kernel, dim3(n * CG2_XB + CG2_WB), dim3(256), 0, s, m->x, n, m->hw, m->ldx, m->xoff, m->cin, m->w,
+                     m->wcount, m->ws);
+  m->w_done = true;
+  if (need_x) m->x_done = true;
+}
 static int cg_bn(int cout) { return cout > 32 ? 64 : (cout > 16 ? 32 : 16); }
 
 // split-K factor of the two-term streaming kernel: only when the launch has fewer workgroups than the device has CUs and a long
@@ -1409,7 +1471,7 @@ static bool cg2_big_for(int cin, int cout, long M, int nk) {
 }
 // one launch of the forward-like kernel (packs its weights first)
 static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int co_real, long s_ci, long s_co,
-                  const short* tsrc, hipStream_t s, bool halo_only = false) {
+                  const short* tsrc, hipStream_t s, F2Maxima* mx, bool halo_only = false) {
   if (a.ntaps <= 0) return DIS_OK;  // empty phase
   if ((long)a.n * a.hv * a.wv <= 0) return DIS_OK;
   const int bn = cg_bn(a.cout), bn0 = bn;
@@ -1419,8 +1481,12 @@ static int cg_run(GenArgs a, const float* w_raw, float* wpack, int ci_real, int 
   if (use3 && a.f2ws && a.cin >= CG3_CK && xb3 < 0x7fff0000L) {  // two-term fp16 form (default): see convg2_fwd_kernel
     a.x_bytes = (unsigned)xb3;
     a.nchunk = (a.cin + CG3_CK - 1) / CG3_CK;
-    if (ch2_plan(a, bn)) return ch2_run(a, bn, w_raw, wpack, ci_real, co_real, s_ci, s_co, tsrc, s);   // large maps: LDS halo form
+    if (ch2_plan(a, bn)) {   // large maps: LDS halo form
+      f2_maxima(mx, false, s);
+      return ch2_run(a, bn, w_raw, wpack, ci_real, co_real, s_ci, s_co, tsrc, s);
+    }
     if (halo_only) return DIS_ERR_UNSUPPORTED;   // (the caller falls back to one launch per phase)
+    f2_maxima(mx, true, s);
     const bool big = cg2_big_for(a.cin, a.cout, (long)a.n * a.hv * a.wv, a.ntaps * a.nchunk);   // deep layers: 256 x 128 tiles
     const int bn = big ? 128 : bn0;
     a.nblk = (a.cout + bn - 1) / bn;
@@ -1583,6 +1649,8 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
   short tsrc[CG_MAXTAPS];
   const long kk = (long)k * k;
   a.f2ws = nullptr; a.ksplit = 1; a.skpart = nullptr; a.skcap = 0; a.nph = 1;
+  F2Maxima mxv = {};
+  F2Maxima* mx = &mxv;
   if (dis_f2_enabled() && cin >= CG3_CK && n <= CG2_NMAX) {
     // (split-K partial sums: behind the packing slices, dis_convg_splitk_workspace floats)
     const int phases = ((mode == DIS_CONVG_CONV_DGRAD || mode == DIS_CONVG_TCONV) && stride == 2) ? 4 : 1;
@@ -1590,8 +1658,8 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
     a.skpart = a.skcap > 0 ? wpack + dis_convg_pack_workspace(cin, cout, k) * phases : nullptr;
     // two-term fp16 form: block maxima of this call's x (per sample) and weights, one launch in front of the packing launch(es)
     float* f2ws = wpack + dis_convg_pack_workspace(cin, cout, k) - CG2_WS;
-    hipLaunchKernelGGL(convg2_absmax_kernel, dim3(n * CG2_XB + CG2_WB), dim3(256), 0, s, x, n, (long)hin * win, ldx, xoff, cin, w,
-                       (long)cin_w * cout_w * kk, f2ws);
+    mxv.x = x; mxv.n = n; mxv.hw = (long)hin * win; mxv.ldx = ldx; mxv.xoff = xoff; mxv.cin = cin;
+    mxv.w = w; mxv.wcount = (long)cin_w * cout_w * kk; mxv.ws = f2ws;
     a.f2ws = f2ws;
   }
   if (mode == DIS_CONVG_CONV || mode == DIS_CONVG_TCONV_DGRAD) {
@@ -1611,7 +1679,7 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
       }
     // conv: w[co][ci][ky][kx] (co rows of cin_w);  tconv dgrad: w[ci_t = out][co_t = in][ky][kx]
     const long s_ci = kk, s_co = (long)cin_w * kk;
-    return cg_run(a, w, wpack, cin_w, cout_w, s_ci, s_co, tsrc, s);
+    return cg_run(a, w, wpack, cin_w, cout_w, s_ci, s_co, tsrc, s, mx);
   }
   // transposed form: out[oy][ox] = sum_{ky,kx : parity} in[(oy + pad - ky)/S][(ox + pad - kx)/S] * W
   //   conv dgrad:  w[ci_in(= conv cout)][co_out(= conv cin)]  stored as w[conv_co][conv_ci][ky][kx]
@@ -1627,7 +1695,7 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
         a.tdx[ky * k + kx] = (short)(pad - kx);
         tsrc[ky * k + kx] = (short)(ky * k + kx);
       }
-    return cg_run(a, w, wpack, cin_w, cout_w, s_ci, s_co, tsrc, s);
+    return cg_run(a, w, wpack, cin_w, cout_w, s_ci, s_co, tsrc, s, mx);
   }
   const long pstride = dis_convg_pack_workspace(cin, cout, k);  // every phase packs into its own slice
   if (a.f2ws && k * k <= 255 && !getenv("DIS_CONVG_NO_FUSED_PHASES")) {
@@ -1657,7 +1725,7 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
       }
     b.ntaps = nt;
     if (ok) {
-      const int rc = cg_run(b, w, wpack, cin_w, cout_w, s_ci, s_co, tsrc, s, true);
+      const int rc = cg_run(b, w, wpack, cin_w, cout_w, s_ci, s_co, tsrc, s, mx, true);
       if (rc != DIS_ERR_UNSUPPORTED) return rc;
     }
   }
@@ -1683,7 +1751,7 @@ extern "C" int dis_convg_run(int mode, const float* x, int ldx, int xoff, const 
         // no tap reaches this parity class (cannot happen for k >= 2): outputs would be bias only
         return DIS_ERR_UNSUPPORTED;
       }
-      int rc = cg_run(b, w, wpack + (long)(py * 2 + px) * pstride, cin_w, cout_w, s_ci, s_co, tsrc, s);
+      int rc = cg_run(b, w, wpack + (long)(py * 2 + px) * pstride, cin_w, cout_w, s_ci, s_co, tsrc, s, mx);
       if (rc != DIS_OK) return rc;
     }
   return DIS_OK;

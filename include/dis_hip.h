@@ -479,8 +479,8 @@ int dis_conv3d_knn_bwd_agg(const float* geom, const float* wf, const float* dens
  * transposed forms in one launch when their weights stay resident); everything else streams (256 x 128 tiles for >= 128 channels
  * on both sides).
  * Arithmetic (dis_set_conv_split, default 1): layers with >= 32 input channels multiply two-term fp16 operands (3 products per
- * MAC, fp32 accumulate; one power-of-two scale per image of x - per halo tile in the slice launches - and one per weight
- * tensor); dis_set_conv_split(0) selects the three-term bf16 split (6 products, >= 24-bit operands) everywhere. */
+ * MAC, fp32 accumulate; one power-of-two scale per image of x in the streaming kernel, per halo tile in the slice launches and in
+ * the halo form, and one per weight tensor); dis_set_conv_split(0) selects the three-term bf16 split (6 products, >= 24-bit operands) everywhere. */
 #define DIS_CONVG_CONV 0
 #define DIS_CONVG_CONV_DGRAD 1
 #define DIS_CONVG_TCONV 2

@@ -168,13 +168,17 @@ HALO_SHAPES = [
 def test_convg_f16x2_halo_form(kind, cin, cin_mem, cout, k, stride, h, w):
     """convh2_kernel (two-term fp16, input halo staged in LDS once per tile and 32-channel chunk) against fp64 and beside the
     streaming kernel convg2_fwd_kernel on the same inputs: forward and input gradient (which runs the same kernel in its other
-    mode: stride-2 input gradients and transposed convolutions as four parity classes).  Both forms split the operands the same
-    way (one scale per image, one for the weights), so their errors against fp64 are of one size: bar 3 x streaming + 2e-7."""
+    mode: stride-2 input gradients and transposed convolutions as four parity classes).  Both forms split the operands into the
+    same two fp16 terms under power-of-two block scales (the streaming kernel one per image, the halo form a running one per tile;
+    one for the weights), so their errors against fp64 are of one size: bar 3 x streaming + 2e-7.  Image 1 is 37 x the others:
+    a halo stage never mixes images, a chunk with a larger magnitude than its predecessors rescales the accumulators."""
     from depthinspace_amd import ops
     g = torch.Generator().manual_seed(cin + cout + k + h)
     n, pad = 3, (k - 1) // 2
     x = torch.randn(n, cin, h, w, generator=g)
     x[1] *= 37.0    # (images with different scales)
+    if cin > 32:
+        x[:, 32:64] *= 50.0   # (... and a second 32-channel chunk far above the first: the running scale must shrink there)
     b = torch.randn(cout, generator=g) * 0.1
     if kind == 'conv':
         wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
