@@ -2234,6 +2234,33 @@ int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int hX, int wX, int c
   return DIS_ERR_UNSUPPORTED;
 }
 
+// 32 -> 32, 4 x 4, stride 2 (FuseNet's down convolution): the two-term fp16 kernel when the split is on (three products per MAC
+// instead of the fp32 MFMA's rate; x staged once for all 16 taps instead of once per tap row), same slabs, same reduce launch
+static int launch_wgrad_k4s2(WgArgs a, float* gw, float* gb, int cin_real, hipStream_t s) {
+  using C = WgCfg<32, 32, 4, 4, 2>;
+  static_assert(C::NCHUNK == 1 && C::NSPLIT == 4 && C::KHB == 1 && C::PART == 4 * 32 * 32 && C::TROWS == 4, "slab layout of conv_wgrad_kernel");
+  static const bool off = getenv("DIS_F2_WGRAD_K4S2") && getenv("DIS_F2_WGRAD_K4S2")[0] == '0';
+  if (off || !dis_f2_enabled() || a.xscale || (long)a.hin * a.win * 32 * 4 >= 0x7fff0000L || (long)a.hout * a.wout * 32 * 4 >= 0x7fff0000L)
+    return launch_wgrad<32, 32, 4, 4, 2>(a, gw, gb, cin_real, s);
+  const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + 3) / 4;
+  const long ntiles = (long)a.n * tiles_y * tiles_x;
+  long workers = 2L * num_cus();
+  if (workers > WG_WORKERS) workers = WG_WORKERS;
+  if (workers > ntiles) workers = ntiles;
+  const long elems = (long)C::NCHUNK * C::NSPLIT * C::PART;
+  float* tmp = a.part + (long)WG_WORKERS * elems;
+  a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
+  a.gact = nullptr; a.gn_stats = nullptr; a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_eps = 0.f;
+  hipError_t le = dis_f2_wgrad_k4s2_launch(a, workers, s);
+  if (le != hipSuccess) return (int)le;
+  const long total = (long)C::NCHUNK * C::NSPLIT * C::MROWS * 32;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(64 * WG_RW), 0, s,
+                     (const float*)a.part, gw, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 4, 4, 32, cin_real, C::PART,
+                     (const float*)(gb ? a.bpart : nullptr), gb, (int)workers);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 #define WG_CASE(CI, CO, K_, S_) \
   if (cin == CI && cout == CO && k == K_ && stride == S_) return launch_wgrad<CI, CO, K_, K_, S_>(a, gw, gb, cin_real, s);
 #define WS_CASE(CI, CO, K_, S_) \
@@ -2250,7 +2277,7 @@ static int dispatch_wgrad(const WgArgs& a, float* gw, float* gb, int cin_real, i
   WG_CASE(48, 32, 3, 1)
   WG_CASE(96, 32, 3, 1)
   WG_CASE(128, 32, 1, 1)
-  WG_CASE(32, 32, 4, 2)
+  if (cin == 32 && cout == 32 && k == 4 && stride == 2) return launch_wgrad_k4s2(a, gw, gb, cin_real, s);
   WG_CASE(4, 32, 7, 2)   // DispNetS conv1 (2 -> 32, k7 s2): all 49 taps in one pass over the pixels
   return DIS_ERR_UNSUPPORTED;
 }

@@ -164,5 +164,6 @@ hipError_t dis_f2_wgrad_launch(const WgArgs& a, int cin, int cout, int inact, lo
 hipError_t dis_f2_conv_gen_launch(const ConvArgs& a, long grid, hipStream_t stream);  // 32 x 32 channel slices (DispNetS)
 hipError_t dis_f2_wgrad_pairs_launch(const WgArgs& a, int cob, unsigned workers, unsigned pairs, int k, int stride, int kh,
                                      hipStream_t stream);
+hipError_t dis_f2_wgrad_k4s2_launch(const WgArgs& a, long workers, hipStream_t stream);   // 32 -> 32, 4 x 4, stride 2
 bool dis_f2_enabled();
 int dis_f2_wgrad_wpc();   // workgroups per CU the two-term weight-gradient kernel is built for

@@ -838,7 +838,9 @@ template <int CIN, int COUT, int INACT = 0, bool INGN = false, bool GEN = false,
 __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_wgrad_f16x2_kernel(WgArgs a) {
   using C = F2WxCfg<CIN, COUT, K_, S_, TR_, KH_>;
   static_assert(!GEN || (CIN == 32 && INACT == 0 && !INGN), "slice-pair form");
-  static_assert(GEN || (K_ == 3 && S_ == 1 && TR_ == 8 && KH_ == 3), "the FuseNet form");
+  static_assert(GEN || (K_ == 3 && S_ == 1 && TR_ == 8 && KH_ == 3) ||
+                    (K_ == 4 && S_ == 2 && TR_ == 4 && KH_ == 4 && CIN == 32 && COUT == 32 && INACT == 0 && !INGN),
+                "the FuseNet forms: 3 x 3 stride 1, and the 4 x 4 stride-2 down convolution (32 -> 32)");
   constexpr int S = S_, KH = KH_;
   const int ky0 = KH < K_ ? (int)blockIdx.z * KH : 0;  // first tap row of this workgroup (7x7: two groups of 4 rows)
   const int ldx = GEN ? a.ldx : CIN, ldg = GEN ? a.ldg : COUT;
@@ -1169,6 +1171,24 @@ hipError_t dis_f2_wgrad_pairs_launch(const WgArgs& a, int cob, unsigned workers,
   if (k == 7 && stride == 1 && kh == 4)
     return launch(conv_wgrad_f16x2_kernel<32, 32, 0, false, true, 7, 1, 8, 4>, F2WxCfg<32, 32, 7, 1, 8, 4>::LDS_BYTES, 5, 2);
   return hipErrorInvalidValue;
+}
+
+// FuseNet's 4 x 4 stride-2 down convolution (32 -> 32, Block2D3D conv2_1): all 16 taps in one workgroup, 4 x 16 output pixels per
+// tile; slab [tap * 32 + ci][co] per worker = conv_wgrad_kernel<32, 32, 4, 4, 2>'s four tap-row splits back to back, so its
+// reduce launch finishes the job.
+hipError_t dis_f2_wgrad_k4s2_launch(const WgArgs& a, long workers, hipStream_t stream) {
+  using C = F2WxCfg<32, 32, 4, 2, 4, 4>;
+  static_assert(C::LDS_BYTES <= 160 * 1024 && C::MB * 16 * 32 == 16 * 32 * 32, "LDS budget / slab size");
+  auto kern = conv_wgrad_f16x2_kernel<32, 32, 0, false, false, 4, 2, 4, 4>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  DIS_TAG("conv_wgrad_f16x2_kernel<32,32> 4x4 stride 2");
+  hipLaunchKernelGGL(kern, dim3((unsigned)workers), dim3(256), C::LDS_BYTES, stream, a);
+  return hipSuccess;
 }
 
 hipError_t dis_f2_wgrad_launch(const WgArgs& a, int cin, int cout, int inact, long workers, hipStream_t stream) {

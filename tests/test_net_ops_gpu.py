@@ -742,6 +742,50 @@ def test_conv_f16x2_dynamic_range(case, cin, cout):
             assert a2 < 1e-9, a2
 
 
+@pytest.mark.parametrize('case', ['randn', 'outlier_pixel', 'tiny_tiles'])
+def test_conv_wgrad_k4s2_f16x2(case):
+    """Weight gradient of FuseNet's 4 x 4 stride-2 down convolution (32 -> 32, Block2D3D conv2_1) on the two-term fp16 kernel (all
+    16 taps in one workgroup, running block scales over the tiles) against fp64, beside the exact-fp32 MFMA kernel the three-term
+    mode keeps for this shape; weight and bias gradient; bar 4 x the fp32 kernel's error + 2e-7 of the largest entry.
+      outlier_pixel  one input pixel and one gradient value of 1e4 among O(1) values (the running scales drop there),
+      tiny_tiles     a 32 x 32 corner of x and a 16 x 16 corner of gy at 1e-6 of the rest."""
+    from depthinspace_amd import lib
+    from tests.conftest import conv_split
+    g = torch.Generator().manual_seed(40 + len(case))
+    n, h, w, c = 3, 46, 70, 32
+    ho, wo = (h + 2 - 4) // 2 + 1, (w + 2 - 4) // 2 + 1
+    x = torch.randn(n, h, w, c, generator=g)
+    gy = torch.randn(n, ho, wo, c, generator=g)
+    if case == 'outlier_pixel':
+        x[1, 20, 21, :] = 1e4
+        gy[2, 7, 30, 3] = 1e4
+    elif case == 'tiny_tiles':
+        x[:, :32, :32, :] *= 1e-6
+        gy[:, :16, :16, :] *= 1e-6
+    xr = x.permute(0, 3, 1, 2).double()
+    wr = torch.zeros(c, c, 4, 4, dtype=torch.float64, requires_grad=True)
+    br = torch.zeros(c, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wr, br, stride=2, padding=1).backward(gy.permute(0, 3, 1, 2).double())
+    out = {}
+    for tag in ('bf16x3', 'f16x2'):
+        with conv_split(tag):
+            gw = torch.empty(c, c, 4, 4, device='cuda')
+            gb = torch.empty(c, device='cuda')
+            ws = torch.empty(lib.fn('dis_conv2d_wgrad_workspace')(c, c, 4, 2), device='cuda')
+            lib.profile_start()
+            lib.call('dis_conv2d_wgrad', x.cuda(), gy.cuda(), gw, gb, ws, n, h, w, c, c, c, 4, 2, 1)
+            tags = {t for (_, _, _, t, _) in lib.profile_stop()}
+            assert any(('f16x2' in t) == (tag == 'f16x2') for t in tags), (tag, tags)
+            out[tag] = (gw.double().cpu(), gb.double().cpu())
+
+    def err(a, ref):
+        return float((a - ref).abs().max() / (ref.abs().max() + 1e-300))
+    for name, i, ref in (('gw', 0, wr.grad), ('gb', 1, br.grad)):
+        e32, e2 = err(out['bf16x3'][i], ref), err(out['f16x2'][i], ref)
+        print(f'{case} {name}: fp32 MFMA {e32:.2e}  f16x2 {e2:.2e}')
+        assert e2 < 4 * e32 + 2e-7, (case, name, e32, e2)
+
+
 @pytest.mark.parametrize('h,w,pad', [(27, 45, 1), (16, 16, 1), (8, 19, 0), (33, 64, 2)])
 @pytest.mark.parametrize('act', [0, 1, 2])
 @pytest.mark.parametrize('cin,cout', [(32, 32), (16, 16), (16, 32), (32, 16)])
