@@ -1929,6 +1929,77 @@ int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int hX, int wX, int c
                         int goff, int hG, int wG, int cG, int cG_w, float* grad_w, float* workspace, int n, int k,
                         int stride, int pad, int bf, hipStream_t s);
 
+// ---- weight gradient of a disparity head: ONE gradient channel (cG_w = 1), 3x3, stride 1 (fp32 twin of conv_bf16.hip's
+// convb_head_wgrad_kernel) ----
+// dW[tap][c] = sum_o x[o + tap - pad][c] * g[o] is a reduction with 9 cX outputs: no matrix core needed, HBM-bound on the ONE read
+// of x (the generic kernel above takes one pass over x per tap: 1.0 GB for a 113 MB tensor, 0.34 ms for the 64-channel head at
+// 128 x 108).  Thread = (8-channel chunk, pixel slot): per x pixel two 16-byte loads and 9 gradient scalars (neighbouring output
+// pixels: L1 / L2), 72 register accumulators; lanes of a chunk are folded with xor-shuffles, waves through LDS, workgroups through
+// [block][tap][cX] slabs finished by convg_head_reduce_kernel (fp64, fixed order: deterministic).
+#define CGH_BLOCKS 512
+template <int C8>
+__global__ __launch_bounds__(256) void convg_head_wgrad_kernel(const float* __restrict__ X, int ldX, int xoff,
+                                                               const float* __restrict__ G, int ldG, int goff,
+                                                               float* __restrict__ part, int n, int h, int w, int pad) {
+  constexpr int PPB = 256 / C8, CX = 8 * C8;
+  __shared__ float red[4][9 * CX];
+  const int chunk = threadIdx.x % C8, slot = threadIdx.x / C8;
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  const long npix = (long)n * h * w;
+  for (long p = (long)blockIdx.x * PPB + slot; p < npix; p += (long)gridDim.x * PPB) {
+    const int xx = (int)(p % w);
+    const long r = p / w;
+    const int yy = (int)(r % h);
+    const float4 v0 = *(const float4*)(X + p * ldX + xoff + chunk * 8);
+    const float4 v1 = *(const float4*)(X + p * ldX + xoff + chunk * 8 + 4);
+    const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int oy = yy - ky + pad, ox = xx - kx + pad;
+        float g = 0.f;
+        if ((unsigned)oy < (unsigned)h && (unsigned)ox < (unsigned)w) g = G[(p + (long)(pad - ky) * w + (pad - kx)) * ldG + goff];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] = fmaf(g, xv[j], acc[ky * 3 + kx][j]);
+      }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = acc[t][j];
+#pragma unroll
+      for (int m = C8; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+      if (lane < C8) red[wave][t * CX + chunk * 8 + j] = a;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * CX; i += 256)
+    part[(long)blockIdx.x * (9 * CX) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+// gw[0][x][tap] = sum over the workgroup slabs, one wave per output (lanes stride over the slabs in fp64, fixed fold order)
+__global__ __launch_bounds__(256) void convg_head_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw,
+                                                                int nslab, int cX, int cXw) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= 9 * cXw) return;
+  const int tap = o / cXw, x = o % cXw;
+  double s = 0.0;
+  for (int k = lane; k < nslab; k += 64) s += (double)part[(long)k * (9 * cX) + tap * cX + x];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+  if (lane == 0) gw[(long)x * 9 + tap] = (float)s;
+}
+static bool cgh_eligible(int cX, int cG_w, int k, int stride, int hX, int wX, int hG, int wG, int pad) {
+  static const bool off = getenv("DIS_CONVG_HEAD_WGRAD") && getenv("DIS_CONVG_HEAD_WGRAD")[0] == '0';
+  return !off && cG_w == 1 && k == 3 && stride == 1 && pad <= 2 && hX == hG && wX == wG &&
+         (cX == 16 || cX == 32 || cX == 64 || cX == 128);
+}
+
 extern "C" long dis_convg_wgrad_workspace(int n, int hG, int wG, int cX, int cG, int k) {
   if (n <= 0 || hG <= 0 || wG <= 0 || cX <= 0 || cG <= 0 || k <= 0 || k * k > CG_MAXTAPS) return -1;
   int nxb, ngb, nsplit, mper, mtw, ntw;
@@ -1938,7 +2009,8 @@ extern "C" long dis_convg_wgrad_workspace(int n, int hG, int wG, int cX, int cG,
   // (the slice-pair form, if dis_convg_wgrad takes it for this layer: the stride is not known here, so size for both)
   const long b1 = dis_wgrad_pairs_workspace(n, 1, 1, hG, wG, cX, cG, 4, 4, k, 1, 0);
   const long b2 = dis_wgrad_pairs_workspace(n, 1, 1, hG, wG, cX, cG, 4, 4, k, 2, 0);
-  const long b3 = b1 > b2 ? b1 : b2;
+  long b3 = b1 > b2 ? b1 : b2;
+  if (cG <= 4 && k == 3 && b3 < (long)CGH_BLOCKS * 9 * cX) b3 = (long)CGH_BLOCKS * 9 * cX;  // head form
   return b3 > f32 ? b3 : f32;
 }
 
@@ -1954,6 +2026,22 @@ extern "C" int dis_convg_wgrad(const float* X, int ldX, int xoff, int hX, int wX
   if (k * k > CG_MAXTAPS || (stride != 1 && stride != 2)) return DIS_ERR_UNSUPPORTED;
   if ((long)n * hG * wG > 2147483647L - 64) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  if (cgh_eligible(cX, cG_w, k, stride, hX, wX, hG, wG, pad)) {   // a disparity head: one gradient channel, one pass over x
+    const long npix = (long)n * hX * wX;
+    const int c8 = cX / 8;
+    long blocks = (npix + 256 / c8 - 1) / (256 / c8);
+    if (blocks > CGH_BLOCKS) blocks = CGH_BLOCKS;
+    DIS_TAG("convg_head_wgrad_kernel (one gradient channel)");
+#define CGH_CASE(C8_) \
+    if (c8 == C8_) hipLaunchKernelGGL((convg_head_wgrad_kernel<C8_>), dim3((unsigned)blocks), dim3(256), 0, s, X, ldX, xoff, G, ldG, goff, \
+                                      workspace, n, hX, wX, pad);
+    CGH_CASE(2) CGH_CASE(4) CGH_CASE(8) CGH_CASE(16)
+#undef CGH_CASE
+    hipLaunchKernelGGL(convg_head_reduce_kernel, dim3((9 * cX_w + 3) / 4), dim3(256), 0, s, (const float*)workspace, grad_w,
+                       (int)blocks, cX, cX_w);
+    DIS_CHECK_LAUNCH();
+    return DIS_OK;
+  }
   if (dis_wgrad_pairs_workspace(n, hX, wX, hG, wG, cX, cG, ldX, ldG, k, stride, 0) >= 0)
     return dis_wgrad_pairs_run(X, ldX, xoff, hX, wX, cX, cX_w, G, ldG, goff, hG, wG, cG, cG_w, grad_w, workspace, n, k,
                                stride, pad, 0, s);
