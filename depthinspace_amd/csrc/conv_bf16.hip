@@ -441,20 +441,21 @@ struct PackArgsB {
 __global__ void convb_pack_kernel(PackArgsB a) {
   const long total = (long)a.ntaps * a.nchunk * a.nblk * 4 * a.bn * 8;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 7);
-    long r = i >> 3;
+    // (thread order: tap fastest, then the channel of its group of 8 - coalesced reads of the OIHW weights; see convb_pack_batch_kernel)
+    const int tap = (int)(i % a.ntaps);
+    long r = i / a.ntaps;
+    const int j = (int)(r & 7);
+    r >>= 3;
     const int col = (int)(r % a.bn);
     r /= a.bn;
     const int lg = (int)(r & 3);
     r >>= 2;
     const int nb = (int)(r % a.nblk);
-    r /= a.nblk;
-    const int chunk = (int)(r % a.nchunk);
-    const int tap = (int)(r / a.nchunk);
+    const int chunk = (int)(r / a.nblk);
     const int ci = chunk * CB_CK + lg * 8 + j, co = nb * a.bn + col;
     float v = 0.f;
     if (ci < a.ci_real && co < a.co_real) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
-    a.packed[i] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
+    a.packed[(((((long)tap * a.nchunk + chunk) * a.nblk + nb) * 4 + lg) * a.bn + col) * 8 + j] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
   }
 }
 
@@ -830,21 +831,21 @@ __global__ void convb_pack_halo_kernel(PackArgsH a) {
   const long total = (long)a.nchunk * a.nblk * a.nks * 4 * a.bn * 8;
   const int gpt = 4 / a.tp;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 7);
-    long r = i >> 3;
+    const int ks = (int)(i % a.nks);   // (thread order: k-step fastest, as convb_pack_batch_kernel)
+    long r = i / a.nks;
+    const int j = (int)(r & 7);
+    r >>= 3;
     const int col = (int)(r % a.bn);
     r /= a.bn;
     const int lg = (int)(r & 3);
     r >>= 2;
-    const int ks = (int)(r % a.nks);
-    r /= a.nks;
     const int nb = (int)(r % a.nblk);
     const int chunk = (int)(r / a.nblk);
     const int tap = ks * a.tp + lg / gpt;
     const int ci = chunk * CB_CK + (lg % gpt) * 8 + j, co = nb * a.bn + col;
     float v = 0.f;
     if (tap < a.ntaps && ci < a.ci_real && co < a.co_real) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
-    a.packed[i] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
+    a.packed[(((((long)chunk * a.nblk + nb) * a.nks + ks) * 4 + lg) * a.bn + col) * 8 + j] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
   }
 }
 
@@ -886,43 +887,47 @@ __global__ __launch_bounds__(256) void convb_pack_batch_kernel(const PackDesc* _
   const PackDesc& d = descs[lo];
   const PackArgsH& a = d.a;
   const long first = (long)((int)blockIdx.x - d.blk0) * 256 + threadIdx.x, stride = (long)d.nblk * 256;
+  // Thread order: the TAP (k-step) index runs fastest, then the channel within its group of 8 - consecutive threads then read
+  // consecutive floats of the weight tensor (the taps of one (co, ci) are adjacent in OIHW, the next ci follows them).  With the
+  // packed order as thread order (channel fastest, taps last) every 4-byte read touched its own sector and the taps of a sector
+  // were read by workgroups far apart in time: 1.88 GB fetched for 126 MB of weights (PMC, scripts/diag/sf_pmc.sh), 0.30 ms.
   if (d.kind == 0) {
     const long total = (long)a.ntaps * a.nchunk * a.nblk * 4 * a.bn * 8;
     for (long i = first; i < total; i += stride) {
-      const int j = (int)(i & 7);
-      long r = i >> 3;
+      const int tap = (int)(i % a.ntaps);
+      long r = i / a.ntaps;
+      const int j = (int)(r & 7);
+      r >>= 3;
       const int col = (int)(r % a.bn);
       r /= a.bn;
       const int lg = (int)(r & 3);
       r >>= 2;
       const int nb = (int)(r % a.nblk);
-      r /= a.nblk;
-      const int chunk = (int)(r % a.nchunk);
-      const int tap = (int)(r / a.nchunk);
+      const int chunk = (int)(r / a.nblk);
       const int ci = chunk * CB_CK + lg * 8 + j, co = nb * a.bn + col;
       float v = 0.f;
       if (ci < a.ci_real && co < a.co_real) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
-      a.packed[i] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
+      a.packed[(((((long)tap * a.nchunk + chunk) * a.nblk + nb) * 4 + lg) * a.bn + col) * 8 + j] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
     }
   } else {
     const long total = (long)a.nchunk * a.nblk * a.nks * 4 * a.bn * 8;
     const int gpt = 4 / a.tp;
     for (long i = first; i < total; i += stride) {
-      const int j = (int)(i & 7);
-      long r = i >> 3;
+      const int ks = (int)(i % a.nks);
+      long r = i / a.nks;
+      const int j = (int)(r & 7);
+      r >>= 3;
       const int col = (int)(r % a.bn);
       r /= a.bn;
       const int lg = (int)(r & 3);
       r >>= 2;
-      const int ks = (int)(r % a.nks);
-      r /= a.nks;
       const int nb = (int)(r % a.nblk);
       const int chunk = (int)(r / a.nblk);
       const int tap = ks * a.tp + lg / gpt;
       const int ci = chunk * CB_CK + (lg % gpt) * 8 + j, co = nb * a.bn + col;
       float v = 0.f;
       if (tap < a.ntaps && ci < a.ci_real && co < a.co_real) v = a.w[ci * a.s_ci + co * a.s_co + a.tsrc[tap]];
-      a.packed[i] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
+      a.packed[(((((long)chunk * a.nblk + nb) * a.nks + ks) * 4 + lg) * a.bn + col) * 8 + j] = (bf16_t)(cb_pack2(v, 0.f) & 0xffffu);
     }
   }
 }

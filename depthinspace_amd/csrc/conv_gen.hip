@@ -531,16 +531,18 @@ __global__ __launch_bounds__(256) void convg2_pack_kernel(Pack2Args a) {
   const float sw = __builtin_ldexpf(1.f, s_ew);
   const long total = (long)a.ntaps * a.nchunk * a.nblk * 4 * a.bn * 4;   // pairs of consecutive channels
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 3) * 2;
-    long r = i >> 2;
+    // (thread order: tap fastest, then the channel pair - consecutive threads read consecutive floats of the OIHW weights, as
+    //  conv_bf16.hip's packing kernels; the packed position is computed from the coordinates)
+    const int tap = (int)(i % a.ntaps);
+    long r = i / a.ntaps;
+    const int j = (int)(r & 3) * 2;
+    r >>= 2;
     const int col = (int)(r % a.bn);
     r /= a.bn;
     const int lg = (int)(r & 3);
     r >>= 2;
     const int nb = (int)(r % a.nblk);
-    r /= a.nblk;
-    const int chunk = (int)(r % a.nchunk);
-    const int tap = (int)(r / a.nchunk);
+    const int chunk = (int)(r / a.nblk);
     const int ci = chunk * CG3_CK + lg * 8 + j, co = nb * a.bn + col;
     float v0 = 0.f, v1 = 0.f;
     if (co < a.co_real) {
@@ -1218,14 +1220,14 @@ __global__ __launch_bounds__(256) void convh2_pack_kernel(PackH2Args a) {
   const int gpt = 4 / a.tp;
   const long total = (long)a.nchunk * a.nblk * a.nks * 4 * a.bn * 4;   // pairs of consecutive channels
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 3) * 2;
-    long r = i >> 2;
+    const int ks = (int)(i % a.nks);   // (thread order: k-step fastest, then the channel pair: coalesced reads of the weights)
+    long r = i / a.nks;
+    const int j = (int)(r & 3) * 2;
+    r >>= 2;
     const int col = (int)(r % a.bn);
     r /= a.bn;
     const int lg = (int)(r & 3);
     r >>= 2;
-    const int ks = (int)(r % a.nks);
-    r /= a.nks;
     const int nb = (int)(r % a.nblk);
     const int chunk = (int)(r / a.nblk);
     const int tap = ks * a.tp + lg / gpt;
