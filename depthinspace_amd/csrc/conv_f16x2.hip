@@ -24,6 +24,9 @@
 #ifndef F2_VALU_PER_GAP
 #define F2_VALU_PER_GAP 6
 #endif
+#ifndef F2_PF2
+#define F2_PF2 1   // two register sets of halo items where the registers allow it (see PF2 in conv_f16x2_kernel)
+#endif
 #define F2_TR 16
 #define F2_TC 16
 
@@ -58,8 +61,22 @@ struct F2Cfg {
   static constexpr int NITEMS = IR * IC * CV;
   static constexpr int NLOAD = (NITEMS + 511) / 512;
   static constexpr int NPIECE = 2 * NT;
-  static constexpr int piece_ks(int i) { return KS == 9 ? 2 * i + 1 : i + 1; }
-  static constexpr int load_ks(int i) { return KS == 9 ? 2 * (i / 2) : i; }
+#ifndef F2_LOAD_SCHED
+#define F2_LOAD_SCHED 0
+#endif
+#ifndef F2_WAIT_MODE
+#define F2_WAIT_MODE 0
+#endif
+  // k-step at which deferred-epilogue piece i is stored / halo item i is staged and its register refilled with the tile after next
+  static constexpr int piece_ks(int i) { return KS == 9 ? (F2_LOAD_SCHED ? i + 3 : 2 * i + 1) : i + 1; }
+  static constexpr int load_ks(int i) { return KS == 9 ? (F2_LOAD_SCHED ? i / 2 : 2 * (i / 2)) : i; }
+  // vector-memory operations a wave issues AFTER its last halo load of a matrix loop (the stores of the pieces that ride at or
+  // behind that k-step: within a k-step the store follows the loads): s_waitcnt vmcnt(that many) = every halo load has landed
+  static constexpr int stores_behind_loads() {
+    int c = 0;
+    for (int i = 0; i < NPIECE; ++i) c += piece_ks(i) >= load_ks(NLOAD - 1) ? 1 : 0;
+    return c;
+  }
   static constexpr int nload_at(int ks) {  // halo items staged (and refilled) at k-step ks
     int c = 0;
     for (int i = 0; i < NLOAD; ++i) c += load_ks(i) == ks ? 1 : 0;
@@ -98,6 +115,25 @@ extern "C" int dis_debug_f2_stamps(unsigned long long* host) {
 #else
 #define F2_T(k)
 #endif
+// Diagnostic builds only (scripts/diag/conv_bound.py; never part of libdis_hip.so): knock-outs of one resource at a time
+// (F2_KO_STORE: the epilogue's stores go out of range and are dropped; F2_KO_LOAD: every halo load reads tile 0 of sample 0,
+// i.e. cache hits with the same data statistics; F2_KO_MFMA: no matrix instructions; F2_KO_SPLIT: the staged items are written
+// without the two-term split; F2_KO_EPI: no activation / statistics arithmetic) and F2_CLK: the in-kernel clock from
+// s_memtime / s_memrealtime around the whole kernel (MI355X_MICROARCH.md, DVFS give-back item 6).  Results are WRONG by design.
+#ifdef F2_KO_MFMA
+// (an empty asm statement keeps the operand registers alive: the fragment reads stay)
+__device__ __forceinline__ f32x4 f2_no_mfma(f16x8_t A, f16x8_t B, f32x4 C) {
+  asm volatile("; operands kept: %0 %1" ::"v"(A), "v"(B));
+  return C;
+}
+#define F2_MFMA(A, B, C) f2_no_mfma(A, B, C)
+#else
+#define F2_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
+#endif
+#ifdef F2_CLK
+__device__ unsigned long long f2_clk[256 * 2];
+extern "C" int dis_debug_f2_clk(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(f2_clk), sizeof(f2_clk)); }
+#endif
 
 // GEN: channel-slice form (DispNetS layers as 32 x 32 slices of wider tensors, conv2d.hip dis_bx_slices_run): x / y point at the
 // slice's first channel, a pixel occupies a.ldx / a.ldy floats, a.cx / a.cy channels of the slice exist (the rest load zeros /
@@ -113,6 +149,9 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 #ifdef BX_STAMP
   unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef F2_CLK
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   constexpr int IC = C::IC, PS = C::PS, NT = C::NT, KS = C::KS, NLOAD = C::NLOAD, NPIECE = C::NPIECE, CV = C::CV, NP = C::NP;
   static_assert(!INGN || (INACT == 0 && 512 % CV == 0), "GroupNorm on load: forward instances");
@@ -133,7 +172,15 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   const int t_lo = (int)((long)ntiles * xcd / nxcd), t_hi = (int)((long)ntiles * (xcd + 1) / nxcd);
   const int d_tx = per % tiles_x, d_ty = (per / tiles_x) % tiles_y, d_n = per / (tiles_x * tiles_y);
 
-  float4 pre[NLOAD], pre2[INACT ? NLOAD : 1];
+  // PF2: TWO register sets of halo items - the loads of tile t + 3 are issued while tile t is multiplied (the items of tile t + 1
+  // are staged from one set, tile t + 2 is in flight in the other): a halo load has more than a whole tile period to land instead
+  // of half of one.  Measured (scripts/diag/conv_bound.py, profiles/r5_dominant_bound.md): the kernel's loads were issued ~half
+  // a tile period ahead of their use while HBM answers in 2 - 3 us at 4 - 5 TB/s of traffic, > 1 us of every tile exposed.
+  // Instances that already sit at the register limit of two waves per SIMD (the channel-sum epilogues, the fused activation
+  // gradient's second operand) keep one set.
+  constexpr bool PF2 = F2_PF2 && !EPIAB && INACT == 0;
+  constexpr int PFD = PF2 ? 2 : 1;   // tiles between the tile whose items are prepared / staged and the tile whose loads are issued
+  float4 pre[NLOAD], preB[NLOAD], pre2[INACT ? NLOAD : 1];   // (preB: PF2 only)
   int it_rc[NLOAD], it_off[NLOAD];
 #pragma unroll
   for (int it = 0; it < NLOAD; ++it) {
@@ -147,25 +194,34 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   }
   const unsigned x_bytes = GEN ? ((unsigned)a.hin * a.win * ldx - a.x_sub) * 4u : (unsigned)a.hin * a.win * (CIN * 4u);
   const unsigned y_bytes = GEN ? ((unsigned)a.hf * a.wf * ldy - a.y_sub) * 4u : (unsigned)a.hf * a.wf * (COUT * 4u);
-  const float* pf_x = a.x;
-  unsigned pf_bytes = 0;
-  int pf_iy0 = 0, pf_ix0 = 0, pf_off0 = 0;
-  auto pf_setup = [&](int n, int ty, int tx, bool live) {
-    pf_iy0 = ty * F2_TR - a.pad_y;
-    pf_ix0 = tx * F2_TC - a.pad_x;
-    pf_off0 = (pf_iy0 * a.win + pf_ix0) * (ldx * 4);
-    pf_x = a.x + (long)n * a.hin * a.win * ldx;
-    pf_bytes = live ? x_bytes : 0u;
+  // where a halo tile lies: the sample's base and byte range (0 when the tile does not exist: its loads return zeros), the
+  // coordinates of the halo's first pixel and their byte offset
+  struct Pf {
+    const float* x;
+    unsigned bytes;
+    int iy0, ix0, off0;
   };
-  auto pf_issue = [&](int it) {
+  auto pf_make = [&](int n, int ty, int tx, bool live) -> Pf {
+#ifdef F2_KO_LOAD
+    n = 0, ty = 1, tx = 1;
+#endif
+    Pf f;
+    f.iy0 = ty * F2_TR - a.pad_y;
+    f.ix0 = tx * F2_TC - a.pad_x;
+    f.off0 = (f.iy0 * a.win + f.ix0) * (ldx * 4);
+    f.x = a.x + (long)n * a.hin * a.win * ldx;
+    f.bytes = live ? x_bytes : 0u;
+    return f;
+  };
+  auto pf_issue = [&](float4 (&P)[NLOAD], const Pf& f, int it) {
     // rows above / below the sample leave the sample's buffer range by themselves (the offset wraps below 0 or passes its
     // end): only the column needs a test - 4 vector instructions per item, the loop is vector-issue-bound
-    const int ix = pf_ix0 + it_rc[it];
-    const unsigned off = (unsigned)ix < (unsigned)a.win ? (unsigned)(pf_off0 + it_off[it]) : BX_OOB;
-    pre[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(pf_x, pf_bytes), off, 0, 0));
+    const int ix = f.ix0 + it_rc[it];
+    const unsigned off = (unsigned)ix < (unsigned)a.win ? (unsigned)(f.off0 + it_off[it]) : BX_OOB;
+    P[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(f.x, f.bytes), off, 0, 0));
     if (INACT)
       pre2[it] = __builtin_bit_cast(
-          float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.xact + (pf_x - a.x), pf_bytes), off, 0, 0));
+          float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.xact + (f.x - a.x), f.bytes), off, 0, 0));
   };
   float4 gn_g = make_float4(0.f, 0.f, 0.f, 0.f), gn_b = gn_g, gn_sc = gn_g, gn_sh = gn_g;
   int gn_n = -1;
@@ -175,7 +231,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   }
   // (1) BEFORE the barrier between two tiles: the final fp32 values of the halo items in flight (activation gradient / GroupNorm
   // applied) and this wave's largest magnitude, left in LDS for the other waves
-  auto prep = [&](int n_cur, int parity) {
+  auto prep = [&](float4 (&P)[NLOAD], const Pf& f, int n_cur, int parity, bool in_loop = false) {
     if (INGN && n_cur != gn_n) {
       gn_n = n_cur;
       float mean, rstd;
@@ -184,16 +240,25 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
       gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
     }
-    const bool gn_interior = INGN && pf_iy0 >= 0 && pf_ix0 >= 0 && pf_iy0 + C::IR <= a.hin && pf_ix0 + C::IC <= a.win;
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    const bool gn_interior = INGN && f.iy0 >= 0 && f.ix0 >= 0 && f.iy0 + C::IR <= a.hin && f.ix0 + C::IC <= a.win;
+    // (one register set: everything in flight is waited for here, in one place; two sets: the other set's loads - and the stores
+    //  behind them - stay in flight, the compiler places the counted waits, vmcnt counts loads and stores together in issue order)
+#if F2_WAIT_MODE == 0
+    if (!PF2) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#elif F2_WAIT_MODE == 2
+    if (!PF2) {
+      if (in_loop) __builtin_amdgcn_s_waitcnt(0x0F70 | C::stores_behind_loads());
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+#endif
     float m = 0.f;
 #pragma unroll
     for (int it = 0; it < NLOAD; ++it) {
-      float4 v = pre[it];
+      float4 v = P[it];
       if (INGN) {
         f32x2 sh_lo = {gn_sh.x, gn_sh.y}, sh_hi = {gn_sh.z, gn_sh.w};
         if (!gn_interior) {
-          const int iy = pf_iy0 + ((int)threadIdx.x + it * 512) / (CV * IC), ix = pf_ix0 + it_rc[it];
+          const int iy = f.iy0 + ((int)threadIdx.x + it * 512) / (CV * IC), ix = f.ix0 + it_rc[it];
           const bool ok = (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
           sh_lo = ok ? sh_lo : (f32x2){0.f, 0.f};
           sh_hi = ok ? sh_hi : (f32x2){0.f, 0.f};
@@ -210,7 +275,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       // (items past the end of the halo - last round only - were loaded out of range, zeros, and are not staged; under GroupNorm
       //  on load they would carry the shift into the tile's maximum)
       if (INGN && (it + 1) * 512 > C::NITEMS && (int)threadIdx.x + it * 512 >= C::NITEMS) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      pre[it] = v;
+      P[it] = v;
       m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.x)), fabsf(v.y));   // -> v_max3_f32 with |.| modifiers
       m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.z)), fabsf(v.w));
     }
@@ -226,11 +291,16 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   // ... and, item by item, scale, split, LDS write into halo buffer xb.  For every tile but a workgroup's first these ride in
   // the matrix loop of the tile before (the even k-steps; the deferred epilogue has the odd ones), each item followed by the
   // load that refills its registers with the tile after.
-  auto stage_item = [&](int it, float sc, unsigned short* xb) {
-    const float4 v = pre[it];
+  auto stage_item = [&](float4 (&P)[NLOAD], int it, float sc, unsigned short* xb) {
+    const float4 v = P[it];
     unsigned a1, a2, b1, b2;
+#ifdef F2_KO_SPLIT
+    a1 = __float_as_uint(v.x) & 0x3fff3fffu, a2 = __float_as_uint(v.y) & 0x3fff3fffu, b1 = __float_as_uint(v.z) & 0x3fff3fffu, b2 = __float_as_uint(v.w) & 0x3fff3fffu;
+    (void)sc;
+#else
     f2_split_pair_scaled(v.x, v.y, sc, a1, a2);
     f2_split_pair_scaled(v.z, v.w, sc, b1, b2);
+#endif
     const int idx = (int)threadIdx.x + it * 512;
     unsigned short* p = xb + (idx / CV) * PS + (idx % CV) * 4;
     // (the last round is partial: its idle threads write a pad - a select instead of a branch, the tap loop stays one basic block)
@@ -241,11 +311,14 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 
   int tile = t_lo + rank;
   int cn = 0, cty = 0, ctx = 0;
+  Pf pfs[PFD];   // pfs[0]: the tile whose items are prepared next (the one after the current tile); pfs[PFD - 1]: the last one issued
+  pfs[0] = pf_make(0, 0, 0, false);
+  if (PF2) pfs[PFD - 1] = pfs[0];
   if (tile < t_hi) {
     ctx = tile % tiles_x, cty = (tile / tiles_x) % tiles_y, cn = tile / (tiles_x * tiles_y);
-    pf_setup(cn, cty, ctx, true);
+    pfs[0] = pf_make(cn, cty, ctx, true);
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) pf_issue(it);  // in flight while the weights are split
+    for (int it = 0; it < NLOAD; ++it) pf_issue(pre, pfs[0], it);  // in flight while the weights are split
   }
   // ---- weights: OIHW fp32 -> scaled fp16 planes in fragment order.  Coalesced copy into the second (still unused) halo buffer,
   // rows padded by one float, largest magnitude over the block, then (k-step, lane group, cout) units of 2 x 8 fp16.  The
@@ -258,6 +331,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     if (ty_ >= tiles_y) ty_ -= tiles_y, ++n_;
   };
   int n1 = cn, ty1 = cty, tx1 = ctx;   // the tile after the current one
+  int nl = cn, tyl = cty, txl = ctx;   // the last tile whose loads were issued
   {
     float* ws = (float*)(xl + C::X_U16);
     float* wmx = (float*)(red + 4);   // the weights' eight wave maxima (their own slots: mxs is the tiles')
@@ -271,7 +345,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       *(unsigned*)(red + 2) = 0u;
       *(unsigned*)(red + 3) = 0u;  // (ab_flush)
     }
-    if (tile < t_hi) prep(cn, parity);
+    if (tile < t_hi) prep(pre, pfs[0], cn, parity);
     __syncthreads();
     const float4 m0 = *(const float4*)(wmx), m1 = *(const float4*)(wmx + 4);
     sw_e = f2_scale_exp(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))));
@@ -280,11 +354,18 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       sx_e = tile_scale(parity);
       const float sc = __builtin_ldexpf(1.f, sx_e);
 #pragma unroll
-      for (int it = 0; it < NLOAD; ++it) stage_item(it, sc, xl);
+      for (int it = 0; it < NLOAD; ++it) stage_item(pre, it, sc, xl);
       advance(n1, ty1, tx1);
-      pf_setup(n1, ty1, tx1, tile + per < t_hi);
+      nl = n1, tyl = ty1, txl = tx1;
+      pfs[0] = pf_make(n1, ty1, tx1, tile + per < t_hi);
 #pragma unroll
-      for (int it = 0; it < NLOAD; ++it) pf_issue(it);
+      for (int it = 0; it < NLOAD; ++it) pf_issue(pre, pfs[0], it);
+      if constexpr (PF2) {   // ... and the tile after that one into the second register set
+        advance(nl, tyl, txl);
+        pfs[PFD - 1] = pf_make(nl, tyl, txl, tile + 2 * per < t_hi);
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it) pf_issue(preB, pfs[PFD - 1], it);
+      }
     }
     parity ^= 1;
     for (int u = threadIdx.x; u < KS * 4 * COUT; u += 512) {
@@ -433,7 +514,11 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   auto epi_piece = [&](int i) {
     const int mt = i / NT, nt = i % NT;
     f32x2 lo = {outv[mt][nt][0], outv[mt][nt][1]}, hi = {outv[mt][nt][2], outv[mt][nt][3]};
+#ifdef F2_KO_EPI
+    if (false) {
+#else
     if (ACT == DIS_ACT_SELU) {
+#endif
       // scale * max(x, 0) + scale * alpha * (exp(min(x, 0)) - 1), branch-free (for x > 0 the second term is sa * 1 - sa = 0
       // exactly), as two packed fused multiply-adds per pair: 5.5 issue slots per element instead of 9
       constexpr float L2E = 1.44269504088896340736f, SA = SELU_SCALE_F * SELU_ALPHA_F;
@@ -450,8 +535,16 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       hi = (f32x2){fmaxf(hi[0], 0.f), fmaxf(hi[1], 0.f)};
     }
     const u32x4 ov = {__float_as_uint(lo[0]), __float_as_uint(lo[1]), __float_as_uint(hi[0]), __float_as_uint(hi[1])};
+#ifdef F2_KO_STORE
+    __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(prev_y, y_bytes), (prev_off[mt] + nt * 64) | BX_OOB, 0, 0);
+#else
     __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(prev_y, y_bytes), GEN ? ((prev_off[mt] + nt * 64) | ymask[nt]) : prev_off[mt] + nt * 64, 0, 0);
+#endif
+#ifdef F2_KO_EPI
+    if (false) {
+#else
     if (STATS) {
+#endif
       const f32x2 sm = lo + hi, sq = lo * lo + hi * hi;
       t1 = __builtin_fmaf(livef[mt], sm[0] + sm[1], t1);
       t2 = __builtin_fmaf(livef[mt], sq[0] + sq[1], t2);
@@ -467,7 +560,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 
   const int xa_lane = (wave * 2 * IC + li) * PS + (CIN == 32 ? lg * 8 : (lg & 1) * 8);
   const bool hi_tap = (lg >> 1) != 0;
-  while (tile < t_hi) {
+  auto iter = [&](float4 (&P)[NLOAD]) __attribute__((always_inline)) {
     const int vy0 = cty * F2_TR + wave * 2, vx0 = ctx * F2_TC + li;
     const int tile_yoff = ((cty * F2_TR * a.osy + a.ooy) * a.wf + ctx * F2_TC * a.osx + a.oox) * (ldy * 4) + y_lane;
     const float* cur_y = a.y + (long)cn * a.hf * a.wf * ldy;
@@ -482,7 +575,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     ab_sample();
     F2_T(0)
     // the NEXT tile's items (in flight since the previous matrix loop; zeros when there is no next tile): final values, maxima
-    prep(n1, parity);
+    prep(P, pfs[0], n1, parity, tile != t_lo + rank);   // (a workgroup's first iteration has no stores behind its halo loads yet)
     F2_T(1)
     // ONE barrier per tile: every wave has finished reading the other halo buffer (the previous tile), this tile's buffer is
     // completely written, the maxima of the next tile are visible
@@ -495,7 +588,8 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     unsigned short* xn = xl + (buf ^ 1) * C::X_U16;        // the next tile's
     int n2 = n1, ty2 = ty1, tx2 = tx1;
     advance(n2, ty2, tx2);
-    pf_setup(n2, ty2, tx2, tile + 2 * per < t_hi);
+    advance(nl, tyl, txl);   // the tile whose loads this iteration issues (into the registers the staged items leave)
+    const Pf pfn = pf_make(nl, tyl, txl, tile + (1 + PFD) * per < t_hi);
     F2_T(3)
     F2_T(4)
     t1 = 0.f;
@@ -507,10 +601,10 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       if (EPIAB && ks == 0) abx_load(a.ab_x + (cur_y - a.y), EPIACT ? a.ab_act_y + (cur_y - a.y) : nullptr, cur_off);
 #pragma unroll
       for (int it = 0; it < NLOAD; ++it)
-        if (C::load_ks(it) == ks) stage_item(it, sc_n, xn);
+        if (C::load_ks(it) == ks) stage_item(P, it, sc_n, xn);
 #pragma unroll
       for (int it = 0; it < NLOAD; ++it)
-        if (C::load_ks(it) == ks) pf_issue(it);
+        if (C::load_ks(it) == ks) pf_issue(P, pfn, it);
 #pragma unroll
       for (int i = 0; i < NPIECE; ++i)
         if (C::piece_ks(i) == ks) epi_piece(i);
@@ -578,9 +672,8 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fb[b][PB[q]][nt]),
-                                                                  __builtin_bit_cast(f16x8_t, R[kx & 1][ky + mt][PA[q]]),
-                                                                  acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = F2_MFMA(__builtin_bit_cast(f16x8_t, fb[b][PB[q]][nt]),
+                                    __builtin_bit_cast(f16x8_t, R[kx & 1][ky + mt][PA[q]]), acc[mt][nt]);
         pattern(std::integral_constant<int, (ks + 1 < KS ? (nky == 0 ? 2 * NP : NP) + NP * NT : 0)>{}, ksc);
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
@@ -611,9 +704,8 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fb[b][PB[q]][nt]),
-                                                                  __builtin_bit_cast(f16x8_t, fa[b][PA[q]][mt]),
-                                                                  acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = F2_MFMA(__builtin_bit_cast(f16x8_t, fb[b][PB[q]][nt]),
+                                    __builtin_bit_cast(f16x8_t, fa[b][PA[q]][mt]), acc[mt][nt]);
         pattern(std::integral_constant<int, (ks + 1 < KS ? NP * (2 + NT) : 0)>{}, ksc);
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
@@ -653,7 +745,23 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     tile += per;
     sx_e = sx_n;
     buf ^= 1;
+    if (PF2) pfs[0] = pfs[PFD - 1];
+    pfs[PFD - 1] = pfn;
     F2_T(6)
+  };
+  if constexpr (PF2) {
+    // the two register sets alternate: tiles go in PAIRS through a loop with ONE exit, an odd last tile has its own copy of the
+    // body behind it.  (With a `break` between the two bodies the control-flow graph holds an edge from the end of the first
+    // body to the loop header, and the compiler's wait-count pass then makes the header wait as if set A had been requested one
+    // body ago - vmcnt(2) instead of vmcnt(12): the second set's loads would be waited for right after their issue.)
+    const int ntl = tile < t_hi ? (t_hi - tile + per - 1) / per : 0;
+    for (int pr = 0; pr < (ntl >> 1); ++pr) {
+      iter(pre);
+      iter(preB);
+    }
+    if (ntl & 1) iter(pre);
+  } else {
+    while (tile < t_hi) iter(pre);
   }
   stats_sample();
   ab_sample();
@@ -671,6 +779,12 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   s2 += (double)t2;
   if (STATS && stat_n >= 0) stats_flush();
   if (EPIAB && ab_n >= 0) ab_flush();
+#ifdef F2_CLK
+  if (threadIdx.x == 0 && blockIdx.x < 256) {
+    f2_clk[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - clk_t0;
+    f2_clk[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  }
+#endif
 #ifdef BX_STAMP
   F2_T(7)
   if (lane == 0 && blockIdx.x < 256)

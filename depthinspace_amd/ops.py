@@ -64,11 +64,22 @@ class _PackBatch(object):
     weight address and call geometry); the first begin_step() outside a graph capture starts a record, the next one stops it, uploads
     the descriptors and from then on every begin_step() (FlatAdam.zero_grad, i.e. in front of the forward pass) packs ALL recorded
     calls in one launch; the calls then pass DIS_CONVB_PREPACKED.  Calls that were not in the record (another network, inference
-    without begin_step) keep packing for themselves.  DIS_PACK_BATCH=0 disables it."""
+    without begin_step) keep packing for themselves.  DIS_PACK_BATCH=0 disables it.
+
+    Lifetime rules (the descriptor table holds RAW device pointers of the weights and of the workspaces):
+      * every recorded entry holds a weak reference to its weight tensor; when one dies (the network was freed) the table is dropped
+        before the next launch and recording starts over (`invalidate`); a weight that was a temporary copy while recording (it
+        died although its network lives) switches the batching off for the process - its pointer can never be replayed;
+      * a recorded workspace is never freed while the table exists: a size / device change of a recorded entry drops the table and
+        parks the old buffer in `retired` (a captured hipGraph may still replay the launch that writes it);
+      * an entry counts as prepacked only while its weight is the recorded tensor at the recorded `_version` (torch-side writes:
+        copy_, load_state_dict, broadcast) and no parameter update ran since the batch launch (`params_changed`, called by the
+        Adam entry points and by every FlatAdam method that rewrites the parameters);
+      * entries that are not part of the table are evicted when the cache passes 4 * CAP entries."""
     enabled = _os_env.environ.get('DIS_PACK_BATCH', '1') != '0'
     CAP = 1024
-    cache = {}        # key -> [wpack tensor, in_table]
-    state = 'idle'    # idle -> recording -> ready
+    cache = {}        # key -> [wpack tensor, in_table, weakref(weight), weight._version at the last batch launch]
+    state = 'idle'    # idle -> recording -> ready   (off: more calls than the table holds / an unstable weight pointer)
     used = None       # keys seen while recording
     host = None
     table = None
@@ -76,6 +87,38 @@ class _PackBatch(object):
     blocks = 0
     step = 0
     packed_step = -1  # the step whose begin_step ran the batch launch
+    dead = False      # a recorded weight tensor was freed
+    retired = []      # workspaces the dropped tables wrote into
+
+    @classmethod
+    def invalidate(cls, off=False):
+        """drop the descriptor table: nothing launches through its pointers again (outside graphs captured earlier, whose
+        buffers stay parked in `retired`)"""
+        for k, ent in list(cls.cache.items()):
+            if ent[1]:
+                cls.retired.append(ent[0])
+                del cls.cache[k]
+        del cls.retired[:-4 * cls.CAP]
+        cls.table, cls.count, cls.blocks, cls.used = None, 0, 0, None
+        if cls.state == 'recording':   # stop the library's recorder
+            import ctypes
+            cnt = (ctypes.c_int * 2)(0, 0)
+            lib.fn('dis_convb_pack_record')(None, 0, ctypes.cast(cnt, ctypes.c_void_p))
+        cls.state = 'off' if off else 'idle'
+        cls.packed_step = -1
+        cls.dead = False
+
+    @classmethod
+    def _on_dead(cls, key):
+        def cb(_ref):
+            ent = cls.cache.get(key)
+            if ent is None or ent[2] is not _ref:   # (the entry was dropped or re-bound to another tensor since)
+                return
+            if ent[1] or (cls.used is not None and key in cls.used):
+                cls.dead = True     # handled at the next begin_step / workspace call (no library calls from a finalizer)
+            else:
+                cls.cache.pop(key, None)
+        return cb
 
     @classmethod
     def begin_step(cls, dev):
@@ -83,6 +126,9 @@ class _PackBatch(object):
         if not cls.enabled:
             return
         capturing = torch.cuda.is_current_stream_capturing()
+        if cls.dead and not capturing:
+            # recorded while the weight was a temporary (died during the record): never batch; died later (its network went away): start over
+            cls.invalidate(off=cls.state == 'recording')
         if cls.state == 'recording' and not capturing:
             import ctypes
             cnt = (ctypes.c_int * 2)(0, 0)
@@ -101,6 +147,10 @@ class _PackBatch(object):
         if cls.state == 'ready':
             lib.call('dis_convb_pack_batch', cls.table, cls.count, cls.blocks)
             cls.packed_step = cls.step
+            for ent in cls.cache.values():
+                if ent[1]:
+                    w = ent[2]()
+                    ent[3] = w._version if w is not None else -1
         elif cls.state == 'idle' and not capturing:
             import ctypes
             if cls.host is None:
@@ -109,16 +159,42 @@ class _PackBatch(object):
                 cls.state, cls.used = 'recording', set()
 
     @classmethod
-    def workspace(cls, key, words, dev):
-        """-> (wpack tensor, prepacked): the call's persistent workspace and whether this step's batch launch has filled it"""
+    def workspace(cls, key, words, dev, w=None):
+        """-> (wpack tensor, prepacked): the call's persistent workspace and whether this step's batch launch has filled it from
+        the weight tensor `w` as it is now"""
         if not cls.enabled:
             return torch.empty(words, dtype=torch.int16, device=dev), False
         ent = cls.cache.get(key)
-        if ent is None or ent[0].numel() != words or ent[0].device != dev:
-            ent = cls.cache[key] = [torch.empty(words, dtype=torch.int16, device=dev), False]
+        if ent is not None and (ent[0].numel() != words or ent[0].device != dev):
+            if ent[1] or (cls.used is not None and key in cls.used):
+                cls.invalidate()        # (the table writes into the old buffer: drop the table, park the buffer)
+            cls.cache.pop(key, None)
+            ent = None
+        if ent is None:
+            if len(cls.cache) >= 4 * cls.CAP:
+                for k in [k for k, e in cls.cache.items() if not e[1] and not (cls.used is not None and k in cls.used)]:
+                    del cls.cache[k]
+            import weakref
+            ent = cls.cache[key] = [torch.empty(words, dtype=torch.int16, device=dev), False,
+                                    weakref.ref(w, cls._on_dead(key)) if w is not None else (lambda: None), -1]
+        elif w is not None and ent[2]() is not w:
+            # the same address and geometry, another tensor object (a re-created view / a new network at a recycled address)
+            if ent[1] or (cls.used is not None and key in cls.used):
+                cls.invalidate()
+                return cls.workspace(key, words, dev, w)
+            import weakref
+            ent[2], ent[3] = weakref.ref(w, cls._on_dead(key)), -1
         if cls.state == 'recording' and cls.used is not None:
             cls.used.add(key)
-        return ent[0], (ent[1] and cls.state == 'ready' and cls.packed_step == cls.step)
+        ok = (ent[1] and cls.state == 'ready' and not cls.dead and cls.packed_step == cls.step and w is not None and
+              ent[2]() is w and w._version == ent[3])
+        return ent[0], ok
+
+
+def params_changed():
+    """Tell the once-per-step weight packing that parameters were rewritten after this step's batch launch (optimizer step,
+    broadcast, checkpoint load): the calls of the rest of this step pack for themselves."""
+    _PackBatch.packed_step = -1
 
 
 def _zeros_d(n, dev):
@@ -1446,7 +1522,7 @@ def _convb_run(mode, x, w, bias, y, n, hin, win, cin, cin_w, hout, wout, cout, c
         raise lib.DisHipError(f'convb: unsupported shape cin={cin} cout={cout} k={k}')
     sk = lib.fn('dis_convb_splitk_workspace')(mode, _isbf(x), n, hin, win, hout, wout, cin, cout, k, stride, pad)   # floats
     key = (w.data_ptr(), mode, _isbf(x), _isbf(y), n, hin, win, cin, cin_w, hout, wout, cout, cout_w, k, stride, pad)
-    wp, prepacked = _PackBatch.workspace(key, per * 4 + 2 * max(sk, 0), x.device)
+    wp, prepacked = _PackBatch.workspace(key, per * 4 + 2 * max(sk, 0), x.device, w)
     ldy = y.stride(2) if y.dim() == 4 else 1
     lib.call('dis_convb_run', mode | (CONVB_PREPACKED if prepacked else 0), x, _isbf(x), _ld(x), 0, w, bias, y, _isbf(y), ldy, 0,
              wp, n, hin, win, cin, cin_w, hout, wout, cout, cout_w, k, stride, pad, act)
@@ -1926,11 +2002,11 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, lr=1e-4, beta1=0.9, b
         raise RuntimeError('adam_step_dev: state must be a 4-element int32 CUDA(HIP) tensor')
     lib.call('dis_adam_step_dev', param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(beta1), float(beta2),
              float(eps), state, float(grad_scale))
-    _PackBatch.packed_step = -1   # the parameters moved: what this step's batch launch packed is stale (inference before the next step packs per call)
+    params_changed()   # what this step's batch launch packed is stale (inference before the next step packs per call)
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     _chk(param, grad, exp_avg, exp_avg_sq)
-    _PackBatch.packed_step = -1
+    params_changed()
     lib.call('dis_adam_step', param, grad, exp_avg, exp_avg_sq, param.numel(), float(lr), float(beta1), float(beta2),
              float(eps), int(step), float(grad_scale))

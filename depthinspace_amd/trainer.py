@@ -203,6 +203,7 @@ class FlatAdam(object):
         if self.world_size > 1:
             for t in (self.flat_p, self.exp_avg, self.exp_avg_sq, self.state_dev):
                 torch.distributed.broadcast(t, src, group=self.process_group)
+            ops.params_changed()   # (weights packed by this step's batch launch are stale)
 
     # torch.optim.Adam's own (de)serialisation layout, so state.dict files are interchangeable with the reference's
     # (reference model/worker.py:342-364,376-402 saves optimizer.state_dict() of torch.optim.Adam)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run one pytest selection N times in THIS process and report every failure's assertion line (flakiness of a tolerance, not of
-the device).   usage: python scripts/diag/repeat_test.py N <pytest args...>"""
+the device).   usage: python scripts/diag/repeat_case.py N <pytest args...>"""
 import sys, io, contextlib, re
 import pytest
 n = int(sys.argv[1])
