@@ -88,6 +88,10 @@ CONV3X3_FORMS = {
     'dis_conv2d_dgrad_bf16x3_gnsums_res': lambda ia, nptr: _f(ia[3:6], ia[8], 0, 3 if nptr >= 6 else 2),
     # activation-fused input gradient + GroupNorm input + activation output (final_conv; not accumulating)
     'dis_conv2d_dgrad_bf16x3_act_gnsums_res': lambda ia, nptr: _f(ia[3:6], ia[8], 1, 2),
+    # (in_act, w_o, w_i, w_row_stride, accumulate, n, h, w, c): GroupNorm backward applied on load - the GroupNorm input read and the
+    # pre-activation gradient written beside the operand (2 extra tensors on the input side); old gradient / GroupNorm input /
+    # activation output of the epilogue forms on the output side (tensor arguments: 6, 8 with the channel sums, 9 with SELU')
+    'dis_conv2d_dgrad_f16x2_gnb': lambda ia, nptr: _f(ia[5:8], 1, 2, (1 if ia[4] else 0) + (1 if nptr >= 8 else 0) + (1 if nptr >= 9 else 0)),
 }
 
 

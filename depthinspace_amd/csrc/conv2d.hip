@@ -1166,6 +1166,8 @@ struct GnIn {  // GroupNorm applied to x on load (ConvArgs::gn_stats ...); stats
   const float* ab_x = nullptr;  // ConvArgs::ab_x / ab_out / ab_act_y (f16x2 kernel only)
   double* ab_out = nullptr;
   const float* ab_act_y = nullptr;
+  const float* gnb_coef = nullptr;  // ConvArgs::gnb_coef / gnb_out (f16x2 kernel only; the second operand arrives as xact)
+  float* gnb_out = nullptr;
 };
 static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o, int w_i, int w_rs, const float* bias, float* y,
                               double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad,
@@ -1190,7 +1192,9 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
   a.xact = xact;
   a.gn_stats = gn.stats; a.gn_gamma = gn.gamma; a.gn_beta = gn.beta; a.gn_eps = gn.eps;
   a.ab_x = gn.ab_x; a.ab_out = gn.ab_out; a.ab_slots = num_cus(); a.ab_act_y = gn.ab_act_y;
-  if (gn.ab_out && !(dis_f2_enabled() && wmode >= 0)) return DIS_ERR_UNSUPPORTED;  // (the two-term kernel's epilogue)
+  a.gnb_coef = gn.gnb_coef; a.gnb_out = gn.gnb_out;
+  if ((gn.ab_out || gn.gnb_coef) && !(dis_f2_enabled() && wmode >= 0)) return DIS_ERR_UNSUPPORTED;  // (the two-term kernel's forms)
+  if (gn.gnb_coef && (!gn.gnb_out || !xact || pad != 1 || cin != cout)) return DIS_ERR_UNSUPPORTED;
   if (gn.stats && (!gn.gamma || !gn.beta)) return DIS_ERR_NULL;
   if (gn.stats && (cin != cout || inact || (act & DIS_CONV_ACCUM) || ((act & 0xff) != DIS_ACT_NONE && (act & 0xff) != DIS_ACT_SELU)))
     return DIS_ERR_UNSUPPORTED;
@@ -1216,7 +1220,7 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
     }
     if (le != hipErrorInvalidValue) return (int)le;
   }
-  if (gn.ab_out) return DIS_ERR_UNSUPPORTED;
+  if (gn.ab_out || gn.gnb_coef) return DIS_ERR_UNSUPPORTED;
   if (cin == 32 && cout == 32) le = bx_launch<32, 32>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
   else if (cin == 16 && cout == 16) le = bx_launch<16, 16>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
   else if (cin == 16 && cout == 32) le = bx_launch<16, 32>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
@@ -1323,6 +1327,35 @@ extern "C" int dis_conv2d_dgrad_bf16x3_act(const float* gy, const float* y, int 
   if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
   return launch_conv_bf16x3(gy, w_oihw, 1, w_o, w_i, w_row_stride, nullptr, gx, nullptr, n, hin, win, cin, cout, 3, 1, pad,
                             accumulate ? DIS_CONV_ACCUM : 0, stream, y, act);
+}
+
+
+/* Input gradient of a 3x3 stride-1 pad-1 convolution c -> c (c in {16, 32}) that is followed by [activation in_act ->] GroupNorm(1
+ * group), WITH that GroupNorm's backward elementwise pass applied while the operand is staged (round 5; reference
+ * model/multi_frame_networks.py:338-345, :514-542):
+ *     gpre = act'(q) * (g * k1_c + q * kx + k0)        g: gradient wrt the GroupNorm's output, q: the GroupNorm's input (this conv's
+ *     gx (+)= conv_T(gpre, w)                             activated output), coef (n, c + 2): dis_gn_bwd_coef's coefficients
+ * and gpre is stored to gpre_out (shaped like g; every pixel once, by the tile that owns it) for the layer's weight-gradient launch.
+ * Replaces dis_gn_bwd_apply_coef (a read of g and q, a write of gpre) + the read of gpre by the plain input-gradient launch.
+ * accumulate != 0: gx += ...  Optional epilogue of the dis_conv2d_dgrad_bf16x3_gnsums / _gnsums_res forms (all three NULL: none):
+ * ab_out != NULL leaves the channel sums of the finished gx and gx * ab_gn_x; ab_act_y != NULL multiplies the finished value by
+ * selu'(ab_act_y) first (accumulate required).  Two-term fp16 kernels only (DIS_ERR_UNSUPPORTED otherwise: the caller keeps the
+ * separate pass). */
+extern "C" int dis_conv2d_dgrad_f16x2_gnb(const float* g, const float* q, const float* coef, int in_act, float* gpre_out,
+                                          const float* w_oihw, int w_o, int w_i, int w_row_stride, float* gx, int accumulate,
+                                          const float* ab_gn_x, const float* ab_act_y, double* ab_out, int n, int hin, int win,
+                                          int c, void* stream) {
+  if (!g || !q || !coef || !gpre_out) return DIS_ERR_NULL;
+  if (in_act != DIS_ACT_NONE && in_act != DIS_ACT_SELU) return DIS_ERR_UNSUPPORTED;
+  if (w_o != c || w_i != c || (c != 16 && c != 32)) return DIS_ERR_UNSUPPORTED;
+  if ((ab_out != nullptr) != (ab_gn_x != nullptr) || (ab_act_y && (!ab_out || !accumulate))) return DIS_ERR_BAD_SHAPE;
+  if (w_row_stride == 0) w_row_stride = w_i * 9;
+  if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
+  GnIn gn;
+  gn.ab_x = ab_gn_x; gn.ab_out = ab_out; gn.ab_act_y = ab_act_y;
+  gn.gnb_coef = coef; gn.gnb_out = gpre_out;
+  return launch_conv_bf16x3(g, w_oihw, 1, w_o, w_i, w_row_stride, nullptr, gx, nullptr, n, hin, win, c, c, 3, 1, 1,
+                            accumulate ? DIS_CONV_ACCUM : 0, stream, q, in_act, gn);
 }
 
 

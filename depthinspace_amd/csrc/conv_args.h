@@ -46,6 +46,12 @@ struct ConvArgs {
   // ... EPIACT form (the accumulating input gradient whose result is the gradient wrt the OUTPUT of act(GroupNorm(.) + residual),
   // ResNetBlock chains): the finished value is multiplied by act'(ab_act_y) before it is stored and summed (ab_act_y: that output)
   const float* ab_act_y;
+  // f16x2 kernel, INCOEF instances (round 5): x is the gradient g wrt the OUTPUT of a GroupNorm whose input q = xact was this conv's
+  // own (activated) output: the kernel stages act'(q) (g k1_c + q kx + k0) - the elementwise pass of the GroupNorm backward from the
+  // per-sample coefficients gnb_coef (n, CIN + 2) of dis_gn_bwd_coef - and stores those values for the pixels a tile OWNS (its halo
+  // minus the rim) to gnb_out (shaped like x): the weight-gradient launch of the same layer reads them from there.
+  const float* gnb_coef;
+  float* gnb_out;
 };
 
 struct WgArgs {

@@ -138,10 +138,14 @@ extern "C" int dis_debug_f2_clk(unsigned long long* host) { return (int)hipMemcp
 // GEN: channel-slice form (DispNetS layers as 32 x 32 slices of wider tensors, conv2d.hip dis_bx_slices_run): x / y point at the
 // slice's first channel, a pixel occupies a.ldx / a.ldy floats, a.cx / a.cy channels of the slice exist (the rest load zeros /
 // are not stored), a.nbias bias entries exist; ACT may be ReLU.
+// INCOEF: x is staged as act'(xact) * (x * k1_c + xact * kx + k0), the elementwise pass of a GroupNorm backward (ConvArgs::gnb_coef),
+// and the staged values of the pixels a tile owns are stored to gnb_out (INACT: the activation between this conv and the GroupNorm).
 template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool INGN = false, bool EPIAB = false, int EPIACT = 0,
-          bool GEN = false>
+          bool GEN = false, bool INCOEF = false>
 __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   using C = F2Cfg<CIN, COUT>;
+  static_assert(!INCOEF || (!GEN && !INGN && !STATS && ACT == DIS_ACT_NONE && CIN == COUT), "GroupNorm backward on load: input-gradient instances");
+  constexpr bool IN2 = INACT != 0 || INCOEF;   // a second operand rides with every halo item
   static_assert(!GEN || (!STATS && INACT == 0 && !INGN && !EPIAB && CIN == 32 && COUT == 32), "slice form: plain convolution / input gradient");
   const int ldx = GEN ? a.ldx : CIN, ldy = GEN ? a.ldy : COUT;  // floats per pixel
   static_assert(!EPIAB || (!STATS && ACT == DIS_ACT_NONE && 2 * COUT <= 64), "channel sums: plain input-gradient instances");
@@ -178,16 +182,18 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   // a tile period ahead of their use while HBM answers in 2 - 3 us at 4 - 5 TB/s of traffic, > 1 us of every tile exposed.
   // Instances that already sit at the register limit of two waves per SIMD (the channel-sum epilogues, the fused activation
   // gradient's second operand) keep one set.
-  constexpr bool PF2 = F2_PF2 && !EPIAB && INACT == 0;
+  constexpr bool PF2 = F2_PF2 && !EPIAB;
   constexpr int PFD = PF2 ? 2 : 1;   // tiles between the tile whose items are prepared / staged and the tile whose loads are issued
-  float4 pre[NLOAD], preB[NLOAD], pre2[INACT ? NLOAD : 1];   // (preB: PF2 only)
+  float4 pre[NLOAD], preB[NLOAD], pre2[IN2 ? NLOAD : 1], pre2B[IN2 ? NLOAD : 1];   // (preB / pre2B: PF2 only)
   int it_rc[NLOAD], it_off[NLOAD];
+  unsigned it_own = 0u;   // INCOEF: bit it = item it lies in the 16 x 16 pixels the tile owns (pad == 1: halo rows / columns 1 .. 16)
 #pragma unroll
   for (int it = 0; it < NLOAD; ++it) {
     const int idx = (int)threadIdx.x + it * 512;
     const int vv = idx % CV, pix = idx / CV;
     const int r = pix / IC, c = pix % IC;
     (void)r;
+    if (INCOEF && idx < C::NITEMS && r >= 1 && r <= F2_TR && c >= 1 && c <= F2_TC) it_own |= 1u << it;
     // (halo column; items past the end of the halo - and, GEN, channels the slice does not have - are never in range: zeros)
     it_rc[it] = (idx < C::NITEMS && (!GEN || vv * 4 < a.cx)) ? c : 0x40000000;
     it_off[it] = ((r * a.win + c) * ldx + vv * 4) * 4;
@@ -213,25 +219,27 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     f.bytes = live ? x_bytes : 0u;
     return f;
   };
-  auto pf_issue = [&](float4 (&P)[NLOAD], const Pf& f, int it) {
+  auto pf_issue = [&](float4 (&P)[NLOAD], float4 (&Q)[IN2 ? NLOAD : 1], const Pf& f, int it) {
     // rows above / below the sample leave the sample's buffer range by themselves (the offset wraps below 0 or passes its
     // end): only the column needs a test - 4 vector instructions per item, the loop is vector-issue-bound
     const int ix = f.ix0 + it_rc[it];
     const unsigned off = (unsigned)ix < (unsigned)a.win ? (unsigned)(f.off0 + it_off[it]) : BX_OOB;
     P[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(f.x, f.bytes), off, 0, 0));
-    if (INACT)
-      pre2[it] = __builtin_bit_cast(
+    if (IN2)
+      Q[it] = __builtin_bit_cast(
           float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.xact + (f.x - a.x), f.bytes), off, 0, 0));
   };
   float4 gn_g = make_float4(0.f, 0.f, 0.f, 0.f), gn_b = gn_g, gn_sc = gn_g, gn_sh = gn_g;
   int gn_n = -1;
+  float4 cf_k1 = gn_g;     // INCOEF: this thread's four k1_c, and the sample's kx, k0
+  float cf_kx = 0.f, cf_k0 = 0.f;
   if (INGN) {
     gn_g = *(const float4*)(a.gn_gamma + ((int)threadIdx.x % CV) * 4);
     gn_b = *(const float4*)(a.gn_beta + ((int)threadIdx.x % CV) * 4);
   }
   // (1) BEFORE the barrier between two tiles: the final fp32 values of the halo items in flight (activation gradient / GroupNorm
   // applied) and this wave's largest magnitude, left in LDS for the other waves
-  auto prep = [&](float4 (&P)[NLOAD], const Pf& f, int n_cur, int parity, bool in_loop = false) {
+  auto prep = [&](float4 (&P)[NLOAD], float4 (&Q)[IN2 ? NLOAD : 1], const Pf& f, int n_cur, int parity, bool in_loop = false) {
     if (INGN && n_cur != gn_n) {
       gn_n = n_cur;
       float mean, rstd;
@@ -239,6 +247,13 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       gn_moments(a.gn_stats, n_cur < a.n ? n_cur : a.n - 1, (double)a.hin * a.win * CIN, a.gn_eps, &mean, &rstd);
       gn_sc = make_float4(rstd * gn_g.x, rstd * gn_g.y, rstd * gn_g.z, rstd * gn_g.w);
       gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
+    }
+    if (INCOEF && n_cur != gn_n) {
+      gn_n = n_cur;
+      const float* cf = a.gnb_coef + (long)(n_cur < a.n ? n_cur : a.n - 1) * (CIN + 2);
+      cf_k1 = *(const float4*)(cf + ((int)threadIdx.x % CV) * 4);
+      cf_kx = cf[CIN];
+      cf_k0 = cf[CIN + 1];
     }
     const bool gn_interior = INGN && f.iy0 >= 0 && f.ix0 >= 0 && f.iy0 + C::IR <= a.hin && f.ix0 + C::IC <= a.win;
     // (one register set: everything in flight is waited for here, in one place; two sets: the other set's loads - and the stores
@@ -267,8 +282,24 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
         const f32x2 hi = (f32x2){v.z, v.w} * (f32x2){gn_sc.z, gn_sc.w} + sh_hi;
         v = make_float4(lo[0], lo[1], hi[0], hi[1]);
       }
-      if (INACT) {
-        const float4 q = pre2[it];
+      if (INCOEF) {   // (the arithmetic of gn_apply_coef_kernel, bit for bit; padding: g = q = 0 loads give k0, which must not be staged)
+        const float4 q = Q[it];
+        const int ix = f.ix0 + it_rc[it];
+        const unsigned off = (unsigned)ix < (unsigned)a.win ? (unsigned)(f.off0 + it_off[it]) : BX_OOB;
+        const bool inside = off < f.bytes;   // (rows above / below the sample: the offset leaves the sample's byte range)
+        v.x = __builtin_fmaf(v.x, cf_k1.x, __builtin_fmaf(q.x, cf_kx, cf_k0));
+        v.y = __builtin_fmaf(v.y, cf_k1.y, __builtin_fmaf(q.y, cf_kx, cf_k0));
+        v.z = __builtin_fmaf(v.z, cf_k1.z, __builtin_fmaf(q.z, cf_kx, cf_k0));
+        v.w = __builtin_fmaf(v.w, cf_k1.w, __builtin_fmaf(q.w, cf_kx, cf_k0));
+        if (INACT) {
+          v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
+          v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
+        }
+        v = inside ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const u32x4 sv = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(sv, bx_rsrc(a.gnb_out + (f.x - a.x), f.bytes), ((it_own >> it) & 1u) ? off : BX_OOB, 0, 0);
+      } else if (INACT) {
+        const float4 q = Q[it];
         v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
         v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
       }
@@ -318,7 +349,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     ctx = tile % tiles_x, cty = (tile / tiles_x) % tiles_y, cn = tile / (tiles_x * tiles_y);
     pfs[0] = pf_make(cn, cty, ctx, true);
 #pragma unroll
-    for (int it = 0; it < NLOAD; ++it) pf_issue(pre, pfs[0], it);  // in flight while the weights are split
+    for (int it = 0; it < NLOAD; ++it) pf_issue(pre, pre2, pfs[0], it);  // in flight while the weights are split
   }
   // ---- weights: OIHW fp32 -> scaled fp16 planes in fragment order.  Coalesced copy into the second (still unused) halo buffer,
   // rows padded by one float, largest magnitude over the block, then (k-step, lane group, cout) units of 2 x 8 fp16.  The
@@ -345,7 +376,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       *(unsigned*)(red + 2) = 0u;
       *(unsigned*)(red + 3) = 0u;  // (ab_flush)
     }
-    if (tile < t_hi) prep(pre, pfs[0], cn, parity);
+    if (tile < t_hi) prep(pre, pre2, pfs[0], cn, parity);
     __syncthreads();
     const float4 m0 = *(const float4*)(wmx), m1 = *(const float4*)(wmx + 4);
     sw_e = f2_scale_exp(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))));
@@ -359,12 +390,12 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
       nl = n1, tyl = ty1, txl = tx1;
       pfs[0] = pf_make(n1, ty1, tx1, tile + per < t_hi);
 #pragma unroll
-      for (int it = 0; it < NLOAD; ++it) pf_issue(pre, pfs[0], it);
+      for (int it = 0; it < NLOAD; ++it) pf_issue(pre, pre2, pfs[0], it);
       if constexpr (PF2) {   // ... and the tile after that one into the second register set
         advance(nl, tyl, txl);
         pfs[PFD - 1] = pf_make(nl, tyl, txl, tile + 2 * per < t_hi);
 #pragma unroll
-        for (int it = 0; it < NLOAD; ++it) pf_issue(preB, pfs[PFD - 1], it);
+        for (int it = 0; it < NLOAD; ++it) pf_issue(preB, pre2B, pfs[PFD - 1], it);
       }
     }
     parity ^= 1;
@@ -560,7 +591,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 
   const int xa_lane = (wave * 2 * IC + li) * PS + (CIN == 32 ? lg * 8 : (lg & 1) * 8);
   const bool hi_tap = (lg >> 1) != 0;
-  auto iter = [&](float4 (&P)[NLOAD]) __attribute__((always_inline)) {
+  auto iter = [&](float4 (&P)[NLOAD], float4 (&Q)[IN2 ? NLOAD : 1]) __attribute__((always_inline)) {
     const int vy0 = cty * F2_TR + wave * 2, vx0 = ctx * F2_TC + li;
     const int tile_yoff = ((cty * F2_TR * a.osy + a.ooy) * a.wf + ctx * F2_TC * a.osx + a.oox) * (ldy * 4) + y_lane;
     const float* cur_y = a.y + (long)cn * a.hf * a.wf * ldy;
@@ -575,7 +606,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     ab_sample();
     F2_T(0)
     // the NEXT tile's items (in flight since the previous matrix loop; zeros when there is no next tile): final values, maxima
-    prep(P, pfs[0], n1, parity, tile != t_lo + rank);   // (a workgroup's first iteration has no stores behind its halo loads yet)
+    prep(P, Q, pfs[0], n1, parity, tile != t_lo + rank);   // (a workgroup's first iteration has no stores behind its halo loads yet)
     F2_T(1)
     // ONE barrier per tile: every wave has finished reading the other halo buffer (the previous tile), this tile's buffer is
     // completely written, the maxima of the next tile are visible
@@ -604,7 +635,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
         if (C::load_ks(it) == ks) stage_item(P, it, sc_n, xn);
 #pragma unroll
       for (int it = 0; it < NLOAD; ++it)
-        if (C::load_ks(it) == ks) pf_issue(P, pfn, it);
+        if (C::load_ks(it) == ks) pf_issue(P, Q, pfn, it);
 #pragma unroll
       for (int i = 0; i < NPIECE; ++i)
         if (C::piece_ks(i) == ks) epi_piece(i);
@@ -756,12 +787,12 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     // body ago - vmcnt(2) instead of vmcnt(12): the second set's loads would be waited for right after their issue.)
     const int ntl = tile < t_hi ? (t_hi - tile + per - 1) / per : 0;
     for (int pr = 0; pr < (ntl >> 1); ++pr) {
-      iter(pre);
-      iter(preB);
+      iter(pre, pre2);
+      iter(preB, pre2B);
     }
-    if (ntl & 1) iter(pre);
+    if (ntl & 1) iter(pre, pre2);
   } else {
-    while (tile < t_hi) iter(pre);
+    while (tile < t_hi) iter(pre, pre2);
   }
   stats_sample();
   ab_sample();
@@ -797,7 +828,7 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
   using C = F2Cfg<CIN, COUT>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
   const bool ingn = a.gn_stats != nullptr;
-  static bool attr_set[18] = {};
+  static bool attr_set[32] = {};
   auto launch = [&](auto kern, int slot) -> hipError_t {
     if (!attr_set[slot]) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -810,6 +841,35 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
   };
   if (a.act != DIS_ACT_NONE && a.act != DIS_ACT_SELU) return hipErrorInvalidValue;
   const bool selu = a.act == DIS_ACT_SELU;
+  if (a.gnb_coef) {  // input gradient whose operand is the GroupNorm backward's elementwise pass, applied on load (INCOEF)
+    if constexpr (CIN == COUT) {
+      if (ingn || selu || stats || !a.xact || !a.gnb_out || (inact != 0 && inact != DIS_ACT_SELU)) return hipErrorInvalidValue;
+      constexpr int S = DIS_ACT_SELU;
+#ifndef F2_INCOEF_FAT
+#define F2_INCOEF_FAT 1
+#endif
+      if (a.ab_out && a.accum && a.ab_act_y) {  // ... + the ResNetBlock-chain epilogue (sums of g, g * x2 behind SELU')
+        if (!F2_INCOEF_FAT && CIN == 32) return hipErrorInvalidValue;
+        if (inact != S) return hipErrorInvalidValue;
+        return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, true, false, S, false, true, S, false, true>, 18);
+      }
+      if (a.ab_out && a.accum) {                // ... + the two-consumer epilogue (Block2D3D conv1_1)
+        if (!F2_INCOEF_FAT && CIN == 32) return hipErrorInvalidValue;
+        if (inact != S) return hipErrorInvalidValue;
+        return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, true, false, S, false, true, 0, false, true>, 19);
+      }
+      if (a.ab_out)                             // ... + the channel sums of a GroupNorm-on-load pair (conv2d_gn_in)
+        return inact ? launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, S, false, true, 0, false, true>, 20)
+                     : launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, 0, false, true, 0, false, true>, 21);
+      if (a.accum)
+        return inact ? launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, true, false, S, false, false, 0, false, true>, 22)
+                     : launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, true, false, 0, false, false, 0, false, true>, 23);
+      return inact ? launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, S, false, false, 0, false, true>, 24)
+                   : launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, 0, false, false, 0, false, true>, 25);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (a.ab_out && inact) {  // ... of a conv that had an activation itself and whose INPUT was SELU(GroupNorm(.) + residual)
     if constexpr (CIN == 16 && COUT == 32) {  // (final_conv behind ref_res3: reference model/multi_frame_networks.py:262-266)
       if (ingn || selu || stats || a.accum || inact != DIS_ACT_SELU || !a.ab_x || !a.ab_act_y) return hipErrorInvalidValue;

@@ -450,10 +450,15 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ gy, const float* _
 // grid n: block b writes coef[b][0..c) = k1_c, coef[b][c] = kx, coef[b][c + 1] = k0 and the sample's dgamma_c / dbeta_c (fp64) behind
 // the coefficients of all samples (pg); the apply kernel's first block adds those over the samples.  Fixed orders: deterministic.
 #define GN_COEF_T 1024
+// fin != nullptr (dis_gn_bwd_coef): the block that arrives LAST at the counter *fin (zeroed by the caller) adds the samples' dgamma /
+// dbeta parts in sample order and writes gg / gb - the job of gn_apply_coef_kernel's first block when the elementwise pass exists.
 __global__ __launch_bounds__(GN_COEF_T) void gn_coef_kernel(const double* __restrict__ ab, int slots, const double* __restrict__ stats,
                                                             const float* __restrict__ gamma, float* __restrict__ coef,
-                                                            double* __restrict__ pg, long hw, int c, float eps) {
+                                                            double* __restrict__ pg, long hw, int c, float eps,
+                                                            unsigned* __restrict__ fin = nullptr, float* __restrict__ gg = nullptr,
+                                                            float* __restrict__ gb = nullptr) {
   __shared__ double sA[GN_MAXC], sB[GN_MAXC], part[GN_COEF_T];
+  __shared__ unsigned s_last;
   const int b = blockIdx.x, t = threadIdx.x;
   const double m = (double)hw * c;
   {  // A_c, B_c of this sample: 16 threads per value, each a sixteenth of the slots with all of its loads in flight (256 slots:
@@ -505,13 +510,33 @@ __global__ __launch_bounds__(GN_COEF_T) void gn_coef_kernel(const double* __rest
       coef[(long)b * (c + 2) + c + 1] = (rstd * rstd) * a2 * mean - rstd * a1;
     }
   }
+  if (fin) {
+    // this block's pg[] entries are visible device-wide before it counts itself in: the barrier completes every thread's stores
+    // (to this XCD's L2), ONE thread's release fence writes the L2 back - a fence in every thread cost 15 us per launch
+    __syncthreads();
+    if (t == 0) {
+      __threadfence();
+      s_last = atomicAdd(fin, 1u) == gridDim.x - 1 ? 1u : 0u;
+      if (s_last) __threadfence();   // acquire: the other blocks' entries (other XCDs' L2s) are read from memory
+    }
+    __syncthreads();
+    if (s_last) {
+      if (t < 2 * c) {
+        double v = 0.0;
+        for (int sn = 0; sn < (int)gridDim.x; ++sn) v += __builtin_nontemporal_load(pg + (long)sn * 2 * c + t);
+        if (t < c) gg[t] = (float)v;
+        else gb[t - c] = (float)v;
+      }
+      if (t == 0) *fin = 0u;   // (re-armed: a captured graph replays this launch on the same counter)
+    }
+  }
 }
 __global__ void gn_apply_coef_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ coef,
                                      float* __restrict__ gx, long hw, int c, int in_act, int nt, const double* __restrict__ pg,
                                      float* __restrict__ gg, float* __restrict__ gb) {
   __shared__ float k1[GN_MAXC], kk[2];
   const int n = blockIdx.y;
-  if (blockIdx.x == 0 && n == 0 && (int)threadIdx.x < 2 * c) {  // dgamma / dbeta: the samples' parts, in order
+  if (pg && blockIdx.x == 0 && n == 0 && (int)threadIdx.x < 2 * c) {  // dgamma / dbeta: the samples' parts, in order
     double v = 0.0;
     for (int sn = 0; sn < (int)gridDim.y; ++sn) v += pg[(long)sn * 2 * c + threadIdx.x];
     if ((int)threadIdx.x < c) gg[threadIdx.x] = (float)v;
@@ -558,6 +583,36 @@ extern "C" int dis_gn_bwd_from_sums(const float* g, const float* x, const double
   if (gxg > 512) gxg = 512;
   hipLaunchKernelGGL(gn_apply_coef_kernel, dim3(gxg, n), dim3(256), 0, s, g, x, (const float*)coef, gx, hw, c, in_act,
                      gn_nt_flags(), (const double*)pg, grad_gamma, grad_beta);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+/* The two halves of dis_gn_bwd_from_sums as separate entry points (round 5): the consumer of gx is usually the 3x3 convolution in
+ * front of the GroupNorm, whose input-gradient launch can apply the elementwise pass while it stages its operand
+ * (dis_conv2d_dgrad_f16x2_gnb) - the pass over g, x and gx then does not exist.
+ *   dis_gn_bwd_coef: sums -> coef (n, c + 2) floats [k1_c..., kx, k0 per sample] followed (8-byte aligned) by n * 2 c doubles, and
+ *     grad_gamma / grad_beta (c), finished by the last block to arrive at *counter (one unsigned, ZERO on entry, zero again on exit).
+ *   dis_gn_bwd_apply_coef: gx = act'(x) (g k1_c + x kx + k0), the elementwise pass alone (the general fallback). */
+extern "C" int dis_gn_bwd_coef(const double* stats, const float* gamma, const double* ab, int slots, float* coef, float* grad_gamma,
+                               float* grad_beta, unsigned* counter, int n, long hw, int c, float eps, void* stream) {
+  if (!stats || !gamma || !ab || !coef || !grad_gamma || !grad_beta || !counter) return DIS_ERR_NULL;
+  if (n <= 0 || hw <= 0 || c <= 0 || slots <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c % 4 != 0 || 2 * c > 64) return DIS_ERR_UNSUPPORTED;
+  double* pg = (double*)(((uintptr_t)(coef + (long)n * (c + 2)) + 7) & ~(uintptr_t)7);
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(n), dim3(GN_COEF_T), 0, (hipStream_t)stream, ab, slots, stats, gamma, coef, pg, hw, c, eps,
+                     counter, grad_gamma, grad_beta);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_gn_bwd_apply_coef(const float* g, const float* x, const float* coef, float* gx, int n, long hw, int c, int in_act,
+                                     void* stream) {
+  if (!g || !x || !coef || !gx) return DIS_ERR_NULL;
+  if (n <= 0 || hw <= 0 || c <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c % 4 != 0 || 2 * c > 64) return DIS_ERR_UNSUPPORTED;
+  int gxg = dis_ew_grid(hw * (c / 4), 256);
+  if (gxg > 512) gxg = 512;
+  hipLaunchKernelGGL(gn_apply_coef_kernel, dim3(gxg, n), dim3(256), 0, (hipStream_t)stream, g, x, coef, gx, hw, c, in_act,
+                     gn_nt_flags(), (const double*)nullptr, (float*)nullptr, (float*)nullptr);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

@@ -67,6 +67,9 @@ SIGS = {
     'dis_conv2d_dgrad_bf16x3_gnsums_res': 'ppiiippppiiiiiip',
     'dis_conv2d_dgrad_bf16x3_act_gnsums_res': 'pppiiippppiiiiiip',
     'dis_gn_bwd_from_sums': 'pppppippppilifip',
+    'dis_gn_bwd_coef': 'pppippppilifp',
+    'dis_gn_bwd_apply_coef': 'ppppiliip',
+    'dis_conv2d_dgrad_f16x2_gnb': 'pppippiiipippp' + 'iiiip',
     'dis_conv2d_wgrad_bf16x3_gn': 'ppppfppppiiiiiiiiip',
     'dis_conv2d_fwd_scaled': 'ppppppp' + 'iiiiiiiii' + 'p',
     'dis_conv2d_wgrad_scaled': 'pppppp' + 'iiiiiiiii' + 'p',
@@ -199,7 +202,13 @@ def profile_stop():
     return [(n, a, e0.elapsed_time(e1), t, k) for (n, a, e0, e1, t, k) in rec]
 
 
-def call(name, *args):
+def call_try(name, *args):
+    """call(), except that DIS_ERR_UNSUPPORTED (-2: this build / mode has no kernel for the configuration) is returned as False
+    instead of raised - for callers that hold a general form of the same operation (never a non-HIP fallback)."""
+    return call(name, *args, _soft=True)
+
+
+def call(name, *args, _soft=False):
     """Call a C-ABI entry point; tensors are passed as device pointers, None as NULL.
     Appends the current HIP stream.  Raises DisHipError on a non-zero status (like the reference's
     C++ exceptions surfacing as RuntimeError, model/ext_functions.py:123-126)."""
@@ -229,8 +238,11 @@ def call(name, *args):
                          sum(1 for a in args if isinstance(a, torch.Tensor))))
     else:
         rc = f(*conv)
+    if rc == -2 and _soft:
+        return False
     if rc != 0:
         raise DisHipError(f'{name} failed: {_ERR.get(rc, "hipError_t " + str(rc))}')
+    return True
 
 
 def host_floats(vals):

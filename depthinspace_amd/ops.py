@@ -40,12 +40,48 @@ _ARENA_DOUBLES = int(_os_env.environ.get('DIS_ARENA_DOUBLES', 1 << 23))   # 64 M
 # gradient tensors whose producer already left the GroupNorm-backward sums (see _Conv2d.backward / _GroupNorm.backward):
 # data_ptr -> (ab, slots)
 _GN_PRE = {}
+# GroupNorm backward applied ON LOAD by the input-gradient launch of the conv in front of the GroupNorm (round 5,
+# dis_conv2d_dgrad_f16x2_gnb): the GroupNorm's backward runs only the coefficient kernel and returns a TOKEN in place of the gradient
+# wrt its input - a one-element tensor expanded to the gradient's shape (no memory, an address no other tensor has); the conv's
+# backward finds (g, q, coef, in_act) under the token's address.  token data_ptr -> (token, g, q, coef, in_act).  Only conv outputs
+# that conv2d() / conv2d_gn_in() marked `_gn_lazy_ok` (their backward understands tokens, and the GroupNorm is their only consumer)
+# are answered with one; begin_step() raises if a token was never redeemed.
+_GN_LAZY = {}
+GN_LAZY = _os_env.environ.get('DIS_GN_LAZY', '1') != '0'
+
+
+def _gn_lazy_defer(g, q, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, in_act):
+    coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=g.device)
+    lib.call('dis_gn_bwd_coef', stats, gamma, ab, slots, coef, gg, gb, _zeros_d(1, g.device), n, hw, c, eps)
+    tok = torch.empty(1, dtype=torch.float32, device=g.device)
+    _GN_LAZY[tok.data_ptr()] = (tok, g, q, coef, in_act)
+    return tok.expand(g.shape)
+
+
+def _gn_lazy_pop(gy):
+    return _GN_LAZY.pop(gy.data_ptr(), None) if _GN_LAZY else None
+
+
+def _gn_lazy_materialize(ent):
+    """the elementwise pass as a launch of its own (the consumer has no on-load form for this configuration)"""
+    _, g, q, coef, in_act = ent
+    n, c = g.shape[0], g.shape[-1]
+    gx = torch.empty_like(g)
+    lib.call('dis_gn_bwd_apply_coef', g, q, coef, gx, n, g.numel() // (n * c), c, in_act)
+    return gx
+
+
+def _gn_lazy_shape(cin, cout, k, stride, pad):
+    return GN_LAZY and BF16X3 and cin == cout and cin in (16, 32) and k == 3 and stride == 1 and pad == 1
 
 
 def begin_step(dev):
     if _GN_PRE:   # a gradient that was handed on pre-multiplied was never picked up by its GroupNorm: the step would be wrong
         _GN_PRE.clear()
         raise RuntimeError('ops: a pre-reduced GroupNorm gradient of the previous backward pass was not consumed')
+    if _GN_LAZY:  # a token stood in for a gradient and nobody redeemed it (the conv output had a second consumer?)
+        _GN_LAZY.clear()
+        raise RuntimeError('ops: a deferred GroupNorm backward (token gradient) of the previous backward pass was not redeemed')
     dev = torch.device(dev)
     a = _ARENA.get(dev)
     if a is None:
@@ -827,6 +863,40 @@ class _Conv2d(torch.autograd.Function):
         stride, pad, act, has_bias, need_dgrad = ctx.cfg
         n, hin, win, cin_pad = x.shape
         cout, cin, k, _ = weight.shape
+        # a token of a GroupNorm behind this conv (ops._GN_LAZY): its backward's elementwise pass is applied by this conv's
+        # input-gradient launch on load, which also writes the values for the weight-gradient launch
+        lz = _gn_lazy_pop(gy)
+        if lz is not None and not (act == ACT_NONE and need_dgrad and ctx.needs_input_grad[0] and cin_pad == cin and
+                                   _gn_lazy_shape(cin, cout, k, stride, pad) and lib.fn('dis_get_conv_split')() == 1):
+            gy, lz = _gn_lazy_materialize(lz), None
+        if lz is not None:
+            _, lg, lq, lcoef, lin_act = lz
+            join = ctx.join
+            second = join is not None and join.buf is not None
+            gx = join.take(x.shape) if second else torch.empty_like(x)
+            gnres = ctx.gnres
+            gpre = torch.empty_like(lg)
+            ab = ab_x = ab_act = None
+            if (gnres is not None and second and (GN_SUMS & 2) and tuple(gnres[0].shape) == tuple(x.shape)):
+                slots = lib.fn('dis_conv2d_gnsums_slots')()   # (the ResNetBlock-chain / two-consumer epilogue, see below)
+                ab = _zeros_d(n * slots * 2 * cin, x.device)
+                ab_x, ab_act = gnres[0], (x if len(gnres) == 1 else None)
+            if lib.call_try('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, weight, cout, cin, weight.stride(0), gx,
+                            1 if second else 0, ab_x, ab_act, ab, n, hin, win, cin):
+                if ab is not None:
+                    _GN_PRE[gx.data_ptr()] = (ab, slots)
+                if join is not None and not second:
+                    gx = join.first(gx)
+                gw, gw_ret = _sink(weight)
+                gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
+                ws = torch.empty(lib.fn('dis_conv2d_wgrad_workspace')(cin_pad, cout, k, stride), dtype=torch.float32, device=x.device)
+                _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
+                _sinks_written()
+                return gx, gw_ret, gb_ret, None, None, None, None, None, None, None, None
+            # (no instance for this combination in this build: the separate pass, then the general path below)
+            if second:
+                join.buf = gx   # (hand the joined buffer back: the general path takes it again)
+            gy = _gn_lazy_materialize(lz)
         gy = _c(gy)
         # bf16x3 shapes: the activation gradient is applied while gy is staged (dgrad and wgrad kernels), no separate pass
         fuse_act = act != ACT_NONE and _bx_shape(cin_pad, cout, k, stride)
@@ -895,7 +965,10 @@ def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, nee
     gy_is_pre: the only consumer of y is group_norm(..., in_act=act), whose backward already multiplies by act'(y);
     the incoming gradient is then taken as the pre-activation gradient.
     join: GradJoin shared with the other consumer of x (see GradJoin)."""
-    return _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre, join, gnres)
+    out = _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre, join, gnres)
+    if (act == ACT_NONE or gy_is_pre) and need_dgrad and _gn_lazy_shape(x.shape[-1], weight.shape[0], weight.shape[2], stride, pad):
+        out[0]._gn_lazy_ok = True   # (a GroupNorm that is this output's ONLY consumer may answer with a token, see _GN_LAZY)
+    return out
 
 
 GN_FUSE = _os.environ.get('DIS_GN_FUSE', '1') != '0'
@@ -918,7 +991,8 @@ class _Conv2dGnIn(torch.autograd.Function):
     activation) and the conv's weight gradient with the same on-load normalisation."""
 
     @staticmethod
-    def forward(ctx, x, gn_stats, gamma, beta, weight, bias, pad, act, want_stats, gy_is_pre, eps, in_act):
+    def forward(ctx, x, gn_stats, gamma, beta, weight, bias, pad, act, want_stats, gy_is_pre, eps, in_act, x_lazy=False):
+        ctx.x_lazy = x_lazy   # the producer of x redeems a token for the GroupNorm's elementwise backward pass (_GN_LAZY)
         x, weight = _c(x), _c(weight)
         _chk(x, gamma, beta, weight, bias)
         n, h, w, cin = x.shape
@@ -946,28 +1020,48 @@ class _Conv2dGnIn(torch.autograd.Function):
         pad, act, has_bias, eps, in_act = ctx.cfg
         n, h, w, cin = x.shape
         cout, _, k, _ = weight.shape
-        gy = _c(gy)
-        if act != ACT_NONE:   # (not the case in the networks here: the consumers are followed by a GroupNorm themselves)
-            gpre = torch.empty_like(gy)
-            lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
-        else:
-            gpre = gy
-        # gradient wrt the normalised tensor, then through the GroupNorm to the producer's (pre-activation) output
+        sums = (GN_SUMS & 4) and lib.fn('dis_get_conv_split')() == 1
+        # (this conv's own output gradient may be a token of the GroupNorm behind it: redeemed by the input-gradient launch below)
+        lz = _gn_lazy_pop(gy)
+        if lz is not None and not (sums and act == ACT_NONE and _gn_lazy_shape(cin, cout, k, 1, pad)):
+            gy, lz = _gn_lazy_materialize(lz), None
         gnorm = torch.empty_like(x)
-        gx = torch.empty_like(x)
+        slots = lib.fn('dis_conv2d_gnsums_slots')() if sums else 0
+        ab = _zeros_d(n * slots * 2 * cin, x.device) if sums else None
+        gpre = None
+        if lz is not None:
+            _, lg, lq, lcoef, lin_act = lz
+            gpre = torch.empty_like(lg)
+            if not lib.call_try('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, weight, cout, cin, weight.stride(0),
+                                gnorm, 0, x, None, ab, n, h, w, cin):
+                gy, gpre = _gn_lazy_materialize(lz), None
+        dgrad_done = gpre is not None
+        if not dgrad_done:
+            gy = _c(gy)
+            if act != ACT_NONE:   # (not the case in the networks here: the consumers are followed by a GroupNorm themselves)
+                gpre = torch.empty_like(gy)
+                lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
+            else:
+                gpre = gy
+        # gradient wrt the normalised tensor, then through the GroupNorm to the producer's (pre-activation) output
         gg, gg_ret = _sink(gamma)
         gbt, gbt_ret = _sink(ctx.beta_ref)
         hw = h * w
-        if (GN_SUMS & 4) and lib.fn('dis_get_conv_split')() == 1:
+        if sums:
             # the input-gradient launch leaves the per-(sample, channel) sums of g and g * x in its epilogue: the GroupNorm
-            # backward is then ONE elementwise pass (no reduce pass over g and x)
-            slots = lib.fn('dis_conv2d_gnsums_slots')()
-            ab = _zeros_d(n * slots * 2 * cin, x.device)
-            lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, weight, cout, cin, weight.stride(0), gnorm, x, ab, n, gpre.shape[1],
-                     gpre.shape[2], cout, cin, k - 1 - pad)
-            coef = torch.empty(n * (cin + 2) + 4 * n * cin + 2, dtype=torch.float32, device=x.device)
-            lib.call('dis_gn_bwd_from_sums', gnorm, x, gn_stats, gamma, ab, slots, gx, gg, gbt, coef, n, hw, cin, eps, in_act)
+            # backward is then ONE elementwise pass (no reduce pass over g and x) - applied by the producer's input-gradient
+            # launch on load when the producer redeems tokens (x_lazy), else a launch of its own
+            if not dgrad_done:
+                lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, weight, cout, cin, weight.stride(0), gnorm, x, ab, n, gpre.shape[1],
+                         gpre.shape[2], cout, cin, k - 1 - pad)
+            if ctx.x_lazy and GN_LAZY:
+                gx = _gn_lazy_defer(gnorm, x, gn_stats, gamma, ab, slots, gg, gbt, n, hw, cin, eps, in_act)
+            else:
+                gx = torch.empty_like(x)
+                coef = torch.empty(n * (cin + 2) + 4 * n * cin + 2, dtype=torch.float32, device=x.device)
+                lib.call('dis_gn_bwd_from_sums', gnorm, x, gn_stats, gamma, ab, slots, gx, gg, gbt, coef, n, hw, cin, eps, in_act)
         else:
+            gx = torch.empty_like(x)
             _conv_fwd_any(gpre, weight, cin, 1, None, gnorm, None, n, gpre.shape[1], gpre.shape[2], cout, cin, k, 1, k - 1 - pad,
                           ACT_NONE)
             wtot = lib.fn('dis_gn_bwd_workspace')(n, cin)
@@ -982,14 +1076,18 @@ class _Conv2dGnIn(torch.autograd.Function):
         lib.call('dis_conv2d_wgrad_bf16x3_gn', x, gn_stats, gamma, ctx.beta_ref, eps, gpre, gw, gb, wws, n, h, w, cin, cin, cout,
                  k, 1, pad)
         _sinks_written()
-        return gx, None, gg_ret, gbt_ret, gw_ret, gb_ret, None, None, None, None, None, None
+        return gx, None, gg_ret, gbt_ret, gw_ret, gb_ret, None, None, None, None, None, None, None
 
 
 def conv2d_gn_in(x, gn_stats, gamma, beta, weight, bias, pad=1, act=ACT_NONE, want_stats=False, gy_is_pre=False, eps=1e-5,
                  in_act=ACT_NONE):
     """conv2d(group_norm(x, gamma, beta, stats=gn_stats, in_act=in_act), weight, bias, 1, pad, act, ...) with the
     normalisation applied on load.  Returns (y, stats|None).  Shapes: see gn_fusable()."""
-    return _Conv2dGnIn.apply(x, gn_stats, gamma, beta, weight, bias, pad, act, want_stats, gy_is_pre, eps, in_act)
+    out = _Conv2dGnIn.apply(x, gn_stats, gamma, beta, weight, bias, pad, act, want_stats, gy_is_pre, eps, in_act,
+                            bool(getattr(x, '_gn_lazy_ok', False)))
+    if (act == ACT_NONE or gy_is_pre) and _gn_lazy_shape(x.shape[-1], weight.shape[0], weight.shape[2], 1, pad):
+        out[0]._gn_lazy_ok = True
+    return out
 
 
 class _Conv2dMulti(torch.autograd.Function):
@@ -1002,6 +1100,8 @@ class _Conv2dMulti(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, bias, pad, act, want_stats, gy_is_pre, gn_stats, gn_gamma, gn_beta, gn_meta, *xs):
+        ctx.x0_lazy = gn_meta is not None and len(gn_meta) > 2 and bool(gn_meta[2])
+        gn_meta = gn_meta[:2] if gn_meta is not None else None
         xs = [_c(x) for x in xs]
         weight = _c(weight)
         _chk(weight, bias, *xs)
@@ -1073,9 +1173,12 @@ class _Conv2dMulti(torch.autograd.Function):
                         ab = _zeros_d(n * slots * 2 * cs[0], x.device)
                         lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, wi, cout, cs[0], wi.stride(0), gnorm, x, ab, n,
                                  gpre.shape[1], gpre.shape[2], cout, cs[0], k - 1 - pad)
-                        coef = torch.empty(n * (cs[0] + 2) + 4 * n * cs[0] + 2, dtype=torch.float32, device=x.device)
-                        lib.call('dis_gn_bwd_from_sums', gnorm, x, gn_stats, gn_gamma, ab, slots, gx, gg, gbt, coef, n, h * w, cs[0],
-                                 float(eps), in_act)
+                        if ctx.x0_lazy and GN_LAZY:   # (the producer of xs[0] applies the elementwise pass on load: _GN_LAZY)
+                            gx = _gn_lazy_defer(gnorm, x, gn_stats, gn_gamma, ab, slots, gg, gbt, n, h * w, cs[0], float(eps), in_act)
+                        else:
+                            coef = torch.empty(n * (cs[0] + 2) + 4 * n * cs[0] + 2, dtype=torch.float32, device=x.device)
+                            lib.call('dis_gn_bwd_from_sums', gnorm, x, gn_stats, gn_gamma, ab, slots, gx, gg, gbt, coef, n, h * w,
+                                     cs[0], float(eps), in_act)
                     else:
                         _conv_fwd_any(gpre, wi, cs[0], 1, None, gnorm, None, n, gpre.shape[1], gpre.shape[2], cout, cs[0], k, 1,
                                       k - 1 - pad, ACT_NONE)
@@ -1114,7 +1217,8 @@ def conv2d_multi(xs, weight, bias, pad=0, act=ACT_NONE, want_stats=False, gy_is_
     """conv2d(cat(xs, channel dim), weight) without the cat.  Returns (y, stats|None).
     gn0 = (stats, gamma, beta, eps, in_act): xs[0] is the INPUT of a GroupNorm(1 group) that is applied on load (conv2d_gn_in)."""
     if gn0 is not None:
-        return _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, gn0[0], gn0[1], gn0[2], (gn0[3], gn0[4]), *xs)
+        return _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, gn0[0], gn0[1], gn0[2],
+                                  (gn0[3], gn0[4], bool(getattr(xs[0], '_gn_lazy_ok', False))), *xs)
     return _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, None, None, None, None, *xs)
 
 
@@ -1693,7 +1797,8 @@ class _WriteChannelsB(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------
 class _GroupNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, stats, gamma, beta, residual, act, eps, in_act=ACT_NONE, join=None):
+    def forward(ctx, x, stats, gamma, beta, residual, act, eps, in_act=ACT_NONE, join=None, x_lazy=False):
+        ctx.x_lazy = x_lazy   # the producer of x redeems a token for the elementwise backward pass (_GN_LAZY)
         x = _c(x)
         residual = _c(residual) if residual is not None else None
         _chk(x, gamma, beta, residual)
@@ -1716,23 +1821,30 @@ class _GroupNorm(torch.autograd.Function):
         x, stats, gamma, y = ctx.saved_tensors
         n, hw, c, act, eps, has_res, in_act = ctx.cfg
         gy = _c(gy)
-        gx = torch.empty_like(x)
         gg, gg_ret = _sink(gamma)
         gb, gb_ret = _sink(ctx.beta_ref)
         pre = _GN_PRE.pop(gy.data_ptr(), None)
         if pre is not None and not has_res and act == ACT_NONE:
             # (a plain GroupNorm output with two consumers: the consumer whose backward ran second left the sums of the complete g)
             ab, slots = pre
-            coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=x.device)
-            lib.call('dis_gn_bwd_from_sums', gy, x, stats, gamma, ab, slots, gx, gg, gb, coef, n, hw, c, eps, in_act)
+            if ctx.x_lazy and GN_LAZY:
+                gx = _gn_lazy_defer(gy, x, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, in_act)
+            else:
+                gx = torch.empty_like(x)
+                coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=x.device)
+                lib.call('dis_gn_bwd_from_sums', gy, x, stats, gamma, ab, slots, gx, gg, gb, coef, n, hw, c, eps, in_act)
             _sinks_written()
-            return gx, None, gg_ret, gb_ret, None, None, None, None, None
+            return gx, None, gg_ret, gb_ret, None, None, None, None, None, None
         if pre is not None and has_res and act == ACT_SELU and in_act == ACT_NONE:
             # gy already IS the gradient wrt the pre-activation value (the producing input-gradient launch multiplied by
             # SELU'(y) and left the channel sums): it doubles as the residual gradient, and one elementwise pass gives gx
             ab, slots = pre
-            coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=x.device)
-            lib.call('dis_gn_bwd_from_sums', gy, x, stats, gamma, ab, slots, gx, gg, gb, coef, n, hw, c, eps, ACT_NONE)
+            if ctx.x_lazy and GN_LAZY:
+                gx = _gn_lazy_defer(gy.view(x.shape), x, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, ACT_NONE)
+            else:
+                gx = torch.empty_like(x)
+                coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=x.device)
+                lib.call('dis_gn_bwd_from_sums', gy, x, stats, gamma, ab, slots, gx, gg, gb, coef, n, hw, c, eps, ACT_NONE)
             gres = gy.view(x.shape)
             if ctx.join is not None:
                 if ctx.join.buf is None:
@@ -1740,12 +1852,13 @@ class _GroupNorm(torch.autograd.Function):
                 else:
                     gres = ctx.join.take(gres.shape).add_(gres)
             _sinks_written()
-            return gx, None, gg_ret, gb_ret, gres, None, None, None, None
+            return gx, None, gg_ret, gb_ret, gres, None, None, None, None, None
         if pre is not None:
             # the producer has ALREADY turned gy into the pre-activation gradient and formed its channel sums: the generic
             # two-pass form below would apply act' a second time.  No networks here reach this; a new caller must not do so silently.
             raise RuntimeError(f'group_norm backward: channel sums were registered for this gradient but no from-sums form matches '
                                f'(residual={has_res}, act={act}, in_act={in_act})')
+        gx = torch.empty_like(x)
         gres = torch.empty_like(x) if has_res else None
         wtot = lib.fn('dis_gn_bwd_workspace')(n, c)
         ws = torch.empty(wtot, dtype=torch.float64, device=x.device)
@@ -1758,7 +1871,7 @@ class _GroupNorm(torch.autograd.Function):
             else:  # the other consumer ran first (not the case in the networks here): plain accumulation
                 gres = ctx.join.take(gres.shape).add_(gres)
         _sinks_written()
-        return gx, None, gg_ret, gb_ret, gres, None, None, None, None
+        return gx, None, gg_ret, gb_ret, gres, None, None, None, None, None
 
 
 def c_ok(x):
@@ -1769,7 +1882,7 @@ def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5
     """GroupNorm(1 group) over all but the first dim of an nhwc tensor; y = act(gn(x) (+ residual)).
     in_act: x is the output of that activation (conv2d(..., act, gy_is_pre=True)); the backward then returns the
     gradient wrt the producer's pre-activation output."""
-    y = _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act, join)
+    y = _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act, join, bool(getattr(x, '_gn_lazy_ok', False)))
     if residual is not None and act == ACT_SELU and in_act == ACT_NONE:
         y._gn_res_src = (x,)   # (a ResNetBlock that takes y as its input hands this to its first conv: conv2d(gnres=...))
     elif residual is None and act == ACT_NONE and c_ok(x):

@@ -325,6 +325,22 @@ int dis_conv2d_dgrad_bf16x3_act_gnsums_res(const float* gy, const float* y, cons
 int dis_gn_bwd_from_sums(const float* g, const float* x, const double* stats, const float* gamma, const double* ab, int slots,
                          float* gx, float* grad_gamma, float* grad_beta, float* coef, int n, long hw, int c, float eps,
                          int in_act, void* stream);
+/* Round 5: the two halves of dis_gn_bwd_from_sums as entry points of their own, and the input-gradient launch that applies the second
+ * half on load (csrc/norm_act.hip, csrc/conv2d.hip; reference backward of GroupNorm(1, C) in front of a 3x3 conv,
+ * model/multi_frame_networks.py:338-345, :514-542).
+ *   dis_gn_bwd_coef: ab (n, slots, 2, c) -> coef: (n, c + 2) floats [k1_c..., kx, k0] followed (8-byte aligned) by n * 2c doubles
+ *     (n * (c + 2) + 4 n c + 2 floats in all), grad_gamma / grad_beta (c); counter: one unsigned, ZERO on entry (zero again on exit).
+ *   dis_gn_bwd_apply_coef: gx = act'(x) (g k1_c + x kx + k0) - the elementwise pass alone.
+ *   dis_conv2d_dgrad_f16x2_gnb: gx (+)= conv_T(gpre, w) with gpre = act'(q) (g k1_c + q kx + k0) formed while g and q are staged,
+ *     gpre also stored to gpre_out for the weight-gradient launch; optional channel-sum epilogue as dis_conv2d_dgrad_bf16x3_gnsums /
+ *     _gnsums_res (ab_gn_x, ab_act_y, ab_out; all NULL: none).  3x3, stride 1, pad 1, c -> c, c in {16, 32}; two-term fp16 kernels only. */
+int dis_gn_bwd_coef(const double* stats, const float* gamma, const double* ab, int slots, float* coef, float* grad_gamma,
+                    float* grad_beta, unsigned* counter, int n, long hw, int c, float eps, void* stream);
+int dis_gn_bwd_apply_coef(const float* g, const float* x, const float* coef, float* gx, int n, long hw, int c, int in_act,
+                          void* stream);
+int dis_conv2d_dgrad_f16x2_gnb(const float* g, const float* q, const float* coef, int in_act, float* gpre_out, const float* w_oihw,
+                               int w_o, int w_i, int w_row_stride, float* gx, int accumulate, const float* ab_gn_x,
+                               const float* ab_act_y, double* ab_out, int n, int hin, int win, int c, void* stream);
 int dis_conv2d_wgrad_bf16x3_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta,
                                float gn_eps, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
                                int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,

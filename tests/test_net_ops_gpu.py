@@ -472,6 +472,83 @@ def test_gn_sums_epilogue_repeats_bitwise():
             assert all(torch.equal(a_, b_) for a_, b_ in zip(cur, first)), rep
 
 
+@pytest.mark.parametrize('c', [16, 32])
+@pytest.mark.parametrize('in_act', [0, 1])
+@pytest.mark.parametrize('form', ['plain', 'accum', 'sums', 'accum_sums', 'accum_sums_act'])
+@pytest.mark.parametrize('n,h,w', [(3, 37, 29), (4, 64, 48), (2, 16, 250)])
+def test_dgrad_with_group_norm_backward_on_load(c, in_act, form, n, h, w):
+    """dis_conv2d_dgrad_f16x2_gnb (round 5): the GroupNorm backward's elementwise pass applied while the input-gradient launch of the
+    conv in front of the GroupNorm stages its operand, against the two launches it replaces - dis_gn_bwd_apply_coef, then the plain /
+    accumulating / channel-sum input-gradient launch on the materialised tensor: the stored pre-activation gradient (every pixel
+    exactly once, ragged tiles and one-tile-high maps included), the input gradient and the channel sums of the epilogue forms must
+    all be BIT-identical (same arithmetic, same summation orders).  dis_gn_bwd_coef against dis_gn_bwd_from_sums likewise
+    (coefficients, grad_gamma, grad_beta).  Reference: GroupNorm(1, C) behind a conv, model/multi_frame_networks.py:338-345,514-542."""
+    from depthinspace_amd import ops
+    L = ops.lib
+    if L.fn('dis_get_conv_split')() != 1:
+        pytest.skip('two-term fp16 kernels only')
+    if form == 'accum_sums_act' and in_act == 0:
+        pytest.skip('the ResNetBlock-chain epilogue follows a SELU conv')
+    g_ = torch.Generator().manual_seed(7 * c + in_act + h)
+    q = torch.randn(n, h, w, c, generator=g_).cuda()
+    if in_act:
+        q = F.selu(q)
+    gq = torch.randn(n, h, w, c, generator=g_).cuda()           # gradient wrt the GroupNorm's output
+    wt = (torch.randn(c, c, 3, 3, generator=g_) * 0.05).cuda()
+    gamma = (torch.rand(c, generator=g_) + 0.5).cuda()
+    st = torch.stack([q.double().sum(dim=(1, 2, 3)), (q.double() ** 2).sum(dim=(1, 2, 3))], 1).reshape(-1).contiguous()
+    slots = L.fn('dis_conv2d_gnsums_slots')()
+    # the sums a producing launch would have left (any values do: one slot per sample carries them)
+    ab0 = torch.zeros(n, slots, 2, c, dtype=torch.float64, device='cuda')
+    ab0[:, 0, 0] = gq.double().sum(dim=(1, 2))
+    ab0[:, 0, 1] = (gq.double() * q.double()).sum(dim=(1, 2))
+    ncoef = n * (c + 2) + 4 * n * c + 2
+    # --- the old composition
+    gpre_ref = torch.empty_like(gq)
+    gg_ref, gb_ref = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+    coef_ref = torch.empty(ncoef, dtype=torch.float32, device='cuda')
+    L.call('dis_gn_bwd_from_sums', gq, q, st, gamma, ab0, slots, gpre_ref, gg_ref, gb_ref, coef_ref, n, h * w, c, 1e-5, in_act)
+    # --- the coefficient kernel alone
+    coef = torch.empty(ncoef, dtype=torch.float32, device='cuda')
+    gg, gb = torch.empty(c, device='cuda'), torch.empty(c, device='cuda')
+    counter = torch.zeros(2, dtype=torch.int32, device='cuda')
+    for _ in range(2):   # (the counter re-arms itself: a second launch on the same word)
+        L.call('dis_gn_bwd_coef', st, gamma, ab0, slots, coef, gg, gb, counter, n, h * w, c, 1e-5)
+    assert torch.equal(coef[:n * (c + 2)], coef_ref[:n * (c + 2)]) and torch.equal(gg, gg_ref) and torch.equal(gb, gb_ref)
+    assert int(counter[0]) == 0
+    gpre2 = torch.empty_like(gq)
+    L.call('dis_gn_bwd_apply_coef', gq, q, coef, gpre2, n, h * w, c, in_act)
+    assert torch.equal(gpre2, gpre_ref)
+    # --- input gradient of the materialised tensor, in the form under test
+    accum = form.startswith('accum')
+    sums = 'sums' in form
+    act_y = F.selu(torch.randn(n, h, w, c, generator=g_)).cuda() if form == 'accum_sums_act' else None
+    gn_x = torch.randn(n, h, w, c, generator=g_).cuda() if sums else None
+    base = torch.randn(n, h, w, c, generator=g_).cuda()
+    gx_ref = base.clone()
+    ab_ref = torch.zeros(n * slots * 2 * c, dtype=torch.float64, device='cuda') if sums else None
+    if form == 'plain' or form == 'accum':
+        L.call('dis_conv2d_fwd_bf16x3_oihw', gpre_ref, wt, 1, c, c, wt.stride(0), None, gx_ref, None, n, h, w, c, c, 3, 1, 1,
+               ops.CONV_ACCUM if accum else 0)
+    elif form == 'sums':
+        L.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre_ref, wt, c, c, wt.stride(0), gx_ref, gn_x, ab_ref, n, h, w, c, c, 1)
+    else:
+        L.call('dis_conv2d_dgrad_bf16x3_gnsums_res', gpre_ref, wt, c, c, wt.stride(0), gx_ref, act_y, gn_x, ab_ref, n, h, w, c, c, 1)
+    # --- the fused launch
+    gx = base.clone()
+    gpre = torch.full_like(gq, float('nan'))
+    ab = torch.zeros(n * slots * 2 * c, dtype=torch.float64, device='cuda') if sums else None
+    ok = L.call_try('dis_conv2d_dgrad_f16x2_gnb', gq, q, coef, in_act, gpre, wt, c, c, wt.stride(0), gx, 1 if accum else 0, gn_x,
+                    act_y, ab, n, h, w, c)
+    if not ok:
+        pytest.skip('no instance for this form in this build')
+    torch.cuda.synchronize()
+    assert torch.equal(gpre, gpre_ref), float((gpre - gpre_ref).abs().max())
+    assert torch.equal(gx, gx_ref), float((gx - gx_ref).abs().max())
+    if sums:
+        assert torch.equal(ab, ab_ref)
+
+
 @pytest.mark.parametrize('stride', [1, 2])
 def test_conv3d_class_ordered_backward(golden_dir, stride):
     """dis_conv3d_knn_bwd_det (the default backward: class-ordered plain read-modify-write, aggregate read back from the forward)
