@@ -87,12 +87,12 @@ class Worker(worker.Worker):
         for s, o in zip(itertools.count(), out):
             o = o.view(-1, *o.shape[2:])
             val, _ = self.ph_losses[0](o, im_lcn, std)
-            vals.append(val / (2 ** s))
+            vals.append((val, 1.0 / (2 ** s)))
         # smoothness
         amb0 = self.data['ambient0']
         amb0 = amb0.contiguous().view(-1, *amb0.shape[2:])
         o = out[0].view(-1, *out[0].shape[2:])
-        vals.append(self.disparity_loss(o, amb0) * 0.8)
+        vals.append((self.disparity_loss(o, amb0), 0.8))
         # geometric
         R, t, amb = self.data['R'], self.data['t'], self.data['ambient0']
         primary_disp = self.data['primary_disp']
@@ -111,14 +111,15 @@ class Worker(worker.Worker):
                               flow_out[f'flow_{tidx0}{tidx1}'], flow_out[f'flow_{tidx1}{tidx0}'], amb[tidx0],
                               amb[tidx1], primary_depth[tidx0], primary_depth[tidx1],
                               accs=(accs[tidx0], accs[tidx1]) if accs is not None else None)
-                vals.append(val * 0.2 / ge_num)
+                vals.append((val, 0.2 / ge_num))
         # warm-up terms
         if train:
             if self.current_epoch < 2:
-                vals.append(ops.l1_mean(out[0], self.data['primary_disp']) * 0.1)
+                vals.append((ops.l1_mean(out[0], self.data['primary_disp']), 0.1))
             if self.current_epoch < self.warmup_epochs and self.data_type == 'real':
-                vals.append(self.sgm_warmup_term(out[0]) * 0.1)
-        return vals
+                vals.append((self.sgm_warmup_term(out[0]), 0.1))
+        # (value, weight) pairs -> the weighted terms the reference returns, with their sum as one autograd node (ops.LossTerms)
+        return ops.weighted_terms(vals)
 
     def sgm_warmup_term(self, o, k=0):
         """reference :168-173 / single_frame_worker.py:158-163: masked L1 to the SGM disparities (valid where > 30) with

@@ -47,12 +47,12 @@ class Worker(multi_frame_worker.Worker):
         # (one launch for all scales: the census terms of the image are shared, networks.RectifiedPatternSimilarityLoss.forward_multi)
         ph = self.ph_losses[0].forward_multi([o.view(-1, *o.shape[2:]) for o in out], im_lcn, std)
         for s, val in zip(itertools.count(), ph):
-            vals.append(val / (2 ** s))
+            vals.append((val, 1.0 / (2 ** s)))
         # smoothness on scale 0
         amb0 = self.data['ambient0']
         amb0 = amb0.contiguous().view(-1, *amb0.shape[2:])
         o = out[0].view(-1, *out[0].shape[2:])
-        vals.append(self.disparity_loss(o, amb0) * 0.4)
+        vals.append((self.disparity_loss(o, amb0), 0.4))
         # geometric
         R, t, amb = self.data['R'], self.data['t'], self.data['ambient0']
         ge_num = self.track_length * (self.track_length - 1) / 2
@@ -68,12 +68,13 @@ class Worker(multi_frame_worker.Worker):
                                        flow_out[f'flow_{tidx0}{tidx1}'], flow_out[f'flow_{tidx1}{tidx0}'],
                                        amb[tidx0], amb[tidx1],
                                        accs=(accs[tidx0], accs[tidx1]) if accs is not None else None)
-                vals.append(val * 0.2 / ge_num)
+                vals.append((val, 0.2 / ge_num))
         # pseudo ground truth (DIS-FTSF)
         if self.use_pseudo_gt:
             for s, o in zip(itertools.count(), out):
-                vals.append(ops.l1_mean(o, self.data['pseudo_gt']) * (0.1 / (2 ** s)))
+                vals.append((ops.l1_mean(o, self.data['pseudo_gt']), 0.1 / (2 ** s)))
         if train and self.data_type == 'real' and self.current_epoch < self.warmup_epochs:
             for s, o in zip(itertools.count(), out):  # every scale, a fresh noise draw each (reference :158-163)
-                vals.append(self.sgm_warmup_term(o, s) * 0.1)
-        return vals
+                vals.append((self.sgm_warmup_term(o, s), 0.1))
+        # (value, weight) pairs -> the weighted terms the reference returns, with their sum as one autograd node (ops.LossTerms)
+        return ops.weighted_terms(vals)

@@ -310,7 +310,8 @@ class Worker(object):
             errs = errs['errs']
         if not isinstance(errs, (list, tuple)):
             errs = [errs]
-        sum(errs).backward()
+        tot = getattr(errs, 'total', None)   # (ops.LossTerms: the sum as one autograd node)
+        (tot if tot is not None else sum(errs)).backward()
         optimizer.step()
         return errs, output
 

@@ -554,6 +554,51 @@ def weighted_mean(x, w=None):
     return _WeightedMean.apply(x, w)
 
 
+class LossTerms(list):
+    """The weighted loss terms a worker's loss_forward returns (a list of device scalars, as the reference returns them) that also
+    carries `total`, their sum as ONE autograd node, and `weighted`, the same values as one vector."""
+    total = None
+    weighted = None
+
+
+_WVEC = {}
+
+
+class _WeightedTotal(torch.autograd.Function):
+    """total = sum_i w_i * val_i over a worker's loss terms in three launches (stack, multiply, sum) and one on the way back, instead
+    of two elementwise launches per term each way plus a chain of scalar additions (reference model/multi_frame_worker.py:103-175,
+    single_frame_worker.py:101-165: `val * 0.2 / ge_num`, `sum(errs)`): ~45 launches of 5 us per DIS-MF step."""
+
+    @staticmethod
+    def forward(ctx, wvec, *vals):
+        weighted = torch.stack([v.reshape(()) for v in vals]) * wvec
+        ctx.save_for_backward(wvec)
+        ctx.set_materialize_grads(False)
+        return weighted.sum(), weighted
+
+    @staticmethod
+    def backward(ctx, gtotal, gw):
+        # (gtotal: through `total`, the step's path; gw: through the individual terms, for a caller that sums them itself)
+        wvec, = ctx.saved_tensors
+        g = wvec * gtotal if gtotal is not None else None
+        if gw is not None:
+            g = wvec * gw if g is None else g + wvec * gw
+        return (None,) + tuple(g.unbind(0))
+
+
+def weighted_terms(pairs):
+    """pairs: [(unweighted loss value: device scalar, weight: python float)] -> LossTerms of the weighted values"""
+    ws = tuple(float(w) for _, w in pairs)
+    dev = pairs[0][0].device
+    wvec = _WVEC.get((ws, dev))
+    if wvec is None:   # (created by the first, eager step; a captured step finds it)
+        wvec = _WVEC[(ws, dev)] = torch.tensor(ws, dtype=torch.float32, device=dev)
+    total, weighted = _WeightedTotal.apply(wvec, *[v for v, _ in pairs])
+    out = LossTerms(weighted.unbind(0))
+    out.total, out.weighted = total, weighted
+    return out
+
+
 class _L1Mean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

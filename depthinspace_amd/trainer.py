@@ -309,8 +309,10 @@ class GraphedStep(object):
         if not isinstance(errs, (list, tuple)):
             errs = [errs]
         self.nterms = len(errs)
-        self.loss_buf[:len(errs)].copy_(torch.stack([e.detach() for e in errs]))
-        return sum(errs)
+        wv = getattr(errs, 'weighted', None)   # (ops.LossTerms: the terms as one vector, their sum as one autograd node)
+        self.loss_buf[:len(errs)].copy_(wv if wv is not None else torch.stack([e.detach() for e in errs]))
+        tot = getattr(errs, 'total', None)
+        return tot if tot is not None else sum(errs)
 
     def _eager(self):
         self._forward_loss().backward()
