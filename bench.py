@@ -37,6 +37,11 @@ PEAK_HBM_GBS = 8000.0           # same guide, HBM3E spec peak
 # path 1.03 GB / frame incl. Conv3D, 16 frames
 SURVEY_8D_STEP_BYTES = 3 * 5.65e9 * 4 + 1.03e9 * 16
 SURVEY_8D_STEP_BYTES_NOTE = 'SURVEY 8(d): convs 3 x 5.65 GB/sample x 4 samples = 67.8 GB + per-pixel path 1.03 GB/frame x 16 = 16.5 GB'
+# DIS-SF (config 2, bs = 8 -> 32 images): SURVEY 8(d) / BASELINE.md section 2: compulsory conv activation traffic 0.198 GB / image
+# forward in fp32 (half of it with bf16 activation storage), training = 3 x; per-pixel kernels 0.10 GB / frame (fp32 either way)
+SURVEY_8D_SF_STEP_BYTES = {'f32': 3 * 0.198e9 * 32 + 0.10e9 * 32, 'bf16': 3 * 0.099e9 * 32 + 0.10e9 * 32}
+SURVEY_8D_SF_STEP_BYTES_NOTE = ('SURVEY 8(d): convs 3 x 0.198 GB/image (fp32; 0.099 with bf16 activation storage) x 32 images + per-pixel '
+                                'kernels 0.10 GB/frame x 32')
 
 
 def make_args(bs, arch='multi_frame'):
@@ -148,6 +153,8 @@ def knn_tie_check(tap, hip_sets, ulps=16.0):
     return {'conv3d_rows': rows, 'rows_whose_set_differs': differ, 'non_tie_rows': non_tie,
             'largest_relative_key_gap_of_a_differing_row': worst, 'largest_gap_over_bound': worst_over_tol,
             'bound': f'2 sqrt(k9) d + d^2, d = {ulps:g} fp32 ulps of the largest plane coordinate',
+            # the smallest d (in ulps) under which every differing row still counts as a tie (the bound is ~linear in d)
+            'ulps_needed': ulps * worst_over_tol,
             'relative_gap_histogram_of_differing_rows': dict(zip(['<=1e-6', '<=1e-5', '<=1e-4', '<=1e-3', '<=1e-2', '>1e-2'], hist)),
             'by_resolution_rows_and_differing': per, 'geometries_checked': len(seen), 'pass': non_tie == 0}
 
@@ -206,7 +213,7 @@ def cpu_baseline(arch='multi_frame', timed_steps=3, knn_sets=None):
                       f'{timed_steps} timed steps (mean {dt:.1f} s), torch threads={want} of os.cpu_count()={os.cpu_count()}'}, first
 
 
-def hip_first_step(arch, settings, dev, dtype='f32'):
+def hip_first_step(arch, settings, dev, dtype='f32', scene='plane'):
     """The HIP path on cpu_baseline()'s inputs: bs=1, batch seed 1234, init_params(seed=0), epoch 2 - one forward + losses.
     Returns (disparity on the host, loss terms, Conv3D neighbour sets or None)."""
     from depthinspace_amd import synth
@@ -214,7 +221,7 @@ def hip_first_step(arch, settings, dev, dtype='f32'):
     from oracle import dis_oracle as O
     mf = arch == 'multi_frame'
     params = O.init_params(O.mf_param_shapes() if mf else O.sf_param_shapes(), seed=0)
-    batch = synth.make_batch(settings, 1, TL, seed=1234)
+    batch = synth.make_batch(settings, 1, TL, seed=1234, scene=scene)
     if mf:
         net = multi_frame_networks.FuseNet(imsize=(H, W), K=settings.K, baseline=settings.baseline, track_length=TL, max_disp=128)
         worker = multi_frame_worker.Worker(make_args(1), settings=settings, train_device=str(dev))
@@ -534,8 +541,8 @@ def main():
         if sel:
             ach = fl / tm / 1e12
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
-            if mf and os.path.exists(tpath):
+            tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json' if mf else f'roofline_traffic_sf_{args.dtype}.json')
+            if os.path.exists(tpath):
                 # HBM bytes per launch from the PMC passes (separate rocprofv3 runs, see profiles/README.md)
                 tj = json.load(open(tpath))
                 traffic, tsrc = tj['hbm_bytes_per_launch'], tj['source']
@@ -546,10 +553,11 @@ def main():
             frac_hbm = (ach_gbs / PEAK_HBM_GBS) if ach_gbs else None
             hbm_bound = frac_hbm is not None and frac_hbm >= frac_mfma
             step_traffic = None
-            if mf and os.path.exists(tpath) and tj.get('step_hbm_bytes'):
-                alg = SURVEY_8D_STEP_BYTES
+            if os.path.exists(tpath) and tj.get('step_hbm_bytes'):
+                alg = SURVEY_8D_STEP_BYTES if mf else SURVEY_8D_SF_STEP_BYTES[args.dtype]
                 step_traffic = {'pmc_bytes_per_step': tj['step_hbm_bytes'], 'algorithmic_bytes_per_step': alg,
-                                'algorithmic_note': SURVEY_8D_STEP_BYTES_NOTE, 'ratio': tj['step_hbm_bytes'] / alg,
+                                'algorithmic_note': SURVEY_8D_STEP_BYTES_NOTE if mf else SURVEY_8D_SF_STEP_BYTES_NOTE,
+                                'ratio': tj['step_hbm_bytes'] / alg,
                                 'source': tj['source'], 'ms_per_step_live': dt / args.steps * 1e3,
                                 'achieved_gbs': tj['step_hbm_bytes'] / (dt / args.steps) / 1e9,
                                 'frac_of_hbm_peak': tj['step_hbm_bytes'] / (dt / args.steps) / 1e9 / PEAK_HBM_GBS,
@@ -645,6 +653,34 @@ def main():
                            (free, 'free_running (tie check failed or unavailable)')
         else:
             chosen, kind = free, 'free_running'
+        if mf and args.dtype == 'f32':
+            # the same comparison, FREE-RUNNING and unconditional, on a scene without lattice symmetry (synth scene 'bumps': a
+            # non-planar surface - symmetric neighbours of a pixel are no longer equidistant, so the top-9-of-36 has no exact key
+            # ties for a host's BLAS to break either way): same seeds, same initial parameters, no forcing, no tie analysis
+            from depthinspace_amd import synth as _synth
+            from oracle import dis_oracle as O
+            hip_b, _, sets_b = hip_first_step(args.arch, settings, dev, args.dtype, scene='bumps')
+            ctx_b = O.StepContext(settings)
+            tb_b = {k: torch.from_numpy(v) for k, v in _synth.make_batch(settings, 1, TL, seed=1234, scene='bumps').items()}
+            nthr_b = torch.get_num_threads()
+            torch.set_num_threads(int(os.environ.get('DIS_CPU_BASELINE_THREADS', str(min(nthr_b, 32)))))
+            try:
+                O.CONV3D_TAP = []
+                with torch.no_grad():
+                    data_b = O.copy_data(ctx_b, tb_b)
+                    ref_b = O.mf_net_forward(ctx_b, O.init_params(O.mf_param_shapes(), seed=0), data_b,
+                                             O.read_optical_flow(data_b, TL)).detach().float()
+                tap_b, O.CONV3D_TAP = O.CONV3D_TAP, None
+            finally:
+                O.CONV3D_TAP = None
+                torch.set_num_threads(nthr_b)
+            d_b = (hip_b.reshape(-1) - ref_b.reshape(-1)).abs()
+            tc_b = knn_tie_check(tap_b, sets_b) if tap_b else None
+            l1_ref['bumps_free_running'] = {
+                'value': float(d_b.mean()), 'max': float(d_b.max()), 'pass': float(d_b.mean()) < bar,
+                'scene': "synth.make_batch(scene='bumps'): non-planar surface, batch seed 1234, init_params(seed=0), bs=1, 512x432",
+                'conv3d_rows_whose_set_differs': tc_b['rows_whose_set_differs'] if tc_b else None,
+                'conv3d_rows': tc_b['conv3d_rows'] if tc_b else None}
         l1_ref.update({'value': chosen['value'], 'max': chosen['max'], 'value_kind': kind, 'pass': chosen['value'] < bar,
                        'sample': 'bs=1 (one 4-frame track, batch seed 1234, init_params(seed=0)), 512x432: free-running HIP forward '
                                  'vs the CPU oracle of cpu_baseline on this host'})
@@ -687,6 +723,8 @@ def main():
                 extra_sf[tag] = {'metric': d['metric'], 'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'],
                                  'dtype': d['dtype'], 'roofline_frac': (d.get('roofline') or {}).get('frac'),
                                  'roofline_bound': (d.get('roofline') or {}).get('bound'),
+                                 'roofline_traffic': (d.get('roofline') or {}).get('traffic'),
+                                 'step_traffic': (d.get('roofline') or {}).get('step_traffic'),
                                  'command': 'python bench.py --arch single_frame' + (' --dtype bf16' if extra else '')}
     if rank == 0:
         frames = world * args.bs * TL * args.steps
