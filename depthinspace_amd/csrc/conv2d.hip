@@ -1305,7 +1305,7 @@ extern "C" int dis_conv2d_dgrad_bf16x3_act_gnsums_res(const float* gy, const flo
                                                       double* ab_out, int n, int hin, int win, int cin, int cout, int pad,
                                                       void* stream) {
   if (!y || !gn_x || !ab_out || !act_y) return DIS_ERR_NULL;
-  if (w_o != 16 || w_i != 32 || cin != w_o || cout != w_i) return DIS_ERR_UNSUPPORTED;
+  if (!((w_o == 16 && w_i == 32) || (w_o == 32 && w_i == 16)) || cin != w_o || cout != w_i) return DIS_ERR_UNSUPPORTED;
   if (w_row_stride == 0) w_row_stride = w_i * 9;
   if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
   GnIn gn;

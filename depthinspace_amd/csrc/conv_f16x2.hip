@@ -871,7 +871,9 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
     }
   }
   if (a.ab_out && inact) {  // ... of a conv that had an activation itself and whose INPUT was SELU(GroupNorm(.) + residual)
-    if constexpr (CIN == 16 && COUT == 32) {  // (final_conv behind ref_res3: reference model/multi_frame_networks.py:262-266)
+    // (final_conv 32 -> 16 behind ref_res3, reference model/multi_frame_networks.py:262-266, and - round 5 - the 16-channel slice of
+    //  ref_conv (48 -> 32) behind amb_res2, :248-256: gy has 32 channels, the gradient 16)
+    if constexpr ((CIN == 16 && COUT == 32) || (CIN == 32 && COUT == 16)) {
       if (ingn || selu || stats || a.accum || inact != DIS_ACT_SELU || !a.ab_x || !a.ab_act_y) return hipErrorInvalidValue;
       return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, DIS_ACT_SELU, false, true, DIS_ACT_SELU>, 16);
     } else {

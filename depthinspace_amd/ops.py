@@ -1147,6 +1147,9 @@ class _Conv2dMulti(torch.autograd.Function):
     def forward(ctx, weight, bias, pad, act, want_stats, gy_is_pre, gn_stats, gn_gamma, gn_beta, gn_meta, *xs):
         ctx.x0_lazy = gn_meta is not None and len(gn_meta) > 2 and bool(gn_meta[2])
         gn_meta = gn_meta[:2] if gn_meta is not None else None
+        # a source that is SELU(GroupNorm(x2) + residual) of a ResNetBlock and has no other consumer: its input-gradient launch
+        # leaves that GroupNorm's backward sums (as _Conv2d.backward does for final_conv)
+        ctx.gnres = [getattr(x, '_gn_res_src', None) if x.requires_grad else None for x in xs]
         xs = [_c(x) for x in xs]
         weight = _c(weight)
         _chk(weight, bias, *xs)
@@ -1232,6 +1235,13 @@ class _Conv2dMulti(torch.autograd.Function):
                         nred2 = wtot // (2 + 2 * cs[0]) * 2
                         lib.call('dis_gn_apply_bwd', gnorm, None, x, gn_stats, gn_gamma, gx, None, gg, gbt, wsd[:nred2], wsd[nred2:],
                                  n, h * w, cs[0], ACT_NONE, float(eps), in_act)
+                elif (fuse_act and act == ACT_SELU and ctx.gnres[i] is not None and (GN_SUMS & 1) and (cout, cs[i]) == (32, 16) and
+                      k == 3 and pad == 1 and tuple(ctx.gnres[i][0].shape) == tuple(x.shape) and lib.fn('dis_get_conv_split')() == 1):
+                    slots = lib.fn('dis_conv2d_gnsums_slots')()
+                    ab = _zeros_d(n * slots * 2 * cs[i], x.device)
+                    lib.call('dis_conv2d_dgrad_bf16x3_act_gnsums_res', gy, y, wi, cout, cs[i], wi.stride(0), gx, x, ctx.gnres[i][0], ab,
+                             n, gy.shape[1], gy.shape[2], cout, cs[i], k - 1 - pad)
+                    _GN_PRE[gx.data_ptr()] = (ab, slots)
                 elif fuse_act:
                     lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, wi, cout, cs[i], wi.stride(0), gx, n, gy.shape[1],
                              gy.shape[2], cout, cs[i], k - 1 - pad, 0)

@@ -318,7 +318,8 @@ int dis_conv2d_dgrad_bf16x3_gnsums_res(const float* gy, const float* w_oihw, int
                                        const float* act_y, const float* gn_x, double* ab_out, int n, int hin, int win, int cin,
                                        int cout, int pad, void* stream);
 /* ... and when the consumer of `out` is a conv with an activation of its own (final_conv, 32 -> 16 + SELU, :262-266):
- * g = conv_T(gy * selu'(y), w) * selu'(act_y), written; cin = 16 (gy / y channels), cout = 32. */
+ * g = conv_T(gy * selu'(y), w) * selu'(act_y), written; cin = 16 (gy / y channels), cout = 32 - or (round 5) cin = 32, cout = 16: the
+ * 16-channel slice w[:, 32:48] of ref_conv (48 -> 32 + SELU, :248-256) behind amb_res2, w_row_stride = 48 * 9. */
 int dis_conv2d_dgrad_bf16x3_act_gnsums_res(const float* gy, const float* y, const float* w_oihw, int w_o, int w_i,
                                            int w_row_stride, float* g, const float* act_y, const float* gn_x, double* ab_out,
                                            int n, int hin, int win, int cin, int cout, int pad, void* stream);

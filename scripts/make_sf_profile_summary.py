@@ -13,7 +13,7 @@ import csv, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONV_FAMILIES = ('convh2_kernel', 'convg2_fwd_kernel', 'convg_fwd_kernel', 'convg3_fwd_kernel', 'convb_halo_kernel', 'convb_fwd_kernel',
-                 'conv_f16x2_kernel', 'conv_bf16x3_kernel')
+                 'convb_fwd128_kernel', 'conv_f16x2_kernel', 'conv_bf16x3_kernel')
 
 
 def main(tag):
