@@ -96,6 +96,9 @@ CONV3X3_FORMS = {
     # (in_act, w_o, w_i, w_row_stride, accumulate, n, h, w, c): GroupNorm backward applied on load - the GroupNorm input read and the
     # pre-activation gradient written beside the operand (2 extra tensors on the input side); old gradient / GroupNorm input /
     # activation output of the epilogue forms on the output side (tensor arguments: 6, 8 with the channel sums, 9 with SELU')
+    # (w_o, w_i, w_row_stride, n, h, w, cin, cout, act): the previous ResNetBlock's output formed on load - its residual read and the
+    # output written beside the operand (2 extra tensors on the input side)
+    'dis_conv2d_fwd_f16x2_gnres': lambda ia, nptr: _f(ia[3:6], 1, 2, 0),
     'dis_conv2d_dgrad_f16x2_gnb': lambda ia, nptr: _f(ia[5:8], 1, 2, (1 if ia[4] else 0) + (1 if nptr >= 8 else 0) + (1 if nptr >= 9 else 0)),
 }
 

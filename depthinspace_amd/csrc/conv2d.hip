@@ -1196,8 +1196,11 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
   if ((gn.ab_out || gn.gnb_coef) && !(dis_f2_enabled() && wmode >= 0)) return DIS_ERR_UNSUPPORTED;  // (the two-term kernel's forms)
   if (gn.gnb_coef && (!gn.gnb_out || !xact || pad != 1 || cin != cout)) return DIS_ERR_UNSUPPORTED;
   if (gn.stats && (!gn.gamma || !gn.beta)) return DIS_ERR_NULL;
-  if (gn.stats && (cin != cout || inact || (act & DIS_CONV_ACCUM) || ((act & 0xff) != DIS_ACT_NONE && (act & 0xff) != DIS_ACT_SELU)))
+  const bool inres = gn.stats && gn.gnb_out && !gn.gnb_coef;   // SELU(GroupNorm(x) + xact) formed on load, stored to gnb_out
+  if (gn.stats && ((cin != cout && !(inres && cin == 32 && cout == 16)) || inact || (act & DIS_CONV_ACCUM) ||
+                   ((act & 0xff) != DIS_ACT_NONE && (act & 0xff) != DIS_ACT_SELU)))
     return DIS_ERR_UNSUPPORTED;
+  if (inres && (!xact || pad != 1 || !(dis_f2_enabled() && wmode >= 0))) return DIS_ERR_UNSUPPORTED;
   if (inact < 0 || inact > DIS_ACT_RELU || (inact && !xact)) return DIS_ERR_UNSUPPORTED;
   if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
   // the kernel addresses x and y per sample through buffer descriptors with 31-bit byte offsets
@@ -1220,7 +1223,7 @@ static int launch_conv_bf16x3(const float* x, const void* w, int wmode, int w_o,
     }
     if (le != hipErrorInvalidValue) return (int)le;
   }
-  if (gn.ab_out || gn.gnb_coef) return DIS_ERR_UNSUPPORTED;
+  if (gn.ab_out || gn.gnb_coef || inres) return DIS_ERR_UNSUPPORTED;
   if (cin == 32 && cout == 32) le = bx_launch<32, 32>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
   else if (cin == 16 && cout == 16) le = bx_launch<16, 16>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
   else if (cin == 16 && cout == 32) le = bx_launch<16, 32>(a, stats != nullptr, inact, grid, (hipStream_t)stream);
@@ -1264,6 +1267,28 @@ extern "C" int dis_conv2d_fwd_bf16x3_gn(const float* x, const double* gn_stats, 
   gn.stats = gn_stats; gn.gamma = gn_gamma; gn.beta = gn_beta; gn.eps = gn_eps;
   return launch_conv_bf16x3(x, w_oihw, 0, w_o, w_i, w_row_stride, bias, y, stats, n, hin, win, cin, cout, k, stride, pad, act,
                             stream, nullptr, 0, gn);
+}
+/* y = act(conv3x3(out) + bias) with out = SELU(GroupNorm(x2) + res) - the output of a ResNetBlock (reference
+ * model/multi_frame_networks.py:514-542) - FORMED ON LOAD from x2 (the block's second conv output), its statistics gn_stats (n, 2) and
+ * the block's residual `res`, with the arithmetic of dis_gn_apply(act = SELU, residual) bit for bit; the conv's tiles also store the
+ * values of the pixels they own to `out` (shaped like x2): the pass dis_gn_apply would have made over x2, res and out does not exist,
+ * and every later reader of `out` (the next block's residual, the backward passes) finds it in memory.  3x3, stride 1, pad 1,
+ * cin == cout in {16, 32} (act SELU, with or without output statistics) or 32 -> 16 (act SELU, no statistics); two-term fp16 kernels
+ * only (DIS_ERR_UNSUPPORTED otherwise: the caller runs dis_gn_apply and the plain forward). */
+extern "C" int dis_conv2d_fwd_f16x2_gnres(const float* x2, const double* gn_stats, const float* gn_gamma, const float* gn_beta,
+                                          float gn_eps, const float* res, float* out, const float* w_oihw, int w_o, int w_i,
+                                          int w_row_stride, const float* bias, float* y, double* stats, int n, int hin, int win,
+                                          int cin, int cout, int act, void* stream) {
+  if (!gn_stats || !gn_gamma || !gn_beta || !res || !out) return DIS_ERR_NULL;
+  if (w_o <= 0 || w_i <= 0 || w_o > 32 || w_i > 32 || cout != w_o || cin != w_i) return DIS_ERR_BAD_SHAPE;
+  if (act != DIS_ACT_SELU) return DIS_ERR_UNSUPPORTED;
+  if (w_row_stride == 0) w_row_stride = w_i * 9;
+  if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
+  GnIn gn;
+  gn.stats = gn_stats; gn.gamma = gn_gamma; gn.beta = gn_beta; gn.eps = gn_eps;
+  gn.gnb_out = out;
+  return launch_conv_bf16x3(x2, w_oihw, 0, w_o, w_i, w_row_stride, bias, y, stats, n, hin, win, cin, cout, 3, 1, 1, act, stream, res,
+                            0, gn);
 }
 /* Input gradient of the conv of dis_conv2d_fwd_bf16x3_gn, g = conv_T(gy, w), which ALSO leaves what the GroupNorm backward needs
  * besides g: per (sample, channel) the sums of g and of g * x over the pixels (x = gn_x, the GroupNorm's input, shaped like g),

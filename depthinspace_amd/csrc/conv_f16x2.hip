@@ -24,6 +24,9 @@
 #ifndef F2_VALU_PER_GAP
 #define F2_VALU_PER_GAP 6
 #endif
+#ifndef F2_PF2_INRES
+#define F2_PF2_INRES 0
+#endif
 #ifndef F2_PF2
 #define F2_PF2 1   // two register sets of halo items where the registers allow it (see PF2 in conv_f16x2_kernel)
 #endif
@@ -140,12 +143,16 @@ extern "C" int dis_debug_f2_clk(unsigned long long* host) { return (int)hipMemcp
 // are not stored), a.nbias bias entries exist; ACT may be ReLU.
 // INCOEF: x is staged as act'(xact) * (x * k1_c + xact * kx + k0), the elementwise pass of a GroupNorm backward (ConvArgs::gnb_coef),
 // and the staged values of the pixels a tile owns are stored to gnb_out (INACT: the activation between this conv and the GroupNorm).
+// INRES (with INGN): x is staged as SELU(GroupNorm(x) + xact) - the output of a ResNetBlock, formed on load (the arithmetic of
+// gn_apply_kernel, bit for bit) - and the staged values of the pixels a tile owns are stored to gnb_out: the block's output tensor
+// is written by the conv that consumes it first instead of by a pass of its own (ConvArgs::gnb_out).
 template <int CIN, int COUT, int ACT, bool ACCUM, bool STATS, int INACT = 0, bool INGN = false, bool EPIAB = false, int EPIACT = 0,
-          bool GEN = false, bool INCOEF = false>
+          bool GEN = false, bool INCOEF = false, bool INRES = false>
 __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   using C = F2Cfg<CIN, COUT>;
   static_assert(!INCOEF || (!GEN && !INGN && !STATS && ACT == DIS_ACT_NONE && CIN == COUT), "GroupNorm backward on load: input-gradient instances");
-  constexpr bool IN2 = INACT != 0 || INCOEF;   // a second operand rides with every halo item
+  static_assert(!INRES || (INGN && !GEN && !INCOEF && INACT == 0 && !ACCUM && !EPIAB), "residual GroupNorm output on load: forward instances");
+  constexpr bool IN2 = INACT != 0 || INCOEF || INRES;   // a second operand rides with every halo item
   static_assert(!GEN || (!STATS && INACT == 0 && !INGN && !EPIAB && CIN == 32 && COUT == 32), "slice form: plain convolution / input gradient");
   const int ldx = GEN ? a.ldx : CIN, ldy = GEN ? a.ldy : COUT;  // floats per pixel
   static_assert(!EPIAB || (!STATS && ACT == DIS_ACT_NONE && 2 * COUT <= 64), "channel sums: plain input-gradient instances");
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
   // a tile period ahead of their use while HBM answers in 2 - 3 us at 4 - 5 TB/s of traffic, > 1 us of every tile exposed.
   // Instances that already sit at the register limit of two waves per SIMD (the channel-sum epilogues, the fused activation
   // gradient's second operand) keep one set.
-  constexpr bool PF2 = F2_PF2 && !EPIAB;
+  constexpr bool PF2 = F2_PF2 && !EPIAB && !(INRES && CIN == 32 && !F2_PF2_INRES);   // (32-channel INRES + two sets of two operands: spills)
   constexpr int PFD = PF2 ? 2 : 1;   // tiles between the tile whose items are prepared / staged and the tile whose loads are issued
   float4 pre[NLOAD], preB[NLOAD], pre2[IN2 ? NLOAD : 1], pre2B[IN2 ? NLOAD : 1];   // (preB / pre2B: PF2 only)
   int it_rc[NLOAD], it_off[NLOAD];
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
     const int vv = idx % CV, pix = idx / CV;
     const int r = pix / IC, c = pix % IC;
     (void)r;
-    if (INCOEF && idx < C::NITEMS && r >= 1 && r <= F2_TR && c >= 1 && c <= F2_TC) it_own |= 1u << it;
+    if ((INCOEF || INRES) && idx < C::NITEMS && r >= 1 && r <= F2_TR && c >= 1 && c <= F2_TC) it_own |= 1u << it;
     // (halo column; items past the end of the halo - and, GEN, channels the slice does not have - are never in range: zeros)
     it_rc[it] = (idx < C::NITEMS && (!GEN || vv * 4 < a.cx)) ? c : 0x40000000;
     it_off[it] = ((r * a.win + c) * ldx + vv * 4) * 4;
@@ -281,6 +288,15 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
         const f32x2 lo = (f32x2){v.x, v.y} * (f32x2){gn_sc.x, gn_sc.y} + sh_lo;
         const f32x2 hi = (f32x2){v.z, v.w} * (f32x2){gn_sc.z, gn_sc.w} + sh_hi;
         v = make_float4(lo[0], lo[1], hi[0], hi[1]);
+        if (INRES) {   // + residual, SELU (padding: 0 * sc + 0 + 0 -> SELU(0) = 0 exactly), and the block output's owner stores it
+          const float4 q = Q[it];
+          v = make_float4(act_apply(v.x + q.x, DIS_ACT_SELU), act_apply(v.y + q.y, DIS_ACT_SELU), act_apply(v.z + q.z, DIS_ACT_SELU),
+                          act_apply(v.w + q.w, DIS_ACT_SELU));
+          const int ixs = f.ix0 + it_rc[it];
+          const unsigned offs = (unsigned)ixs < (unsigned)a.win ? (unsigned)(f.off0 + it_off[it]) : BX_OOB;
+          const u32x4 sv = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+          __builtin_amdgcn_raw_buffer_store_b128(sv, bx_rsrc(a.gnb_out + (f.x - a.x), f.bytes), ((it_own >> it) & 1u) ? offs : BX_OOB, 0, 0);
+        }
       }
       if (INCOEF) {   // (the arithmetic of gn_apply_coef_kernel, bit for bit; padding: g = q = 0 loads give k0, which must not be staged)
         const float4 q = Q[it];
@@ -890,6 +906,20 @@ static hipError_t f2_launch(const ConvArgs& a, bool stats, int inact, long grid,
       if (a.accum)  // accumulating form without an activation behind the GroupNorm (a GroupNorm output with two consumers)
         return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, true, false, 0, false, true, 0>, 17);
       return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_NONE, false, false, 0, false, true>, 10);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
+  if (ingn && a.gnb_out) {  // the residual form: x = SELU(GroupNorm(x2) + res), formed on load and stored by its owner tiles (INRES)
+    if (inact || a.accum || !a.xact) return hipErrorInvalidValue;
+    if constexpr (CIN == COUT) {
+      if (selu)
+        return stats ? launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_SELU, false, true, 0, true, false, 0, false, false, true>, 26)
+                     : launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_SELU, false, false, 0, true, false, 0, false, false, true>, 27);
+      return hipErrorInvalidValue;
+    } else if constexpr (CIN == 32 && COUT == 16) {   // (final_conv behind ref_res3)
+      if (selu && !stats) return launch(conv_f16x2_kernel<CIN, COUT, DIS_ACT_SELU, false, false, 0, true, false, 0, false, false, true>, 28);
+      return hipErrorInvalidValue;
     } else {
       return hipErrorInvalidValue;
     }

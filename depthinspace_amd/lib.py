@@ -67,6 +67,7 @@ SIGS = {
     'dis_conv2d_dgrad_bf16x3_gnsums_res': 'ppiiippppiiiiiip',
     'dis_conv2d_dgrad_bf16x3_act_gnsums_res': 'pppiiippppiiiiiip',
     'dis_gn_bwd_from_sums': 'pppppippppilifip',
+    'dis_conv2d_fwd_f16x2_gnres': 'ppppfpppiiipppiiiiiip',
     'dis_gn_bwd_coef': 'pppippppilifp',
     'dis_gn_bwd_apply_coef': 'ppppiliip',
     'dis_conv2d_dgrad_f16x2_gnb': 'pppippiiipippp' + 'iiiip',

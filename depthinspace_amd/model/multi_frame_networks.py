@@ -88,7 +88,9 @@ class ResNetBlock(torch.nn.Module):
         self.conv2 = ConvParams(planes, planes, 3)
         self.bn2 = NormParams(planes)
 
-    def forward(self, x):
+    def forward(self, x, defer_out=False):
+        """defer_out: the caller hands the result STRAIGHT to a 3x3 conv (the next ResNetBlock, final_conv): that conv writes the
+        block's output while it loads it (ops.group_norm(defer=True)); x may itself be such an unwritten output."""
         j = ops.GradJoin() if x.requires_grad else None  # x feeds conv1 and the residual: one shared gradient buffer
         # (x may be the previous ResNetBlock's SELU(GroupNorm(.) + residual): conv1's input-gradient launch then also serves
         # that GroupNorm's backward, ops._Conv2d.backward)
@@ -101,7 +103,7 @@ class ResNetBlock(torch.nn.Module):
         else:
             o = ops.group_norm(o, self.bn1.weight, self.bn1.bias, stats=st, in_act=SELU)
             o, st = ops.conv2d(o, self.conv2.weight, self.conv2.bias, 1, 1, NONE, want_stats=True)
-        return ops.group_norm(o, self.bn2.weight, self.bn2.bias, stats=st, residual=x, act=SELU, join=j)
+        return ops.group_norm(o, self.bn2.weight, self.bn2.bias, stats=st, residual=x, act=SELU, join=j, defer=defer_out)
 
 
 class Conv3D(TimedModule):
@@ -261,16 +263,16 @@ class FuseNet(TimedModule):
         x = c(x, self.conv2, 1, 1)
         x = c(x, self.conv3, 1, 1)
         x = c(x, self.conv4, 1, 1)
-        return self.res3(self.res2(self.res1(x)))
+        return self.res3(self.res2(self.res1(x, defer_out=True), defer_out=True))
 
     def post_process(self, feat, amb4):
         """reference :229-267; feat (N,h,w,C) nhwc, amb4 (N,H,W,4) = ambient + zero channels"""
         H, W = self.im_height, self.im_width
         a = ops.conv2d(amb4, self.amb_conv[1].weight, self.amb_conv[1].bias, 1, 1, SELU, need_dgrad=False)[0]
-        a = self.amb_res2(self.amb_res1(a))
+        a = self.amb_res2(self.amb_res1(a, defer_out=True))
         up = ops.resize_nhwc(feat, (H, W), True)
         x = ops.conv2d_multi((up, a), self.ref_conv[1].weight, self.ref_conv[1].bias, 1, SELU)[0]
-        x = self.ref_res3(self.ref_res2(self.ref_res1(x)))
+        x = self.ref_res3(self.ref_res2(self.ref_res1(x, defer_out=True), defer_out=True), defer_out=True)
         # (x = ref_res3's SELU(GroupNorm(.) + residual) and final_conv is its only consumer: gnres, see ResNetBlock.forward)
         x = ops.conv2d(x, self.final_conv[1].weight, self.final_conv[1].bias, 1, 1, SELU,
                        gnres=getattr(x, '_gn_res_src', None) if x.requires_grad else None)[0]

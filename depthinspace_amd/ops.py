@@ -50,6 +50,26 @@ _GN_LAZY = {}
 GN_LAZY = _os_env.environ.get('DIS_GN_LAZY', '1') != '0'
 
 
+# Forward twin of the tokens (round 5, dis_conv2d_fwd_f16x2_gnres): group_norm(..., residual, act=SELU, defer=True) does NOT run its
+# elementwise pass; the output tensor exists but is unwritten, `_pending_gn` = (x2, stats, gamma, beta, residual, eps) hangs on it, and
+# the 3x3 conv that consumes it first - conv2d() looks for the attribute - forms the values on load and stores them as a side
+# output.  Every other reader must come after that conv (a ResNetBlock's own residual use does) or call realize() first;
+# begin_step() raises if an output was never written.
+_GN_PENDING = {}
+
+
+def realize(t):
+    """run the deferred GroupNorm pass of `t` now (a consumer without an on-load form)"""
+    pend = getattr(t, '_pending_gn', None)
+    if pend is not None:
+        x2, stats, gamma, beta, res, eps = pend
+        n, c = x2.shape[0], x2.shape[-1]
+        lib.call('dis_gn_apply', x2, stats, gamma, beta, res, t, n, x2.numel() // (n * c), c, ACT_SELU, float(eps))
+        t._pending_gn = None
+        _GN_PENDING.pop(t.data_ptr(), None)
+    return t
+
+
 def _gn_lazy_defer(g, q, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, in_act):
     coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=g.device)
     lib.call('dis_gn_bwd_coef', stats, gamma, ab, slots, coef, gg, gb, _zeros_d(1, g.device), n, hw, c, eps)
@@ -79,6 +99,9 @@ def begin_step(dev):
     if _GN_PRE:   # a gradient that was handed on pre-multiplied was never picked up by its GroupNorm: the step would be wrong
         _GN_PRE.clear()
         raise RuntimeError('ops: a pre-reduced GroupNorm gradient of the previous backward pass was not consumed')
+    if _GN_PENDING:  # a deferred GroupNorm output was never written
+        _GN_PENDING.clear()
+        raise RuntimeError('ops: a deferred GroupNorm output (group_norm(defer=True)) of the previous forward pass was never realised')
     if _GN_LAZY:  # a token stood in for a gradient and nobody redeemed it (the conv output had a second consumer?)
         _GN_LAZY.clear()
         raise RuntimeError('ops: a deferred GroupNorm backward (token gradient) of the previous backward pass was not redeemed')
@@ -879,7 +902,7 @@ def _bx_shape(cin, cout, k, stride):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre=False, join=None, gnres=None):
+    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre=False, join=None, gnres=None, pend=None):
         x, weight = _c(x), _c(weight)
         _chk(x, weight, bias)
         ctx.gnres = gnres
@@ -889,7 +912,19 @@ class _Conv2d(torch.autograd.Function):
         wo = (win + 2 * pad - k) // stride + 1
         y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
         stats = _zeros_d(2 * n, x.device) if want_stats else None
-        _conv_fwd_any(x, weight, cin_pad, 0, bias, y, stats, n, hin, win, cin_pad, cout, k, stride, pad, act)
+        if pend is not None:
+            # x = SELU(GroupNorm(x2) + res) has not been written yet: this launch forms it on load and stores it (conv2d() checked
+            # the shape; an unsupported mode falls back to the pass of its own)
+            x2, gst, gam, bet, res, eps = pend
+            if lib.call_try('dis_conv2d_fwd_f16x2_gnres', x2, gst, gam, bet, float(eps), res, x, weight, cout, cin, weight.stride(0),
+                            bias, y, stats, n, hin, win, cin_pad, cout, act):
+                _GN_PENDING.pop(x.data_ptr(), None)
+            else:
+                lib.call('dis_gn_apply', x2, gst, gam, bet, res, x, n, hin * win, cin_pad, ACT_SELU, float(eps))
+                _GN_PENDING.pop(x.data_ptr(), None)
+                _conv_fwd_any(x, weight, cin_pad, 0, bias, y, stats, n, hin, win, cin_pad, cout, k, stride, pad, act)
+        else:
+            _conv_fwd_any(x, weight, cin_pad, 0, bias, y, stats, n, hin, win, cin_pad, cout, k, stride, pad, act)
         if gy_is_pre:
             act = ACT_NONE  # the consumer (group_norm(in_act=...)) hands back the pre-activation gradient
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
@@ -937,7 +972,7 @@ class _Conv2d(torch.autograd.Function):
                 ws = torch.empty(lib.fn('dis_conv2d_wgrad_workspace')(cin_pad, cout, k, stride), dtype=torch.float32, device=x.device)
                 _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
                 _sinks_written()
-                return gx, gw_ret, gb_ret, None, None, None, None, None, None, None, None
+                return gx, gw_ret, gb_ret, None, None, None, None, None, None, None, None, None
             # (no instance for this combination in this build: the separate pass, then the general path below)
             if second:
                 join.buf = gx   # (hand the joined buffer back: the general path takes it again)
@@ -1001,7 +1036,7 @@ class _Conv2d(torch.autograd.Function):
         else:
             _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
         _sinks_written()
-        return gx, gw_ret, gb_ret, None, None, None, None, None, None, None, None
+        return gx, gw_ret, gb_ret, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, need_dgrad=True, gy_is_pre=False,
@@ -1010,7 +1045,16 @@ def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, nee
     gy_is_pre: the only consumer of y is group_norm(..., in_act=act), whose backward already multiplies by act'(y);
     the incoming gradient is then taken as the pre-activation gradient.
     join: GradJoin shared with the other consumer of x (see GradJoin)."""
-    out = _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre, join, gnres)
+    pend = getattr(x, '_pending_gn', None)
+    if pend is not None:
+        cout_, cin_, k_, _ = weight.shape
+        if not (k_ == 3 and stride == 1 and pad == 1 and act == ACT_SELU and x.shape[-1] == cin_ and BF16X3 and
+                ((cin_ == cout_ and cin_ in (16, 32)) or ((cin_, cout_) == (32, 16) and not want_stats))):
+            realize(x)
+            pend = None
+        else:
+            x._pending_gn = None   # (written by the launch below)
+    out = _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre, join, gnres, pend)
     if (act == ACT_NONE or gy_is_pre) and need_dgrad and _gn_lazy_shape(x.shape[-1], weight.shape[0], weight.shape[2], stride, pad):
         out[0]._gn_lazy_ok = True   # (a GroupNorm that is this output's ONLY consumer may answer with a token, see _GN_LAZY)
     return out
@@ -1852,7 +1896,7 @@ class _WriteChannelsB(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------
 class _GroupNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, stats, gamma, beta, residual, act, eps, in_act=ACT_NONE, join=None, x_lazy=False):
+    def forward(ctx, x, stats, gamma, beta, residual, act, eps, in_act=ACT_NONE, join=None, x_lazy=False, defer=False):
         ctx.x_lazy = x_lazy   # the producer of x redeems a token for the elementwise backward pass (_GN_LAZY)
         x = _c(x)
         residual = _c(residual) if residual is not None else None
@@ -1864,7 +1908,8 @@ class _GroupNorm(torch.autograd.Function):
             stats = _zeros_d(2 * n, x.device)
             lib.call('dis_gn_stats', x, stats, n, hw * c)
         y = torch.empty_like(x)
-        lib.call('dis_gn_apply', x, stats, gamma, beta, residual, y, n, hw, c, act, float(eps))
+        if not defer:   # (defer: the 3x3 conv that consumes y first writes it, see _GN_PENDING)
+            lib.call('dis_gn_apply', x, stats, gamma, beta, residual, y, n, hw, c, act, float(eps))
         ctx.save_for_backward(x, stats, gamma, y if act != ACT_NONE else None)
         ctx.cfg = (n, hw, c, act, float(eps), residual is not None, in_act)
         ctx.beta_ref = beta
@@ -1889,7 +1934,7 @@ class _GroupNorm(torch.autograd.Function):
                 coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=x.device)
                 lib.call('dis_gn_bwd_from_sums', gy, x, stats, gamma, ab, slots, gx, gg, gb, coef, n, hw, c, eps, in_act)
             _sinks_written()
-            return gx, None, gg_ret, gb_ret, None, None, None, None, None, None
+            return gx, None, gg_ret, gb_ret, None, None, None, None, None, None, None
         if pre is not None and has_res and act == ACT_SELU and in_act == ACT_NONE:
             # gy already IS the gradient wrt the pre-activation value (the producing input-gradient launch multiplied by
             # SELU'(y) and left the channel sums): it doubles as the residual gradient, and one elementwise pass gives gx
@@ -1907,7 +1952,7 @@ class _GroupNorm(torch.autograd.Function):
                 else:
                     gres = ctx.join.take(gres.shape).add_(gres)
             _sinks_written()
-            return gx, None, gg_ret, gb_ret, gres, None, None, None, None, None
+            return gx, None, gg_ret, gb_ret, gres, None, None, None, None, None, None
         if pre is not None:
             # the producer has ALREADY turned gy into the pre-activation gradient and formed its channel sums: the generic
             # two-pass form below would apply act' a second time.  No networks here reach this; a new caller must not do so silently.
@@ -1926,18 +1971,28 @@ class _GroupNorm(torch.autograd.Function):
             else:  # the other consumer ran first (not the case in the networks here): plain accumulation
                 gres = ctx.join.take(gres.shape).add_(gres)
         _sinks_written()
-        return gx, None, gg_ret, gb_ret, gres, None, None, None, None, None
+        return gx, None, gg_ret, gb_ret, gres, None, None, None, None, None, None
 
 
 def c_ok(x):
     return x.shape[-1] in (16, 32)
 
 
-def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5, in_act=ACT_NONE, join=None):
+GN_DEFER = _os.environ.get('DIS_GN_DEFER', '1') != '0'
+
+
+def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5, in_act=ACT_NONE, join=None, defer=False):
     """GroupNorm(1 group) over all but the first dim of an nhwc tensor; y = act(gn(x) (+ residual)).
     in_act: x is the output of that activation (conv2d(..., act, gy_is_pre=True)); the backward then returns the
-    gradient wrt the producer's pre-activation output."""
-    y = _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act, join, bool(getattr(x, '_gn_lazy_ok', False)))
+    gradient wrt the producer's pre-activation output.
+    defer (residual + SELU form with known statistics only): y is NOT written here; the caller guarantees that its first reader is
+    conv2d(y, ...) - which forms the values on load and stores them - or calls ops.realize(y) (see _GN_PENDING)."""
+    defer = bool(defer and GN_DEFER and residual is not None and act == ACT_SELU and in_act == ACT_NONE and stats is not None and
+                 x.dim() == 4 and c_ok(x) and BF16X3)
+    y = _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act, join, bool(getattr(x, '_gn_lazy_ok', False)), defer)
+    if defer:
+        y._pending_gn = (_c(x), stats, gamma, beta, _c(residual), float(eps))
+        _GN_PENDING[y.data_ptr()] = True
     if residual is not None and act == ACT_SELU and in_act == ACT_NONE:
         y._gn_res_src = (x,)   # (a ResNetBlock that takes y as its input hands this to its first conv: conv2d(gnres=...))
     elif residual is None and act == ACT_NONE and c_ok(x):

@@ -310,7 +310,7 @@ class GraphedStep(object):
             errs = [errs]
         self.nterms = len(errs)
         wv = getattr(errs, 'weighted', None)   # (ops.LossTerms: the terms as one vector, their sum as one autograd node)
-        self.loss_buf[:len(errs)].copy_(wv if wv is not None else torch.stack([e.detach() for e in errs]))
+        self.loss_buf[:len(errs)].copy_(wv.detach() if wv is not None else torch.stack([e.detach() for e in errs]))
         tot = getattr(errs, 'total', None)
         return tot if tot is not None else sum(errs)
 

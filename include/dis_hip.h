@@ -335,6 +335,14 @@ int dis_gn_bwd_from_sums(const float* g, const float* x, const double* stats, co
  *   dis_conv2d_dgrad_f16x2_gnb: gx (+)= conv_T(gpre, w) with gpre = act'(q) (g k1_c + q kx + k0) formed while g and q are staged,
  *     gpre also stored to gpre_out for the weight-gradient launch; optional channel-sum epilogue as dis_conv2d_dgrad_bf16x3_gnsums /
  *     _gnsums_res (ab_gn_x, ab_act_y, ab_out; all NULL: none).  3x3, stride 1, pad 1, c -> c, c in {16, 32}; two-term fp16 kernels only. */
+/* Round 5: y = act(conv3x3(out) + bias), out = SELU(GroupNorm(x2) + res) formed while x2 and res are staged (dis_gn_apply's arithmetic,
+ * bit for bit) and stored to `out` by the tiles that own each pixel: a ResNetBlock's output is written by the conv that consumes it
+ * first (reference model/multi_frame_networks.py:514-542).  3x3 stride 1 pad 1; c -> c (c in {16, 32}; stats optional) or 32 -> 16 (no
+ * stats); act SELU; two-term fp16 kernels only. */
+int dis_conv2d_fwd_f16x2_gnres(const float* x2, const double* gn_stats, const float* gn_gamma, const float* gn_beta, float gn_eps,
+                               const float* res, float* out, const float* w_oihw, int w_o, int w_i, int w_row_stride,
+                               const float* bias, float* y, double* stats, int n, int hin, int win, int cin, int cout, int act,
+                               void* stream);
 int dis_gn_bwd_coef(const double* stats, const float* gamma, const double* ab, int slots, float* coef, float* grad_gamma,
                     float* grad_beta, unsigned* counter, int n, long hw, int c, float eps, void* stream);
 int dis_gn_bwd_apply_coef(const float* g, const float* x, const float* coef, float* gx, int n, long hw, int c, int in_act,

@@ -549,6 +549,48 @@ def test_dgrad_with_group_norm_backward_on_load(c, in_act, form, n, h, w):
         assert torch.equal(ab, ab_ref)
 
 
+@pytest.mark.parametrize('c', [16, 32])
+@pytest.mark.parametrize('n,h,w', [(3, 37, 29), (2, 64, 48)])
+def test_resnet_chain_with_deferred_block_outputs(c, n, h, w):
+    """ResNetBlock(defer_out=True): the block's output SELU(GroupNorm(x2) + x) is not written by a pass of its own but by the next
+    block's first conv while it loads it (dis_conv2d_fwd_f16x2_gnres).  A chain of three blocks + a 32 -> 16 conv with and without the
+    deferral: outputs, every block output tensor, and ALL gradients bit-identical (the staging repeats dis_gn_apply's arithmetic).
+    Reference: model/multi_frame_networks.py:514-542."""
+    from depthinspace_amd import ops
+    from depthinspace_amd.model import multi_frame_networks as mfn
+    if ops.lib.fn('dis_get_conv_split')() != 1:
+        pytest.skip('two-term fp16 kernels only')
+    torch.manual_seed(5 + c + h)
+    blocks = [mfn.ResNetBlock(c).cuda() for _ in range(3)]
+    tail = mfn.ConvParams(c, 16, 3).cuda()
+    for b in blocks + [tail]:
+        for p_ in b.parameters():
+            if p_.dim() > 1:
+                torch.nn.init.normal_(p_, std=0.08)
+            else:
+                torch.nn.init.normal_(p_, mean=0.5 if p_.dim() == 1 else 0.0, std=0.2)
+    x0 = torch.randn(n, h, w, c).cuda()
+    go = torch.randn(n, h, w, 16).cuda()
+    res = []
+    for defer in (False, True):
+        ops.begin_step('cuda:0')
+        for b in blocks + [tail]:
+            for p_ in b.parameters():
+                p_.grad = None
+        x = x0.clone().requires_grad_(True)
+        o1 = blocks[0](x, defer_out=defer)
+        o2 = blocks[1](o1, defer_out=defer)
+        o3 = blocks[2](o2, defer_out=defer and c == 32)
+        y = ops.conv2d(o3, tail.weight, tail.bias, 1, 1, ops.ACT_SELU, gnres=getattr(o3, '_gn_res_src', None))[0]
+        y.backward(go)
+        torch.cuda.synchronize()
+        assert not ops._GN_PENDING and not ops._GN_LAZY and not ops._GN_PRE
+        res.append([t.detach().clone() for t in (y, o1, o2, o3, x.grad)] +
+                   [p_.grad.clone() for b in blocks + [tail] for p_ in b.parameters()])
+    for i, (a_, b_) in enumerate(zip(res[0], res[1])):
+        assert torch.equal(a_, b_), (i, float((a_ - b_).abs().max()))
+
+
 @pytest.mark.parametrize('stride', [1, 2])
 def test_conv3d_class_ordered_backward(golden_dir, stride):
     """dis_conv3d_knn_bwd_det (the default backward: class-ordered plain read-modify-write, aggregate read back from the forward)
