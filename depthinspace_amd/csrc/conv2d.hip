@@ -2619,3 +2619,16 @@ extern "C" int dis_disp_head_bwd(const float* x, const float* w, const float* y,
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
+
+// ---- split-neutral names of the `_bf16x3` entry points (include/dis_hip.h): aliases of the functions above
+#ifndef __HIP_DEVICE_COMPILE__
+extern "C" int dis_conv2d_fwd_split_oihw(const float* x, const float* w_oihw, int mode, int w_o, int w_i, int w_row_stride, const float* bias, float* y, double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act, void* stream) __attribute__((alias("dis_conv2d_fwd_bf16x3_oihw")));
+extern "C" int dis_conv2d_fwd_split_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta, float gn_eps, const float* w_oihw, int w_o, int w_i, int w_row_stride, const float* bias, float* y, double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act, void* stream) __attribute__((alias("dis_conv2d_fwd_bf16x3_gn")));
+extern "C" int dis_conv2d_dgrad_split_gnsums(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g, const float* gn_x, double* ab_out, int n, int hin, int win, int cin, int cout, int pad, void* stream) __attribute__((alias("dis_conv2d_dgrad_bf16x3_gnsums")));
+extern "C" int dis_conv2d_dgrad_split_gnsums_res(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g, const float* act_y, const float* gn_x, double* ab_out, int n, int hin, int win, int cin, int cout, int pad, void* stream) __attribute__((alias("dis_conv2d_dgrad_bf16x3_gnsums_res")));
+extern "C" int dis_conv2d_dgrad_split_act_gnsums_res(const float* gy, const float* y, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g, const float* act_y, const float* gn_x, double* ab_out, int n, int hin, int win, int cin, int cout, int pad, void* stream) __attribute__((alias("dis_conv2d_dgrad_bf16x3_act_gnsums_res")));
+extern "C" int dis_conv2d_dgrad_split_act(const float* gy, const float* y, int act, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* gx, int n, int hin, int win, int cin, int cout, int pad, int accumulate, void* stream) __attribute__((alias("dis_conv2d_dgrad_bf16x3_act")));
+extern "C" int dis_conv2d_wgrad_split(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad, void* stream) __attribute__((alias("dis_conv2d_wgrad_bf16x3")));
+extern "C" int dis_conv2d_wgrad_split_act(const float* x, const float* gy, const float* y, int act, float* grad_w, float* grad_b, float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad, void* stream) __attribute__((alias("dis_conv2d_wgrad_bf16x3_act")));
+extern "C" int dis_conv2d_wgrad_split_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta, float gn_eps, const float* gy, float* grad_w, float* grad_b, float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad, void* stream) __attribute__((alias("dis_conv2d_wgrad_bf16x3_gn")));
+#endif

@@ -123,12 +123,14 @@ extern "C" int dis_debug_f2_stamps(unsigned long long* host) {
 // i.e. cache hits with the same data statistics; F2_KO_MFMA: no matrix instructions; F2_KO_SPLIT: the staged items are written
 // without the two-term split; F2_KO_EPI: no activation / statistics arithmetic) and F2_CLK: the in-kernel clock from
 // s_memtime / s_memrealtime around the whole kernel (MI355X_MICROARCH.md, DVFS give-back item 6).  Results are WRONG by design.
-#ifdef F2_KO_MFMA
+#if defined(F2_KO_MFMA) || defined(F2W_KO_MFMA)
 // (an empty asm statement keeps the operand registers alive: the fragment reads stay)
 __device__ __forceinline__ f32x4 f2_no_mfma(f16x8_t A, f16x8_t B, f32x4 C) {
   asm volatile("; operands kept: %0 %1" ::"v"(A), "v"(B));
   return C;
 }
+#endif
+#ifdef F2_KO_MFMA
 #define F2_MFMA(A, B, C) f2_no_mfma(A, B, C)
 #else
 #define F2_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
@@ -1044,6 +1046,9 @@ template <int CIN, int COUT, int INACT = 0, bool INGN = false, bool GEN = false,
 __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_wgrad_f16x2_kernel(WgArgs a) {
   using C = F2WxCfg<CIN, COUT, K_, S_, TR_, KH_>;
   static_assert(!GEN || (CIN == 32 && INACT == 0 && !INGN), "slice-pair form");
+#ifdef F2_CLK
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   static_assert(GEN || (K_ == 3 && S_ == 1 && TR_ == 8 && KH_ == 3) ||
                     (K_ == 4 && S_ == 2 && TR_ == 4 && KH_ == 4 && CIN == 32 && COUT == 32 && INACT == 0 && !INGN),
                 "the FuseNet forms: 3 x 3 stride 1, and the 4 x 4 stride-2 down convolution (32 -> 32)");
@@ -1096,6 +1101,9 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
     gn_b = *(const float4*)(a.gn_beta + ((int)threadIdx.x % C::CVX) * 4);
   }
   auto prefetch = [&](int tile) __attribute__((always_inline)) {
+#ifdef F2W_KO_LOAD   // (diagnostic build: every tile reads tile 0 - cache hits with the same data statistics)
+    tile = 0;
+#endif
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * (TR * S) - a.pad + ky0, ix0 = tx * (16 * S) - a.pad;
     st_iy0 = iy0, st_ix0 = ix0, st_n = n;
@@ -1195,8 +1203,12 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
       if (idx < C::NIX) {
         const float4 v = prex[it];
         unsigned a1, a2, b1, b2;
+#ifdef F2W_KO_SPLIT
+        a1 = __float_as_uint(v.x) & 0x3fff3fffu, a2 = __float_as_uint(v.y) & 0x3fff3fffu, b1 = __float_as_uint(v.z) & 0x3fff3fffu, b2 = __float_as_uint(v.w) & 0x3fff3fffu;
+#else
         f2_split_pair_scaled(v.x, v.y, scx, a1, a2);
         f2_split_pair_scaled(v.z, v.w, scx, b1, b2);
+#endif
         unsigned short* p = xl + (idx / C::CVX) * PSX + (idx % C::CVX) * 4;
         *(uint2*)(p) = make_uint2(a1, b1);
         *(uint2*)(p + CIN) = make_uint2(a2, b2);
@@ -1265,9 +1277,13 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
             if (t >= T0 && t < T1) {
 #pragma unroll
               for (int q = 0; q < 3; ++q)
+#ifdef F2W_KO_MFMA
+                acc[t - T0] = f2_no_mfma(__builtin_bit_cast(f16x8_t, fa[u & 1][PA[q]]), __builtin_bit_cast(f16x8_t, fb[ks & 1][PB[q]][nb]), acc[t - T0]);
+#else
                 acc[t - T0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa[u & 1][PA[q]]),
                                                                      __builtin_bit_cast(f16x8_t, fb[ks & 1][PB[q]][nb]),
                                                                      acc[t - T0], 0, 0, 0);
+#endif
               nm += 3;
             }
           }
@@ -1301,6 +1317,12 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
     case 2: run(std::integral_constant<int, 2>{}); break;
     default: run(std::integral_constant<int, 3>{}); break;
   }
+#ifdef F2_CLK
+  if (threadIdx.x == 0 && blockIdx.x < 256 && blockIdx.y == 0 && blockIdx.z == 0) {
+    f2_clk[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - clk_t0;
+    f2_clk[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  }
+#endif
   if (a.bpart) {
     __syncthreads();
     const int vv = threadIdx.x % C::CVG, row = threadIdx.x / C::CVG;

@@ -67,6 +67,15 @@ SIGS = {
     'dis_conv2d_dgrad_bf16x3_gnsums_res': 'ppiiippppiiiiiip',
     'dis_conv2d_dgrad_bf16x3_act_gnsums_res': 'pppiiippppiiiiiip',
     'dis_gn_bwd_from_sums': 'pppppippppilifip',
+    'dis_conv2d_fwd_split_oihw': 'ppiiiipppiiiiiiiiip',
+    'dis_conv2d_fwd_split_gn': 'ppppfpiiipppiiiiiiiiip',
+    'dis_conv2d_dgrad_split_gnsums': 'ppiiipppiiiiiip',
+    'dis_conv2d_dgrad_split_gnsums_res': 'ppiiippppiiiiiip',
+    'dis_conv2d_dgrad_split_act_gnsums_res': 'pppiiippppiiiiiip',
+    'dis_conv2d_dgrad_split_act': 'ppipiiipiiiiiiip',
+    'dis_conv2d_wgrad_split': 'pppppiiiiiiiiip',
+    'dis_conv2d_wgrad_split_act': 'pppipppiiiiiiiiip',
+    'dis_conv2d_wgrad_split_gn': 'ppppfppppiiiiiiiiip',
     'dis_conv2d_fwd_f16x2_gnres': 'ppppfpppiiipppiiiiiip',
     'dis_gn_bwd_coef': 'pppippppilifp',
     'dis_gn_bwd_apply_coef': 'ppppiliip',

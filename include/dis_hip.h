@@ -354,6 +354,19 @@ int dis_conv2d_wgrad_bf16x3_gn(const float* x, const double* gn_stats, const flo
                                float gn_eps, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
                                int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,
                                void* stream);
+/* Split-neutral names (round 5) of the 3x3 entry points above whose `_bf16x3` suffix is history: which operand split multiplies is a
+ * process-wide mode (dis_set_conv_split: 1 = two-term fp16, 3 products per MAC, the default; 0 = three-term bf16, 6 products, >= 24-bit
+ * operands), not a property of the entry point.  Same symbols' code (ELF aliases), same arguments. */
+int dis_conv2d_fwd_split_oihw(const float* x, const float* w_oihw, int mode, int w_o, int w_i, int w_row_stride, const float* bias, float* y, double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act, void* stream);
+int dis_conv2d_fwd_split_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta, float gn_eps, const float* w_oihw, int w_o, int w_i, int w_row_stride, const float* bias, float* y, double* stats, int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int act, void* stream);
+int dis_conv2d_dgrad_split_gnsums(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g, const float* gn_x, double* ab_out, int n, int hin, int win, int cin, int cout, int pad, void* stream);
+int dis_conv2d_dgrad_split_gnsums_res(const float* gy, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g, const float* act_y, const float* gn_x, double* ab_out, int n, int hin, int win, int cin, int cout, int pad, void* stream);
+int dis_conv2d_dgrad_split_act_gnsums_res(const float* gy, const float* y, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* g, const float* act_y, const float* gn_x, double* ab_out, int n, int hin, int win, int cin, int cout, int pad, void* stream);
+int dis_conv2d_dgrad_split_act(const float* gy, const float* y, int act, const float* w_oihw, int w_o, int w_i, int w_row_stride, float* gx, int n, int hin, int win, int cin, int cout, int pad, int accumulate, void* stream);
+int dis_conv2d_wgrad_split(const float* x, const float* gy, float* grad_w, float* grad_b, float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad, void* stream);
+int dis_conv2d_wgrad_split_act(const float* x, const float* gy, const float* y, int act, float* grad_w, float* grad_b, float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad, void* stream);
+int dis_conv2d_wgrad_split_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta, float gn_eps, const float* gy, float* grad_w, float* grad_b, float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad, void* stream);
+
 /* Input gradient of a k=4, stride=2, pad=1 convolution (transposed convolution) as four 2x2 phase convolutions on
  * the matrix cores.  w_oihw is the unpacked weight (cout,cin,4,4).  workspace: 16*cin*cout floats.
  * gx: (n,hin,win,cin) overwritten, or added to when `accumulate` != 0. */

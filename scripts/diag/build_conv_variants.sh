@@ -26,6 +26,11 @@ V[early_wait1]="-DF2_CLK -DF2_PF2=0 -DF2_LOAD_SCHED=1 -DF2_WAIT_MODE=1"
 V[pf2]="-DF2_CLK"
 V[pf2_early]="-DF2_CLK -DF2_LOAD_SCHED=1"
 V[pf2_ko_mfma]="-DF2_CLK -DF2_KO_MFMA"
+V[w_ko_mfma]="-DF2_CLK -DF2W_KO_MFMA"
+V[w_ko_load]="-DF2_CLK -DF2W_KO_LOAD"
+V[w_ko_both]="-DF2_CLK -DF2W_KO_LOAD -DF2W_KO_MFMA"
+V[w_ko_split]="-DF2_CLK -DF2W_KO_SPLIT"
+V[w_wpc1]="-DF2_CLK -DF2W_WPC=1"
 V[early_wait2]="-DF2_CLK -DF2_PF2=0 -DF2_LOAD_SCHED=1 -DF2_WAIT_MODE=2"
 NAMES="${@:-${!V[@]}}"
 for v in $NAMES; do
