@@ -2190,6 +2190,20 @@ __global__ __launch_bounds__(256) void wgrad_pairs_reduce_kernel(const float* __
     const float* p = part + ((long)grp * npairs + pair) * workers * psz + e;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // fp64 over the worker slabs (see wgrad_reduce_kernel)
     int wk = 0;
+    // (sixteen slabs in flight per round: with four the launch was workers / 4 dependent memory round trips - 19 us at 27 launches per
+    //  DIS-SF step, the latency chain, not the 22 MB it reads)
+    for (; wk + 15 < workers; wk += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = p[(long)(wk + u) * psz];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        s0 += (double)v[u];
+        s1 += (double)v[u + 1];
+        s2 += (double)v[u + 2];
+        s3 += (double)v[u + 3];
+      }
+    }
     for (; wk + 3 < workers; wk += 4) {
       s0 += (double)p[(long)wk * psz];
       s1 += (double)p[(long)(wk + 1) * psz];
