@@ -1021,6 +1021,13 @@ struct F2WxCfg {
   static_assert(TR % 2 == 0 && (TR * 16 * CVG) % 256 == 0, "tile geometry");
 };
 
+#ifndef F2W_PF2
+// two register sets of staged items in the weight-gradient kernel (see WPF2).  OFF: measured twice (round 4 by hand, round 5 with
+// the pair loop and verified counted waits, vmcnt(19..10)): 504.8 / 499.2 frames/s without, 495.6 / 495.0 with it in alternating
+// same-box runs (profiles/r5_ab_wgrad_pf2.txt) - the kernel's cycles are its instruction stream (scripts/diag/wgrad_bound.py), the
+// loads it would hide are hidden by the CU's second workgroup already, and 68 more registers cost the matrix phase its schedule.
+#define F2W_PF2 0
+#endif
 #ifndef F2W_WPC
 #define F2W_WPC 2   // workgroups per CU (= waves per SIMD) the weight-gradient kernel is built for
 #endif
@@ -1075,7 +1082,16 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
   for (int j = 0; j < TW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  float4 prex[NLX], preg[NLG], preg2[INACT ? NLG : 1];
+  // WPF2: two register sets of staged items (the FuseNet 3 x 3 forms): the loads of tile t + 2 are issued when tile t has been staged,
+  // those of tile t + 1 are in flight meanwhile - a load has a whole tile period to land instead of one matrix phase (~1 us against
+  // an HBM latency of 2 - 3 us under this traffic: scripts/diag/wgrad_bound.py, profiles/r5_dominant_bound.md)
+  constexpr bool WPF2 = F2W_PF2 && !GEN && K_ == 3 && S_ == 1;
+  struct WSet {
+    float4 x[NLX], g[NLG], g2[INACT ? NLG : 1];
+    int iy0, ix0, n;
+  };
+  WSet SA, SB;
+  SA.iy0 = SA.ix0 = 0, SA.n = -1, SB.iy0 = SB.ix0 = 0, SB.n = -1;
   int ix_rc[NLX], ix_off[NLX], ig_rc[NLG], ig_off[NLG];
 #pragma unroll
   for (int it = 0; it < NLX; ++it) {
@@ -1093,20 +1109,25 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
     ig_rc[it] = (!GEN || COUT * gbk + vv * 4 < a.cg) ? ((pix >> 4) | ((pix & 15) << 16)) : 0x40000000;
     ig_off[it] = (((pix >> 4) * a.wout + (pix & 15)) * ldg + gc0 + vv * 4) * 4;
   }
-  const unsigned x_bytes = (unsigned)a.hin * a.win * (ldx * 4u), g_bytes = (unsigned)a.hout * a.wout * (ldg * 4u);
-  int st_iy0 = 0, st_ix0 = 0, st_n = -1, gn_n = -1;
+  const unsigned x_bytes_all = (unsigned)a.hin * a.win * (ldx * 4u), g_bytes_all = (unsigned)a.hout * a.wout * (ldg * 4u);
+  int gn_n = -1;
   float4 gn_g = make_float4(0.f, 0.f, 0.f, 0.f), gn_b = gn_g, gn_sc = gn_g, gn_sh = gn_g;
   if (INGN) {
     gn_g = *(const float4*)(a.gn_gamma + ((int)threadIdx.x % C::CVX) * 4);
     gn_b = *(const float4*)(a.gn_beta + ((int)threadIdx.x % C::CVX) * 4);
   }
-  auto prefetch = [&](int tile) __attribute__((always_inline)) {
+  // (a tile past the workgroup's last one: the loads are issued all the same, through empty descriptors - they return zeros nobody
+  //  reads - so that the number of memory operations between two waits is the same on every path and the counted waits stay exact)
+  auto prefetch = [&](WSet& W, int tile) __attribute__((always_inline)) {
+    const bool live = tile < ntiles;
+    if (!live) tile = 0;
 #ifdef F2W_KO_LOAD   // (diagnostic build: every tile reads tile 0 - cache hits with the same data statistics)
     tile = 0;
 #endif
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * (TR * S) - a.pad + ky0, ix0 = tx * (16 * S) - a.pad;
-    st_iy0 = iy0, st_ix0 = ix0, st_n = n;
+    W.iy0 = iy0, W.ix0 = ix0, W.n = n;
+    const unsigned x_bytes = live ? x_bytes_all : 0u, g_bytes = live ? g_bytes_all : 0u;
     const char* xb = (const char*)a.x + (long)n * a.hin * a.win * ldx * 4;
     const int xoff0 = (iy0 * a.win + ix0) * (ldx * 4);
 #pragma unroll
@@ -1114,7 +1135,7 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
       // (rows above / below the sample leave the sample's buffer range by themselves: only the column is tested)
       const int ix = ix0 + (ix_rc[it] >> 16);
       const bool ok = (unsigned)ix < (unsigned)a.win;
-      prex[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+      W.x[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(xb, x_bytes), ok ? (unsigned)(xoff0 + ix_off[it]) : BX_OOB, 0, 0));
     }
     const char* gb = (const char*)a.gy + (long)n * a.hout * a.wout * ldg * 4;
@@ -1123,16 +1144,17 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
     for (int it = 0; it < NLG; ++it) {
       const int ox = tx * 16 + (ig_rc[it] >> 16);
       const bool ok = ox < a.wout;   // (rows below the sample: past the end of its buffer range)
-      preg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+      W.g[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(gb, g_bytes), ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
       if (INACT)
-        preg2[it] = __builtin_bit_cast(
+        W.g2[it] = __builtin_bit_cast(
             float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc((const char*)a.gact + (gb - (const char*)a.gy), g_bytes),
                                                           ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
     }
   };
   // (1) before the barrier: final fp32 values of the items in flight, this wave's two maxima into LDS
-  auto prep = [&](int parity) __attribute__((always_inline)) {
+  auto prep = [&](WSet& W, int parity) __attribute__((always_inline)) {
+    const int st_iy0 = W.iy0, st_ix0 = W.ix0, st_n = W.n;
     if (INGN && st_n != gn_n) {
       gn_n = st_n;
       float mean, rstd;
@@ -1141,11 +1163,11 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
       gn_sh = make_float4(gn_b.x - gn_sc.x * mean, gn_b.y - gn_sc.y * mean, gn_b.z - gn_sc.z * mean, gn_b.w - gn_sc.w * mean);
     }
     const bool gn_interior = INGN && st_iy0 >= 0 && st_ix0 >= 0 && st_iy0 + C::IR <= a.hin && st_ix0 + C::IC <= a.win;
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    if (!WPF2) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)  (two sets: the other set stays in flight, the compiler counts)
     float mx = 0.f, mg = 0.f;
 #pragma unroll
     for (int it = 0; it < NLX; ++it) {
-      float4 v = prex[it];
+      float4 v = W.x[it];
       if (INGN) {
         f32x2 sh_lo = {gn_sh.x, gn_sh.y}, sh_hi = {gn_sh.z, gn_sh.w};
         if (!gn_interior) {
@@ -1157,19 +1179,19 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
         const f32x2 lo = (f32x2){v.x, v.y} * (f32x2){gn_sc.x, gn_sc.y} + sh_lo;
         const f32x2 hi = (f32x2){v.z, v.w} * (f32x2){gn_sc.z, gn_sc.w} + sh_hi;
         v = make_float4(lo[0], lo[1], hi[0], hi[1]);
-        prex[it] = v;
+        W.x[it] = v;
       }
       const float mv = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)), fabsf(v.w));
       mx = (!INGN || (it + 1) * 256 <= C::NIX || (int)threadIdx.x + it * 256 < C::NIX) ? fmaxf(mx, mv) : mx;  // (not loaded: zeros)
     }
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
-      float4 v = preg[it];
+      float4 v = W.g[it];
       if (INACT) {
-        const float4 q = preg2[it];
+        const float4 q = W.g2[it];
         v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
         v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
-        preg[it] = v;
+        W.g[it] = v;
       }
       bsum.x += v.x, bsum.y += v.y, bsum.z += v.z, bsum.w += v.w;
       mg = __builtin_fmaxf(__builtin_fmaxf(mg, fabsf(v.x)), fabsf(v.y));
@@ -1184,7 +1206,7 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
   };
   int sx_e = 60, sg_e = 60;  // running scale exponents (the clamp's upper end: any real tile lowers them)
   // (2) after it: running scales (accumulators follow), split, LDS write
-  auto stage = [&](int parity) __attribute__((always_inline)) {
+  auto stage = [&](WSet& W, int parity) __attribute__((always_inline)) {
     const float4 m0 = *(const float4*)(mxs + parity * 8), m1 = *(const float4*)(mxs + parity * 8 + 4);
     const int ex = f2_scale_exp(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)));
     const int eg = f2_scale_exp(fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
@@ -1201,7 +1223,7 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
     for (int it = 0; it < NLX; ++it) {
       const int idx = (int)threadIdx.x + it * 256;
       if (idx < C::NIX) {
-        const float4 v = prex[it];
+        const float4 v = W.x[it];
         unsigned a1, a2, b1, b2;
 #ifdef F2W_KO_SPLIT
         a1 = __float_as_uint(v.x) & 0x3fff3fffu, a2 = __float_as_uint(v.y) & 0x3fff3fffu, b1 = __float_as_uint(v.z) & 0x3fff3fffu, b2 = __float_as_uint(v.w) & 0x3fff3fffu;
@@ -1217,7 +1239,7 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
       const int idx = threadIdx.x + it * 256;
-      const float4 v = preg[it];
+      const float4 v = W.g[it];
       unsigned a1, a2, b1, b2;
       f2_split_pair_scaled(v.x, v.y, scg, a1, a2);
       f2_split_pair_scaled(v.z, v.w, scg, b1, b2);
@@ -1227,7 +1249,8 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
     }
   };
 
-  if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+  prefetch(SA, blockIdx.x);
+  if (WPF2) prefetch(SB, blockIdx.x + gridDim.x);
   auto run = [&](auto wc) __attribute__((always_inline)) {
     constexpr int W = decltype(wc)::value, T0 = TW * W, T1 = (T0 + TW < C::T) ? T0 + TW : C::T;
     constexpr int NTW = T1 > T0 ? T1 - T0 : 0;
@@ -1247,13 +1270,13 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
       for (int p = 0; p < NP; ++p) F[p] = f2_tr_read8(xq + p * CIN, xq + S * WX_IC * PSX + p * CIN);
     };
     int parity = 0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      prep(parity);
+    auto body = [&](WSet& W, int tile) __attribute__((always_inline)) {
+      prep(W, parity);
       __syncthreads();
-      stage(parity);
+      stage(W, parity);
       __syncthreads();
       parity ^= 1;
-      if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+      prefetch(W, tile + (WPF2 ? 2 : 1) * (int)gridDim.x);
       if (NTW > 0) {
         s16x8 fa[2][NP], fb[2][NP][NB];
         load_fb(0, fb[0]);
@@ -1300,6 +1323,20 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
           __builtin_amdgcn_sched_barrier(0);
         });
       }
+    };
+    if constexpr (WPF2) {
+      // pairs of tiles through a loop with ONE exit, an odd last tile behind it (see conv_f16x2_kernel: a `break` between the two
+      // bodies costs the counted waits)
+      const int ntl = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+      int tile = blockIdx.x;
+      for (int pr = 0; pr < (ntl >> 1); ++pr) {
+        body(SA, tile);
+        body(SB, tile + (int)gridDim.x);
+        tile += 2 * (int)gridDim.x;
+      }
+      if (ntl & 1) body(SA, tile);
+    } else {
+      for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) body(SA, tile);
     }
     // partial slab of this workgroup: [m = mb*16 + row][co], scales undone
     const float desc = __builtin_ldexpf(1.f, -(sx_e + sg_e));
