@@ -657,9 +657,12 @@ def main():
         else:
             chosen, kind = free, 'free_running'
         if mf and args.dtype == 'f32':
-            # the same comparison, FREE-RUNNING and unconditional, on a scene without lattice symmetry (synth scene 'bumps': a
-            # non-planar surface - symmetric neighbours of a pixel are no longer equidistant, so the top-9-of-36 has no exact key
-            # ties for a host's BLAS to break either way): same seeds, same initial parameters, no forcing, no tie analysis
+            # the same comparison on a scene without lattice symmetry (synth scene 'bumps': a non-planar surface): same seeds, same
+            # initial parameters - FREE-RUNNING, then with its own tie analysis and on the HIP path's neighbour sets.  (Round-4 review
+            # item 6 expected the free-running figure to pass there; it does not on a host whose CPU kernels round the oracle's keys
+            # differently from the fixture host: ~2.5 % of the Conv3D rows have two candidates within 1e-5 relative of each other on
+            # ANY smooth scene, and which one the oracle picks is the host's rounding.  The HIP selection equals the reference's
+            # torch.topk on the committed fixtures, tests/test_step_gpu.py incl. mf_128_bumps.)
             from depthinspace_amd import synth as _synth
             from oracle import dis_oracle as O
             hip_b, _, sets_b = hip_first_step(args.arch, settings, dev, args.dtype, scene='bumps')
@@ -668,22 +671,31 @@ def main():
             nthr_b = torch.get_num_threads()
             torch.set_num_threads(int(os.environ.get('DIS_CPU_BASELINE_THREADS', str(min(nthr_b, 32)))))
             try:
-                O.CONV3D_TAP = []
+                p0_b = O.init_params(O.mf_param_shapes(), seed=0)
                 with torch.no_grad():
                     data_b = O.copy_data(ctx_b, tb_b)
-                    ref_b = O.mf_net_forward(ctx_b, O.init_params(O.mf_param_shapes(), seed=0), data_b,
-                                             O.read_optical_flow(data_b, TL)).detach().float()
-                tap_b, O.CONV3D_TAP = O.CONV3D_TAP, None
+                    O.CONV3D_TAP = []
+                    try:
+                        ref_b = O.mf_net_forward(ctx_b, p0_b, data_b, O.read_optical_flow(data_b, TL)).detach().float()
+                    finally:
+                        tap_b, O.CONV3D_TAP = O.CONV3D_TAP, None
+                    O.CONV3D_FORCE = {'core': sets_b[0].long(), 'quarter': sets_b[1].long()}
+                    try:
+                        forced_b = O.mf_net_forward(ctx_b, p0_b, data_b, O.read_optical_flow(data_b, TL)).detach().float()
+                    finally:
+                        O.CONV3D_FORCE = None
             finally:
-                O.CONV3D_TAP = None
                 torch.set_num_threads(nthr_b)
             d_b = (hip_b.reshape(-1) - ref_b.reshape(-1)).abs()
-            tc_b = knn_tie_check(tap_b, sets_b) if tap_b else None
+            d_bf = (hip_b.reshape(-1) - forced_b.reshape(-1)).abs()
+            tc_b = knn_tie_check(tap_b, sets_b) if tap_b else {'pass': False, 'error': 'no tap'}
             l1_ref['bumps_free_running'] = {
                 'value': float(d_b.mean()), 'max': float(d_b.max()), 'pass': float(d_b.mean()) < bar,
                 'scene': "synth.make_batch(scene='bumps'): non-planar surface, batch seed 1234, init_params(seed=0), bs=1, 512x432",
-                'conv3d_rows_whose_set_differs': tc_b['rows_whose_set_differs'] if tc_b else None,
-                'conv3d_rows': tc_b['conv3d_rows'] if tc_b else None}
+                'on_hip_neighbour_sets': {'value': float(d_bf.mean()), 'max': float(d_bf.max()), 'pass': float(d_bf.mean()) < bar},
+                'tie_check': {k: tc_b.get(k) for k in ('conv3d_rows', 'rows_whose_set_differs', 'non_tie_rows', 'ulps_needed',
+                                                       'largest_relative_key_gap_of_a_differing_row',
+                                                       'relative_gap_histogram_of_differing_rows', 'pass', 'error') if k in tc_b}}
         l1_ref.update({'value': chosen['value'], 'max': chosen['max'], 'value_kind': kind, 'pass': chosen['value'] < bar,
                        'sample': 'bs=1 (one 4-frame track, batch seed 1234, init_params(seed=0)), 512x432: free-running HIP forward '
                                  'vs the CPU oracle of cpu_baseline on this host'})
