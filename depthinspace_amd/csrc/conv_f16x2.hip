@@ -1028,6 +1028,9 @@ struct F2WxCfg {
 // loads it would hide are hidden by the CU's second workgroup already, and 68 more registers cost the matrix phase its schedule.
 #define F2W_PF2 0
 #endif
+#ifndef F2W_FD
+#define F2W_FD 1   // units the weight-gradient kernel's LDS fragment reads run ahead of their matrix instructions
+#endif
 #ifndef F2W_WPC
 #define F2W_WPC 2   // workgroups per CU (= waves per SIMD) the weight-gradient kernel is built for
 #endif
@@ -1278,17 +1281,25 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
       parity ^= 1;
       prefetch(W, tile + (WPF2 ? 2 : 1) * (int)gridDim.x);
       if (NTW > 0) {
-        s16x8 fa[2][NP], fb[2][NP][NB];
+        // fragment reads run FD units (a unit = one x fragment against the gy fragments of its k-step: <= 6 matrix instructions,
+        // ~100 cycles) ahead of the matrix instructions that consume them
+        constexpr int FD = (F2W_FD > 1 && NGD >= 2) ? 2 : 1, FA = FD + 1;   // (two gy-fragment buffers: a unit two ahead is at most one k-step ahead)
+        s16x8 fa[FA][NP], fb[2][NP][NB];
         load_fb(0, fb[0]);
-        load_fa(0, MB0, fa[0]);
+#pragma unroll
+        for (int v = 0; v < FD; ++v)
+          if (v < NU) {
+            if (v > 0 && v % NGD == 0) load_fb(v / NGD, fb[(v / NGD) & 1]);
+            load_fa(v / NGD, MB0 + v % NGD, fa[v % FA]);
+          }
         f2_static_for<0, NU>([&](auto uc) __attribute__((always_inline)) {
           constexpr int u = decltype(uc)::value;
           constexpr int ks = u / NGD, gi = u % NGD, mb = MB0 + gi;
           int nread = 0;
-          if (u + 1 < NU) {
-            const int ks2 = (u + 1) / NGD, gi2 = (u + 1) % NGD;
+          if (u + FD < NU) {
+            const int ks2 = (u + FD) / NGD, gi2 = (u + FD) % NGD;
             if (gi2 == 0) load_fb(ks2, fb[ks2 & 1]), nread += 2 * NP * NB;
-            load_fa(ks2, MB0 + gi2, fa[(u + 1) & 1]);
+            load_fa(ks2, MB0 + gi2, fa[(u + FD) % FA]);
             nread += 2 * NP;
           }
           constexpr int PA[3] = {1, 0, 0};
@@ -1301,9 +1312,9 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
 #pragma unroll
               for (int q = 0; q < 3; ++q)
 #ifdef F2W_KO_MFMA
-                acc[t - T0] = f2_no_mfma(__builtin_bit_cast(f16x8_t, fa[u & 1][PA[q]]), __builtin_bit_cast(f16x8_t, fb[ks & 1][PB[q]][nb]), acc[t - T0]);
+                acc[t - T0] = f2_no_mfma(__builtin_bit_cast(f16x8_t, fa[u % FA][PA[q]]), __builtin_bit_cast(f16x8_t, fb[ks & 1][PB[q]][nb]), acc[t - T0]);
 #else
-                acc[t - T0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa[u & 1][PA[q]]),
+                acc[t - T0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa[u % FA][PA[q]]),
                                                                      __builtin_bit_cast(f16x8_t, fb[ks & 1][PB[q]][nb]),
                                                                      acc[t - T0], 0, 0, 0);
 #endif
