@@ -1996,9 +1996,11 @@ __global__ __launch_bounds__(256) void convg_head_reduce_kernel(const float* __r
   for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
   if (lane == 0) gw[(long)x * 9 + tap] = (float)s;
 }
-static bool cgh_eligible(int cX, int cG_w, int k, int stride, int hX, int wX, int hG, int wG, int pad) {
+// (cG <= 4: the padded gradient tensor of a disparity head - dis_convg_wgrad_workspace sizes the head form's slabs under exactly this
+//  condition; pad == 1: the only padding with hX == hG for a 3 x 3 window)
+static bool cgh_eligible(int cX, int cG, int cG_w, int k, int stride, int hX, int wX, int hG, int wG, int pad) {
   static const bool off = getenv("DIS_CONVG_HEAD_WGRAD") && getenv("DIS_CONVG_HEAD_WGRAD")[0] == '0';
-  return !off && cG_w == 1 && k == 3 && stride == 1 && pad <= 2 && hX == hG && wX == wG &&
+  return !off && cG <= 4 && cG_w == 1 && k == 3 && stride == 1 && pad == 1 && hX == hG && wX == wG &&
          (cX == 16 || cX == 32 || cX == 64 || cX == 128);
 }
 
@@ -2028,7 +2030,7 @@ extern "C" int dis_convg_wgrad(const float* X, int ldX, int xoff, int hX, int wX
   if (k * k > CG_MAXTAPS || (stride != 1 && stride != 2)) return DIS_ERR_UNSUPPORTED;
   if ((long)n * hG * wG > 2147483647L - 64) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (cgh_eligible(cX, cG_w, k, stride, hX, wX, hG, wG, pad)) {   // a disparity head: one gradient channel, one pass over x
+  if (cgh_eligible(cX, cG, cG_w, k, stride, hX, wX, hG, wG, pad)) {   // a disparity head: one gradient channel, one pass over x
     const long npix = (long)n * hX * wX;
     const int c8 = cX / 8;
     long blocks = (npix + 256 / c8 - 1) / (256 / c8);

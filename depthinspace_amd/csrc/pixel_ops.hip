@@ -272,8 +272,10 @@ extern "C" int dis_photometric_bwd(const float* es, const float* ta, const float
 // The soft sign of the TARGET differences, h(ta_nb - ta_c), is the same for every estimate: evaluated once per tap instead of
 // once per estimate (5 reciprocal square roots per tap for S = 4 instead of 8; the kernels are bound by exactly this
 // arithmetic).  9 x 9 window; 2 pixels per lane, a tap row of both is 10 consecutive LDS values (5 ds_read_b64 instead of 18
-// ds_read_b32); the factor 0.5 of h is applied once at the end (a power of two: every partial sum scales exactly), so the
-// results equal S calls of dis_photometric_fwd / dis_photometric_bwd bit for bit.
+// ds_read_b32); the factor 0.5 of h is applied once at the end (a power of two: every partial sum scales exactly).  The results
+// equal S calls of dis_photometric_fwd / dis_photometric_bwd TO ROUNDING, not bit for bit: these kernels form d * d + eps as one
+// fused multiply-add (census_rsq_fma) and take the sign through a clamp (tests/test_pixel_ops_gpu.py compares both forms with the
+// oracle and with each other; DIS_PHOTO_SINGLE_VIA_MULTI=0 keeps the general kernels on the single-estimate calls).
 // ------------------------------------------------------------------------------------------------
 #define PM_TX 64
 #define PM_TY 8

@@ -284,7 +284,11 @@ def test_convg_channel_slices_of_wider_buffers():
     y_ref = F.relu(F.conv2d(xs, wt, b, padding=1)).permute(0, 2, 3, 1)
     yw = torch.full((n, h, w, ldy), 7.0).cuda()
     xd, wd, bd = xw.cuda(), wt.cuda(), b.cuda()
-    wp = torch.empty(lib.fn('dis_convg_pack_workspace')(cin, cout, 3), dtype=torch.float32, device='cuda')
+    # (the packing slices PLUS the split-K partial-sum area dis_convg_run derives for small maps - 0 here, but the contract is the sum)
+    wp = torch.empty(lib.fn('dis_convg_pack_workspace')(cin, cout, 3) +
+                     max(lib.fn('dis_convg_splitk_workspace')(ops.CONVG_CONV, n, h, w, h, w, cin, cout, 3, 1, 1), 0) +
+                     max(lib.fn('dis_convg_splitk_workspace')(ops.CONVG_CONV_DGRAD, n, h, w, h, w, cout, cin, 3, 1, 1), 0),
+                     dtype=torch.float32, device='cuda')
     lib.call('dis_convg_run', ops.CONVG_CONV, xd, ldx, xoff, wd, bd, yw, ldy, yoff, wp, n, h, w, cin, 17, h, w, cout, cout,
              3, 1, 1, ops.ACT_RELU)
     assert relerr(yw[..., yoff:yoff + cout].cpu(), y_ref) < 2e-5

@@ -46,8 +46,12 @@ def test_lcn_full_size():
 
 @pytest.mark.parametrize('name', ['mse', 'sad', 'census_mse', 'census_sad'])
 @pytest.mark.parametrize('blk,eps', [(9, 0.5), (5, 0.1)])
-def test_photometric_golden(G, name, blk, eps):
+@pytest.mark.parametrize('via_multi', [True, False])
+def test_photometric_golden(G, name, blk, eps, via_multi, monkeypatch):
+    """(via_multi False = DIS_PHOTO_SINGLE_VIA_MULTI=0: the general single-estimate kernels stay pinned to the reference's values
+    too, now that ops.photometric() routes the 9 x 9 census calls through the multi-estimate kernels by default)"""
     from depthinspace_amd import ops
+    monkeypatch.setattr(ops, 'PHOTO_SINGLE_VIA_MULTI', via_multi)
     es = dev(G['ph_es']).requires_grad_(True)
     out = ops.photometric(es, dev(G['ph_ta']), blk, O.PHOTO_TYPES[name], eps)
     out.backward(dev(G['ph_go']))
