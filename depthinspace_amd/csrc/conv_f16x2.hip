@@ -720,9 +720,15 @@ __global__ __launch_bounds__(512) void conv_f16x2_kernel(ConvArgs a) {
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nn = 0; nn < NT; ++nn) {
+#ifdef F2_SNAKE   // (diagnostic: consecutive matrix instructions always share one operand)
+              const int nt = ((mt + q) & 1) ? NT - 1 - nn : nn;
+#else
+              const int nt = nn;
+#endif
               acc[mt][nt] = F2_MFMA(__builtin_bit_cast(f16x8_t, fb[b][PB[q]][nt]),
                                     __builtin_bit_cast(f16x8_t, R[kx & 1][ky + mt][PA[q]]), acc[mt][nt]);
+            }
         pattern(std::integral_constant<int, (ks + 1 < KS ? (nky == 0 ? 2 * NP : NP) + NP * NT : 0)>{}, ksc);
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});

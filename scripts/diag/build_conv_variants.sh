@@ -31,6 +31,7 @@ V[w_ko_load]="-DF2_CLK -DF2W_KO_LOAD"
 V[w_ko_both]="-DF2_CLK -DF2W_KO_LOAD -DF2W_KO_MFMA"
 V[w_ko_split]="-DF2_CLK -DF2W_KO_SPLIT"
 V[w_wpc1]="-DF2_CLK -DF2W_WPC=1"
+V[snake]="-DF2_CLK -DF2_SNAKE"
 V[early_wait2]="-DF2_CLK -DF2_PF2=0 -DF2_LOAD_SCHED=1 -DF2_WAIT_MODE=2"
 NAMES="${@:-${!V[@]}}"
 for v in $NAMES; do
