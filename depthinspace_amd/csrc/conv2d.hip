@@ -68,9 +68,14 @@ __host__ __device__ inline long packed_w_offset(int tap, int c, int co, int cin,
 #define DIS_T2_ACC(t2, v) t2 = __builtin_fmaf(v, v, t2)
 #endif
 
-template <int CIN, int COUT, int KH, int KW, int S>
+// GNB (1 x 1 only, round 5): x is the gradient g wrt the OUTPUT of a GroupNorm whose input q = a.xact was this conv's output: the
+// tile is staged as act'(q) (g k1_c + q kx + k0) - the elementwise pass of the GroupNorm backward, a.gnb_coef (n, CIN + 2) from
+// dis_gn_bwd_coef, gn_apply_coef_kernel's arithmetic bit for bit - and those values are stored to a.gnb_out for the layer's
+// weight-gradient launch (a 1 x 1 window has no halo: every staged pixel belongs to exactly one tile).
+template <int CIN, int COUT, int KH, int KW, int S, bool GNB = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   using C = ConvCfg<CIN, COUT, KH, KW, S>;
+  static_assert(!GNB || (KH == 1 && KW == 1 && S == 1 && C::NCHUNK == 1 && 256 % C::NV == 0), "GroupNorm backward on load: 1 x 1");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;
   float* xl = smem + C::W_FLOATS;
@@ -92,9 +97,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
   // when they are written to LDS: a load under a branch made hipcc wait for it (s_waitcnt vmcnt(0)) right at the
   // issue point.  Everything that does not depend on the tile (item -> row/col/channel-group, element offset
   // inside the halo window) is computed once per thread; interior tiles skip the per-item clamps.
-  float4 pre[C::NLOAD];
+  float4 pre[C::NLOAD], preq[GNB ? C::NLOAD : 1];
   float psc[C::NLOAD];
   unsigned okmask = 0;
+  int st_n = 0, st_iy0 = 0, st_ix0 = 0, cf_n = -1;   // GNB: the prefetched tile, the sample whose coefficients are loaded
+  float4 cf_k1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float cf_kx = 0.f, cf_k0 = 0.f;
   int it_r[C::NLOAD], it_c[C::NLOAD], it_off[C::NLOAD], it_lds[C::NLOAD];
 #pragma unroll
   for (int it = 0; it < C::NLOAD; ++it) {
@@ -111,11 +119,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     const int iy0 = ty * C::TROWS * S - a.pad_y, ix0 = tx * C::TCOLS * S - a.pad_x;
     const float* xb = a.x + (long)n * a.hin * a.win * CIN + chunk * C::CINB;
     const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + C::IN_ROWS <= a.hin && ix0 + C::IN_COLS <= a.win;
+    if (GNB) st_n = n, st_iy0 = iy0, st_ix0 = ix0;
     if (interior) {
       const float* xo = xb + ((long)iy0 * a.win + ix0) * CIN;
       okmask = 0xffffffffu;
 #pragma unroll
       for (int it = 0; it < C::NLOAD; ++it) pre[it] = *(const float4*)(xo + it_off[it]);
+      if (GNB) {
+#pragma unroll
+        for (int it = 0; it < C::NLOAD; ++it) preq[it] = *(const float4*)(a.xact + (xo - a.x) + it_off[it]);
+      }
     } else {
       okmask = 0;
 #pragma unroll
@@ -124,6 +137,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
         const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
         pre[it] = *(const float4*)(xb + ((long)cy * a.win + cx) * CIN + it_lds[it] % C::CS);
+        if (GNB) preq[it] = *(const float4*)(a.xact + (xb - a.x) + ((long)cy * a.win + cx) * CIN + it_lds[it] % C::CS);
         okmask |= (ok ? 1u : 0u) << it;
       }
     }
@@ -136,11 +150,34 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     }
   };
   auto stage = [&]() {
+    if (GNB && st_n != cf_n) {   // (a thread's items share its channel group: 256 % NV == 0)
+      cf_n = st_n;
+      const float* cf = a.gnb_coef + (long)st_n * (CIN + 2);
+      cf_k1 = *(const float4*)(cf + ((int)threadIdx.x % C::NV) * 4);
+      cf_kx = cf[CIN];
+      cf_k0 = cf[CIN + 1];
+    }
 #pragma unroll
     for (int it = 0; it < C::NLOAD; ++it) {
       if ((int)threadIdx.x + it * 256 < C::NITEMS) {
         const bool ok = (okmask >> it) & 1u;
         const float sc = psc[it];
+        if (GNB) {
+          const float4 q = preq[it];
+          float4 v = pre[it];
+          v.x = __builtin_fmaf(v.x, cf_k1.x, __builtin_fmaf(q.x, cf_kx, cf_k0));
+          v.y = __builtin_fmaf(v.y, cf_k1.y, __builtin_fmaf(q.y, cf_kx, cf_k0));
+          v.z = __builtin_fmaf(v.z, cf_k1.z, __builtin_fmaf(q.z, cf_kx, cf_k0));
+          v.w = __builtin_fmaf(v.w, cf_k1.w, __builtin_fmaf(q.w, cf_kx, cf_k0));
+          if (a.gnb_act != DIS_ACT_NONE) {
+            v.x *= act_grad_from_out(q.x, a.gnb_act), v.y *= act_grad_from_out(q.y, a.gnb_act);
+            v.z *= act_grad_from_out(q.z, a.gnb_act), v.w *= act_grad_from_out(q.w, a.gnb_act);
+          }
+          pre[it] = v;
+          if (ok)
+            *(float4*)(a.gnb_out + (((long)st_n * a.hin + (st_iy0 + it_r[it])) * a.win + (st_ix0 + it_c[it])) * CIN +
+                       it_lds[it] % C::CS) = v;
+        }
         *(float4*)(xl + it_lds[it]) =
             ok ? make_float4(pre[it].x * sc, pre[it].y * sc, pre[it].z * sc, pre[it].w * sc) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -404,12 +441,12 @@ static int num_cus() {
   return g_num_cu;
 }
 
-template <int CIN, int COUT, int KH, int KW, int S>
+template <int CIN, int COUT, int KH, int KW, int S, bool GNB = false>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
   using C = ConvCfg<CIN, COUT, KH, KW, S>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
   static bool attr_set = false;
-  auto kern = conv_fwd_kernel<CIN, COUT, KH, KW, S>;
+  auto kern = conv_fwd_kernel<CIN, COUT, KH, KW, S, GNB>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
@@ -468,6 +505,7 @@ extern "C" int dis_conv2d_fwd(const float* x, const float* w_packed, const float
   a.accum = (act & DIS_CONV_ACCUM) ? 1 : 0;
   a.xscale = nullptr;
   a.yscale = nullptr;
+  a.xact = nullptr; a.gnb_coef = nullptr; a.gnb_out = nullptr; a.gnb_act = 0;
   if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
   return dispatch_conv(a, cin, cout, k, k, stride, (hipStream_t)stream);
 }
@@ -489,8 +527,33 @@ extern "C" int dis_conv2d_fwd_scaled(const float* x, const float* xscale, const 
   a.accum = (act & DIS_CONV_ACCUM) ? 1 : 0;
   a.xscale = xscale;
   a.yscale = yscale;
+  a.xact = nullptr; a.gnb_coef = nullptr; a.gnb_out = nullptr; a.gnb_act = 0;
   if (a.act > DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
   return dispatch_conv(a, cin, cout, k, k, stride, (hipStream_t)stream);
+}
+
+/* Input gradient of the 1 x 1 multi-frame convolution (128 -> 32, slot weights applied to its input: reference
+ * model/multi_frame_networks.py:406-413) that is followed by GroupNorm(1 group), WITH that GroupNorm's backward elementwise pass
+ * applied while the operand is staged (round 5): gpre = act'(q) (g k1_c + q kx + k0) with g the gradient wrt the GroupNorm's output
+ * (n, h, w, 32), q the GroupNorm's input (this conv's output), coef (n, 34) from dis_gn_bwd_coef; gx (n, h, w, 128) (+)= (gpre W^T)
+ * times yscale (n, h, w, 4; may be NULL); gpre is stored to gpre_out for dis_conv2d_wgrad_scaled.  w_packed: the mode-1 packing
+ * of the conv's weight (dis_conv2d_pack_weights).  Replaces dis_gn_bwd_apply_coef + dis_conv2d_fwd_scaled. */
+extern "C" int dis_conv2d_dgrad1x1_scaled_gnb(const float* g, const float* q, const float* coef, int in_act, float* gpre_out,
+                                              const float* w_packed, float* gx, const float* yscale, int n, int hin, int win,
+                                              int cin, int cout, int accumulate, void* stream) {
+  if (!g || !q || !coef || !gpre_out || !w_packed || !gx) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0) return DIS_ERR_BAD_SHAPE;
+  if (cin != 32 || cout != 128 || (in_act != DIS_ACT_NONE && in_act != DIS_ACT_SELU)) return DIS_ERR_UNSUPPORTED;
+  ConvArgs a;
+  a.x = g; a.w = w_packed; a.bias = nullptr; a.y = gx; a.stats = nullptr;
+  a.n = n; a.hin = hin; a.win = win; a.hv = hin; a.wv = win; a.pad_y = 0; a.pad_x = 0;
+  a.hf = hin; a.wf = win; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
+  a.act = DIS_ACT_NONE;
+  a.accum = accumulate ? 1 : 0;
+  a.xscale = nullptr;
+  a.yscale = yscale;
+  a.xact = q; a.gnb_coef = coef; a.gnb_out = gpre_out; a.gnb_act = in_act;
+  return launch_conv<32, 128, 1, 1, 1, true>(a, (hipStream_t)stream);
 }
 
 // Input gradient of a k4/stride-2/pad-1 convolution: four 2x2 stride-1 phase convolutions of gy on the

@@ -52,6 +52,7 @@ struct ConvArgs {
   // minus the rim) to gnb_out (shaped like x): the weight-gradient launch of the same layer reads them from there.
   const float* gnb_coef;
   float* gnb_out;
+  int gnb_act;  // conv_fwd_kernel<..., GNB>: the activation between the conv and the GroupNorm (the f16x2 kernel takes it as INACT)
 };
 
 struct WgArgs {

@@ -77,6 +77,7 @@ SIGS = {
     'dis_conv2d_wgrad_split_act': 'pppipppiiiiiiiiip',
     'dis_conv2d_wgrad_split_gn': 'ppppfppppiiiiiiiiip',
     'dis_conv2d_fwd_f16x2_gnres': 'ppppfpppiiipppiiiiiip',
+    'dis_conv2d_dgrad1x1_scaled_gnb': 'pppippppiiiiiip',
     'dis_gn_bwd_coef': 'pppippppilifp',
     'dis_gn_bwd_apply_coef': 'ppppiliip',
     'dis_conv2d_dgrad_f16x2_gnb': 'pppippiiipippp' + 'iiiip',

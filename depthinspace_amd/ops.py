@@ -1354,9 +1354,23 @@ class _Conv2dScaledIn(torch.autograd.Function):
         stride, pad, has_bias = ctx.cfg
         n, hin, win, cin = x.shape
         cout, _, k, _ = weight.shape
-        gy = _c(gy)
+        # (a token of the GroupNorm behind this conv, ops._GN_LAZY: the 1 x 1 input-gradient launch applies the pass on load)
+        lz = _gn_lazy_pop(gy)
+        if lz is not None and not (ctx.needs_input_grad[0] and k == 1 and stride == 1 and pad == 0 and (cin, cout) == (128, 32)):
+            gy, lz = _gn_lazy_materialize(lz), None
         gx = None
-        if ctx.needs_input_grad[0]:
+        if lz is not None:
+            _, lg, lq, lcoef, lin_act = lz
+            join = ctx.join
+            second = join is not None and join.buf is not None
+            gx = join.take(x.shape) if second else torch.empty_like(x)
+            gy = torch.empty_like(lg)
+            lib.call('dis_conv2d_dgrad1x1_scaled_gnb', lg, lq, lcoef, lin_act, gy, _pack_w(weight, cin, 1), gx, xscale, n, hin, win,
+                     cout, cin, 1 if second else 0)
+            if join is not None and not second:
+                gx = join.first(gx)
+        gy = _c(gy)
+        if lz is None and ctx.needs_input_grad[0]:
             assert stride == 1
             join = ctx.join
             second = join is not None and join.buf is not None
@@ -1375,7 +1389,10 @@ class _Conv2dScaledIn(torch.autograd.Function):
 
 
 def conv2d_scaled_in(x, xscale, weight, bias, stride=1, pad=0, want_stats=False, join=None):
-    return _Conv2dScaledIn.apply(x, xscale, weight, bias, stride, pad, ACT_NONE, want_stats, join)
+    out = _Conv2dScaledIn.apply(x, xscale, weight, bias, stride, pad, ACT_NONE, want_stats, join)
+    if GN_LAZY and weight.shape[2] == 1 and stride == 1 and pad == 0 and (x.shape[-1], weight.shape[0]) == (128, 32):
+        out[0]._gn_lazy_ok = True   # (its backward redeems GroupNorm tokens: dis_conv2d_dgrad1x1_scaled_gnb)
+    return out
 
 
 def slot_weights(geom):

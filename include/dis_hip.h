@@ -343,6 +343,13 @@ int dis_conv2d_fwd_f16x2_gnres(const float* x2, const double* gn_stats, const fl
                                const float* res, float* out, const float* w_oihw, int w_o, int w_i, int w_row_stride,
                                const float* bias, float* y, double* stats, int n, int hin, int win, int cin, int cout, int act,
                                void* stream);
+/* ... and the same for the 1 x 1 multi-frame conv (128 -> 32 with slot weights, model/multi_frame_networks.py:406-413), whose input
+ * gradient runs on the fp32 MFMA kernel: g (n, h, w, 32) the gradient wrt the GroupNorm's output, q the GroupNorm's input, coef
+ * (n, 34); gx (n, h, w, 128) (+)= (gpre W^T) * yscale[pixel][32-channel group] (yscale may be NULL); gpre stored to gpre_out for
+ * dis_conv2d_wgrad_scaled.  w_packed = dis_conv2d_pack_weights(mode 1). */
+int dis_conv2d_dgrad1x1_scaled_gnb(const float* g, const float* q, const float* coef, int in_act, float* gpre_out,
+                                   const float* w_packed, float* gx, const float* yscale, int n, int hin, int win, int cin,
+                                   int cout, int accumulate, void* stream);
 int dis_gn_bwd_coef(const double* stats, const float* gamma, const double* ab, int slots, float* coef, float* grad_gamma,
                     float* grad_beta, unsigned* counter, int n, long hw, int c, float eps, void* stream);
 int dis_gn_bwd_apply_coef(const float* g, const float* x, const float* coef, float* gx, int n, long hw, int c, int in_act,

@@ -591,6 +591,40 @@ def test_resnet_chain_with_deferred_block_outputs(c, n, h, w):
         assert torch.equal(a_, b_), (i, float((a_ - b_).abs().max()))
 
 
+@pytest.mark.parametrize('in_act', [0, 1])
+@pytest.mark.parametrize('accum', [0, 1])
+@pytest.mark.parametrize('n,h,w', [(3, 21, 37), (2, 64, 48)])
+def test_dgrad1x1_with_group_norm_backward_on_load(in_act, accum, n, h, w):
+    """dis_conv2d_dgrad1x1_scaled_gnb (round 5): the input gradient of the 1 x 1 multi-frame conv (128 -> 32, slot weights on its
+    input) with the GroupNorm backward's elementwise pass applied while g is staged, against dis_gn_bwd_apply_coef followed by
+    dis_conv2d_fwd_scaled on the materialised tensor: stored values and input gradient bit-identical (ragged tiles included).
+    Reference: model/multi_frame_networks.py:406-413 (conv_mf + GroupNorm)."""
+    from depthinspace_amd import ops
+    L = ops.lib
+    g_ = torch.Generator().manual_seed(31 + in_act + 2 * accum + h)
+    c, cw = 32, 128
+    q = torch.randn(n, h, w, c, generator=g_).cuda()
+    if in_act:
+        q = F.selu(q)
+    gq = torch.randn(n, h, w, c, generator=g_).cuda()
+    wt = (torch.randn(c, cw, 1, 1, generator=g_) * 0.1).cuda()
+    ysc = torch.rand(n, h, w, cw // 32, generator=g_).cuda()
+    coef = (torch.randn(n * (c + 2) + 4 * n * c + 2, generator=g_) * 0.5).cuda()
+    base = torch.randn(n, h, w, cw, generator=g_).cuda()
+    wp = ops._pack_w(wt, cw, 1)
+    gpre_ref = torch.empty_like(gq)
+    L.call('dis_gn_bwd_apply_coef', gq, q, coef, gpre_ref, n, h * w, c, in_act)
+    gx_ref = base.clone()
+    L.call('dis_conv2d_fwd_scaled', gpre_ref, None, wp, None, gx_ref, ysc, None, n, h, w, c, cw, 1, 1, 0,
+           ops.ACT_NONE | (ops.CONV_ACCUM if accum else 0))
+    gx = base.clone()
+    gpre = torch.full_like(gq, float('nan'))
+    L.call('dis_conv2d_dgrad1x1_scaled_gnb', gq, q, coef, in_act, gpre, wp, gx, ysc, n, h, w, c, cw, accum)
+    torch.cuda.synchronize()
+    assert torch.equal(gpre, gpre_ref), float((gpre - gpre_ref).abs().max())
+    assert torch.equal(gx, gx_ref), float((gx - gx_ref).abs().max())
+
+
 @pytest.mark.parametrize('stride', [1, 2])
 def test_conv3d_class_ordered_backward(golden_dir, stride):
     """dis_conv3d_knn_bwd_det (the default backward: class-ordered plain read-modify-write, aggregate read back from the forward)
