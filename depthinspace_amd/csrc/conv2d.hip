@@ -2371,12 +2371,18 @@ int dis_wgrad_pairs_run(const float* X, int ldX, int xoff, int hX, int wX, int c
 
 // 32 -> 32, 4 x 4, stride 2 (FuseNet's down convolution): the two-term fp16 kernel when the split is on (three products per MAC
 // instead of the fp32 MFMA's rate; x staged once for all 16 taps instead of once per tap row), same slabs, same reduce launch
-static int launch_wgrad_k4s2(WgArgs a, float* gw, float* gb, int cin_real, hipStream_t s) {
+struct GnbW {  // GroupNorm backward applied on load of gy (WgArgs::gnb_coef): q = the GroupNorm's input, the gradient is written to out
+  const float* q = nullptr;
+  const float* coef = nullptr;
+  float* out = nullptr;
+  int act = 0;
+};
+static int launch_wgrad_k4s2(WgArgs a, float* gw, float* gb, int cin_real, hipStream_t s, GnbW gnb = GnbW()) {
   using C = WgCfg<32, 32, 4, 4, 2>;
   static_assert(C::NCHUNK == 1 && C::NSPLIT == 4 && C::KHB == 1 && C::PART == 4 * 32 * 32 && C::TROWS == 4, "slab layout of conv_wgrad_kernel");
   static const bool off = getenv("DIS_F2_WGRAD_K4S2") && getenv("DIS_F2_WGRAD_K4S2")[0] == '0';
   if (off || !dis_f2_enabled() || a.xscale || (long)a.hin * a.win * 32 * 4 >= 0x7fff0000L || (long)a.hout * a.wout * 32 * 4 >= 0x7fff0000L)
-    return launch_wgrad<32, 32, 4, 4, 2>(a, gw, gb, cin_real, s);
+    return gnb.coef ? DIS_ERR_UNSUPPORTED : launch_wgrad<32, 32, 4, 4, 2>(a, gw, gb, cin_real, s);
   const int tiles_x = (a.wout + 15) / 16, tiles_y = (a.hout + 3) / 4;
   const long ntiles = (long)a.n * tiles_y * tiles_x;
   long workers = 2L * num_cus();
@@ -2385,8 +2391,9 @@ static int launch_wgrad_k4s2(WgArgs a, float* gw, float* gb, int cin_real, hipSt
   const long elems = (long)C::NCHUNK * C::NSPLIT * C::PART;
   float* tmp = a.part + (long)WG_WORKERS * elems;
   a.bpart = gb ? tmp + (long)WG_RSPLIT * elems : nullptr;
-  a.gact = nullptr; a.gn_stats = nullptr; a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_eps = 0.f;
-  hipError_t le = dis_f2_wgrad_k4s2_launch(a, workers, s);
+  a.gact = gnb.q; a.gn_stats = nullptr; a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_eps = 0.f;
+  a.gnb_coef = gnb.coef; a.gnb_out = gnb.out;
+  hipError_t le = dis_f2_wgrad_k4s2_launch(a, gnb.act, workers, s);
   if (le != hipSuccess) return (int)le;
   const long total = (long)C::NCHUNK * C::NSPLIT * C::MROWS * 32;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, gb != nullptr)), dim3(64 * WG_RW), 0, s,
@@ -2415,6 +2422,28 @@ static int dispatch_wgrad(const WgArgs& a, float* gw, float* gb, int cin_real, i
   if (cin == 32 && cout == 32 && k == 4 && stride == 2) return launch_wgrad_k4s2(a, gw, gb, cin_real, s);
   WG_CASE(4, 32, 7, 2)   // DispNetS conv1 (2 -> 32, k7 s2): all 49 taps in one pass over the pixels
   return DIS_ERR_UNSUPPORTED;
+}
+
+/* Weight gradient of FuseNet's 4 x 4 stride-2 pad-1 convolution (32 -> 32; reference model/multi_frame_networks.py:338-345,
+ * Block2D3D.conv2_1) that is followed by [SELU ->] GroupNorm, WITH that GroupNorm's backward elementwise pass applied while gy is
+ * staged (round 5): gpre = act'(q) (g k1_c + q kx + k0), g the gradient wrt the GroupNorm's output (n, hout, wout, 32), q the
+ * GroupNorm's input, coef (n, 34) from dis_gn_bwd_coef; grad_w / grad_b are the gradients for gpre, and gpre is stored to gpre_out
+ * for the input-gradient launches (dis_conv2d_dgrad_strided).  workspace: dis_conv2d_wgrad_workspace(32, 32, 4, 2) floats.
+ * Two-term fp16 kernel only (DIS_ERR_UNSUPPORTED otherwise: the caller runs dis_gn_bwd_apply_coef and dis_conv2d_wgrad). */
+extern "C" int dis_conv2d_wgrad_k4s2_f16x2_gnb(const float* x, const float* g, const float* q, const float* coef, int in_act,
+                                               float* gpre_out, float* grad_w, float* grad_b, float* workspace, int n, int hin,
+                                               int win, void* stream) {
+  if (!x || !g || !q || !coef || !gpre_out || !grad_w || !workspace) return DIS_ERR_NULL;
+  if (n <= 0 || hin < 2 || win < 2) return DIS_ERR_BAD_SHAPE;
+  if (in_act != DIS_ACT_NONE && in_act != DIS_ACT_SELU) return DIS_ERR_UNSUPPORTED;
+  WgArgs a;
+  a.x = x; a.gy = g; a.part = workspace; a.bpart = nullptr;
+  a.n = n; a.hin = hin; a.win = win; a.hout = (hin + 2 - 4) / 2 + 1; a.wout = (win + 2 - 4) / 2 + 1; a.pad = 1;
+  a.xscale = nullptr; a.gact = nullptr;
+  a.gn_stats = nullptr; a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_eps = 0.f;
+  GnbW gnb;
+  gnb.q = q; gnb.coef = coef; gnb.out = gpre_out; gnb.act = in_act;
+  return launch_wgrad_k4s2(a, grad_w, grad_b, 32, (hipStream_t)stream, gnb);
 }
 
 extern "C" long dis_conv2d_wgrad_workspace(int cin, int cout, int k, int stride) {

@@ -72,6 +72,12 @@ struct WgArgs {
   const float* gn_gamma;
   const float* gn_beta;
   float gn_eps;
+  // f16x2 kernel, INCOEF instance (round 5; FuseNet's 4 x 4 stride-2 conv): gy is the gradient wrt the OUTPUT of the GroupNorm behind
+  // the conv, gact the GroupNorm's input (the conv's activated output): staged as act'(gact) (gy k1_c + gact kx + k0) with the
+  // coefficients gnb_coef (n, COUT + 2) of dis_gn_bwd_coef, and stored to gnb_out (every gy pixel belongs to one tile) for the
+  // input-gradient launches
+  const float* gnb_coef;
+  float* gnb_out;
 };
 
 // Weight prologue of the LDS-resident-weight kernels (512 threads): copy an OIHW block - w_o <= 32 rows of `row` <= 288 floats,
@@ -171,6 +177,6 @@ hipError_t dis_f2_wgrad_launch(const WgArgs& a, int cin, int cout, int inact, lo
 hipError_t dis_f2_conv_gen_launch(const ConvArgs& a, long grid, hipStream_t stream);  // 32 x 32 channel slices (DispNetS)
 hipError_t dis_f2_wgrad_pairs_launch(const WgArgs& a, int cob, unsigned workers, unsigned pairs, int k, int stride, int kh,
                                      hipStream_t stream);
-hipError_t dis_f2_wgrad_k4s2_launch(const WgArgs& a, long workers, hipStream_t stream);   // 32 -> 32, 4 x 4, stride 2
+hipError_t dis_f2_wgrad_k4s2_launch(const WgArgs& a, int gnb_act, long workers, hipStream_t stream);   // 32 -> 32, 4 x 4, stride 2
 bool dis_f2_enabled();
 int dis_f2_wgrad_wpc();   // workgroups per CU the two-term weight-gradient kernel is built for

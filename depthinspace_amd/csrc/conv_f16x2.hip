@@ -1058,15 +1058,18 @@ __device__ __forceinline__ void f2_static_for(F&& f) {
 // GEN: channel-slice PAIRS of a wide layer (DispNetS, conv2d.hip dis_wgrad_pairs_run: 3 x 3, stride 1): blockIdx.y = gb * npx + cb
 // selects x channels [32 cb, 32 cb + 32) and gy channels [COUT gb, + COUT) of pixels that occupy a.ldx / a.ldg floats; channels
 // past the layer's last one load zeros; one slab per (pair, worker).
-template <int CIN, int COUT, int INACT = 0, bool INGN = false, bool GEN = false, int K_ = 3, int S_ = 1, int TR_ = 8, int KH_ = K_>
+template <int CIN, int COUT, int INACT = 0, bool INGN = false, bool GEN = false, int K_ = 3, int S_ = 1, int TR_ = 8, int KH_ = K_,
+          bool INCOEF = false>
 __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_wgrad_f16x2_kernel(WgArgs a) {
   using C = F2WxCfg<CIN, COUT, K_, S_, TR_, KH_>;
   static_assert(!GEN || (CIN == 32 && INACT == 0 && !INGN), "slice-pair form");
+  static_assert(!INCOEF || (!GEN && !INGN && 256 % (COUT / 4) == 0), "GroupNorm backward on load: a thread keeps its 4 gy channels");
+  constexpr bool G2 = INACT != 0 || INCOEF;   // the activation output / GroupNorm input rides with every gy item
 #ifdef F2_CLK
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   static_assert(GEN || (K_ == 3 && S_ == 1 && TR_ == 8 && KH_ == 3) ||
-                    (K_ == 4 && S_ == 2 && TR_ == 4 && KH_ == 4 && CIN == 32 && COUT == 32 && INACT == 0 && !INGN),
+                    (K_ == 4 && S_ == 2 && TR_ == 4 && KH_ == 4 && CIN == 32 && COUT == 32 && (INACT == 0 || INCOEF) && !INGN),
                 "the FuseNet forms: 3 x 3 stride 1, and the 4 x 4 stride-2 down convolution (32 -> 32)");
   constexpr int S = S_, KH = KH_;
   const int ky0 = KH < K_ ? (int)blockIdx.z * KH : 0;  // first tap row of this workgroup (7x7: two groups of 4 rows)
@@ -1096,11 +1099,15 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
   // an HBM latency of 2 - 3 us under this traffic: scripts/diag/wgrad_bound.py, profiles/r5_dominant_bound.md)
   constexpr bool WPF2 = F2W_PF2 && !GEN && K_ == 3 && S_ == 1;
   struct WSet {
-    float4 x[NLX], g[NLG], g2[INACT ? NLG : 1];
+    float4 x[NLX], g[NLG], g2[G2 ? NLG : 1];
     int iy0, ix0, n;
+    bool live;
   };
   WSet SA, SB;
-  SA.iy0 = SA.ix0 = 0, SA.n = -1, SB.iy0 = SB.ix0 = 0, SB.n = -1;
+  SA.iy0 = SA.ix0 = 0, SA.n = -1, SA.live = false, SB.iy0 = SB.ix0 = 0, SB.n = -1, SB.live = false;
+  float4 cf_k1 = make_float4(0.f, 0.f, 0.f, 0.f);   // INCOEF: this thread's four k1_c, the sample's kx, k0
+  float cf_kx = 0.f, cf_k0 = 0.f;
+  int cf_n = -1;
   int ix_rc[NLX], ix_off[NLX], ig_rc[NLG], ig_off[NLG];
 #pragma unroll
   for (int it = 0; it < NLX; ++it) {
@@ -1135,7 +1142,7 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
 #endif
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int iy0 = ty * (TR * S) - a.pad + ky0, ix0 = tx * (16 * S) - a.pad;
-    W.iy0 = iy0, W.ix0 = ix0, W.n = n;
+    W.iy0 = iy0, W.ix0 = ix0, W.n = n, W.live = live;
     const unsigned x_bytes = live ? x_bytes_all : 0u, g_bytes = live ? g_bytes_all : 0u;
     const char* xb = (const char*)a.x + (long)n * a.hin * a.win * ldx * 4;
     const int xoff0 = (iy0 * a.win + ix0) * (ldx * 4);
@@ -1155,7 +1162,7 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
       const bool ok = ox < a.wout;   // (rows below the sample: past the end of its buffer range)
       W.g[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 bx_rsrc(gb, g_bytes), ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
-      if (INACT)
+      if (G2)
         W.g2[it] = __builtin_bit_cast(
             float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc((const char*)a.gact + (gb - (const char*)a.gy), g_bytes),
                                                           ok ? (unsigned)(goff0 + ig_off[it]) : BX_OOB, 0, 0));
@@ -1164,6 +1171,13 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
   // (1) before the barrier: final fp32 values of the items in flight, this wave's two maxima into LDS
   auto prep = [&](WSet& W, int parity) __attribute__((always_inline)) {
     const int st_iy0 = W.iy0, st_ix0 = W.ix0, st_n = W.n;
+    if (INCOEF && st_n != cf_n) {
+      cf_n = st_n;
+      const float* cf = a.gnb_coef + (long)(st_n < a.n ? st_n : a.n - 1) * (COUT + 2);
+      cf_k1 = *(const float4*)(cf + ((int)threadIdx.x % C::CVG) * 4);
+      cf_kx = cf[COUT];
+      cf_k0 = cf[COUT + 1];
+    }
     if (INGN && st_n != gn_n) {
       gn_n = st_n;
       float mean, rstd;
@@ -1196,11 +1210,33 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
       float4 v = W.g[it];
+      unsigned gnb_off = BX_OOB;
+      if (INCOEF) {   // (gn_apply_coef_kernel's arithmetic, bit for bit; the stored values feed the input-gradient launches)
+        const float4 q = W.g2[it];
+        // the item's own pixel, or nothing: positions past the map (ragged tiles) and the tiles past the workgroup's last one load
+        // g = q = 0, which the affine map would turn into k0 - they must stay zero in the sums, in the bias gradient and in memory
+        const int tx_ = (W.ix0 + a.pad) / (16 * S), ty_ = (W.iy0 + a.pad - ky0) / (TR * S);
+        const int ox = tx_ * 16 + (ig_rc[it] >> 16);
+        gnb_off = ox < a.wout ? (unsigned)((ty_ * TR * a.wout + tx_ * 16) * (ldg * 4) + ig_off[it]) : BX_OOB;
+        const bool inside = gnb_off < (W.live ? g_bytes_all : 0u);
+        v.x = __builtin_fmaf(v.x, cf_k1.x, __builtin_fmaf(q.x, cf_kx, cf_k0));
+        v.y = __builtin_fmaf(v.y, cf_k1.y, __builtin_fmaf(q.y, cf_kx, cf_k0));
+        v.z = __builtin_fmaf(v.z, cf_k1.z, __builtin_fmaf(q.z, cf_kx, cf_k0));
+        v.w = __builtin_fmaf(v.w, cf_k1.w, __builtin_fmaf(q.w, cf_kx, cf_k0));
+        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       if (INACT) {
         const float4 q = W.g2[it];
         v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
         v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
         W.g[it] = v;
+      }
+      if (INCOEF) {
+        W.g[it] = v;
+        // (every gy pixel belongs to exactly one tile; out-of-range items are dropped by the offset / the descriptor's range)
+        const u32x4 sv = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(sv, bx_rsrc((char*)a.gnb_out + (long)W.n * a.hout * a.wout * ldg * 4, W.live ? g_bytes_all : 0u),
+                                               gnb_off, 0, 0);
       }
       bsum.x += v.x, bsum.y += v.y, bsum.z += v.z, bsum.w += v.w;
       mg = __builtin_fmaxf(__builtin_fmaxf(mg, fabsf(v.x)), fabsf(v.y));
@@ -1458,19 +1494,26 @@ hipError_t dis_f2_wgrad_pairs_launch(const WgArgs& a, int cob, unsigned workers,
 // FuseNet's 4 x 4 stride-2 down convolution (32 -> 32, Block2D3D conv2_1): all 16 taps in one workgroup, 4 x 16 output pixels per
 // tile; slab [tap * 32 + ci][co] per worker = conv_wgrad_kernel<32, 32, 4, 4, 2>'s four tap-row splits back to back, so its
 // reduce launch finishes the job.
-hipError_t dis_f2_wgrad_k4s2_launch(const WgArgs& a, long workers, hipStream_t stream) {
+hipError_t dis_f2_wgrad_k4s2_launch(const WgArgs& a, int gnb_act, long workers, hipStream_t stream) {
   using C = F2WxCfg<32, 32, 4, 2, 4, 4>;
   static_assert(C::LDS_BYTES <= 160 * 1024 && C::MB * 16 * 32 == 16 * 32 * 32, "LDS budget / slab size");
-  auto kern = conv_wgrad_f16x2_kernel<32, 32, 0, false, false, 4, 2, 4, 4>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
+  static bool attr_set[3] = {};
+  auto launch = [&](auto kern, int slot) -> hipError_t {
+    if (!attr_set[slot]) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+      if (e != hipSuccess) return e;
+      attr_set[slot] = true;
+    }
+    DIS_TAG("conv_wgrad_f16x2_kernel<32,32> 4x4 stride 2");
+    hipLaunchKernelGGL(kern, dim3((unsigned)workers), dim3(256), C::LDS_BYTES, stream, a);
+    return hipSuccess;
+  };
+  if (a.gnb_coef) {   // GroupNorm backward applied on load (a.gact: the GroupNorm's input), SELU between conv and GroupNorm or none
+    if (!a.gact || !a.gnb_out) return hipErrorInvalidValue;
+    return gnb_act == DIS_ACT_SELU ? launch(conv_wgrad_f16x2_kernel<32, 32, DIS_ACT_SELU, false, false, 4, 2, 4, 4, true>, 1)
+                                   : launch(conv_wgrad_f16x2_kernel<32, 32, 0, false, false, 4, 2, 4, 4, true>, 2);
   }
-  DIS_TAG("conv_wgrad_f16x2_kernel<32,32> 4x4 stride 2");
-  hipLaunchKernelGGL(kern, dim3((unsigned)workers), dim3(256), C::LDS_BYTES, stream, a);
-  return hipSuccess;
+  return launch(conv_wgrad_f16x2_kernel<32, 32, 0, false, false, 4, 2, 4, 4>, 0);
 }
 
 hipError_t dis_f2_wgrad_launch(const WgArgs& a, int cin, int cout, int inact, long workers, hipStream_t stream) {

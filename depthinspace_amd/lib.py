@@ -78,6 +78,7 @@ SIGS = {
     'dis_conv2d_wgrad_split_gn': 'ppppfppppiiiiiiiiip',
     'dis_conv2d_fwd_f16x2_gnres': 'ppppfpppiiipppiiiiiip',
     'dis_conv2d_dgrad1x1_scaled_gnb': 'pppippppiiiiiip',
+    'dis_conv2d_wgrad_k4s2_f16x2_gnb': 'ppppippppiiip',
     'dis_gn_bwd_coef': 'pppippppilifp',
     'dis_gn_bwd_apply_coef': 'ppppiliip',
     'dis_conv2d_dgrad_f16x2_gnb': 'pppippiiipippp' + 'iiiip',

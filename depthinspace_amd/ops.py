@@ -95,6 +95,12 @@ def _gn_lazy_shape(cin, cout, k, stride, pad):
     return GN_LAZY and BF16X3 and cin == cout and cin in (16, 32) and k == 3 and stride == 1 and pad == 1
 
 
+def _gn_lazy_k4s2(cin_pad, cin, cout, k, stride, pad):
+    """FuseNet's 4 x 4 stride-2 down convolution (dis_conv2d_wgrad_k4s2_f16x2_gnb; DIS_F2_WGRAD_K4S2=0 keeps it on the fp32 kernel)"""
+    return (GN_LAZY and BF16X3 and cin_pad == cin == 32 and cout == 32 and (k, stride, pad) == (4, 2, 1) and
+            _os_env.environ.get('DIS_F2_WGRAD_K4S2', '1') != '0')
+
+
 def begin_step(dev):
     if _GN_PRE:   # a gradient that was handed on pre-multiplied was never picked up by its GroupNorm: the step would be wrong
         _GN_PRE.clear()
@@ -946,6 +952,29 @@ class _Conv2d(torch.autograd.Function):
         # a token of a GroupNorm behind this conv (ops._GN_LAZY): its backward's elementwise pass is applied by this conv's
         # input-gradient launch on load, which also writes the values for the weight-gradient launch
         lz = _gn_lazy_pop(gy)
+        if (lz is not None and act == ACT_NONE and _gn_lazy_k4s2(cin_pad, cin, cout, k, stride, pad) and
+                lib.fn('dis_get_conv_split')() == 1 and x[0].numel() * 4 < 0x7fff0000):   # (the kernel's per-sample 31-bit offsets)
+            # the 4 x 4 stride-2 down convolution: the WEIGHT-gradient launch applies the pass while it stages gy (no halo there)
+            # and stores the values for the four parity launches of the input gradient
+            _, lg, lq, lcoef, lin_act = lz
+            gpre = torch.empty_like(lg)
+            gw, gw_ret = _sink(weight)
+            gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
+            ws = torch.empty(lib.fn('dis_conv2d_wgrad_workspace')(cin_pad, cout, k, stride), dtype=torch.float32, device=x.device)
+            if lib.call_try('dis_conv2d_wgrad_k4s2_f16x2_gnb', x, lg, lq, lcoef, lin_act, gpre, gw, gb, ws, n, hin, win):
+                gx = None
+                if need_dgrad and ctx.needs_input_grad[0]:
+                    join = ctx.join
+                    second = join is not None and join.buf is not None
+                    gx = join.take(x.shape) if second else torch.empty_like(x)
+                    wsd = torch.empty(16 * cin * cout, dtype=torch.float32, device=x.device)
+                    lib.call('dis_conv2d_dgrad_strided', gpre, weight, gx, wsd, n, hin, win, cin, cout, k, stride, pad,
+                             1 if second else 0)
+                    if join is not None and not second:
+                        gx = join.first(gx)
+                _sinks_written()
+                return gx, gw_ret, gb_ret, None, None, None, None, None, None, None, None, None
+            raise lib.DisHipError('dis_conv2d_wgrad_k4s2_f16x2_gnb: unsupported in this mode although the two-term split is on')
         if lz is not None and not (act == ACT_NONE and need_dgrad and ctx.needs_input_grad[0] and cin_pad == cin and
                                    _gn_lazy_shape(cin, cout, k, stride, pad) and lib.fn('dis_get_conv_split')() == 1):
             gy, lz = _gn_lazy_materialize(lz), None
@@ -1055,7 +1084,8 @@ def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, nee
         else:
             x._pending_gn = None   # (written by the launch below)
     out = _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre, join, gnres, pend)
-    if (act == ACT_NONE or gy_is_pre) and need_dgrad and _gn_lazy_shape(x.shape[-1], weight.shape[0], weight.shape[2], stride, pad):
+    if (act == ACT_NONE or gy_is_pre) and ((need_dgrad and _gn_lazy_shape(x.shape[-1], weight.shape[0], weight.shape[2], stride, pad)) or
+                                           _gn_lazy_k4s2(x.shape[-1], weight.shape[1], weight.shape[0], weight.shape[2], stride, pad)):
         out[0]._gn_lazy_ok = True   # (a GroupNorm that is this output's ONLY consumer may answer with a token, see _GN_LAZY)
     return out
 

@@ -350,6 +350,11 @@ int dis_conv2d_fwd_f16x2_gnres(const float* x2, const double* gn_stats, const fl
 int dis_conv2d_dgrad1x1_scaled_gnb(const float* g, const float* q, const float* coef, int in_act, float* gpre_out,
                                    const float* w_packed, float* gx, const float* yscale, int n, int hin, int win, int cin,
                                    int cout, int accumulate, void* stream);
+/* ... and for the 4 x 4 stride-2 pad-1 conv (32 -> 32, Block2D3D.conv2_1, :338-345): here the WEIGHT-gradient launch applies the pass
+ * while it stages gy (every gy pixel belongs to one tile) and stores gpre for dis_conv2d_dgrad_strided.  g / q (n, hout, wout, 32),
+ * coef (n, 34), x (n, hin, win, 32); workspace: dis_conv2d_wgrad_workspace(32, 32, 4, 2) floats.  Two-term fp16 kernel only. */
+int dis_conv2d_wgrad_k4s2_f16x2_gnb(const float* x, const float* g, const float* q, const float* coef, int in_act, float* gpre_out,
+                                    float* grad_w, float* grad_b, float* workspace, int n, int hin, int win, void* stream);
 int dis_gn_bwd_coef(const double* stats, const float* gamma, const double* ab, int slots, float* coef, float* grad_gamma,
                     float* grad_beta, unsigned* counter, int n, long hw, int c, float eps, void* stream);
 int dis_gn_bwd_apply_coef(const float* g, const float* x, const float* coef, float* gx, int n, long hw, int c, int in_act,

@@ -625,6 +625,40 @@ def test_dgrad1x1_with_group_norm_backward_on_load(in_act, accum, n, h, w):
     assert torch.equal(gx, gx_ref), float((gx - gx_ref).abs().max())
 
 
+@pytest.mark.parametrize('in_act', [0, 1])
+@pytest.mark.parametrize('n,h,w', [(3, 38, 30), (2, 64, 48), (16, 64, 54)])
+def test_wgrad_k4s2_with_group_norm_backward_on_load(in_act, n, h, w):
+    """dis_conv2d_wgrad_k4s2_f16x2_gnb (round 5): the weight gradient of FuseNet's 4 x 4 stride-2 conv with the GroupNorm backward's
+    elementwise pass applied while gy is staged, against dis_gn_bwd_apply_coef + dis_conv2d_wgrad on the materialised tensor: the
+    stored values, grad_w and grad_b bit-identical (ragged tiles, several tiles per workgroup).  Reference:
+    model/multi_frame_networks.py:338-345 (conv2_1: Conv2d(k4, s2, p1) -> SELU -> GroupNorm)."""
+    from depthinspace_amd import ops
+    L = ops.lib
+    if L.fn('dis_get_conv_split')() != 1:
+        pytest.skip('two-term fp16 kernels only')
+    g_ = torch.Generator().manual_seed(77 + in_act + h)
+    c = 32
+    ho, wo = h // 2, w // 2
+    x = torch.randn(n, h, w, c, generator=g_).cuda()
+    q = torch.randn(n, ho, wo, c, generator=g_).cuda()
+    if in_act:
+        q = F.selu(q)
+    gq = torch.randn(n, ho, wo, c, generator=g_).cuda()
+    coef = (torch.randn(n * (c + 2) + 4 * n * c + 2, generator=g_) * 0.5).cuda()
+    wsz = L.fn('dis_conv2d_wgrad_workspace')(c, c, 4, 2)
+    gpre_ref = torch.empty_like(gq)
+    L.call('dis_gn_bwd_apply_coef', gq, q, coef, gpre_ref, n, ho * wo, c, in_act)
+    gw_ref, gb_ref = torch.empty(c, c, 4, 4, device='cuda'), torch.empty(c, device='cuda')
+    L.call('dis_conv2d_wgrad', x, gpre_ref, gw_ref, gb_ref, torch.empty(wsz, device='cuda'), n, h, w, c, c, c, 4, 2, 1)
+    gpre = torch.full_like(gq, float('nan'))
+    gw, gb = torch.empty(c, c, 4, 4, device='cuda'), torch.empty(c, device='cuda')
+    L.call('dis_conv2d_wgrad_k4s2_f16x2_gnb', x, gq, q, coef, in_act, gpre, gw, gb, torch.empty(wsz, device='cuda'), n, h, w)
+    torch.cuda.synchronize()
+    assert torch.equal(gpre, gpre_ref), float((gpre - gpre_ref).abs().max())
+    assert torch.equal(gw, gw_ref), float((gw - gw_ref).abs().max())
+    assert torch.equal(gb, gb_ref), float((gb - gb_ref).abs().max())
+
+
 @pytest.mark.parametrize('stride', [1, 2])
 def test_conv3d_class_ordered_backward(golden_dir, stride):
     """dis_conv3d_knn_bwd_det (the default backward: class-ordered plain read-modify-write, aggregate read back from the forward)
