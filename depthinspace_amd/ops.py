@@ -880,6 +880,9 @@ import os as _os
 BF16X3 = _os.environ.get('DIS_CONV_BF16X3', '1') != '0'
 
 
+K4S2_F2 = _os.environ.get('DIS_K4S2_F2', '1') != '0'   # DIS_K4S2_F2=0: the 4 x 4 stride-2 forward on the exact-fp32 MFMA kernel
+
+
 def _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad):
     """dis_conv2d_wgrad, or its bf16x3 form for 3x3 stride-1 layers with 16 / 32 channels on both sides."""
     name = 'dis_conv2d_wgrad'
@@ -892,6 +895,9 @@ def _conv_fwd_any(x, weight, cin_pad, mode, bias, y, stats, n, hin, win, cin, co
     """dis_conv2d_fwd, or its bf16x3 form (fp32 accuracy on the bf16 matrix cores) for 3x3 stride-1 layers with 16 / 32
     channels on both sides.  `weight` is the module's OIHW tensor, `mode` the weight order (0 forward, 1 stride-1 input
     gradient); `cin` / `cout` are the channel counts of x and y in THIS call (swapped for the input gradient)."""
+    if (BF16X3 and K4S2_F2 and (cin, cout, k, stride, pad) == (32, 32, 4, 2, 1) and weight.is_contiguous() and
+            lib.call_try('dis_conv2d_fwd_k4s2_f16x2', x, weight, bias, y, stats, n, hin, win, act)):
+        return   # (FuseNet's 4 x 4 stride-2 down convolution on the two-term kernel; under the three-term mode the call says unsupported)
     if BF16X3 and cin in (16, 32) and cout in (16, 32) and k == 3 and stride == 1:
         # `weight` may be a slice w[:, a:b] of a wider weight (conv2d_multi): the kernel reads it through its row stride
         assert weight.stride(1) == 9 and weight.stride(2) == 3 and weight.stride(3) == 1

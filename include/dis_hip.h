@@ -355,6 +355,11 @@ int dis_conv2d_dgrad1x1_scaled_gnb(const float* g, const float* q, const float* 
  * coef (n, 34), x (n, hin, win, 32); workspace: dis_conv2d_wgrad_workspace(32, 32, 4, 2) floats.  Two-term fp16 kernel only. */
 int dis_conv2d_wgrad_k4s2_f16x2_gnb(const float* x, const float* g, const float* q, const float* coef, int in_act, float* gpre_out,
                                     float* grad_w, float* grad_b, float* workspace, int n, int hin, int win, void* stream);
+/* Round 5: FuseNet's 4 x 4 stride-2 pad-1 down convolution (32 -> 32, Block2D3D.conv2_1, model/multi_frame_networks.py:338-345)
+ * forward on the two-term fp16 kernels (csrc/conv_k4s2.hip: wave-resident weights, de-interleaved halo columns): y = act(conv(x, w) +
+ * bias), w OIHW (32, 32, 4, 4) unpacked, stats (n, 2) accumulated or NULL.  DIS_ERR_UNSUPPORTED under dis_set_conv_split(0). */
+int dis_conv2d_fwd_k4s2_f16x2(const float* x, const float* w_oihw, const float* bias, float* y, double* stats, int n, int hin, int win,
+                              int act, void* stream);
 int dis_gn_bwd_coef(const double* stats, const float* gamma, const double* ab, int slots, float* coef, float* grad_gamma,
                     float* grad_beta, unsigned* counter, int n, long hw, int c, float eps, void* stream);
 int dis_gn_bwd_apply_coef(const float* g, const float* x, const float* coef, float* gx, int n, long hw, int c, int in_act,

@@ -38,6 +38,10 @@ def cur_fwd():
 
 cur_fwd()
 print('current fwd  err', float((y0.double() - ref).abs().max()), 'us', timeit(cur_fwd))
+y2 = torch.empty_like(y0)
+f2 = lambda: lib.call('dis_conv2d_fwd_k4s2_f16x2', x, wt, b, y2, st, n, h, w, ops.ACT_NONE)
+f2()
+print('k4s2 f16x2 fwd err', float((y2.double() - ref).abs().max()), 'us', timeit(f2))
 y1 = torch.empty_like(y0)
 try:
     f = lambda: ops._convg_run(ops.CONVG_CONV, x, wt, b, y1, n, h, w, c, c, ho, wo, c, c, 4, 2, 1, ops.ACT_NONE)

@@ -659,6 +659,50 @@ def test_wgrad_k4s2_with_group_norm_backward_on_load(in_act, n, h, w):
     assert torch.equal(gb, gb_ref), float((gb - gb_ref).abs().max())
 
 
+@pytest.mark.parametrize('case', ['randn', 'outlier', 'tiny_corner'])
+@pytest.mark.parametrize('n,h,w,act', [(3, 38, 30, 1), (2, 64, 48, 0), (16, 64, 56, 1), (1, 17, 70, 2)])
+def test_conv_fwd_k4s2_f16x2(case, n, h, w, act):
+    """dis_conv2d_fwd_k4s2_f16x2 (round 5, csrc/conv_k4s2.hip): FuseNet's 4 x 4 stride-2 pad-1 down convolution (32 -> 32) forward on
+    the two-term fp16 kernel - wave-resident weight fragments, de-interleaved halo columns, one scale per 18 x 34 halo tile - against
+    fp64 (bar: 1e-6 of the largest output, the bar of the 3 x 3 two-term kernels) beside the exact-fp32 MFMA kernel it replaces,
+    with the GroupNorm statistics of the epilogue; ragged tiles, odd sizes, several tiles per workgroup, a 1e4 outlier pixel and a
+    1e-6 corner (block scaling).  Reference: model/multi_frame_networks.py:338-345 (conv2_1: Conv2d(32, 32, 4, stride 2, pad 1) + SELU)."""
+    from depthinspace_amd import ops
+    L = ops.lib
+    if L.fn('dis_get_conv_split')() != 1:
+        pytest.skip('two-term fp16 kernels only')
+    g_ = torch.Generator().manual_seed(n + h + w + act + len(case))
+    c = 32
+    x = torch.randn(n, c, h, w, generator=g_)
+    if case == 'outlier':
+        x[0, :, h // 2, w // 3] = 1e4
+    elif case == 'tiny_corner':
+        x[:, :, : h // 2, : w // 2] *= 1e-6
+    wt = torch.randn(c, c, 4, 4, generator=g_) / (c * 16) ** 0.5
+    b = torch.randn(c, generator=g_) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=2, padding=1)
+    ref = {0: ref, 1: F.selu(ref), 2: F.relu(ref)}[act].permute(0, 2, 3, 1)
+    ho, wo = ref.shape[1], ref.shape[2]
+    xd, wd, bd = nhwc(x).cuda(), wt.cuda(), b.cuda()
+    y = torch.full((n, ho, wo, c), float('nan'), device='cuda')
+    st = torch.zeros(2 * n, dtype=torch.float64, device='cuda')
+    L.call('dis_conv2d_fwd_k4s2_f16x2', xd, wd, bd, y, st, n, h, w, act)
+    y0 = torch.empty_like(y)
+    st0 = torch.zeros(2 * n, dtype=torch.float64, device='cuda')
+    L.call('dis_conv2d_fwd', xd, ops._pack_w(wd, c, 0), bd, y0, st0, n, h, w, c, c, 4, 2, 1, act)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    e2, e0 = float((y.double().cpu() - ref).abs().max()) / scale, float((y0.double().cpu() - ref).abs().max()) / scale
+    print(f'{case} {n}x{h}x{w} act {act}: two-term {e2:.2e}, fp32 MFMA {e0:.2e}')
+    assert e2 < 1e-6, (e2, e0)
+    if case == 'tiny_corner':   # the small region keeps its own relative accuracy where whole tiles lie inside it (its tiles' own scale)
+        sub, sref = y[:, : ho // 2 - 5, : wo // 2 - 9].double().cpu(), ref[:, : ho // 2 - 5, : wo // 2 - 9]
+        if sub.numel() and act != 1:   # (SELU adds the bias-dominated offset: judge the linear cases)
+            assert float((sub - sref).abs().max()) < 1e-6 * max(float(sref.abs().max()), 1e-30) + 1e-7 * float(b.abs().max())
+    sums = torch.stack([y.double().sum(dim=(1, 2, 3)), (y.double() ** 2).sum(dim=(1, 2, 3))], 1).reshape(-1)
+    assert float((st - sums).abs().max()) < 1e-5 * float(sums.abs().max())
+
+
 @pytest.mark.parametrize('stride', [1, 2])
 def test_conv3d_class_ordered_backward(golden_dir, stride):
     """dis_conv3d_knn_bwd_det (the default backward: class-ordered plain read-modify-write, aggregate read back from the forward)
