@@ -284,3 +284,204 @@ extern "C" int dis_conv2d_fwd_k4s2_f16x2(const float* x, const float* w_oihw, co
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Input gradient of the same convolution: gx[2 i + py][2 j + px] = sum over the class's 2 x 2 taps of gy[i + dy][j + dx] W^T[tap] - the
+// four parity classes of the transposed convolution FROM ONE gy HALO TILE IN ONE LAUNCH (the exact-fp32 path ran four launches of a
+// 2 x 2-tap kernel and four weight-packing launches: 117 us per call).  A tile is 4 x 16 gy pixels (halo 6 x 18, 17 KB in two fp16
+// planes) and writes 8 x 32 gx pixels; wave = (gy row pair mp, input-channel half nt) with the 16 taps' W^T fragments of its 16
+// channels resident in registers (A operand: rows = input channels, K = the 32 output channels); per class 4 taps x 2 rows x 3
+// products, one epilogue (optionally adding to gx: the layer's input has a second consumer).  Two 4-wave workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+struct K4DArgs {
+  const float* gy;  // (n, hout, wout, 32)
+  const float* w;   // OIHW (32, 32, 4, 4)
+  float* gx;        // (n, 2 hout, 2 wout, 32)
+  int n, hout, wout;
+  int accum;
+};
+#define K4D_TR 4
+#define K4D_IR (K4D_TR + 2)
+#define K4D_IC (K4_TC + 2)
+#define K4D_NT 256
+#define K4D_NIT (K4D_IR * K4D_IC * 8)
+#define K4D_NLOAD ((K4D_NIT + K4D_NT - 1) / K4D_NT)
+#define K4D_X_U16 (K4D_IR * K4D_IC * K4_PS)
+#define K4D_BUF_U16 (32 * 516 * 4 / 2)   // the weight staging area (66 KB) is the larger use of the buffer
+#define K4D_LDS_BYTES (K4D_BUF_U16 * 2 + 2 * K4_PS * 2 + 64 + 64)
+static_assert(K4D_X_U16 <= K4D_BUF_U16 && 2 * K4D_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+__global__ __launch_bounds__(K4D_NT, 2) void conv_k4s2_f16x2_dgrad_kernel(K4DArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  unsigned short* gl = smem16;
+  float* mxs = (float*)(smem16 + K4D_BUF_U16 + 2 * K4_PS);
+  float* wmx = mxs + 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int nt = wave & 1, mp = wave >> 1;
+  const int tiles_x = (a.wout + K4_TC - 1) / K4_TC, tiles_y = (a.hout + K4D_TR - 1) / K4D_TR;
+  const int ntiles = a.n * tiles_y * tiles_x;
+  const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
+  const int xcd = blockIdx.x % nxcd, rank = blockIdx.x / nxcd, per = gridDim.x / nxcd;
+  const int t_lo = (int)((long)ntiles * xcd / nxcd), t_hi = (int)((long)ntiles * (xcd + 1) / nxcd);
+  const int hin = 2 * a.hout, win = 2 * a.wout;
+
+  float4 pre[K4D_NLOAD];
+  int it_c[K4D_NLOAD], it_off[K4D_NLOAD], it_lds[K4D_NLOAD];
+#pragma unroll
+  for (int it = 0; it < K4D_NLOAD; ++it) {
+    const int idx = (int)threadIdx.x + it * K4D_NT;
+    const int ch = idx & 7, pix = idx >> 3;
+    const int r = pix / K4D_IC, c = pix % K4D_IC;
+    const bool ok = idx < K4D_NIT;
+    it_c[it] = ok ? c : 0x40000000;
+    it_off[it] = ((r * a.wout + c) * 32 + ch * 4) * 4;
+    it_lds[it] = ok ? (r * K4D_IC + c) * K4_PS + ch * 4 : K4D_BUF_U16 + (idx & 1) * K4_PS;
+  }
+  const unsigned g_bytes = (unsigned)a.hout * a.wout * 128u;
+  auto prefetch = [&](int tile, bool live) __attribute__((always_inline)) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int iy0 = ty * K4D_TR - 1, ix0 = tx * K4_TC - 1;
+    const float* gb = a.gy + (long)n * a.hout * a.wout * 32;
+    const int off0 = (iy0 * a.wout + ix0) * 128;
+    const unsigned bytes = live ? g_bytes : 0u;
+#pragma unroll
+    for (int it = 0; it < K4D_NLOAD; ++it) {
+      const unsigned off = (unsigned)(ix0 + it_c[it]) < (unsigned)a.wout ? (unsigned)(off0 + it_off[it]) : BX_OOB;
+      pre[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(gb, bytes), off, 0, 0));
+    }
+  };
+  int tile = t_lo + rank;
+  prefetch(tile < t_hi ? tile : 0, tile < t_hi);
+
+  // ---- W^T fragments of this wave's 16 input channels -> registers: lane (li, lg) holds input channel nt * 16 + li, output channels
+  // lg * 8 .. + 7 of every tap (staged through LDS like the forward kernel's)
+  s16x8 wf[16][2];
+  int sw_e;
+  {
+    float* ws = (float*)gl;
+    constexpr int NW4 = 32 * 32 * 16 / 4, WL = (NW4 + K4D_NT - 1) / K4D_NT;
+    float m = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < WL; ++i) {
+      const int q = (int)threadIdx.x + i * K4D_NT;
+      const float4 v = q < NW4 ? ((const float4*)a.w)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < NW4) *(float4*)(ws + (q / 128) * 516 + (q % 128) * 4) = v;
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    m = f2_wave_max(m);
+    if (lane == 0) wmx[wave] = m;
+    __syncthreads();
+    sw_e = f2_scale_exp(fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3])));
+    const float sw = __builtin_ldexpf(1.f, sw_e);
+    const float* wp = ws + (lg * 8) * 516 + (nt * 16 + li) * 16;
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      unsigned p0[4], p1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f2_split_pair(wp[(2 * j) * 516 + tap] * sw, wp[(2 * j + 1) * 516 + tap] * sw, p0[j], p1[j]);
+      wf[tap][0] = __builtin_bit_cast(s16x8, make_uint4(p0[0], p0[1], p0[2], p0[3]));
+      wf[tap][1] = __builtin_bit_cast(s16x8, make_uint4(p1[0], p1[1], p1[2], p1[3]));
+    }
+    __syncthreads();
+  }
+  // this lane's gy fragment for halo row 2 mp, halo column li
+  const int ga_lane = ((2 * mp) * K4D_IC + li) * K4_PS + lg * 8;
+
+  while (tile < t_hi) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    float m = 0.f;
+#pragma unroll
+    for (int it = 0; it < K4D_NLOAD; ++it) {
+      const float4 v = pre[it];
+      m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.x)), fabsf(v.y));
+      m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.z)), fabsf(v.w));
+    }
+    m = f2_wave_max(m);
+    if (lane == 0) mxs[wave] = m;
+    __syncthreads();
+    const int sx_e = f2_scale_exp(fmaxf(fmaxf(mxs[0], mxs[1]), fmaxf(mxs[2], mxs[3])));
+    const float sc = __builtin_ldexpf(1.f, sx_e);
+#pragma unroll
+    for (int it = 0; it < K4D_NLOAD; ++it) {
+      const float4 v = pre[it];
+      unsigned a1, a2, b1, b2;
+      f2_split_pair_scaled(v.x, v.y, sc, a1, a2);
+      f2_split_pair_scaled(v.z, v.w, sc, b1, b2);
+      unsigned short* p = gl + it_lds[it];
+      *(uint2*)(p) = make_uint2(a1, b1);
+      *(uint2*)(p + 32) = make_uint2(a2, b2);
+    }
+    __syncthreads();
+    prefetch(tile + per < t_hi ? tile + per : 0, tile + per < t_hi);
+
+    const float desc = __builtin_ldexpf(1.f, -(sx_e + sw_e));
+    constexpr int PA[3] = {1, 0, 0};
+    constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+      const int py = cls >> 1, px = cls & 1;
+      f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        // the class's taps: ky in {1, 3} (py = 0) or {0, 2} (py = 1); gy row i + dy with dy = (4 - ky) >> 1 - 1 -> halo row offset (4 - ky) >> 1
+        const int ky = (py ? 0 : 1) + 2 * (t >> 1), kx = (px ? 0 : 1) + 2 * (t & 1);
+        const int ro = (4 - ky) >> 1, co = (4 - kx) >> 1;
+        const unsigned short* q = gl + ga_lane + (ro * K4D_IC + co) * K4_PS;
+        s16x8 gf[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) gf[mt][p] = *(const s16x8*)(q + mt * (K4D_IC * K4_PS) + p * 32);
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, wf[ky * 4 + kx][PB[qq]]),
+                                                            __builtin_bit_cast(f16x8_t, gf[mt][PA[qq]]), acc[mt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int oy = ty * K4D_TR + 2 * mp + mt, ox = tx * K4_TC + li;
+        if (oy < a.hout && ox < a.wout) {
+          float4* dst = (float4*)(a.gx + (((long)n * hin + (2 * oy + py)) * win + (2 * ox + px)) * 32 + nt * 16 + lg * 4);
+          float4 v = make_float4(acc[mt][0] * desc, acc[mt][1] * desc, acc[mt][2] * desc, acc[mt][3] * desc);
+          if (a.accum) {
+            const float4 o = *dst;
+            v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+          }
+          *dst = v;
+        }
+      }
+    }
+    tile += per;
+  }
+}
+
+/* gx (+)= conv_transpose of gy: the input gradient of FuseNet's 4 x 4 stride-2 pad-1 convolution (32 -> 32), gy (n, hin / 2, win / 2, 32),
+ * gx (n, hin, win, 32), hin and win even, w OIHW (32, 32, 4, 4) unpacked; accumulate != 0 adds to gx.  One launch for the four parity
+ * classes, two-term fp16 operands (DIS_ERR_UNSUPPORTED under dis_set_conv_split(0): dis_conv2d_dgrad_strided remains). */
+extern "C" int dis_conv2d_dgrad_k4s2_f16x2(const float* gy, const float* w_oihw, float* gx, int n, int hin, int win, int accumulate,
+                                           void* stream) {
+  if (!gy || !w_oihw || !gx) return DIS_ERR_NULL;
+  if (n <= 0 || hin < 2 || win < 2) return DIS_ERR_BAD_SHAPE;
+  if ((hin & 1) || (win & 1) || !dis_f2_enabled()) return DIS_ERR_UNSUPPORTED;
+  if ((long)hin * win * 128 >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
+  K4DArgs a;
+  a.gy = gy; a.w = w_oihw; a.gx = gx; a.n = n; a.hout = hin / 2; a.wout = win / 2; a.accum = accumulate ? 1 : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_k4s2_f16x2_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, K4D_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long ntiles = (long)n * ((a.hout + K4D_TR - 1) / K4D_TR) * ((a.wout + K4_TC - 1) / K4_TC);
+  long grid = 2L * k4_num_cus();
+  if (grid > ntiles) grid = ntiles;
+  if (grid >= 8) grid -= grid % 8;
+  if (grid < 1) grid = 1;
+  DIS_TAG("conv_k4s2_f16x2_dgrad_kernel");
+  hipLaunchKernelGGL(conv_k4s2_f16x2_dgrad_kernel, dim3((unsigned)grid), dim3(K4D_NT), K4D_LDS_BYTES, (hipStream_t)stream, a);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}

@@ -80,6 +80,7 @@ SIGS = {
     'dis_conv2d_dgrad1x1_scaled_gnb': 'pppippppiiiiiip',
     'dis_conv2d_wgrad_k4s2_f16x2_gnb': 'ppppippppiiip',
     'dis_conv2d_fwd_k4s2_f16x2': 'pppppiiiip',
+    'dis_conv2d_dgrad_k4s2_f16x2': 'pppiiiip',
     'dis_gn_bwd_coef': 'pppippppilifp',
     'dis_gn_bwd_apply_coef': 'ppppiliip',
     'dis_conv2d_dgrad_f16x2_gnb': 'pppippiiipippp' + 'iiiip',

@@ -883,6 +883,16 @@ BF16X3 = _os.environ.get('DIS_CONV_BF16X3', '1') != '0'
 K4S2_F2 = _os.environ.get('DIS_K4S2_F2', '1') != '0'   # DIS_K4S2_F2=0: the 4 x 4 stride-2 forward on the exact-fp32 MFMA kernel
 
 
+def _dgrad_k4s2(gpre, weight, gx, n, hin, win, cin, cout, accumulate):
+    """input gradient of a 4 x 4 stride-2 pad-1 conv: the one-launch two-term kernel for 32 -> 32 (csrc/conv_k4s2.hip), else - other
+    channel counts, the three-term mode, DIS_K4S2_F2=0 - the four parity launches on the exact-fp32 kernel"""
+    if (BF16X3 and K4S2_F2 and cin == 32 and cout == 32 and weight.is_contiguous() and
+            lib.call_try('dis_conv2d_dgrad_k4s2_f16x2', gpre, weight, gx, n, hin, win, 1 if accumulate else 0)):
+        return
+    ws = torch.empty(16 * cin * cout, dtype=torch.float32, device=gx.device)
+    lib.call('dis_conv2d_dgrad_strided', gpre, weight, gx, ws, n, hin, win, cin, cout, 4, 2, 1, 1 if accumulate else 0)
+
+
 def _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad):
     """dis_conv2d_wgrad, or its bf16x3 form for 3x3 stride-1 layers with 16 / 32 channels on both sides."""
     name = 'dis_conv2d_wgrad'
@@ -973,9 +983,7 @@ class _Conv2d(torch.autograd.Function):
                     join = ctx.join
                     second = join is not None and join.buf is not None
                     gx = join.take(x.shape) if second else torch.empty_like(x)
-                    wsd = torch.empty(16 * cin * cout, dtype=torch.float32, device=x.device)
-                    lib.call('dis_conv2d_dgrad_strided', gpre, weight, gx, wsd, n, hin, win, cin, cout, k, stride, pad,
-                             1 if second else 0)
+                    _dgrad_k4s2(gpre, weight, gx, n, hin, win, cin, cout, second)
                     if join is not None and not second:
                         gx = join.first(gx)
                 _sinks_written()
@@ -1054,9 +1062,7 @@ class _Conv2d(torch.autograd.Function):
                 _conv_fwd_any(gpre, weight, cin, 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cin, k, 1,
                               k - 1 - pad, ACT_NONE | (CONV_ACCUM if second else 0))
             else:
-                ws = torch.empty(16 * cin * cout, dtype=torch.float32, device=x.device)
-                lib.call('dis_conv2d_dgrad_strided', gpre, weight, gx, ws, n, hin, win, cin, cout, k, stride, pad,
-                         1 if second else 0)
+                _dgrad_k4s2(gpre, weight, gx, n, hin, win, cin, cout, second)
             if join is not None and not second:
                 gx = join.first(gx)
         gw, gw_ret = _sink(weight)

@@ -360,6 +360,9 @@ int dis_conv2d_wgrad_k4s2_f16x2_gnb(const float* x, const float* g, const float*
  * bias), w OIHW (32, 32, 4, 4) unpacked, stats (n, 2) accumulated or NULL.  DIS_ERR_UNSUPPORTED under dis_set_conv_split(0). */
 int dis_conv2d_fwd_k4s2_f16x2(const float* x, const float* w_oihw, const float* bias, float* y, double* stats, int n, int hin, int win,
                               int act, void* stream);
+/* ... and its input gradient: gx (n, hin, win, 32) (+)= conv_transpose(gy (n, hin / 2, win / 2, 32), w), the four parity classes from
+ * one gy halo tile in one launch (replaces dis_conv2d_dgrad_strided's four launches + four packing launches); hin, win even. */
+int dis_conv2d_dgrad_k4s2_f16x2(const float* gy, const float* w_oihw, float* gx, int n, int hin, int win, int accumulate, void* stream);
 int dis_gn_bwd_coef(const double* stats, const float* gamma, const double* ab, int slots, float* coef, float* grad_gamma,
                     float* grad_beta, unsigned* counter, int n, long hw, int c, float eps, void* stream);
 int dis_gn_bwd_apply_coef(const float* g, const float* x, const float* coef, float* gx, int n, long hw, int c, int in_act,

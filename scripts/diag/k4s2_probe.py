@@ -58,6 +58,10 @@ ws = torch.empty(16 * c * c, dtype=torch.float32, device='cuda')
 cur_d = lambda: lib.call('dis_conv2d_dgrad_strided', gy, wt, g0, ws, n, h, w, c, c, 4, 2, 1, 0)
 cur_d()
 print('current dgrad err', float((g0.double() - gref).abs().max()), 'us', timeit(cur_d))
+g2 = torch.empty_like(x)
+fd = lambda: lib.call('dis_conv2d_dgrad_k4s2_f16x2', gy, wt, g2, n, h, w, 0)
+fd()
+print('k4s2 f16x2 dgrad err', float((g2.double() - gref).abs().max()), 'us', timeit(fd))
 g1 = torch.empty_like(x)
 try:
     f = lambda: ops._convg_run(ops.CONVG_CONV_DGRAD, gy, wt, None, g1, n, ho, wo, c, c, h, w, c, c, 4, 2, 1, ops.ACT_NONE)

@@ -703,6 +703,39 @@ def test_conv_fwd_k4s2_f16x2(case, n, h, w, act):
     assert float((st - sums).abs().max()) < 1e-5 * float(sums.abs().max())
 
 
+@pytest.mark.parametrize('case', ['randn', 'outlier', 'tiny_corner'])
+@pytest.mark.parametrize('n,h,w,accum', [(3, 38, 30, 0), (2, 64, 48, 1), (16, 64, 56, 0), (1, 18, 70, 1)])
+def test_conv_dgrad_k4s2_f16x2(case, n, h, w, accum):
+    """dis_conv2d_dgrad_k4s2_f16x2 (round 5): the input gradient of FuseNet's 4 x 4 stride-2 conv, all four parity classes from one gy
+    halo tile in one launch on the two-term kernel, against fp64 (bar 1e-6 of the largest entry) beside the four fp32 parity launches
+    it replaces (dis_conv2d_dgrad_strided); writing and accumulating, ragged tiles, block-scaling cases."""
+    from depthinspace_amd import ops
+    L = ops.lib
+    if L.fn('dis_get_conv_split')() != 1:
+        pytest.skip('two-term fp16 kernels only')
+    g_ = torch.Generator().manual_seed(n + h + w + accum + len(case))
+    c = 32
+    ho, wo = h // 2, w // 2
+    gy = torch.randn(n, c, ho, wo, generator=g_)
+    if case == 'outlier':
+        gy[0, :, ho // 2, wo // 3] = 1e4
+    elif case == 'tiny_corner':
+        gy[:, :, : ho // 2, : wo // 2] *= 1e-6
+    wt = torch.randn(c, c, 4, 4, generator=g_) / (c * 4) ** 0.5
+    base = torch.randn(n, h, w, c, generator=g_) if accum else torch.zeros(n, h, w, c)
+    ref = F.conv_transpose2d(gy.double(), wt.double(), stride=2, padding=1).permute(0, 2, 3, 1) + base.double()
+    gd, wd = nhwc(gy).cuda(), wt.cuda()
+    gx = base.clone().cuda() if accum else torch.full((n, h, w, c), float('nan'), device='cuda')
+    L.call('dis_conv2d_dgrad_k4s2_f16x2', gd, wd, gx, n, h, w, accum)
+    gx0 = base.clone().cuda()
+    L.call('dis_conv2d_dgrad_strided', gd, wd, gx0, torch.empty(16 * c * c, device='cuda'), n, h, w, c, c, 4, 2, 1, accum)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    e2, e0 = float((gx.double().cpu() - ref).abs().max()) / scale, float((gx0.double().cpu() - ref).abs().max()) / scale
+    print(f'{case} {n}x{h}x{w} accum {accum}: two-term {e2:.2e}, fp32 MFMA {e0:.2e}')
+    assert e2 < 1e-6, (e2, e0)
+
+
 @pytest.mark.parametrize('stride', [1, 2])
 def test_conv3d_class_ordered_backward(golden_dir, stride):
     """dis_conv3d_knn_bwd_det (the default backward: class-ordered plain read-modify-write, aggregate read back from the forward)
