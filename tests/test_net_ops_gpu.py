@@ -68,9 +68,15 @@ def test_conv2d_fwd_bwd(cin, cout, k, stride, pad, cin_pad, h, w, act):
     yd.backward(nhwc(go).cuda())
     assert relerr(nchw(yd), y) < 2e-6
     # fused GroupNorm statistics of the output
+    # (they are the sums of the kernel's OWN outputs - tight; against the fp32 reference's sums the allowance is what the 2e-6 output
+    # bar leaves of a sum of numel outputs with errors of random sign: the two-term 4 x 4 stride-2 kernel, K = 512, measured 2e-4 on 7680)
     st = stats.view(n, 2).cpu()
-    assert torch.allclose(st[:, 0], y.double().sum(dim=(1, 2, 3)), rtol=1e-6, atol=1e-4)
-    assert torch.allclose(st[:, 1], (y.double() ** 2).sum(dim=(1, 2, 3)), rtol=1e-6, atol=1e-4)
+    yo = nchw(yd).detach().double().cpu()
+    assert torch.allclose(st[:, 0], yo.sum(dim=(1, 2, 3)), rtol=1e-6, atol=2e-5)
+    assert torch.allclose(st[:, 1], (yo ** 2).sum(dim=(1, 2, 3)), rtol=1e-6, atol=2e-5)
+    slack = 1e-4 + 2e-6 * float(y.abs().max()) * (y[0].numel() ** 0.5)
+    assert torch.allclose(st[:, 0], y.double().sum(dim=(1, 2, 3)), rtol=1e-6, atol=slack)
+    assert torch.allclose(st[:, 1], (y.double() ** 2).sum(dim=(1, 2, 3)), rtol=1e-6, atol=slack * 2 * float(y.abs().max()))
     assert relerr(wd.grad, wr.grad) < 1e-5
     assert relerr(bd.grad, br.grad) < 1e-5
     if dgrad:
