@@ -223,11 +223,179 @@ __global__ void resize_nhwc_bwd_kernel(const float* __restrict__ gy, float* __re
   }
 }
 
+// ---- tiled forms (round 5; c = 4 * CG, 16-byte aligned tensors).  The grid-stride kernels above walk the output in row-major order: the
+// four taps of an output row and of the row below it are fetched by workgroups that sit on different XCDs (workgroup i -> XCD i % 8),
+// each through its own L2 - 155 MB fetched for 38 MB of source (profiles/r5v5_kernels.md).  Here a workgroup owns an 8-row x (256 / CG)-
+// column tile of pixels: its source footprint stays in its CU's L1 / its XCD's L2, loads and stores are 16 B per lane.  Same
+// arithmetic, term by term.
+#define RZ_ROWS 8
+template <int CG>
+__global__ __launch_bounds__(256) void resize_nhwc_fwd_tiled_kernel(const float4* __restrict__ x, float4* __restrict__ y, int hin,
+                                                                    int win, int hout, int wout, int ac, int tiles_x, int tiles_y) {
+  constexpr int PX = 256 / CG;
+  int tile = blockIdx.x;
+  const int tx = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty = tile % tiles_y, b = tile / tiles_y;
+  const int g = threadIdx.x % CG, ox = tx * PX + threadIdx.x / CG;
+  if (ox >= wout) return;
+  const float sy = resize_scale(hin, hout, ac), sx = resize_scale(win, wout, ac);
+  const Lerp Lx = resize_src(ox, sx, win, ac);
+  const float4* base = x + (long)b * hin * win * CG + g;
+  float4* out = y + (long)b * hout * wout * CG + g;
+  const int oy_end = min(ty * RZ_ROWS + RZ_ROWS, hout);
+  for (int oy = ty * RZ_ROWS; oy < oy_end; ++oy) {
+    const Lerp Ly = resize_src(oy, sy, hin, ac);
+    const float4 a = base[((long)Ly.i0 * win + Lx.i0) * CG], bb = base[((long)Ly.i0 * win + Lx.i1) * CG];
+    const float4 c4 = base[((long)Ly.i1 * win + Lx.i0) * CG], d = base[((long)Ly.i1 * win + Lx.i1) * CG];
+    float4 o;
+    o.x = Ly.l0 * (Lx.l0 * a.x + Lx.l1 * bb.x) + Ly.l1 * (Lx.l0 * c4.x + Lx.l1 * d.x);
+    o.y = Ly.l0 * (Lx.l0 * a.y + Lx.l1 * bb.y) + Ly.l1 * (Lx.l0 * c4.y + Lx.l1 * d.y);
+    o.z = Ly.l0 * (Lx.l0 * a.z + Lx.l1 * bb.z) + Ly.l1 * (Lx.l0 * c4.z + Lx.l1 * d.z);
+    o.w = Ly.l0 * (Lx.l0 * a.w + Lx.l1 * bb.w) + Ly.l1 * (Lx.l0 * c4.w + Lx.l1 * d.w);
+    out[((long)oy * wout + ox) * CG] = o;
+  }
+}
+
+// Backward, tiled: a workgroup owns 8 rows x (256 / CG) columns of SOURCE pixels.  The destination rows / columns that read a source
+// row / column and their weights are worked out once per workgroup into LDS (first destination index + up to RZ_NZ weights: a 2 x
+// align_corners upsample has at most 5), so that a thread's loads are RZ_NZ x RZ_NZ independent 16-byte reads with no index arithmetic
+// between them; the sum runs in the order of the gather kernel above (destination rows outer, columns inner).  A scale with more
+// than RZ_NZ contributing destination indices per source index (upsampling by more than ~2.5) sets `wide` and the workgroup runs
+// the general loop.
+#define RZ_NZ 5
+struct RzTab {
+  int first;
+  float w[RZ_NZ];
+};
+__device__ __forceinline__ float resize_weight_of(int dst, int src_i, float scale, int in, int ac) {
+  const Lerp L = resize_src(dst, scale, in, ac);
+  return (L.i0 == src_i ? L.l0 : 0.f) + (L.i1 == src_i ? L.l1 : 0.f);
+}
+template <int CG>
+__global__ __launch_bounds__(256) void resize_nhwc_bwd_tiled_kernel(const float4* __restrict__ gy, float4* __restrict__ gx, int hin,
+                                                                    int win, int hout, int wout, int ac, int tiles_x, int tiles_y) {
+  constexpr int PX = 256 / CG;
+  __shared__ RzTab tab[RZ_ROWS + PX];
+  __shared__ int wide;
+  int tile = blockIdx.x;
+  const int tx = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty = tile % tiles_y, b = tile / tiles_y;
+  const float sy = resize_scale(hin, hout, ac), sx = resize_scale(win, wout, ac);
+  const int t = threadIdx.x;
+  if (t == 0) wide = 0;
+  __syncthreads();
+  if (t < RZ_ROWS + PX) {
+    const bool row = t < RZ_ROWS;
+    const int i = row ? ty * RZ_ROWS + t : tx * PX + (t - RZ_ROWS);
+    const int in = row ? hin : win, out = row ? hout : wout;
+    const float sc = row ? sy : sx;
+    RzTab T;
+    T.first = 0;
+#pragma unroll
+    for (int k = 0; k < RZ_NZ; ++k) T.w[k] = 0.f;
+    tab[t] = T;
+    if (i < in) {
+      int lo, hi, first = -1;
+      resize_dst_range(i, sc, in, out, ac, &lo, &hi);
+      for (int d = lo; d <= hi; ++d) {
+        const float wgt = resize_weight_of(d, i, sc, in, ac);
+        if (wgt == 0.f) continue;
+        if (first < 0) {
+          first = d;
+          tab[t].first = d;
+        }
+        if (d - first < RZ_NZ)
+          tab[t].w[d - first] = wgt;
+        else
+          wide = 1;
+      }
+    }
+  }
+  __syncthreads();
+  const int g = t % CG, px = t / CG, ix = tx * PX + px;
+  if (ix >= win) return;
+  const float4* src = gy + (long)b * hout * wout * CG + g;
+  float4* dst = gx + (long)b * hin * win * CG + g;
+  const int iy_end = min(ty * RZ_ROWS + RZ_ROWS, hin);
+  if (wide) {   // (block-uniform)
+    int xlo, xhi;
+    resize_dst_range(ix, sx, win, wout, ac, &xlo, &xhi);
+    for (int iy = ty * RZ_ROWS; iy < iy_end; ++iy) {
+      int ylo, yhi;
+      resize_dst_range(iy, sy, hin, hout, ac, &ylo, &yhi);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = resize_weight_of(oy, iy, sy, hin, ac);
+        if (wy == 0.f) continue;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const float wx = resize_weight_of(ox, ix, sx, win, ac);
+          if (wx == 0.f) continue;
+          const float4 v = src[((long)oy * wout + ox) * CG];
+          const float wgt = wy * wx;
+          acc.x += wgt * v.x, acc.y += wgt * v.y, acc.z += wgt * v.z, acc.w += wgt * v.w;
+        }
+      }
+      dst[((long)iy * win + ix) * CG] = acc;
+    }
+    return;
+  }
+  const RzTab X = tab[RZ_ROWS + px];
+  for (int iy = ty * RZ_ROWS; iy < iy_end; ++iy) {
+    RzTab Y = tab[iy - ty * RZ_ROWS];   // (the same for every thread of the workgroup: scalar registers, scalar branches below)
+    Y.first = __builtin_amdgcn_readfirstlane(Y.first);
+#pragma unroll
+    for (int r = 0; r < RZ_NZ; ++r) Y.w[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Y.w[r])));
+    float4 v[RZ_NZ][RZ_NZ];
+#pragma unroll
+    for (int r = 0; r < RZ_NZ; ++r) {
+      if (Y.w[r] != 0.f) {
+#pragma unroll
+        for (int k = 0; k < RZ_NZ; ++k) {
+          // (a zero weight: the slot lies outside the contributing range - possibly outside the tensor; read the first slot instead)
+          const int ox = X.w[k] != 0.f ? X.first + k : X.first;
+          v[r][k] = src[((long)(Y.first + r) * wout + ox) * CG];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < RZ_NZ; ++k) v[r][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < RZ_NZ; ++r)
+#pragma unroll
+      for (int k = 0; k < RZ_NZ; ++k) {
+        if (Y.w[r] != 0.f && X.w[k] != 0.f) {
+          const float wgt = Y.w[r] * X.w[k];
+          acc.x += wgt * v[r][k].x, acc.y += wgt * v[r][k].y, acc.z += wgt * v[r][k].z, acc.w += wgt * v[r][k].w;
+        }
+      }
+    dst[((long)iy * win + ix) * CG] = acc;
+  }
+}
+static inline bool rz_aligned(const void* a, const void* b) { return ((((size_t)a) | ((size_t)b)) & 15) == 0; }
+
 extern "C" int dis_resize_bilinear_nhwc_fwd(const float* x, float* y, int n, int hin, int win, int hout, int wout,
                                             int c, int align_corners, void* stream) {
   if (!x || !y) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || c <= 0) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  if ((c == 32 || c == 16) && rz_aligned(x, y)) {
+    const int px = 256 / (c / 4), tiles_x = dis_cdiv(wout, px), tiles_y = dis_cdiv(hout, RZ_ROWS);
+    const long tiles = (long)n * tiles_x * tiles_y;
+    if (tiles <= 0x7fffffffL) {
+      if (c == 32)
+        hipLaunchKernelGGL(resize_nhwc_fwd_tiled_kernel<8>, dim3((unsigned)tiles), dim3(256), 0, s, (const float4*)x, (float4*)y, hin,
+                           win, hout, wout, align_corners, tiles_x, tiles_y);
+      else
+        hipLaunchKernelGGL(resize_nhwc_fwd_tiled_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, s, (const float4*)x, (float4*)y, hin,
+                           win, hout, wout, align_corners, tiles_x, tiles_y);
+      DIS_CHECK_LAUNCH();
+      return DIS_OK;
+    }
+  }
   if (c % 4 == 0) {
     long total = (long)n * hout * wout * (c / 4);
     hipLaunchKernelGGL(resize_nhwc_fwd_kernel<4>, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, x, y, n, hin, win,
@@ -245,6 +413,20 @@ extern "C" int dis_resize_bilinear_nhwc_bwd(const float* gy, float* gx, int n, i
   if (!gy || !gx) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0 || c <= 0) return DIS_ERR_BAD_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  if ((c == 32 || c == 16) && rz_aligned(gy, gx)) {
+    const int px = 256 / (c / 4), tiles_x = dis_cdiv(win, px), tiles_y = dis_cdiv(hin, RZ_ROWS);
+    const long tiles = (long)n * tiles_x * tiles_y;
+    if (tiles <= 0x7fffffffL) {
+      if (c == 32)
+        hipLaunchKernelGGL(resize_nhwc_bwd_tiled_kernel<8>, dim3((unsigned)tiles), dim3(256), 0, s, (const float4*)gy, (float4*)gx,
+                           hin, win, hout, wout, align_corners, tiles_x, tiles_y);
+      else
+        hipLaunchKernelGGL(resize_nhwc_bwd_tiled_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, s, (const float4*)gy, (float4*)gx,
+                           hin, win, hout, wout, align_corners, tiles_x, tiles_y);
+      DIS_CHECK_LAUNCH();
+      return DIS_OK;
+    }
+  }
   if (c % 4 == 0) {
     long total = (long)n * hin * win * (c / 4);
     hipLaunchKernelGGL(resize_nhwc_bwd_kernel<4>, dim3(dis_ew_grid(total, 256)), dim3(256), 0, s, gy, gx, n, hin,

@@ -241,6 +241,46 @@ def test_resize(ac, hin, win, ho, wo):
     assert relerr(xp.grad, xr.grad) < 1e-5
 
 
+@pytest.mark.parametrize('ac', [True, False])
+@pytest.mark.parametrize('c', [32, 16])
+@pytest.mark.parametrize('hin,win,ho,wo', [(27, 45, 54, 90), (16, 70, 32, 140), (30, 38, 15, 19), (9, 13, 27, 39), (7, 5, 40, 33),
+                                           (13, 67, 21, 100), (1, 3, 2, 6)])
+def test_resize_nhwc_tiled(ac, c, hin, win, ho, wo):
+    """the tiled resize kernels (round 5: a workgroup owns an 8-row tile, per-workgroup weight tables in the backward) against torch and,
+    bit for bit, against the grid-stride kernels they replace (reached through a tensor that is not 16-byte aligned); 2 x upsampling
+    with ragged tiles, downsampling, 3 x and 6 x upsampling (more than five contributing destination indices: the general loop)"""
+    from depthinspace_amd import ops
+    L = ops.lib
+    g = torch.Generator().manual_seed(hin * win + c)
+    n = 3
+    x = torch.randn(n, c, hin, win, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y = F.interpolate(xr, size=(ho, wo), mode='bilinear', align_corners=ac)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+    xd, gd = nhwc(x).cuda(), nhwc(go).cuda()
+    yd = torch.full((n, ho, wo, c), float('nan'), device='cuda')
+    gx = torch.full((n, hin, win, c), float('nan'), device='cuda')
+    L.call('dis_resize_bilinear_nhwc_fwd', xd, yd, n, hin, win, ho, wo, c, int(ac))
+    L.call('dis_resize_bilinear_nhwc_bwd', gd, gx, n, hin, win, ho, wo, c, int(ac))
+    # (source positions near 66 carry 8e-6 of fp32 rounding: the weights of torch's kernel and of this one may differ by that much)
+    assert relerr(nchw(yd), y) < 5e-6
+    assert relerr(nchw(gx), xr.grad) < 2e-5
+
+    def unaligned(t):
+        buf = torch.empty(t.numel() + 1, device='cuda')
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 4
+        return v
+    xu, gu = unaligned(xd), unaligned(gd)
+    yu, gxu = unaligned(torch.full_like(yd, float('nan'))), unaligned(torch.full_like(gx, float('nan')))
+    L.call('dis_resize_bilinear_nhwc_fwd', xu, yu, n, hin, win, ho, wo, c, int(ac))
+    L.call('dis_resize_bilinear_nhwc_bwd', gu, gxu, n, hin, win, ho, wo, c, int(ac))
+    assert torch.equal(yu, yd)
+    assert torch.equal(gxu, gx)
+
+
 def test_resize_flow_scale(golden_dir):
     from depthinspace_amd import ops
     G = np.load(os.path.join(golden_dir, 'ops.npz'))
