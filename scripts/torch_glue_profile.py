@@ -29,7 +29,8 @@ def step():
     flow = worker.read_optical_flow(train=True)
     out = worker.net_forward(net, flow)
     errs = worker.loss_forward(out, True, flow)
-    sum(errs).backward()
+    tot = getattr(errs, 'total', None)
+    (tot if tot is not None else sum(errs)).backward()
     opt.step()
 
 
@@ -49,5 +50,6 @@ for ev in prof.key_averages(group_by_input_shape=True):
     k = (ev.key, str(ev.input_shapes)[:90])
     agg[k] += ev.count
     tim[k] += dt
+print('ops.begin_step:', hasattr(ops, 'begin_step'))
 for (name, where), c in sorted(agg.items(), key=lambda kv: -tim[kv[0]])[:60]:
     print(f'{c:4d} x {name:22s} {tim[(name, where)]:8.0f} us  {where}')
