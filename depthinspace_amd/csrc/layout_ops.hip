@@ -587,6 +587,66 @@ __global__ void gather_warped_feat_fwd_kernel(const float* __restrict__ feat, co
   }
 }
 
+// Tiled form (round 5).  The grid-stride kernel above walks (pixel, slot) in row-major order, 8 pixels per workgroup: the two source rows
+// an output row reads are fetched again for the next output row by a workgroup on another XCD, and again by each of the three other
+// targets that warp the same frame - ~840 MB leave the L2s for a 113 MB feature tensor at core resolution (profiles/r5v5_kernels.md).
+// Here a workgroup owns a GT_TH x GT_TW tile of pixels of ONE target (8-pixel column strips, walked downwards: the lower source row of
+// one pass is the upper one of the next), and the blockIdx -> (tile, target) map puts the tl targets of a tile on the SAME XCD one
+// after the other (workgroups go to XCD blockIdx % 8): their warped reads of the shared source frames meet in that XCD's L2.
+// Arithmetic: the kernel above, term by term.
+#define GT_TH 8
+#define GT_TW 32
+__global__ __launch_bounds__(256) void gather_warped_feat_fwd_tiled_kernel(const float* __restrict__ feat, const float* __restrict__ flows,
+                                                                           float* __restrict__ out, int tl, int bs, int h, int w, int c,
+                                                                           int nt, int tiles_x, int tiles_y, int ntile) {
+  const int cg = c >> 2, tpp = tl * cg, pxp = 256 / tpp;
+  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int t = k % tl, tile_lin = (k / tl) * 8 + xcd;
+  if (tile_lin >= ntile) return;
+  const int tx = tile_lin % tiles_x, ty = (tile_lin / tiles_x) % tiles_y, b = tile_lin / (tiles_x * tiles_y);
+  const int g = threadIdx.x % cg, s = (threadIdx.x / cg) % tl, pi = threadIdx.x / tpp;
+  const long hw = (long)h * w;
+  const int j = slot_frame(t, s);
+  const float* src = feat + ((long)j * bs + b) * hw * c + g * 4;
+  const float* fl = flows + (((long)t * tl + j) * bs + b) * hw * 2;
+  float* ob = out + ((long)t * bs + b) * hw * tl * c + (long)s * c + g * 4;
+  const int y_end = min(ty * GT_TH + GT_TH, h);
+  for (int x0 = tx * GT_TW; x0 < min(tx * GT_TW + GT_TW, w); x0 += pxp) {
+    const int x = x0 + pi;
+    if (x >= w) continue;
+#pragma unroll 4
+    for (int y = ty * GT_TH; y < y_end; ++y) {
+      const long p = (long)y * w + x;
+      float4 v;
+      if (s == 0) {
+        v = *(const float4*)(src + p * c);
+      } else {
+        const float2 f = *(const float2*)(fl + p * 2);
+        const Taps tp = make_taps(f.x + (float)x, f.y + (float)y, h, w);
+        const int xa = min(max(tp.x0, 0), w - 1), xb = min(max(tp.x0 + 1, 0), w - 1);
+        const int ya = min(max(tp.y0, 0), h - 1), yb = min(max(tp.y0 + 1, 0), h - 1);
+        const float w00 = tp.v00 ? tp.w00 : 0.f, w01 = tp.v01 ? tp.w01 : 0.f;
+        const float w10 = tp.v10 ? tp.w10 : 0.f, w11 = tp.v11 ? tp.w11 : 0.f;
+        const float4 a = *(const float4*)(src + ((long)ya * w + xa) * c);
+        const float4 bq = *(const float4*)(src + ((long)ya * w + xb) * c);
+        const float4 cq = *(const float4*)(src + ((long)yb * w + xa) * c);
+        const float4 d = *(const float4*)(src + ((long)yb * w + xb) * c);
+        v.x = a.x * w00 + bq.x * w01 + cq.x * w10 + d.x * w11;
+        v.y = a.y * w00 + bq.y * w01 + cq.y * w10 + d.y * w11;
+        v.z = a.z * w00 + bq.z * w01 + cq.z * w10 + d.z * w11;
+        v.w = a.w * w00 + bq.w * w01 + cq.w * w10 + d.w * w11;
+      }
+      float* op = ob + p * tl * c;
+      if (nt) __builtin_nontemporal_store((lo_v4f){v.x, v.y, v.z, v.w}, (lo_v4f*)op);
+      else *(float4*)op = v;
+    }
+  }
+}
+static inline bool gather_tiled_on() {   // DIS_GATHER_TILED=0: the grid-stride kernels (read per call: tests compare the two forms)
+  const char* e = getenv("DIS_GATHER_TILED");
+  return !(e && e[0] == '0');
+}
+
 // Backward.  Phase 1 (plain stores, also replaces a memset): grad_feat[t] = grad_out[t, slot 0].
 // Phase 2 (float atomics): the warped slots scatter through their 4 bilinear taps.  One LANE = one channel,
 // so a wave-instruction's 64 atomics are two contiguous 128-byte rows: the shape the memory-side atomic unit
@@ -636,6 +696,17 @@ extern "C" int dis_gather_warped_feat_fwd(const float* feat, const float* flows,
   if (c % 4 != 0) return DIS_ERR_UNSUPPORTED;
   long total = (long)tl * bs * h * w * tl * (c / 4);
   static const int nt = getenv("DIS_GATHER_NT") ? atoi(getenv("DIS_GATHER_NT")) : 1;
+  const int tpp = tl * (c / 4);
+  if (tpp <= 256 && 256 % tpp == 0 && GT_TW % (256 / tpp) == 0 && gather_tiled_on()) {
+    const int tiles_x = dis_cdiv(w, GT_TW), tiles_y = dis_cdiv(h, GT_TH);
+    const long ntile = (long)bs * tiles_x * tiles_y, blocks = (ntile + 7) / 8 * 8 * tl;
+    if (blocks <= 0x7fffffffL) {
+      hipLaunchKernelGGL(gather_warped_feat_fwd_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, feat, flows,
+                         out, tl, bs, h, w, c, nt, tiles_x, tiles_y, (int)ntile);
+      DIS_CHECK_LAUNCH();
+      return DIS_OK;
+    }
+  }
   hipLaunchKernelGGL(gather_warped_feat_fwd_kernel, dim3(dis_ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      feat, flows, out, tl, bs, h, w, c, nt);
   DIS_CHECK_LAUNCH();
@@ -831,6 +902,60 @@ __global__ void gather_warped_feat_bwd_csr_kernel(const float* __restrict__ gout
   }
 }
 
+// Tiled form (round 5): a workgroup owns a GT_TH x GT_TW tile of destination pixels of one (frame, sample) (a row segment of 256 / cg
+// pixels per pass); consecutive tiles of a frame go to the same XCD (its share of the tiles is one contiguous range), so the rows of
+// grad_out that neighbouring destinations share are found in that XCD's L2; four entries and their rows in flight per round instead
+// of one.  The sum runs in entry order: bit for bit the kernel above.
+__global__ __launch_bounds__(256) void gather_warped_feat_bwd_csr_tiled_kernel(const float* __restrict__ gout, const int* __restrict__ offsets,
+                                                                               const int* __restrict__ entries,
+                                                                               const float* __restrict__ init, float* __restrict__ gfeat,
+                                                                               int h, int w, int tl, int c, int tiles_x, int tiles_y,
+                                                                               int ntile, int per_xcd) {
+  const int cg = c >> 2, pxp = 256 / cg;
+  const int tile_lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || tile_lin >= ntile) return;
+  const int tx = tile_lin % tiles_x, ty = (tile_lin / tiles_x) % tiles_y;
+  const long fb = tile_lin / (tiles_x * tiles_y);   // frame * bs + sample
+  const int g = threadIdx.x % cg, pi = threadIdx.x / cg;
+  const int y_end = min(ty * GT_TH + GT_TH, h);
+  for (int x0 = tx * GT_TW; x0 < min(tx * GT_TW + GT_TW, w); x0 += pxp) {
+    const int x = x0 + pi;
+    if (x >= w) continue;
+    for (int y = ty * GT_TH; y < y_end; ++y) {
+      const long d = (fb * h + y) * w + x;
+      float4 acc = *(const float4*)(gout + (d * tl) * c + g * 4);
+      if (init) {
+        const float4 q = *(const float4*)(init + d * c + g * 4);
+        acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+      }
+      const int lo = offsets[d], hi = offsets[d + 1];
+      int e = lo;
+      for (; e + 3 < hi; e += 4) {
+        int row[4];
+        float wgt[4];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          row[u] = entries[2 * (long)(e + u)];   // (the pairs start at an odd word of the csr block: two 4-byte loads)
+          wgt[u] = __int_as_float(entries[2 * (long)(e + u) + 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(gout + (long)row[u] * c + g * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc.x += v[u].x * wgt[u]; acc.y += v[u].y * wgt[u]; acc.z += v[u].z * wgt[u]; acc.w += v[u].w * wgt[u];
+        }
+      }
+      for (; e < hi; ++e) {
+        const float wgt = __int_as_float(entries[2 * (long)e + 1]);
+        const float4 v = *(const float4*)(gout + (long)entries[2 * (long)e] * c + g * 4);
+        acc.x += v.x * wgt; acc.y += v.y * wgt; acc.z += v.z * wgt; acc.w += v.w * wgt;
+      }
+      *(float4*)(gfeat + d * c + g * 4) = acc;
+    }
+  }
+}
+
 static long csr_words(int tl, int bs, int h, int w) {
   const long nd = (long)tl * bs * h * w;
   return (nd + 1) + nd + 2 * nd * (tl - 1) * 4;
@@ -965,6 +1090,18 @@ extern "C" int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* 
   if (c % 4 != 0) return DIS_ERR_UNSUPPORTED;
   const long nd = (long)tl * bs * h * w;
   const long total = nd * (c / 4);
+  const int cg4 = c / 4;
+  if (cg4 <= 256 && 256 % cg4 == 0 && GT_TW % (256 / cg4) == 0 && gather_tiled_on()) {
+    const int tiles_x = dis_cdiv(w, GT_TW), tiles_y = dis_cdiv(h, GT_TH);
+    const long ntile = (long)tl * bs * tiles_x * tiles_y;
+    const long per_xcd = (ntile + 7) / 8;
+    if (per_xcd * 8 <= 0x7fffffffL) {
+      hipLaunchKernelGGL(gather_warped_feat_bwd_csr_tiled_kernel, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, (hipStream_t)stream,
+                         grad_out, csr, csr + 2 * nd + 1, init, grad_feat, h, w, tl, c, tiles_x, tiles_y, (int)ntile, (int)per_xcd);
+      DIS_CHECK_LAUNCH();
+      return DIS_OK;
+    }
+  }
   int grid = dis_cdiv(total, 256);
   if (grid > 16384) grid = 16384;
   hipLaunchKernelGGL(gather_warped_feat_bwd_csr_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_out, csr,
