@@ -1134,9 +1134,19 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
   }
   // (a tile past the workgroup's last one: the loads are issued all the same, through empty descriptors - they return zeros nobody
   //  reads - so that the number of memory operations between two waits is the same on every path and the counted waits stay exact)
-  auto prefetch = [&](WSet& W, int tile) __attribute__((always_inline)) {
-    const bool live = tile < ntiles;
-    if (!live) tile = 0;
+  // tile of trip j of this workgroup: each XCD (workgroup i sits on XCD i % 8) works through a contiguous eighth of the tiles, its
+  // workgroups side by side - neighbouring tiles are in flight on ONE XCD at the same time and find their shared halo rows / columns in
+  // its L2 (F2W_XCD=0: tile = blockIdx.x + j gridDim.x, neighbours on different XCDs, every halo item fetched from memory)
+#ifndef F2W_XCD
+#define F2W_XCD 1
+#endif
+  const int w_nx = (F2W_XCD && gridDim.x % 8 == 0) ? 8 : 1;
+  const int w_xcd = (int)blockIdx.x % w_nx, w_rank = (int)blockIdx.x / w_nx, w_per = (int)gridDim.x / w_nx;
+  const int w_lo = (int)((long)ntiles * w_xcd / w_nx), w_hi = (int)((long)ntiles * (w_xcd + 1) / w_nx);
+  const int ntl = w_hi - w_lo > w_rank ? (w_hi - w_lo - w_rank + w_per - 1) / w_per : 0;   // trips of this workgroup
+  auto prefetch = [&](WSet& W, int trip) __attribute__((always_inline)) {
+    const bool live = trip < ntl;
+    int tile = live ? w_lo + trip * w_per + w_rank : 0;
 #ifdef F2W_KO_LOAD   // (diagnostic build: every tile reads tile 0 - cache hits with the same data statistics)
     tile = 0;
 #endif
@@ -1294,8 +1304,8 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
     }
   };
 
-  prefetch(SA, blockIdx.x);
-  if (WPF2) prefetch(SB, blockIdx.x + gridDim.x);
+  prefetch(SA, 0);
+  if (WPF2) prefetch(SB, 1);
   auto run = [&](auto wc) __attribute__((always_inline)) {
     constexpr int W = decltype(wc)::value, T0 = TW * W, T1 = (T0 + TW < C::T) ? T0 + TW : C::T;
     constexpr int NTW = T1 > T0 ? T1 - T0 : 0;
@@ -1321,7 +1331,7 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
       stage(W, parity);
       __syncthreads();
       parity ^= 1;
-      prefetch(W, tile + (WPF2 ? 2 : 1) * (int)gridDim.x);
+      prefetch(W, tile + (WPF2 ? 2 : 1));
       if (NTW > 0) {
         // fragment reads run FD units (a unit = one x fragment against the gy fragments of its k-step: <= 6 matrix instructions,
         // ~100 cycles) ahead of the matrix instructions that consume them
@@ -1380,16 +1390,15 @@ __global__ __launch_bounds__(256, (K_ == 3 && S_ == 1) ? F2W_WPC : 1) void conv_
     if constexpr (WPF2) {
       // pairs of tiles through a loop with ONE exit, an odd last tile behind it (see conv_f16x2_kernel: a `break` between the two
       // bodies costs the counted waits)
-      const int ntl = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-      int tile = blockIdx.x;
+      int tile = 0;   // (trip index)
       for (int pr = 0; pr < (ntl >> 1); ++pr) {
         body(SA, tile);
-        body(SB, tile + (int)gridDim.x);
-        tile += 2 * (int)gridDim.x;
+        body(SB, tile + 1);
+        tile += 2;
       }
       if (ntl & 1) body(SA, tile);
     } else {
-      for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) body(SA, tile);
+      for (int tile = 0; tile < ntl; ++tile) body(SA, tile);
     }
     // partial slab of this workgroup: [m = mb*16 + row][co], scales undone
     const float desc = __builtin_ldexpf(1.f, -(sx_e + sg_e));
