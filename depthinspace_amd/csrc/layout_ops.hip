@@ -596,6 +596,7 @@ __global__ void gather_warped_feat_fwd_kernel(const float* __restrict__ feat, co
 // Arithmetic: the kernel above, term by term.
 #define GT_TH 8
 #define GT_TW 32
+#define GC_E 12   // CSR backward: entries of a destination fetched together
 __global__ __launch_bounds__(256) void gather_warped_feat_fwd_tiled_kernel(const float* __restrict__ feat, const float* __restrict__ flows,
                                                                            float* __restrict__ out, int tl, int bs, int h, int w, int c,
                                                                            int nt, int tiles_x, int tiles_y, int ntile) {
@@ -610,35 +611,55 @@ __global__ __launch_bounds__(256) void gather_warped_feat_fwd_tiled_kernel(const
   const float* src = feat + ((long)j * bs + b) * hw * c + g * 4;
   const float* fl = flows + (((long)t * tl + j) * bs + b) * hw * 2;
   float* ob = out + ((long)t * bs + b) * hw * tl * c + (long)s * c + g * 4;
-  const int y_end = min(ty * GT_TH + GT_TH, h);
+  const int y0 = ty * GT_TH, nrow = min(GT_TH, h - y0);
   for (int x0 = tx * GT_TW; x0 < min(tx * GT_TW + GT_TW, w); x0 += pxp) {
     const int x = x0 + pi;
     if (x >= w) continue;
-#pragma unroll 4
-    for (int y = ty * GT_TH; y < y_end; ++y) {
-      const long p = (long)y * w + x;
-      float4 v;
-      if (s == 0) {
-        v = *(const float4*)(src + p * c);
-      } else {
-        const float2 f = *(const float2*)(fl + p * 2);
-        const Taps tp = make_taps(f.x + (float)x, f.y + (float)y, h, w);
-        const int xa = min(max(tp.x0, 0), w - 1), xb = min(max(tp.x0 + 1, 0), w - 1);
-        const int ya = min(max(tp.y0, 0), h - 1), yb = min(max(tp.y0 + 1, 0), h - 1);
-        const float w00 = tp.v00 ? tp.w00 : 0.f, w01 = tp.v01 ? tp.w01 : 0.f;
-        const float w10 = tp.v10 ? tp.w10 : 0.f, w11 = tp.v11 ? tp.w11 : 0.f;
-        const float4 a = *(const float4*)(src + ((long)ya * w + xa) * c);
-        const float4 bq = *(const float4*)(src + ((long)ya * w + xb) * c);
-        const float4 cq = *(const float4*)(src + ((long)yb * w + xa) * c);
-        const float4 d = *(const float4*)(src + ((long)yb * w + xb) * c);
-        v.x = a.x * w00 + bq.x * w01 + cq.x * w10 + d.x * w11;
-        v.y = a.y * w00 + bq.y * w01 + cq.y * w10 + d.y * w11;
-        v.z = a.z * w00 + bq.z * w01 + cq.z * w10 + d.z * w11;
-        v.w = a.w * w00 + bq.w * w01 + cq.w * w10 + d.w * w11;
+    // the flows of the strip's rows first (one round trip), then the four taps of four rows in flight together: a thread's chain is
+    // 3 dependent memory round trips per strip instead of 2 per row
+    float2 f[GT_TH];
+#pragma unroll
+    for (int r = 0; r < GT_TH; ++r) {
+      const int y = min(y0 + r, h - 1);
+      f[r] = s == 0 ? make_float2(0.f, 0.f) : *(const float2*)(fl + ((long)y * w + x) * 2);
+    }
+#pragma unroll
+    for (int r0 = 0; r0 < GT_TH; r0 += 4) {
+      float4 ta[4], tb[4], tc[4], td[4];
+      float w00[4], w01[4], w10[4], w11[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int y = min(y0 + r0 + u, h - 1);
+        if (s == 0) {
+          ta[u] = *(const float4*)(src + ((long)y * w + x) * c);
+        } else {
+          const Taps tp = make_taps(f[r0 + u].x + (float)x, f[r0 + u].y + (float)y, h, w);
+          const int xa = min(max(tp.x0, 0), w - 1), xb = min(max(tp.x0 + 1, 0), w - 1);
+          const int ya = min(max(tp.y0, 0), h - 1), yb = min(max(tp.y0 + 1, 0), h - 1);
+          w00[u] = tp.v00 ? tp.w00 : 0.f, w01[u] = tp.v01 ? tp.w01 : 0.f;
+          w10[u] = tp.v10 ? tp.w10 : 0.f, w11[u] = tp.v11 ? tp.w11 : 0.f;
+          ta[u] = *(const float4*)(src + ((long)ya * w + xa) * c);
+          tb[u] = *(const float4*)(src + ((long)ya * w + xb) * c);
+          tc[u] = *(const float4*)(src + ((long)yb * w + xa) * c);
+          td[u] = *(const float4*)(src + ((long)yb * w + xb) * c);
+        }
       }
-      float* op = ob + p * tl * c;
-      if (nt) __builtin_nontemporal_store((lo_v4f){v.x, v.y, v.z, v.w}, (lo_v4f*)op);
-      else *(float4*)op = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r0 + u >= nrow) break;
+        float4 v;
+        if (s == 0) {
+          v = ta[u];
+        } else {
+          v.x = ta[u].x * w00[u] + tb[u].x * w01[u] + tc[u].x * w10[u] + td[u].x * w11[u];
+          v.y = ta[u].y * w00[u] + tb[u].y * w01[u] + tc[u].y * w10[u] + td[u].y * w11[u];
+          v.z = ta[u].z * w00[u] + tb[u].z * w01[u] + tc[u].z * w10[u] + td[u].z * w11[u];
+          v.w = ta[u].w * w00[u] + tb[u].w * w01[u] + tc[u].w * w10[u] + td[u].w * w11[u];
+        }
+        float* op = ob + ((long)(y0 + r0 + u) * w + x) * tl * c;
+        if (nt) __builtin_nontemporal_store((lo_v4f){v.x, v.y, v.z, v.w}, (lo_v4f*)op);
+        else *(float4*)op = v;
+      }
     }
   }
 }
@@ -917,39 +938,52 @@ __global__ __launch_bounds__(256) void gather_warped_feat_bwd_csr_tiled_kernel(c
   const int tx = tile_lin % tiles_x, ty = (tile_lin / tiles_x) % tiles_y;
   const long fb = tile_lin / (tiles_x * tiles_y);   // frame * bs + sample
   const int g = threadIdx.x % cg, pi = threadIdx.x / cg;
-  const int y_end = min(ty * GT_TH + GT_TH, h);
+  const int y0 = ty * GT_TH, nrow = min(GT_TH, h - y0);
   for (int x0 = tx * GT_TW; x0 < min(tx * GT_TW + GT_TW, w); x0 += pxp) {
     const int x = x0 + pi;
     if (x >= w) continue;
-    for (int y = ty * GT_TH; y < y_end; ++y) {
-      const long d = (fb * h + y) * w + x;
+    // offsets of the strip's rows first; per destination: its first GC_E entries (an interior pixel has (tl - 1) * 4 = 12) in one
+    // round trip, their rows in a second one - the chain was offsets -> entry -> row per entry.  Sum in entry order.
+    int lo[GT_TH], hi[GT_TH];
+#pragma unroll
+    for (int r = 0; r < GT_TH; ++r) {
+      const long d = (fb * h + min(y0 + r, h - 1)) * w + x;
+      lo[r] = offsets[d], hi[r] = offsets[d + 1];
+    }
+#pragma unroll 1
+    for (int r = 0; r < nrow; ++r) {
+      const long d = (fb * h + y0 + r) * w + x;
+      int e0 = lo[0], e1 = hi[0];
+#pragma unroll
+      for (int q = 1; q < GT_TH; ++q)
+        if (q == r) e0 = lo[q], e1 = hi[q];   // (register array, dynamic row: selects, no scratch)
       float4 acc = *(const float4*)(gout + (d * tl) * c + g * 4);
-      if (init) {
-        const float4 q = *(const float4*)(init + d * c + g * 4);
-        acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (init) q4 = *(const float4*)(init + d * c + g * 4);
+      int row[GC_E];
+      float wgt[GC_E];
+      float4 v[GC_E];
+#pragma unroll
+      for (int u = 0; u < GC_E; ++u) {
+        const bool on = e0 + u < e1;
+        const long e = on ? e0 + u : 0;   // (past the list: entry 0 is read and dropped, row 0 of grad_out stands in - never summed)
+        const int rw = entries[2 * e], wb = entries[2 * e + 1];
+        row[u] = on ? rw : 0;
+        wgt[u] = on ? __int_as_float(wb) : 0.f;
       }
-      const int lo = offsets[d], hi = offsets[d + 1];
-      int e = lo;
-      for (; e + 3 < hi; e += 4) {
-        int row[4];
-        float wgt[4];
-        float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          row[u] = entries[2 * (long)(e + u)];   // (the pairs start at an odd word of the csr block: two 4-byte loads)
-          wgt[u] = __int_as_float(entries[2 * (long)(e + u) + 1]);
-        }
+      for (int u = 0; u < GC_E; ++u) v[u] = *(const float4*)(gout + (long)row[u] * c + g * 4);
+      if (init) { acc.x += q4.x; acc.y += q4.y; acc.z += q4.z; acc.w += q4.w; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(gout + (long)row[u] * c + g * 4);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < GC_E; ++u) {
+        if (e0 + u < e1) {
           acc.x += v[u].x * wgt[u]; acc.y += v[u].y * wgt[u]; acc.z += v[u].z * wgt[u]; acc.w += v[u].w * wgt[u];
         }
       }
-      for (; e < hi; ++e) {
-        const float wgt = __int_as_float(entries[2 * (long)e + 1]);
-        const float4 v = *(const float4*)(gout + (long)entries[2 * (long)e] * c + g * 4);
-        acc.x += v.x * wgt; acc.y += v.y * wgt; acc.z += v.z * wgt; acc.w += v.w * wgt;
+      for (int e = e0 + GC_E; e < e1; ++e) {
+        const float wg = __int_as_float(entries[2 * (long)e + 1]);
+        const float4 vv = *(const float4*)(gout + (long)entries[2 * (long)e] * c + g * 4);
+        acc.x += vv.x * wg; acc.y += vv.y * wg; acc.z += vv.z * wg; acc.w += vv.w * wg;
       }
       *(float4*)(gfeat + d * c + g * 4) = acc;
     }
