@@ -587,6 +587,64 @@ extern "C" int dis_gn_bwd_from_sums(const float* g, const float* x, const double
   return DIS_OK;
 }
 
+// Channel sums for the from-sums backward when NO convolution produced the gradient (round 5): the GroupNorm's output gradient comes
+// from a join / a resize / a feature warp, so nobody left A_c = sum g, B_c = sum g x.  One pass over gy (and y: g = gy act'(y), stored
+// as the residual gradient when the GroupNorm has a residual; and x) writes them in the slot layout of the convolution epilogues -
+// block (s, n) -> ab[n][s][2][c] - after which the backward is dis_gn_bwd_coef + an elementwise pass that the producer of x applies on
+// load (dis_conv2d_dgrad_f16x2_gnb): the reduce + apply pair of dis_gn_apply_bwd (read gy, y, x twice, write gx, gres) becomes
+// read gy, y, x; write gres.  A thread keeps its 4 channels over its items (the stride is a multiple of c / 4); fixed orders.
+#define GN_RS_T 256
+__global__ __launch_bounds__(GN_RS_T) void gn_res_sums_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                              const float* __restrict__ x, float* __restrict__ gres,
+                                                              double* __restrict__ ab, long hw, int c, int act, int nt) {
+  __shared__ float sa[GN_RS_T][4], sb[GN_RS_T][4];
+  const int n = blockIdx.y, t = threadIdx.x;
+  const int cg = c >> 2;
+  const long per4 = hw * cg;
+  const float4* gp = (const float4*)(gy + (long)n * hw * c);
+  const float4* yp = y ? (const float4*)(y + (long)n * hw * c) : nullptr;
+  const float4* xp = (const float4*)(x + (long)n * hw * c);
+  float4* rp = gres ? (float4*)(gres + (long)n * hw * c) : nullptr;
+  float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long i = blockIdx.x * (long)GN_RS_T + t; i < per4; i += (long)gridDim.x * GN_RS_T) {
+    float4 g = gn_ld4(gp + i, nt & 2);
+    if (yp) {
+      const float4 yv = gn_ld4(yp + i, nt & 2);
+      g.x *= act_grad_from_out(yv.x, act); g.y *= act_grad_from_out(yv.y, act);
+      g.z *= act_grad_from_out(yv.z, act); g.w *= act_grad_from_out(yv.w, act);
+    }
+    if (rp) rp[i] = g;   // (read again by the consumers of the residual gradient and by the on-load pass: a plain store)
+    const float4 xv = gn_ld4(xp + i, nt & 2);
+    a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
+    b[0] = __builtin_fmaf(g.x, xv.x, b[0]); b[1] = __builtin_fmaf(g.y, xv.y, b[1]);
+    b[2] = __builtin_fmaf(g.z, xv.z, b[2]); b[3] = __builtin_fmaf(g.w, xv.w, b[3]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sa[t][k] = a[k], sb[t][k] = b[k];
+  __syncthreads();
+  if (t < 2 * c) {   // thread j < c: A_j, c <= j < 2c: B_(j - c): the GN_RS_T / cg threads of channel group j / 4, in thread order
+    const int ch = t < c ? t : t - c, grp = ch >> 2, k = ch & 3;
+    double v = 0.0;
+    for (int u = grp; u < GN_RS_T; u += cg) v += (double)(t < c ? sa[u][k] : sb[u][k]);
+    ab[((long)n * gridDim.x + blockIdx.x) * (2 * c) + t] = v;
+  }
+}
+/* gy (n, hw, c): gradient wrt the output of a GroupNorm(1 group) with input x; y / act: the output and its activation when the output
+ * went through one (g = gy act'(y); NULL / DIS_ACT_NONE: g = gy); gres: g stored (the residual gradient; may be NULL).
+ * ab_out (n, slots, 2, c) doubles, every slot written: slots = dis_conv2d_gnsums_slots() when the result feeds dis_gn_bwd_coef.
+ * c % 4 == 0, 2 c <= 64, 256 % (c / 4) == 0. */
+extern "C" int dis_gn_bwd_res_sums(const float* gy, const float* y, const float* x, float* gres, double* ab_out, int slots, int n,
+                                   long hw, int c, int act, void* stream) {
+  if (!gy || !x || !ab_out) return DIS_ERR_NULL;
+  if (act != DIS_ACT_NONE && !y) return DIS_ERR_NULL;
+  if (n <= 0 || hw <= 0 || c <= 0 || slots <= 0 || n > 65535) return DIS_ERR_BAD_SHAPE;
+  if (c % 4 != 0 || 2 * c > 64 || GN_RS_T % (c / 4) != 0) return DIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gn_res_sums_kernel, dim3(slots, n), dim3(GN_RS_T), 0, (hipStream_t)stream, gy, act != DIS_ACT_NONE ? y : nullptr, x,
+                     gres, ab_out, hw, c, act, gn_nt_flags());
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 /* The two halves of dis_gn_bwd_from_sums as separate entry points (round 5): the consumer of gx is usually the 3x3 convolution in
  * front of the GroupNorm, whose input-gradient launch can apply the elementwise pass while it stages its operand
  * (dis_conv2d_dgrad_f16x2_gnb) - the pass over g, x and gx then does not exist.

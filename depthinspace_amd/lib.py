@@ -82,6 +82,7 @@ SIGS = {
     'dis_conv2d_fwd_k4s2_f16x2': 'pppppiiiip',
     'dis_conv2d_dgrad_k4s2_f16x2': 'pppiiiip',
     'dis_gn_bwd_coef': 'pppippppilifp',
+    'dis_gn_bwd_res_sums': 'pppppiiliip',
     'dis_gn_bwd_apply_coef': 'ppppiliip',
     'dis_conv2d_dgrad_f16x2_gnb': 'pppippiiipippp' + 'iiiip',
     'dis_conv2d_wgrad_bf16x3_gn': 'ppppfppppiiiiiiiiip',

@@ -1233,6 +1233,8 @@ class _Conv2dMulti(torch.autograd.Function):
     def forward(ctx, weight, bias, pad, act, want_stats, gy_is_pre, gn_stats, gn_gamma, gn_beta, gn_meta, *xs):
         ctx.x0_lazy = gn_meta is not None and len(gn_meta) > 2 and bool(gn_meta[2])
         gn_meta = gn_meta[:2] if gn_meta is not None else None
+        # (tokens of a GroupNorm behind this conv are redeemed by the first source's 3 x 3 c -> c input-gradient launch)
+        ctx.lazy_ok = _multi_lazy_ok(weight, xs, pad, act)
         # a source that is SELU(GroupNorm(x2) + residual) of a ResNetBlock and has no other consumer: its input-gradient launch
         # leaves that GroupNorm's backward sums (as _Conv2d.backward does for final_conv)
         ctx.gnres = [getattr(x, '_gn_res_src', None) if x.requires_grad else None for x in xs]
@@ -1277,10 +1279,19 @@ class _Conv2dMulti(torch.autograd.Function):
         pad, act, has_bias, cs, gn_meta = ctx.cfg
         cout, cin, k, _ = weight.shape
         n, h, w, _ = xs[0].shape
-        gy = _c(gy)
         fuse_act = act != ACT_NONE and all(_bx_shape(c_, cout, k, 1) for c_ in cs)  # see _Conv2d.backward
         assert gn_meta is None or act == ACT_NONE
-        if act != ACT_NONE and not fuse_act:
+        # this conv's output gradient may be a token of the GroupNorm behind it (conv_fuse): the FIRST source's input-gradient launch
+        # applies the elementwise pass on load and stores the result for every other launch of this node
+        lz = _gn_lazy_pop(gy)
+        if lz is not None and not (act == ACT_NONE and ctx.lazy_ok and ctx.needs_input_grad[10] and
+                                   (gn_meta is None or (GN_SUMS & 8)) and lib.fn('dis_get_conv_split')() == 1):
+            gy, lz = _gn_lazy_materialize(lz), None
+        if lz is None:
+            gy = _c(gy)
+        if lz is not None:
+            gpre = None   # (set by the first source's launch below)
+        elif act != ACT_NONE and not fuse_act:
             gpre = torch.empty_like(gy)
             lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
         else:
@@ -1305,8 +1316,14 @@ class _Conv2dMulti(torch.autograd.Function):
                     if (GN_SUMS & 8) and lib.fn('dis_get_conv_split')() == 1:
                         slots = lib.fn('dis_conv2d_gnsums_slots')()
                         ab = _zeros_d(n * slots * 2 * cs[0], x.device)
-                        lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, wi, cout, cs[0], wi.stride(0), gnorm, x, ab, n,
-                                 gpre.shape[1], gpre.shape[2], cout, cs[0], k - 1 - pad)
+                        if lz is not None:
+                            _, lg, lq, lcoef, lin_act = lz
+                            gpre, lz = torch.empty_like(lg), None
+                            lib.call('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, wi, cout, cs[0], wi.stride(0), gnorm, 0,
+                                     x, None, ab, n, h, w, cs[0])
+                        else:
+                            lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, wi, cout, cs[0], wi.stride(0), gnorm, x, ab, n,
+                                     gpre.shape[1], gpre.shape[2], cout, cs[0], k - 1 - pad)
                         if ctx.x0_lazy and GN_LAZY:   # (the producer of xs[0] applies the elementwise pass on load: _GN_LAZY)
                             gx = _gn_lazy_defer(gnorm, x, gn_stats, gn_gamma, ab, slots, gg, gbt, n, h * w, cs[0], float(eps), in_act)
                         else:
@@ -1331,9 +1348,15 @@ class _Conv2dMulti(torch.autograd.Function):
                 elif fuse_act:
                     lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, wi, cout, cs[i], wi.stride(0), gx, n, gy.shape[1],
                              gy.shape[2], cout, cs[i], k - 1 - pad, 0)
+                elif lz is not None:   # (i == 0: the token's pass on load, no epilogue)
+                    _, lg, lq, lcoef, lin_act = lz
+                    gpre, lz = torch.empty_like(lg), None
+                    lib.call('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, wi, cout, cs[i], wi.stride(0), gx, 0, None, None,
+                             None, n, h, w, cs[i])
                 else:
                     _conv_fwd_any(gpre, wi, cs[i], 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cs[i], k, 1,
                                   k - 1 - pad, ACT_NONE)
+            assert lz is None   # (redeemed by the first source's launch: ctx.lazy_ok guarantees that it has one)
             gxs.append(gx)
             gwi = torch.empty((cout, cs[i], k, k), dtype=torch.float32, device=x.device)
             wsz = lib.fn('dis_conv2d_wgrad_workspace')(cs[i], cout, k, 1)
@@ -1354,13 +1377,22 @@ class _Conv2dMulti(torch.autograd.Function):
         return (gw_ret, gb_ret, None, None, None, None, None, gg_ret, gbt_ret, None) + tuple(gxs)
 
 
+def _multi_lazy_ok(weight, xs, pad, act):
+    cout, _, k, _ = weight.shape
+    return bool(act == ACT_NONE and xs[0].requires_grad and xs[0].shape[-1] == cout and _gn_lazy_shape(cout, cout, k, 1, pad))
+
+
 def conv2d_multi(xs, weight, bias, pad=0, act=ACT_NONE, want_stats=False, gy_is_pre=False, gn0=None):
     """conv2d(cat(xs, channel dim), weight) without the cat.  Returns (y, stats|None).
     gn0 = (stats, gamma, beta, eps, in_act): xs[0] is the INPUT of a GroupNorm(1 group) that is applied on load (conv2d_gn_in)."""
     if gn0 is not None:
-        return _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, gn0[0], gn0[1], gn0[2],
-                                  (gn0[3], gn0[4], bool(getattr(xs[0], '_gn_lazy_ok', False))), *xs)
-    return _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, None, None, None, None, *xs)
+        out = _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, gn0[0], gn0[1], gn0[2],
+                                 (gn0[3], gn0[4], bool(getattr(xs[0], '_gn_lazy_ok', False))), *xs)
+    else:
+        out = _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, None, None, None, None, *xs)
+    if _multi_lazy_ok(weight, xs, pad, act):
+        out[0]._gn_lazy_ok = True   # (a GroupNorm that is this output's ONLY consumer may answer with a token, see _GN_LAZY)
+    return out
 
 
 class _Conv2dScaledIn(torch.autograd.Function):
@@ -2017,13 +2049,27 @@ class _GroupNorm(torch.autograd.Function):
             # two-pass form below would apply act' a second time.  No networks here reach this; a new caller must not do so silently.
             raise RuntimeError(f'group_norm backward: channel sums were registered for this gradient but no from-sums form matches '
                                f'(residual={has_res}, act={act}, in_act={in_act})')
-        gx = torch.empty_like(x)
-        gres = torch.empty_like(x) if has_res else None
-        wtot = lib.fn('dis_gn_bwd_workspace')(n, c)
-        ws = torch.empty(wtot, dtype=torch.float64, device=x.device)
-        nred2 = wtot // (2 + 2 * c) * 2  # (n * blocks-per-sample-max) pairs of per-block sums, then the parameter partials
-        red, pacc = ws[:nred2], ws[nred2:]
-        lib.call('dis_gn_apply_bwd', gy, y, x, stats, gamma, gx, gres, gg, gb, red, pacc, n, hw, c, act, eps, in_act)
+        if (ctx.x_lazy and GN_LAZY and GN_RES_SUMS and c in (16, 32) and x.dim() == 4 and (act == ACT_NONE or has_res) and
+                (in_act == ACT_NONE or act == ACT_NONE) and lib.fn('dis_get_conv_split')() == 1):
+            # nobody left channel sums for this gradient (it comes from a join, a resize, a feature warp), but the producer of x
+            # redeems tokens: ONE pass forms g = gy act'(y) (the residual gradient, stored), and the sums of g and g x; the
+            # elementwise pass rides on the producer's input-gradient launch (instead of a reduce and an apply launch over gy, y, x)
+            slots = lib.fn('dis_conv2d_gnsums_slots')()
+            ab = _zeros_d(n * slots * 2 * c, x.device)
+            gres = torch.empty_like(x) if (has_res or act != ACT_NONE) else None
+            lib.call('dis_gn_bwd_res_sums', gy, y, x, gres, ab, slots, n, hw, c, act)
+            g_ = gres if gres is not None else gy.view(x.shape)
+            gx = _gn_lazy_defer(g_, x, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, in_act)
+            if not has_res:
+                gres = None
+        else:
+            gx = torch.empty_like(x)
+            gres = torch.empty_like(x) if has_res else None
+            wtot = lib.fn('dis_gn_bwd_workspace')(n, c)
+            ws = torch.empty(wtot, dtype=torch.float64, device=x.device)
+            nred2 = wtot // (2 + 2 * c) * 2  # (n * blocks-per-sample-max) pairs of per-block sums, then the parameter partials
+            red, pacc = ws[:nred2], ws[nred2:]
+            lib.call('dis_gn_apply_bwd', gy, y, x, stats, gamma, gx, gres, gg, gb, red, pacc, n, hw, c, act, eps, in_act)
         if gres is not None and ctx.join is not None:
             if ctx.join.buf is None:
                 gres = ctx.join.first(gres)
@@ -2038,6 +2084,7 @@ def c_ok(x):
 
 
 GN_DEFER = _os.environ.get('DIS_GN_DEFER', '1') != '0'
+GN_RES_SUMS = _os.environ.get('DIS_GN_RES_SUMS', '1') != '0'   # =0: dis_gn_apply_bwd (reduce + apply launches) where no conv left the channel sums
 
 
 def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5, in_act=ACT_NONE, join=None, defer=False):

@@ -363,6 +363,13 @@ int dis_conv2d_fwd_k4s2_f16x2(const float* x, const float* w_oihw, const float* 
 /* ... and its input gradient: gx (n, hin, win, 32) (+)= conv_transpose(gy (n, hin / 2, win / 2, 32), w), the four parity classes from
  * one gy halo tile in one launch (replaces dis_conv2d_dgrad_strided's four launches + four packing launches); hin, win even. */
 int dis_conv2d_dgrad_k4s2_f16x2(const float* gy, const float* w_oihw, float* gx, int n, int hin, int win, int accumulate, void* stream);
+/* Round 5: the channel sums dis_gn_bwd_coef starts from when NO convolution epilogue left them (the gradient wrt the GroupNorm's output
+ * arrives from a join, a resize or a feature warp: Block2D3D's conv_fuse GroupNorm with its residual, model/multi_frame_networks.py
+ * :338-345, FuseNet.res3's last GroupNorm, :514-542): g = gy * act'(y) (y / act: the GroupNorm output's activation; NULL / 0: g = gy),
+ * g stored to gres when given (the residual gradient), ab_out (n, slots, 2, c) doubles = per-block sums of g and g * x, every slot
+ * written.  With dis_gn_bwd_coef and an on-load elementwise pass this replaces dis_gn_apply_bwd's reduce + apply launches. */
+int dis_gn_bwd_res_sums(const float* gy, const float* y, const float* x, float* gres, double* ab_out, int slots, int n, long hw, int c,
+                        int act, void* stream);
 int dis_gn_bwd_coef(const double* stats, const float* gamma, const double* ab, int slots, float* coef, float* grad_gamma,
                     float* grad_beta, unsigned* counter, int n, long hw, int c, float eps, void* stream);
 int dis_gn_bwd_apply_coef(const float* g, const float* x, const float* coef, float* gx, int n, long hw, int c, int in_act,

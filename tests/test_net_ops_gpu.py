@@ -637,6 +637,91 @@ def test_resnet_chain_with_deferred_block_outputs(c, n, h, w):
         assert torch.equal(a_, b_), (i, float((a_ - b_).abs().max()))
 
 
+@pytest.mark.parametrize('c', [16, 32])
+@pytest.mark.parametrize('act,res', [(1, True), (0, False)])
+@pytest.mark.parametrize('n,hw', [(3, 37 * 29), (2, 64 * 48), (1, 5)])
+def test_gn_bwd_res_sums(c, act, res, n, hw):
+    """dis_gn_bwd_res_sums (round 5): g = gy SELU'(y) stored, per-(sample, channel) sums of g and g x in the slot layout of the conv
+    epilogues (n, slots, 2, c) - against fp64; the sums repeat bit for bit."""
+    from depthinspace_amd import ops
+    L = ops.lib
+    g_ = torch.Generator().manual_seed(c + hw + act)
+    gy = torch.randn(n, hw, c, generator=g_).cuda()
+    y = (torch.randn(n, hw, c, generator=g_) * 1.5).cuda()
+    x = (torch.randn(n, hw, c, generator=g_) * 2 + 0.3).cuda()
+    slots = L.fn('dis_conv2d_gnsums_slots')()
+    outs = []
+    for _ in range(2):
+        ab = torch.full((n, slots, 2, c), float('nan'), dtype=torch.float64, device='cuda')
+        gres = torch.full_like(gy, float('nan')) if res else None
+        L.call('dis_gn_bwd_res_sums', gy, y if act else None, x, gres, ab, slots, n, hw, c, act)
+        outs.append((ab.clone(), gres.clone() if res else None))
+    assert torch.equal(outs[0][0], outs[1][0])
+    yd = y.double()
+    sel = torch.where(yd > 0, torch.full_like(yd, 1.0507009873554805), yd + 1.0507009873554805 * 1.6732632423543772)
+    g = gy.double() * sel if act else gy.double()
+    if res:
+        assert relerr(outs[0][1], g) < 1e-6
+    ab = outs[0][0].sum(dim=1)   # (n, 2, c)
+    assert relerr(ab[:, 0], g.sum(dim=1)) < 2e-6
+    assert relerr(ab[:, 1], (g * x.double()).sum(dim=1)) < 2e-6
+
+
+@pytest.mark.parametrize('fuse_a', [True, False])
+@pytest.mark.parametrize('n,h,w', [(3, 37, 29), (2, 64, 48)])
+def test_conv_multi_group_norm_backward_from_a_join(fuse_a, n, h, w):
+    """Block2D3D's tail (reference model/multi_frame_networks.py:338-345): out = SELU(GroupNorm(conv_fuse(cat(a, b, c))) + feat), whose
+    output gradient arrives from a join (no conv epilogue left channel sums).  Round 5: one pass forms the residual gradient and the
+    sums (dis_gn_bwd_res_sums), the elementwise pass rides on the first slice's input-gradient launch of conv_fuse
+    (dis_conv2d_dgrad_f16x2_gnb) - against dis_gn_apply_bwd's reduce + apply launches (DIS_GN_RES_SUMS=0) and against torch."""
+    from depthinspace_amd import ops
+    if ops.lib.fn('dis_get_conv_split')() != 1:
+        pytest.skip('two-term fp16 kernels only')
+    C = 32
+    g_ = torch.Generator().manual_seed(n + h)
+    mk = lambda *sh, s=1.0: (torch.randn(*sh, generator=g_) * s)
+    a0, b0, c0, feat0 = mk(n, h, w, C), mk(n, h, w, C), mk(n, h, w, C), mk(n, h, w, C)
+    wt, bias = mk(C, 3 * C, 3, 3, s=0.06), mk(C, s=0.1)
+    gam, bet = mk(C, s=0.2) + 0.8, mk(C, s=0.2)
+    gam_a, bet_a = mk(C, s=0.2) + 0.9, mk(C, s=0.2)
+    go = mk(n, h, w, C)
+    runs = []
+    for flag in (True, False):
+        ops.GN_RES_SUMS = flag
+        try:
+            ops.begin_step('cuda:0')
+            leaves = [t.clone().cuda().requires_grad_(True) for t in (a0, b0, c0, feat0, wt, bias, gam, bet, gam_a, bet_a)]
+            a, b, c, feat, wd, bd, gd, btd, gad, bad = leaves
+            if fuse_a:   # the first source is a GroupNorm input applied on load (conv1_2's GroupNorm), as in Block2D3D
+                # (a conv in front so that the source is a conv output, as the token path requires of its producer)
+                a_in, st_a = ops.conv2d(a, wd[:, :C].contiguous() * 0.5, None, 1, 1, ops.ACT_SELU, want_stats=True, gy_is_pre=True)
+                f, st = ops.conv2d_multi((a_in, b, c), wd, bd, 1, ops.ACT_NONE, want_stats=True, gn0=(st_a, gad, bad, 1e-5, ops.ACT_SELU))
+            else:
+                f, st = ops.conv2d_multi((a, b, c), wd, bd, 1, ops.ACT_NONE, want_stats=True)
+            out = ops.group_norm(f, gd, btd, stats=st, residual=feat, act=ops.ACT_SELU)
+            out.backward(go.cuda())
+            torch.cuda.synchronize()
+            assert not ops._GN_LAZY and not ops._GN_PRE
+            runs.append([out.detach().clone()] + [t.grad.clone() if t.grad is not None else None for t in leaves])
+        finally:
+            ops.GN_RES_SUMS = True
+    for i, (p_, q_) in enumerate(zip(runs[0], runs[1])):
+        if p_ is None:
+            assert q_ is None
+            continue
+        assert relerr(p_, q_) < 2e-5, (i, relerr(p_, q_))
+    if not fuse_a:   # torch reference of the plain form
+        lv = [t.clone().double().requires_grad_(True) for t in (a0, b0, c0, feat0, wt, bias, gam, bet)]
+        a, b, c, feat, wd, bd, gd, btd = lv
+        xin = torch.cat([a, b, c], 3).permute(0, 3, 1, 2)
+        f = F.conv2d(xin, wd, bd, padding=1)
+        o = F.selu(F.group_norm(f, 1, gd, btd, 1e-5) + feat.permute(0, 3, 1, 2))
+        o.backward(go.double().permute(0, 3, 1, 2))
+        assert relerr(nchw(runs[0][0]), o) < 1e-5
+        for i, t in enumerate(lv):
+            assert relerr(runs[0][1 + i], t.grad) < 5e-5, i
+
+
 @pytest.mark.parametrize('in_act', [0, 1])
 @pytest.mark.parametrize('accum', [0, 1])
 @pytest.mark.parametrize('n,h,w', [(3, 21, 37), (2, 64, 48)])
