@@ -29,7 +29,9 @@ def test_single_gpu_line_roofline_covers_the_whole_kernel_family():
     # every 32 -> 32 launch of the dominant template: forward, GroupNorm-on-load, all input-gradient forms
     assert r['launches_per_step'] == 76, r['launches_by_entry_point']
     assert sum(r['launches_by_entry_point'].values()) == 76
-    assert any(k.startswith('dis_conv2d_dgrad_bf16x3_gnsums') for k in r['launches_by_entry_point'])
+    # (round 5: every input-gradient launch in front of a GroupNorm applies that GroupNorm's backward pass on load - the channel-sum
+    #  epilogues of dis_conv2d_dgrad_bf16x3_gnsums* run inside dis_conv2d_dgrad_f16x2_gnb launches)
+    assert any(k.startswith(('dis_conv2d_dgrad_bf16x3_gnsums', 'dis_conv2d_dgrad_f16x2_gnb')) for k in r['launches_by_entry_point'])
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] == ('GB/s' if r['bound'] == 'hbm' else 'TFLOP/s')
     assert abs(r['frac'] - max(r['frac_mfma'], r['frac_hbm'])) < 1e-12
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
