@@ -1038,17 +1038,18 @@ __device__ __forceinline__ void reproject(const GeoCam& cam, int u, int v, float
   vec_matT(xc, cam.K, uvw);  // uvw = xc . K^T
 }
 
-__global__ void geo_loss_fwd_kernel(const float* __restrict__ depth0, const float* __restrict__ depth1,
-                                    const float* __restrict__ flow0, const float* __restrict__ flow1,
-                                    const float* __restrict__ amb0, const float* __restrict__ amb1,
-                                    const float* __restrict__ pdepth1, const float* __restrict__ R0,
-                                    const float* __restrict__ t0, const float* __restrict__ R1,
-                                    const float* __restrict__ t1, GeoCam cam, float clampv,
-                                    float* __restrict__ mask_out, double* __restrict__ acc, int bs, int h, int w) {
-  __shared__ double sm[8];
+// (bid / nblk: the block's index and the block count of THIS term - of a launch of its own, or its row of a multi-term launch)
+__device__ __forceinline__ void geo_loss_fwd_body(double* sm, const float* __restrict__ depth0, const float* __restrict__ depth1,
+                                                  const float* __restrict__ flow0, const float* __restrict__ flow1,
+                                                  const float* __restrict__ amb0, const float* __restrict__ amb1,
+                                                  const float* __restrict__ pdepth1, const float* __restrict__ R0,
+                                                  const float* __restrict__ t0, const float* __restrict__ R1,
+                                                  const float* __restrict__ t1, const GeoCam& cam, float clampv,
+                                                  float* __restrict__ mask_out, double* __restrict__ acc, int bs, int h, int w,
+                                                  const int bid, const int nblk) {
   const long hw = (long)h * w, total = (long)bs * hw;
   double s_diff = 0.0, s_mask = 0.0;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = bid * (long)blockDim.x + threadIdx.x; i < total; i += (long)nblk * blockDim.x) {
     const int b = (int)(i / hw);
     const long p = i - (long)b * hw;
     const int y = (int)(p / w), x = (int)(p - (long)y * w);
@@ -1100,9 +1101,20 @@ __global__ void geo_loss_fwd_kernel(const float* __restrict__ depth0, const floa
   double r0 = block_sum_d(s_diff, sm);
   double r1 = block_sum_d(s_mask, sm);
   if (threadIdx.x == 0) {
-    acc[2 + 2 * blockIdx.x] = r0;
-    acc[3 + 2 * blockIdx.x] = r1;
+    acc[2 + 2 * bid] = r0;
+    acc[3 + 2 * bid] = r1;
   }
+}
+__global__ void geo_loss_fwd_kernel(const float* __restrict__ depth0, const float* __restrict__ depth1,
+                                    const float* __restrict__ flow0, const float* __restrict__ flow1,
+                                    const float* __restrict__ amb0, const float* __restrict__ amb1,
+                                    const float* __restrict__ pdepth1, const float* __restrict__ R0,
+                                    const float* __restrict__ t0, const float* __restrict__ R1,
+                                    const float* __restrict__ t1, GeoCam cam, float clampv,
+                                    float* __restrict__ mask_out, double* __restrict__ acc, int bs, int h, int w) {
+  __shared__ double sm[8];
+  geo_loss_fwd_body(sm, depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1, cam, clampv, mask_out, acc, bs, h, w,
+                    (int)blockIdx.x, (int)gridDim.x);
 }
 #define GEO_BLOCKS 1024
 __global__ __launch_bounds__(256) void geo_finalize_kernel(double* __restrict__ acc, float* __restrict__ out, int nblocks,
@@ -1207,6 +1219,133 @@ extern "C" int dis_geo_loss_bwd(const float* depth0, const float* depth1, const 
   hipLaunchKernelGGL(geo_loss_bwd_kernel, dim3(dis_ew_grid((long)bs * h * w, 256)), dim3(256), 0,
                      (hipStream_t)stream, depth0, depth1, flow0, R0, t0, R1, t1, cam, clampv, mask, acc, gscale,
                      grad_depth0, grad_depth1, bs, h, w);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
+// ---- all directional terms of a step in one launch each way (round 5) ----
+// A training step evaluates tl (tl - 1) = 12 directional terms (model/multi_frame_worker.py:139-158, single_frame_worker.py:126-149),
+// each over bs images only: 12 forward, 12 finalize and 12 backward launches of 20 - 40 us that are bound by the latency of their
+// dependent gathers, not by their 50 MB.  Here blockIdx.y selects the term (pointer table by value), every term keeps its own block
+// slots, sums and 1 / (mask sum) - the forward values are those of the single launches bit for bit; the backward adds BOTH depth
+// gradients with float atomics (terms that share a frame run concurrently; the single launch's `+=` would race), so the depth
+// gradient repeats to rounding, not bitwise, like the warped frame's always did.
+#define GEO_MULTI_MAX 16
+#define GEO_MULTI_BLOCKS 1024   // (= GEO_BLOCKS: the same partition of the pixels as a single-term launch, hence the same sums)
+struct GeoTermTable {
+  DisGeoTerm t[GEO_MULTI_MAX];
+};
+__global__ __launch_bounds__(256) void geo_loss_fwd_multi_kernel(const GeoTermTable tab, GeoCam cam, float clampv,
+                                                                 double* __restrict__ acc, int bs, int h, int w) {
+  __shared__ double sm[8];
+  const DisGeoTerm& q = tab.t[blockIdx.y];
+  geo_loss_fwd_body(sm, q.depth0, q.depth1, q.flow0, q.flow1, q.amb0, q.amb1, q.pdepth1, q.R0, q.t0, q.R1, q.t1, cam, clampv, q.mask,
+                    acc + (long)blockIdx.y * (2 + 2 * GEO_MULTI_BLOCKS), bs, h, w, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ __launch_bounds__(256) void geo_finalize_multi_kernel(double* __restrict__ acc, float* __restrict__ out, int nblocks,
+                                                                 double eps_den) {
+  __shared__ double sm[8];
+  double* ac = acc + (long)blockIdx.x * (2 + 2 * GEO_MULTI_BLOCKS);
+  double a = 0.0, b = 0.0;
+  for (int k = threadIdx.x; k < nblocks; k += 256) {
+    a += ac[2 + 2 * k];
+    b += ac[3 + 2 * k];
+  }
+  a = block_sum_d(a, sm);
+  b = block_sum_d(b, sm);
+  if (threadIdx.x == 0) {
+    ac[0] = a;
+    ac[1] = b;
+    out[blockIdx.x] = (float)((float)a / ((float)b + (float)eps_den));
+  }
+}
+__global__ __launch_bounds__(256) void geo_loss_bwd_multi_kernel(const GeoTermTable tab, GeoCam cam, float clampv,
+                                                                 const double* __restrict__ acc, const float* __restrict__ gscale,
+                                                                 int bs, int h, int w) {
+  const DisGeoTerm& q = tab.t[blockIdx.y];
+  const float* __restrict__ depth0 = q.depth0;
+  const float* __restrict__ depth1 = q.depth1;
+  const float* __restrict__ flow0 = q.flow0;
+  const float* __restrict__ mask = q.mask;
+  const long hw = (long)h * w, total = (long)bs * hw;
+  const float gs = gscale[blockIdx.y] / ((float)acc[(long)blockIdx.y * (2 + 2 * GEO_MULTI_BLOCKS) + 1] + 1e-8f);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float m = mask[i];
+    if (m == 0.f) continue;
+    const int b = (int)(i / hw);
+    const long p = i - (long)b * hw;
+    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    const float *rA = q.R0 + b * 9, *tA = q.t0 + b * 3, *rB = q.R1 + b * 9, *tB = q.t1 + b * 3;
+    float uvw[3];
+    reproject(cam, x, y, depth0[i], rA, tA, rB, tB, uvw);
+    const float d1 = uvw[2];
+    const float f0x = flow0[(long)b * 2 * hw + p], f0y = flow0[(long)b * 2 * hw + hw + p];
+    Bilin bl = bilin_zeros(f0x + (float)x, f0y + (float)y, h, w);
+    const float depth10 = bilin_fetch(depth1 + (long)b * hw, bl, w);
+    const float raw = d1 - depth10;
+    const float a = fabsf(raw);
+    if (clampv > 0.f && a > clampv) continue;
+    const float sgn = raw > 0.f ? 1.f : (raw < 0.f ? -1.f : 0.f);
+    const float g = gs * m * sgn;
+    float ray[3], a1[3], a2[3], a3[3];
+    pixel_ray(cam.Ki, x, y, ray);
+    vec_mat(ray, rA, a1);
+    vec_matT(a1, rB, a2);
+    vec_matT(a2, cam.K, a3);
+    atomicAdd(q.gdepth0 + i, g * a3[2]);
+    float* g1 = q.gdepth1 + (long)b * hw;
+    if (bl.v00) atomicAdd(g1 + (long)bl.y0 * w + bl.x0, -g * bl.nw);
+    if (bl.v01) atomicAdd(g1 + (long)bl.y0 * w + bl.x0 + 1, -g * bl.ne);
+    if (bl.v10) atomicAdd(g1 + (long)(bl.y0 + 1) * w + bl.x0, -g * bl.sw);
+    if (bl.v11) atomicAdd(g1 + (long)(bl.y0 + 1) * w + bl.x0 + 1, -g * bl.se);
+  }
+}
+extern "C" long dis_geo_loss_multi_acc_doubles(int nterms) {
+  return nterms > 0 && nterms <= GEO_MULTI_MAX ? (long)nterms * (2 + 2 * GEO_MULTI_BLOCKS) : -1;
+}
+static int geo_multi_table(const DisGeoTerm* terms, int nterms, bool bwd, GeoTermTable* tab) {
+  for (int k = 0; k < nterms; ++k) {
+    const DisGeoTerm& q = terms[k];
+    if (!q.depth0 || !q.depth1 || !q.flow0 || !q.R0 || !q.t0 || !q.R1 || !q.t1 || !q.mask) return DIS_ERR_NULL;
+    if (!bwd && (!q.flow1 || !q.amb0 || !q.amb1)) return DIS_ERR_NULL;
+    if (bwd && (!q.gdepth0 || !q.gdepth1)) return DIS_ERR_NULL;
+    tab->t[k] = q;
+  }
+  for (int k = nterms; k < GEO_MULTI_MAX; ++k) tab->t[k] = DisGeoTerm{};
+  return DIS_OK;
+}
+extern "C" int dis_geo_loss_fwd_multi(const DisGeoTerm* terms, int nterms, const float* K_host, const float* Kinv_host, float clampv,
+                                      double* acc, float* out, int bs, int h, int w, void* stream) {
+  if (!terms || !K_host || !Kinv_host || !acc || !out) return DIS_ERR_NULL;
+  if (nterms <= 0 || bs <= 0 || h <= 1 || w <= 1) return DIS_ERR_BAD_SHAPE;
+  if (nterms > GEO_MULTI_MAX) return DIS_ERR_UNSUPPORTED;
+  GeoTermTable tab;
+  const int rc = geo_multi_table(terms, nterms, false, &tab);
+  if (rc != DIS_OK) return rc;
+  GeoCam cam;
+  fill_cam(cam, K_host, Kinv_host);
+  hipStream_t s = (hipStream_t)stream;
+  const long gl = ((long)bs * h * w + 255) / 256;
+  const int grid = (int)(gl > GEO_MULTI_BLOCKS ? GEO_MULTI_BLOCKS : gl);
+  hipLaunchKernelGGL(geo_loss_fwd_multi_kernel, dim3(grid, nterms), dim3(256), 0, s, tab, cam, clampv, acc, bs, h, w);
+  hipLaunchKernelGGL(geo_finalize_multi_kernel, dim3(nterms), dim3(256), 0, s, acc, out, grid, 1e-8);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+extern "C" int dis_geo_loss_bwd_multi(const DisGeoTerm* terms, int nterms, const float* K_host, const float* Kinv_host, float clampv,
+                                      const double* acc, const float* gscale, int bs, int h, int w, void* stream) {
+  if (!terms || !K_host || !Kinv_host || !acc || !gscale) return DIS_ERR_NULL;
+  if (nterms <= 0 || bs <= 0 || h <= 1 || w <= 1) return DIS_ERR_BAD_SHAPE;
+  if (nterms > GEO_MULTI_MAX) return DIS_ERR_UNSUPPORTED;
+  GeoTermTable tab;
+  const int rc = geo_multi_table(terms, nterms, true, &tab);
+  if (rc != DIS_OK) return rc;
+  GeoCam cam;
+  fill_cam(cam, K_host, Kinv_host);
+  long gl = ((long)bs * h * w + 255) / 256;
+  if (gl > 1024) gl = 1024;
+  hipLaunchKernelGGL(geo_loss_bwd_multi_kernel, dim3((unsigned)gl, nterms), dim3(256), 0, (hipStream_t)stream, tab, cam, clampv, acc,
+                     gscale, bs, h, w);
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

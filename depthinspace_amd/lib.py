@@ -114,6 +114,9 @@ SIGS = {
     'dis_conv3d_knn_bwd_agg': 'ppppppp' + 'ppppppp' + 'iiiiip',
     'dis_conv3d_knn_bwd_det_workspace': 'iiiii',
     'dis_geo_loss_acc_doubles': '',
+    'dis_geo_loss_multi_acc_doubles': 'i',
+    'dis_geo_loss_fwd_multi': 'pippfppiiip',
+    'dis_geo_loss_bwd_multi': 'pippfppiiip',
     'dis_conv3d_knn_bwd_workspace': '',
     'dis_conv3d_knn_bwd': 'ppppppp' + 'pppppp' + 'iiiiip',
     'dis_conv3d_knn_bwd_csr': 'ppppppp' + 'pppppp' + 'ppi' + 'iiiiip',
@@ -148,7 +151,7 @@ SIGS = {
     'dis_adam_step_dev': 'pppplfddfpfp',
 }
 _RET_LONG = {'dis_convb_pack_desc_bytes', 'dis_convg_splitk_workspace', 'dis_convb_splitk_workspace', 'dis_conv2d_gnsums_slots', 'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
-             'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_act_bwd_ld_bias_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_geo_loss_acc_doubles', 'dis_conv3d_knn_bwd_det_workspace', 'dis_conv3d_knn_bwd_stage', 'dis_conv3d_csr_workspace', 'dis_gather_csr_workspace',
+             'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_act_bwd_ld_bias_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_geo_loss_acc_doubles', 'dis_geo_loss_multi_acc_doubles', 'dis_conv3d_knn_bwd_det_workspace', 'dis_conv3d_knn_bwd_stage', 'dis_conv3d_csr_workspace', 'dis_gather_csr_workspace',
              'dis_conv2d_pack_bf16x3_size', 'dis_disp_head_bwd_workspace'}
 
 _CT = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float, 'd': ctypes.c_double}

@@ -319,6 +319,22 @@ class ProjectionBaseLoss(TimedModule):
         self._Ki_host = lib.host_floats(np.asarray(Ki, dtype=np.float32).reshape(-1))
 
 
+def _geo_terms_all(loss, depth, R, t, flow_out, amb, primary_depth, clamp):
+    """The per-pair values l_{ij} + l_{ji}, i < j (the loops of reference multi_frame_worker.py:139-158 / single_frame_worker.py
+    :126-149), from ONE forward / backward launch over all directional terms (ops.geo_loss_all); None: the caller runs the loops
+    (more than 16 terms, DIS_GEO_MULTI=0).  depth / amb / primary_depth (tl, bs, 1, h, w)."""
+    tl = depth.shape[0]
+    if not ops.GEO_MULTI or tl * (tl - 1) > ops.GEO_MULTI_MAX or tl < 2:
+        return None
+    pairs, flows = [], []
+    for i in range(tl):
+        for j in range(i + 1, tl):
+            pairs += [(i, j), (j, i)]
+            flows += [(flow_out[f'flow_{i}{j}'], flow_out[f'flow_{j}{i}']), (flow_out[f'flow_{j}{i}'], flow_out[f'flow_{i}{j}'])]
+    vals = ops.geo_loss_all(depth, amb, primary_depth, R, t, loss._K_host, loss._Ki_host, clamp, pairs, flows)
+    return vals.view(-1, 2).sum(1).unbind(0)
+
+
 class Multi_Frame_Flow_Consistency_Loss(ProjectionBaseLoss):
     """reference model/networks.py:554-607"""
 
@@ -326,6 +342,9 @@ class Multi_Frame_Flow_Consistency_Loss(ProjectionBaseLoss):
         super().__init__(*args)
         self.mod_name = 'Multi_Frame_Flow_Consistency_Loss'
         self.clamp = clamp  # stored but unused, as in the reference
+
+    def forward_all(self, depth, R, t, flow_out, amb, primary_depth):
+        return _geo_terms_all(self, depth, R, t, flow_out, amb, primary_depth, -1.0)
 
     def fwd(self, depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1, primary_depth1, accs=None):
         val, _ = ops.geo_loss_dir(depth0, depth1, flow0, flow1, amb0, amb1, primary_depth1, R0, t0, R1, t1,
@@ -349,6 +368,9 @@ class Single_Frame_Flow_Consistency_Loss(ProjectionBaseLoss):
         super().__init__(*args)
         self.mod_name = 'Single_Frame_Flow_Consistency_Loss'
         self.clamp = clamp
+
+    def forward_all(self, depth, R, t, flow_out, amb):
+        return _geo_terms_all(self, depth, R, t, flow_out, amb, None, float(self.clamp))
 
     def fwd(self, depth0, depth1, R0, t0, R1, t1, flow0, flow1, amb0, amb1, accs=None):
         val, mask = ops.geo_loss_dir(depth0, depth1, flow0, flow1, amb0, amb1, None, R0, t0, R1, t1,

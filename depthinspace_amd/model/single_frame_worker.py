@@ -60,10 +60,13 @@ class Worker(multi_frame_worker.Worker):
         ge_loss = self.ge_losses[0]
         # one unbind (backward: one stack) instead of a select per use, and one shared gradient buffer per frame for the
         # 6 directional terms it takes part in (their backward kernels accumulate): as in multi_frame_worker
-        ds = depth.unbind(0)
+        allv = ge_loss.forward_all(depth, R, t, flow_out, amb)   # (one launch each way for the 12 directional terms)
+        if allv is not None:
+            vals += [(v, 0.2 / ge_num) for v in allv]
+        ds = depth.unbind(0) if allv is None else ()
         accs = [ops.GradAccum() for _ in ds] if depth.requires_grad else None
-        for tidx0 in range(depth.shape[0]):
-            for tidx1 in range(tidx0 + 1, depth.shape[0]):
+        for tidx0 in range(len(ds)):
+            for tidx1 in range(tidx0 + 1, len(ds)):
                 val, _, _, _ = ge_loss(ds[tidx0], ds[tidx1], R[tidx0], t[tidx0], R[tidx1], t[tidx1],
                                        flow_out[f'flow_{tidx0}{tidx1}'], flow_out[f'flow_{tidx1}{tidx0}'],
                                        amb[tidx0], amb[tidx1],

@@ -772,6 +772,79 @@ def geo_loss_dir(depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, 
     return _GeoLossDir.apply(depth0, depth1, flow0, flow1, amb0, amb1, pdepth1, R0, t0, R1, t1, K, Kinv, clamp, accs)
 
 
+import ctypes as _ct
+import os as _os
+GEO_MULTI = _os.environ.get('DIS_GEO_MULTI', '1') != '0'   # =0: one launch per directional term (dis_geo_loss_fwd / _bwd)
+GEO_MULTI_MAX = 16
+
+
+class _GeoTerm(_ct.Structure):   # include/dis_hip.h: DisGeoTerm
+    _fields_ = [(n_, _ct.c_void_p) for n_ in ('depth0', 'depth1', 'flow0', 'flow1', 'amb0', 'amb1', 'pdepth1', 'R0', 't0', 'R1', 't1',
+                                              'mask', 'gdepth0', 'gdepth1')]
+
+
+class _GeoLossAll(torch.autograd.Function):
+    """Every directional flow-consistency term of a step in one forward and one backward launch (dis_geo_loss_fwd_multi / _bwd_multi).
+    depth / amb / pdepth (tl, bs, 1, h, w), R (tl, bs, 3, 3), t (tl, bs, 3); pairs: ((i0, i1), ...) one per term; flows: per term
+    flow_{i0 i1}, flow_{i1 i0}.  Returns the (len(pairs),) vector of term values."""
+
+    @staticmethod
+    def _table(pairs, depth, R, t, mask, flows0, flows1=None, amb=None, pdepth=None, gdepth=None):
+        tl, bs = depth.shape[0], depth.shape[1]
+        fs = depth[0].numel() * 4
+        tab = (_GeoTerm * len(pairs))()
+        for k, (i0, i1) in enumerate(pairs):
+            q = tab[k]
+            q.depth0, q.depth1 = depth.data_ptr() + i0 * fs, depth.data_ptr() + i1 * fs
+            q.flow0 = flows0[k].data_ptr()
+            q.R0, q.R1 = R.data_ptr() + i0 * bs * 36, R.data_ptr() + i1 * bs * 36
+            q.t0, q.t1 = t.data_ptr() + i0 * bs * 12, t.data_ptr() + i1 * bs * 12
+            q.mask = mask.data_ptr() + k * fs
+            if flows1 is not None:
+                q.flow1 = flows1[k].data_ptr()
+                q.amb0, q.amb1 = amb.data_ptr() + i0 * fs, amb.data_ptr() + i1 * fs
+                q.pdepth1 = pdepth.data_ptr() + i1 * fs if pdepth is not None else None
+            if gdepth is not None:
+                q.gdepth0, q.gdepth1 = gdepth.data_ptr() + i0 * fs, gdepth.data_ptr() + i1 * fs
+        return tab
+
+    @staticmethod
+    def forward(ctx, depth, amb, pdepth, R, t, K, Kinv, clamp, pairs, *flows):
+        depth, amb, R, t = _c(depth), _c(amb), _c(R), _c(t)
+        pdepth = _c(pdepth) if pdepth is not None else None
+        flows = [_c(f) for f in flows]
+        _chk(depth, amb, pdepth, R, t, *flows)
+        tl, bs, _, h, w = depth.shape
+        T = len(pairs)
+        assert len(flows) == 2 * T and T <= GEO_MULTI_MAX and amb.shape == depth.shape and (pdepth is None or pdepth.shape == depth.shape)
+        assert tuple(R.shape) == (tl, bs, 3, 3) and tuple(t.shape) == (tl, bs, 3) and all(tuple(f.shape) == (bs, 2, h, w) for f in flows)
+        mask = torch.empty((T, bs, 1, h, w), dtype=torch.float32, device=depth.device)
+        acc = torch.empty(lib.fn('dis_geo_loss_multi_acc_doubles')(T), dtype=torch.float64, device=depth.device)
+        out = torch.empty(T, dtype=torch.float32, device=depth.device)
+        tab = _GeoLossAll._table(pairs, depth, R, t, mask, flows[0::2], flows[1::2], amb, pdepth)
+        lib.call('dis_geo_loss_fwd_multi', tab, T, K, Kinv, float(clamp), acc, out, bs, h, w)
+        ctx.save_for_backward(depth, R, t, mask, acc, *flows[0::2])
+        ctx.cfg = (K, Kinv, float(clamp), pairs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        depth, R, t, mask, acc = ctx.saved_tensors[:5]
+        flows0 = ctx.saved_tensors[5:]
+        K, Kinv, clamp, pairs = ctx.cfg
+        tl, bs, _, h, w = depth.shape
+        gd = torch.zeros_like(depth)
+        tab = _GeoLossAll._table(pairs, depth, R, t, mask, flows0, gdepth=gd)
+        lib.call('dis_geo_loss_bwd_multi', tab, len(pairs), K, Kinv, clamp, acc, _c(g.float()), bs, h, w)
+        return (gd,) + (None,) * (8 + 2 * len(pairs))
+
+
+def geo_loss_all(depth, amb, pdepth, R, t, K, Kinv, clamp, pairs, flows):
+    """all directional terms at once: pairs ((i0, i1), ...), flows [(flow_{i0 i1}, flow_{i1 i0}), ...] -> (len(pairs),) values"""
+    flat = [f for pr in flows for f in pr]
+    return _GeoLossAll.apply(depth, amb, pdepth, R, t, K, Kinv, clamp, tuple(pairs), *flat)
+
+
 # --------------------------------------------------------------------------------------------------
 # layout helpers (no gradient: they only touch network inputs)
 # --------------------------------------------------------------------------------------------------

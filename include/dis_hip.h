@@ -138,6 +138,23 @@ int dis_geo_loss_bwd(const float* depth0, const float* depth1, const float* flow
                      const float* gscale, float* grad_depth0, float* grad_depth1, int bs, int h, int w,
                      void* stream);
 
+/* Round 5: ALL directional terms of a step - tl (tl - 1) = 12 (reference model/multi_frame_worker.py:139-158, single_frame_worker.py
+ * :126-149; model/networks.py:554-661) - in one forward and one backward launch.  terms: HOST array of nterms <= 16 tables of DEVICE
+ * pointers, argument for argument those of dis_geo_loss_fwd / _bwd (pdepth1 may be NULL: no primary-depth mask; flow1 / amb0 / amb1
+ * are not read by the backward; gdepth0 / gdepth1 not by the forward).  acc: dis_geo_loss_multi_acc_doubles(nterms) doubles (kept for
+ * the backward); out (nterms) floats: the values of nterms single calls, bit for bit.  Backward: gscale (nterms) device floats;
+ * both depth gradients are ADDED with float atomics into gdepth0 / gdepth1 (zeroed or pre-filled by the caller; terms may share
+ * them): equal to the single calls to rounding. */
+typedef struct DisGeoTerm {
+  const float *depth0, *depth1, *flow0, *flow1, *amb0, *amb1, *pdepth1, *R0, *t0, *R1, *t1;
+  float *mask, *gdepth0, *gdepth1;
+} DisGeoTerm;
+long dis_geo_loss_multi_acc_doubles(int nterms);
+int dis_geo_loss_fwd_multi(const DisGeoTerm* terms, int nterms, const float* K_host, const float* Kinv_host, float clampv, double* acc,
+                           float* out, int bs, int h, int w, void* stream);
+int dis_geo_loss_bwd_multi(const DisGeoTerm* terms, int nterms, const float* K_host, const float* Kinv_host, float clampv,
+                           const double* acc, const float* gscale, int bs, int h, int w, void* stream);
+
 /* ---------------------------------------------------------------- layout / resize / warp ---- */
 
 /* Pack up to 4 planar single-channel sources (n,1,h,w) into nhwc C=4 (NULL source => zeros).

@@ -201,6 +201,54 @@ def test_geo_loss_golden(G, mode):
     close(disp.grad, ref, 2e-5 * scale, 1e-4, what='grad')
 
 
+@pytest.mark.parametrize('mode', ['mf', 'sf'])
+@pytest.mark.parametrize('hw', [(48, 56), (130, 94)])
+def test_geo_loss_all_terms_in_one_launch(G, mode, hw):
+    """dis_geo_loss_fwd_multi / _bwd_multi (round 5): the 12 directional terms of a step in one launch each way against 12 calls of
+    dis_geo_loss_fwd / _bwd - values and masks bit for bit (same pixel partition, same sums), the depth gradient to rounding (the
+    multi-term backward adds both gradients with atomics); the golden pair (0, 2) of test_geo_loss_golden among them."""
+    from depthinspace_amd import ops, synth, lib
+    st = synth.make_settings(*hw)
+    b = synth.make_random_batch(st, 2, 4, seed=int(G['ge_seed']))
+    tb = {k: torch.from_numpy(v).transpose(0, 1).contiguous() if v.ndim > 2 else torch.from_numpy(v) for k, v in b.items()}
+    K = lib.host_floats(st.K.reshape(-1))
+    Ki = lib.host_floats(np.linalg.inv(st.K).reshape(-1))
+    bf = float(st.K[0, 0]) * st.baseline
+    tl = 4
+    disp0 = dev(G['ge_disp']) if hw == (48, 56) else (tb['primary_disp'] * 1.03 + 0.4).cuda()
+    pdepth = ops.disp_to_depth(tb['primary_disp'].cuda(), bf) if mode == 'mf' else None
+    amb, R, t = tb['ambient0'].contiguous().cuda(), tb['R'].cuda(), tb['t'].cuda()
+    flow = {k: v[0].contiguous().cuda() if v.dim() == 5 else v.contiguous().cuda() for k, v in tb.items() if k.startswith('flow_')}
+    clamp = -1.0 if mode == 'mf' else 0.1
+    pairs, flows = [], []
+    for i in range(tl):
+        for j in range(i + 1, tl):
+            pairs += [(i, j), (j, i)]
+            flows += [(flow[f'flow_{i}{j}'], flow[f'flow_{j}{i}']), (flow[f'flow_{j}{i}'], flow[f'flow_{i}{j}'])]
+    gvec = torch.linspace(0.5, 1.5, len(pairs)).cuda()
+    # one launch each way
+    d1 = disp0.clone().requires_grad_(True)
+    depth = ops.disp_to_depth(d1, bf)
+    vals = ops.geo_loss_all(depth, amb, pdepth, R, t, K, Ki, clamp, pairs, flows)
+    (vals * gvec).sum().backward()
+    # one call per term
+    d2 = disp0.clone().requires_grad_(True)
+    depth2 = ops.disp_to_depth(d2, bf)
+    singles = []
+    for (i, j), (f0, f1) in zip(pairs, flows):
+        v, _ = ops.geo_loss_dir(depth2[i], depth2[j], f0, f1, amb[i], amb[j], pdepth[j] if pdepth is not None else None, R[i], t[i], R[j],
+                                t[j], K, Ki, clamp)
+        singles.append(v)
+    sv = torch.stack(singles)
+    (sv * gvec).sum().backward()
+    assert torch.equal(vals, sv), (vals, sv)
+    scale = float(d2.grad.abs().max())
+    assert scale > 0 and float((d1.grad - d2.grad).abs().max()) < 2e-6 * scale
+    if hw == (48, 56):   # the golden pair
+        k = pairs.index((0, 2))
+        close(vals[k] + vals[k + 1], float(G[f'ge_{mode}_val']), 1e-7, 2e-5, what='val')
+
+
 @pytest.mark.parametrize('cfg', [(48, 56, 2, 3, True), (64, 64, 1, 1234, False), (130, 94, 1, 7, True)])
 @pytest.mark.parametrize('mode', ['mf', 'sf'])
 def test_geo_loss_masks_bit_exact(cfg, mode):
