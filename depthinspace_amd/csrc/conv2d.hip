@@ -2599,6 +2599,66 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   }
 }
 
+// Tiled form (round 5): a workgroup owns HD_TH rows x (256 / NQ) columns of output pixels and walks DOWN the rows with three running
+// sums per thread (the output rows r - 1, r, r + 1 that input row r feeds), so an input pixel is loaded three times (left / centre /
+// right of neighbouring threads of one wave: L1 hits) instead of nine, and never by a workgroup of another XCD except for the two
+// halo rows.  Every output accumulates its taps in the order of the kernel above (ky outer, kx inner, out-of-image taps skipped):
+// bit-identical results.
+#define HD_TH 16
+template <int CIN>
+__global__ __launch_bounds__(256) void head_fwd_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ y, int h, int wd,
+                                                             float alpha, float offset, int tiles_x, int tiles_y) {
+  constexpr int NQ = CIN / 4, PXB = 256 / NQ;
+  __shared__ float4 ws[9 * NQ];
+  for (int i = threadIdx.x; i < 9 * CIN; i += blockDim.x) {
+    const int tap = i / CIN, ci = i % CIN;
+    ((float*)ws)[i] = w[ci * 9 + tap];  // (1,cin,3,3) -> [tap][ci]
+  }
+  __syncthreads();
+  int tile = blockIdx.x;
+  const int tx = tile % tiles_x;
+  tile /= tiles_x;
+  const int ty = tile % tiles_y;
+  const long nb = tile / tiles_y;
+  const int quad = threadIdx.x % NQ, px = tx * PXB + (int)threadIdx.x / NQ;
+  const float bias = b[0] - offset;
+  const int y0 = ty * HD_TH, y1 = min(y0 + HD_TH, h);
+  const bool col = px < wd;
+  const int pxc = col ? px : wd - 1;   // (idle columns of a ragged tile read the last column and store nothing)
+  const bool okl = pxc - 1 >= 0, okr = pxc + 1 < wd;
+  float4 wt[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wt[t] = ws[t * NQ + quad];
+  auto dot = [](const float4& v, const float4& q) { return (v.x * q.x + v.y * q.y) + (v.z * q.z + v.w * q.w); };
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;   // sums of the output rows r - 1, r, r + 1
+  for (int r = y0 - 1; r <= y1; ++r) {
+    if (r >= 0 && r < h) {
+      const float* row = x + ((nb * h + r) * wd + pxc) * CIN + quad * 4;
+      const float4 vm = *(const float4*)(row);
+      const float4 vl = okl ? *(const float4*)(row - CIN) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 vr = okr ? *(const float4*)(row + CIN) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // (input row r is tap row ky = 2 of output row r - 1, ky = 1 of row r, ky = 0 of row r + 1)
+      if (okl) a0 += dot(vl, wt[6]);
+      a0 += dot(vm, wt[7]);
+      if (okr) a0 += dot(vr, wt[8]);
+      if (okl) a1 += dot(vl, wt[3]);
+      a1 += dot(vm, wt[4]);
+      if (okr) a1 += dot(vr, wt[5]);
+      if (okl) a2 += dot(vl, wt[0]);
+      a2 += dot(vm, wt[1]);
+      if (okr) a2 += dot(vr, wt[2]);
+    }
+    if (r - 1 >= y0) {   // output row r - 1 is complete
+      float acc = a0;
+#pragma unroll
+      for (int off = NQ / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (quad == 0 && col) y[(nb * h + (r - 1)) * wd + px] = alpha / (1.f + expf(-(acc + bias)));
+    }
+    a0 = a1, a1 = a2, a2 = 0.f;
+  }
+}
+
 // pre-sigmoid gradient plane
 __global__ void head_gpre_kernel(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gp,
                                  float alpha, long count) {
@@ -2614,7 +2674,7 @@ __global__ void head_gpre_kernel(const float* __restrict__ y, const float* __res
 // so x is read once (coalesced float4 rows) and the neighbourhood only through the 1-channel g.  Per-thread fp32
 // partials -> fp64 sums over the lanes that share a channel group -> one slab per block (head_reduce_kernel adds the
 // slabs in a fixed order: deterministic, no atomics).
-#define HEAD_SLABS 512
+#define HEAD_SLABS 2048   // (512 until round 5: two workgroups per CU left the kernel waiting on its loads, 175 us for 450 MB)
 template <int CIN>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ gp, float* __restrict__ gx,
@@ -2695,6 +2755,22 @@ extern "C" int dis_disp_head_fwd(const float* x, const float* w, const float* b,
                                  int cin, float alpha, float offset, void* stream) {
   if (!x || !w || !b || !y) return DIS_ERR_NULL;
   if (n <= 0 || h <= 0 || wd <= 0) return DIS_ERR_BAD_SHAPE;
+  if (cin == 16 || cin == 32) {
+    const int pxb = 256 / (cin / 4), tiles_x = dis_cdiv(wd, pxb), tiles_y = dis_cdiv(h, HD_TH);
+    const long tiles = (long)n * tiles_x * tiles_y;
+    const char* env = getenv("DIS_HEAD_TILED");   // (=0: the grid-stride kernel; read per call: tests compare the two forms)
+    const bool tiled = !(env && env[0] == '0');
+    if (tiled && tiles <= 0x7fffffffL) {
+      if (cin == 16)
+        hipLaunchKernelGGL(head_fwd_tiled_kernel<16>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w, b, y, h, wd, alpha,
+                           offset, tiles_x, tiles_y);
+      else
+        hipLaunchKernelGGL(head_fwd_tiled_kernel<32>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, w, b, y, h, wd, alpha,
+                           offset, tiles_x, tiles_y);
+      DIS_CHECK_LAUNCH();
+      return DIS_OK;
+    }
+  }
   const dim3 grid(dis_ew_grid((long)n * h * wd * (cin / 4), 256));
   if (cin == 16) hipLaunchKernelGGL(head_fwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, n, h, wd, alpha, offset);
   else if (cin == 32) hipLaunchKernelGGL(head_fwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, w, b, y, n, h, wd, alpha, offset);

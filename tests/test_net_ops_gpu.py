@@ -931,6 +931,31 @@ def test_disp_head():
     assert relerr(bd.grad, br.grad) < 1e-5
 
 
+@pytest.mark.parametrize('cin', [16, 32])
+@pytest.mark.parametrize('n,h,w', [(2, 37, 45), (3, 16, 64), (1, 33, 130), (2, 5, 3)])
+def test_disp_head_tiled_forward(cin, n, h, w):
+    """head_fwd_tiled_kernel (round 5: a workgroup walks down a 16-row tile with three running sums per thread) against the grid-stride
+    kernel it replaces (DIS_HEAD_TILED=0, read per call) - bit for bit, ragged tiles and maps smaller than a tile included - and torch."""
+    from depthinspace_amd import ops
+    L = ops.lib
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = (torch.randn(1, cin, 3, 3, generator=g) * 0.2).cuda()
+    b = torch.randn(1, generator=g).cuda()
+    ys = []
+    for mode in ('1', '0'):
+        os.environ['DIS_HEAD_TILED'] = mode
+        try:
+            y = torch.full((n, 1, h, w), float('nan'), device='cuda')
+            L.call('dis_disp_head_fwd', x, wt, b, y, n, h, w, cin, 128.0, 0.5)
+            ys.append(y)
+        finally:
+            os.environ.pop('DIS_HEAD_TILED')
+    assert torch.equal(ys[0], ys[1])
+    ref = 128.0 * torch.sigmoid(F.conv2d(nchw(x).double(), wt.double(), b.double(), padding=1) - 0.5)
+    assert relerr(ys[0], ref) < 2e-6
+
+
 def test_adam_matches_torch():
     from depthinspace_amd import ops
     g = torch.Generator().manual_seed(4)
