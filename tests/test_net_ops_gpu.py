@@ -329,6 +329,38 @@ def test_gather_warped_feat():
     assert torch.equal(grads[0], grads[1])
 
 
+@pytest.mark.parametrize('tl,bs,c,h,w', [(4, 2, 32, 37, 45), (4, 1, 16, 16, 70), (3, 2, 32, 9, 33), (2, 3, 64, 21, 8)])
+def test_gather_warped_feat_tiled_kernels(tl, bs, c, h, w):
+    """the tiled feature-warp kernels (round 5: 8 x 32 pixel tiles, the targets of a tile on one XCD, several rows / CSR entries in flight)
+    against the grid-stride kernels they replace (DIS_GATHER_TILED=0, read per call): forward and CSR backward bit for bit - ragged
+    tiles, 16 / 32 / 64 channels, 2 - 4 frames, large flows that leave the image."""
+    from depthinspace_amd import ops
+    L = ops.lib
+    g = torch.Generator().manual_seed(tl * 100 + c + h)
+    feat = torch.randn(tl, bs, h, w, c, generator=g).cuda()
+    flows = (torch.randn(tl * tl, bs, h, w, 2, generator=g) * 5).cuda()
+    go = torch.randn(tl, bs, h, w, tl, c, generator=g).cuda()
+    init = torch.randn(tl, bs, h, w, c, generator=g).cuda()
+    csr = ops.gather_csr(flows)
+    res = []
+    for mode in ('1', '0'):
+        os.environ['DIS_GATHER_TILED'] = mode
+        try:
+            out = torch.full((tl, bs, h, w, tl, c), float('nan'), device='cuda')
+            L.call('dis_gather_warped_feat_fwd', feat, flows, out, tl, bs, h, w, c)
+            gf = torch.full((tl, bs, h, w, c), float('nan'), device='cuda')
+            L.call('dis_gather_warped_feat_bwd_csr', go, csr, None, gf, tl, bs, h, w, c)
+            gf2 = torch.full((tl, bs, h, w, c), float('nan'), device='cuda')
+            L.call('dis_gather_warped_feat_bwd_csr', go, csr, init, gf2, tl, bs, h, w, c)
+            res.append((out, gf, gf2))
+        finally:
+            os.environ.pop('DIS_GATHER_TILED')
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_)
+    assert not torch.isnan(res[0][0]).any() and not torch.isnan(res[0][1]).any()
+    assert relerr(res[0][2], res[0][1] + init) < 1e-6
+
+
 @pytest.mark.parametrize('cfg', [(64, 48, 2, 8, True, {}), (128, 128, 1, 4321, False, dict(scene='bumps', motion=1.5)),
                                  (256, 216, 1, 5, False, {})])
 def test_mf_geometry_masks_and_selection_bit_exact(cfg):

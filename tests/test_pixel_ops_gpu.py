@@ -242,6 +242,10 @@ def test_geo_loss_all_terms_in_one_launch(G, mode, hw):
     sv = torch.stack(singles)
     (sv * gvec).sum().backward()
     assert torch.equal(vals, sv), (vals, sv)
+    # a subset of the terms (three frames: six terms) gives the same six values
+    sub = [k for k, (i, j) in enumerate(pairs) if i < 3 and j < 3]
+    v3 = ops.geo_loss_all(depth2.detach(), amb, pdepth, R, t, K, Ki, clamp, [pairs[k] for k in sub], [flows[k] for k in sub])
+    assert torch.equal(v3, vals[sub])
     scale = float(d2.grad.abs().max())
     assert scale > 0 and float((d1.grad - d2.grad).abs().max()) < 2e-6 * scale
     if hw == (48, 56):   # the golden pair
