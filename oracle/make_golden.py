@@ -499,6 +499,10 @@ CASES = [
                             real_sgm=True)),
     ('sf_64_real_sgm', dict(arch='single_frame', size=(64, 64), bs=1, pseed=25, bseed=809, epoch=2, pattern='real',
                             real_sgm=True)),
+    # the metric's own size and bench.py's own sample (cpu_baseline / hip_first_step: batch seed 1234, init_params(seed=0),
+    # epoch 2, bs=1): the reference's disparity, neighbour ids and loss terms at 512x432 (reference
+    # model/multi_frame_worker.py:87-175); ~1 min per reference step on 8 threads, ~5 MB
+    ('mf_512x432_bs1', dict(arch='multi_frame', size=(512, 432), bs=1, pseed=0, bseed=1234, epoch=2)),
 ]
 
 

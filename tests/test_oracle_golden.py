@@ -124,7 +124,7 @@ def test_geometry_against_numpy_convention():
 
 
 STEP_FIXTURES = ['mf_64_bs1', 'mf_64_bs2_rnd', 'mf_128_bs1', 'mf_128_bumps', 'mf_64_real_sgm', 'sf_64_bs1', 'sf_128_bs1_pgt',
-                 'sf_128x108_bs1', 'sf_128_real_pgt', 'sf_64_real_sgm']
+                 'sf_128x108_bs1', 'sf_128_real_pgt', 'sf_64_real_sgm', 'mf_512x432_bs1']
 
 
 def test_committed_fixtures_are_what_the_generator_writes(golden_dir):
