@@ -515,9 +515,9 @@ __global__ __launch_bounds__(GN_COEF_T) void gn_coef_kernel(const double* __rest
     // (to this XCD's L2), ONE thread's release fence writes the L2 back - a fence in every thread cost 15 us per launch
     __syncthreads();
     if (t == 0) {
-      __threadfence();
-      s_last = atomicAdd(fin, 1u) == gridDim.x - 1 ? 1u : 0u;
-      if (s_last) __threadfence();   // acquire: the other blocks' entries (other XCDs' L2s) are read from memory
+      // release (agent scope, cumulative over the barrier above: every thread's pg[] stores) + acquire (the other blocks' entries,
+      // written through other XCDs' L2s, are read from memory by the threads behind the next barrier) spelled out on the atomic
+      s_last = __hip_atomic_fetch_add(fin, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (s_last) {

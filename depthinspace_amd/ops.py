@@ -70,16 +70,68 @@ def realize(t):
     return t
 
 
-def _gn_lazy_defer(g, q, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, in_act):
+# Tokens come from a persistent per-device pool filled with NaN ONCE (unique addresses, no launch per step): arithmetic on a token
+# that was not redeemed - autograd summing it with the gradient of a second consumer of the conv output - poisons the loss of the
+# same step visibly.  _GN_TOKEN_FOR: uid of the conv node whose output a token stands for -> the token's address; that conv's
+# backward raises if what it receives is not the token (see _gn_lazy_pop).
+_TOKEN_POOL = {}
+_TOKEN_POOL_SIZE = 4096
+_GN_TOKEN_FOR = {}
+import itertools as _it
+_LAZY_UID = _it.count(1)
+
+
+def _new_token(dev):
+    pool = _TOKEN_POOL.get(dev)
+    if pool is None:
+        pool = _TOKEN_POOL[dev] = [torch.full((_TOKEN_POOL_SIZE,), float('nan'), dtype=torch.float32, device=dev), 0]
+    if pool[1] >= _TOKEN_POOL_SIZE:   # (no begin_step between many backward passes: tests, ad-hoc use)
+        return torch.full((1,), float('nan'), dtype=torch.float32, device=dev)
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]
+
+
+def _mark_lazy_ok(out):
+    """`out` = (y, stats) of a conv node whose backward redeems GroupNorm tokens: a GroupNorm that is y's ONLY consumer may answer
+    with one.  The mark is the node's uid (truthy); the node keeps it (the ctx of a torch.autograd.Function IS the output's grad_fn)."""
+    uid = next(_LAZY_UID)
+    out[0]._gn_lazy_ok = uid
+    if out[0].grad_fn is not None:
+        out[0].grad_fn.lazy_uid = uid
+
+
+def _gn_lazy_defer(g, q, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, in_act, uid=0):
     coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=g.device)
     lib.call('dis_gn_bwd_coef', stats, gamma, ab, slots, coef, gg, gb, _zeros_d(1, g.device), n, hw, c, eps)
-    tok = torch.empty(1, dtype=torch.float32, device=g.device)
+    tok = _new_token(g.device)
     _GN_LAZY[tok.data_ptr()] = (tok, g, q, coef, in_act)
+    if uid and uid is not True:
+        _GN_TOKEN_FOR[uid] = tok.data_ptr()
     return tok.expand(g.shape)
 
 
-def _gn_lazy_pop(gy):
-    return _GN_LAZY.pop(gy.data_ptr(), None) if _GN_LAZY else None
+def _gn_lazy_pop(gy, ctx=None):
+    ent = _GN_LAZY.pop(gy.data_ptr(), None) if _GN_LAZY else None
+    if _GN_TOKEN_FOR:
+        exp = _GN_TOKEN_FOR.pop(getattr(ctx, 'lazy_uid', None), None)
+        if exp is not None and (ent is None or ent[0].data_ptr() != exp):
+            if ent is not None:
+                _GN_LAZY[gy.data_ptr()] = ent
+            raise RuntimeError('ops: GroupNorm token was summed with another gradient: the conv output has a second consumer '
+                               '(only an output whose ONLY consumer is the GroupNorm may be answered with a token)')
+    return ent
+
+
+def check_backward_complete():
+    """every token redeemed, every pre-reduced gradient picked up: called by FlatAdam.step() BEFORE the update (and by tests)"""
+    if _GN_LAZY or _GN_TOKEN_FOR:
+        _GN_LAZY.clear()
+        _GN_TOKEN_FOR.clear()
+        raise RuntimeError('ops: a deferred GroupNorm backward (token gradient) of this backward pass was not redeemed')
+    if _GN_PRE:
+        _GN_PRE.clear()
+        raise RuntimeError('ops: a pre-reduced GroupNorm gradient of this backward pass was not consumed')
 
 
 def _gn_lazy_materialize(ent):
@@ -108,10 +160,13 @@ def begin_step(dev):
     if _GN_PENDING:  # a deferred GroupNorm output was never written
         _GN_PENDING.clear()
         raise RuntimeError('ops: a deferred GroupNorm output (group_norm(defer=True)) of the previous forward pass was never realised')
-    if _GN_LAZY:  # a token stood in for a gradient and nobody redeemed it (the conv output had a second consumer?)
+    if _GN_LAZY or _GN_TOKEN_FOR:  # a token stood in for a gradient and nobody redeemed it (the conv output had a second consumer?)
         _GN_LAZY.clear()
+        _GN_TOKEN_FOR.clear()
         raise RuntimeError('ops: a deferred GroupNorm backward (token gradient) of the previous backward pass was not redeemed')
     dev = torch.device(dev)
+    if dev in _TOKEN_POOL:
+        _TOKEN_POOL[dev][1] = 0
     a = _ARENA.get(dev)
     if a is None:
         a = _ARENA[dev] = [torch.zeros(_ARENA_DOUBLES, dtype=torch.float64, device=dev), 0, 0]
@@ -209,7 +264,7 @@ class _PackBatch(object):
             else:
                 cls.state = 'idle' if n == 0 else 'off'   # (no bf16 convolution ran / more calls than the table holds)
             cls.used = None
-        if cls.state == 'ready':
+        if cls.state == 'ready' and not cls.dead:   # (dead while capturing: the table points at freed weights - no launch, every call packs for itself)
             lib.call('dis_convb_pack_batch', cls.table, cls.count, cls.blocks)
             cls.packed_step = cls.step
             for ent in cls.cache.values():
@@ -370,6 +425,19 @@ def _sink(param):
         return e[0], None
     g = torch.empty_like(param)
     return g, g
+
+
+def _unsink(param, got):
+    """hand a sink back (the launch it was taken for did not run): the next _sink(param) gets it again"""
+    if param is None or got is None or got[1] is not None:
+        return
+    e = _GRAD_SINK.get(param.data_ptr())
+    if e is not None and e[1]:
+        e[1] = False
+        for i_ in range(len(_SINK_PENDING) - 1, -1, -1):
+            if _SINK_PENDING[i_] is param:
+                del _SINK_PENDING[i_]
+                break
 
 
 def _sink_opt(param):
@@ -1040,7 +1108,7 @@ class _Conv2d(torch.autograd.Function):
         cout, cin, k, _ = weight.shape
         # a token of a GroupNorm behind this conv (ops._GN_LAZY): its backward's elementwise pass is applied by this conv's
         # input-gradient launch on load, which also writes the values for the weight-gradient launch
-        lz = _gn_lazy_pop(gy)
+        lz = _gn_lazy_pop(gy, ctx)
         if (lz is not None and act == ACT_NONE and _gn_lazy_k4s2(cin_pad, cin, cout, k, stride, pad) and
                 lib.fn('dis_get_conv_split')() == 1 and x[0].numel() * 4 < 0x7fff0000):   # (the kernel's per-sample 31-bit offsets)
             # the 4 x 4 stride-2 down convolution: the WEIGHT-gradient launch applies the pass while it stages gy (no halo there)
@@ -1061,7 +1129,12 @@ class _Conv2d(torch.autograd.Function):
                         gx = join.first(gx)
                 _sinks_written()
                 return gx, gw_ret, gb_ret, None, None, None, None, None, None, None, None, None
-            raise lib.DisHipError('dis_conv2d_wgrad_k4s2_f16x2_gnb: unsupported in this mode although the two-term split is on')
+            # (no instance for this configuration in this build - e.g. an input activation the kernel has no form for: the sinks go
+            #  back, the pass runs as a launch of its own, the general path below does the rest)
+            _unsink(weight, (gw, gw_ret))
+            if has_bias:
+                _unsink(ctx.bias_ref, (gb, gb_ret))
+            gy, lz = _gn_lazy_materialize(lz), None
         if lz is not None and not (act == ACT_NONE and need_dgrad and ctx.needs_input_grad[0] and cin_pad == cin and
                                    _gn_lazy_shape(cin, cout, k, stride, pad) and lib.fn('dis_get_conv_split')() == 1):
             gy, lz = _gn_lazy_materialize(lz), None
@@ -1171,7 +1244,7 @@ def conv2d(x, weight, bias, stride=1, pad=0, act=ACT_NONE, want_stats=False, nee
     out = _Conv2d.apply(x, weight, bias, stride, pad, act, want_stats, need_dgrad, gy_is_pre, join, gnres, pend)
     if (act == ACT_NONE or gy_is_pre) and ((need_dgrad and _gn_lazy_shape(x.shape[-1], weight.shape[0], weight.shape[2], stride, pad)) or
                                            _gn_lazy_k4s2(x.shape[-1], weight.shape[1], weight.shape[0], weight.shape[2], stride, pad)):
-        out[0]._gn_lazy_ok = True   # (a GroupNorm that is this output's ONLY consumer may answer with a token, see _GN_LAZY)
+        _mark_lazy_ok(out)   # (a GroupNorm that is this output's ONLY consumer may answer with a token, see _GN_LAZY)
     return out
 
 
@@ -1226,7 +1299,7 @@ class _Conv2dGnIn(torch.autograd.Function):
         cout, _, k, _ = weight.shape
         sums = (GN_SUMS & 4) and lib.fn('dis_get_conv_split')() == 1
         # (this conv's own output gradient may be a token of the GroupNorm behind it: redeemed by the input-gradient launch below)
-        lz = _gn_lazy_pop(gy)
+        lz = _gn_lazy_pop(gy, ctx)
         if lz is not None and not (sums and act == ACT_NONE and _gn_lazy_shape(cin, cout, k, 1, pad)):
             gy, lz = _gn_lazy_materialize(lz), None
         gnorm = torch.empty_like(x)
@@ -1259,7 +1332,7 @@ class _Conv2dGnIn(torch.autograd.Function):
                 lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, weight, cout, cin, weight.stride(0), gnorm, x, ab, n, gpre.shape[1],
                          gpre.shape[2], cout, cin, k - 1 - pad)
             if ctx.x_lazy and GN_LAZY:
-                gx = _gn_lazy_defer(gnorm, x, gn_stats, gamma, ab, slots, gg, gbt, n, hw, cin, eps, in_act)
+                gx = _gn_lazy_defer(gnorm, x, gn_stats, gamma, ab, slots, gg, gbt, n, hw, cin, eps, in_act, uid=ctx.x_lazy)
             else:
                 gx = torch.empty_like(x)
                 coef = torch.empty(n * (cin + 2) + 4 * n * cin + 2, dtype=torch.float32, device=x.device)
@@ -1288,9 +1361,9 @@ def conv2d_gn_in(x, gn_stats, gamma, beta, weight, bias, pad=1, act=ACT_NONE, wa
     """conv2d(group_norm(x, gamma, beta, stats=gn_stats, in_act=in_act), weight, bias, 1, pad, act, ...) with the
     normalisation applied on load.  Returns (y, stats|None).  Shapes: see gn_fusable()."""
     out = _Conv2dGnIn.apply(x, gn_stats, gamma, beta, weight, bias, pad, act, want_stats, gy_is_pre, eps, in_act,
-                            bool(getattr(x, '_gn_lazy_ok', False)))
+                            int(getattr(x, '_gn_lazy_ok', 0)))
     if (act == ACT_NONE or gy_is_pre) and _gn_lazy_shape(x.shape[-1], weight.shape[0], weight.shape[2], 1, pad):
-        out[0]._gn_lazy_ok = True
+        _mark_lazy_ok(out)
     return out
 
 
@@ -1304,7 +1377,7 @@ class _Conv2dMulti(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, bias, pad, act, want_stats, gy_is_pre, gn_stats, gn_gamma, gn_beta, gn_meta, *xs):
-        ctx.x0_lazy = gn_meta is not None and len(gn_meta) > 2 and bool(gn_meta[2])
+        ctx.x0_lazy = int(gn_meta[2]) if (gn_meta is not None and len(gn_meta) > 2 and gn_meta[2]) else 0   # (uid of xs[0]'s producer)
         gn_meta = gn_meta[:2] if gn_meta is not None else None
         # (tokens of a GroupNorm behind this conv are redeemed by the first source's 3 x 3 c -> c input-gradient launch)
         ctx.lazy_ok = _multi_lazy_ok(weight, xs, pad, act)
@@ -1356,7 +1429,7 @@ class _Conv2dMulti(torch.autograd.Function):
         assert gn_meta is None or act == ACT_NONE
         # this conv's output gradient may be a token of the GroupNorm behind it (conv_fuse): the FIRST source's input-gradient launch
         # applies the elementwise pass on load and stores the result for every other launch of this node
-        lz = _gn_lazy_pop(gy)
+        lz = _gn_lazy_pop(gy, ctx)
         if lz is not None and not (act == ACT_NONE and ctx.lazy_ok and ctx.needs_input_grad[10] and
                                    (gn_meta is None or (GN_SUMS & 8)) and lib.fn('dis_get_conv_split')() == 1):
             gy, lz = _gn_lazy_materialize(lz), None
@@ -1391,14 +1464,18 @@ class _Conv2dMulti(torch.autograd.Function):
                         ab = _zeros_d(n * slots * 2 * cs[0], x.device)
                         if lz is not None:
                             _, lg, lq, lcoef, lin_act = lz
-                            gpre, lz = torch.empty_like(lg), None
-                            lib.call('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, wi, cout, cs[0], wi.stride(0), gnorm, 0,
-                                     x, None, ab, n, h, w, cs[0])
+                            gpre = torch.empty_like(lg)
+                            if not lib.call_try('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, wi, cout, cs[0], wi.stride(0),
+                                                gnorm, 0, x, None, ab, n, h, w, cs[0]):
+                                gpre = _gn_lazy_materialize(lz)   # (no instance in this build: the pass as a launch of its own)
+                                lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, wi, cout, cs[0], wi.stride(0), gnorm, x, ab, n,
+                                         gpre.shape[1], gpre.shape[2], cout, cs[0], k - 1 - pad)
+                            lz = None
                         else:
                             lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, wi, cout, cs[0], wi.stride(0), gnorm, x, ab, n,
                                      gpre.shape[1], gpre.shape[2], cout, cs[0], k - 1 - pad)
                         if ctx.x0_lazy and GN_LAZY:   # (the producer of xs[0] applies the elementwise pass on load: _GN_LAZY)
-                            gx = _gn_lazy_defer(gnorm, x, gn_stats, gn_gamma, ab, slots, gg, gbt, n, h * w, cs[0], float(eps), in_act)
+                            gx = _gn_lazy_defer(gnorm, x, gn_stats, gn_gamma, ab, slots, gg, gbt, n, h * w, cs[0], float(eps), in_act, uid=ctx.x0_lazy)
                         else:
                             coef = torch.empty(n * (cs[0] + 2) + 4 * n * cs[0] + 2, dtype=torch.float32, device=x.device)
                             lib.call('dis_gn_bwd_from_sums', gnorm, x, gn_stats, gn_gamma, ab, slots, gx, gg, gbt, coef, n, h * w,
@@ -1423,9 +1500,13 @@ class _Conv2dMulti(torch.autograd.Function):
                              gy.shape[2], cout, cs[i], k - 1 - pad, 0)
                 elif lz is not None:   # (i == 0: the token's pass on load, no epilogue)
                     _, lg, lq, lcoef, lin_act = lz
-                    gpre, lz = torch.empty_like(lg), None
-                    lib.call('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, wi, cout, cs[i], wi.stride(0), gx, 0, None, None,
-                             None, n, h, w, cs[i])
+                    gpre = torch.empty_like(lg)
+                    if not lib.call_try('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, wi, cout, cs[i], wi.stride(0), gx, 0,
+                                        None, None, None, n, h, w, cs[i]):
+                        gpre = _gn_lazy_materialize(lz)
+                        _conv_fwd_any(gpre, wi, cs[i], 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cs[i], k, 1,
+                                      k - 1 - pad, ACT_NONE)
+                    lz = None
                 else:
                     _conv_fwd_any(gpre, wi, cs[i], 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cs[i], k, 1,
                                   k - 1 - pad, ACT_NONE)
@@ -1460,11 +1541,11 @@ def conv2d_multi(xs, weight, bias, pad=0, act=ACT_NONE, want_stats=False, gy_is_
     gn0 = (stats, gamma, beta, eps, in_act): xs[0] is the INPUT of a GroupNorm(1 group) that is applied on load (conv2d_gn_in)."""
     if gn0 is not None:
         out = _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, gn0[0], gn0[1], gn0[2],
-                                 (gn0[3], gn0[4], bool(getattr(xs[0], '_gn_lazy_ok', False))), *xs)
+                                 (gn0[3], gn0[4], int(getattr(xs[0], '_gn_lazy_ok', 0))), *xs)
     else:
         out = _Conv2dMulti.apply(weight, bias, pad, act, want_stats, gy_is_pre, None, None, None, None, *xs)
     if _multi_lazy_ok(weight, xs, pad, act):
-        out[0]._gn_lazy_ok = True   # (a GroupNorm that is this output's ONLY consumer may answer with a token, see _GN_LAZY)
+        _mark_lazy_ok(out)   # (a GroupNorm that is this output's ONLY consumer may answer with a token, see _GN_LAZY)
     return out
 
 
@@ -1502,7 +1583,7 @@ class _Conv2dScaledIn(torch.autograd.Function):
         n, hin, win, cin = x.shape
         cout, _, k, _ = weight.shape
         # (a token of the GroupNorm behind this conv, ops._GN_LAZY: the 1 x 1 input-gradient launch applies the pass on load)
-        lz = _gn_lazy_pop(gy)
+        lz = _gn_lazy_pop(gy, ctx)
         if lz is not None and not (ctx.needs_input_grad[0] and k == 1 and stride == 1 and pad == 0 and (cin, cout) == (128, 32)):
             gy, lz = _gn_lazy_materialize(lz), None
         gx = None
@@ -1538,7 +1619,7 @@ class _Conv2dScaledIn(torch.autograd.Function):
 def conv2d_scaled_in(x, xscale, weight, bias, stride=1, pad=0, want_stats=False, join=None):
     out = _Conv2dScaledIn.apply(x, xscale, weight, bias, stride, pad, ACT_NONE, want_stats, join)
     if GN_LAZY and weight.shape[2] == 1 and stride == 1 and pad == 0 and (x.shape[-1], weight.shape[0]) == (128, 32):
-        out[0]._gn_lazy_ok = True   # (its backward redeems GroupNorm tokens: dis_conv2d_dgrad1x1_scaled_gnb)
+        _mark_lazy_ok(out)   # (its backward redeems GroupNorm tokens: dis_conv2d_dgrad1x1_scaled_gnb)
     return out
 
 
@@ -2092,7 +2173,7 @@ class _GroupNorm(torch.autograd.Function):
             # (a plain GroupNorm output with two consumers: the consumer whose backward ran second left the sums of the complete g)
             ab, slots = pre
             if ctx.x_lazy and GN_LAZY:
-                gx = _gn_lazy_defer(gy, x, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, in_act)
+                gx = _gn_lazy_defer(gy, x, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, in_act, uid=ctx.x_lazy)
             else:
                 gx = torch.empty_like(x)
                 coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=x.device)
@@ -2104,7 +2185,7 @@ class _GroupNorm(torch.autograd.Function):
             # SELU'(y) and left the channel sums): it doubles as the residual gradient, and one elementwise pass gives gx
             ab, slots = pre
             if ctx.x_lazy and GN_LAZY:
-                gx = _gn_lazy_defer(gy.view(x.shape), x, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, ACT_NONE)
+                gx = _gn_lazy_defer(gy.view(x.shape), x, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, ACT_NONE, uid=ctx.x_lazy)
             else:
                 gx = torch.empty_like(x)
                 coef = torch.empty(n * (c + 2) + 4 * n * c + 2, dtype=torch.float32, device=x.device)
@@ -2132,7 +2213,7 @@ class _GroupNorm(torch.autograd.Function):
             gres = torch.empty_like(x) if (has_res or act != ACT_NONE) else None
             lib.call('dis_gn_bwd_res_sums', gy, y, x, gres, ab, slots, n, hw, c, act)
             g_ = gres if gres is not None else gy.view(x.shape)
-            gx = _gn_lazy_defer(g_, x, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, in_act)
+            gx = _gn_lazy_defer(g_, x, stats, gamma, ab, slots, gg, gb, n, hw, c, eps, in_act, uid=ctx.x_lazy)
             if not has_res:
                 gres = None
         else:
@@ -2168,7 +2249,7 @@ def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5
     conv2d(y, ...) - which forms the values on load and stores them - or calls ops.realize(y) (see _GN_PENDING)."""
     defer = bool(defer and GN_DEFER and residual is not None and act == ACT_SELU and in_act == ACT_NONE and stats is not None and
                  x.dim() == 4 and c_ok(x) and BF16X3)
-    y = _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act, join, bool(getattr(x, '_gn_lazy_ok', False)), defer)
+    y = _GroupNorm.apply(x, stats, gamma, beta, residual, act, eps, in_act, join, int(getattr(x, '_gn_lazy_ok', 0)), defer)
     if defer:
         y._pending_gn = (_c(x), stats, gamma, beta, _c(residual), float(eps))
         _GN_PENDING[y.data_ptr()] = True

@@ -193,6 +193,9 @@ class FlatAdam(object):
         return int(self.state_dev[0])  # device -> host: only checkpointing / tests read it
 
     def step(self, all_reduce=True):
+        # every GroupNorm token of this backward pass redeemed, every pre-reduced gradient picked up - checked BEFORE the update
+        # (a stale table means gradients of this step are wrong; the next zero_grad() would be one update too late)
+        ops.check_backward_complete()
         if all_reduce:
             self.finish_grads()
         ops.adam_step_dev(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.state_dev, self.lr,
