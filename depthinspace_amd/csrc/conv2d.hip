@@ -2234,6 +2234,76 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
   return DIS_OK;
 }
 
+/* Input gradient AND weight gradient of a 3x3 stride-1 pad-1 convolution c -> c (c = 32) in ONE launch (round 6, conv_bwd_fused.hip):
+ * the gy halo an input-gradient tile stages in LDS also feeds the weight-gradient products of the pixels the tile owns, so gy (or
+ * gpre, the GroupNorm-backward pass formed on load) is read once and never written for a second launch.  Reference: one autograd node
+ * per Conv2d of ResNetBlock / Block2D3D, /root/reference/model/multi_frame_networks.py:338-345,514-542.
+ *   operand of both products: coef != null: gpre = act'(q) (g k1_c + q kx + k0) as dis_conv2d_dgrad_f16x2_gnb forms it (stored to gpre_out
+ *   too when that is non-null); coef == null: g itself (in_act == 0) or g act'(q) (q = the conv's activated output).
+ *   input gradient: exactly dis_conv2d_dgrad_f16x2_gnb's forms (accumulate, ab_gn_x / ab_act_y / ab_out) - gx is bit-identical to it.
+ *   weight gradient: x = the conv's input (n, hin, win, c); x_gn_stats != null: x is staged as GroupNorm(x) (dis_conv2d_wgrad_bf16x3_gn).
+ *   x may be the same tensor as ab_gn_x or ab_act_y (it is then fetched once).  grad_w (c, c, 3, 3), grad_b (c) or null;
+ *   workspace: dis_conv2d_wgrad_workspace(c, c, 3, 1) floats.
+ * DIS_ERR_UNSUPPORTED: no instance for this combination (the caller keeps the two launches). */
+extern "C" int dis_conv2d_bwd_fused_f16x2(const float* g, const float* q, const float* coef, int in_act, float* gpre_out,
+                                          const float* w_oihw, int w_o, int w_i, int w_row_stride, float* gx, int accumulate,
+                                          const float* ab_gn_x, const float* ab_act_y, double* ab_out, const float* x,
+                                          const double* x_gn_stats, const float* x_gn_gamma, const float* x_gn_beta, float x_gn_eps,
+                                          float* grad_w, float* grad_b, float* workspace, int n, int hin, int win, int c,
+                                          void* stream) {
+  if (!g || !w_oihw || !gx || !x || !grad_w || !workspace) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c != 32 || w_o != c || w_i != c) return DIS_ERR_UNSUPPORTED;
+  if (in_act != DIS_ACT_NONE && in_act != DIS_ACT_SELU) return DIS_ERR_UNSUPPORTED;
+  if ((coef || in_act) && !q) return DIS_ERR_NULL;
+  if (gpre_out && !coef) return DIS_ERR_BAD_SHAPE;
+  if ((ab_out != nullptr) != (ab_gn_x != nullptr) || (ab_act_y && (!ab_out || !accumulate))) return DIS_ERR_BAD_SHAPE;
+  if (x_gn_stats && (!x_gn_gamma || !x_gn_beta)) return DIS_ERR_NULL;
+  if (w_row_stride == 0) w_row_stride = w_i * 9;
+  if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
+  static const bool off = getenv("DIS_BWD_FUSED") && getenv("DIS_BWD_FUSED")[0] == '0';
+  if (off || !dis_f2_enabled()) return DIS_ERR_UNSUPPORTED;
+  if ((long)hin * win * c * 4 >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
+  using C = WgCfg<32, 32, 3, 3, 1>;
+  FbArgs f;
+  ConvArgs& a = f.c;
+  a.x = g; a.w = w_oihw; a.bias = nullptr; a.y = gx; a.stats = nullptr;
+  a.n = n; a.hin = hin; a.win = win; a.hv = hin; a.wv = win; a.pad_y = 1; a.pad_x = 1;
+  a.hf = hin; a.wf = win; a.osy = 1; a.ooy = 0; a.osx = 1; a.oox = 0;
+  a.act = DIS_ACT_NONE; a.accum = accumulate ? 1 : 0;
+  a.xscale = nullptr; a.yscale = nullptr;
+  a.wmode = 1; a.w_o = w_o; a.w_i = w_i; a.w_rs = w_row_stride;
+  a.xact = q;
+  a.ldx = a.ldy = c; a.cx = a.cy = c; a.x_sub = a.y_sub = 0; a.nbias = 0; a.wtap0 = 0; a.wtap_step = 0;
+  a.gn_stats = nullptr; a.gn_gamma = nullptr; a.gn_beta = nullptr; a.gn_eps = 0.f;
+  a.ab_x = ab_gn_x; a.ab_out = ab_out; a.ab_slots = num_cus(); a.ab_act_y = ab_act_y;
+  a.gnb_coef = coef; a.gnb_out = gpre_out; a.gnb_act = 0;
+  const int xsrc = (ab_gn_x && x == ab_gn_x) ? 1 : ((ab_act_y && x == ab_act_y) ? 2 : 0);
+  f.wx = x; f.wx_gn_stats = x_gn_stats; f.wx_gn_gamma = x_gn_gamma; f.wx_gn_beta = x_gn_beta; f.wx_gn_eps = x_gn_eps;
+  const int tiles_x = (win + 15) / 16, tiles_y = (hin + 15) / 16;
+  const long ntiles = (long)n * tiles_y * tiles_x;
+  long grid = num_cus();
+  if (grid > WG_WORKERS) grid = WG_WORKERS;
+  if (grid > ntiles) grid = ntiles;
+  if (grid >= 8) grid -= grid % 8;
+  if (grid < 1) grid = 1;
+  const long elems = C::PART;
+  static_assert(C::PART == 9 * 32 * 32, "slab layout");
+  f.part = workspace;
+  float* tmp = workspace + (long)WG_WORKERS * elems;
+  f.bpart = grad_b ? tmp + (long)WG_RSPLIT * elems : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t le = dis_fb_launch(f, in_act, x_gn_stats != nullptr, xsrc, grid, s);
+  if (le == hipErrorInvalidValue) return DIS_ERR_UNSUPPORTED;
+  if (le != hipSuccess) return (int)le;
+  const long total = (long)C::MROWS * 32;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, grad_b != nullptr)), dim3(64 * WG_RW), 0, s,
+                     (const float*)f.part, grad_w, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, 32, 32, C::PART,
+                     (const float*)(grad_b ? f.bpart : nullptr), grad_b, (int)grid);
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+
 // ---- wide layers as 32 x 32 channel-slice pairs (DispNetS, called from dis_convg_wgrad) ----
 // gw[g][x][tap] = sum over the pair's worker slabs; slab element [tap * 32 + xc][gc] (WxCfg<32, 32, K>: m = 16 mb + row,
 // mb = 2 tap + half).  Fixed summation order: deterministic.

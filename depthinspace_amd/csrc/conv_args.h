@@ -80,6 +80,19 @@ struct WgArgs {
   float* gnb_out;
 };
 
+// conv_bwd_fused.hip: input gradient + weight gradient of a 3x3 stride-1 pad-1 conv C -> C in one launch
+struct FbArgs {
+  ConvArgs c;           // the input-gradient launch exactly as conv_f16x2_kernel takes it (x = gy / g, y = gx, xact, gnb_*, ab_*)
+  const float* wx;      // the conv's INPUT (weight-gradient operand), shaped like c.y; XSRC != 0: taken from c.ab_x / c.ab_act_y instead
+  const double* wx_gn_stats;   // XGN: wx is staged as GroupNorm(wx) (n, 2) sums, as dis_gn_apply takes them
+  const float* wx_gn_gamma;
+  const float* wx_gn_beta;
+  float wx_gn_eps;
+  float* part;    // weight-gradient slabs [workgroup][9 * C * C], element [(tap * C + ci) * C + co] (conv_wgrad_f16x2_kernel's layout)
+  float* bpart;   // bias-gradient partials [workgroup][C], may be null
+};
+hipError_t dis_fb_launch(const FbArgs& f, int inact, bool xgn, int xsrc, long grid, hipStream_t stream);
+
 // Weight prologue of the LDS-resident-weight kernels (512 threads): copy an OIHW block - w_o <= 32 rows of `row` <= 288 floats,
 // rows w_rs floats apart in memory - into LDS rows padded by one float.  ALL of a thread's loads are issued before the first
 // is used: the plain `for (i = tid; i < n; i += 512) lds[..] = w[..]` form waits for every load in turn, 18 memory round trips

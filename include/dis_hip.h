@@ -394,6 +394,21 @@ int dis_gn_bwd_apply_coef(const float* g, const float* x, const float* coef, flo
 int dis_conv2d_dgrad_f16x2_gnb(const float* g, const float* q, const float* coef, int in_act, float* gpre_out, const float* w_oihw,
                                int w_o, int w_i, int w_row_stride, float* gx, int accumulate, const float* ab_gn_x,
                                const float* ab_act_y, double* ab_out, int n, int hin, int win, int c, void* stream);
+/* Round 6 - input gradient AND weight gradient of a 3x3 stride-1 pad-1 conv c -> c (c = 32) in ONE launch (csrc/conv_bwd_fused.hip):
+ * replaces the pair dis_conv2d_dgrad_f16x2_gnb / dis_conv2d_fwd_bf16x3_oihw(mode 1) + dis_conv2d_wgrad_bf16x3[_gn | _act] of one Conv2d
+ * node (reference: torch.nn.Conv2d's backward inside ResNetBlock / Block2D3D, model/multi_frame_networks.py:338-345,514-542).
+ *   operand of both products: coef != NULL: gpre = act'(q) (g k1_c + q kx + k0), as dis_conv2d_dgrad_f16x2_gnb forms it (also stored to
+ *     gpre_out when that is non-NULL); coef == NULL: g (in_act == 0) or g act'(q) (q = the conv's activated output).
+ *   input gradient gx: dis_conv2d_dgrad_f16x2_gnb's forms (accumulate, ab_gn_x / ab_act_y / ab_out) - bit-identical results.
+ *   weight gradient: x (n, hin, win, c) = the conv's input; x_gn_stats != NULL: staged as GroupNorm(x) (dis_conv2d_wgrad_bf16x3_gn);
+ *     x may be the tensor ab_gn_x or ab_act_y (fetched once).  grad_w (c, c, 3, 3), grad_b (c) or NULL;
+ *     workspace: dis_conv2d_wgrad_workspace(c, c, 3, 1) floats.
+ * DIS_ERR_UNSUPPORTED: no instance for the combination / the three-term mode / DIS_BWD_FUSED=0 (the caller keeps the two launches). */
+int dis_conv2d_bwd_fused_f16x2(const float* g, const float* q, const float* coef, int in_act, float* gpre_out, const float* w_oihw,
+                               int w_o, int w_i, int w_row_stride, float* gx, int accumulate, const float* ab_gn_x,
+                               const float* ab_act_y, double* ab_out, const float* x, const double* x_gn_stats,
+                               const float* x_gn_gamma, const float* x_gn_beta, float x_gn_eps, float* grad_w, float* grad_b,
+                               float* workspace, int n, int hin, int win, int c, void* stream);
 int dis_conv2d_wgrad_bf16x3_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta,
                                float gn_eps, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
                                int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,
