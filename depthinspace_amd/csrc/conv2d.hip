@@ -2243,8 +2243,13 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
  *   input gradient: exactly dis_conv2d_dgrad_f16x2_gnb's forms (accumulate, ab_gn_x / ab_act_y / ab_out) - gx is bit-identical to it.
  *   weight gradient: x = the conv's input (n, hin, win, c); x_gn_stats != null: x is staged as GroupNorm(x) (dis_conv2d_wgrad_bf16x3_gn).
  *   x may be the same tensor as ab_gn_x or ab_act_y (it is then fetched once).  grad_w (c, c, 3, 3), grad_b (c) or null;
- *   workspace: dis_conv2d_wgrad_workspace(c, c, 3, 1) floats.
+ *   workspace: dis_conv2d_bwd_fused_workspace(c) floats.
  * DIS_ERR_UNSUPPORTED: no instance for this combination (the caller keeps the two launches). */
+extern "C" long dis_conv2d_bwd_fused_workspace(int c) {
+  if (c != 32) return -1;
+  // the weight-gradient kernels' slabs + bias partials, then one spill slab per (workgroup, wave) for passes that end early (rare)
+  return wgrad_ws<32, 32, 3, 3, 1>() + (long)WG_WORKERS * 4 * 9 * 32 * 32;
+}
 extern "C" int dis_conv2d_bwd_fused_f16x2(const float* g, const float* q, const float* coef, int in_act, float* gpre_out,
                                           const float* w_oihw, int w_o, int w_i, int w_row_stride, float* gx, int accumulate,
                                           const float* ab_gn_x, const float* ab_act_y, double* ab_out, const float* x,
@@ -2292,6 +2297,7 @@ extern "C" int dis_conv2d_bwd_fused_f16x2(const float* g, const float* q, const 
   f.part = workspace;
   float* tmp = workspace + (long)WG_WORKERS * elems;
   f.bpart = grad_b ? tmp + (long)WG_RSPLIT * elems : nullptr;
+  f.spill = workspace + wgrad_ws<32, 32, 3, 3, 1>();
   hipStream_t s = (hipStream_t)stream;
   hipError_t le = dis_fb_launch(f, in_act, x_gn_stats != nullptr, xsrc, grid, s);
   if (le == hipErrorInvalidValue) return DIS_ERR_UNSUPPORTED;

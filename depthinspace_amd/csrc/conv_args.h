@@ -90,6 +90,7 @@ struct FbArgs {
   float wx_gn_eps;
   float* part;    // weight-gradient slabs [workgroup][9 * C * C], element [(tap * C + ci) * C + co] (conv_wgrad_f16x2_kernel's layout)
   float* bpart;   // bias-gradient partials [workgroup][C], may be null
+  float* spill;   // [workgroup][wave][36 * 256]: where a wave parks its dW accumulators when the dW exponent has to move (rare)
 };
 hipError_t dis_fb_launch(const FbArgs& f, int inact, bool xgn, int xsrc, long grid, hipStream_t stream);
 

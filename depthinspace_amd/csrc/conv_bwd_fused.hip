@@ -41,8 +41,30 @@ __device__ __forceinline__ void fb_static_for(F&& f) {
   }
 }
 
+#ifndef FB_ZLIT
+#define FB_ZLIT 1   // the first product of an input-gradient accumulator starts from a zero literal (no register moves)
+#endif
+#ifndef FB_BLIND
+#define FB_BLIND 0   // (re-blinding p0 with an empty asm statement produced WRONG results in the INACT instances: off)
+#endif
+// Diagnostic build only (scripts/diag/fb_stamps.py, -DFB_STAMP): per-wave s_memtime sums of the phases of a tile
+#ifdef FB_STAMP
+__device__ unsigned long long fb_stamps[256 * 4 * 8];
+#define FB_T(k)                                                   \
+  {                                                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    st_[k] += now_ - last_;                                       \
+    last_ = now_;                                                 \
+  }
+extern "C" int dis_debug_fb_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fb_stamps), sizeof(fb_stamps)); }
+#else
+#define FB_T(k)
+#endif
 #define FB_TR 16
 #define FB_TC 16
+#ifndef FB_SMARGIN
+#define FB_SMARGIN 6   // bits of headroom the dW exponent keeps when it is (re)set: a later tile may be 2^6 larger before the accumulators move again
+#endif
 struct FbCfg {
   static constexpr int C = 32, IR = FB_TR + 2, IC = FB_TC + 2, CV = C / 4, NP = 2, PS = 80, NT = 2, KS = 9;
   static constexpr int NW = 4, NTHR = 64 * NW, MT = FB_TR / NW;
@@ -71,6 +93,10 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   static_assert(EPIACT == 0 || EPIAB, "activation gradient at the output: only with the channel sums");
   static_assert(XSRC == 0 || (XSRC == 1 && EPIAB) || (XSRC == 2 && EPIACT), "shared x operand");
   static_assert(!GST || INCOEF, "gpre store: only where the operand is formed on load");
+#ifdef FB_STAMP
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   unsigned short* wl = smem16;
   unsigned short* xl = smem16 + K::W_U16;
@@ -292,7 +318,8 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       const float sc = __builtin_ldexpf(1.f, sx_e);
 #pragma unroll
       for (int it = 0; it < NLOAD; ++it) stage_item(it, sc, xl);
-      centre_issue(cn, cty, ctx, true);
+      // (the order of a steady-state iteration - the next tile's halo loads, THEN the current tile's centre loads: the compiler's
+      //  wait counts at the loop head are merged over both ways in, and with the other order they waited for everything in flight)
       advance(n1, ty1, tx1);
       pf0 = pf_make(n1, ty1, tx1, tile + per < t_hi);
 #pragma unroll
@@ -369,37 +396,73 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   constexpr int PA[3] = {1, 0, 0};
   constexpr int PB[3] = {0, 1, 0};
 
-  while (tile < t_hi) {
-    asm volatile("" : "+v"(p0v));
-    unsigned cur_off[MT];
-    centre_off(cty, ctx, cur_off);
-    const float* cur_y = a.y + (long)cn * a.hf * a.wf * C;
-    if (EPIAB && cn != ab_n) {
-      if (ab_n >= 0) ab_flush();
-      ab_n = cn;
+  auto xraw = [&](int i) -> float4 { return XSRC == 1 ? cab[EPIAB ? i : 0] : (XSRC == 2 ? cact[EPIACT ? i : 0] : cxw[XSRC == 0 ? i : 0]); };
+  auto xval = [&](int i, const unsigned (&cur_off)[MT]) -> float4 {   // the value the products see: GroupNorm applied (XGN), pixels past the map zero
+    float4 v = xraw(i);
+    if (XGN) {
+      const int nt = i % NT;
+      const bool ok = cur_off[i / NT] != BX_OOB;
+      v.x = v.x * xg_sc[nt].x + xg_sh[nt].x, v.y = v.y * xg_sc[nt].y + xg_sh[nt].y;
+      v.z = v.z * xg_sc[nt].z + xg_sh[nt].z, v.w = v.w * xg_sc[nt].w + xg_sh[nt].w;
+      v = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // the NEXT tile's items (in flight since the previous iteration): final values, maxima
-    prep(pf0, n1, parity);
-    // ONE barrier per tile: every wave has finished reading the other halo buffer (previous tile: both products), this tile's buffer is
-    // completely written, the maxima of the next tile are visible
-    __syncthreads();
-    const float gmax_n = tile_max(parity);
-    const int sx_n = f2_scale_exp(gmax_n);
-    const float sc_n = __builtin_ldexpf(1.f, sx_n);
-    parity ^= 1;
-    const unsigned short* xc = xl + buf * K::X_U16;
-    unsigned short* xn = xl + (buf ^ 1) * K::X_U16;
-    int n2 = n1, ty2 = ty1, tx2 = tx1;
-    advance(n2, ty2, tx2);
-    const Pf pfn = pf_make(n2, ty2, tx2, tile + 2 * per < t_hi);
+    return v;
+  };
+  // ---- a tile goes through two phases: D (the input gradient's products; the NEXT tile's halo is split and staged on the way) and W
+  // (the input gradient's epilogue and the dW products of the same tile, against the halo D has just read).  The loop runs W(t), D(t + 1):
+  // the dW accumulators are carried around a loop in which only matrix instructions touch them, so they stay in accumulation registers.
+  // When the dW exponent has to move (a tile whose product magnitude exceeds every earlier one's by more than the headroom - rare), the
+  // inner loop is LEFT, the accumulators go to this wave's spill slab in memory, and a new pass starts from zero accumulators.  (With the
+  // rescale as a branch inside the loop the compiler kept all 144 accumulators in vector registers across it: ~290 register copies per
+  // tile and spills to scratch, whose reloads made every halo load synchronous.)
+  f32x4 acc[MT][NT];
+  unsigned cur_off[MT];
+  const unsigned short* xc = xl;
+  int sx_n = 0, n2 = 0, ty2 = 0, tx2 = 0, ex_w = 0;
+  float gmax_n = 0.f, xm = 0.f;
+  Pf pfn = pf0;
+  // RESUME (rare): the tile's D has run already, the wave left the loop in front of W to park its dW accumulators; only the products
+  // are formed again (the halo buffer is untouched until the next D stages into the other one) - no barrier, no staging, no loads.
+  auto dphase = [&](auto rsm) __attribute__((always_inline)) {
+    constexpr bool RESUME = decltype(rsm)::value;
+    float sc_n = 0.f;
+    unsigned short* xn = xl;
+    if constexpr (!RESUME) {
+#if FB_BLIND
+      asm volatile("" : "+v"(p0v));
+#endif
+      centre_off(cty, ctx, cur_off);
+      // the NEXT tile's items (in flight since the previous D): final values, maxima
+      FB_T(0)
+      prep(pf0, n1, parity);
+      // this tile's centre operands (x strip, gx so far, GroupNorm input, activation output): requested here, used from the end of D on -
+      // a whole D phase to land.  (Requested in the previous W they were the youngest loads in flight at the loop head, where the
+      // compiler's merged wait counts wait for everything: ~2.2 k cycles per tile, scripts/diag/fb_stamps.py.)
+      centre_issue(cn, cty, ctx, true);
+      FB_T(1)
+      // ONE barrier per tile: every wave has finished reading the other halo buffer (previous tile: both products), this tile's buffer
+      // is completely written, the maxima of the next tile are visible
+      __syncthreads();
+      FB_T(2)
+      gmax_n = tile_max(parity);
+      sx_n = f2_scale_exp(gmax_n);
+      sc_n = __builtin_ldexpf(1.f, sx_n);
+      parity ^= 1;
+      xc = xl + buf * K::X_U16;
+      xn = xl + (buf ^ 1) * K::X_U16;
+      n2 = n1, ty2 = ty1, tx2 = tx1;
+      advance(n2, ty2, tx2);
+      pfn = pf_make(n2, ty2, tx2, tile + 2 * per < t_hi);
+    }
 
     // ---------------- input gradient: 9 taps x (4 rows x 2 channel blocks) x 3 products; the next tile's items are split and written
     // to the other halo buffer on the way, each followed by the load that refills its registers with the tile after next
-    f32x4 acc[MT][NT];
+    if (!FB_ZLIT) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     {
       // row fragments: ONE set R[halo row 0 .. MT + 1][plane] for the current kx.  Step (kx, ky) multiplies rows ky .. ky + MT - 1:
       // during (kx, 2) rows 0, 1 are dead and take kx + 1's; step (kx + 1, 0) fetches rows 2 .. MT + 1 first and multiplies rows 0, 1
@@ -430,12 +493,15 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         if (ky == 0 && kx > 0) load_rows(kx, 2, MT + 2);
         if (ky == 2 && kx < 2) load_rows(kx + 1, 0, 2);   // (this step reads rows 2 .. MT + 1: rows 0, 1 are dead)
         // the next tile's items that ride in this k-step: split, LDS write, refill with the tile after next
+        if constexpr (!RESUME) {
 #pragma unroll
-        for (int it = 0; it < NLOAD; ++it)
-          if (it * KS / NLOAD == ks) {
-            stage_item(it, sc_n, xn);
-            pf_issue(pfn, it);
-          }
+          for (int it = 0; it < NLOAD; ++it)
+            if (it * KS / NLOAD == ks) {
+              stage_item(it, sc_n, xn);
+              __builtin_amdgcn_sched_barrier(0);   // (the load below reuses the registers the item has just left: not before their last read)
+              pf_issue(pfn, it);
+            }
+        }
         auto mm = [&](int mt0, int mt1) __attribute__((always_inline)) {
 #pragma unroll
           for (int q = 0; q < 3; ++q)
@@ -444,8 +510,9 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
               if (mt >= mt0 && mt < mt1) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fw[b][PB[q]][nt]),
-                                                                       __builtin_bit_cast(f16x8_t, R[ky + mt][PA[q]]), acc[mt][nt], 0, 0, 0);
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                      __builtin_bit_cast(f16x8_t, fw[b][PB[q]][nt]), __builtin_bit_cast(f16x8_t, R[ky + mt][PA[q]]),
+                      (FB_ZLIT && ks == 0 && q == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mt][nt], 0, 0, 0);   // (the first product starts from a zero literal)
               }
         };
         if (ky == 0 && kx > 0) {
@@ -459,6 +526,39 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       });
     }
 
+
+    FB_T(3)
+    // this wave's x strip of the tile (requested during the previous W): largest magnitude -> its exponent
+    if constexpr (!RESUME) {
+      if (XGN && cn != xg_n) {
+        xg_n = cn;
+        float mean, rstd;
+        gn_moments(fa_.wx_gn_stats, cn, (double)a.hf * a.wf * C, fa_.wx_gn_eps, &mean, &rstd);
+  #pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float4 g_ = *(const float4*)(fa_.wx_gn_gamma + nt * 16 + lg * 4), b_ = *(const float4*)(fa_.wx_gn_beta + nt * 16 + lg * 4);
+          xg_sc[nt] = make_float4(rstd * g_.x, rstd * g_.y, rstd * g_.z, rstd * g_.w);
+          xg_sh[nt] = make_float4(b_.x - xg_sc[nt].x * mean, b_.y - xg_sc[nt].y * mean, b_.z - xg_sc[nt].z * mean, b_.w - xg_sc[nt].w * mean);
+        }
+      }
+      xm = 0.f;
+  #pragma unroll
+      for (int i = 0; i < NPIECE; ++i) {
+        const float4 v = xval(i, cur_off);
+        xm = __builtin_fmaxf(__builtin_fmaxf(xm, fabsf(v.x)), fabsf(v.y));
+        xm = __builtin_fmaxf(__builtin_fmaxf(xm, fabsf(v.z)), fabsf(v.w));
+      }
+      xm = f2_wave_max(xm);
+      ex_w = f2_scale_exp(xm);
+    }
+  };
+  auto wphase = [&]() __attribute__((always_inline)) {
+    FB_T(4)
+    const float* cur_y = a.y + (long)cn * a.hf * a.wf * C;
+    if (EPIAB && cn != ab_n) {   // (two flushes are always separated by D's barrier)
+      if (ab_n >= 0) ab_flush();
+      ab_n = cn;
+    }
     // ---------------- epilogue of the input gradient (conv_f16x2_kernel's arithmetic, undeferred): piece i rides under the dW products
     const float desc = __builtin_ldexpf(1.f, -(sx_e + sw_e));
     auto epi_piece = [&](int i) __attribute__((always_inline)) {
@@ -475,7 +575,11 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
                      act_grad_from_out(q.w, EPIACT)};
       }
       const u32x4 ov = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+#ifdef FB_KO_STORE   // (diagnostic: the stores are dropped)
+      __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(cur_y, y_bytes), (cur_off[mt] + nt * 64) | BX_OOB, 0, 0);
+#else
       __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(cur_y, y_bytes), cur_off[mt] + nt * 64, 0, 0);
+#endif
       if (EPIAB) {
         const float4 xv = cab[EPIAB ? i : 0];
         const float g0 = o[0] * livef, g1 = o[1] * livef, g2 = o[2] * livef, g3 = o[3] * livef;
@@ -485,46 +589,9 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       }
     };
 
+
     // ---------------- weight gradient: this wave's 64 pixels (two k-steps of 32) against the halo in LDS
     {
-      auto xraw = [&](int i) -> float4 { return XSRC == 1 ? cab[EPIAB ? i : 0] : (XSRC == 2 ? cact[EPIACT ? i : 0] : cxw[XSRC == 0 ? i : 0]); };
-      if (XGN && cn != xg_n) {
-        xg_n = cn;
-        float mean, rstd;
-        gn_moments(fa_.wx_gn_stats, cn, (double)a.hf * a.wf * C, fa_.wx_gn_eps, &mean, &rstd);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const float4 g_ = *(const float4*)(fa_.wx_gn_gamma + nt * 16 + lg * 4), b_ = *(const float4*)(fa_.wx_gn_beta + nt * 16 + lg * 4);
-          xg_sc[nt] = make_float4(rstd * g_.x, rstd * g_.y, rstd * g_.z, rstd * g_.w);
-          xg_sh[nt] = make_float4(b_.x - xg_sc[nt].x * mean, b_.y - xg_sc[nt].y * mean, b_.z - xg_sc[nt].z * mean, b_.w - xg_sc[nt].w * mean);
-        }
-      }
-      auto xval = [&](int i) -> float4 {   // the value the products see: GroupNorm applied (XGN), pixels past the map zero
-        float4 v = xraw(i);
-        if (XGN) {
-          const int nt = i % NT;
-          const bool ok = cur_off[i / NT] != BX_OOB;
-          v.x = v.x * xg_sc[nt].x + xg_sh[nt].x, v.y = v.y * xg_sc[nt].y + xg_sh[nt].y;
-          v.z = v.z * xg_sc[nt].z + xg_sh[nt].z, v.w = v.w * xg_sc[nt].w + xg_sh[nt].w;
-          v = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return v;
-      };
-      float m = 0.f;
-#pragma unroll
-      for (int i = 0; i < NPIECE; ++i) {
-        const float4 v = xval(i);
-        m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.x)), fabsf(v.y));
-        m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.z)), fabsf(v.w));
-      }
-      m = f2_wave_max(m);
-      const int ex_w = f2_scale_exp(m);
-      if (m > 0.f && gmax > 0.f && ex_w + sx_e < S_w) {   // (wave-uniform, rare) a larger product magnitude than any before
-        const float r = __builtin_ldexpf(1.f, ex_w + sx_e - S_w);
-#pragma unroll
-        for (int j = 0; j < K::NACC; ++j) accw[j] *= r;
-        S_w = ex_w + sx_e;
-      }
       // (a term carries 2^(es + sx_e); where that is not 2^S_w - the halo or the strip is all zero - the term is zero anyway)
       const int es = S_w - sx_e < ex_w ? S_w - sx_e : ex_w;
       const float scx = __builtin_ldexpf(1.f, es);
@@ -535,7 +602,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            const float4 v = xval((2 * h + mi) * NT + nt);
+            const float4 v = xval((2 * h + mi) * NT + nt, cur_off);
             unsigned a1, a2, b1, b2;
             f2_split_pair_scaled(v.x, v.y, scx, a1, a2);
             f2_split_pair_scaled(v.z, v.w, scx, b1, b2);
@@ -551,7 +618,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
           for (int p = 0; p < NP; ++p) fx[ah][p] = fb_tr_read8(xq + ah * 16 + p * C, xq + 16 * PS + ah * 16 + p * C);
         // units u = (tap, co half): two gy fragments (one per plane) against the four x fragments, 6 products; the next unit's
         // fragments are fetched under this unit's products
-        s16x8 fg[2][NP];
+        s16x8 fg[3][NP];   // (three sets, fetched two units ahead: one unit = 6 products = ~100 cycles, less than an LDS round trip)
         auto load_g = [&](int u, s16x8 (&G)[NP]) __attribute__((always_inline)) {
           const int tap = u >> 1, bh = u & 1, ky = tap / 3, kx = tap % 3;
           // centre pixel (r', c') of this k-step meets the halo pixel (r' + 2 - ky, c' + 2 - kx)
@@ -560,9 +627,10 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
           for (int p = 0; p < NP; ++p) G[p] = fb_tr_read8(gq + p * C, gq + IC * PS + p * C);
         };
         load_g(0, fg[0]);
+        load_g(1, fg[1]);
         fb_static_for<0, 18>([&](auto uc) __attribute__((always_inline)) {
           constexpr int u = decltype(uc)::value;
-          if (u + 1 < 18) load_g(u + 1, fg[(u + 1) & 1]);
+          if (u + 2 < 18) load_g(u + 2, fg[(u + 2) % 3]);
           // what rides under the products: the input gradient's epilogue in the first k-step, the next tile's centre loads in the second
           if (h == 0 && u % 2 == 0 && u / 2 < NPIECE) epi_piece(u / 2);
 #pragma unroll
@@ -570,24 +638,60 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
 #pragma unroll
             for (int q = 0; q < 3; ++q)
               accw[(u >> 1) * 4 + ah * 2 + (u & 1)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                  __builtin_bit_cast(f16x8_t, fx[ah][PA[q]]), __builtin_bit_cast(f16x8_t, fg[u & 1][PB[q]]),
+                  __builtin_bit_cast(f16x8_t, fx[ah][PA[q]]), __builtin_bit_cast(f16x8_t, fg[u % 3][PB[q]]),
                   accw[(u >> 1) * 4 + ah * 2 + (u & 1)], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         });
       });
     }
-
-    // the next tile becomes the current one; its centre operands go out now (the registers are free)
+    FB_T(5)
+    // the next tile becomes the current one
     cn = n1, cty = ty1, ctx = tx1;
     n1 = n2, ty1 = ty2, tx1 = tx2;
     tile += per;
-    centre_issue(cn, cty, ctx, tile < t_hi);
     sx_e = sx_n;
     gmax = gmax_n;
     buf ^= 1;
     pf0 = pfn;
+  };
+  int flushed = 0;
+  bool resume = false;
+  for (;;) {   // one pass per dW exponent: almost always exactly one
+#pragma unroll
+    for (int j = 0; j < K::NACC; ++j) accw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    S_w = 120;
+    bool s_set = false, need = false;
+    while (tile < t_hi) {
+      if (resume) dphase(std::true_type{});
+      else dphase(std::false_type{});
+      resume = false;
+      const bool adds = xm > 0.f && gmax > 0.f;   // (wave-uniform) this tile has something to add to dW
+      if (s_set && adds && ex_w + sx_e < S_w) {   // (rare) a larger product magnitude than the exponent allows: the accumulators leave first
+        need = true;
+        break;
+      }
+      if (!s_set && adds) {   // the first tile with something to add sets the exponent, FB_SMARGIN bits of headroom
+        S_w = ex_w + sx_e - FB_SMARGIN;
+        s_set = true;
+      }
+      wphase();
+    }
+    if (!need) break;
+    {   // the accumulators so far leave for this wave's spill slab (added to what an earlier pass left there)
+      const float dsc = __builtin_ldexpf(1.f, -S_w);
+      f32x4* sp = (f32x4*)(fa_.spill + ((long)blockIdx.x * NW + wave) * (K::NACC * 256)) + lane;
+#pragma unroll
+      for (int j = 0; j < K::NACC; ++j) {
+        f32x4 v = accw[j] * dsc;
+        if (flushed) v += sp[j * 64];
+        sp[j * 64] = v;
+      }
+      flushed = 1;
+      resume = true;
+    }
   }
 
+  FB_T(6)
   // ---------------- the workgroup's results leave: channel sums, bias partials, the dW slab
   if (EPIAB) {
     __syncthreads();   // (a flush inside the last iteration and the final one must not overlap: see conv_f16x2_kernel)
@@ -598,6 +702,11 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     const float desc = __builtin_ldexpf(1.f, -S_w);
 #pragma unroll
     for (int j = 0; j < K::NACC; ++j) accw[j] *= desc;
+    if (flushed) {   // (rare: earlier passes of this wave, written by these very lanes)
+      const f32x4* sp = (const f32x4*)(fa_.spill + ((long)blockIdx.x * NW + wave) * (K::NACC * 256)) + lane;
+#pragma unroll
+      for (int j = 0; j < K::NACC; ++j) accw[j] += sp[j * 64];
+    }
     f32x4* rbuf = (f32x4*)smem16;   // [wave - 1][tile j][lane]
     if (wave > 0) {
 #pragma unroll
@@ -632,6 +741,11 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       fa_.bpart[(long)blockIdx.x * C + threadIdx.x] = sum;
     }
   }
+#ifdef FB_STAMP
+  FB_T(7)
+  if (lane == 0 && blockIdx.x < 256)
+    for (int k = 0; k < 8; ++k) fb_stamps[(blockIdx.x * 4 + wave) * 8 + k] = st_[k];
+#endif
 }
 
 // Launch: hipErrorInvalidValue when no instance exists for the combination (the caller keeps the two launches).
@@ -650,6 +764,9 @@ hipError_t dis_fb_launch(const FbArgs& f, int inact, bool xgn, int xsrc, long gr
     return hipSuccess;
   };
   constexpr int S = DIS_ACT_SELU;
+#ifdef FB_ONLY
+  return launch(conv_bwd_fused_kernel<FB_ONLY>, 0);
+#endif
   if (inact != 0 && inact != S) return hipErrorInvalidValue;
   const bool coef = a.gnb_coef != nullptr, gst = a.gnb_out != nullptr, ab = a.ab_out != nullptr, epiact = a.ab_act_y != nullptr;
   if (!coef) {

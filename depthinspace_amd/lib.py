@@ -85,6 +85,7 @@ SIGS = {
     'dis_gn_bwd_res_sums': 'pppppiiliip',
     'dis_gn_bwd_apply_coef': 'ppppiliip',
     'dis_conv2d_dgrad_f16x2_gnb': 'pppippiiipippp' + 'iiiip',
+    'dis_conv2d_bwd_fused_workspace': 'i',
     'dis_conv2d_bwd_fused_f16x2': 'pppippiiipippp' + 'pppp' + 'f' + 'ppp' + 'iiiip',
     'dis_conv2d_wgrad_bf16x3_gn': 'ppppfppppiiiiiiiiip',
     'dis_conv2d_fwd_scaled': 'ppppppp' + 'iiiiiiiii' + 'p',
@@ -151,7 +152,7 @@ SIGS = {
     'dis_adam_step': 'pppplfddfifp',
     'dis_adam_step_dev': 'pppplfddfpfp',
 }
-_RET_LONG = {'dis_convb_pack_desc_bytes', 'dis_convg_splitk_workspace', 'dis_convb_splitk_workspace', 'dis_conv2d_gnsums_slots', 'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
+_RET_LONG = {'dis_conv2d_bwd_fused_workspace', 'dis_convb_pack_desc_bytes', 'dis_convg_splitk_workspace', 'dis_convb_splitk_workspace', 'dis_conv2d_gnsums_slots', 'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
              'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_act_bwd_ld_bias_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_geo_loss_acc_doubles', 'dis_geo_loss_multi_acc_doubles', 'dis_conv3d_knn_bwd_det_workspace', 'dis_conv3d_knn_bwd_stage', 'dis_conv3d_csr_workspace', 'dis_gather_csr_workspace',
              'dis_conv2d_pack_bf16x3_size', 'dis_disp_head_bwd_workspace'}
 

@@ -1059,6 +1059,33 @@ def _conv_fwd_any(x, weight, cin_pad, mode, bias, y, stats, n, hin, win, cin, co
                  pad, act)
 
 
+# Round 6: input gradient + weight gradient of a 3x3 stride-1 conv 32 -> 32 in one launch (dis_conv2d_bwd_fused_f16x2).  Complete and
+# parity-green (tests/test_bwd_fused_gpu.py), but measured SLOWER than the two launches it replaces on MI355X (profiles/r6_bwd_fused.md:
+# same-box A/B per form, per-tile cycle table, register budget) - OFF by default; DIS_BWD_FUSED=1 routes the backward of these layers
+# through it
+BWD_FUSED = _os.environ.get('DIS_BWD_FUSED', '0') == '1'
+_FUSED_WS = {}
+
+
+def _bwd_fused_ok(cin, cout, k, stride, pad):
+    return BWD_FUSED and BF16X3 and cin == 32 and cout == 32 and k == 3 and stride == 1 and pad == 1
+
+
+def _bwd_fused(g, q, coef, in_act, gpre_out, weight, gx, accumulate, ab_x, ab_act, ab, x, xgn, gw, gb, n, h, w):
+    """one launch for both gradients of a 3x3 stride-1 pad-1 conv 32 -> 32; False: no instance (the caller runs its two launches).
+    xgn = (stats, gamma, beta, eps) when the conv's input is GroupNorm(x) applied on load, else None"""
+    c = x.shape[-1]
+    wsz = _FUSED_WS.get(c)
+    if wsz is None:
+        wsz = _FUSED_WS[c] = lib.fn('dis_conv2d_bwd_fused_workspace')(c)
+    if wsz < 0:
+        return False
+    ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
+    st, gam, bet, eps = xgn if xgn is not None else (None, None, None, 0.0)
+    return lib.call_try('dis_conv2d_bwd_fused_f16x2', g, q, coef, in_act, gpre_out, weight, weight.shape[0], weight.shape[1],
+                        weight.stride(0), gx, 1 if accumulate else 0, ab_x, ab_act, ab, x, st, gam, bet, float(eps), gw, gb, ws, n, h, w, c)
+
+
 def _bx_shape(cin, cout, k, stride):
     return BF16X3 and cin in (16, 32) and cout in (16, 32) and k == 3 and stride == 1
 
@@ -1150,6 +1177,20 @@ class _Conv2d(torch.autograd.Function):
                 slots = lib.fn('dis_conv2d_gnsums_slots')()   # (the ResNetBlock-chain / two-consumer epilogue, see below)
                 ab = _zeros_d(n * slots * 2 * cin, x.device)
                 ab_x, ab_act = gnres[0], (x if len(gnres) == 1 else None)
+            if _bwd_fused_ok(cin, cout, k, stride, pad):
+                # one launch: the operand formed on load feeds the input gradient AND the weight gradient (gpre is never written)
+                gw, gw_ret = _sink(weight)
+                gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
+                if _bwd_fused(lg, lq, lcoef, lin_act, None, weight, gx, second, ab_x, ab_act, ab, x, None, gw, gb, n, hin, win):
+                    if ab is not None:
+                        _GN_PRE[gx.data_ptr()] = (ab, slots)
+                    if join is not None and not second:
+                        gx = join.first(gx)
+                    _sinks_written()
+                    return gx, gw_ret, gb_ret, None, None, None, None, None, None, None, None, None
+                _unsink(weight, (gw, gw_ret))
+                if has_bias:
+                    _unsink(ctx.bias_ref, (gb, gb_ret))
             if lib.call_try('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, weight, cout, cin, weight.stride(0), gx,
                             1 if second else 0, ab_x, ab_act, ab, n, hin, win, cin):
                 if ab is not None:
@@ -1175,6 +1216,28 @@ class _Conv2d(torch.autograd.Function):
         else:
             gpre = gy
         gx = None
+        if (need_dgrad and ctx.needs_input_grad[0] and cin_pad == cin and _bwd_fused_ok(cin, cout, k, stride, pad) and
+                (fuse_act or gpre is gy) and lib.fn('dis_get_conv_split')() == 1 and
+                not (ctx.gnres is not None and ctx.join is not None and ctx.join.buf is not None and (GN_SUMS & 2) and
+                     tuple(ctx.gnres[0].shape) == tuple(x.shape))):
+            # no GroupNorm-backward operand, no channel-sum epilogue: gy (or gy act'(y)) feeds both gradients in one launch
+            join = ctx.join
+            second = join is not None and join.buf is not None
+            gx = join.take(x.shape) if second else torch.empty_like(x)
+            gw, gw_ret = _sink(weight)
+            gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
+            if _bwd_fused(gy, y if fuse_act else None, None, act if fuse_act else ACT_NONE, None, weight, gx, second, None, None, None, x,
+                          None, gw, gb, n, hin, win):
+                if join is not None and not second:
+                    gx = join.first(gx)
+                _sinks_written()
+                return gx, gw_ret, gb_ret, None, None, None, None, None, None, None, None, None
+            _unsink(weight, (gw, gw_ret))
+            if has_bias:
+                _unsink(ctx.bias_ref, (gb, gb_ret))
+            if second:
+                join.buf = gx
+            gx = None
         if need_dgrad and ctx.needs_input_grad[0]:
             assert cin_pad == cin
             join = ctx.join
@@ -1306,12 +1369,26 @@ class _Conv2dGnIn(torch.autograd.Function):
         slots = lib.fn('dis_conv2d_gnsums_slots')() if sums else 0
         ab = _zeros_d(n * slots * 2 * cin, x.device) if sums else None
         gpre = None
+        fused_done = False
         if lz is not None:
             _, lg, lq, lcoef, lin_act = lz
-            gpre = torch.empty_like(lg)
-            if not lib.call_try('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, weight, cout, cin, weight.stride(0),
-                                gnorm, 0, x, None, ab, n, h, w, cin):
-                gy, gpre = _gn_lazy_materialize(lz), None
+            if _bwd_fused_ok(cin, cout, k, 1, pad):
+                # one launch: input gradient (+ the channel sums for this node's own GroupNorm) and the weight gradient with the
+                # GroupNorm of x applied on load; x is fetched once for both
+                gw, gw_ret = _sink(weight)
+                gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
+                if _bwd_fused(lg, lq, lcoef, lin_act, None, weight, gnorm, False, x, None, ab, x, (gn_stats, gamma, ctx.beta_ref, eps), gw, gb,
+                              n, h, w):
+                    fused_done, gpre = True, lg   # (gpre: only its shape is used below)
+                else:
+                    _unsink(weight, (gw, gw_ret))
+                    if has_bias:
+                        _unsink(ctx.bias_ref, (gb, gb_ret))
+            if not fused_done:
+                gpre = torch.empty_like(lg)
+                if not lib.call_try('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, weight, cout, cin, weight.stride(0),
+                                    gnorm, 0, x, None, ab, n, h, w, cin):
+                    gy, gpre = _gn_lazy_materialize(lz), None
         dgrad_done = gpre is not None
         if not dgrad_done:
             gy = _c(gy)
@@ -1346,12 +1423,13 @@ class _Conv2dGnIn(torch.autograd.Function):
             nred2 = wtot // (2 + 2 * cin) * 2
             lib.call('dis_gn_apply_bwd', gnorm, None, x, gn_stats, gamma, gx, None, gg, gbt, ws[:nred2], ws[nred2:], n, hw, cin,
                      ACT_NONE, eps, in_act)
-        gw, gw_ret = _sink(weight)
-        gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
-        wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin, cout, k, 1)
-        wws = torch.empty(wsz, dtype=torch.float32, device=x.device)
-        lib.call('dis_conv2d_wgrad_bf16x3_gn', x, gn_stats, gamma, ctx.beta_ref, eps, gpre, gw, gb, wws, n, h, w, cin, cin, cout,
-                 k, 1, pad)
+        if not fused_done:
+            gw, gw_ret = _sink(weight)
+            gb, gb_ret = _sink(ctx.bias_ref) if has_bias else (None, None)
+            wsz = lib.fn('dis_conv2d_wgrad_workspace')(cin, cout, k, 1)
+            wws = torch.empty(wsz, dtype=torch.float32, device=x.device)
+            lib.call('dis_conv2d_wgrad_bf16x3_gn', x, gn_stats, gamma, ctx.beta_ref, eps, gpre, gw, gb, wws, n, h, w, cin, cin, cout,
+                     k, 1, pad)
         _sinks_written()
         return gx, None, gg_ret, gbt_ret, gw_ret, gb_ret, None, None, None, None, None, None, None
 

@@ -402,8 +402,9 @@ int dis_conv2d_dgrad_f16x2_gnb(const float* g, const float* q, const float* coef
  *   input gradient gx: dis_conv2d_dgrad_f16x2_gnb's forms (accumulate, ab_gn_x / ab_act_y / ab_out) - bit-identical results.
  *   weight gradient: x (n, hin, win, c) = the conv's input; x_gn_stats != NULL: staged as GroupNorm(x) (dis_conv2d_wgrad_bf16x3_gn);
  *     x may be the tensor ab_gn_x or ab_act_y (fetched once).  grad_w (c, c, 3, 3), grad_b (c) or NULL;
- *     workspace: dis_conv2d_wgrad_workspace(c, c, 3, 1) floats.
+ *     workspace: dis_conv2d_bwd_fused_workspace(c) floats (-1: no kernel for this channel count).
  * DIS_ERR_UNSUPPORTED: no instance for the combination / the three-term mode / DIS_BWD_FUSED=0 (the caller keeps the two launches). */
+long dis_conv2d_bwd_fused_workspace(int c);
 int dis_conv2d_bwd_fused_f16x2(const float* g, const float* q, const float* coef, int in_act, float* gpre_out, const float* w_oihw,
                                int w_o, int w_i, int w_row_stride, float* gx, int accumulate, const float* ab_gn_x,
                                const float* ab_act_y, double* ab_out, const float* x, const double* x_gn_stats,

@@ -110,7 +110,7 @@ def test_bwd_fused_matches_the_two_launches(form, n, h, w):
     gpre = torch.full_like(gq, float('nan')) if store else None
     ab = torch.zeros(n * slots * 2 * c, dtype=torch.float64, device='cuda') if sums else None
     gw, gb = torch.full((c, c, 3, 3), float('nan'), device='cuda'), torch.full((c,), float('nan'), device='cuda')
-    ws2 = torch.empty(wsz, dtype=torch.float32, device='cuda')
+    ws2 = torch.empty(L.fn('dis_conv2d_bwd_fused_workspace')(c), dtype=torch.float32, device='cuda')
     ok = L.call_try('dis_conv2d_bwd_fused_f16x2', gq, q if (coef_form or in_act) else None, coef, in_act, gpre, wt, c, c, wt.stride(0), gx,
                     1 if accum else 0, ab_x, act_y, ab, x, xg[0] if xgn else None, xg[1] if xgn else None, xg[2] if xgn else None, 1e-5,
                     gw, gb, ws2, n, h, w, c)
@@ -148,7 +148,7 @@ def test_bwd_fused_is_reproducible_and_handles_extreme_ranges():
     x[4, 30, 2, 11] = -3e3
     gy[0, :16, :16] = 0.0
     wt = (torch.randn(c, c, 3, 3, generator=g_) * 0.05).cuda()
-    wsz = L.fn('dis_conv2d_wgrad_workspace')(c, c, 3, 1)
+    wsz = L.fn('dis_conv2d_bwd_fused_workspace')(c)
     outs = []
     for rep in range(3):
         gx = torch.empty_like(x)
