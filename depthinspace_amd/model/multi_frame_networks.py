@@ -322,4 +322,7 @@ class FuseNet(TimedModule):
 
         amb4 = ops.pack4_nhwc([(amb, HW)], N, H, W)
         disp = self.post_process(feat.view(N, h, w, self.channels), amb4)
+        # every deferred block output (ops.group_norm(defer=True)) has been written by its first consumer by now; checked HERE, in the
+        # forward that created it, because evaluation / inference loops never reach the optimizer's begin_step() check
+        ops.check_forward_complete()
         return disp.view(tl, bs, 1, H, W)

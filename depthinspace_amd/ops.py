@@ -123,6 +123,13 @@ def _gn_lazy_pop(gy, ctx=None):
     return ent
 
 
+def check_forward_complete():
+    """no deferred GroupNorm output (group_norm(defer=True)) is left unwritten: called at the end of FuseNet's forward"""
+    if _GN_PENDING:
+        _GN_PENDING.clear()
+        raise RuntimeError('ops: a deferred GroupNorm output (group_norm(defer=True)) of this forward pass was never realised')
+
+
 def check_backward_complete():
     """every token redeemed, every pre-reduced gradient picked up: called by FlatAdam.step() BEFORE the update (and by tests)"""
     if _GN_LAZY or _GN_TOKEN_FOR:
