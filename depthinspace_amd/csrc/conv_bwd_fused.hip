@@ -15,8 +15,12 @@
 // the 16 x 16 tile: its input-gradient accumulators (4 x 2 tiles) and - for dW - those 64 pixels as TWO k-steps of 32 pixels against
 // all 36 (tap, ci half, co half) tiles: no cross-wave reduction until the workgroup's last tile.  The x values of a wave's pixels live
 // in a wave-private LDS strip (one k-step at a time, [pixel][plane][channel], read back with ds_read_b64_tr_b16): no barrier for them.
-// dW scales: the gy halo carries the input gradient's per-tile scale 2^sg(t); x is split with 2^(S - sg(t)), S a per-wave RUNNING
-// exponent that only shrinks (the accumulators follow by the exact ratio when it does), so that every term of the sum carries 2^S.
+// dW scales: the gy halo carries the input gradient's per-tile scale 2^sg(t); x is split with 2^(S - sg(t)), S a per-wave exponent set by
+// the first tile that has something to add (FB_SMARGIN bits of headroom), so that every term of the sum carries 2^S.  A later tile
+// whose product magnitude exceeds the headroom makes the wave LEAVE the tile loop: the accumulators go to a spill slab in memory
+// (scaled by 2^-S), a new pass starts from zero accumulators with a new S (RESUME copy of D: the tile's products are formed again).
+// Status (round 6): parity-green in all forms, NOT faster than the two launches it replaces on MI355X - the register budget
+// (profiles/r6_bwd_fused.md); the step uses it only with DIS_BWD_FUSED=1.
 // LDS: weights 36.9 KB + two halo buffers 2 x 51.8 KB + x strips 4 x 5 KB + 1.2 KB = 162.2 KB of 160 KiB.
 #include "conv_args.h"
 #include <type_traits>
@@ -89,7 +93,6 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   constexpr int C = K::C, IC = K::IC, PS = K::PS, NT = K::NT, KS = K::KS, NLOAD = K::NLOAD, NPIECE = K::NPIECE, CV = K::CV, NP = K::NP;
   constexpr int MT = K::MT, NW = K::NW, NTHR = K::NTHR;
   constexpr bool IN2 = INACT != 0 || INCOEF;
-  static_assert(!INCOEF || true, "");
   static_assert(EPIACT == 0 || EPIAB, "activation gradient at the output: only with the channel sums");
   static_assert(XSRC == 0 || (XSRC == 1 && EPIAB) || (XSRC == 2 && EPIACT), "shared x operand");
   static_assert(!GST || INCOEF, "gpre store: only where the operand is formed on load");
@@ -252,7 +255,6 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   const int yrow = a.wf * (C * 4);
   const int y_lane = ((wave * MT * a.wf + li) * C + lg * 4) * 4;
   float4 cy[ACCUM ? NPIECE : 1], cab[EPIAB ? NPIECE : 1], cact[EPIACT ? NPIECE : 1], cxw[XSRC == 0 ? NPIECE : 1];
-  const float* wx_base = XSRC == 1 ? a.ab_x : (XSRC == 2 ? a.ab_act_y : fa_.wx);
   auto centre_off = [&](int ty, int tx, unsigned (&off)[MT]) {
     const int vy0 = ty * FB_TR + wave * MT, vx0 = tx * FB_TC + li;
     const int t0 = (ty * FB_TR * a.wf + tx * FB_TC) * (C * 4) + y_lane;
@@ -273,7 +275,6 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       if (XSRC == 0) cxw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(fa_.wx + sb, bytes), o, 0, 0));
     }
   };
-  (void)wx_base;
 
   // ---- weights: OIHW fp32 -> scaled fp16 planes in fragment order (conv_f16x2_kernel's prologue with 4 waves); the workgroup's first
   // tile is staged in between
@@ -764,7 +765,7 @@ hipError_t dis_fb_launch(const FbArgs& f, int inact, bool xgn, int xsrc, long gr
     return hipSuccess;
   };
   constexpr int S = DIS_ACT_SELU;
-#ifdef FB_ONLY
+#ifdef FB_ONLY   // (diagnostic builds: one instance, e.g. -DFB_ONLY=0,false,false,false,0,0,false,false - resource reports, ISA studies)
   return launch(conv_bwd_fused_kernel<FB_ONLY>, 0);
 #endif
   if (inact != 0 && inact != S) return hipErrorInvalidValue;
