@@ -72,20 +72,21 @@ extern "C" int dis_debug_fb_stamps(unsigned long long* host) { return (int)hipMe
 struct FbCfg {
   static constexpr int C = 32, IR = FB_TR + 2, IC = FB_TC + 2, CV = C / 4, NP = 2, PS = 80, NT = 2, KS = 9;
   static constexpr int NW = 4, NTHR = 64 * NW, MT = FB_TR / NW;
-  static constexpr int W_U16 = KS * NP * 4 * C * 8, X_U16 = IR * IC * PS, XW_U16 = 32 * PS;
+  static constexpr int W_U16 = KS * NP * 4 * C * 8, X_U16 = IR * IC * PS, XT_U16 = FB_TR * FB_TC * PS;
   static constexpr int NITEMS = IR * IC * CV, NLOAD = (NITEMS + NTHR - 1) / NTHR, NPIECE = MT * NT;
-  static constexpr int SMALL_U16 = 32 + 32 + NW * 2 * C * 2 + C + 8;   // red (8 doubles), mxs, abw [wave][2 C] floats, write pad (both planes of an idle item)
-  static constexpr int LDS_BYTES = (W_U16 + 2 * X_U16 + NW * XW_U16 + SMALL_U16) * 2;
-  static constexpr int NACC = 9 * 2 * 2;   // dW accumulator tiles per wave: (tap, ci half, co half)
+  static constexpr int SMALL_U16 = 32 + 64 + NW * 2 * C * 2 + C + 8;   // red (8 doubles), maxima [parity][gy | x][wave], abw [wave][2 C] floats, write pad
+  static constexpr int LDS_BYTES = (W_U16 + X_U16 + XT_U16 + SMALL_U16) * 2;
+  static constexpr int NACC = 9;   // dW accumulator tiles per wave: the 9 taps of its (ci half, co half)
 };
 static_assert(FbCfg::LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert((FbCfg::NW - 1) * FbCfg::NACC * 64 * 16 <= (FbCfg::W_U16 + 2 * FbCfg::X_U16) * 2, "end-of-kernel reduction aliases weights + halos");
+static_assert(32 * (32 * 9 + 1) * 4 <= FbCfg::XT_U16 * 2, "the weight prologue's fp32 scratch aliases the x tile");
 
 // INACT / INCOEF / ACCUM / EPIAB / EPIACT: conv_f16x2_kernel's forms of the input gradient (see there).
 // XSRC: where the weight gradient's x comes from - 0: a.wx, 1: c.ab_x (the GroupNorm input the channel sums are formed with IS the
 // conv's input: conv2d_gn_in), 2: c.ab_act_y (the activation output the result is multiplied with IS the conv's input: ResNetBlock
-// chains).  XGN: x is staged as GroupNorm(x).  GST: the staged values of the pixels a tile owns are stored to c.gnb_out as well (the
-// other launches of a multi-source node read them).
+// chains); x always has its own registers (fetched one tile ahead), the epilogue's operands are fetched in their own tile.
+// XGN: x is staged as GroupNorm(x).  GST: the staged values of the pixels a tile owns are stored to c.gnb_out as well (the other
+// launches of a multi-source node read them).
 template <int INACT, bool INCOEF, bool ACCUM, bool EPIAB, int EPIACT, int XSRC, bool XGN, bool GST>
 __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   using K = FbCfg;
@@ -101,17 +102,18 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
-  unsigned short* wl = smem16;
-  unsigned short* xl = smem16 + K::W_U16;
-  unsigned short* xw = smem16 + K::W_U16 + 2 * K::X_U16 + (threadIdx.x >> 6) * K::XW_U16;   // this wave's x strip
-  unsigned short* small = smem16 + K::W_U16 + 2 * K::X_U16 + NW * K::XW_U16;
+  unsigned short* wl = smem16;                              // weights, fragment order, two planes
+  unsigned short* xh = smem16 + K::W_U16;                   // the gy halo of the current tile [18 x 18 pixels][plane][channel]
+  unsigned short* xt = smem16 + K::W_U16 + K::X_U16;        // the x tile of the current tile  [16 x 16 pixels][plane][channel]
+  unsigned short* small = smem16 + K::W_U16 + K::X_U16 + K::XT_U16;
   double* red = (double*)small;
-  float* mxs = (float*)(small + 32);      // [parity][wave] (2 x 4 floats)
-  float* abw = (float*)(small + 64);      // EPIAB: [wave][2 C]
-  unsigned short* pad16 = small + 64 + NW * 2 * C * 2 + C;   // (idle threads of the last round write pad16 - C and pad16)
+  float* mxs = (float*)(small + 32);      // [parity][gy | x][wave]
+  float* abw = (float*)(small + 96);      // EPIAB: [wave][2 C]
+  unsigned short* pad16 = small + 96 + NW * 2 * C * 2 + C;   // (idle threads of the last round write pad16 - C and pad16)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4, tq = li >> 2, tp = li & 3;
+  const int ah = wave >> 1, bh = wave & 1;   // dW: this wave's (ci half, co half)
   const int tiles_x = (a.wv + FB_TC - 1) / FB_TC, tiles_y = (a.hv + FB_TR - 1) / FB_TR;
   const int ntiles = a.n * tiles_y * tiles_x;
   const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
@@ -121,15 +123,13 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
 
   // ---- halo items of this thread (conv_f16x2_kernel's, 256 threads): item it = float4 vv of halo pixel pix = p0 + 32 it, p0 = thread / 8.
   // Nothing per item is kept in registers: row / column follow from p0 and compile-time constants (32 it = 18 A + B), the LDS address
-  // is a constant offset from one base - 33 loop-invariant registers per thread less than tables of offsets (which the compiler
-  // spilled to scratch, whose reloads then made every halo load of the loop synchronous: s_waitcnt vmcnt(0) all over the tap loop).
+  // is a constant offset from one base.
   float4 pre[NLOAD], pre2[IN2 ? NLOAD : 1];
   const int p0 = (int)threadIdx.x >> 3;
   const int vv4 = ((int)threadIdx.x & 7) * 16;   // byte offset of this thread's 4 channels within a pixel (the same for all its items)
-  int p0v = p0;                                  // (re-blinded every iteration: keeps the per-item arithmetic out of loop-invariant registers)
   auto item_rc = [&](int it, int& r, int& c) __attribute__((always_inline)) {
     const int A = (32 * it) / IC, B = (32 * it) % IC;
-    const int sft = p0v + B;
+    const int sft = p0 + B;
     const int k = sft >= 2 * IC ? 2 : (sft >= IC ? 1 : 0);
     r = A + k;
     c = sft - IC * k;
@@ -168,11 +168,11 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   float cf_kx = 0.f, cf_k0 = 0.f;
   int cf_n = -1;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient: this thread's 4 channels over the pixels its tiles own
-  // (1) before the barrier: final fp32 values of the next tile's items, this wave's largest magnitude into LDS
-  auto prep = [&](const Pf& f, int n_cur, int parity) {
+  // final fp32 values of the current tile's halo items (in place) and this wave's largest magnitude
+  auto prep = [&](const Pf& f, int n_cur) -> float {
     if (INCOEF && n_cur != cf_n) {
       cf_n = n_cur;
-      const float* cf = a.gnb_coef + (long)(n_cur < a.n ? n_cur : a.n - 1) * (C + 2);
+      const float* cf = a.gnb_coef + (long)n_cur * (C + 2);
       cf_k1 = *(const float4*)(cf + ((int)threadIdx.x % CV) * 4);
       cf_kx = cf[C];
       cf_k0 = cf[C + 1];
@@ -214,21 +214,16 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.x)), fabsf(v.y));
       m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.z)), fabsf(v.w));
     }
-    m = f2_wave_max(m);
-    if (lane == 0) mxs[parity * NW + wave] = m;
-  };
-  auto tile_max = [&](int parity) -> float {
-    const float4 m0 = *(const float4*)(mxs + parity * NW);
-    return fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w));
+    return f2_wave_max(m);
   };
   const int lds_item = p0 * PS + ((int)threadIdx.x & 7) * 4;
-  auto stage_item = [&](int it, float sc, unsigned short* xb) {
+  auto stage_item = [&](int it, float sc) {
     const float4 v = pre[it];
     unsigned a1, a2, b1, b2;
     f2_split_pair_scaled(v.x, v.y, sc, a1, a2);
     f2_split_pair_scaled(v.z, v.w, sc, b1, b2);
     const int idx = (int)threadIdx.x + it * NTHR;
-    unsigned short* p = xb + lds_item + it * (32 * PS);   // pixel p0 + 32 it, channels 4 vv ..: one base, constant offsets
+    unsigned short* p = xh + lds_item + it * (32 * PS);   // pixel p0 + 32 it, channels 4 vv ..: one base, constant offsets
     if ((it + 1) * NTHR > K::NITEMS) p = idx < K::NITEMS ? p : pad16 - C;
     *(uint2*)(p) = make_uint2(a1, b1);
     *(uint2*)(p + C) = make_uint2(a2, b2);
@@ -236,52 +231,59 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
 
   int tile = t_lo + rank;
   int cn = 0, cty = 0, ctx = 0;
-  Pf pf0 = pf_make(0, 0, 0, false);
-  if (tile < t_hi) {
-    ctx = tile % tiles_x, cty = (tile / tiles_x) % tiles_y, cn = tile / (tiles_x * tiles_y);
-    pf0 = pf_make(cn, cty, ctx, true);
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) pf_issue(pf0, it);
-  }
   auto advance = [&](int& n_, int& ty_, int& tx_) {
     tx_ += d_tx, ty_ += d_ty, n_ += d_n;
     if (tx_ >= tiles_x) tx_ -= tiles_x, ++ty_;
     if (ty_ >= tiles_y) ty_ -= tiles_y, ++n_;
   };
-  int n1 = cn, ty1 = cty, tx1 = ctx;   // the tile after the current one
 
-  // ---- the centre operands of a tile: this lane's 8 pieces (row MT wave + mt, column li, channels 16 nt + 4 lg ..) of gx-so-far
-  // (ACCUM), the GroupNorm input of the channel sums (EPIAB), the activation output (EPIACT) and x - fetched one tile ahead
+  // ---- centre operands: this lane's 8 pieces (row MT wave + mt, column li, channels 16 nt + 4 lg ..) of x (fetched one tile ahead: its
+  // values are staged at the top of the tile) and of the epilogue's operands - gx so far (ACCUM), the GroupNorm input of the channel
+  // sums (EPIAB), the activation output (EPIACT) - fetched at the top of their own tile, used after the input-gradient products
   const int yrow = a.wf * (C * 4);
   const int y_lane = ((wave * MT * a.wf + li) * C + lg * 4) * 4;
-  float4 cy[ACCUM ? NPIECE : 1], cab[EPIAB ? NPIECE : 1], cact[EPIACT ? NPIECE : 1], cxw[XSRC == 0 ? NPIECE : 1];
+  float4 cxw[NPIECE], cy[ACCUM ? NPIECE : 1], cab[EPIAB ? NPIECE : 1], cact[EPIACT ? NPIECE : 1];
+  const float* wx_base = XSRC == 1 ? a.ab_x : (XSRC == 2 ? a.ab_act_y : fa_.wx);
   auto centre_off = [&](int ty, int tx, unsigned (&off)[MT]) {
     const int vy0 = ty * FB_TR + wave * MT, vx0 = tx * FB_TC + li;
     const int t0 = (ty * FB_TR * a.wf + tx * FB_TC) * (C * 4) + y_lane;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) off[mt] = (vx0 < a.wv && vy0 + mt < a.hv) ? (unsigned)(t0 + mt * yrow) : BX_OOB;
   };
-  auto centre_issue = [&](int n, int ty, int tx, bool live) {
+  auto x_issue = [&](int n, int ty, int tx, bool live) {
     unsigned off[MT];
     centre_off(ty, tx, off);
     const long sb = (long)n * a.hf * a.wf * C;
     const unsigned bytes = live ? y_bytes : 0u;
 #pragma unroll
+    for (int i = 0; i < NPIECE; ++i)
+      cxw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(wx_base + sb, bytes), off[i / NT] + (i % NT) * 64, 0, 0));
+  };
+  auto epi_issue = [&](int n, const unsigned (&off)[MT]) {
+    const long sb = (long)n * a.hf * a.wf * C;
+#pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
       const unsigned o = off[i / NT] + (i % NT) * 64;
-      if (ACCUM) cy[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.y + sb, bytes), o, 0, 0));
-      if (EPIAB) cab[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.ab_x + sb, bytes), o, 0, 0));
-      if (EPIACT) cact[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.ab_act_y + sb, bytes), o, 0, 0));
-      if (XSRC == 0) cxw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(fa_.wx + sb, bytes), o, 0, 0));
+      if (ACCUM) cy[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.y + sb, y_bytes), o, 0, 0));
+      if (EPIAB) cab[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.ab_x + sb, y_bytes), o, 0, 0));
+      if (EPIACT) cact[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.ab_act_y + sb, y_bytes), o, 0, 0));
     }
   };
 
-  // ---- weights: OIHW fp32 -> scaled fp16 planes in fragment order (conv_f16x2_kernel's prologue with 4 waves); the workgroup's first
-  // tile is staged in between
-  int sw_e = 0, parity = 0, buf = 0, sx_e = 0;
-  float gmax = 0.f;   // largest magnitude of the current tile's halo (0: nothing to add to dW)
+  Pf pfc = pf_make(0, 0, 0, false);   // the current tile's halo (its items are in `pre` when an iteration starts)
+  if (tile < t_hi) {
+    ctx = tile % tiles_x, cty = (tile / tiles_x) % tiles_y, cn = tile / (tiles_x * tiles_y);
+    pfc = pf_make(cn, cty, ctx, true);
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) pf_issue(pfc, it);
+    x_issue(cn, cty, ctx, true);
+  }
+
+  // ---- weights: OIHW fp32 -> scaled fp16 planes in fragment order (conv_f16x2_kernel's prologue with 4 waves; the fp32 copy sits in
+  // the x tile, which is first written after the first barrier of the tile loop)
+  int sw_e = 0;
   {
-    float* ws = (float*)(xl + K::X_U16);
+    float* ws = (float*)xt;
     float* wmx = (float*)(red + 4);
     const int row = a.w_i * 9;
     const unsigned wbytes = (unsigned)((a.w_o - 1) * a.w_rs + row) * 4u;
@@ -308,25 +310,10 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     m = f2_wave_max(m);
     if (lane == 0) wmx[wave] = m;
     if (threadIdx.x == 0) *(unsigned*)(red + 3) = 0u;   // (ab_flush's arrival counter)
-    if (tile < t_hi) prep(pf0, cn, parity);
     __syncthreads();
     const float4 m0 = *(const float4*)(wmx);
     sw_e = f2_scale_exp(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)));
     const float sw = __builtin_ldexpf(1.f, sw_e);
-    if (tile < t_hi) {
-      gmax = tile_max(parity);
-      sx_e = f2_scale_exp(gmax);
-      const float sc = __builtin_ldexpf(1.f, sx_e);
-#pragma unroll
-      for (int it = 0; it < NLOAD; ++it) stage_item(it, sc, xl);
-      // (the order of a steady-state iteration - the next tile's halo loads, THEN the current tile's centre loads: the compiler's
-      //  wait counts at the loop head are merged over both ways in, and with the other order they waited for everything in flight)
-      advance(n1, ty1, tx1);
-      pf0 = pf_make(n1, ty1, tx1, tile + per < t_hi);
-#pragma unroll
-      for (int it = 0; it < NLOAD; ++it) pf_issue(pf0, it);
-    }
-    parity ^= 1;
     for (int u = threadIdx.x; u < KS * 4 * C; u += NTHR) {
       const int co = u % C, g = (u / C) & 3, ks = u / (4 * C);
       unsigned pl[2][4];
@@ -340,12 +327,13 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       for (int p = 0; p < NP; ++p)
         *(uint4*)(wl + (((ks * NP + p) * 4 + g) * C + co) * 8) = make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]);
     }
+    // (no barrier here: barrier A of the first tile separates the last read of `ws` from the first write of the x tile, barrier B
+    //  publishes the weight planes)
   }
 
-  f32x4 accw[K::NACC];   // dW: tile (tap, ci half a, co half b) at index (tap * 2 + a) * 2 + b, this wave's pixels
+  f32x4 accw[K::NACC];   // dW: this wave's (ci half, co half), tap j
 #pragma unroll
   for (int j = 0; j < K::NACC; ++j) accw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int S_w = 120;   // running exponent of the dW terms (the clamp's upper end: the first real tile lowers it)
   float sA[NT][4], sB[NT][4];
   int ab_n = -1;
 #pragma unroll
@@ -397,9 +385,15 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   constexpr int PA[3] = {1, 0, 0};
   constexpr int PB[3] = {0, 1, 0};
 
-  auto xraw = [&](int i) -> float4 { return XSRC == 1 ? cab[EPIAB ? i : 0] : (XSRC == 2 ? cact[EPIACT ? i : 0] : cxw[XSRC == 0 ? i : 0]); };
-  auto xval = [&](int i, const unsigned (&cur_off)[MT]) -> float4 {   // the value the products see: GroupNorm applied (XGN), pixels past the map zero
-    float4 v = xraw(i);
+  // ---- one tile: TOP (final values + maxima | barrier A | exponents | halo and x tile split and staged, next tile requested |
+  // barrier B), D (the input gradient's 216 products per wave), W (its epilogue + this wave's 216 dW products over the WHOLE tile).
+  // The dW exponent S is workgroup-uniform; when it has to move (rare) every wave leaves the loop in front of the staging, adds its
+  // accumulators to the slab, and the pass restarts from zero with this tile setting S.
+  unsigned cur_off[MT];
+  float gmax = 0.f, xmax = 0.f;
+  int sx_e = 0, ex_e = 0, S_w = 120, parity = 0;
+  auto xval = [&](int i) -> float4 {   // the x value the products see: GroupNorm applied (XGN), pixels past the map zero
+    float4 v = cxw[i];
     if (XGN) {
       const int nt = i % NT;
       const bool ok = cur_off[i / NT] != BX_OOB;
@@ -409,61 +403,83 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     }
     return v;
   };
-  // ---- a tile goes through two phases: D (the input gradient's products; the NEXT tile's halo is split and staged on the way) and W
-  // (the input gradient's epilogue and the dW products of the same tile, against the halo D has just read).  The loop runs W(t), D(t + 1):
-  // the dW accumulators are carried around a loop in which only matrix instructions touch them, so they stay in accumulation registers.
-  // When the dW exponent has to move (a tile whose product magnitude exceeds every earlier one's by more than the headroom - rare), the
-  // inner loop is LEFT, the accumulators go to this wave's spill slab in memory, and a new pass starts from zero accumulators.  (With the
-  // rescale as a branch inside the loop the compiler kept all 144 accumulators in vector registers across it: ~290 register copies per
-  // tile and spills to scratch, whose reloads made every halo load synchronous.)
+  auto top_a = [&]() __attribute__((always_inline)) {   // up to barrier A and the exponents (not repeated when a pass restarts at this tile)
+    FB_T(0)
+    centre_off(cty, ctx, cur_off);
+    if (EPIAB && cn != ab_n) {   // (two flushes are always separated by a tile's barriers)
+      if (ab_n >= 0) ab_flush();
+      ab_n = cn;
+    }
+    if (XGN && cn != xg_n) {
+      xg_n = cn;
+      float mean, rstd;
+      gn_moments(fa_.wx_gn_stats, cn, (double)a.hf * a.wf * C, fa_.wx_gn_eps, &mean, &rstd);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float4 g_ = *(const float4*)(fa_.wx_gn_gamma + nt * 16 + lg * 4), b_ = *(const float4*)(fa_.wx_gn_beta + nt * 16 + lg * 4);
+        xg_sc[nt] = make_float4(rstd * g_.x, rstd * g_.y, rstd * g_.z, rstd * g_.w);
+        xg_sh[nt] = make_float4(b_.x - xg_sc[nt].x * mean, b_.y - xg_sc[nt].y * mean, b_.z - xg_sc[nt].z * mean, b_.w - xg_sc[nt].w * mean);
+      }
+    }
+    const float mg = prep(pfc, cn);
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const float4 v = xval(i);
+      mx = __builtin_fmaxf(__builtin_fmaxf(mx, fabsf(v.x)), fabsf(v.y));
+      mx = __builtin_fmaxf(__builtin_fmaxf(mx, fabsf(v.z)), fabsf(v.w));
+    }
+    mx = f2_wave_max(mx);
+    if (lane == 0) {
+      mxs[parity * 2 * NW + wave] = mg;
+      mxs[parity * 2 * NW + NW + wave] = mx;
+    }
+    FB_T(1)
+    // barrier A: every wave has finished the previous tile (halo and x tile may be overwritten), the maxima are visible
+    __syncthreads();
+    FB_T(2)
+    const float4 m0 = *(const float4*)(mxs + parity * 2 * NW), m1 = *(const float4*)(mxs + parity * 2 * NW + NW);
+    parity ^= 1;
+    gmax = fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w));
+    xmax = fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w));
+    sx_e = f2_scale_exp(gmax);
+    ex_e = f2_scale_exp(xmax);
+  };
   f32x4 acc[MT][NT];
-  unsigned cur_off[MT];
-  const unsigned short* xc = xl;
-  int sx_n = 0, n2 = 0, ty2 = 0, tx2 = 0, ex_w = 0;
-  float gmax_n = 0.f, xm = 0.f;
-  Pf pfn = pf0;
-  // RESUME (rare): the tile's D has run already, the wave left the loop in front of W to park its dW accumulators; only the products
-  // are formed again (the halo buffer is untouched until the next D stages into the other one) - no barrier, no staging, no loads.
-  auto dphase = [&](auto rsm) __attribute__((always_inline)) {
-    constexpr bool RESUME = decltype(rsm)::value;
-    float sc_n = 0.f;
-    unsigned short* xn = xl;
-    if constexpr (!RESUME) {
-#if FB_BLIND
-      asm volatile("" : "+v"(p0v));
-#endif
-      centre_off(cty, ctx, cur_off);
-      // the NEXT tile's items (in flight since the previous D): final values, maxima
-      FB_T(0)
-      prep(pf0, n1, parity);
-      // this tile's centre operands (x strip, gx so far, GroupNorm input, activation output): requested here, used from the end of D on -
-      // a whole D phase to land.  (Requested in the previous W they were the youngest loads in flight at the loop head, where the
-      // compiler's merged wait counts wait for everything: ~2.2 k cycles per tile, scripts/diag/fb_stamps.py.)
-      centre_issue(cn, cty, ctx, true);
-      FB_T(1)
-      // ONE barrier per tile: every wave has finished reading the other halo buffer (previous tile: both products), this tile's buffer
-      // is completely written, the maxima of the next tile are visible
-      __syncthreads();
-      FB_T(2)
-      gmax_n = tile_max(parity);
-      sx_n = f2_scale_exp(gmax_n);
-      sc_n = __builtin_ldexpf(1.f, sx_n);
-      parity ^= 1;
-      xc = xl + buf * K::X_U16;
-      xn = xl + (buf ^ 1) * K::X_U16;
-      n2 = n1, ty2 = ty1, tx2 = tx1;
-      advance(n2, ty2, tx2);
-      pfn = pf_make(n2, ty2, tx2, tile + 2 * per < t_hi);
+  auto rest = [&]() __attribute__((always_inline)) {
+    // ---- staging: the halo with its own per-tile scale, x with 2^(S - sx_e) (a term of dW carries 2^S; where the halo or the x tile
+    // is all zero the exponent does not matter)
+    {
+      const float sc = __builtin_ldexpf(1.f, sx_e);
+#pragma unroll
+      for (int it = 0; it < NLOAD; ++it) stage_item(it, sc);
+      const int es = S_w - sx_e < ex_e ? S_w - sx_e : ex_e;
+      const float scx = __builtin_ldexpf(1.f, es);
+#pragma unroll
+      for (int i = 0; i < NPIECE; ++i) {
+        const float4 v = xval(i);
+        unsigned a1, a2, b1, b2;
+        f2_split_pair_scaled(v.x, v.y, scx, a1, a2);
+        f2_split_pair_scaled(v.z, v.w, scx, b1, b2);
+        unsigned short* p = xt + ((wave * MT + i / NT) * FB_TC + li) * PS + (i % NT) * 16 + lg * 4;
+        *(uint2*)(p) = make_uint2(a1, b1);
+        *(uint2*)(p + C) = make_uint2(a2, b2);
+      }
     }
+    // the next tile's halo and x strip are requested now (a whole tile to land), this tile's epilogue operands too
+    int n1 = cn, ty1 = cty, tx1 = ctx;
+    advance(n1, ty1, tx1);
+    const Pf pfn = pf_make(n1, ty1, tx1, tile + per < t_hi);
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) pf_issue(pfn, it);
+    x_issue(n1, ty1, tx1, tile + per < t_hi);
+    epi_issue(cn, cur_off);
+    FB_T(3)
+    // barrier B: halo, x tile (and, first tile, the weight planes) are complete
+    __syncthreads();
+    FB_T(4)
 
-    // ---------------- input gradient: 9 taps x (4 rows x 2 channel blocks) x 3 products; the next tile's items are split and written
-    // to the other halo buffer on the way, each followed by the load that refills its registers with the tile after next
-    if (!FB_ZLIT) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    // ---------------- input gradient: 9 taps x (4 rows x 2 channel blocks) x 3 products
     {
       // row fragments: ONE set R[halo row 0 .. MT + 1][plane] for the current kx.  Step (kx, ky) multiplies rows ky .. ky + MT - 1:
       // during (kx, 2) rows 0, 1 are dead and take kx + 1's; step (kx + 1, 0) fetches rows 2 .. MT + 1 first and multiplies rows 0, 1
@@ -475,7 +491,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         for (int j = 0; j < MT + 2; ++j)
           if (j >= j0 && j < j1) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) R[j][p] = *(const s16x8*)(xc + xa_lane + (j * IC + kx) * PS + p * C);
+            for (int p = 0; p < NP; ++p) R[j][p] = *(const s16x8*)(xh + xa_lane + (j * IC + kx) * PS + p * C);
           }
       };
       auto load_w = [&](int ks, s16x8 (&B)[NP][NT]) __attribute__((always_inline)) {
@@ -493,16 +509,6 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         if (ks + 1 < KS) load_w(ks + 1, fw[b ^ 1]);
         if (ky == 0 && kx > 0) load_rows(kx, 2, MT + 2);
         if (ky == 2 && kx < 2) load_rows(kx + 1, 0, 2);   // (this step reads rows 2 .. MT + 1: rows 0, 1 are dead)
-        // the next tile's items that ride in this k-step: split, LDS write, refill with the tile after next
-        if constexpr (!RESUME) {
-#pragma unroll
-          for (int it = 0; it < NLOAD; ++it)
-            if (it * KS / NLOAD == ks) {
-              stage_item(it, sc_n, xn);
-              __builtin_amdgcn_sched_barrier(0);   // (the load below reuses the registers the item has just left: not before their last read)
-              pf_issue(pfn, it);
-            }
-        }
         auto mm = [&](int mt0, int mt1) __attribute__((always_inline)) {
 #pragma unroll
           for (int q = 0; q < 3; ++q)
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
                 for (int nt = 0; nt < NT; ++nt)
                   acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                       __builtin_bit_cast(f16x8_t, fw[b][PB[q]][nt]), __builtin_bit_cast(f16x8_t, R[ky + mt][PA[q]]),
-                      (FB_ZLIT && ks == 0 && q == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mt][nt], 0, 0, 0);   // (the first product starts from a zero literal)
+                      (ks == 0 && q == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mt][nt], 0, 0, 0);   // (the first product starts from a zero literal)
               }
         };
         if (ky == 0 && kx > 0) {
@@ -526,41 +532,10 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         __builtin_amdgcn_sched_barrier(0);
       });
     }
+    FB_T(5)
 
-
-    FB_T(3)
-    // this wave's x strip of the tile (requested during the previous W): largest magnitude -> its exponent
-    if constexpr (!RESUME) {
-      if (XGN && cn != xg_n) {
-        xg_n = cn;
-        float mean, rstd;
-        gn_moments(fa_.wx_gn_stats, cn, (double)a.hf * a.wf * C, fa_.wx_gn_eps, &mean, &rstd);
-  #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const float4 g_ = *(const float4*)(fa_.wx_gn_gamma + nt * 16 + lg * 4), b_ = *(const float4*)(fa_.wx_gn_beta + nt * 16 + lg * 4);
-          xg_sc[nt] = make_float4(rstd * g_.x, rstd * g_.y, rstd * g_.z, rstd * g_.w);
-          xg_sh[nt] = make_float4(b_.x - xg_sc[nt].x * mean, b_.y - xg_sc[nt].y * mean, b_.z - xg_sc[nt].z * mean, b_.w - xg_sc[nt].w * mean);
-        }
-      }
-      xm = 0.f;
-  #pragma unroll
-      for (int i = 0; i < NPIECE; ++i) {
-        const float4 v = xval(i, cur_off);
-        xm = __builtin_fmaxf(__builtin_fmaxf(xm, fabsf(v.x)), fabsf(v.y));
-        xm = __builtin_fmaxf(__builtin_fmaxf(xm, fabsf(v.z)), fabsf(v.w));
-      }
-      xm = f2_wave_max(xm);
-      ex_w = f2_scale_exp(xm);
-    }
-  };
-  auto wphase = [&]() __attribute__((always_inline)) {
-    FB_T(4)
-    const float* cur_y = a.y + (long)cn * a.hf * a.wf * C;
-    if (EPIAB && cn != ab_n) {   // (two flushes are always separated by D's barrier)
-      if (ab_n >= 0) ab_flush();
-      ab_n = cn;
-    }
     // ---------------- epilogue of the input gradient (conv_f16x2_kernel's arithmetic, undeferred): piece i rides under the dW products
+    const float* cur_y = a.y + (long)cn * a.hf * a.wf * C;
     const float desc = __builtin_ldexpf(1.f, -(sx_e + sw_e));
     auto epi_piece = [&](int i) __attribute__((always_inline)) {
       const int mt = i / NT, nt = i % NT;
@@ -590,146 +565,98 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       }
     };
 
-
-    // ---------------- weight gradient: this wave's 64 pixels (two k-steps of 32) against the halo in LDS
+    // ---------------- weight gradient: this wave's 9 accumulator tiles (tap j; ci half ah, co half bh) over ALL 256 pixels of the
+    // tile: 8 k-steps of 32 pixels (tile rows 2 ks, 2 ks + 1), per k-step two x^T fragments (planes) against the gy fragments of the
+    // 9 tap shifts - centre pixel (r', c') meets the halo pixel (r' + 2 - ky, c' + 2 - kx)
     {
-      // (a term carries 2^(es + sx_e); where that is not 2^S_w - the halo or the strip is all zero - the term is zero anyway)
-      const int es = S_w - sx_e < ex_w ? S_w - sx_e : ex_w;
-      const float scx = __builtin_ldexpf(1.f, es);
-      __builtin_amdgcn_sched_barrier(0);
-      fb_static_for<0, 2>([&](auto hc) __attribute__((always_inline)) {
-        constexpr int h = decltype(hc)::value;
+      s16x8 fx[2][NP];        // [k-step parity][plane]
+      s16x8 fg[2][3][NP];     // [tap-row parity][kx][plane]: the three taps of a tap row, fetched one tap row ahead
+      auto load_x = [&](int ks, s16x8 (&F)[NP]) __attribute__((always_inline)) {
+        const unsigned short* xq = xt + (2 * ks * FB_TC + 4 * lg + tq) * PS + ah * 16 + tp * 4;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int p = 0; p < NP; ++p) F[p] = fb_tr_read8(xq + p * C, xq + FB_TC * PS + p * C);
+      };
+      auto load_g = [&](int ks, int ky, s16x8 (&G)[3][NP]) __attribute__((always_inline)) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const float4 v = xval((2 * h + mi) * NT + nt, cur_off);
-            unsigned a1, a2, b1, b2;
-            f2_split_pair_scaled(v.x, v.y, scx, a1, a2);
-            f2_split_pair_scaled(v.z, v.w, scx, b1, b2);
-            unsigned short* p = xw + (mi * 16 + li) * PS + nt * 16 + lg * 4;
-            *(uint2*)(p) = make_uint2(a1, b1);
-            *(uint2*)(p + C) = make_uint2(a2, b2);
-          }
-        s16x8 fx[2][NP];   // x^T: [ci half][plane], k = this k-step's 32 pixels
-        const unsigned short* xq = xw + (4 * lg + tq) * PS + tp * 4;
+        for (int kx = 0; kx < 3; ++kx) {
+          const unsigned short* gq = xh + ((2 * ks + 2 - ky) * IC + (4 * lg + tq) + 2 - kx) * PS + bh * 16 + tp * 4;
 #pragma unroll
-        for (int ah = 0; ah < 2; ++ah)
+          for (int p = 0; p < NP; ++p) G[kx][p] = fb_tr_read8(gq + p * C, gq + IC * PS + p * C);
+        }
+      };
+      load_x(0, fx[0]);
+      load_g(0, 0, fg[0]);
+      fb_static_for<0, 24>([&](auto uc) __attribute__((always_inline)) {   // unit u = (k-step, tap row): 9 products
+        constexpr int u = decltype(uc)::value;
+        constexpr int ks = u / 3, ky = u % 3;
+        if (u + 1 < 24) load_g((u + 1) / 3, (u + 1) % 3, fg[(u + 1) & 1]);
+        if (ky == 0 && ks + 1 < 8) load_x(ks + 1, fx[(ks + 1) & 1]);
+        if (ky == 1 && ks < NPIECE) epi_piece(ks);   // (one piece of the input gradient's epilogue per k-step)
 #pragma unroll
-          for (int p = 0; p < NP; ++p) fx[ah][p] = fb_tr_read8(xq + ah * 16 + p * C, xq + 16 * PS + ah * 16 + p * C);
-        // units u = (tap, co half): two gy fragments (one per plane) against the four x fragments, 6 products; the next unit's
-        // fragments are fetched under this unit's products
-        s16x8 fg[3][NP];   // (three sets, fetched two units ahead: one unit = 6 products = ~100 cycles, less than an LDS round trip)
-        auto load_g = [&](int u, s16x8 (&G)[NP]) __attribute__((always_inline)) {
-          const int tap = u >> 1, bh = u & 1, ky = tap / 3, kx = tap % 3;
-          // centre pixel (r', c') of this k-step meets the halo pixel (r' + 2 - ky, c' + 2 - kx)
-          const unsigned short* gq = xc + ((MT * wave + 2 * h + 2 - ky) * IC + (4 * lg + tq) + 2 - kx) * PS + tp * 4 + bh * 16;
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-          for (int p = 0; p < NP; ++p) G[p] = fb_tr_read8(gq + p * C, gq + IC * PS + p * C);
-        };
-        load_g(0, fg[0]);
-        load_g(1, fg[1]);
-        fb_static_for<0, 18>([&](auto uc) __attribute__((always_inline)) {
-          constexpr int u = decltype(uc)::value;
-          if (u + 2 < 18) load_g(u + 2, fg[(u + 2) % 3]);
-          // what rides under the products: the input gradient's epilogue in the first k-step, the next tile's centre loads in the second
-          if (h == 0 && u % 2 == 0 && u / 2 < NPIECE) epi_piece(u / 2);
-#pragma unroll
-          for (int ah = 0; ah < 2; ++ah)
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-              accw[(u >> 1) * 4 + ah * 2 + (u & 1)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                  __builtin_bit_cast(f16x8_t, fx[ah][PA[q]]), __builtin_bit_cast(f16x8_t, fg[u % 3][PB[q]]),
-                  accw[(u >> 1) * 4 + ah * 2 + (u & 1)], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        });
+          for (int q = 0; q < 3; ++q)
+            accw[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fx[ks & 1][PA[q]]),
+                                                                       __builtin_bit_cast(f16x8_t, fg[u & 1][kx][PB[q]]), accw[ky * 3 + kx], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       });
     }
-    FB_T(5)
+    FB_T(6)
     // the next tile becomes the current one
     cn = n1, cty = ty1, ctx = tx1;
-    n1 = n2, ty1 = ty2, tx1 = tx2;
     tile += per;
-    sx_e = sx_n;
-    gmax = gmax_n;
-    buf ^= 1;
-    pf0 = pfn;
+    pfc = pfn;
   };
+
   int flushed = 0;
   bool resume = false;
+  float* out = fa_.part + (long)blockIdx.x * (9 * C * C);
+  auto slab_write = [&](bool add) {   // this wave's 9 tiles leave for the workgroup's slab (other waves own the other elements)
+    const float dsc = __builtin_ldexpf(1.f, -S_w);
+#pragma unroll
+    for (int j = 0; j < K::NACC; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* p = out + ((j * 2 + ah) * 16 + lg * 4 + r) * C + bh * 16 + li;
+        const float v = accw[j][r] * dsc;
+        *p = add ? *p + v : v;
+      }
+  };
   for (;;) {   // one pass per dW exponent: almost always exactly one
 #pragma unroll
     for (int j = 0; j < K::NACC; ++j) accw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     S_w = 120;
     bool s_set = false, need = false;
     while (tile < t_hi) {
-      if (resume) dphase(std::true_type{});
-      else dphase(std::false_type{});
+      if (!resume) top_a();
       resume = false;
-      const bool adds = xm > 0.f && gmax > 0.f;   // (wave-uniform) this tile has something to add to dW
-      if (s_set && adds && ex_w + sx_e < S_w) {   // (rare) a larger product magnitude than the exponent allows: the accumulators leave first
+      const bool adds = xmax > 0.f && gmax > 0.f;   // (workgroup-uniform) this tile has something to add to dW
+      if (s_set && adds && ex_e + sx_e < S_w) {     // (rare) a larger product magnitude than the exponent allows: the accumulators leave first
         need = true;
         break;
       }
       if (!s_set && adds) {   // the first tile with something to add sets the exponent, FB_SMARGIN bits of headroom
-        S_w = ex_w + sx_e - FB_SMARGIN;
+        S_w = ex_e + sx_e - FB_SMARGIN;
         s_set = true;
       }
-      wphase();
+      rest();
     }
     if (!need) break;
-    {   // the accumulators so far leave for this wave's spill slab (added to what an earlier pass left there)
-      const float dsc = __builtin_ldexpf(1.f, -S_w);
-      f32x4* sp = (f32x4*)(fa_.spill + ((long)blockIdx.x * NW + wave) * (K::NACC * 256)) + lane;
-#pragma unroll
-      for (int j = 0; j < K::NACC; ++j) {
-        f32x4 v = accw[j] * dsc;
-        if (flushed) v += sp[j * 64];
-        sp[j * 64] = v;
-      }
-      flushed = 1;
-      resume = true;
-    }
+    slab_write(flushed != 0);
+    flushed = 1;
+    resume = true;
   }
 
-  FB_T(6)
-  // ---------------- the workgroup's results leave: channel sums, bias partials, the dW slab
+  FB_T(7)
+  // ---------------- the workgroup's results leave: dW slab, channel sums, bias partials
+  slab_write(flushed != 0);
   if (EPIAB) {
     __syncthreads();   // (a flush inside the last iteration and the final one must not overlap: see conv_f16x2_kernel)
     if (ab_n >= 0) ab_flush();
   }
-  __syncthreads();     // every wave is done with the weights and the halo buffers: the reductions below alias them
-  {
-    const float desc = __builtin_ldexpf(1.f, -S_w);
-#pragma unroll
-    for (int j = 0; j < K::NACC; ++j) accw[j] *= desc;
-    if (flushed) {   // (rare: earlier passes of this wave, written by these very lanes)
-      const f32x4* sp = (const f32x4*)(fa_.spill + ((long)blockIdx.x * NW + wave) * (K::NACC * 256)) + lane;
-#pragma unroll
-      for (int j = 0; j < K::NACC; ++j) accw[j] += sp[j * 64];
-    }
-    f32x4* rbuf = (f32x4*)smem16;   // [wave - 1][tile j][lane]
-    if (wave > 0) {
-#pragma unroll
-      for (int j = 0; j < K::NACC; ++j) rbuf[((wave - 1) * K::NACC + j) * 64 + lane] = accw[j];
-    }
-    __syncthreads();
-    if (wave == 0) {
-      float* out = fa_.part + (long)blockIdx.x * (9 * C * C);
-#pragma unroll
-      for (int j = 0; j < K::NACC; ++j) {
-        f32x4 s = accw[j];
-#pragma unroll
-        for (int wv = 1; wv < NW; ++wv) s += rbuf[((wv - 1) * K::NACC + j) * 64 + lane];
-        const int mb = j >> 1, nb = j & 1;   // (mb = tap * 2 + ci half)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[(mb * 16 + lg * 4 + r) * C + nb * 16 + li] = s[r];
-      }
-    }
-  }
   if (fa_.bpart) {
-    __syncthreads();
-    float* bred = (float*)smem16;
+    __syncthreads();   // (every wave is done with the halo: the scratch below aliases it)
+    float* bred = (float*)xh;
     const int vv = threadIdx.x % CV, row = threadIdx.x / CV;
     bred[row * C + vv * 4 + 0] = bsum.x;
     bred[row * C + vv * 4 + 1] = bsum.y;
@@ -743,7 +670,6 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     }
   }
 #ifdef FB_STAMP
-  FB_T(7)
   if (lane == 0 && blockIdx.x < 256)
     for (int k = 0; k < 8; ++k) fb_stamps[(blockIdx.x * 4 + wave) * 8 + k] = st_[k];
 #endif
