@@ -53,7 +53,7 @@ __device__ __forceinline__ void fb_static_for(F&& f) {
 #endif
 // Diagnostic build only (scripts/diag/fb_stamps.py, -DFB_STAMP): per-wave s_memtime sums of the phases of a tile
 #ifdef FB_STAMP
-__device__ unsigned long long fb_stamps[256 * 4 * 8];
+__device__ unsigned long long fb_stamps[256 * 4 * 12];
 #define FB_T(k)                                                   \
   {                                                               \
     const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   static_assert(XSRC == 0 || (XSRC == 1 && EPIAB) || (XSRC == 2 && EPIACT), "shared x operand");
   static_assert(!GST || INCOEF, "gpre store: only where the operand is formed on load");
 #ifdef FB_STAMP
-  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_amdgcn_s_memtime();
 #endif
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
@@ -229,6 +229,30 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     *(uint2*)(p + C) = make_uint2(a2, b2);
   };
 
+  // two halo items, stage by stage (see the staging phase)
+  auto stage_item2 = [&](int it, float sc) __attribute__((always_inline)) {
+    const float4 va = pre[it], vb = pre[it + 1];
+    const float x_[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+    f32x2 v_[4], r_[4];
+    f16x2_t h1_[4], h2_[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v_[k] = (f32x2){x_[2 * k] * sc, x_[2 * k + 1] * sc};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h1_[k] = __builtin_convertvector(v_[k], f16x2_t);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r_[k] = (f32x2){__builtin_fmaf(x_[2 * k], sc, -(float)h1_[k][0]), __builtin_fmaf(x_[2 * k + 1], sc, -(float)h1_[k][1])};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h2_[k] = __builtin_convertvector(r_[k], f16x2_t);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = (int)threadIdx.x + (it + j) * NTHR;
+      unsigned short* p = xh + lds_item + (it + j) * (32 * PS);
+      if ((it + j + 1) * NTHR > K::NITEMS) p = idx < K::NITEMS ? p : pad16 - C;
+      *(uint2*)(p) = make_uint2(__builtin_bit_cast(unsigned, h1_[2 * j]), __builtin_bit_cast(unsigned, h1_[2 * j + 1]));
+      *(uint2*)(p + C) = make_uint2(__builtin_bit_cast(unsigned, h2_[2 * j]), __builtin_bit_cast(unsigned, h2_[2 * j + 1]));
+    }
+  };
+
   int tile = t_lo + rank;
   int cn = 0, cty = 0, ctx = 0;
   auto advance = [&](int& n_, int& ty_, int& tx_) {
@@ -250,14 +274,15 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) off[mt] = (vx0 < a.wv && vy0 + mt < a.hv) ? (unsigned)(t0 + mt * yrow) : BX_OOB;
   };
-  auto x_issue = [&](int n, int ty, int tx, bool live) {
+  auto x_issue = [&](int n, int ty, int tx, bool live, int i0 = 0, int i1 = NPIECE) __attribute__((always_inline)) {
     unsigned off[MT];
     centre_off(ty, tx, off);
     const long sb = (long)n * a.hf * a.wf * C;
     const unsigned bytes = live ? y_bytes : 0u;
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i)
-      cxw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(wx_base + sb, bytes), off[i / NT] + (i % NT) * 64, 0, 0));
+      if (i >= i0 && i < i1)
+        cxw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(wx_base + sb, bytes), off[i / NT] + (i % NT) * 64, 0, 0));
   };
   auto epi_issue = [&](int n, const unsigned (&off)[MT]) {
     const long sb = (long)n * a.hf * a.wf * C;
@@ -451,28 +476,42 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     // is all zero the exponent does not matter)
     {
       const float sc = __builtin_ldexpf(1.f, sx_e);
+      // (one wave per SIMD: nothing hides the latency of a dependent vector instruction, and the compiler keeps source order - the
+      //  split's chain mul -> cvt -> fma -> cvt of TWO items is interleaved by hand: 2.7 k -> cycles per tile for the 19 items)
 #pragma unroll
-      for (int it = 0; it < NLOAD; ++it) stage_item(it, sc);
+      for (int it = 0; it + 1 < NLOAD; it += 2) stage_item2(it, sc);
+      if (NLOAD & 1) stage_item(NLOAD - 1, sc);
+      FB_T(8)
       const int es = S_w - sx_e < ex_e ? S_w - sx_e : ex_e;
       const float scx = __builtin_ldexpf(1.f, es);
 #pragma unroll
-      for (int i = 0; i < NPIECE; ++i) {
-        const float4 v = xval(i);
-        unsigned a1, a2, b1, b2;
-        f2_split_pair_scaled(v.x, v.y, scx, a1, a2);
-        f2_split_pair_scaled(v.z, v.w, scx, b1, b2);
-        unsigned short* p = xt + ((wave * MT + i / NT) * FB_TC + li) * PS + (i % NT) * 16 + lg * 4;
-        *(uint2*)(p) = make_uint2(a1, b1);
-        *(uint2*)(p + C) = make_uint2(a2, b2);
+      for (int i = 0; i < NPIECE; i += 2) {   // (two pieces at a time, stage by stage: see stage_item2)
+        const float4 va = xval(i), vb = xval(i + 1);
+        const float x_[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        f32x2 v_[4], r_[4];
+        f16x2_t h1_[4], h2_[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v_[k] = (f32x2){x_[2 * k] * scx, x_[2 * k + 1] * scx};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h1_[k] = __builtin_convertvector(v_[k], f16x2_t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r_[k] = (f32x2){__builtin_fmaf(x_[2 * k], scx, -(float)h1_[k][0]), __builtin_fmaf(x_[2 * k + 1], scx, -(float)h1_[k][1])};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h2_[k] = __builtin_convertvector(r_[k], f16x2_t);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned short* p = xt + ((wave * MT + (i + j) / NT) * FB_TC + li) * PS + ((i + j) % NT) * 16 + lg * 4;
+          *(uint2*)(p) = make_uint2(__builtin_bit_cast(unsigned, h1_[2 * j]), __builtin_bit_cast(unsigned, h1_[2 * j + 1]));
+          *(uint2*)(p + C) = make_uint2(__builtin_bit_cast(unsigned, h2_[2 * j]), __builtin_bit_cast(unsigned, h2_[2 * j + 1]));
+        }
       }
     }
-    // the next tile's halo and x strip are requested now (a whole tile to land), this tile's epilogue operands too
+    FB_T(9)
+    // this tile's epilogue operands are requested now (used after D); the next tile's halo and x strip ride in D's first k-steps (a
+    // wave issues one 1-KB load per ~16 cycles at best: 19 - 30 of them in a row cost ~2 k cycles per tile in front of barrier B)
     int n1 = cn, ty1 = cty, tx1 = ctx;
     advance(n1, ty1, tx1);
     const Pf pfn = pf_make(n1, ty1, tx1, tile + per < t_hi);
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) pf_issue(pfn, it);
-    x_issue(n1, ty1, tx1, tile + per < t_hi);
     epi_issue(cn, cur_off);
     FB_T(3)
     // barrier B: halo, x tile (and, first tile, the weight planes) are complete
@@ -509,6 +548,11 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         if (ks + 1 < KS) load_w(ks + 1, fw[b ^ 1]);
         if (ky == 0 && kx > 0) load_rows(kx, 2, MT + 2);
         if (ky == 2 && kx < 2) load_rows(kx + 1, 0, 2);   // (this step reads rows 2 .. MT + 1: rows 0, 1 are dead)
+        // the next tile's loads that ride in this k-step (their registers were emptied by the staging above)
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it)
+          if (it * 6 / NLOAD == ks) pf_issue(pfn, it);
+        if (ks >= 6 && ks < 8) x_issue(n1, ty1, tx1, tile + per < t_hi, (ks - 6) * (NPIECE / 2), (ks - 5) * (NPIECE / 2));
         auto mm = [&](int mt0, int mt1) __attribute__((always_inline)) {
 #pragma unroll
           for (int q = 0; q < 3; ++q)
@@ -569,35 +613,51 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     // tile: 8 k-steps of 32 pixels (tile rows 2 ks, 2 ks + 1), per k-step two x^T fragments (planes) against the gy fragments of the
     // 9 tap shifts - centre pixel (r', c') meets the halo pixel (r' + 2 - ky, c' + 2 - kx)
     {
-      s16x8 fx[2][NP];        // [k-step parity][plane]
-      s16x8 fg[2][3][NP];     // [tap-row parity][kx][plane]: the three taps of a tap row, fetched one tap row ahead
+      // gy fragments by halo row pair: tap row ky of k-step ks reads halo rows (2 ks + 2 - ky, + 1) - the pair of (ks, ky = 2) is the
+      // pair of (ks - 1, ky = 0): fetched once, used twice (a k-step fetches two new pairs, not three: the phase is bound by the LDS
+      // bandwidth of the transposing reads, 128 B per clock: 314 -> 250 reads per wave and tile).  Order within a k-step: ky = 2, 0, 1.
+      s16x8 fx[2][NP];        // x^T: [k-step parity][plane]
+      s16x8 G0[2][3][NP];     // even pairs (ky = 0 of k-step ks, ky = 2 of ks + 1): [ks parity][kx][plane]
+      s16x8 G1[3][NP];        // odd pairs (ky = 1)
       auto load_x = [&](int ks, s16x8 (&F)[NP]) __attribute__((always_inline)) {
         const unsigned short* xq = xt + (2 * ks * FB_TC + 4 * lg + tq) * PS + ah * 16 + tp * 4;
 #pragma unroll
         for (int p = 0; p < NP; ++p) F[p] = fb_tr_read8(xq + p * C, xq + FB_TC * PS + p * C);
       };
-      auto load_g = [&](int ks, int ky, s16x8 (&G)[3][NP]) __attribute__((always_inline)) {
+      auto load_pair = [&](int row0, s16x8 (&G)[3][NP]) __attribute__((always_inline)) {   // halo rows row0, row0 + 1, the three kx shifts
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const unsigned short* gq = xh + ((2 * ks + 2 - ky) * IC + (4 * lg + tq) + 2 - kx) * PS + bh * 16 + tp * 4;
+          const unsigned short* gq = xh + (row0 * IC + (4 * lg + tq) + 2 - kx) * PS + bh * 16 + tp * 4;
 #pragma unroll
           for (int p = 0; p < NP; ++p) G[kx][p] = fb_tr_read8(gq + p * C, gq + IC * PS + p * C);
         }
       };
-      load_x(0, fx[0]);
-      load_g(0, 0, fg[0]);
-      fb_static_for<0, 24>([&](auto uc) __attribute__((always_inline)) {   // unit u = (k-step, tap row): 9 products
-        constexpr int u = decltype(uc)::value;
-        constexpr int ks = u / 3, ky = u % 3;
-        if (u + 1 < 24) load_g((u + 1) / 3, (u + 1) % 3, fg[(u + 1) & 1]);
-        if (ky == 0 && ks + 1 < 8) load_x(ks + 1, fx[(ks + 1) & 1]);
-        if (ky == 1 && ks < NPIECE) epi_piece(ks);   // (one piece of the input gradient's epilogue per k-step)
+      auto mm3 = [&](int ks, int ky, s16x8 (&G)[3][NP]) __attribute__((always_inline)) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
           for (int q = 0; q < 3; ++q)
             accw[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fx[ks & 1][PA[q]]),
-                                                                       __builtin_bit_cast(f16x8_t, fg[u & 1][kx][PB[q]]), accw[ky * 3 + kx], 0, 0, 0);
+                                                                       __builtin_bit_cast(f16x8_t, G[kx][PB[q]]), accw[ky * 3 + kx], 0, 0, 0);
+      };
+      load_x(0, fx[0]);
+      load_pair(0, G0[1]);   // (k-step 0, ky = 2)
+      load_pair(2, G0[0]);   // (k-step 0, ky = 0)
+      fb_static_for<0, 8>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(kc)::value;
+        // ky = 2 (the pair fetched for ky = 0 of the previous k-step); the odd pair of this k-step is fetched under it
+        load_pair(2 * ks + 1, G1);
+        if (ks < NPIECE / 2) epi_piece(2 * ks);       // (the input gradient's epilogue rides in the first k-steps: its stores leave early)
+        mm3(ks, 2, G0[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // ky = 0; the next k-step's x^T fragments are fetched under it
+        if (ks + 1 < 8) load_x(ks + 1, fx[(ks + 1) & 1]);
+        if (ks < NPIECE / 2) epi_piece(2 * ks + 1);
+        mm3(ks, 0, G0[ks & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // ky = 1; the next k-step's even pair is fetched under it (into the set ky = 2 has just left)
+        if (ks + 1 < 8) load_pair(2 * ks + 4, G0[(ks + 1) & 1]);
+        mm3(ks, 1, G1);
         __builtin_amdgcn_sched_barrier(0);
       });
     }
@@ -671,7 +731,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   }
 #ifdef FB_STAMP
   if (lane == 0 && blockIdx.x < 256)
-    for (int k = 0; k < 8; ++k) fb_stamps[(blockIdx.x * 4 + wave) * 8 + k] = st_[k];
+    for (int k = 0; k < 12; ++k) fb_stamps[(blockIdx.x * 4 + wave) * 12 + k] = st_[k];
 #endif
 }
 

@@ -21,18 +21,19 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 L.call_try('dis_conv2d_bwd_fused_f16x2', gq, None, None, 0, None, wt, c, c, wt.stride(0), gx, 0, None, None, None, x, None, None, None, 1e-5, gw, gb, ws, n, h, w, c)
 e1.record(); torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * (256 * 4 * 8))()
+buf = (ctypes.c_ulonglong * (256 * 4 * 12))()
 lib = L.load()
 lib.dis_debug_fb_stamps.argtypes = [ctypes.c_void_p]
 assert lib.dis_debug_fb_stamps(ctypes.cast(buf, ctypes.c_void_p)) == 0
-a = np.array(buf, dtype=np.float64).reshape(256, 4, 8)
+a = np.array(buf, dtype=np.float64).reshape(256, 4, 12)
 tiles = n * (h // 16) * ((w + 15) // 16) / 256.0
-names = ['rotate+loop top', 'prep (next halo: values, max)', 'barrier wait', 'D: 216 products + staging + loads', 'x strip max', 'W: epilogue + 216 dW products',
-         'after the loop', 'slab reduce / bias / store']
+names = ['loop control + flush of the channel sums', 'TOP: final values + maxima (halo, x strip)', 'barrier A', 'staging (halo + x tile split, LDS writes), next loads issued',
+         'barrier B', 'D: 216 input-gradient products', 'W: epilogue + 216 dW products', 'after the loop: slab / bias',
+         '  (staging: halo items split + written)', '  (staging: x strip split + written)', '', '']
 print(f'launch {e0.elapsed_time(e1) * 1e3:.1f} us, {tiles:.1f} tiles per workgroup; s_memtime ticks (100 MHz) per tile and wave, median over workgroups')
 tot = 0.0
-for k in range(8):
-    v = np.median(a[:, :, k]) / (tiles if k < 6 else 1.0)
-    tot += np.median(a[:, :, k])
-    print(f'  {names[k]:40s} {v:9.1f} ticks = {v * 10:.0f} ns' + (' per tile' if k < 6 else ' once'))
+for k in range(10):
+    v = np.median(a[:, :, k]) / (tiles if k != 7 else 1.0)
+    tot += np.median(a[:, :, k]) if k < 8 else 0.0
+    print(f'  {names[k]:40s} {v:9.1f} ticks = {v * 10:.0f} ns' + (' per tile' if k != 7 else ' once'))
 print(f'  sum {tot:.0f} ticks = {tot / 100:.1f} us per workgroup')
