@@ -1066,11 +1066,11 @@ def _conv_fwd_any(x, weight, cin_pad, mode, bias, y, stats, n, hin, win, cin, co
                  pad, act)
 
 
-# Round 6: input gradient + weight gradient of a 3x3 stride-1 conv 32 -> 32 in one launch (dis_conv2d_bwd_fused_f16x2).  Complete and
-# parity-green (tests/test_bwd_fused_gpu.py), but measured SLOWER than the two launches it replaces on MI355X (profiles/r6_bwd_fused.md:
-# same-box A/B per form, per-tile cycle table, register budget) - OFF by default; DIS_BWD_FUSED=1 routes the backward of these layers
-# through it
-BWD_FUSED = _os.environ.get('DIS_BWD_FUSED', '0') == '1'
+# Round 6: input gradient + weight gradient of a 3x3 stride-1 conv 32 -> 32 in ONE launch (dis_conv2d_bwd_fused_f16x2,
+# csrc/conv_bwd_fused.hip): the gy halo a tile stages feeds both products, gpre (the GroupNorm-backward pass formed on load) is never
+# written, x and gy are read once.  Same-box: 0.79 - 0.95 of the two launches per layer, DIS-MF step 513.9 -> 537.6 frames/s
+# (profiles/r6_bwd_fused.md).  DIS_BWD_FUSED=0 keeps the two launches.
+BWD_FUSED = _os.environ.get('DIS_BWD_FUSED', '1') != '0'
 _FUSED_WS = {}
 
 
