@@ -206,9 +206,14 @@ _profile = None
 _tagbuf = ctypes.create_string_buffer(96)
 
 
+_profile_ptrs = []   # per recorded call: the device address of every tensor argument (None elsewhere), aligned with profile_stop()
+last_profile_ptrs = []
+
+
 def profile_start():
     global _profile
     _profile = []
+    del _profile_ptrs[:]
     fn('dis_last_kernel')(ctypes.cast(_tagbuf, ctypes.c_void_p), len(_tagbuf), 1)
 
 
@@ -217,7 +222,9 @@ def profile_stop():
     kernel family the conv dispatchers report through dis_last_kernel ('' for the other entry points); n_tensor_args: how many
     of the call's pointer arguments were not NULL (optional operands change a launch's algorithmic bytes)."""
     global _profile
+    global last_profile_ptrs
     rec, _profile = _profile, None
+    last_profile_ptrs = list(_profile_ptrs)
     torch.cuda.synchronize()
     return [(n, a, e0.elapsed_time(e1), t, k) for (n, a, e0, e1, t, k) in rec]
 
@@ -256,6 +263,7 @@ def call(name, *args, _soft=False):
         tag = _tagbuf.value.decode()
         _profile.append((name, tuple(a for a in args if isinstance(a, int)), e0, e1, tag,
                          sum(1 for a in args if isinstance(a, torch.Tensor))))
+        _profile_ptrs.append(tuple(a.data_ptr() if isinstance(a, torch.Tensor) else None for a in args))
     else:
         rc = f(*conv)
     if rc == -2 and _soft:

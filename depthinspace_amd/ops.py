@@ -1532,6 +1532,7 @@ class _Conv2dMulti(torch.autograd.Function):
         gg_ret = gbt_ret = None
         gxs = []
         off = 0
+        need_w = [None]   # the weight gradient of the current slice when a fused launch has produced it
         for i, x in enumerate(xs):
             wi = weight[:, off:off + cs[i]]  # a view: no copy
             gn0 = i == 0 and gn_meta is not None
@@ -1550,8 +1551,17 @@ class _Conv2dMulti(torch.autograd.Function):
                         if lz is not None:
                             _, lg, lq, lcoef, lin_act = lz
                             gpre = torch.empty_like(lg)
-                            if not lib.call_try('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, wi, cout, cs[0], wi.stride(0),
-                                                gnorm, 0, x, None, ab, n, h, w, cs[0]):
+                            if _bwd_fused_ok(cs[0], cout, k, 1, pad) and need_w[0] is None:
+                                # one launch: operand formed on load (stored for the other sources' launches), input gradient +
+                                # channel sums, and this slice's weight / bias gradient with GroupNorm(x) on load
+                                gw0 = torch.empty((cout, cs[0], k, k), dtype=torch.float32, device=x.device)
+                                if _bwd_fused(lg, lq, lcoef, lin_act, gpre, wi, gnorm, False, x, None, ab, x,
+                                              (gn_stats, gn_gamma, ctx.beta_ref, float(gn_meta[0])), gw0, gb if has_bias else None, n, h, w):
+                                    need_w[0] = gw0
+                            if need_w[0] is not None:
+                                pass
+                            elif not lib.call_try('dis_conv2d_dgrad_f16x2_gnb', lg, lq, lcoef, lin_act, gpre, wi, cout, cs[0], wi.stride(0),
+                                                  gnorm, 0, x, None, ab, n, h, w, cs[0]):
                                 gpre = _gn_lazy_materialize(lz)   # (no instance in this build: the pass as a launch of its own)
                                 lib.call('dis_conv2d_dgrad_bf16x3_gnsums', gpre, wi, cout, cs[0], wi.stride(0), gnorm, x, ab, n,
                                          gpre.shape[1], gpre.shape[2], cout, cs[0], k - 1 - pad)
@@ -1593,10 +1603,21 @@ class _Conv2dMulti(torch.autograd.Function):
                                       k - 1 - pad, ACT_NONE)
                     lz = None
                 else:
-                    _conv_fwd_any(gpre, wi, cs[i], 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cs[i], k, 1,
-                                  k - 1 - pad, ACT_NONE)
+                    if _bwd_fused_ok(cs[i], cout, k, 1, pad) and lib.fn('dis_get_conv_split')() == 1:
+                        gwf = torch.empty((cout, cs[i], k, k), dtype=torch.float32, device=x.device)
+                        if _bwd_fused(gpre, None, None, ACT_NONE, None, wi, gx, False, None, None, None, x, None, gwf,
+                                      gb if (i == 0 and has_bias) else None, n, h, w):
+                            need_w[0] = gwf
+                    if need_w[0] is None:
+                        _conv_fwd_any(gpre, wi, cs[i], 1, None, gx, None, n, gpre.shape[1], gpre.shape[2], cout, cs[i], k, 1,
+                                      k - 1 - pad, ACT_NONE)
             assert lz is None   # (redeemed by the first source's launch: ctx.lazy_ok guarantees that it has one)
             gxs.append(gx)
+            if need_w[0] is not None:   # (the fused launch above has left this slice's weight gradient)
+                gw[:, off:off + cs[i]].copy_(need_w[0])
+                need_w[0] = None
+                off += cs[i]
+                continue
             gwi = torch.empty((cout, cs[i], k, k), dtype=torch.float32, device=x.device)
             wsz = lib.fn('dis_conv2d_wgrad_workspace')(cs[i], cout, k, 1)
             if wsz < 0:
