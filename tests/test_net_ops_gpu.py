@@ -201,6 +201,10 @@ def test_conv_with_group_norm_on_load_equals_the_two_pass_form(c, act, n, h, w):
             # the fused pair's GroupNorm backward works from the per-(sample, channel) sums of its input-gradient epilogue
             # (dis_gn_bwd_from_sums): the same quantities, factored differently - equal to rounding, not bit for bit
             assert relerr(a_, b_) < 2e-5, (name, relerr(a_, b_))
+        elif name in ('gw', 'gb') and ops.BWD_FUSED and c == 32:
+            # round 6: the two-pass form's conv backward is the fused input- / weight-gradient launch, the pair's is the stand-alone
+            # weight-gradient kernel - the same sums in another order (both within 2e-7 of fp64, tests/test_bwd_fused_gpu.py)
+            assert relerr(a_, b_) < 2e-6, (name, relerr(a_, b_))
         else:
             assert torch.equal(a_, b_), (name, float((a_ - b_).abs().max()))
     # torch on the host
