@@ -474,25 +474,13 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   auto rest = [&]() __attribute__((always_inline)) {
     // ---- staging: the halo with its own per-tile scale, x with 2^(S - sx_e) (a term of dW carries 2^S; where the halo or the x tile
     // is all zero the exponent does not matter)
-    // (the next tile: its loads follow each item into the registers it leaves - issued HERE they have the staging, D and W to land,
-    //  ~6 us, and their issue slots lie between the split's dependent instructions)
-    int n1 = cn, ty1 = cty, tx1 = ctx;
-    advance(n1, ty1, tx1);
-    const Pf pfn = pf_make(n1, ty1, tx1, tile + per < t_hi);
     {
       const float sc = __builtin_ldexpf(1.f, sx_e);
       // (one wave per SIMD: nothing hides the latency of a dependent vector instruction, and the compiler keeps source order - the
-      //  split's chain mul -> cvt -> fma -> cvt of TWO items is interleaved by hand)
+      //  split's chain mul -> cvt -> fma -> cvt of TWO items is interleaved by hand: 2.7 k -> cycles per tile for the 19 items)
 #pragma unroll
-      for (int it = 0; it + 1 < NLOAD; it += 2) {
-        stage_item2(it, sc);
-        pf_issue(pfn, it);
-        pf_issue(pfn, it + 1);
-      }
-      if (NLOAD & 1) {
-        stage_item(NLOAD - 1, sc);
-        pf_issue(pfn, NLOAD - 1);
-      }
+      for (int it = 0; it + 1 < NLOAD; it += 2) stage_item2(it, sc);
+      if (NLOAD & 1) stage_item(NLOAD - 1, sc);
       FB_T(8)
       const int es = S_w - sx_e < ex_e ? S_w - sx_e : ex_e;
       const float scx = __builtin_ldexpf(1.f, es);
@@ -519,8 +507,11 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       }
     }
     FB_T(9)
-    // the next tile's x strip (its registers are free now) and this tile's epilogue operands (used after D)
-    x_issue(n1, ty1, tx1, tile + per < t_hi);
+    // this tile's epilogue operands are requested now (used after D); the next tile's halo and x strip ride in D's first k-steps (a
+    // wave issues one 1-KB load per ~16 cycles at best: 19 - 30 of them in a row cost ~2 k cycles per tile in front of barrier B)
+    int n1 = cn, ty1 = cty, tx1 = ctx;
+    advance(n1, ty1, tx1);
+    const Pf pfn = pf_make(n1, ty1, tx1, tile + per < t_hi);
     epi_issue(cn, cur_off);
     FB_T(3)
     // barrier B: halo, x tile (and, first tile, the weight planes) are complete
@@ -557,6 +548,11 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         if (ks + 1 < KS) load_w(ks + 1, fw[b ^ 1]);
         if (ky == 0 && kx > 0) load_rows(kx, 2, MT + 2);
         if (ky == 2 && kx < 2) load_rows(kx + 1, 0, 2);   // (this step reads rows 2 .. MT + 1: rows 0, 1 are dead)
+        // the next tile's loads that ride in this k-step (their registers were emptied by the staging above)
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it)
+          if (it * 6 / NLOAD == ks) pf_issue(pfn, it);
+        if (ks >= 6 && ks < 8) x_issue(n1, ty1, tx1, tile + per < t_hi, (ks - 6) * (NPIECE / 2), (ks - 5) * (NPIECE / 2));
         auto mm = [&](int mt0, int mt1) __attribute__((always_inline)) {
 #pragma unroll
           for (int q = 0; q < 3; ++q)
