@@ -147,6 +147,9 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     int iy0, ix0, off0;
   };
   auto pf_make = [&](int n, int ty, int tx, bool live) -> Pf {
+#ifdef FB_KO_LOAD   // (diagnostic: every halo load reads tile (1, 1) of sample 0 - cache hits)
+    n = 0, ty = 1, tx = 1;
+#endif
     Pf f;
     f.iy0 = ty * FB_TR - 1;
     f.ix0 = tx * FB_TC - 1;
@@ -269,6 +272,9 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   float4 cxw[NPIECE], cy[ACCUM ? NPIECE : 1], cab[EPIAB ? NPIECE : 1], cact[EPIACT ? NPIECE : 1];
   const float* wx_base = XSRC == 1 ? a.ab_x : (XSRC == 2 ? a.ab_act_y : fa_.wx);
   auto centre_off = [&](int ty, int tx, unsigned (&off)[MT]) {
+#ifdef FB_KO_LOAD
+    ty = 1, tx = 1;
+#endif
     const int vy0 = ty * FB_TR + wave * MT, vx0 = tx * FB_TC + li;
     const int t0 = (ty * FB_TR * a.wf + tx * FB_TC) * (C * 4) + y_lane;
 #pragma unroll

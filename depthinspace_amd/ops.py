@@ -1591,8 +1591,15 @@ class _Conv2dMulti(torch.autograd.Function):
                              n, gy.shape[1], gy.shape[2], cout, cs[i], k - 1 - pad)
                     _GN_PRE[gx.data_ptr()] = (ab, slots)
                 elif fuse_act:
-                    lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, wi, cout, cs[i], wi.stride(0), gx, n, gy.shape[1],
-                             gy.shape[2], cout, cs[i], k - 1 - pad, 0)
+                    if _bwd_fused_ok(cs[i], cout, k, 1, pad) and lib.fn('dis_get_conv_split')() == 1:
+                        # (ref_conv's 32-channel slice: gy act'(y) feeds the input gradient and the weight gradient in one launch)
+                        gwf = torch.empty((cout, cs[i], k, k), dtype=torch.float32, device=x.device)
+                        if _bwd_fused(gy, y, None, act, None, wi, gx, False, None, None, None, x, None, gwf,
+                                      gb if (i == 0 and has_bias) else None, n, h, w):
+                            need_w[0] = gwf
+                    if need_w[0] is None:
+                        lib.call('dis_conv2d_dgrad_bf16x3_act', gy, y, act, wi, cout, cs[i], wi.stride(0), gx, n, gy.shape[1],
+                                 gy.shape[2], cout, cs[i], k - 1 - pad, 0)
                 elif lz is not None:   # (i == 0: the token's pass on load, no epilogue)
                     _, lg, lq, lcoef, lin_act = lz
                     gpre = torch.empty_like(lg)
