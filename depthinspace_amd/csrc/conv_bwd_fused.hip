@@ -238,6 +238,18 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     const float x_[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
     f32x2 v_[4], r_[4];
     f16x2_t h1_[4], h2_[4];
+#ifdef FB_KO_SPLIT   // (diagnostic: the staged bits are not the split - WRONG results; what the split's instructions cost)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = (int)threadIdx.x + (it + j) * NTHR;
+      unsigned short* p = xh + lds_item + (it + j) * (32 * PS);
+      if ((it + j + 1) * NTHR > K::NITEMS) p = idx < K::NITEMS ? p : pad16 - C;
+      *(uint2*)(p) = make_uint2(__float_as_uint(x_[4 * j]) & 0x3fff3fffu, __float_as_uint(x_[4 * j + 1]) & 0x3fff3fffu);
+      *(uint2*)(p + C) = make_uint2(__float_as_uint(x_[4 * j + 2]) & 0x3fff3fffu, __float_as_uint(x_[4 * j + 3]) & 0x3fff3fffu);
+    }
+    (void)sc; (void)v_; (void)r_; (void)h1_; (void)h2_;
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) v_[k] = (f32x2){x_[2 * k] * sc, x_[2 * k + 1] * sc};
 #pragma unroll
