@@ -10,18 +10,32 @@
 // Two-term fp16 operands, three products on v_mfma_f32_16x16x32_f16, as conv_f16x2.hip (same split, same per-tile scale, same order of
 // the accumulation per output element: gx is BIT-identical to conv_f16x2_kernel's).
 //
-// Shape of the kernel: 4 waves of 64 lanes, ONE per SIMD, 512 registers each - the 36 accumulator tiles of dW (144 registers) need
-// them; with 8 waves (256 registers each) the input-gradient kernel's INCOEF instances alone sit at 236 - 256.  A wave owns 4 rows of
-// the 16 x 16 tile: its input-gradient accumulators (4 x 2 tiles) and - for dW - those 64 pixels as TWO k-steps of 32 pixels against
-// all 36 (tap, ci half, co half) tiles: no cross-wave reduction until the workgroup's last tile.  The x values of a wave's pixels live
-// in a wave-private LDS strip (one k-step at a time, [pixel][plane][channel], read back with ds_read_b64_tr_b16): no barrier for them.
-// dW scales: the gy halo carries the input gradient's per-tile scale 2^sg(t); x is split with 2^(S - sg(t)), S a per-wave exponent set by
-// the first tile that has something to add (FB_SMARGIN bits of headroom), so that every term of the sum carries 2^S.  A later tile
-// whose product magnitude exceeds the headroom makes the wave LEAVE the tile loop: the accumulators go to a spill slab in memory
-// (scaled by 2^-S), a new pass starts from zero accumulators with a new S (RESUME copy of D: the tile's products are formed again).
-// Status (round 6): parity-green in all forms, NOT faster than the two launches it replaces on MI355X - the register budget
-// (profiles/r6_bwd_fused.md); the step uses it only with DIS_BWD_FUSED=1.
-// LDS: weights 36.9 KB + two halo buffers 2 x 51.8 KB + x strips 4 x 5 KB + 1.2 KB = 162.2 KB of 160 KiB.
+// Shape of the kernel: 4 waves of 64 lanes, ONE per SIMD, 512 registers each, one workgroup per CU (grid = #CUs, persistent over the
+// tiles of its XCD's share).  Per 16 x 16 tile:
+//   top      maxima of the next halo and of the x tile per wave (DPP), exchanged through LDS
+//   barrier A  (every wave has left the previous tile: halo and x tile may be overwritten; the maxima are visible)
+//   staging  the gy halo (18 x 18 x 32, two fp16 planes, per-tile scale 2^sg) and the x tile (16 x 16 x 32, scale 2^(S - sg)) go to
+//            LDS, ONE copy of each shared by the four waves
+//   barrier B
+//   D        input gradient: wave w owns tile rows 4 w .. 4 w + 3 (8 accumulator tiles), 9 taps x 3 products; the next tile's halo /
+//            x loads are issued inside the first k-steps (their registers were emptied by the staging)
+//   W        weight gradient: wave (ah, bh) = (wave >> 1, wave & 1) owns the 9 tap tiles of (ci half ah, co half bh) - 36 accumulation
+//            registers, not 144 - over ALL 256 pixels of the tile: 8 k-steps of 32 pixels, x^T and the shifted gy fragments read back
+//            with ds_read_b64_tr_b16 (an even halo row pair serves tap row 0 of one k-step and tap row 2 of the next); the input
+//            gradient's epilogue (8 stores, channel sums) rides in its first k-steps
+// No cross-wave reduction of dW at all: a wave's 9 tiles are its own elements of the workgroup's slab, written once per workgroup and
+// summed over workgroups by wgrad_reduce_kernel (fixed order, fp64).
+// dW scales: the gy halo carries the input gradient's per-tile scale 2^sg(t); x is split with 2^(S - sg(t)), S a WORKGROUP-uniform
+// exponent set by the first tile that has something to add (FB_SMARGIN bits of headroom), so that every term of the sum carries 2^S.
+// A later tile whose product magnitude exceeds the headroom makes the workgroup LEAVE the tile loop (inside it only matrix instructions
+// touch the dW accumulators - a rescale branch in the loop makes the allocator keep them in vector registers): the accumulators go to
+// the slab (scaled by 2^-S, added to what an earlier pass left there), a new pass starts from zero with a new S at the same tile.
+//
+// History (profiles/r6_bwd_fused.md): the first form of this kernel gave every wave ALL 36 dW tiles over its own 64 pixels (144
+// accumulation registers, wave-private x strips, two halo buffers, 162 KB of LDS) - correct, and 1.5 - 3.6 x slower than the two
+// launches in every form behind a GroupNorm: 530 - 600 registers of state against 512.  The tile split above needs 110 - 256 + 256 and
+// is 0.79 - 0.95 of the two launches (same-box A/B per form); the step uses it wherever an instance exists (DIS_BWD_FUSED=0: off).
+// LDS: weights 36.9 KB + halo 51.8 KB + x tile 41.0 KB + 1.2 KB = 130.9 KB.
 #include "conv_args.h"
 #include <type_traits>
 
@@ -94,6 +108,10 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   constexpr int C = K::C, IC = K::IC, PS = K::PS, NT = K::NT, KS = K::KS, NLOAD = K::NLOAD, NPIECE = K::NPIECE, CV = K::CV, NP = K::NP;
   constexpr int MT = K::MT, NW = K::NW, NTHR = K::NTHR;
   constexpr bool IN2 = INACT != 0 || INCOEF;
+  // RIDE: the next tile's halo items become final under the dW products of the current tile (prep_item in W) instead of at the top of
+  // their own tile.  Not where the accumulating GroupNorm-backward forms already fill the register file: measured 163 -> 188 us
+  // (coef + act' + accumulate) and 196 -> 222 us (chain) with it, 139 -> 129 / 164 -> 157 us for the forms that have room.
+  constexpr bool RIDE = !(INCOEF && ACCUM);
   static_assert(EPIACT == 0 || EPIAB, "activation gradient at the output: only with the channel sums");
   static_assert(XSRC == 0 || (XSRC == 1 && EPIAB) || (XSRC == 2 && EPIACT), "shared x operand");
   static_assert(!GST || INCOEF, "gpre store: only where the operand is formed on load");
@@ -171,53 +189,53 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   float cf_kx = 0.f, cf_k0 = 0.f;
   int cf_n = -1;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // bias gradient: this thread's 4 channels over the pixels its tiles own
-  // final fp32 values of the current tile's halo items (in place) and this wave's largest magnitude
-  auto prep = [&](const Pf& f, int n_cur) -> float {
-    if (INCOEF && n_cur != cf_n) {
-      cf_n = n_cur;
-      const float* cf = a.gnb_coef + (long)n_cur * (C + 2);
+  // final fp32 values of a tile's halo items (in place) and this lane's largest magnitude.  One wave per SIMD issues a vector
+  // instruction per >= 4 cycles and nothing else runs meanwhile: at the top of a tile these 170 - 500 instructions were 1.2 - 2.5 k
+  // exposed cycles, so the NEXT tile's items are finished under the dW products of the current one (prep_item rides in W; the first
+  // tile's in the prologue).
+  auto prep_cf = [&](int n_) {
+    if (INCOEF && n_ != cf_n) {
+      cf_n = n_;
+      const float* cf = a.gnb_coef + (long)n_ * (C + 2);
       cf_k1 = *(const float4*)(cf + ((int)threadIdx.x % CV) * 4);
       cf_kx = cf[C];
       cf_k0 = cf[C + 1];
     }
-    float m = 0.f;
-#pragma unroll
-    for (int it = 0; it < NLOAD; ++it) {
-      float4 v = pre[it];
-      if (INCOEF) {   // (gn_apply_coef_kernel's arithmetic, bit for bit; padding: g = q = 0 would give k0, which must not be staged)
-        const float4 q = pre2[it];
-        int r_, c_;
-        item_rc(it, r_, c_);
-        const int ix = f.ix0 + c_;
-        const unsigned off = (unsigned)ix < (unsigned)a.win ? (unsigned)(f.off0 + (r_ * a.win + c_) * (C * 4) + vv4) : BX_OOB;
-        const bool inside = off < f.bytes;
-        v.x = __builtin_fmaf(v.x, cf_k1.x, __builtin_fmaf(q.x, cf_kx, cf_k0));
-        v.y = __builtin_fmaf(v.y, cf_k1.y, __builtin_fmaf(q.y, cf_kx, cf_k0));
-        v.z = __builtin_fmaf(v.z, cf_k1.z, __builtin_fmaf(q.z, cf_kx, cf_k0));
-        v.w = __builtin_fmaf(v.w, cf_k1.w, __builtin_fmaf(q.w, cf_kx, cf_k0));
-        if (INACT) {
-          v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
-          v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
-        }
-        v = inside ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (GST) {
-          const u32x4 sv = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-          __builtin_amdgcn_raw_buffer_store_b128(sv, bx_rsrc(a.gnb_out + (f.x - a.x), f.bytes), item_own(it) ? off : BX_OOB, 0, 0);
-        }
-      } else if (INACT) {
-        const float4 q = pre2[it];
+  };
+  auto prep_item = [&](const Pf& f, int it, float& m) __attribute__((always_inline)) {
+    float4 v = pre[it];
+    if (INCOEF) {   // (gn_apply_coef_kernel's arithmetic, bit for bit; padding: g = q = 0 would give k0, which must not be staged)
+      const float4 q = pre2[it];
+      int r_, c_;
+      item_rc(it, r_, c_);
+      const int ix = f.ix0 + c_;
+      const unsigned off = (unsigned)ix < (unsigned)a.win ? (unsigned)(f.off0 + (r_ * a.win + c_) * (C * 4) + vv4) : BX_OOB;
+      const bool inside = off < f.bytes;
+      v.x = __builtin_fmaf(v.x, cf_k1.x, __builtin_fmaf(q.x, cf_kx, cf_k0));
+      v.y = __builtin_fmaf(v.y, cf_k1.y, __builtin_fmaf(q.y, cf_kx, cf_k0));
+      v.z = __builtin_fmaf(v.z, cf_k1.z, __builtin_fmaf(q.z, cf_kx, cf_k0));
+      v.w = __builtin_fmaf(v.w, cf_k1.w, __builtin_fmaf(q.w, cf_kx, cf_k0));
+      if (INACT) {
         v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
         v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
       }
-      pre[it] = v;
-      {   // (bias gradient: the pixels this tile owns; a select, not a branch)
-        const bool own = item_own(it);
-        bsum.x += own ? v.x : 0.f, bsum.y += own ? v.y : 0.f, bsum.z += own ? v.z : 0.f, bsum.w += own ? v.w : 0.f;
+      v = inside ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (GST) {
+        const u32x4 sv = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(sv, bx_rsrc(a.gnb_out + (f.x - a.x), f.bytes), item_own(it) ? off : BX_OOB, 0, 0);
       }
-      m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.x)), fabsf(v.y));
-      m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.z)), fabsf(v.w));
+    } else if (INACT) {
+      const float4 q = pre2[it];
+      v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
+      v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
     }
-    return f2_wave_max(m);
+    pre[it] = v;
+    {   // (bias gradient: the pixels this tile owns; a select, not a branch)
+      const bool own = item_own(it);
+      bsum.x += own ? v.x : 0.f, bsum.y += own ? v.y : 0.f, bsum.z += own ? v.z : 0.f, bsum.w += own ? v.w : 0.f;
+    }
+    m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.x)), fabsf(v.y));
+    m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.z)), fabsf(v.w));
   };
   const int lds_item = p0 * PS + ((int)threadIdx.x & 7) * 4;
   auto stage_item = [&](int it, float sc) {
@@ -374,6 +392,12 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     //  publishes the weight planes)
   }
 
+  float mg_lane = 0.f;   // this lane's largest halo magnitude of the tile that comes next (formed one tile ahead, see prep_item)
+  if (RIDE && tile < t_hi) {
+    prep_cf(cn);
+#pragma unroll
+    for (int it = 0; it < NLOAD; ++it) prep_item(pfc, it, mg_lane);
+  }
   f32x4 accw[K::NACC];   // dW: this wave's (ci half, co half), tap j
 #pragma unroll
   for (int j = 0; j < K::NACC; ++j) accw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -464,11 +488,18 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         xg_sh[nt] = make_float4(b_.x - xg_sc[nt].x * mean, b_.y - xg_sc[nt].y * mean, b_.z - xg_sc[nt].z * mean, b_.w - xg_sc[nt].w * mean);
       }
     }
-    const float mg = prep(pfc, cn);
+    if (!RIDE) {
+      prep_cf(cn);
+      mg_lane = 0.f;
+#pragma unroll
+      for (int it = 0; it < NLOAD; ++it) prep_item(pfc, it, mg_lane);
+    }
+    const float mg = f2_wave_max(mg_lane);
     float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
       const float4 v = xval(i);
+      if (XGN) cxw[i] = v;   // (final in place: the staging below does not apply the GroupNorm a second time)
       mx = __builtin_fmaxf(__builtin_fmaxf(mx, fabsf(v.x)), fabsf(v.y));
       mx = __builtin_fmaxf(__builtin_fmaxf(mx, fabsf(v.z)), fabsf(v.w));
     }
@@ -504,7 +535,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       const float scx = __builtin_ldexpf(1.f, es);
 #pragma unroll
       for (int i = 0; i < NPIECE; i += 2) {   // (two pieces at a time, stage by stage: see stage_item2)
-        const float4 va = xval(i), vb = xval(i + 1);
+        const float4 va = cxw[i], vb = cxw[i + 1];   // (final since top_a)
         const float x_[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
         f32x2 v_[4], r_[4];
         f16x2_t h1_[4], h2_[4];
@@ -531,6 +562,8 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     advance(n1, ty1, tx1);
     const Pf pfn = pf_make(n1, ty1, tx1, tile + per < t_hi);
     epi_issue(cn, cur_off);
+    if (RIDE) prep_cf(n1);   // (the current tile's items are final: the coefficients may move on to the next tile's sample)
+    float mg_next = 0.f;
     FB_T(3)
     // barrier B: halo, x tile (and, first tile, the weight planes) are complete
     __syncthreads();
@@ -675,6 +708,9 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         __builtin_amdgcn_sched_barrier(0);
         // ky = 1; the next k-step's even pair is fetched under it (into the set ky = 2 has just left)
         if (ks + 1 < 8) load_pair(2 * ks + 4, G0[(ks + 1) & 1]);
+#pragma unroll
+        for (int it = 0; it < NLOAD; ++it)
+          if (RIDE && it * 8 / NLOAD == ks) prep_item(pfn, it, mg_next);   // the next tile's halo items (requested in D) become final
         mm3(ks, 1, G1);
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -684,6 +720,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     cn = n1, cty = ty1, ctx = tx1;
     tile += per;
     pfc = pfn;
+    if (RIDE) mg_lane = mg_next;
   };
 
   int flushed = 0;
