@@ -523,6 +523,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   auto rest = [&]() __attribute__((always_inline)) {
     // ---- staging: the halo with its own per-tile scale, x with 2^(S - sx_e) (a term of dW carries 2^S; where the halo or the x tile
     // is all zero the exponent does not matter)
+#ifndef FB_KO_STAGE   // (diagnostic: nothing is staged - what the phase costs; WRONG results)
     {
       const float sc = __builtin_ldexpf(1.f, sx_e);
       // (one wave per SIMD: nothing hides the latency of a dependent vector instruction, and the compiler keeps source order - the
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         }
       }
     }
+#endif
     FB_T(9)
     // this tile's epilogue operands are requested now (used after D); the next tile's halo and x strip ride in D's first k-steps (a
     // wave issues one 1-KB load per ~16 cycles at best: 19 - 30 of them in a row cost ~2 k cycles per tile in front of barrier B)
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         // the next tile's loads that ride in this k-step (their registers were emptied by the staging above)
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it)
-          if (it * 6 / NLOAD == ks) pf_issue(pfn, it);
+          if (it * 6 / NLOAD == ks) pf_issue(pfn, it);   // (spread over 3 or 9 k-steps, or the x loads moved into W: no measurable difference)
         if (ks >= 6 && ks < 8) x_issue(n1, ty1, tx1, tile + per < t_hi, (ks - 6) * (NPIECE / 2), (ks - 5) * (NPIECE / 2));
         auto mm = [&](int mt0, int mt1) __attribute__((always_inline)) {
 #pragma unroll
@@ -617,6 +619,9 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
                       (ks == 0 && q == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[mt][nt], 0, 0, 0);   // (the first product starts from a zero literal)
               }
         };
+#ifdef FB_KO_D   // (diagnostic: no input-gradient products)
+        if (false)
+#endif
         if (ky == 0 && kx > 0) {
           mm(0, 2);
           __builtin_amdgcn_sched_barrier(0);
@@ -694,24 +699,33 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       load_x(0, fx[0]);
       load_pair(0, G0[1]);   // (k-step 0, ky = 2)
       load_pair(2, G0[0]);   // (k-step 0, ky = 0)
+#ifdef FB_KO_W   // (diagnostic: no dW products / reads; the epilogue and the riding work stay)
+#define FB_MM3(a_, b_, c_)
+#define FB_LP(a_, b_)
+#define FB_LX(a_, b_)
+#else
+#define FB_MM3(a_, b_, c_) mm3(a_, b_, c_)
+#define FB_LP(a_, b_) load_pair(a_, b_)
+#define FB_LX(a_, b_) load_x(a_, b_)
+#endif
       fb_static_for<0, 8>([&](auto kc) __attribute__((always_inline)) {
         constexpr int ks = decltype(kc)::value;
         // ky = 2 (the pair fetched for ky = 0 of the previous k-step); the odd pair of this k-step is fetched under it
-        load_pair(2 * ks + 1, G1);
+        FB_LP(2 * ks + 1, G1);
         if (ks < NPIECE / 2) epi_piece(2 * ks);       // (the input gradient's epilogue rides in the first k-steps: its stores leave early)
-        mm3(ks, 2, G0[(ks + 1) & 1]);
+        FB_MM3(ks, 2, G0[(ks + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
         // ky = 0; the next k-step's x^T fragments are fetched under it
-        if (ks + 1 < 8) load_x(ks + 1, fx[(ks + 1) & 1]);
+        if (ks + 1 < 8) FB_LX(ks + 1, fx[(ks + 1) & 1]);
         if (ks < NPIECE / 2) epi_piece(2 * ks + 1);
-        mm3(ks, 0, G0[ks & 1]);
+        FB_MM3(ks, 0, G0[ks & 1]);
         __builtin_amdgcn_sched_barrier(0);
         // ky = 1; the next k-step's even pair is fetched under it (into the set ky = 2 has just left)
-        if (ks + 1 < 8) load_pair(2 * ks + 4, G0[(ks + 1) & 1]);
+        if (ks + 1 < 8) FB_LP(2 * ks + 4, G0[(ks + 1) & 1]);
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it)
           if (RIDE && it * 8 / NLOAD == ks) prep_item(pfn, it, mg_next);   // the next tile's halo items (requested in D) become final
-        mm3(ks, 1, G1);
+        FB_MM3(ks, 1, G1);
         __builtin_amdgcn_sched_barrier(0);
       });
     }
