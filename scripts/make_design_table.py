@@ -18,10 +18,11 @@ FAMILIES = [
     ('conv_f16x2_kernel', 'two-term fp16 3x3 conv: forward / input gradient, 16 / 32 channels (GroupNorm on load, GroupNorm backward on load, channel sums, deferred block outputs)',
      'csrc/conv_f16x2.hip', 'Conv2d 3x3 + SELU (+ GroupNorm passes next to it) of ResNetBlock / Block2D3D, multi_frame_networks.py:338-345,514-542',
      'HBM (exposed latency in a power-limited clock; 72 flop/B < the 104 flop/B balance of 3 fp16 products)'),
-    ('conv_wgrad_f16x2_kernel', 'two-term fp16 weight gradient (3x3; 4x4 stride 2), slabs per workgroup', 'csrc/conv_f16x2.hip',
-     'the weight / bias gradient of the same convs', 'its own instruction stream (transposing LDS reads, split, 2 barriers per tile); HBM 4 TB/s'),
-    ('conv_bwd_fused_kernel', 'input + weight gradient in one launch (round 6; OFF by default)', 'csrc/conv_bwd_fused.hip', 'one Conv2d backward node',
-     'registers (profiles/r6_bwd_fused.md)'),
+    ('conv_wgrad_f16x2_kernel', 'two-term fp16 weight gradient (3x3 of the 16-channel and 16 <-> 32 layers; 4x4 stride 2), slabs per workgroup', 'csrc/conv_f16x2.hip',
+     'the weight / bias gradient of the convs without a fused instance', 'its own instruction stream (transposing LDS reads, split, 2 barriers per tile); HBM 4 TB/s'),
+    ('conv_bwd_fused_kernel', 'input + weight gradient of a 3x3 conv 32 -> 32 in one launch (round 6), every on-load / epilogue form of the input gradient', 'csrc/conv_bwd_fused.hip',
+     'one Conv2d backward node of ResNetBlock / Block2D3D, multi_frame_networks.py:338-345,514-542',
+     'LDS bandwidth of the transposing reads (dW phase) + serial vector-instruction issue at one wave per SIMD; HBM 3.4 TB/s (profiles/r6_bwd_fused.md)'),
     ('conv3d_bwd2_kernel', 'Conv3D backward, class-ordered deterministic form', 'csrc/conv3d_knn.hip', 'Conv3D backward incl. the gather scatter, multi_frame_networks.py:469-512',
      'dependent-instruction latency at 2 waves per SIMD'),
     ('conv3d_fwd_kernel', 'Conv3D forward (top-9-of-36 selection shared by all blocks)', 'csrc/conv3d_knn.hip', 'Conv3D.forward, :469-512', 'latency of the selection -> geometry -> gather chain'),
