@@ -151,6 +151,10 @@ SIGS = {
     'dis_colsum_bf16': 'piilippp',
     'dis_adam_step': 'pppplfddfifp',
     'dis_adam_step_dev': 'pppplfddfpfp',
+    'dis_allreduce_unique_id': 'p',
+    'dis_allreduce_init': 'ppii',
+    'dis_allreduce_sum_f32': 'pplip',
+    'dis_allreduce_destroy': 'p',
 }
 _RET_LONG = {'dis_conv2d_bwd_fused_workspace', 'dis_convb_pack_desc_bytes', 'dis_convg_splitk_workspace', 'dis_convb_splitk_workspace', 'dis_conv2d_gnsums_slots', 'dis_conv2d_wgrad_workspace', 'dis_convg_pack_workspace', 'dis_convg_wgrad_workspace',
              'dis_colsum_workspace', 'dis_convb_pack_workspace', 'dis_convb_wgrad_workspace', 'dis_colsum_bf16_workspace', 'dis_gn_bwd_workspace', 'dis_act_bwd_ld_bias_workspace', 'dis_conv3d_knn_bwd_workspace', 'dis_geo_loss_acc_doubles', 'dis_geo_loss_multi_acc_doubles', 'dis_conv3d_knn_bwd_det_workspace', 'dis_conv3d_knn_bwd_stage', 'dis_conv3d_csr_workspace', 'dis_gather_csr_workspace',

@@ -32,6 +32,51 @@ def init_distributed(backend=None):
     return rank, world, local_rank
 
 
+class AbiComm(object):
+    """The C ABI's own gradient exchange (include/dis_hip.h: dis_allreduce_*; RCCL bound by the library itself) - what a host
+    that is not PyTorch would use.  torch.distributed (any backend) only carries rank 0's 128-byte id to the other ranks.
+    FlatAdam uses it instead of torch.distributed.all_reduce when DIS_ALLREDUCE=abi."""
+
+    def __init__(self, rank=0, world_size=1, process_group=None, unique_id=None):
+        import ctypes
+        L = ops.lib
+        self._ct = ctypes
+        self.rank, self.world_size = rank, world_size
+        if unique_id is None:
+            buf = ctypes.create_string_buffer(128)
+            if rank == 0:
+                rc = L.fn('dis_allreduce_unique_id')(ctypes.cast(buf, ctypes.c_void_p))
+                if rc != 0:
+                    raise L.DisHipError(f'dis_allreduce_unique_id failed: {rc}')
+            obj = [buf.raw]
+            if world_size > 1:
+                torch.distributed.broadcast_object_list(obj, src=0, group=process_group)
+            unique_id = obj[0]
+        assert len(unique_id) == 128
+        self.unique_id = bytes(unique_id)
+        idb = ctypes.create_string_buffer(self.unique_id, 128)
+        h = ctypes.c_void_p()
+        rc = L.fn('dis_allreduce_init')(ctypes.cast(ctypes.pointer(h), ctypes.c_void_p), ctypes.cast(idb, ctypes.c_void_p), world_size, rank)
+        if rc != 0:
+            raise L.DisHipError(f'dis_allreduce_init failed: {rc}')
+        self.handle = h
+
+    def all_reduce(self, t, average=False):
+        """in place on a contiguous fp32 device tensor, asynchronous on the current stream"""
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        ops.lib.call('dis_allreduce_sum_f32', self.handle.value, t, t.numel(), 1 if average else 0)
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            ops.lib.fn('dis_allreduce_destroy')(self.handle)
+            self.handle = None
+
+
+class _Done(object):
+    def wait(self):
+        pass
+
+
 class FlatAdam(object):
     """Adam with torch.optim.Adam's default hyper-parameters on a flattened view of `params`.
 
@@ -78,6 +123,11 @@ class FlatAdam(object):
         self.world_size = world_size
         self.process_group = process_group
         self.overlap = bool(overlap) and world_size > 1
+        # DIS_ALLREDUCE=abi: the exchange goes through the C ABI's dis_allreduce_* (the library's own RCCL binding) instead of
+        # torch.distributed.all_reduce - same buckets, same streams
+        self._abi = None
+        if world_size > 1 and dev.type == 'cuda' and os.environ.get('DIS_ALLREDUCE', '') == 'abi':
+            self._abi = AbiComm(torch.distributed.get_rank(process_group), world_size, process_group)
         if dev.type == 'cuda':
             ops.register_grad_sinks(self.params, self._notify if self.overlap else None)
         # ---- buckets (reverse parameter order)
@@ -131,7 +181,11 @@ class FlatAdam(object):
             ev.record(torch.cuda.current_stream())
             self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
-                w = torch.distributed.all_reduce(view, group=self.process_group, async_op=True)
+                if self._abi is not None:
+                    self._abi.all_reduce(view)
+                    w = _Done()
+                else:
+                    w = torch.distributed.all_reduce(view, group=self.process_group, async_op=True)
         else:
             w = torch.distributed.all_reduce(view, group=self.process_group, async_op=True)
         self._works.append(w)
@@ -186,7 +240,10 @@ class FlatAdam(object):
 
     def all_reduce_grads(self):
         if self.world_size > 1:
-            torch.distributed.all_reduce(self.flat_g, group=self.process_group)
+            if self._abi is not None:
+                self._abi.all_reduce(self.flat_g)
+            else:
+                torch.distributed.all_reduce(self.flat_g, group=self.process_group)
 
     @property
     def step_count(self):

@@ -687,6 +687,22 @@ int dis_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int dis_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long count, float lr,
                       double beta1, double beta2, float eps, int* state, float grad_scale, void* stream);
 
+/* ---------------------------------------------------------------- gradient exchange -------- */
+
+/* The data-parallel step's collective behind the C ABI (ONE all-reduce of the flat fp32 gradient per
+ * step, mean of the per-rank gradients; the reference itself is single-GPU, train_val.py:55-56, and has no counterpart).  RCCL is
+ * bound at the first call (dlopen by soname: a process that already holds torch's copy keeps ONE RCCL); DIS_ERR_UNSUPPORTED when no
+ * librccl can be found.  RCCL's own errors come back as 10000 + ncclResult_t.
+ *   dis_allreduce_unique_id: rank 0 fills 128 bytes (ncclUniqueId) and hands them to the other ranks by its own means;
+ *   dis_allreduce_init:      every rank, collectively; *comm is an opaque handle owned by the caller (dis_allreduce_destroy);
+ *   dis_allreduce_sum_f32:   in place on `count` floats of device memory, asynchronous on `stream`; average != 0: the sum / nranks
+ *                            (ncclAvg) - the DP mean, so that dis_adam_step runs with grad_scale 1; count 0 is a no-op.
+ * One process per GPU, the device current at dis_allreduce_init is the communicator's. */
+int dis_allreduce_unique_id(void* id128);
+int dis_allreduce_init(void** comm, const void* id128, int nranks, int rank);
+int dis_allreduce_sum_f32(void* comm, float* buf, long count, int average, void* stream);
+int dis_allreduce_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif
