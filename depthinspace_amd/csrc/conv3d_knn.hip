@@ -434,6 +434,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_bwd_kernel(const float4* __rest
       for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
+#ifdef C3_KO_MFMA
+          if (r == 0 && ms == 0)
+#endif
           dh1 = __builtin_amdgcn_mfma_f32_16x16x4f32(L.w2[(ms * 16 + Q.lg * 4 + r) * C3_W2S + Q.li], dpre2[ms][r], dh1, 0,
                                                      0, 0);
 #pragma unroll
@@ -462,6 +465,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_bwd_kernel(const float4* __rest
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
+#ifdef C3_KO_MFMA
+          if (r == 0)
+#endif
           accW2[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpre2D[mt][r], h1D[r], accW2[mt], 0, 0, 0);
       // feature gradient: 128-B rows (2 pixels per wave instruction) of float atomics
 #pragma unroll
@@ -693,7 +699,11 @@ __device__ __forceinline__ void c3_mlp_lds(const C3Lds2& L, int li, int lg, cons
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) pre[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][e], h1[e], pre[mt], 0, 0, 0);
+    for (int mt = 0; mt < 2; ++mt)
+#ifdef C3_KO_MFMA   // (diagnostic: one product instead of four - WRONG results; what the exact-fp32 products cost)
+      if (e == 0)
+#endif
+      pre[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][e], h1[e], pre[mt], 0, 0, 0);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const f32x4 b = *(const f32x4*)(L.B2 + mt * 16 + lg * 4);
@@ -813,15 +823,40 @@ __global__ __launch_bounds__(256, C3D_WPE) void conv3d_bwd2_kernel(const float4*
   const int hw = d.h * d.w;
   const __amdgpu_buffer_rsrc_t wf_rs = bx_rsrc(wf, (unsigned)d.tl * d.bs * hw * (C3_TL * C3_C * 4u));
   const __amdgpu_buffer_rsrc_t gwf_rs = bx_rsrc(gwf, (unsigned)d.tl * d.bs * hw * (C3_TL * C3_C * 4u));
-  for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
-    const int il = grp * C3_GP + Q.li;
-    const bool pv = il < total;
-    const unsigned ilc = pv ? il : total - 1;
+  // ---- one group ahead: the selection ids of a group's pixels.  ids -> {neighbour geometry, feature rows, gradient rows} were two
+  // DEPENDENT global round trips in front of everything else a group does (a wave has ~3 groups per launch and one partner wave on
+  // its SIMD: nothing hid them).  The next group's ids are requested before the neighbour loop of the current one - unconditionally
+  // (the last group asks for its own again): a load under a condition inside the rolled loop would make every wait behind it
+  // conservative - so a group starts with its ids in registers and everything that depends on them is ONE round trip.
+  auto decode = [&](int g_, bool& pv_, int& i_, int& oy_, int& ox_, int& tb_) {
+    const int il = g_ * C3_GP + Q.li;
+    pv_ = il < total;
+    const unsigned ilc = pv_ ? il : total - 1;
     const unsigned t1 = ilc / (unsigned)nx;
-    const int ox = cx + cn * (int)(ilc - t1 * nx);
-    const int tb = (int)(t1 / (unsigned)ny);
-    const int oy = cy + cn * (int)(t1 - (unsigned)tb * ny);
-    const int i = (tb * d.ho + oy) * d.wo + ox;
+    ox_ = cx + cn * (int)(ilc - t1 * nx);
+    tb_ = (int)(t1 / (unsigned)ny);
+    oy_ = cy + cn * (int)(t1 - (unsigned)tb_ * ny);
+    i_ = (tb_ * d.ho + oy_) * d.wo + ox_;
+  };
+  auto load_ids = [&](bool pv_, int i_, unsigned (&id_)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int n = Q.lg + 4 * k;
+      id_[k] = 0xffu;
+      if (n < C3_NB && pv_) id_[k] = idx[i_ * C3_NB + n];
+    }
+  };
+  const int gstep = gridDim.x * 4;
+  bool pvN = false;
+  int iN = 0, oyN = 0, oxN = 0, tbN = 0;
+  unsigned idN[3] = {0xffu, 0xffu, 0xffu};
+  if ((int)(blockIdx.x * 4 + wave) < ngroups) {
+    decode(blockIdx.x * 4 + wave, pvN, iN, oyN, oxN, tbN);
+    load_ids(pvN, iN, idN);
+  }
+  for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gstep) {
+    const bool pv = pvN;
+    const int i = iN, oy = oyN, ox = oxN, tb = tbN;
     const float4 ctr = geom[(long)(tb * hw + oy * d.stride * d.w + ox * d.stride) * C3_TL];
     // ---- rows of the 9 neighbours (lane (li, lg): neighbours lg, lg + 4, lg + 8 of pixel li), then their geometry
     int myrow[3];
@@ -831,7 +866,7 @@ __global__ __launch_bounds__(256, C3D_WPE) void conv3d_bwd2_kernel(const float4*
       const int n = Q.lg + 4 * k;
       myrow[k] = -1;
       if (n < C3_NB && pv) {
-        const unsigned id = idx[i * C3_NB + n];
+        const unsigned id = idN[k];
         const unsigned tap = id >> 2, slot = id & 3, ty = (tap * 11u) >> 5;   // (C3_TL = 4; tap / 3 for tap < 9)
         const int iy = oy * d.stride - 1 + (int)ty, ix = ox * d.stride - 1 + (int)(tap - 3 * ty);
         if ((unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w) myrow[k] = (tb * hw + iy * d.w + ix) * C3_TL + (int)slot;
@@ -843,6 +878,12 @@ __global__ __launch_bounds__(256, C3D_WPE) void conv3d_bwd2_kernel(const float4*
     for (int k = 0; k < 3; ++k) {
       qn[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (myrow[k] >= 0) qn[k] = geom[myrow[k]];
+    }
+    // ---- the next group's ids (this group's own again when it is the wave's last)
+    {
+      const int gn = grp + gstep < ngroups ? grp + gstep : grp;
+      decode(gn, pvN, iN, oyN, oxN, tbN);
+      load_ids(pvN, iN, idN);
     }
     // ---- gy, y, agg of the group
     f32x4 gpre[2], aggv[2];
