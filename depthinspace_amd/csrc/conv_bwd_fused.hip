@@ -112,6 +112,10 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   // their own tile.  Not where the accumulating GroupNorm-backward forms already fill the register file: measured 163 -> 188 us
   // (coef + act' + accumulate) and 196 -> 222 us (chain) with it, 139 -> 129 / 164 -> 157 us for the forms that have room.
   constexpr bool RIDE = !(INCOEF && ACCUM);
+  // XSH: x IS one of the epilogue's operands (XSRC 1: the GroupNorm input of the channel sums, XSRC 2: the activation output): one
+  // register set and one fetch serve both.  The epilogue of tile t reads piece i in W's k-steps 0 - 3, so the NEXT tile's x pieces
+  // are requested right behind it there (not in D's last k-steps): 32 registers and 8 loads per thread and tile less.
+  constexpr bool XSH = XSRC != 0;
   static_assert(EPIACT == 0 || EPIAB, "activation gradient at the output: only with the channel sums");
   static_assert(XSRC == 0 || (XSRC == 1 && EPIAB) || (XSRC == 2 && EPIACT), "shared x operand");
   static_assert(!GST || INCOEF, "gpre store: only where the operand is formed on load");
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
   // sums (EPIAB), the activation output (EPIACT) - fetched at the top of their own tile, used after the input-gradient products
   const int yrow = a.wf * (C * 4);
   const int y_lane = ((wave * MT * a.wf + li) * C + lg * 4) * 4;
-  float4 cxw[NPIECE], cy[ACCUM ? NPIECE : 1], cab[EPIAB ? NPIECE : 1], cact[EPIACT ? NPIECE : 1];
+  float4 cxw[NPIECE], cy[ACCUM ? NPIECE : 1], cab[EPIAB && XSRC != 1 ? NPIECE : 1], cact[EPIACT && XSRC != 2 ? NPIECE : 1];
   const float* wx_base = XSRC == 1 ? a.ab_x : (XSRC == 2 ? a.ab_act_y : fa_.wx);
   auto centre_off = [&](int ty, int tx, unsigned (&off)[MT]) {
 #ifdef FB_KO_LOAD
@@ -326,8 +330,8 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     for (int i = 0; i < NPIECE; ++i) {
       const unsigned o = off[i / NT] + (i % NT) * 64;
       if (ACCUM) cy[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.y + sb, y_bytes), o, 0, 0));
-      if (EPIAB) cab[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.ab_x + sb, y_bytes), o, 0, 0));
-      if (EPIACT) cact[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.ab_act_y + sb, y_bytes), o, 0, 0));
+      if (EPIAB && XSRC != 1) cab[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.ab_x + sb, y_bytes), o, 0, 0));
+      if (EPIACT && XSRC != 2) cact[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bx_rsrc(a.ab_act_y + sb, y_bytes), o, 0, 0));
     }
   };
 
@@ -499,7 +503,6 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
       const float4 v = xval(i);
-      if (XGN) cxw[i] = v;   // (final in place: the staging below does not apply the GroupNorm a second time)
       mx = __builtin_fmaxf(__builtin_fmaxf(mx, fabsf(v.x)), fabsf(v.y));
       mx = __builtin_fmaxf(__builtin_fmaxf(mx, fabsf(v.z)), fabsf(v.w));
     }
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       const float scx = __builtin_ldexpf(1.f, es);
 #pragma unroll
       for (int i = 0; i < NPIECE; i += 2) {   // (two pieces at a time, stage by stage: see stage_item2)
-        const float4 va = cxw[i], vb = cxw[i + 1];   // (final since top_a)
+        const float4 va = xval(i), vb = xval(i + 1);
         const float x_[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
         f32x2 v_[4], r_[4];
         f16x2_t h1_[4], h2_[4];
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it)
           if (it * 6 / NLOAD == ks) pf_issue(pfn, it);   // (spread over 3 or 9 k-steps, or the x loads moved into W: no measurable difference)
-        if (ks >= 6 && ks < 8) x_issue(n1, ty1, tx1, tile + per < t_hi, (ks - 6) * (NPIECE / 2), (ks - 5) * (NPIECE / 2));
+        if (!XSH && ks >= 6 && ks < 8) x_issue(n1, ty1, tx1, tile + per < t_hi, (ks - 6) * (NPIECE / 2), (ks - 5) * (NPIECE / 2));
         auto mm = [&](int mt0, int mt1) __attribute__((always_inline)) {
 #pragma unroll
           for (int q = 0; q < 3; ++q)
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         o += (f32x4){q.x, q.y, q.z, q.w};
       }
       if (EPIACT) {
-        const float4 q = cact[EPIACT ? i : 0];
+        const float4 q = XSRC == 2 ? cxw[i] : cact[EPIACT && XSRC != 2 ? i : 0];
         o *= (f32x4){act_grad_from_out(q.x, EPIACT), act_grad_from_out(q.y, EPIACT), act_grad_from_out(q.z, EPIACT),
                      act_grad_from_out(q.w, EPIACT)};
       }
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       __builtin_amdgcn_raw_buffer_store_b128(ov, bx_rsrc(cur_y, y_bytes), cur_off[mt] + nt * 64, 0, 0);
 #endif
       if (EPIAB) {
-        const float4 xv = cab[EPIAB ? i : 0];
+        const float4 xv = XSRC == 1 ? cxw[i] : cab[EPIAB && XSRC != 1 ? i : 0];
         const float g0 = o[0] * livef, g1 = o[1] * livef, g2 = o[2] * livef, g3 = o[3] * livef;
         sA[nt][0] += g0, sA[nt][1] += g1, sA[nt][2] += g2, sA[nt][3] += g3;
         sB[nt][0] = __builtin_fmaf(g0, xv.x, sB[nt][0]), sB[nt][1] = __builtin_fmaf(g1, xv.y, sB[nt][1]);
@@ -722,6 +725,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         __builtin_amdgcn_sched_barrier(0);
         // ky = 1; the next k-step's even pair is fetched under it (into the set ky = 2 has just left)
         if (ks + 1 < 8) FB_LP(2 * ks + 4, G0[(ks + 1) & 1]);
+        if (XSH && ks < NPIECE / 2) x_issue(n1, ty1, tx1, tile + per < t_hi, 2 * ks, 2 * ks + 2);   // (behind the epilogue's pieces 2 ks, 2 ks + 1)
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it)
           if (RIDE && it * 8 / NLOAD == ks) prep_item(pfn, it, mg_next);   // the next tile's halo items (requested in D) become final
