@@ -2242,7 +2242,8 @@ static int launch_wgrad_bf16x3(WgArgs a, float* gw, float* gb, int cin_real, hip
  *   too when that is non-null); coef == null: g itself (in_act == 0) or g act'(q) (q = the conv's activated output).
  *   input gradient: exactly dis_conv2d_dgrad_f16x2_gnb's forms (accumulate, ab_gn_x / ab_act_y / ab_out) - gx is bit-identical to it.
  *   weight gradient: x = the conv's input (n, hin, win, c); x_gn_stats != null: x is staged as GroupNorm(x) (dis_conv2d_wgrad_bf16x3_gn).
- *   x may be the same tensor as ab_gn_x or ab_act_y (it is then fetched once).  grad_w (c, c, 3, 3), grad_b (c) or null;
+ *   x may be the same tensor as ab_gn_x or ab_act_y (it is then fetched once).  grad_w (c, c, 3, 3) with rows grad_w_row_stride
+ *   floats apart (0: contiguous; the slice of a wider OIHW gradient otherwise), grad_b (c) or null;
  *   workspace: dis_conv2d_bwd_fused_workspace(c) floats.
  * DIS_ERR_UNSUPPORTED: no instance for this combination (the caller keeps the two launches). */
 extern "C" long dis_conv2d_bwd_fused_workspace(int c) {
@@ -2255,7 +2256,7 @@ extern "C" int dis_conv2d_bwd_fused_f16x2(const float* g, const float* q, const 
                                           const float* ab_gn_x, const float* ab_act_y, double* ab_out, const float* x,
                                           const double* x_gn_stats, const float* x_gn_gamma, const float* x_gn_beta, float x_gn_eps,
                                           float* grad_w, float* grad_b, float* workspace, int n, int hin, int win, int c,
-                                          void* stream) {
+                                          int grad_w_row_stride, void* stream) {
   if (!g || !w_oihw || !gx || !x || !grad_w || !workspace) return DIS_ERR_NULL;
   if (n <= 0 || hin <= 0 || win <= 0) return DIS_ERR_BAD_SHAPE;
   if (c != 32 || w_o != c || w_i != c) return DIS_ERR_UNSUPPORTED;
@@ -2266,6 +2267,10 @@ extern "C" int dis_conv2d_bwd_fused_f16x2(const float* g, const float* q, const 
   if (x_gn_stats && (!x_gn_gamma || !x_gn_beta)) return DIS_ERR_NULL;
   if (w_row_stride == 0) w_row_stride = w_i * 9;
   if (w_row_stride < w_i * 9) return DIS_ERR_BAD_SHAPE;
+  // grad_w may be the (c, c, 3, 3) slice of a wider OIHW gradient (conv over a channel concatenation): its rows are then
+  // grad_w_row_stride floats apart (a multiple of 9: whole input channels), 0 = contiguous
+  if (grad_w_row_stride == 0) grad_w_row_stride = c * 9;
+  if (grad_w_row_stride < c * 9 || grad_w_row_stride % 9) return DIS_ERR_BAD_SHAPE;
   static const bool off = getenv("DIS_BWD_FUSED") && getenv("DIS_BWD_FUSED")[0] == '0';
   if (off || !dis_f2_enabled()) return DIS_ERR_UNSUPPORTED;
   if ((long)hin * win * c * 4 >= 0x7fff0000L) return DIS_ERR_UNSUPPORTED;
@@ -2304,8 +2309,8 @@ extern "C" int dis_conv2d_bwd_fused_f16x2(const float* g, const float* q, const 
   if (le != hipSuccess) return (int)le;
   const long total = (long)C::MROWS * 32;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_grid(total, grad_b != nullptr)), dim3(64 * WG_RW), 0, s,
-                     (const float*)f.part, grad_w, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, 32, 32, C::PART,
-                     (const float*)(grad_b ? f.bpart : nullptr), grad_b, (int)grid);
+                     (const float*)f.part, grad_w, C::CINB, C::NCHUNK, C::NSPLIT, C::KHB, 3, 3, 32, grad_w_row_stride / 9, C::PART,
+                     (const float*)(grad_b ? f.bpart : nullptr), grad_b, (int)grid);   // (cin_real = the row pitch in input channels)
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }

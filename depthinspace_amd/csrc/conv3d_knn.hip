@@ -729,7 +729,9 @@ __device__ __forceinline__ void c3_mlp_lds(const C3Lds2& L, int li, int lg, cons
 // (Tried and dropped: a block of 3 waves per group, 3 neighbours each, to shorten a class launch's critical path - the per-group
 //  work every wave repeats made it slower: 44 us per class launch of 1536 groups.)
 // ================================================================================================
+#ifndef C3D_CAP
 #define C3D_CAP 768             // blocks per launch (at most)
+#endif
 #pragma clang fp contract(fast)  // (tolerance-checked gradients: fused multiply-adds from here on; the forward and the selection keep every rounding)
 
 #ifdef C3_STAMP   // diagnostic build (scripts/diag/conv3d_bwd_modes.py --stamps): phase time stamps of one wave's first group

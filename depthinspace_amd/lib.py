@@ -86,7 +86,7 @@ SIGS = {
     'dis_gn_bwd_apply_coef': 'ppppiliip',
     'dis_conv2d_dgrad_f16x2_gnb': 'pppippiiipippp' + 'iiiip',
     'dis_conv2d_bwd_fused_workspace': 'i',
-    'dis_conv2d_bwd_fused_f16x2': 'pppippiiipippp' + 'pppp' + 'f' + 'ppp' + 'iiiip',
+    'dis_conv2d_bwd_fused_f16x2': 'pppippiiipippp' + 'pppp' + 'f' + 'ppp' + 'iiiiip',
     'dis_conv2d_wgrad_bf16x3_gn': 'ppppfppppiiiiiiiiip',
     'dis_conv2d_fwd_scaled': 'ppppppp' + 'iiiiiiiii' + 'p',
     'dis_conv2d_wgrad_scaled': 'pppppp' + 'iiiiiiiii' + 'p',

@@ -34,7 +34,7 @@ def _c(t):
 # A slice is handed out at most once between two clears; without begin_step (tests, inference) the arena simply runs
 # out and plain torch.zeros takes over.
 _ARENA = {}
-_ARENA_DOUBLES = int(_os_env.environ.get('DIS_ARENA_DOUBLES', 1 << 23))   # 64 MiB: the per-workgroup channel-sum slots of the GroupNorm backward are 2 MiB per launch, ~30 per step
+_ARENA_DOUBLES = int(_os_env.environ.get('DIS_ARENA_DOUBLES', 3 << 22))   # 96 MiB (64 MiB sent 7 requests per DIS-MF step to torch.zeros): the per-workgroup channel-sum slots of the GroupNorm backward are 2 MiB per launch, ~30 per step
 
 
 # gradient tensors whose producer already left the GroupNorm-backward sums (see _Conv2d.backward / _GroupNorm.backward):
@@ -1074,6 +1074,17 @@ BWD_FUSED = _os.environ.get('DIS_BWD_FUSED', '1') != '0'
 _FUSED_WS = {}
 
 
+# DIS_GW_INPLACE=0: conv2d_multi's fused launches write their weight-gradient slice to a temporary that is copied into the full
+# gradient afterwards (the form before the slab reduce took a row pitch; A/B only)
+GW_INPLACE = _os_env.environ.get('DIS_GW_INPLACE', '1') != '0'
+
+
+def _gw_slice(gw, off, cs_i):
+    if GW_INPLACE:
+        return gw[:, off:off + cs_i]
+    return torch.empty((gw.shape[0], cs_i, gw.shape[2], gw.shape[3]), dtype=torch.float32, device=gw.device)
+
+
 def _bwd_fused_ok(cin, cout, k, stride, pad):
     return BWD_FUSED and BF16X3 and cin == 32 and cout == 32 and k == 3 and stride == 1 and pad == 1
 
@@ -1089,8 +1100,11 @@ def _bwd_fused(g, q, coef, in_act, gpre_out, weight, gx, accumulate, ab_x, ab_ac
         return False
     ws = torch.empty(wsz, dtype=torch.float32, device=x.device)
     st, gam, bet, eps = xgn if xgn is not None else (None, None, None, 0.0)
+    # gw may be the (c, c, 3, 3) slice of a wider OIHW gradient (conv2d_multi): the slab reduce writes it in place
+    assert tuple(gw.stride()[1:]) == (9, 3, 1) and gw.stride(0) % 9 == 0
     return lib.call_try('dis_conv2d_bwd_fused_f16x2', g, q, coef, in_act, gpre_out, weight, weight.shape[0], weight.shape[1],
-                        weight.stride(0), gx, 1 if accumulate else 0, ab_x, ab_act, ab, x, st, gam, bet, float(eps), gw, gb, ws, n, h, w, c)
+                        weight.stride(0), gx, 1 if accumulate else 0, ab_x, ab_act, ab, x, st, gam, bet, float(eps), gw, gb, ws, n, h, w, c,
+                        0 if gw.is_contiguous() else gw.stride(0))
 
 
 def _bx_shape(cin, cout, k, stride):
@@ -1554,7 +1568,7 @@ class _Conv2dMulti(torch.autograd.Function):
                             if _bwd_fused_ok(cs[0], cout, k, 1, pad) and need_w[0] is None:
                                 # one launch: operand formed on load (stored for the other sources' launches), input gradient +
                                 # channel sums, and this slice's weight / bias gradient with GroupNorm(x) on load
-                                gw0 = torch.empty((cout, cs[0], k, k), dtype=torch.float32, device=x.device)
+                                gw0 = _gw_slice(gw, off, cs[0])   # (the slab reduce writes the slice of the full gradient in place)
                                 if _bwd_fused(lg, lq, lcoef, lin_act, gpre, wi, gnorm, False, x, None, ab, x,
                                               (gn_stats, gn_gamma, ctx.beta_ref, float(gn_meta[0])), gw0, gb if has_bias else None, n, h, w):
                                     need_w[0] = gw0
@@ -1593,7 +1607,7 @@ class _Conv2dMulti(torch.autograd.Function):
                 elif fuse_act:
                     if _bwd_fused_ok(cs[i], cout, k, 1, pad) and lib.fn('dis_get_conv_split')() == 1:
                         # (ref_conv's 32-channel slice: gy act'(y) feeds the input gradient and the weight gradient in one launch)
-                        gwf = torch.empty((cout, cs[i], k, k), dtype=torch.float32, device=x.device)
+                        gwf = _gw_slice(gw, off, cs[i])
                         if _bwd_fused(gy, y, None, act, None, wi, gx, False, None, None, None, x, None, gwf,
                                       gb if (i == 0 and has_bias) else None, n, h, w):
                             need_w[0] = gwf
@@ -1611,7 +1625,7 @@ class _Conv2dMulti(torch.autograd.Function):
                     lz = None
                 else:
                     if _bwd_fused_ok(cs[i], cout, k, 1, pad) and lib.fn('dis_get_conv_split')() == 1:
-                        gwf = torch.empty((cout, cs[i], k, k), dtype=torch.float32, device=x.device)
+                        gwf = _gw_slice(gw, off, cs[i])
                         if _bwd_fused(gpre, None, None, ACT_NONE, None, wi, gx, False, None, None, None, x, None, gwf,
                                       gb if (i == 0 and has_bias) else None, n, h, w):
                             need_w[0] = gwf
@@ -1620,8 +1634,9 @@ class _Conv2dMulti(torch.autograd.Function):
                                       k - 1 - pad, ACT_NONE)
             assert lz is None   # (redeemed by the first source's launch: ctx.lazy_ok guarantees that it has one)
             gxs.append(gx)
-            if need_w[0] is not None:   # (the fused launch above has left this slice's weight gradient)
-                gw[:, off:off + cs[i]].copy_(need_w[0])
+            if need_w[0] is not None:   # (the fused launch above has written this slice of the weight gradient in place)
+                if not GW_INPLACE:
+                    gw[:, off:off + cs[i]].copy_(need_w[0])
                 need_w[0] = None
                 off += cs[i]
                 continue

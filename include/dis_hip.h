@@ -401,7 +401,8 @@ int dis_conv2d_dgrad_f16x2_gnb(const float* g, const float* q, const float* coef
  *     gpre_out when that is non-NULL); coef == NULL: g (in_act == 0) or g act'(q) (q = the conv's activated output).
  *   input gradient gx: dis_conv2d_dgrad_f16x2_gnb's forms (accumulate, ab_gn_x / ab_act_y / ab_out) - bit-identical results.
  *   weight gradient: x (n, hin, win, c) = the conv's input; x_gn_stats != NULL: staged as GroupNorm(x) (dis_conv2d_wgrad_bf16x3_gn);
- *     x may be the tensor ab_gn_x or ab_act_y (fetched once).  grad_w (c, c, 3, 3), grad_b (c) or NULL;
+ *     x may be the tensor ab_gn_x or ab_act_y (fetched once).  grad_w (c, c, 3, 3), rows grad_w_row_stride floats apart (0 = contiguous;
+ *     a multiple of 9 >= 9 c: the slice of a wider OIHW gradient, e.g. of a conv over a channel concatenation), grad_b (c) or NULL;
  *     workspace: dis_conv2d_bwd_fused_workspace(c) floats (-1: no kernel for this channel count).
  * DIS_ERR_UNSUPPORTED: no instance for the combination / the three-term mode / DIS_BWD_FUSED=0 (the caller keeps the two launches). */
 long dis_conv2d_bwd_fused_workspace(int c);
@@ -409,7 +410,7 @@ int dis_conv2d_bwd_fused_f16x2(const float* g, const float* q, const float* coef
                                int w_o, int w_i, int w_row_stride, float* gx, int accumulate, const float* ab_gn_x,
                                const float* ab_act_y, double* ab_out, const float* x, const double* x_gn_stats,
                                const float* x_gn_gamma, const float* x_gn_beta, float x_gn_eps, float* grad_w, float* grad_b,
-                               float* workspace, int n, int hin, int win, int c, void* stream);
+                               float* workspace, int n, int hin, int win, int c, int grad_w_row_stride, void* stream);
 int dis_conv2d_wgrad_bf16x3_gn(const float* x, const double* gn_stats, const float* gn_gamma, const float* gn_beta,
                                float gn_eps, const float* gy, float* grad_w, float* grad_b, float* workspace, int n,
                                int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad,

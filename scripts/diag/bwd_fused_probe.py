@@ -21,7 +21,7 @@ def main():
     n, c = 16, 32
     g_ = torch.Generator().manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g_).cuda()
-    q0 = rnd(n, h, w, c)
+    q0 = rnd(n, h, w, c, 0)
     gq = rnd(n, h, w, c)
     wt = (rnd(c, c, 3, 3) * 0.05).contiguous()
     x = rnd(n, h, w, c)
@@ -81,7 +81,7 @@ def main():
         def new():
             ok = L.call_try('dis_conv2d_bwd_fused_f16x2', gq, q if (cf or in_act) else None, coef, in_act, None, wt, c, c, wt.stride(0), gx,
                             1 if accum else 0, ab_x, act_y, ab, xx, xst if xgn else None, xgam if xgn else None, xbet if xgn else None,
-                            1e-5, gw, gb, ws, n, h, w, c)
+                            1e-5, gw, gb, ws, n, h, w, c, 0)
             assert ok
 
         t = {'old': [], 'new': []}

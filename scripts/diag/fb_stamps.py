@@ -15,11 +15,11 @@ gx = torch.empty_like(x); gw = torch.empty(c, c, 3, 3, device='cuda'); gb = torc
 ws = torch.empty(L.fn('dis_conv2d_bwd_fused_workspace')(c), dtype=torch.float32, device='cuda')
 for _ in range(3):
     assert L.call_try('dis_conv2d_bwd_fused_f16x2', gq, None, None, 0, None, wt, c, c, wt.stride(0), gx, 0, None, None, None, x, None, None, None,
-                      1e-5, gw, gb, ws, n, h, w, c)
+                      1e-5, gw, gb, ws, n, h, w, c, 0)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-L.call_try('dis_conv2d_bwd_fused_f16x2', gq, None, None, 0, None, wt, c, c, wt.stride(0), gx, 0, None, None, None, x, None, None, None, 1e-5, gw, gb, ws, n, h, w, c)
+L.call_try('dis_conv2d_bwd_fused_f16x2', gq, None, None, 0, None, wt, c, c, wt.stride(0), gx, 0, None, None, None, x, None, None, None, 1e-5, gw, gb, ws, n, h, w, c, 0)
 e1.record(); torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (256 * 4 * 12))()
 lib = L.load()

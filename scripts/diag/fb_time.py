@@ -9,7 +9,7 @@ wt = (torch.randn(c, c, 3, 3, generator=g_) * 0.05).cuda()
 gx = torch.empty_like(x); gw = torch.empty(c, c, 3, 3, device='cuda'); gb = torch.empty(c, device='cuda')
 ws = torch.empty(L.fn('dis_conv2d_bwd_fused_workspace')(c), dtype=torch.float32, device='cuda')
 def run():
-    L.call_try('dis_conv2d_bwd_fused_f16x2', gq, None, None, 0, None, wt, c, c, wt.stride(0), gx, 0, None, None, None, x, None, None, None, 1e-5, gw, gb, ws, n, h, w, c)
+    L.call_try('dis_conv2d_bwd_fused_f16x2', gq, None, None, 0, None, wt, c, c, wt.stride(0), gx, 0, None, None, None, x, None, None, None, 1e-5, gw, gb, ws, n, h, w, c, 0)
 for _ in range(5): run()
 ts = []
 for r in range(7):

@@ -113,7 +113,7 @@ def test_bwd_fused_matches_the_two_launches(form, n, h, w):
     ws2 = torch.empty(L.fn('dis_conv2d_bwd_fused_workspace')(c), dtype=torch.float32, device='cuda')
     ok = L.call_try('dis_conv2d_bwd_fused_f16x2', gq, q if (coef_form or in_act) else None, coef, in_act, gpre, wt, c, c, wt.stride(0), gx,
                     1 if accum else 0, ab_x, act_y, ab, x, xg[0] if xgn else None, xg[1] if xgn else None, xg[2] if xgn else None, 1e-5,
-                    gw, gb, ws2, n, h, w, c)
+                    gw, gb, ws2, n, h, w, c, 0)
     if not ok:
         pytest.skip('no instance for this form in this build')
     torch.cuda.synchronize()
@@ -155,7 +155,7 @@ def test_bwd_fused_is_reproducible_and_handles_extreme_ranges():
         gw, gb = torch.empty(c, c, 3, 3, device='cuda'), torch.empty(c, device='cuda')
         ws = torch.empty(wsz, dtype=torch.float32, device='cuda')
         if not L.call_try('dis_conv2d_bwd_fused_f16x2', gy, None, None, 0, None, wt, c, c, wt.stride(0), gx, 0, None, None, None, x, None,
-                          None, None, 1e-5, gw, gb, ws, n, h, w, c):
+                          None, None, 1e-5, gw, gb, ws, n, h, w, c, 0):
             pytest.skip('no instance')
         outs.append((gx, gw, gb))
     torch.cuda.synchronize()
@@ -165,3 +165,41 @@ def test_bwd_fused_is_reproducible_and_handles_extreme_ranges():
     assert bool(torch.isfinite(outs[0][1]).all())
     assert float((outs[0][1].double() - gw64).abs().max()) < 1e-6 * float(gw64.abs().max())
     assert float((outs[0][2].double() - gb64).abs().max()) < 1e-6 * float(gb64.abs().max())
+
+
+def test_bwd_fused_writes_a_slice_of_a_wider_weight_gradient():
+    """grad_w_row_stride: the slab reduce writes the (32, 32, 3, 3) slice of a (32, 96, 3, 3) gradient in place (conv2d_multi's
+    conv over a channel concatenation): the slice equals the contiguous result bit for bit, the rest of the tensor is untouched."""
+    from depthinspace_amd import ops
+    L = ops.lib
+    if L.fn('dis_get_conv_split')() != 1:
+        pytest.skip('two-term fp16 kernels only')
+    n, h, w, c = 2, 40, 56, 32
+    g_ = torch.Generator().manual_seed(5)
+    gy = torch.randn(n, h, w, c, generator=g_).cuda()
+    x = torch.randn(n, h, w, c, generator=g_).cuda()
+    wt = (torch.randn(c, c, 3, 3, generator=g_) * 0.05).cuda()
+    wsz = L.fn('dis_conv2d_bwd_fused_workspace')(c)
+
+    def run(gw, stride):
+        gx, gb = torch.empty_like(x), torch.empty(c, device='cuda')
+        ws = torch.empty(wsz, dtype=torch.float32, device='cuda')
+        ok = L.call_try('dis_conv2d_bwd_fused_f16x2', gy, None, None, 0, None, wt, c, c, wt.stride(0), gx, 0, None, None, None, x, None,
+                        None, None, 1e-5, gw, gb, ws, n, h, w, c, stride)
+        torch.cuda.synchronize()
+        return ok, gx, gb
+
+    ref = torch.empty(c, c, 3, 3, device='cuda')
+    ok, gx0, gb0 = run(ref, 0)
+    if not ok:
+        pytest.skip('no instance')
+    wide = torch.full((c, 3 * c, 3, 3), 7.0, device='cuda')
+    sl = wide[:, c:2 * c]
+    ok, gx1, gb1 = run(sl, sl.stride(0))
+    assert ok and torch.equal(gx0, gx1) and torch.equal(gb0, gb1)
+    assert torch.equal(sl, ref)
+    assert bool((wide[:, :c] == 7.0).all()) and bool((wide[:, 2 * c:] == 7.0).all())
+    # a pitch that is not whole input channels / narrower than the slice is refused
+    for bad in (c * 9 + 1, c * 9 - 9):
+        with pytest.raises(L.DisHipError):
+            run(ref, bad)
