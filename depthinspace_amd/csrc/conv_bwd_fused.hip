@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     for (int it = 0; it < NLOAD; ++it) pf_issue(pfc, it);
     x_issue(cn, cty, ctx, true);
   }
+  FB_T(10)
 
   // ---- weights: OIHW fp32 -> scaled fp16 planes in fragment order (conv_f16x2_kernel's prologue with 4 waves; the fp32 copy sits in
   // the x tile, which is first written after the first barrier of the tile loop)
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     // (no barrier here: barrier A of the first tile separates the last read of `ws` from the first write of the x tile, barrier B
     //  publishes the weight planes)
   }
+  FB_T(11)
 
   float mg_lane = 0.f;   // this lane's largest halo magnitude of the tile that comes next (formed one tile ahead, see prep_item)
   if (RIDE && tile < t_hi) {

@@ -291,6 +291,8 @@ class RectifiedPatternSimilarityLoss(TimedModule):
             return [self(d, im, std)[0] for d in disps]
         if self.pattern.device != disps[0].device:
             self.pattern = self.pattern.to(disps[0].device)
+        if ops.PHOTO_LOSS_ONE_NODE:
+            return ops.pattern_photo_loss_multi(self.pattern, disps, im.contiguous(), std, 9, type_id, self.loss_eps)
         projs = [ops.pattern_warp(self.pattern, d) for d in disps]
         diffs = ops.photometric_multi(projs, im.contiguous(), 9, type_id, self.loss_eps)
         return [ops.weighted_mean(d, std) for d in diffs]

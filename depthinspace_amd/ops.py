@@ -586,6 +586,10 @@ class _PhotometricMulti(torch.autograd.Function):
         return ges, None, None, None, None
 
 
+# DIS_PHOTO_LOSS_ONE_NODE=0: pattern warp, census loss and weighted mean of the S estimates as separate autograd nodes (A/B)
+PHOTO_LOSS_ONE_NODE = _os_env.environ.get('DIS_PHOTO_LOSS_ONE_NODE', '1') != '0'
+
+
 def photometric_multi_ok(n_estimates, channels, block_size, type):
     return 1 <= n_estimates <= 4 and channels == 1 and int(block_size) == 9 and int(type) in (2, 3)
 
@@ -622,6 +626,62 @@ class _PatternWarp(torch.autograd.Function):
 
 def pattern_warp(pattern, disp):
     return _PatternWarp.apply(pattern, disp)
+
+
+class _PatternPhotoLossMulti(torch.autograd.Function):
+    """[weighted_mean(photometric(pattern_warp(pattern, d), ta), std) for d in disps] as ONE autograd node: the S projections are
+    written into the slices of one (S, n, 1, h, w) buffer, the census loss of all S runs in one launch (dis_photometric_fwd_multi)
+    and the S weighted means read its slices - and on the way back the S mean gradients are written into the slices of ONE buffer.
+    As separate nodes (pattern_warp, photometric_multi over torch.stack, weighted_mean over unbind) autograd moved the S maps
+    through a stack on the way in and a cat on the way back: 2 x 113 MB of copies per DIS-SF bs = 8 step.  Same launches, same
+    arithmetic per launch as the separate nodes (reference model/single_frame_worker.py:110-118 -> model/networks.py:336-377)."""
+
+    @staticmethod
+    def forward(ctx, pattern, ta, std, block_size, type, eps, *disps):
+        pattern, ta = _c(pattern), _c(ta)
+        std = _c(std) if std is not None else None
+        disps = [_c(d) for d in disps]
+        _chk(pattern, ta, std, *disps)
+        s = len(disps)
+        n, c, h, w = disps[0].shape
+        assert c == 1 and tuple(ta.shape) == (n, 1, h, w) and pattern.numel() == h * w
+        assert all(tuple(d.shape) == (n, 1, h, w) for d in disps)
+        proj = torch.empty((s, n, 1, h, w), dtype=torch.float32, device=ta.device)
+        for k in range(s):
+            lib.call('dis_pattern_warp_fwd', pattern, disps[k], proj[k], n, h, w)
+        diff = torch.empty_like(proj)
+        lib.call('dis_photometric_fwd_multi', proj, ta, diff, s, n, h, w, int(block_size), int(type), float(eps))
+        accs = _zeros_d(2 * s, ta.device)
+        outs = torch.empty(s, dtype=torch.float32, device=ta.device)
+        for k in range(s):
+            lib.call('dis_weighted_mean_fwd', diff[k], std, accs[2 * k:2 * k + 2], outs[k:k + 1], diff[k].numel())
+        ctx.save_for_backward(pattern, ta, std, proj, accs, *disps)
+        ctx.cfg = (int(block_size), int(type), float(eps), s)
+        return tuple(outs[k] for k in range(s))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        pattern, ta, std, proj, accs = ctx.saved_tensors[:5]
+        disps = ctx.saved_tensors[5:]
+        block, type, eps, s = ctx.cfg
+        n, _, h, w = disps[0].shape
+        gdiff = torch.empty_like(proj)
+        for k in range(s):
+            g = gs[k] if gs[k] is not None else torch.zeros((), dtype=torch.float32, device=proj.device)
+            lib.call('dis_weighted_mean_bwd', std, accs[2 * k:2 * k + 2], _c(g), gdiff[k], gdiff[k].numel())
+        gproj = torch.empty_like(proj)
+        lib.call('dis_photometric_bwd_multi', proj, ta, gdiff, gproj, s, n, h, w, block, type, eps)
+        gds = []
+        for k in range(s):
+            gd = torch.empty_like(disps[k])
+            lib.call('dis_pattern_warp_bwd', pattern, disps[k], gproj[k], gd, n, h, w)
+            gds.append(gd)
+        return (None, None, None, None, None, None) + tuple(gds)
+
+
+def pattern_photo_loss_multi(pattern, disps, ta, std, block_size, type, eps):
+    """per-estimate census loss values (device scalars) of the pattern warped by each disparity map against one image"""
+    return list(_PatternPhotoLossMulti.apply(pattern, ta, std, block_size, type, eps, *disps))
 
 
 # --------------------------------------------------------------------------------------------------

@@ -29,11 +29,12 @@ a = np.array(buf, dtype=np.float64).reshape(256, 4, 12)
 tiles = n * (h // 16) * ((w + 15) // 16) / 256.0
 names = ['loop control + flush of the channel sums', 'TOP: final values + maxima (halo, x strip)', 'barrier A', 'staging (halo + x tile split, LDS writes), next loads issued',
          'barrier B', 'D: 216 input-gradient products', 'W: epilogue + 216 dW products', 'after the loop: slab / bias',
-         '  (staging: halo items split + written)', '  (staging: x strip split + written)', '', '']
+         '  (staging: halo items split + written)', '  (staging: x strip split + written)',
+         'prologue: first tile requested (once)', 'prologue: weights -> fp16 planes in LDS (once)']
 print(f'launch {e0.elapsed_time(e1) * 1e3:.1f} us, {tiles:.1f} tiles per workgroup; s_memtime ticks (100 MHz) per tile and wave, median over workgroups')
 tot = 0.0
-for k in range(10):
-    v = np.median(a[:, :, k]) / (tiles if k != 7 else 1.0)
+for k in range(12):
+    v = np.median(a[:, :, k]) / (tiles if k not in (7, 10, 11) else 1.0)
     tot += np.median(a[:, :, k]) if k < 8 else 0.0
-    print(f'  {names[k]:40s} {v:9.1f} ticks = {v * 10:.0f} ns' + (' per tile' if k != 7 else ' once'))
+    print(f'  {names[k]:40s} {v:9.1f} ticks = {v * 10:.0f} ns' + (' per tile' if k not in (7, 10, 11) else ' once'))
 print(f'  sum {tot:.0f} ticks = {tot / 100:.1f} us per workgroup')

@@ -133,6 +133,40 @@ def test_pattern_loss_golden(G):
     close(disp.grad, G['pl_grad'], 1e-8, 2e-4, what='grad')
 
 
+@pytest.mark.parametrize('s', [1, 3, 4])
+def test_pattern_photo_loss_one_node_equals_the_separate_nodes(G, s):
+    """ops.pattern_photo_loss_multi (pattern warp -> census loss of S estimates in one launch -> weighted means as ONE autograd node,
+    no stack / cat of the S maps): the same launches as the separate nodes, so values and disparity gradients are bit-identical; and
+    the golden vector of the single-estimate chain holds for estimate 0."""
+    from depthinspace_amd import ops
+    pat = torch.from_numpy(G['pl_pat'])
+    pat1 = torch.cat([pat] * 3, 1).mean(dim=1, keepdim=True).contiguous().cuda()
+    im, std = dev(G['pl_im']), dev(G['pl_std'])
+    g = torch.Generator().manual_seed(s)
+    d0 = torch.from_numpy(G['pl_disp'])
+    base = [d0] + [d0 + 0.7 * k * torch.rand(d0.shape, generator=g) for k in range(1, s)]
+    wts = [1.0, 0.5, 0.25, 0.125][:s]
+    da = [b.cuda().requires_grad_(True) for b in base]
+    va = ops.pattern_photo_loss_multi(pat1, da, im, std, 9, 3, 0.5)
+    sum(v * w_ for v, w_ in zip(va, wts)).backward()
+    db = [b.cuda().requires_grad_(True) for b in base]
+    projs = [ops.pattern_warp(pat1, d) for d in db]
+    vb = [ops.weighted_mean(x, std) for x in ops.photometric_multi(projs, im, 9, 3, 0.5)]
+    sum(v * w_ for v, w_ in zip(vb, wts)).backward()
+    for k in range(s):
+        assert torch.equal(va[k], vb[k]), (k, float(va[k]), float(vb[k]))
+        assert torch.equal(da[k].grad, db[k].grad), k
+    close(va[0], float(G['pl_val']), 1e-6, 1e-5, what='val')
+    close(da[0].grad, G['pl_grad'], 1e-8, 2e-4, what='grad')
+    # an estimate whose value is not used gets a zero gradient
+    dc = [b.cuda().requires_grad_(True) for b in base]
+    vc = ops.pattern_photo_loss_multi(pat1, dc, im, std, 9, 3, 0.5)
+    vc[0].backward()
+    assert torch.equal(dc[0].grad, da[0].grad / 1.0) or float((dc[0].grad - da[0].grad).abs().max()) < 1e-12
+    for k in range(1, s):
+        assert dc[k].grad is None or float(dc[k].grad.abs().max()) == 0.0
+
+
 def test_smooth_golden(G):
     from depthinspace_amd import ops
     disp = dev(G['sm_disp']).requires_grad_(True)
