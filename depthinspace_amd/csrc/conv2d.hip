@@ -1583,7 +1583,7 @@ struct WgCfg {
 };
 
 
-template <int CIN, int COUT, int KH, int KW, int S>
+template <int CIN, int COUT, int KH, int KW, int S, bool GACT = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   using C = WgCfg<CIN, COUT, KH, KW, S>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1622,7 +1622,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   // while the MFMAs of the current one run
   constexpr int NIX = C::IN_ROWS * C::IN_COLS * C::NV, NLX = (NIX + 255) / 256;
   constexpr int NIG = C::TROWS * 16 * (COUT / 4), NLG = (NIG + 255) / 256;
-  float4 prex[NLX], preg[NLG];
+  float4 prex[NLX], preg[NLG], preq[GACT ? NLG : 1];   // (GACT: the activated output at gy's positions)
   float presc[NLX];
 #pragma unroll
   for (int it = 0; it < NLX; ++it) presc[it] = 1.f;
@@ -1655,11 +1655,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     for (int it = 0; it < NLG; ++it) {
       const int idx = threadIdx.x + it * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (GACT) preq[GACT ? it : 0] = v;   // (pixels past the map: gy = 0 must not meet an unset act'(.) - 0 x NaN)
       if (idx < NIG) {
         const int vv = idx % (COUT / 4), pix = idx / (COUT / 4);
         const int c = pix % 16, r = pix / 16;
         const int oy = ty * C::TROWS + r, ox = tx * 16 + c;
-        if (oy < a.hout && ox < a.wout) v = *(const float4*)(gb + ((long)oy * a.wout + ox) * COUT + vv * 4);
+        if (oy < a.hout && ox < a.wout) {
+          v = *(const float4*)(gb + ((long)oy * a.wout + ox) * COUT + vv * 4);
+          if (GACT) preq[GACT ? it : 0] = *(const float4*)(a.gact + (gb - a.gy) + ((long)oy * a.wout + ox) * COUT + vv * 4);
+        }
       }
       preg[it] = v;
     }
@@ -1677,7 +1681,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int it = 0; it < NLG; ++it) {
       const int idx = threadIdx.x + it * 256;
-      if (idx < NIG) *(float4*)(gl + (idx / (COUT / 4)) * C::GS + (idx % (COUT / 4)) * 4) = preg[it];
+      if (idx < NIG) {
+        float4 v = preg[it];
+        if (GACT) {   // (dis_act_bwd's arithmetic on load: gpre = gy * act'(y); pixels past the map hold gy = 0)
+          const float4 q = preq[GACT ? it : 0];
+          v.x *= act_grad_from_out(q.x, a.gact_act), v.y *= act_grad_from_out(q.y, a.gact_act);
+          v.z *= act_grad_from_out(q.z, a.gact_act), v.w *= act_grad_from_out(q.w, a.gact_act);
+        }
+        *(float4*)(gl + (idx / (COUT / 4)) * C::GS + (idx % (COUT / 4)) * 4) = v;
+      }
     }
   };
 
@@ -1856,13 +1868,13 @@ static long wgrad_ws(void) {
   return (long)WG_WORKERS * elems + (long)WG_RSPLIT * elems + (long)WG_WORKERS * COUT;
 }
 
-template <int CIN, int COUT, int KH, int KW, int S>
+template <int CIN, int COUT, int KH, int KW, int S, bool GACT = false>
 static int launch_wgrad(WgArgs a, float* gw, float* gb, int cin_real, hipStream_t s) {
   using C = WgCfg<CIN, COUT, KH, KW, S>;
   static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
   static_assert(C::IN_FLOATS + C::G_FLOATS >= 4 * C::NB * 256, "reduction scratch does not fit the tile buffers");
   static bool attr_set = false;
-  auto kern = conv_wgrad_kernel<CIN, COUT, KH, KW, S>;
+  auto kern = conv_wgrad_kernel<CIN, COUT, KH, KW, S, GACT>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
@@ -2619,6 +2631,31 @@ extern "C" int dis_conv2d_wgrad(const float* x, const float* gy, float* grad_w, 
   a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
   a.xscale = nullptr;
   return dispatch_wgrad(a, grad_w, grad_b, cin_real, cin_pad, cout, k, stride, (hipStream_t)stream);
+}
+
+/* dis_conv2d_wgrad with the activation gradient applied while gy is staged (round 6): grad_w / grad_b are the gradients for
+ * gpre = gy * act'(y), y = the conv's activated output - for the layers whose input gradient is never needed (FuseNet's stems:
+ * conv1 4 -> 16 k4 s2, amb_conv 4 -> 16 k3 s1; reference model/multi_frame_networks.py:216-227, 229-233), where the separate
+ * dis_act_bwd pass (read gy, y; write gpre) existed for this launch alone.  Exact-fp32 MFMA kernel (conv_wgrad_kernel).
+ * DIS_ERR_UNSUPPORTED: another shape (the caller runs dis_act_bwd + dis_conv2d_wgrad). */
+extern "C" int dis_conv2d_wgrad_act(const float* x, const float* gy, const float* y, int act, float* grad_w, float* grad_b,
+                                    float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k,
+                                    int stride, int pad, void* stream) {
+  if (!x || !gy || !y || !grad_w || !workspace) return DIS_ERR_NULL;
+  if (n <= 0 || hin <= 0 || win <= 0 || cin_pad <= 0 || cin_real <= 0 || cin_real > cin_pad || cout <= 0)
+    return DIS_ERR_BAD_SHAPE;
+  if (act != DIS_ACT_SELU && act != DIS_ACT_RELU) return DIS_ERR_UNSUPPORTED;
+  const int hout = (hin + 2 * pad - k) / stride + 1, wout = (win + 2 * pad - k) / stride + 1;
+  if (hout <= 0 || wout <= 0) return DIS_ERR_BAD_SHAPE;
+  WgArgs a;
+  a.x = x; a.gy = gy; a.part = workspace; a.bpart = nullptr;
+  a.n = n; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.pad = pad;
+  a.xscale = nullptr;
+  a.gact = y; a.gact_act = act;
+  hipStream_t s = (hipStream_t)stream;
+  if (cin_pad == 4 && cout == 16 && k == 4 && stride == 2) return launch_wgrad<4, 16, 4, 4, 2, true>(a, grad_w, grad_b, cin_real, s);
+  if (cin_pad == 4 && cout == 16 && k == 3 && stride == 1) return launch_wgrad<4, 16, 3, 3, 1, true>(a, grad_w, grad_b, cin_real, s);
+  return DIS_ERR_UNSUPPORTED;
 }
 
 extern "C" int dis_conv2d_wgrad_scaled(const float* x, const float* xscale, const float* gy, float* grad_w, float* grad_b,

@@ -78,6 +78,9 @@ struct WgArgs {
   // input-gradient launches
   const float* gnb_coef;
   float* gnb_out;
+  // conv_wgrad_kernel<..., GACT = true> (round 6; the 4 -> 16 stems, whose input gradient is never needed): gy is staged as
+  // gy * act'(gact), gact = the conv's activated output - the separate dis_act_bwd pass (read gy, y; write gpre) does not exist
+  int gact_act;
 };
 
 // conv_bwd_fused.hip: input gradient + weight gradient of a 3x3 stride-1 pad-1 conv C -> C in one launch

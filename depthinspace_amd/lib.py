@@ -93,6 +93,7 @@ SIGS = {
     'dis_slot_weights': 'pplip',
     'dis_conv2d_wgrad_workspace': 'iiii',
     'dis_conv2d_wgrad': 'pppppiiiiiiiiip',
+    'dis_conv2d_wgrad_act': 'pppipppiiiiiiiiip',
     'dis_conv2d_wgrad_bf16x3': 'pppppiiiiiiiiip',
     'dis_conv2d_dgrad_strided': 'ppppiiiiiiiiip',
     'dis_disp_head_fwd': 'ppppiiiiffp',

@@ -1134,6 +1134,8 @@ BWD_FUSED = _os.environ.get('DIS_BWD_FUSED', '1') != '0'
 _FUSED_WS = {}
 
 
+# DIS_WGRAD_ACT=0: the 4 -> 16 stems run dis_act_bwd + dis_conv2d_wgrad instead of dis_conv2d_wgrad_act (A/B only)
+WGRAD_ACT = _os_env.environ.get('DIS_WGRAD_ACT', '1') != '0'
 # DIS_GW_INPLACE=0: conv2d_multi's fused launches write their weight-gradient slice to a temporary that is copied into the full
 # gradient afterwards (the form before the slab reduce took a row pitch; A/B only)
 GW_INPLACE = _os_env.environ.get('DIS_GW_INPLACE', '1') != '0'
@@ -1291,7 +1293,11 @@ class _Conv2d(torch.autograd.Function):
         gy = _c(gy)
         # bf16x3 shapes: the activation gradient is applied while gy is staged (dgrad and wgrad kernels), no separate pass
         fuse_act = act != ACT_NONE and _bx_shape(cin_pad, cout, k, stride)
-        if act != ACT_NONE and not fuse_act:
+        # the 4 -> 16 stems (conv1, amb_conv): no input gradient is asked for, so gy act'(y) would be formed for the weight-gradient
+        # launch alone - that launch forms it on load (dis_conv2d_wgrad_act), the pass (read gy, y; write gpre) does not exist
+        wgrad_act = (WGRAD_ACT and act != ACT_NONE and not fuse_act and not (need_dgrad and ctx.needs_input_grad[0]) and
+                     cin_pad == 4 and cout == 16 and (k, stride) in ((3, 1), (4, 2)))
+        if act != ACT_NONE and not fuse_act and not wgrad_act:
             gpre = torch.empty_like(gy)
             lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
         else:
@@ -1364,6 +1370,11 @@ class _Conv2d(torch.autograd.Function):
         if fuse_act:
             lib.call('dis_conv2d_wgrad_bf16x3_act', x, gy, y, act, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride,
                      pad)
+        elif wgrad_act:
+            if not lib.call_try('dis_conv2d_wgrad_act', x, gy, y, act, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad):
+                gpre = torch.empty_like(gy)   # (no instance in this build: the pass as a launch of its own)
+                lib.call('dis_act_bwd', gy, y, gpre, act, gy.numel())
+                _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
         else:
             _conv_wgrad_any(x, gpre, gw, gb, ws, n, hin, win, cin_pad, cin, cout, k, stride, pad)
         _sinks_written()

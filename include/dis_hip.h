@@ -276,6 +276,12 @@ int dis_slot_weights(const float* geom, float* wgt, long pixels, int tl, void* s
  * grad_w: (cout,cin_real,k,k) OIHW, grad_b: (cout) or NULL, both OVERWRITTEN.  Deterministic (partial slabs
  * per workgroup summed in a fixed order, no float atomics). */
 long dis_conv2d_wgrad_workspace(int cin_pad, int cout, int k, int stride);
+/* Round 6 - dis_conv2d_wgrad with gy * act'(y) formed while gy is staged (y = the conv's activated output): the layers whose input
+ * gradient is never needed (FuseNet's stems conv1 4 -> 16 k4 s2 and amb_conv 4 -> 16 k3 s1, reference
+ * model/multi_frame_networks.py:216-233) no longer need the dis_act_bwd pass.  workspace: dis_conv2d_wgrad_workspace(cin_pad, cout, k,
+ * stride) floats.  DIS_ERR_UNSUPPORTED for any other shape. */
+int dis_conv2d_wgrad_act(const float* x, const float* gy, const float* y, int act, float* grad_w, float* grad_b, float* workspace,
+                         int n, int hin, int win, int cin_pad, int cin_real, int cout, int k, int stride, int pad, void* stream);
 /* dis_conv2d_wgrad of conv(x * xscale) (see dis_conv2d_fwd_scaled); xscale may be NULL */
 int dis_conv2d_wgrad_scaled(const float* x, const float* xscale, const float* gy, float* grad_w, float* grad_b,
                             float* workspace, int n, int hin, int win, int cin_pad, int cin_real, int cout, int k,

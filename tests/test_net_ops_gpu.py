@@ -1354,3 +1354,45 @@ def _fused_activation_gradient(cin, cout, act):
     lib.call('dis_conv2d_wgrad_bf16x3', x, gpre, gw0, gb0, ws, n, h, w, cin, cin, cout, 3, 1, 1)
     lib.call('dis_conv2d_wgrad_bf16x3_act', x, gy, y, act, gw1, gb1, ws, n, h, w, cin, cin, cout, 3, 1, 1)
     assert torch.equal(gw0, gw1) and torch.equal(gb0, gb1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,stride,pad', [(3, 1, 1), (4, 2, 1)])
+@pytest.mark.parametrize('n,h,w', [(2, 40, 56), (1, 33, 47), (3, 16, 130)])
+@pytest.mark.parametrize('act', ['selu', 'relu'])
+def test_conv_wgrad_act_on_load_equals_the_separate_pass(k, stride, pad, n, h, w, act):
+    """dis_conv2d_wgrad_act (round 6; FuseNet's 4 -> 16 stems conv1 / amb_conv, reference model/multi_frame_networks.py:216-233): the
+    weight / bias gradient for gy * act'(y) with the product formed while gy is staged - bit-identical to dis_act_bwd followed by
+    dis_conv2d_wgrad (the same fp32 product, the same kernel behind it), and within 1e-6 of the largest entry of the fp64 result."""
+    from depthinspace_amd import ops
+    L = ops.lib
+    a = ops.ACT_SELU if act == 'selu' else ops.ACT_RELU
+    if (h + 2 * pad - k) // stride + 1 <= 0:
+        pytest.skip('empty output')
+    g_ = torch.Generator().manual_seed(100 * k + h + w)
+    cin_pad, cin, cout = 4, 3, 16
+    x = torch.randn(n, h, w, cin_pad, generator=g_)
+    x[..., cin:] = 0.0
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    pre = torch.randn(n, ho, wo, cout, generator=g_)
+    y = (torch.nn.functional.selu(pre) if act == 'selu' else torch.relu(pre)).cuda()
+    gy = torch.randn(n, ho, wo, cout, generator=g_).cuda()
+    x = x.cuda()
+    wsz = L.fn('dis_conv2d_wgrad_workspace')(cin_pad, cout, k, stride)
+    assert wsz > 0
+    gw_a, gb_a = torch.full((cout, cin, k, k), float('nan'), device='cuda'), torch.full((cout,), float('nan'), device='cuda')
+    L.call('dis_conv2d_wgrad_act', x, gy, y, a, gw_a, gb_a, torch.empty(wsz, device='cuda'), n, h, w, cin_pad, cin, cout, k, stride, pad)
+    gpre = torch.empty_like(gy)
+    L.call('dis_act_bwd', gy, y, gpre, a, gy.numel())
+    gw_b, gb_b = torch.empty(cout, cin, k, k, device='cuda'), torch.empty(cout, device='cuda')
+    L.call('dis_conv2d_wgrad', x, gpre, gw_b, gb_b, torch.empty(wsz, device='cuda'), n, h, w, cin_pad, cin, cout, k, stride, pad)
+    torch.cuda.synchronize()
+    assert torch.equal(gw_a, gw_b) and torch.equal(gb_a, gb_b)
+    xn = x[..., :cin].permute(0, 3, 1, 2).double()
+    gn = gpre.permute(0, 3, 1, 2).double()
+    gw64 = torch.nn.grad.conv2d_weight(xn, (cout, cin, k, k), gn, stride=stride, padding=pad)
+    assert float((gw_a.double() - gw64).abs().max()) < 1e-6 * float(gw64.abs().max())
+    assert float((gb_a.double() - gn.sum(dim=(0, 2, 3))).abs().max()) < 1e-6 * float(gn.sum(dim=(0, 2, 3)).abs().max())
+    # another shape: refused, the caller keeps the two launches
+    assert not L.call_try('dis_conv2d_wgrad_act', x, gy, y, a, gw_a, gb_a, torch.empty(wsz, device='cuda'), n, h, w, cin_pad, cin, 32, k,
+                          stride, pad)
