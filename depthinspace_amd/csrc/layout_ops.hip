@@ -80,9 +80,38 @@ static int launch_transpose(const float* x, float* y, int batch, int rows, int c
   DIS_CHECK_LAUNCH();
   return DIS_OK;
 }
+// planar -> nhwc for 2 .. 4 channels (the flow fields of the DIS-MF step: 64 x 2 x h x w): one thread per pixel reads its C plane
+// values (coalesced per plane) and writes them as one vector.  The 32 x 32 tiles of transpose_kernel hold 2 of 32 rows here
+// (46 us per launch at 1.2 TB/s in round 6's profile, two launches per step).
+template <int C>
+__global__ __launch_bounds__(256) void planar_to_nhwc_small_kernel(const float* __restrict__ x, float* __restrict__ y, long hw,
+                                                                    long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / hw, p = i - n * hw;
+    float v[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) v[k] = x[(n * C + k) * hw + p];
+    if (C == 2) *(float2*)(y + i * 2) = make_float2(v[0], v[1]);
+    else if (C == 4) *(float4*)(y + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+      for (int k = 0; k < C; ++k) y[i * C + k] = v[k];
+    }
+  }
+}
 extern "C" int dis_planar_to_nhwc(const float* x, float* y, int n, int c, int h, int w, void* stream) {
   if (!x || !y) return DIS_ERR_NULL;
   if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c >= 2 && c <= 4 && (((uintptr_t)y) & 15) == 0) {
+    const long hw = (long)h * w, total = (long)n * hw;
+    const dim3 grid(dis_ew_grid(total, 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (c == 2) hipLaunchKernelGGL(planar_to_nhwc_small_kernel<2>, grid, dim3(256), 0, s, x, y, hw, total);
+    else if (c == 3) hipLaunchKernelGGL(planar_to_nhwc_small_kernel<3>, grid, dim3(256), 0, s, x, y, hw, total);
+    else hipLaunchKernelGGL(planar_to_nhwc_small_kernel<4>, grid, dim3(256), 0, s, x, y, hw, total);
+    DIS_CHECK_LAUNCH();
+    return DIS_OK;
+  }
   return launch_transpose(x, y, n, c, h * w, stream);
 }
 extern "C" int dis_nhwc_to_planar(const float* x, float* y, int n, int c, int h, int w, void* stream) {

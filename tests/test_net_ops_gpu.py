@@ -1396,3 +1396,17 @@ def test_conv_wgrad_act_on_load_equals_the_separate_pass(k, stride, pad, n, h, w
     # another shape: refused, the caller keeps the two launches
     assert not L.call_try('dis_conv2d_wgrad_act', x, gy, y, a, gw_a, gb_a, torch.empty(wsz, device='cuda'), n, h, w, cin_pad, cin, 32, k,
                           stride, pad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('c', [1, 2, 3, 4, 5, 32])
+@pytest.mark.parametrize('n,h,w', [(3, 17, 23), (64, 32, 27), (1, 1, 1)])
+def test_planar_to_nhwc_all_channel_counts(c, n, h, w):
+    """dis_planar_to_nhwc: the per-pixel kernel for 2 .. 4 channels (the flow fields) and the tiled transpose for the rest are the
+    same permutation as torch's"""
+    from depthinspace_amd import ops
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(c * 100 + h)).cuda()
+    y = ops.planar_to_nhwc(x)
+    assert tuple(y.shape) == (n, h, w, c)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_planar(y), x)
