@@ -956,11 +956,24 @@ __global__ void gather_warped_feat_bwd_csr_kernel(const float* __restrict__ gout
 // pixels per pass); consecutive tiles of a frame go to the same XCD (its share of the tiles is one contiguous range), so the rows of
 // grad_out that neighbouring destinations share are found in that XCD's L2; four entries and their rows in flight per round instead
 // of one.  The sum runs in entry order: bit for bit the kernel above.
+// GNRES (round 6): feat IS y = SELU(GroupNorm(x2) + residual) (a Block2D3D / ResNetBlock output) and this launch completes the
+// gradient wrt y - the epilogue of dis_gn_bwd_res_sums rides here: what is stored is gres = g SELU'(y) (the pre-activation gradient,
+// which doubles as the residual gradient) and the workgroup leaves A_c = sum gres, B_c = sum gres x2 of its tile in slot
+// (tile within the image) mod slots of ab (n, slots, 2, c) doubles - the pass that read g, y, x2 again and wrote gres is gone.
+struct GatherGnRes {
+  const float* y;     // the gather's input (values), shaped like grad_feat
+  const float* x2;    // the GroupNorm's input
+  double* ab;         // (n, slots, 2, c), zeroed by the caller
+  int slots, act, atomic;   // atomic: more tiles per image than slots - several workgroups add to one slot
+};
+template <bool GNRES>
 __global__ __launch_bounds__(256) void gather_warped_feat_bwd_csr_tiled_kernel(const float* __restrict__ gout, const int* __restrict__ offsets,
                                                                                const int* __restrict__ entries,
                                                                                const float* __restrict__ init, float* __restrict__ gfeat,
                                                                                int h, int w, int tl, int c, int tiles_x, int tiles_y,
-                                                                               int ntile, int per_xcd) {
+                                                                               int ntile, int per_xcd, GatherGnRes gr) {
+  __shared__ float gsa[GNRES ? 256 : 1][4], gsb[GNRES ? 256 : 1][4];
+  float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
   const int cg = c >> 2, pxp = 256 / cg;
   const int tile_lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per_xcd || tile_lin >= ntile) return;
@@ -989,6 +1002,11 @@ __global__ __launch_bounds__(256) void gather_warped_feat_bwd_csr_tiled_kernel(c
       float4 acc = *(const float4*)(gout + (d * tl) * c + g * 4);
       float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (init) q4 = *(const float4*)(init + d * c + g * 4);
+      float4 yv = make_float4(0.f, 0.f, 0.f, 0.f), xv = yv;
+      if (GNRES) {   // (requested with the row's own operands: in flight under the entry -> row chain below)
+        yv = *(const float4*)(gr.y + d * c + g * 4);
+        xv = *(const float4*)(gr.x2 + d * c + g * 4);
+      }
       int row[GC_E];
       float wgt[GC_E];
       float4 v[GC_E];
@@ -1014,7 +1032,28 @@ __global__ __launch_bounds__(256) void gather_warped_feat_bwd_csr_tiled_kernel(c
         const float4 vv = *(const float4*)(gout + (long)entries[2 * (long)e] * c + g * 4);
         acc.x += vv.x * wg; acc.y += vv.y * wg; acc.z += vv.z * wg; acc.w += vv.w * wg;
       }
+      if (GNRES) {   // (gn_res_sums_kernel's arithmetic per element)
+        acc.x *= act_grad_from_out(yv.x, gr.act), acc.y *= act_grad_from_out(yv.y, gr.act);
+        acc.z *= act_grad_from_out(yv.z, gr.act), acc.w *= act_grad_from_out(yv.w, gr.act);
+        sa[0] += acc.x, sa[1] += acc.y, sa[2] += acc.z, sa[3] += acc.w;
+        sb[0] = __builtin_fmaf(acc.x, xv.x, sb[0]), sb[1] = __builtin_fmaf(acc.y, xv.y, sb[1]);
+        sb[2] = __builtin_fmaf(acc.z, xv.z, sb[2]), sb[3] = __builtin_fmaf(acc.w, xv.w, sb[3]);
+      }
       *(float4*)(gfeat + d * c + g * 4) = acc;
+    }
+  }
+  if (GNRES) {   // the tile's channel sums: the 256 / cg threads of a channel group in thread order (fixed), then one slot
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gsa[threadIdx.x][k] = sa[k], gsb[threadIdx.x][k] = sb[k];
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * c) {
+      const int t = threadIdx.x, ch = t < c ? t : t - c, grp = ch >> 2, k = ch & 3;
+      double v = 0.0;
+      for (int u = grp; u < 256; u += cg) v += (double)(t < c ? gsa[u][k] : gsb[u][k]);
+      const int tin = tile_lin % (tiles_x * tiles_y);
+      double* dst = gr.ab + ((long)fb * gr.slots + tin % gr.slots) * (2 * c) + t;
+      if (gr.atomic) atomic_add_d(dst, v);
+      else *dst = v;
     }
   }
 }
@@ -1146,6 +1185,43 @@ extern "C" int dis_conv3d_csr_build(const unsigned char* idx, int* csr, int tl, 
   return DIS_OK;
 }
 
+static int gather_bwd_csr_tiled(const float* grad_out, const int* csr, const float* init, float* grad_feat, int tl, int bs, int h,
+                                int w, int c, const GatherGnRes* gr, void* stream) {
+  const long nd = (long)tl * bs * h * w;
+  const int cg4 = c / 4;
+  if (!(cg4 <= 256 && 256 % cg4 == 0 && GT_TW % (256 / cg4) == 0 && gather_tiled_on())) return DIS_ERR_UNSUPPORTED;
+  const int tiles_x = dis_cdiv(w, GT_TW), tiles_y = dis_cdiv(h, GT_TH);
+  const long ntile = (long)tl * bs * tiles_x * tiles_y;
+  const long per_xcd = (ntile + 7) / 8;
+  if (per_xcd * 8 > 0x7fffffffL) return DIS_ERR_UNSUPPORTED;
+  if (gr) {
+    GatherGnRes g2 = *gr;
+    g2.atomic = tiles_x * tiles_y > g2.slots ? 1 : 0;
+    hipLaunchKernelGGL(gather_warped_feat_bwd_csr_tiled_kernel<true>, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, csr, csr + 2 * nd + 1, init, grad_feat, h, w, tl, c, tiles_x, tiles_y, (int)ntile, (int)per_xcd, g2);
+  } else {
+    hipLaunchKernelGGL(gather_warped_feat_bwd_csr_tiled_kernel<false>, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, csr, csr + 2 * nd + 1, init, grad_feat, h, w, tl, c, tiles_x, tiles_y, (int)ntile, (int)per_xcd,
+                       GatherGnRes{nullptr, nullptr, nullptr, 1, 0, 0});
+  }
+  DIS_CHECK_LAUNCH();
+  return DIS_OK;
+}
+/* dis_gather_warped_feat_bwd_csr for a `feat` that IS y = act(GroupNorm(x2) + residual) (act = SELU; a Block2D3D / ResNetBlock output,
+ * reference model/multi_frame_networks.py:428-430, 540-542) when this launch completes the gradient wrt y (init = what the other
+ * consumer left): grad_feat receives gres = g act'(y) - the gradient wrt the pre-activation value, which is also the residual
+ * gradient - and ab_out (tl * bs, slots, 2, c) doubles (ZEROED by the caller) the channel sums A_c = sum gres, B_c = sum gres x2
+ * that dis_gn_bwd_coef takes: the dis_gn_bwd_res_sums pass over g, y, x2 does not exist.  c % 4 == 0, 2 c <= 64.
+ * DIS_ERR_UNSUPPORTED: no tiled instance for the shape (the caller runs dis_gather_warped_feat_bwd_csr + dis_gn_bwd_res_sums). */
+extern "C" int dis_gather_warped_feat_bwd_csr_gnres(const float* grad_out, const int* csr, const float* init, float* grad_feat,
+                                                    const float* y, const float* x2, double* ab_out, int slots, int act, int tl,
+                                                    int bs, int h, int w, int c, void* stream) {
+  if (!grad_out || !csr || !grad_feat || !y || !x2 || !ab_out) return DIS_ERR_NULL;
+  if (tl <= 1 || bs <= 0 || h <= 1 || w <= 1 || c <= 0 || slots <= 0) return DIS_ERR_BAD_SHAPE;
+  if (c % 4 != 0 || 2 * c > 64 || (act != DIS_ACT_SELU && act != DIS_ACT_RELU && act != DIS_ACT_NONE)) return DIS_ERR_UNSUPPORTED;
+  GatherGnRes gr{y, x2, ab_out, slots, act, 0};
+  return gather_bwd_csr_tiled(grad_out, csr, init, grad_feat, tl, bs, h, w, c, &gr, stream);
+}
 extern "C" int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* csr, const float* init,
                                               float* grad_feat, int tl, int bs, int h, int w, int c, void* stream) {
   if (!grad_out || !csr || !grad_feat) return DIS_ERR_NULL;
@@ -1153,18 +1229,7 @@ extern "C" int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* 
   if (c % 4 != 0) return DIS_ERR_UNSUPPORTED;
   const long nd = (long)tl * bs * h * w;
   const long total = nd * (c / 4);
-  const int cg4 = c / 4;
-  if (cg4 <= 256 && 256 % cg4 == 0 && GT_TW % (256 / cg4) == 0 && gather_tiled_on()) {
-    const int tiles_x = dis_cdiv(w, GT_TW), tiles_y = dis_cdiv(h, GT_TH);
-    const long ntile = (long)tl * bs * tiles_x * tiles_y;
-    const long per_xcd = (ntile + 7) / 8;
-    if (per_xcd * 8 <= 0x7fffffffL) {
-      hipLaunchKernelGGL(gather_warped_feat_bwd_csr_tiled_kernel, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, (hipStream_t)stream,
-                         grad_out, csr, csr + 2 * nd + 1, init, grad_feat, h, w, tl, c, tiles_x, tiles_y, (int)ntile, (int)per_xcd);
-      DIS_CHECK_LAUNCH();
-      return DIS_OK;
-    }
-  }
+  if (gather_bwd_csr_tiled(grad_out, csr, init, grad_feat, tl, bs, h, w, c, nullptr, stream) == DIS_OK) return DIS_OK;
   int grid = dis_cdiv(total, 256);
   if (grid > 16384) grid = 16384;
   hipLaunchKernelGGL(gather_warped_feat_bwd_csr_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_out, csr,

@@ -48,6 +48,7 @@ SIGS = {
     'dis_gather_csr_workspace': 'iiii',
     'dis_gather_csr_build': 'ppiiiip',
     'dis_gather_warped_feat_bwd_csr': 'ppppiiiiip',
+    'dis_gather_warped_feat_bwd_csr_gnres': 'ppppppp' + 'iiiiiiip',
     'dis_mf_geometry': 'pppppiipiiiip',
     'dis_mf_geometry_resize': 'ppiiiiiip',
     'dis_conv2d_pack_weights': 'ppiiiiip',

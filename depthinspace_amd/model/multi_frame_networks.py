@@ -177,7 +177,9 @@ class Block2D3D(TimedModule):
         grad = torch.is_grad_enabled() and feat.requires_grad
         j_feat, j_wf, j_mf = (ops.GradJoin(), ops.GradJoin(), ops.GradJoin()) if grad else (None, None, None)
         # 3-D branch (fwd_3d_1 / fwd_3d_2, reference :376-404)
-        wf = ops.gather_warped_feat(feat, flows, csr, j_feat)
+        # (feat is the previous block's / res3's SELU(GroupNorm(.) + residual): the feature warp's backward, which completes the
+        #  gradient wrt feat, then also does the first pass of that GroupNorm's backward - ops._GatherWarpedFeat)
+        wf = ops.gather_warped_feat(feat, flows, csr, j_feat, gnres=getattr(feat, '_gn_res_src', None) if grad else None)
         o3d1 = self.conv3d_1(geom, wf, idx, j_wf)
         wfq = ops.gather_warped_feat(o3d1, flows_q, csr_q)
         o3d2 = self.conv3d_2(geom_q, wfq, idx_q)
@@ -206,7 +208,9 @@ class Block2D3D(TimedModule):
             f, st = ops.conv2d_multi((a, b, c), self.conv_fuse[1].weight, self.conv_fuse[1].bias, 1, NONE, want_stats=True)
         out = ops.group_norm(f, self.conv_fuse[2].weight, self.conv_fuse[2].bias, stats=st,
                              residual=feat.view(N, h, w, C), act=SELU, join=j_feat)
-        return out.view(tl, bs, h, w, C)
+        o5 = out.view(tl, bs, h, w, C)
+        o5._gn_res_src = getattr(out, '_gn_res_src', None)   # (the next block's feature warp reads it, see above)
+        return o5
 
 
 class FuseNet(TimedModule):
@@ -286,7 +290,9 @@ class FuseNet(TimedModule):
         ir, amb, d, depth = ir.contiguous(), amb.contiguous(), d.contiguous(), depth.contiguous()
         R, t = R.contiguous(), t.contiguous()
         x4 = ops.pack4_nhwc([(ir, 2 * HW), (ir.view(-1)[HW:], 2 * HW), (amb, HW), (d, HW)], N, H, W)
-        feat = self.pre_process(x4).view(tl, bs, h, w, self.channels)
+        f4 = self.pre_process(x4)
+        feat = f4.view(tl, bs, h, w, self.channels)
+        feat._gn_res_src = getattr(f4, '_gn_res_src', None)   # (res3's output: Block2D3D's feature warp reads it)
 
         # parameter-free pyramids, no gradient (reference :280-294, :392-394)
         with torch.no_grad():

@@ -2462,30 +2462,52 @@ def group_norm(x, gamma, beta, stats=None, residual=None, act=ACT_NONE, eps=1e-5
 # --------------------------------------------------------------------------------------------------
 # multi-frame: gathered/warped features, geometry, slot weighting, Conv3D
 # --------------------------------------------------------------------------------------------------
+# DIS_GATHER_GNRES=0: the feature warp's backward leaves the plain gradient and the GroupNorm behind it runs dis_gn_bwd_res_sums (A/B)
+GATHER_GNRES = _os_env.environ.get('DIS_GATHER_GNRES', '1') != '0'
+
+
 class _GatherWarpedFeat(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, flows, csr, join):
+    def forward(ctx, feat, flows, csr, join, gnres=None):
         feat, flows = _c(feat), _c(flows)
         _chk(feat, flows)
         tl, bs, h, w, c = feat.shape
         assert flows.shape == (tl * tl, bs, h, w, 2), flows.shape
         out = torch.empty((tl, bs, h, w, tl, c), dtype=torch.float32, device=feat.device)
         lib.call('dis_gather_warped_feat_fwd', feat, flows, out, tl, bs, h, w, c)
-        ctx.save_for_backward(flows, csr)
+        # gnres = (x2,): feat IS y = SELU(GroupNorm(x2) + residual) and the other consumer of y shares `join`: the backward pass that
+        # runs second completes the gradient wrt y - if that is this one, it also does the GroupNorm backward's first pass (below)
+        ctx.gnres = bool(gnres is not None and join is not None and csr is not None and GATHER_GNRES and GN_RES_SUMS and GN_LAZY and
+                         2 * c <= 64 and tuple(gnres[0].shape[-3:]) == (h, w, c) and gnres[0].numel() == feat.numel())
+        if ctx.gnres:
+            ctx.save_for_backward(flows, csr, feat, _c(gnres[0]))
+        else:
+            ctx.save_for_backward(flows, csr)
         ctx.shape = feat.shape
         ctx.join = join
         return out
 
     @staticmethod
     def backward(ctx, g):
-        flows, csr = ctx.saved_tensors
+        flows, csr = ctx.saved_tensors[:2]
         tl, bs, h, w, c = ctx.shape
         join = ctx.join
         second = join is not None and join.buf is not None
         if csr is not None:
             init = join.take(ctx.shape) if second else None
             gf = init if second else torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
-            lib.call('dis_gather_warped_feat_bwd_csr', _c(g), csr, init, gf, tl, bs, h, w, c)
+            done = False
+            if ctx.gnres and second and lib.fn('dis_get_conv_split')() == 1:
+                # this launch completes the gradient wrt y = SELU(GroupNorm(x2) + residual): it stores g SELU'(y) and leaves the channel
+                # sums of the GroupNorm's backward (_GroupNorm.backward finds them: no pass over g, y, x2 of its own)
+                y, x2 = ctx.saved_tensors[2:4]
+                slots = lib.fn('dis_conv2d_gnsums_slots')()
+                ab = _zeros_d(tl * bs * slots * 2 * c, g.device)
+                if lib.call_try('dis_gather_warped_feat_bwd_csr_gnres', _c(g), csr, init, gf, y, x2, ab, slots, ACT_SELU, tl, bs, h, w, c):
+                    _GN_PRE[gf.data_ptr()] = (ab, slots)
+                    done = True
+            if not done:
+                lib.call('dis_gather_warped_feat_bwd_csr', _c(g), csr, init, gf, tl, bs, h, w, c)
         else:
             gf = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
             lib.call('dis_gather_warped_feat_bwd', _c(g), flows, gf, tl, bs, h, w, c)
@@ -2493,7 +2515,7 @@ class _GatherWarpedFeat(torch.autograd.Function):
                 gf.add_(join.take(ctx.shape))
         if join is not None and not second:
             gf = join.first(gf)
-        return gf, None, None, None
+        return gf, None, None, None, None
 
 
 def gather_csr(flows):
@@ -2511,8 +2533,9 @@ def gather_csr(flows):
     return csr
 
 
-def gather_warped_feat(feat, flows, csr=None, join=None):
-    return _GatherWarpedFeat.apply(feat, flows, csr, join)
+def gather_warped_feat(feat, flows, csr=None, join=None, gnres=None):
+    """gnres = (x2,): feat is SELU(GroupNorm(x2) + residual) (group_norm's `_gn_res_src`) whose other consumer shares `join`"""
+    return _GatherWarpedFeat.apply(feat, flows, csr, join, gnres)
 
 
 def mf_geometry(depth_core, R, t, flows_core, Kinv, u_step, v_step):

@@ -199,6 +199,14 @@ long dis_gather_csr_workspace(int tl, int bs, int h, int w);
 int dis_gather_csr_build(const float* flows, int* csr, int tl, int bs, int h, int w, void* stream);
 int dis_gather_warped_feat_bwd_csr(const float* grad_out, const int* csr, const float* init, float* grad_feat, int tl,
                                    int bs, int h, int w, int c, void* stream);
+/* Round 6 - dis_gather_warped_feat_bwd_csr when `feat` IS y = act(GroupNorm(x2) + residual) (a Block2D3D / ResNetBlock output,
+ * reference model/multi_frame_networks.py:428-430, 540-542) and this launch completes the gradient wrt y: grad_feat receives
+ * gres = g act'(y) (the pre-activation gradient = the residual gradient), ab_out (tl * bs, slots, 2, c) doubles - ZEROED by the caller,
+ * slots = dis_conv2d_gnsums_slots() - the channel sums dis_gn_bwd_coef takes.  Replaces the dis_gn_bwd_res_sums pass over g, y, x2.
+ * DIS_ERR_UNSUPPORTED: no tiled instance (the caller runs the two launches). */
+int dis_gather_warped_feat_bwd_csr_gnres(const float* grad_out, const int* csr, const float* init, float* grad_feat, const float* y,
+                                         const float* x2, double* ab_out, int slots, int act, int tl, int bs, int h, int w, int c,
+                                         void* stream);
 
 /* unproject + change_view_angle + gather_warped_xyz + forward/backward flow mask for every target,
  * reference multi_frame_networks.py:172-214,283-294.  No gradient.

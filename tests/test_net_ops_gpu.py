@@ -1410,3 +1410,45 @@ def test_planar_to_nhwc_all_channel_counts(c, n, h, w):
     assert tuple(y.shape) == (n, h, w, c)
     assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
     assert torch.equal(ops.nhwc_to_planar(y), x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tl,bs,c,h,w,slots', [(4, 2, 32, 37, 45, 256), (4, 1, 16, 16, 70, 256), (3, 2, 32, 24, 200, 8), (4, 4, 32, 64, 54, 256)])
+def test_gather_bwd_with_group_norm_sums(tl, bs, c, h, w, slots):
+    """dis_gather_warped_feat_bwd_csr_gnres (round 6): the feature warp's backward when its input IS y = SELU(GroupNorm(x2) + residual)
+    and the launch completes the gradient wrt y - against the two launches it replaces: the stored g SELU'(y) is bit-identical to
+    dis_gather_warped_feat_bwd_csr followed by dis_gn_bwd_res_sums' residual gradient, the channel sums agree to 1e-6 of the largest
+    (other partial-sum partition); also with more tiles per image than slots (fp64 atomics into shared slots)."""
+    from depthinspace_amd import ops
+    L = ops.lib
+    g = torch.Generator().manual_seed(tl * 100 + c + h)
+    flows = (torch.randn(tl * tl, bs, h, w, 2, generator=g) * 5).cuda()
+    go = torch.randn(tl, bs, h, w, tl, c, generator=g).cuda()
+    init = torch.randn(tl, bs, h, w, c, generator=g).cuda()
+    x2 = torch.randn(tl, bs, h, w, c, generator=g).cuda()
+    y = torch.nn.functional.selu(torch.randn(tl, bs, h, w, c, generator=g)).cuda()
+    csr = ops.gather_csr(flows)
+    n = tl * bs
+    # the two launches
+    gf = init.clone()
+    L.call('dis_gather_warped_feat_bwd_csr', go, csr, gf, gf, tl, bs, h, w, c)
+    s_ref = int(L.fn('dis_conv2d_gnsums_slots')())
+    ab_ref = torch.zeros(n * s_ref * 2 * c, dtype=torch.float64, device='cuda')
+    gres_ref = torch.empty_like(gf)
+    L.call('dis_gn_bwd_res_sums', gf, y, x2, gres_ref, ab_ref, s_ref, n, h * w, c, ops.ACT_SELU)
+    # one launch
+    gf1 = init.clone()
+    ab = torch.zeros(n * slots * 2 * c, dtype=torch.float64, device='cuda')
+    ok = L.call_try('dis_gather_warped_feat_bwd_csr_gnres', go, csr, gf1, gf1, y, x2, ab, slots, ops.ACT_SELU, tl, bs, h, w, c)
+    if not ok:
+        pytest.skip('no tiled instance for this shape')
+    torch.cuda.synchronize()
+    assert torch.equal(gf1, gres_ref)
+    got, ref = ab.view(n, slots, 2, c).sum(dim=1), ab_ref.view(n, s_ref, 2, c).sum(dim=1)
+    assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), float((got - ref).abs().max())
+    # fixed order where every tile has its own slot: repeats bit for bit
+    if slots >= ((h + 7) // 8) * ((w + 31) // 32):
+        gf2 = init.clone()
+        ab2 = torch.zeros_like(ab)
+        L.call('dis_gather_warped_feat_bwd_csr_gnres', go, csr, gf2, gf2, y, x2, ab2, slots, ops.ACT_SELU, tl, bs, h, w, c)
+        assert torch.equal(ab, ab2) and torch.equal(gf1, gf2)
