@@ -743,6 +743,10 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
     if (RIDE) mg_lane = mg_next;
   };
 
+#ifdef FB_STAGGER   // (diagnostic: every second workgroup starts its tile loop FB_STAGGER x 64 cycles late - are the workgroups' phases, all
+                    //  requesting their next tile at the same time, what the loads wait for?  Measured with 60 and 110: 135 - 146 us either way, same box)
+  if (rank & 1) __builtin_amdgcn_s_sleep(FB_STAGGER);
+#endif
   int flushed = 0;
   bool resume = false;
   float* out = fa_.part + (long)blockIdx.x * (9 * C * C);
