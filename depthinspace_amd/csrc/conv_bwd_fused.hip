@@ -80,6 +80,9 @@ extern "C" int dis_debug_fb_stamps(unsigned long long* host) { return (int)hipMe
 #endif
 #define FB_TR 16
 #define FB_TC 16
+#ifndef FB_XGRP
+#define FB_XGRP 2   // x pieces staged together, stage by stage (independent chains: one wave per SIMD exposes every dependent latency)
+#endif
 #ifndef FB_SMARGIN
 #define FB_SMARGIN 6   // bits of headroom the dW exponent keeps when it is (re)set: a later tile may be 2^6 larger before the accumulators move again
 #endif
@@ -540,21 +543,25 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       const int es = S_w - sx_e < ex_e ? S_w - sx_e : ex_e;
       const float scx = __builtin_ldexpf(1.f, es);
 #pragma unroll
-      for (int i = 0; i < NPIECE; i += 2) {   // (two pieces at a time, stage by stage: see stage_item2)
-        const float4 va = xval(i), vb = xval(i + 1);
-        const float x_[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-        f32x2 v_[4], r_[4];
-        f16x2_t h1_[4], h2_[4];
+      for (int i = 0; i < NPIECE; i += FB_XGRP) {   // (FB_XGRP pieces at a time, stage by stage: see stage_item2)
+        float x_[4 * FB_XGRP];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v_[k] = (f32x2){x_[2 * k] * scx, x_[2 * k + 1] * scx};
+        for (int j = 0; j < FB_XGRP; ++j) {
+          const float4 va = xval(i + j);
+          x_[4 * j] = va.x, x_[4 * j + 1] = va.y, x_[4 * j + 2] = va.z, x_[4 * j + 3] = va.w;
+        }
+        f32x2 v_[2 * FB_XGRP], r_[2 * FB_XGRP];
+        f16x2_t h1_[2 * FB_XGRP], h2_[2 * FB_XGRP];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) h1_[k] = __builtin_convertvector(v_[k], f16x2_t);
+        for (int k = 0; k < 2 * FB_XGRP; ++k) v_[k] = (f32x2){x_[2 * k] * scx, x_[2 * k + 1] * scx};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r_[k] = (f32x2){__builtin_fmaf(x_[2 * k], scx, -(float)h1_[k][0]), __builtin_fmaf(x_[2 * k + 1], scx, -(float)h1_[k][1])};
+        for (int k = 0; k < 2 * FB_XGRP; ++k) h1_[k] = __builtin_convertvector(v_[k], f16x2_t);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) h2_[k] = __builtin_convertvector(r_[k], f16x2_t);
+        for (int k = 0; k < 2 * FB_XGRP; ++k) r_[k] = (f32x2){__builtin_fmaf(x_[2 * k], scx, -(float)h1_[k][0]), __builtin_fmaf(x_[2 * k + 1], scx, -(float)h1_[k][1])};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int k = 0; k < 2 * FB_XGRP; ++k) h2_[k] = __builtin_convertvector(r_[k], f16x2_t);
+#pragma unroll
+        for (int j = 0; j < FB_XGRP; ++j) {
           unsigned short* p = xt + ((wave * MT + (i + j) / NT) * FB_TC + li) * PS + ((i + j) % NT) * 16 + lg * 4;
           *(uint2*)(p) = make_uint2(__builtin_bit_cast(unsigned, h1_[2 * j]), __builtin_bit_cast(unsigned, h1_[2 * j + 1]));
           *(uint2*)(p + C) = make_uint2(__builtin_bit_cast(unsigned, h2_[2 * j]), __builtin_bit_cast(unsigned, h2_[2 * j + 1]));
@@ -610,7 +617,11 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
 #pragma unroll
         for (int it = 0; it < NLOAD; ++it)
           if (it * 6 / NLOAD == ks) pf_issue(pfn, it);   // (spread over 3 or 9 k-steps, or the x loads moved into W: no measurable difference)
-        if (!XSH && ks >= 6 && ks < 8) x_issue(n1, ty1, tx1, tile + per < t_hi, (ks - 6) * (NPIECE / 2), (ks - 5) * (NPIECE / 2));
+#ifndef FB_XKS
+#define FB_XKS 6   // the k-steps of D (FB_XKS, FB_XKS + 1) in which the next tile's x pieces are requested
+#endif
+        if (!XSH && ks >= FB_XKS && ks < FB_XKS + 2)
+          x_issue(n1, ty1, tx1, tile + per < t_hi, (ks - FB_XKS) * (NPIECE / 2), (ks - FB_XKS + 1) * (NPIECE / 2));
         auto mm = [&](int mt0, int mt1) __attribute__((always_inline)) {
 #pragma unroll
           for (int q = 0; q < 3; ++q)
