@@ -696,12 +696,34 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) F[p] = fb_tr_read8(xq + p * C, xq + FB_TC * PS + p * C);
       };
+      // KX1: the kx = 1 fragments are assembled from the kx = 0 and kx = 2 ones (a one-pixel shift of the same rows: two
+      // v_alignbit_b32 per 4 pixels) instead of being read - 20 of 28 transposing reads per k-step.  Same-box A/B per form
+      // (profiles/r6_bwd_fused.md): plain 141.5 -> 133.7 us, plain + act' +-0, the GroupNorm-backward forms with channel sums
+      // 149 -> 156 us (their W phase is short of vector issue slots, not of LDS bandwidth): on for the plain forms only.
+#ifndef FB_KX1_ALIGN
+#define FB_KX1_ALIGN (!INCOEF && INACT == 0)
+#endif
       auto load_pair = [&](int row0, s16x8 (&G)[3][NP]) __attribute__((always_inline)) {   // halo rows row0, row0 + 1, the three kx shifts
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
+          if (FB_KX1_ALIGN && kx == 1) continue;
           const unsigned short* gq = xh + (row0 * IC + (4 * lg + tq) + 2 - kx) * PS + bh * 16 + tp * 4;
 #pragma unroll
           for (int p = 0; p < NP; ++p) G[kx][p] = fb_tr_read8(gq + p * C, gq + IC * PS + p * C);
+        }
+        if (FB_KX1_ALIGN) {
+          // a lane's 4 + 4 values of a fragment are pixels q .. q + 3 of rows row0, row0 + 1 (q = 4 lg + 2 - kx): kx = 2 holds
+          // (p0 p1 | p2 p3), kx = 0 holds (p2 p3 | p4 p5), kx = 1 is (p1 p2 | p3 p4)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const u32x4 a = __builtin_bit_cast(u32x4, G[2][p]), b = __builtin_bit_cast(u32x4, G[0][p]);
+            u32x4 m;
+            m[0] = __builtin_amdgcn_alignbit(a[1], a[0], 16);
+            m[1] = __builtin_amdgcn_alignbit(b[1], b[0], 16);
+            m[2] = __builtin_amdgcn_alignbit(a[3], a[2], 16);
+            m[3] = __builtin_amdgcn_alignbit(b[3], b[2], 16);
+            G[1][p] = __builtin_bit_cast(s16x8, m);
+          }
         }
       };
       auto mm3 = [&](int ks, int ky, s16x8 (&G)[3][NP]) __attribute__((always_inline)) {

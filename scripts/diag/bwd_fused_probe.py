@@ -21,7 +21,7 @@ def main():
     n, c = 16, 32
     g_ = torch.Generator().manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g_).cuda()
-    q0 = rnd(n, h, w, c, 0)
+    q0 = rnd(n, h, w, c)
     gq = rnd(n, h, w, c)
     wt = (rnd(c, c, 3, 3) * 0.05).contiguous()
     x = rnd(n, h, w, c)
