@@ -217,7 +217,6 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       item_rc(it, r_, c_);
       const int ix = f.ix0 + c_;
       const unsigned off = (unsigned)ix < (unsigned)a.win ? (unsigned)(f.off0 + (r_ * a.win + c_) * (C * 4) + vv4) : BX_OOB;
-      const bool inside = off < f.bytes;
       v.x = __builtin_fmaf(v.x, cf_k1.x, __builtin_fmaf(q.x, cf_kx, cf_k0));
       v.y = __builtin_fmaf(v.y, cf_k1.y, __builtin_fmaf(q.y, cf_kx, cf_k0));
       v.z = __builtin_fmaf(v.z, cf_k1.z, __builtin_fmaf(q.z, cf_kx, cf_k0));
@@ -226,7 +225,15 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
         v.x *= act_grad_from_out(q.x, INACT), v.y *= act_grad_from_out(q.y, INACT);
         v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
       }
-      v = inside ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef FB_KO_INSIDE   // (diagnostic: padding is not zeroed - WRONG at the image border; what the selects cost)
+      // (padding must not be staged as k0.  Knock-out: these selects are 4 - 5 % of the forms with channel sums, the bias sums below
+      //  2 - 3 %; skipping them behind a workgroup-uniform "the whole halo lies inside the image" branch was measured SLOWER
+      //  (151.7 -> 154.2 us: the branch splits the block the riding arithmetic is scheduled in) - they stay unconditional)
+      {
+        const bool inside = off < f.bytes;
+        v = inside ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#endif
       if (GST) {
         const u32x4 sv = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
         __builtin_amdgcn_raw_buffer_store_b128(sv, bx_rsrc(a.gnb_out + (f.x - a.x), f.bytes), item_own(it) ? off : BX_OOB, 0, 0);
@@ -237,10 +244,12 @@ __global__ __launch_bounds__(256) void conv_bwd_fused_kernel(FbArgs fa_) {
       v.z *= act_grad_from_out(q.z, INACT), v.w *= act_grad_from_out(q.w, INACT);
     }
     pre[it] = v;
+#ifndef FB_KO_BSUM   // (diagnostic: no bias gradient - what its selects and adds cost)
     {   // (bias gradient: the pixels this tile owns; a select, not a branch)
       const bool own = item_own(it);
       bsum.x += own ? v.x : 0.f, bsum.y += own ? v.y : 0.f, bsum.z += own ? v.z : 0.f, bsum.w += own ? v.w : 0.f;
     }
+#endif
     m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.x)), fabsf(v.y));
     m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(v.z)), fabsf(v.w));
   };
